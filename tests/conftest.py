@@ -1,0 +1,44 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long CPU test")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def golden_spec(g, prefix="spec"):
+    return [(str(n), tuple(int(x) for x in str(s).split(",")) if str(s) else ())
+            for n, s in zip(g[prefix + "_names"], g[prefix + "_shapes"])]
+
+
+class NoiseStream:
+    """the seeded standard-normal stream tools/gen_golden.py injected into the reference samplers"""
+
+    def __init__(self, seed):
+        self.rs = np.random.RandomState(int(seed))
+        self.count = 0
+
+    def __call__(self, size):
+        self.count += 1
+        return self.rs.standard_normal(tuple(size)).astype(np.float32)
+
+
+@pytest.fixture(scope="session")
+def gpu_device():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")

@@ -1,0 +1,240 @@
+"""CPU tests: pin the oracle (oracle/) against (a) hand-derived known answers, (b) golden vectors the
+REFERENCE's own Python produced (tools/gen_golden.py -> tests/golden/).  No GPU, no /root/reference."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import NoiseStream, golden_spec, load_golden
+from oracle import denoiser_np as D
+from oracle import ops as O
+from slide_amd.synth import synth_state_dict
+
+
+# ----------------------------------------------------------------------------- known answers
+def test_opt_n_threads():
+    # include/cuda_utils.h:13-19 : clamp(2^floor(log2 w), 1, 512)
+    assert [O.opt_n_threads(w) for w in (1, 2, 3, 16, 17, 100, 511, 512, 513, 5000)] == \
+        [1, 2, 2, 16, 16, 64, 256, 512, 512, 512]
+
+
+def test_fps_known_answers():
+    # index 0 is always emitted first (sampling_gpu.cu:85-86); then the farthest point each time
+    p = np.array([[[1, 0, 0], [1.1, 0, 0], [5, 0, 0], [3, 0, 0]]], np.float32)
+    assert O.furthest_point_sampling(p, 4).tolist() == [[0, 2, 3, 1]]
+    # points inside the 1e-3 origin ball are never selected (sampling_gpu.cu:100-101) ...
+    p = np.array([[[1, 0, 0], [0.01, 0.01, 0], [2, 0, 0], [-9, 0, 0.0]]], np.float32)
+    idx, temp = O.furthest_point_sampling(p, 4, return_temp=True)
+    assert idx.tolist() == [[0, 3, 2, 0]]  # 4th pick: only index 0 is left with distance 0 -> 0
+    assert temp[0, 1] == np.float32(1e10)  # ... and their temp entry is never written
+    # ... except index 0, which is emitted first even when invalid
+    p = np.array([[[0, 0, 0], [1, 0, 0], [0, 2, 0]]], np.float32)
+    assert O.furthest_point_sampling(p, 3).tolist() == [[0, 2, 1]]
+    # all points invalid -> every later pick falls back to (best=-1, besti=0)
+    p = np.zeros((1, 4, 3), np.float32)
+    assert O.furthest_point_sampling(p, 3).tolist() == [[0, 0, 0]]
+
+
+def test_fps_tie_break_is_reduction_tree_order():
+    # n=4 -> block of 4 lanes; points 1 and 2 are equidistant from point 0.  The shared-memory tree
+    # (sampling_gpu.cu:59-65,115-168) first folds lane 2 into lane 0 and lane 3 into lane 1, then lane 1
+    # into lane 0 keeping the LOWER slot on ties -> lane 2 wins over lane 1 (bit-reversed lane order).
+    p = np.array([[[1, 1, 1], [1, 3, 1], [3, 1, 1], [1, 1, 1.5]]], np.float32)
+    assert O.furthest_point_sampling(p, 2).tolist() == [[0, 2]]
+    # within one lane the smaller k wins (strict '>'): n=5, bs=4, lane 0 owns k=0 and k=4
+    p = np.array([[[1, 1, 1], [1, 1, 1.1], [1, 1, 1.2], [1, 1, 1.3], [1, 1, 1]]], np.float32)
+    assert O.furthest_point_sampling(p, 2).tolist() == [[0, 3]]
+
+
+def test_ball_query_known_answers():
+    xyz = np.array([[[0, 0, 0], [0.1, 0, 0], [5, 0, 0], [0.2, 0, 0], [0.05, 0, 0]]], np.float32)
+    q = np.array([[[0, 0, 0], [9, 9, 9], [5, 0, 0]]], np.float32)
+    idx, cnt = O.ball_query(q, xyz, 0.15, 4)
+    # first hit floods all slots, later hits overwrite in order; empty ball -> zeros, count 0
+    assert idx.tolist() == [[[0, 1, 4, 0], [0, 0, 0, 0], [2, 2, 2, 2]]]
+    assert cnt.tolist() == [[3, 0, 1]]
+    # strict '<' on the squared radius
+    idx, cnt = O.ball_query(np.zeros((1, 1, 3), np.float32), np.array([[[0.5, 0, 0]]], np.float32), 0.5, 2)
+    assert cnt.tolist() == [[0]]
+    # stops after nsample hits
+    idx, cnt = O.ball_query(q[:, :1], xyz, 10.0, 2)
+    assert idx.tolist() == [[[0, 1]]] and cnt.tolist() == [[2]]
+
+
+def test_three_nn_known_answers():
+    known = np.array([[[0, 0, 0], [1, 0, 0]]], np.float32)
+    d, i = O.three_nn(np.array([[[0.25, 0, 0]]], np.float32), known)
+    assert i.tolist() == [[[0, 1, 0]]]
+    assert d[0, 0, 0] == np.float32(0.0625) and d[0, 0, 1] == np.float32(0.5625) and np.isinf(d[0, 0, 2])
+    # equal distances never displace an earlier index
+    known = np.array([[[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0]]], np.float32)
+    d, i = O.three_nn(np.zeros((1, 1, 3), np.float32), known)
+    assert i.tolist() == [[[0, 1, 2]]]
+
+
+def test_knn_known_answers():
+    p = np.array([[[0, 0, 0], [1, 0, 0], [-1, 0, 0], [0, 3, 0]]], np.float32)
+    d, i = O.knn_points(p, p, 4)
+    assert i[0, 0].tolist() == [0, 1, 2, 3]  # self first with EXACT zero distance, tie -> lower index
+    assert d[0, 0].tolist() == [0.0, 1.0, 1.0, 9.0]
+    assert (np.diff(d, axis=-1) >= 0).all()
+    g = O.knn_gather(p, i)
+    assert np.array_equal(g[0, 0], p[0][i[0, 0]])
+    d, i = O.knn_points(p, p, 3, lengths2=np.array([2]))
+    assert i[0, 3].tolist() == [1, 0, 0] or i[0, 3].tolist() == [0, 1, 0]
+    assert i[0, 3, 2] == 0 and d[0, 3, 2] == 0  # slots beyond lengths2 stay zero
+
+
+def test_gather_group_interpolate_and_grads():
+    rs = np.random.RandomState(0)
+    pts = rs.standard_normal((2, 5, 9)).astype(np.float32)
+    idx = rs.randint(0, 9, (2, 4)).astype(np.int32)
+    out = O.gather_points(pts, idx)
+    assert np.array_equal(out, np.take_along_axis(pts, idx[:, None, :].repeat(5, 1), axis=2))
+    gidx = rs.randint(0, 9, (2, 3, 4)).astype(np.int32)
+    go = O.group_points(pts, gidx)
+    for b in range(2):
+        assert np.array_equal(go[b], pts[b][:, gidx[b]])
+    # grads are the transposes of the gathers: <G, gather(P)> == <gather_grad(G), P>
+    G = rs.standard_normal(out.shape).astype(np.float32)
+    assert np.allclose((G * out).sum(), (O.gather_points_grad(G, idx, 9) * pts).sum(), rtol=1e-4)
+    G = rs.standard_normal(go.shape).astype(np.float32)
+    assert np.allclose((G * go).sum(), (O.group_points_grad(G, gidx, 9) * pts).sum(), rtol=1e-4)
+    i3 = rs.randint(0, 9, (2, 6, 3)).astype(np.int32)
+    w = rs.uniform(0, 1, (2, 6, 3)).astype(np.float32)
+    ti = O.three_interpolate(pts, i3, w)
+    ref = sum(np.take_along_axis(pts, i3[:, None, :, q].repeat(5, 1), axis=2) * w[:, None, :, q] for q in range(3))
+    assert np.allclose(ti, ref, atol=1e-6)
+    G = rs.standard_normal(ti.shape).astype(np.float32)
+    assert np.allclose((G * ti).sum(), (O.three_interpolate_grad(G, i3, w, 9) * pts).sum(), rtol=1e-4)
+
+
+# ----------------------------------------------------------------------------- op-level fixtures
+def test_ops_golden_regression():
+    g = load_golden("golden_ops.npz")
+    for ci in range(int(g["n_fps"])):
+        idx, temp = O.furthest_point_sampling(g["fps%d_in" % ci], g["fps%d_idx" % ci].shape[1], return_temp=True)
+        assert np.array_equal(idx, g["fps%d_idx" % ci]) and np.array_equal(temp, g["fps%d_temp" % ci])
+    assert np.array_equal(O.furthest_point_sampling(g["fps_grid_in"], 100), g["fps_grid_idx"])
+    for ci in range(int(g["n_bq"])):
+        idx, cnt = O.ball_query(g["bq%d_new" % ci], g["bq%d_xyz" % ci], float(g["bq%d_r" % ci]), int(g["bq%d_ns" % ci]))
+        assert np.array_equal(idx, g["bq%d_idx" % ci]) and np.array_equal(cnt, g["bq%d_cnt" % ci])
+    for ci in range(int(g["n_knn"])):
+        d, i = O.knn_points(g["knn%d_p1" % ci], g["knn%d_p2" % ci], int(g["knn%d_K" % ci]))
+        assert np.array_equal(i, g["knn%d_i" % ci]) and np.array_equal(d, g["knn%d_d" % ci])
+    for ci in range(int(g["n_tn"])):
+        d, i = O.three_nn(g["tn%d_u" % ci], g["tn%d_k" % ci])
+        assert np.array_equal(i, g["tn%d_i" % ci]) and np.array_equal(d, g["tn%d_d" % ci])
+
+
+# ----------------------------------------------------------------------------- reference-module fixtures
+def _sd(g, prefix, tag):
+    spec = golden_spec(g, prefix)
+    vals = synth_state_dict([(tag + n, s) for n, s in spec])
+    return {n: vals[tag + n] for n, _ in spec}
+
+
+def test_blocks_against_reference_modules():
+    g = load_golden("golden_blocks.npz")
+    xyz, feats = g["xyz"], g["feats"]
+    fidx = O.furthest_point_sampling(xyz, g["fps_idx"].shape[1])
+    assert np.array_equal(fidx, g["fps_idx"])
+    new_xyz = np.ascontiguousarray(O.gather_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), fidx).transpose(0, 2, 1))
+    assert np.array_equal(new_xyz, g["new_xyz"])
+    o, c, _ = D.query_and_group(xyz, new_xyz, feats, 0, 8, "nn", True, True, True)
+    assert np.array_equal(o, g["qg_nn"]) and np.array_equal(c, g["qg_nn_counts"])
+    o2, _, _ = D.query_and_group_nn(xyz, new_xyz, feats, 8)
+    assert np.array_equal(o2, g["qg_nn"])
+    o, c, _ = D.query_and_group(xyz, new_xyz, feats, 0.6, 8, "radius", True, True, False)
+    assert np.array_equal(o, g["qg_radius"]) and np.array_equal(c, g["qg_radius_counts"])
+    o, c, _ = D.query_and_group(xyz, g["q2"], feats, 0.6, 8, "radius", True, True, False, subset=False)
+    assert np.array_equal(c, g["qg_radius_nosubset_counts"]) and (c == 0).any()
+    assert np.allclose(o, g["qg_radius_nosubset"], atol=1e-7)
+    gk = D.group_knn(new_xyz, xyz, feats, 6)
+    assert np.allclose(gk, g["group_knn"], rtol=1e-6, atol=1e-6)
+    d2, i3 = O.three_nn(xyz, new_xyz)
+    assert np.array_equal(i3, g["three_nn_idx"]) and np.allclose(np.sqrt(d2), g["three_nn_dist"], atol=1e-7)
+    fp = D.pointnet_fp_module(xyz, new_xyz, g["fp_unknown_feats"], g["fp_known_feats"], _sd(g, "fp_spec", "fpmod."), "")
+    assert np.allclose(fp, g["fp_out"], atol=2e-5)
+    sd = _sd(g, "sa_spec", "samod.")
+    sd = {"S." + k: v for k, v in sd.items()}
+    nx, nf = D.sa_module(xyz, feats, sd, "S", 12, 8, g["sa_t_emb"], g["sa_cond_emb"])
+    assert np.array_equal(nx, g["sa_new_xyz"]) and np.allclose(nf, g["sa_new_features"], atol=2e-5)
+    sd = {"A." + k: v for k, v in _sd(g, "att_spec", "attmod.").items()}
+    a = D.attention_module(g["att_query"], g["qg_radius"], g["att_grouped_feat_out"], sd, "A", count=g["qg_radius_counts"])
+    assert np.allclose(a, g["att_out"], atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["pos", "feat"])
+def test_denoiser_against_reference(name):
+    g = load_golden("golden_denoiser_%s.npz" % name)
+    hp = json.loads(str(g["config_json"]))
+    sd = synth_state_dict(golden_spec(g))
+    assert sum(v.size for v in sd.values()) == {"pos": 728261, "feat": 4009321}[name]
+    for k in ["t0", "t1", "t500", "t999", "mixed"]:
+        y = D.denoiser_forward(hp, sd, g["x_" + k], g["ts_" + k], g["label_" + k])
+        ref = g["eps_" + k]
+        assert np.abs(y - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), k
+
+
+def test_schedules_against_reference():
+    g = load_golden("golden_sampler_pos.npz")
+    dh = D.calc_diffusion_hyperparams(1000, 1e-4, 0.02)
+    for k in ["Beta", "Alpha", "Alpha_bar"]:
+        assert np.array_equal(dh[k], g["sched_" + k]), k
+    # torch's CPU float32 sqrt is not correctly rounded: 9 of 1000 entries sit 1 ulp below numpy's
+    assert np.abs(dh["Sigma"] - g["sched_Sigma"]).max() <= 1.5e-8 and (dh["Sigma"] != g["sched_Sigma"]).sum() < 20
+    g = load_golden("golden_sampler_feat.npz")
+    dp = D.latent_diffusion_params(json.loads(str(g["config_json"])))
+    for k in ["logvar", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
+              "posterior_mean_coef2"]:
+        assert np.array_equal(dp[k], g["sched_" + k]), k
+
+
+def _net(name):
+    g = load_golden("golden_denoiser_%s.npz" % name)
+    hp = json.loads(str(g["config_json"]))
+    sd = synth_state_dict(golden_spec(g))
+    return lambda x, ts, label: D.denoiser_forward(hp, sd, x, ts, label)
+
+
+def test_position_sampler_tail_against_reference():
+    g = load_golden("golden_sampler_pos.npz")
+    dh = D.calc_diffusion_hyperparams(1000, 1e-4, 0.02)
+    ns = NoiseStream(g["tail_seed"])
+    size = g["tail_XT"].shape
+    ns(size)  # sampling() draws x_T first even when a precomputed X_T is supplied (util.py:225)
+    step = int(g["tail_step"])
+    x = g["tail_XT"] + dh["Sigma"][step] * ns(size)
+    x0 = D.position_sampling(_net("pos"), dh, g["label"], x, lambda: ns(size), t_start=step - 1)
+    assert ns.count == int(g["tail_ndraws"])
+    assert np.abs(x0 - g["tail_x0"]).max() <= 1e-3 * np.abs(g["tail_x0"]).max()
+
+
+@pytest.mark.slow
+def test_position_sampler_full_chain_against_reference():
+    g = load_golden("golden_sampler_pos.npz")
+    dh = D.calc_diffusion_hyperparams(1000, 1e-4, 0.02)
+    ns = NoiseStream(g["full_seed"])
+    size = g["full_x0"].shape
+    x0 = D.position_sampling(_net("pos"), dh, g["label"], ns(size), lambda: ns(size))
+    assert ns.count == int(g["full_ndraws"])
+    rel = np.abs(x0 - g["full_x0"]).max() / np.abs(g["full_x0"]).max()
+    assert rel <= 1e-3, rel
+
+
+def test_feature_sampler_against_reference():
+    g = load_golden("golden_sampler_feat.npz")
+    dp = D.latent_diffusion_params(json.loads(str(g["config_json"])))
+    net = _net("feat")
+    size = g["head_x"].shape
+    ns = NoiseStream(g["head_seed"])
+    n = int(g["head_nsteps"])
+    x = D.feature_sampling(net, dp, g["keypoint"], g["label"], ns(size), lambda: ns(size), t_end=1000 - n)
+    assert ns.count == int(g["head_ndraws"])
+    assert np.abs(x - g["head_x"]).max() <= 1e-3 * np.abs(g["head_x"]).max()
+    ns = NoiseStream(g["tail_seed"])
+    x = D.feature_sampling(net, dp, g["keypoint"], g["label"], g["tail_x_in"], lambda: ns(size),
+                           t_start=int(g["tail_curr_step"]) - 1)
+    assert ns.count == int(g["tail_ndraws"])
+    assert np.abs(x - g["tail_x0"]).max() <= 1e-3 * np.abs(g["tail_x0"]).max()

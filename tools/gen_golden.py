@@ -1,0 +1,350 @@
+"""tools/gen_golden.py -- AUTHORING-CONTAINER ONLY.  Generates tests/golden/*.npz.
+
+Runs the REFERENCE's own Python (imported from /root/reference via tools/ref_shims.py, never
+copied) on seeded inputs and records inputs + outputs as small fixtures:
+  golden_denoiser_{pos,feat}.npz  PointNet2CloudCondition.forward at t in {0,1,500,999}, per-level
+                                  features (forward hooks), state-dict spec (names + shapes)
+  golden_sampler_{pos,feat}.npz   util.sampling / LatentDiffusion.denoise_and_reconstruct segments with
+                                  the noise stream injected (seeded numpy RandomState), schedule tables
+  golden_blocks.npz               stand-alone reference modules (QueryAndGroup, group_knn, Mlp_plus_t_emb,
+                                  AttentionModule, PointnetSAModule w/ FPS, PointnetFPModule (three_nn path))
+  golden_ops.npz                  op-level adversarial cases (computed by the C oracle -- the reference has
+                                  no CPU path for `_ext`; the oracle itself is pinned by the files above)
+Weights are NOT stored: slide_amd.synth.synth_state_dict(spec) regenerates them from the names.
+
+usage:  python tools/gen_golden.py [--out tests/golden]
+"""
+import argparse
+import copy
+import io
+import contextlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+from tools import ref_shims  # noqa: E402
+
+ref_shims.install()
+from slide_amd.synth import synth_state_dict, synth_keypoints  # noqa: E402
+
+CFG = "/root/reference/pointnet2/configs/shapenet_psr_configs/"
+POS_CFG = CFG + "ddpm_keypoint_training_configs/config_standard_attention_batchsize_32_s3_ema_model_keypoint_airplane_02691156.json"
+FEAT_CFG = CFG + "latent_ddpm_training_configs/config_latent_ddpm_s3_dim_16_32_ae_kp_noise_0.04_keypoint_conditional_chair_ae_trained_on_chair.json"
+
+
+def load_cfg(path):
+    from data_utils.json_reader import restore_string_to_list_in_a_dict
+    with open(path) as f:
+        return restore_string_to_list_in_a_dict(json.loads(f.read()))
+
+
+def build_net(cfg):
+    from models.pointnet2_with_pcld_condition import PointNet2CloudCondition
+    net = PointNet2CloudCondition(copy.deepcopy(cfg["pointnet_config"]))
+    spec = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    sd = synth_state_dict(spec)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    return net, spec
+
+
+def spec_arrays(spec):
+    names = np.array([n for n, _ in spec])
+    shapes = np.array([",".join(str(d) for d in s) for _, s in spec])
+    return names, shapes
+
+
+class NoiseStream:
+    """seeded standard-normal stream shared (by construction) with the tests"""
+
+    def __init__(self, seed):
+        self.rs = np.random.RandomState(seed)
+        self.count = 0
+
+    def __call__(self, size):
+        self.count += 1
+        return torch.from_numpy(self.rs.standard_normal(tuple(size)).astype(np.float32))
+
+
+def gen_denoiser(name, cfg_path, out, B=3):
+    cfg = load_cfg(cfg_path)
+    net, spec = build_net(cfg)
+    hp = cfg["pointnet_config"]
+    C = 3 + hp["in_fea_dim"]
+    rs = np.random.RandomState(7)
+    res = {}
+    names, shapes = spec_arrays(spec)
+    res["spec_names"], res["spec_shapes"] = names, shapes
+    res["config_json"] = np.array(json.dumps(hp))
+    inter = {}
+
+    def hook(tag):
+        def fn(mod, inp, outp):
+            inter[tag] = (outp[1] if isinstance(outp, tuple) else outp).detach().numpy().copy()
+        return fn
+
+    for i, m in enumerate(net.SA_modules):
+        m.register_forward_hook(hook("sa%d" % i))
+    for i, m in enumerate(net.FP_modules):
+        m.register_forward_hook(hook("fp%d" % i))
+    for t in [0, 1, 500, 999]:
+        x = rs.standard_normal((B, 16, C)).astype(np.float32)
+        if name == "feat":
+            x[:, :, 0:3] = synth_keypoints(B, 16, seed=t)
+        elif t < 500:
+            x[:, :, 0:3] *= 0.5
+        label = rs.randint(0, 13, size=(B,)).astype(np.int64)
+        ts = np.full((B,), t, np.float32)
+        with torch.no_grad():
+            y = net(torch.from_numpy(x), ts=torch.from_numpy(ts), label=torch.from_numpy(label))
+        res["x_t%d" % t] = x; res["label_t%d" % t] = label; res["ts_t%d" % t] = ts
+        res["eps_t%d" % t] = y.numpy()
+        for k, v in inter.items():
+            res["%s_t%d" % (k, t)] = v
+    # mixed per-sample timesteps in one batch
+    x = rs.standard_normal((B, 16, C)).astype(np.float32)
+    ts = np.array([3, 250, 998][:B], np.float32)
+    label = np.array([0, 4, 12][:B], np.int64)
+    with torch.no_grad():
+        y = net(torch.from_numpy(x), ts=torch.from_numpy(ts), label=torch.from_numpy(label))
+    res["x_mixed"], res["ts_mixed"], res["label_mixed"], res["eps_mixed"] = x, ts, label, y.numpy()
+    np.savez_compressed(os.path.join(out, "golden_denoiser_%s.npz" % name), **res)
+    print("denoiser", name, "params", sum(int(np.prod(s)) for _, s in spec), "tensors", len(spec))
+    return net, cfg
+
+
+def gen_sampler_pos(net, cfg, out, B=2):
+    import util
+    res = {}
+    dh = util.calc_diffusion_hyperparams(**cfg["diffusion_config"])
+    for k in ["Beta", "Alpha", "Alpha_bar", "Sigma"]:
+        res["sched_" + k] = dh[k].numpy()
+    label = torch.tensor([0, 4][:B]).long()
+    res["label"] = label.numpy()
+
+    def run(seed, **kw):
+        ns = NoiseStream(seed)
+        old = util.std_normal
+        util.std_normal = ns
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                x = util.sampling(net, (B, 16, 3), dh, label=label, verbose=False, **kw)
+        finally:
+            util.std_normal = old
+        return x.numpy(), ns.count
+
+    # (a) the last 20 reverse steps from a supplied X_T (reference: use_a_precomputed_XT, util.py:228-230)
+    XT = (0.5 * np.random.RandomState(11).standard_normal((B, 16, 3))).astype(np.float32)
+    res["tail_XT"] = XT; res["tail_step"] = np.array(20); res["tail_seed"] = np.array(101)
+    res["tail_x0"], res["tail_ndraws"] = run(101, use_a_precomputed_XT=True, step=20, XT=torch.from_numpy(XT))
+    # (b) the full 1000-step chain
+    res["full_seed"] = np.array(202)
+    res["full_x0"], res["full_ndraws"] = run(202)
+    np.savez_compressed(os.path.join(out, "golden_sampler_pos.npz"), **res)
+    print("sampler pos: tail draws", res["tail_ndraws"], "full draws", res["full_ndraws"])
+
+
+def gen_sampler_feat(net, cfg, out, B=2):
+    from diffusion_utils import diffusion as D
+    res = {}
+    dcfg = copy.deepcopy(cfg["standard_diffusion_config"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        dm = D.LatentDiffusion(dcfg, autoencoder=None, device=torch.device("cpu"))
+    dm.decode = lambda latent, keypoint_dim, label: latent  # skip the autoencoder; the loop is untouched
+    for k in ["logvar", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
+              "posterior_mean_coef2"]:
+        res["sched_" + k] = np.asarray(getattr(dm, k), np.float64)
+    res["config_json"] = np.array(json.dumps(dcfg))
+    label = torch.tensor([4, 4][:B]).long()
+    keypoint = torch.from_numpy(synth_keypoints(B, 16, seed=5))
+    res["label"] = label.numpy(); res["keypoint"] = keypoint.numpy()
+
+    def run(seed, **kw):
+        ns = NoiseStream(seed)
+        o1, o2 = torch.randn, torch.randn_like
+        torch.randn = lambda *size, **k: ns(size)
+        torch.randn_like = lambda x, **k: ns(x.shape)
+        try:
+            with torch.no_grad():
+                _, kp, feat = dm.denoise_and_reconstruct(B, net, 3, (16, 51), label=label, keypoint=keypoint,
+                                                         return_keypoint_feature=True, **kw)
+        finally:
+            torch.randn, torch.randn_like = o1, o2
+        return torch.cat([kp, feat], dim=2).numpy(), ns.count
+
+    # (a) first 20 steps t=999..980 from x_T ~ N(0,1)
+    res["head_seed"] = np.array(303); res["head_nsteps"] = np.array(20)
+    res["head_x"], res["head_ndraws"] = run(303, n_steps=20)
+    # (b) last 20 steps t=19..0 from a supplied x_20
+    x20 = (0.7 * np.random.RandomState(12).standard_normal((B, 16, 51))).astype(np.float32)
+    res["tail_x_in"] = x20; res["tail_seed"] = np.array(404); res["tail_curr_step"] = np.array(20)
+    res["tail_x0"], res["tail_ndraws"] = run(404, x=torch.from_numpy(x20), curr_step=20)
+    np.savez_compressed(os.path.join(out, "golden_sampler_feat.npz"), **res)
+    print("sampler feat: head draws", res["head_ndraws"], "tail draws", res["tail_ndraws"])
+
+
+def gen_blocks(out):
+    """stand-alone reference modules on seeded inputs, covering branches the DDPM configs skip"""
+    from pointnet2_ops import pointnet2_utils as PU
+    from pointnet2_ops import pointnet2_modules as PM
+    from pointnet2_ops.attention import AttentionModule
+    rs = np.random.RandomState(21)
+    res = {}
+    B, N, npoint, C = 2, 40, 12, 5
+    xyz = rs.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    feats = rs.standard_normal((B, C, N)).astype(np.float32)
+    res["xyz"], res["feats"] = xyz, feats
+    txyz, tf = torch.from_numpy(xyz), torch.from_numpy(feats)
+    # FPS + gather + QueryAndGroup in both neighbour definitions
+    fidx = PU.furthest_point_sample(txyz, npoint)
+    new_xyz = PU.gather_operation(txyz.transpose(1, 2).contiguous(), fidx).transpose(1, 2).contiguous()
+    res["fps_idx"] = fidx.numpy(); res["new_xyz"] = new_xyz.numpy()
+    g_nn = PU.QueryAndGroup(0, 8, use_xyz=True, include_abs_coordinate=True, include_center_coordinate=True,
+                            neighbor_def="nn")
+    o, c = g_nn(txyz, new_xyz, tf, subset=True, return_counts=True)
+    res["qg_nn"], res["qg_nn_counts"] = o.numpy(), c.numpy()
+    g_r = PU.QueryAndGroup(0.6, 8, use_xyz=True, include_abs_coordinate=True, include_center_coordinate=False,
+                           neighbor_def="radius")
+    o, c = g_r(txyz, new_xyz, tf, subset=True, return_counts=True)
+    res["qg_radius"], res["qg_radius_counts"] = o.numpy(), c.numpy()
+    q2 = rs.uniform(-1.5, 1.5, (B, 9, 3)).astype(np.float32)
+    res["q2"] = q2
+    o, c = g_r(txyz, torch.from_numpy(q2), tf, subset=False, return_counts=True)
+    res["qg_radius_nosubset"], res["qg_radius_nosubset_counts"] = o.numpy(), c.numpy()
+    # group_knn
+    res["group_knn"] = PU.group_knn(new_xyz, txyz, tf, 6, transpose=True).numpy()
+    # three_nn / three_interpolate through PointnetFPModule
+    fp = PM.PointnetFPModule(mlp=[C + 7, 16, 16], bn=True, include_t=False, bias=True, res_connect=True)
+    spec = [(k, tuple(v.shape)) for k, v in fp.state_dict().items()]
+    vals = synth_state_dict([("fpmod." + n, s) for n, s in spec])
+    fp.load_state_dict({n: torch.from_numpy(vals["fpmod." + n]) for n, _ in spec})
+    fp.eval()
+    uf = rs.standard_normal((B, 7, N)).astype(np.float32)
+    kf = rs.standard_normal((B, C, npoint)).astype(np.float32)
+    res["fp_unknown_feats"], res["fp_known_feats"] = uf, kf
+    res["fp_spec_names"], res["fp_spec_shapes"] = spec_arrays(spec)
+    with torch.no_grad():
+        res["fp_out"] = fp(txyz, new_xyz, torch.from_numpy(uf), torch.from_numpy(kf)).numpy()
+    d, i = PU.three_nn(txyz, new_xyz)
+    res["three_nn_dist"], res["three_nn_idx"] = d.numpy(), i.numpy()
+    # PointnetSAModule with FPS (N > npoint), t-embedding + condition + attention
+    att = {"use_attention_module": True, "attention_bn": True, "transform_grouped_feat_out": True,
+           "last_activation": True}
+    sa = PM.PointnetSAModule(mlp=[C, 16, 16, 32], npoint=npoint, radius=0, nsample=8, bn=True, use_xyz=True,
+                             t_dim=24, include_t=True, include_abs_coordinate=True, include_center_coordinate=True,
+                             bias=True, res_connect=True, include_condition=True, condition_dim=10,
+                             neighbor_def="nn", attention_setting=att)
+    spec = [(k, tuple(v.shape)) for k, v in sa.state_dict().items()]
+    vals = synth_state_dict([("samod." + n, s) for n, s in spec])
+    sa.load_state_dict({n: torch.from_numpy(vals["samod." + n]) for n, _ in spec})
+    sa.eval()
+    temb = rs.standard_normal((B, 24)).astype(np.float32); cemb = rs.standard_normal((B, 10)).astype(np.float32)
+    res["sa_t_emb"], res["sa_cond_emb"] = temb, cemb
+    res["sa_spec_names"], res["sa_spec_shapes"] = spec_arrays(spec)
+    with torch.no_grad():
+        nx, nf = sa(txyz, tf, t_emb=torch.from_numpy(temb), condition_emb=torch.from_numpy(cemb))
+    res["sa_new_xyz"], res["sa_new_features"] = nx.numpy(), nf.numpy()
+    # AttentionModule with a count mask (radius grouping path)
+    am = AttentionModule(C, C + 6, C, C + 6, 32, attention_bn=True, transform_grouped_feat_out=True,
+                         last_activation=True)
+    spec = [(k, tuple(v.shape)) for k, v in am.state_dict().items()]
+    vals = synth_state_dict([("attmod." + n, s) for n, s in spec])
+    am.load_state_dict({n: torch.from_numpy(vals["attmod." + n]) for n, _ in spec})
+    am.eval()
+    gfo = rs.standard_normal((B, 32, npoint, 8)).astype(np.float32)
+    res["att_grouped_feat_out"] = gfo
+    res["att_spec_names"], res["att_spec_shapes"] = spec_arrays(spec)
+    qfeat = PU.gather_operation(tf, fidx)
+    res["att_query"] = qfeat.numpy()
+    with torch.no_grad():
+        res["att_out"] = am(qfeat, torch.from_numpy(res["qg_radius"]), torch.from_numpy(gfo),
+                            torch.from_numpy(res["qg_radius_counts"])).numpy()
+    np.savez_compressed(os.path.join(out, "golden_blocks.npz"), **res)
+    print("blocks done")
+
+
+def gen_ops(out):
+    from oracle import ops as O
+    rs = np.random.RandomState(3)
+    res = {}
+
+    def cloud(B, N, dup=0, origin=0, scale=1.0):
+        p = rs.uniform(-1, 1, (B, N, 3)).astype(np.float32) * np.float32(scale)
+        for b in range(B):
+            for _ in range(dup):  # exact duplicates -> exact distance ties
+                i, j = rs.randint(0, N, 2)
+                p[b, j] = p[b, i]
+            for _ in range(origin):  # inside the 1e-3 origin ball (|p|^2 <= 1e-3): FPS skips them
+                p[b, rs.randint(0, N)] = rs.uniform(-0.015, 0.015, 3).astype(np.float32)
+        return p
+
+    fps_cases = [(2, 16, 16, 0, 0), (2, 64, 16, 3, 2), (2, 100, 37, 5, 3), (1, 256, 128, 4, 4), (2, 1024, 256, 8, 6),
+                 (1, 700, 64, 0, 0), (1, 5, 5, 1, 1), (1, 1500, 40, 10, 5), (1, 33, 1, 0, 0)]
+    for ci, (B, N, m, dup, org) in enumerate(fps_cases):
+        p = cloud(B, N, dup, org)
+        if ci == 2:
+            p[:, 0] = 0.0  # index 0 itself invalid
+        idx, temp = O.furthest_point_sampling(p, m, return_temp=True)
+        res["fps%d_in" % ci], res["fps%d_idx" % ci], res["fps%d_temp" % ci] = p, idx, temp
+    # grid cloud: massive exact ties exercise the reduction-tree tie-break
+    g = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(4), indexing="ij"), -1).reshape(1, -1, 3)
+    g = (g.astype(np.float32) - 2.0) * 0.25
+    res["fps_grid_in"] = g
+    res["fps_grid_idx"], res["fps_grid_temp"] = O.furthest_point_sampling(g, 100, return_temp=True)
+    res["n_fps"] = np.array(len(fps_cases))
+
+    bq_cases = [(2, 64, 16, 0.4, 8), (2, 100, 33, 0.25, 16), (1, 16, 16, 5.0, 32), (1, 300, 50, 0.05, 4),
+                (2, 1024, 256, 0.2, 32)]
+    for ci, (B, N, M, r, ns) in enumerate(bq_cases):
+        p = cloud(B, N, 2, 0); q = cloud(B, M, 0, 0, 1.2)
+        q[:, 0] = p[:, 3]
+        idx, cnt = O.ball_query(q, p, r, ns)
+        res["bq%d_xyz" % ci], res["bq%d_new" % ci] = p, q
+        res["bq%d_r" % ci], res["bq%d_ns" % ci] = np.float32(r), np.array(ns)
+        res["bq%d_idx" % ci], res["bq%d_cnt" % ci] = idx, cnt
+    res["n_bq"] = np.array(len(bq_cases))
+
+    knn_cases = [(2, 16, 16, 16), (2, 16, 16, 8), (2, 40, 100, 32), (1, 256, 1024, 32), (2, 64, 16, 8), (1, 7, 3, 3),
+                 (1, 300, 257, 4)]
+    for ci, (B, N1, N2, K) in enumerate(knn_cases):
+        p2 = cloud(B, N2, 2 if N2 > 8 else 0, 0)
+        p1 = p2.copy() if N1 == N2 else cloud(B, N1, 0, 0)
+        d, i = O.knn_points(p1, p2, K)
+        res["knn%d_p1" % ci], res["knn%d_p2" % ci], res["knn%d_K" % ci] = p1, p2, np.array(K)
+        res["knn%d_d" % ci], res["knn%d_i" % ci] = d, i
+    res["n_knn"] = np.array(len(knn_cases))
+    # three_nn incl. m < 3 (trailing idx 0, dist inf)
+    tn_cases = [(2, 50, 20), (1, 16, 2), (1, 300, 64), (1, 9, 1)]
+    for ci, (B, n, m) in enumerate(tn_cases):
+        u = cloud(B, n); k = cloud(B, m, 1 if m > 4 else 0)
+        d, i = O.three_nn(u, k)
+        res["tn%d_u" % ci], res["tn%d_k" % ci], res["tn%d_d" % ci], res["tn%d_i" % ci] = u, k, d, i
+    res["n_tn"] = np.array(len(tn_cases))
+    np.savez_compressed(os.path.join(out, "golden_ops.npz"), **res)
+    print("ops done")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    torch.manual_seed(0)
+    want = set(a.only.split(",")) if a.only else {"ops", "blocks", "pos", "feat"}
+    if "ops" in want:
+        gen_ops(a.out)
+    if "blocks" in want:
+        gen_blocks(a.out)
+    if "pos" in want:
+        net, cfg = gen_denoiser("pos", POS_CFG, a.out)
+        gen_sampler_pos(net, cfg, a.out)
+    if "feat" in want:
+        net, cfg = gen_denoiser("feat", FEAT_CFG, a.out)
+        gen_sampler_feat(net, cfg, a.out)
