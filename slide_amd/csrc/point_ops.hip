@@ -1,0 +1,583 @@
+// point_ops.hip -- gfx950 kernels behind the `pointnet2_ops._ext` operator API (+ pytorch3d knn).
+//
+// Written for CDNA4: 64-wide wavefronts, one workgroup per (batch element, tile of queries) instead of
+// the reference's one-block-per-batch-element launches, coalesced channel-minor traffic, LDS-staged
+// search sets.  Index semantics are bit-exact with oracle/ops_cpu.c (which restates
+// _ext-src/src/*.cu); distances use the shared recipe fmaf(dz,dz,fmaf(dy,dy,dx*dx)) and this file is
+// compiled with -ffp-contract=off so nothing else is contracted.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/slide_hip.h"
+
+#define LAUNCH_STATUS() ((int)hipGetLastError())
+
+namespace {
+
+__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+// ---------------------------------------------------------------------------------------------- gather
+// out[b,c,j] = points[b,c,idx[b,j]]   (_ext-src/src/sampling_gpu.cu:8-20)
+__global__ void gather_points_kernel(int c, int n, int m, const float *__restrict__ points,
+                                     const int *__restrict__ idx, float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const int a = idx[(size_t)b * m + j];
+  for (int l = blockIdx.y; l < c; l += gridDim.y)
+    out[((size_t)b * c + l) * m + j] = points[((size_t)b * c + l) * n + a];
+}
+
+// grad_points[b,c,idx[b,j]] += grad_out[b,c,j]   (sampling_gpu.cu:34-47)
+__global__ void gather_points_grad_kernel(int c, int n, int m, const float *__restrict__ grad_out,
+                                          const int *__restrict__ idx, float *__restrict__ grad_points) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const int a = idx[(size_t)b * m + j];
+  for (int l = blockIdx.y; l < c; l += gridDim.y)
+    atomicAdd(grad_points + ((size_t)b * c + l) * n + a, grad_out[((size_t)b * c + l) * m + j]);
+}
+
+// ---------------------------------------------------------------------------------------------- FPS
+// Reference: sampling_gpu.cu:59-173.  The reference's answer depends on its block size bs =
+// opt_n_threads(n) only through the ORDER in which ties are resolved: per lane the smallest k wins,
+// across lanes the shared-memory tree keeps the lower slot, i.e. the lane with the smallest
+// bit-reversed id.  We encode that order in a 64-bit key (value bits | ~rank) and take a plain max, so
+// the thread->point mapping here is free (coalesced, points and running distances live in registers,
+// the candidate set is staged once in LDS) and one barrier per iteration suffices.
+__device__ __forceinline__ unsigned fps_rank(int k, int bs, int lg, int L) {
+  const unsigned t = (unsigned)k & (unsigned)(bs - 1);
+  const unsigned rev = lg ? (__brev(t) >> (32 - lg)) : 0u;
+  return rev * (unsigned)L + (unsigned)(k / bs);
+}
+__device__ __forceinline__ int fps_unrank(unsigned r, int bs, int lg, int L) {
+  const unsigned rb = r / (unsigned)L, kk = r % (unsigned)L;
+  const unsigned t = lg ? (__brev(rb) >> (32 - lg)) : 0u;
+  return (int)(kk * (unsigned)bs + t);
+}
+
+template <int PPT, int NT>
+__global__ __launch_bounds__(NT) void fps_kernel(int n, int m, int bs, int lg, int L, int use_lds,
+                                                 const float *__restrict__ dataset,
+                                                 float *__restrict__ temp, int *__restrict__ idxs) {
+  extern __shared__ __attribute__((aligned(16))) float spts[];
+  __shared__ unsigned long long wkeys[2][NT / 64 > 0 ? NT / 64 : 1];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  dataset += (size_t)b * n * 3;
+  temp += (size_t)b * n;
+  idxs += (size_t)b * m;
+
+  float px[PPT], py[PPT], pz[PPT], td[PPT];
+  unsigned low[PPT];
+  bool valid[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = tid + i * NT;
+    valid[i] = false;
+    px[i] = py[i] = pz[i] = 0.f;
+    td[i] = 0.f;
+    low[i] = 0;
+    if (k < n) {
+      px[i] = dataset[k * 3 + 0];
+      py[i] = dataset[k * 3 + 1];
+      pz[i] = dataset[k * 3 + 2];
+      td[i] = temp[k];
+      const float mag = fmaf(pz[i], pz[i], fmaf(py[i], py[i], px[i] * px[i]));
+      valid[i] = !((double)mag <= 1e-3);  // sampling_gpu.cu:100-101 (double literal)
+      low[i] = 0xFFFFFFFFu - fps_rank(k, bs, lg, L);
+      if (use_lds) {
+        spts[k * 3 + 0] = px[i];
+        spts[k * 3 + 1] = py[i];
+        spts[k * 3 + 2] = pz[i];
+      }
+    }
+  }
+  const float *src = use_lds ? spts : dataset;
+  int old = 0;
+  if (tid == 0) idxs[0] = 0;
+  __syncthreads();
+  for (int j = 1; j < m; ++j) {
+    const float x1 = src[old * 3 + 0], y1 = src[old * 3 + 1], z1 = src[old * 3 + 2];
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      if (valid[i]) {
+        const float d = sqdist3(px[i], py[i], pz[i], x1, y1, z1);
+        const float d2 = fminf(d, td[i]);
+        td[i] = d2;
+        const unsigned long long key =
+            ((unsigned long long)(__float_as_uint(d2) + 1u) << 32) | (unsigned long long)low[i];
+        best = key > best ? key : best;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned hi = __shfl_xor((unsigned)(best >> 32), off);
+      const unsigned lo = __shfl_xor((unsigned)best, off);
+      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+      best = o > best ? o : best;
+    }
+    if (NT > 64) {
+      if ((tid & 63) == 0) wkeys[j & 1][tid >> 6] = best;
+      __syncthreads();
+#pragma unroll
+      for (int w = 0; w < NT / 64; ++w) {
+        const unsigned long long o = wkeys[j & 1][w];
+        best = o > best ? o : best;
+      }
+    }
+    old = best == 0ull ? 0 : fps_unrank(0xFFFFFFFFu - (unsigned)best, bs, lg, L);
+    if (tid == 0) idxs[j] = old;
+  }
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = tid + i * NT;
+    if (k < n && valid[i]) temp[k] = td[i];
+  }
+}
+
+// n > 8192: running distances stay in global memory (rarely used; decode tops out at 4096 points)
+__global__ __launch_bounds__(1024) void fps_kernel_large(int n, int m, int bs, int lg, int L,
+                                                         const float *__restrict__ dataset,
+                                                         float *__restrict__ temp, int *__restrict__ idxs) {
+  __shared__ unsigned long long wkeys[2][16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  dataset += (size_t)b * n * 3;
+  temp += (size_t)b * n;
+  idxs += (size_t)b * m;
+  int old = 0;
+  if (tid == 0) idxs[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = dataset[old * 3 + 0], y1 = dataset[old * 3 + 1], z1 = dataset[old * 3 + 2];
+    unsigned long long best = 0ull;
+    for (int k = tid; k < n; k += 1024) {
+      const float x2 = dataset[k * 3 + 0], y2 = dataset[k * 3 + 1], z2 = dataset[k * 3 + 2];
+      const float mag = fmaf(z2, z2, fmaf(y2, y2, x2 * x2));
+      if ((double)mag <= 1e-3) continue;
+      const float d2 = fminf(sqdist3(x2, y2, z2, x1, y1, z1), temp[k]);
+      temp[k] = d2;
+      const unsigned long long key = ((unsigned long long)(__float_as_uint(d2) + 1u) << 32) |
+                                     (unsigned long long)(0xFFFFFFFFu - fps_rank(k, bs, lg, L));
+      best = key > best ? key : best;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned hi = __shfl_xor((unsigned)(best >> 32), off);
+      const unsigned lo = __shfl_xor((unsigned)best, off);
+      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+      best = o > best ? o : best;
+    }
+    if ((tid & 63) == 0) wkeys[j & 1][tid >> 6] = best;
+    __syncthreads();
+    for (int w = 0; w < 16; ++w) {
+      const unsigned long long o = wkeys[j & 1][w];
+      best = o > best ? o : best;
+    }
+    old = best == 0ull ? 0 : fps_unrank(0xFFFFFFFFu - (unsigned)best, bs, lg, L);
+    if (tid == 0) idxs[j] = old;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- ball query
+// ball_query_gpu.cu:9-47: one thread per query, search set staged through LDS in tiles.
+constexpr int BQ_TILE = 1024;
+__global__ __launch_bounds__(256) void ball_query_kernel(int n, int m, float radius2, int nsample,
+                                                         const float *__restrict__ new_xyz,
+                                                         const float *__restrict__ xyz, int *__restrict__ idx,
+                                                         int *__restrict__ counts) {
+  __shared__ float tile[BQ_TILE * 3];
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  xyz += (size_t)b * n * 3;
+  const bool active = j < m;
+  float nx = 0.f, ny = 0.f, nz = 0.f;
+  int *oi = idx + ((size_t)b * m + (active ? j : 0)) * nsample;
+  if (active) {
+    const float *q = new_xyz + ((size_t)b * m + j) * 3;
+    nx = q[0]; ny = q[1]; nz = q[2];
+  }
+  int cnt = 0;
+  for (int t0 = 0; t0 < n; t0 += BQ_TILE) {
+    const int tn = min(BQ_TILE, n - t0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < tn * 3; i += blockDim.x) tile[i] = xyz[(size_t)t0 * 3 + i];
+    __syncthreads();
+    if (active && cnt < nsample) {
+      for (int k = 0; k < tn && cnt < nsample; ++k) {
+        const float d2 = sqdist3(nx, ny, nz, tile[k * 3 + 0], tile[k * 3 + 1], tile[k * 3 + 2]);
+        if (d2 < radius2) {
+          const int kk = t0 + k;
+          if (cnt == 0)
+            for (int l = 0; l < nsample; ++l) oi[l] = kk;
+          oi[cnt] = kk;
+          ++cnt;
+        }
+      }
+    }
+  }
+  if (active && cnt > 0) counts[(size_t)b * m + j] = cnt;
+}
+
+// ---------------------------------------------------------------------------------------------- grouping
+// out[b,l,j,k] = points[b,l,idx[b,j,k]]  (group_points_gpu.cu:8-28).  One thread per (j,k) slot keeps its
+// index in a register and walks a chunk of channels: index reads and output writes are coalesced.
+__global__ __launch_bounds__(256) void group_points_kernel(int c, int n, int slots, int cchunk,
+                                                           const float *__restrict__ points,
+                                                           const int *__restrict__ idx, float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= slots) return;
+  const int ii = idx[(size_t)b * slots + s];
+  const int l0 = blockIdx.y * cchunk, l1 = min(c, l0 + cchunk);
+  const float *p = points + (size_t)b * c * n;
+  float *o = out + (size_t)b * c * slots;
+  for (int l = l0; l < l1; ++l) o[(size_t)l * slots + s] = p[(size_t)l * n + ii];
+}
+
+__global__ __launch_bounds__(256) void group_points_grad_kernel(int c, int n, int slots, int cchunk,
+                                                                const float *__restrict__ grad_out,
+                                                                const int *__restrict__ idx,
+                                                                float *__restrict__ grad_points) {
+  const int b = blockIdx.z;
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= slots) return;
+  const int ii = idx[(size_t)b * slots + s];
+  const int l0 = blockIdx.y * cchunk, l1 = min(c, l0 + cchunk);
+  const float *g = grad_out + (size_t)b * c * slots;
+  float *gp = grad_points + (size_t)b * c * n;
+  for (int l = l0; l < l1; ++l) atomicAdd(gp + (size_t)l * n + ii, g[(size_t)l * slots + s]);
+}
+
+// ---------------------------------------------------------------------------------------------- three_nn
+// interpolate_gpu.cu:9-59.  (double 1e40 bests == +inf in float for every comparison that can occur.)
+__global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float *__restrict__ unknown,
+                                                       const float *__restrict__ known,
+                                                       float *__restrict__ dist2, int *__restrict__ idx) {
+  __shared__ float tile[BQ_TILE * 3];
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  known += (size_t)b * m * 3;
+  const bool active = j < n;
+  float ux = 0.f, uy = 0.f, uz = 0.f;
+  if (active) {
+    const float *u = unknown + ((size_t)b * n + j) * 3;
+    ux = u[0]; uy = u[1]; uz = u[2];
+  }
+  float best1 = INFINITY, best2 = INFINITY, best3 = INFINITY;
+  int besti1 = 0, besti2 = 0, besti3 = 0;
+  for (int t0 = 0; t0 < m; t0 += BQ_TILE) {
+    const int tn = min(BQ_TILE, m - t0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < tn * 3; i += blockDim.x) tile[i] = known[(size_t)t0 * 3 + i];
+    __syncthreads();
+    if (active) {
+      for (int k = 0; k < tn; ++k) {
+        const float d = sqdist3(ux, uy, uz, tile[k * 3 + 0], tile[k * 3 + 1], tile[k * 3 + 2]);
+        const int kk = t0 + k;
+        if (d < best1) {
+          best3 = best2; besti3 = besti2;
+          best2 = best1; besti2 = besti1;
+          best1 = d; besti1 = kk;
+        } else if (d < best2) {
+          best3 = best2; besti3 = besti2;
+          best2 = d; besti2 = kk;
+        } else if (d < best3) {
+          best3 = d; besti3 = kk;
+        }
+      }
+    }
+  }
+  if (active) {
+    float *od = dist2 + ((size_t)b * n + j) * 3;
+    int *oi = idx + ((size_t)b * n + j) * 3;
+    od[0] = best1; od[1] = best2; od[2] = best3;
+    oi[0] = besti1; oi[1] = besti2; oi[2] = besti3;
+  }
+}
+
+// out[b,l,j] = p[l,i1]*w1 + p[l,i2]*w2 + p[l,i3]*w3 (interpolate_gpu.cu:72-101), shared fma recipe.
+__global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, int n, int cchunk,
+                                                                const float *__restrict__ points,
+                                                                const int *__restrict__ idx,
+                                                                const float *__restrict__ weight,
+                                                                float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int *id = idx + ((size_t)b * n + j) * 3;
+  const float *w = weight + ((size_t)b * n + j) * 3;
+  const int i1 = id[0], i2 = id[1], i3 = id[2];
+  const float w1 = w[0], w2 = w[1], w3 = w[2];
+  const int l0 = blockIdx.y * cchunk, l1 = min(c, l0 + cchunk);
+  const float *p = points + (size_t)b * c * m;
+  float *o = out + (size_t)b * c * n;
+  for (int l = l0; l < l1; ++l) {
+    const float *pl = p + (size_t)l * m;
+    o[(size_t)l * n + j] = fmaf(pl[i3], w3, fmaf(pl[i2], w2, pl[i1] * w1));
+  }
+}
+
+__global__ __launch_bounds__(256) void three_interpolate_grad_kernel(int c, int n, int m, int cchunk,
+                                                                     const float *__restrict__ grad_out,
+                                                                     const int *__restrict__ idx,
+                                                                     const float *__restrict__ weight,
+                                                                     float *__restrict__ grad_points) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int *id = idx + ((size_t)b * n + j) * 3;
+  const float *w = weight + ((size_t)b * n + j) * 3;
+  const int i1 = id[0], i2 = id[1], i3 = id[2];
+  const float w1 = w[0], w2 = w[1], w3 = w[2];
+  const int l0 = blockIdx.y * cchunk, l1 = min(c, l0 + cchunk);
+  const float *g = grad_out + (size_t)b * c * n;
+  float *gp = grad_points + (size_t)b * c * m;
+  for (int l = l0; l < l1; ++l) {
+    const float go = g[(size_t)l * n + j];
+    atomicAdd(gp + (size_t)l * m + i1, go * w1);
+    atomicAdd(gp + (size_t)l * m + i2, go * w2);
+    atomicAdd(gp + (size_t)l * m + i3, go * w3);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- kNN
+// pytorch3d knn_points semantics (see oracle/ops_cpu.c ora_knn_points).  One thread per query, search
+// set LDS-tiled, the K-best list of each thread is a private column in LDS (stable insertion, strict '<').
+constexpr int KNN_TILE = 512;
+template <int NT>
+__global__ __launch_bounds__(NT) void knn_kernel(int n1, int n2, int K, const float *__restrict__ p1,
+                                                 const float *__restrict__ p2,
+                                                 const int64_t *__restrict__ lengths2,
+                                                 float *__restrict__ dists, int64_t *__restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *tile = smem;                              // KNN_TILE*3
+  float *dl = smem + KNN_TILE * 3;                 // [K][NT]
+  int *il = (int *)(dl + (size_t)K * NT);          // [K][NT]
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int i = blockIdx.x * NT + tid;
+  p2 += (size_t)b * n2 * 3;
+  const int len2 = lengths2 ? (int)lengths2[b] : n2;
+  const bool active = i < n1;
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  if (active) {
+    const float *a = p1 + ((size_t)b * n1 + i) * 3;
+    ax = a[0]; ay = a[1]; az = a[2];
+  }
+  int cnt = 0;
+  float worst = INFINITY;
+#define DL(p) dl[(p)*NT + tid]
+#define IL(p) il[(p)*NT + tid]
+  for (int t0 = 0; t0 < len2; t0 += KNN_TILE) {
+    const int tn = min(KNN_TILE, len2 - t0);
+    __syncthreads();
+    for (int q = tid; q < tn * 3; q += NT) tile[q] = p2[(size_t)t0 * 3 + q];
+    __syncthreads();
+    if (!active) continue;
+    for (int k = 0; k < tn; ++k) {
+      const float d = sqdist3(ax, ay, az, tile[k * 3 + 0], tile[k * 3 + 1], tile[k * 3 + 2]);
+      if (cnt == K && !(d < worst)) continue;
+      int pos = cnt < K ? cnt : K - 1;
+      while (pos > 0 && d < DL(pos - 1)) {
+        DL(pos) = DL(pos - 1);
+        IL(pos) = IL(pos - 1);
+        --pos;
+      }
+      DL(pos) = d;
+      IL(pos) = t0 + k;
+      if (cnt < K) ++cnt;
+      if (cnt == K) worst = DL(K - 1);
+    }
+  }
+  if (active) {
+    float *od = dists + ((size_t)b * n1 + i) * K;
+    int64_t *oi = idx + ((size_t)b * n1 + i) * K;
+    for (int k = 0; k < K; ++k) {
+      od[k] = k < cnt ? DL(k) : 0.f;
+      oi[k] = k < cnt ? (int64_t)IL(k) : 0;
+    }
+  }
+#undef DL
+#undef IL
+}
+
+__global__ __launch_bounds__(256) void knn_gather_kernel(int n2, int u, size_t total,
+                                                         const float *__restrict__ x,
+                                                         const int64_t *__restrict__ idx,
+                                                         float *__restrict__ out, int n1K) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const size_t slot = e / u;
+    const int ch = (int)(e % u);
+    const size_t b = slot / n1K;
+    out[e] = x[(b * n2 + (size_t)idx[slot]) * u + ch];
+  }
+}
+
+inline int ilog2(int v) {
+  int l = 0;
+  while ((1 << (l + 1)) <= v) ++l;
+  return l;
+}
+// include/cuda_utils.h:13-19 (floor(log2) computed exactly; the reference's double-log version agrees
+// for every w < 65536)
+inline int opt_n_threads(int w) {
+  int v = 1 << ilog2(w < 1 ? 1 : w);
+  return v > 512 ? 512 : (v < 1 ? 1 : v);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *slide_hip_version(void) { return "slide_hip 0.1 (gfx950)"; }
+
+int slide_hip_device_ok(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return 0;
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, 0) != hipSuccess) return 0;
+  const char *a = p.gcnArchName;
+  return a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0';
+}
+
+int gather_points_kernel_wrapper(int b, int c, int n, int npoints, const float *points, const int *idx,
+                                 float *out, slide_stream_t stream) {
+  if (b <= 0 || c <= 0 || npoints <= 0) return 0;
+  dim3 grid((npoints + 255) / 256, c < 64 ? c : 64, b);
+  hipLaunchKernelGGL(gather_points_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, n, npoints, points,
+                     idx, out);
+  return LAUNCH_STATUS();
+}
+
+int gather_points_grad_kernel_wrapper(int b, int c, int n, int npoints, const float *grad_out,
+                                      const int *idx, float *grad_points, slide_stream_t stream) {
+  if (b <= 0 || c <= 0 || npoints <= 0) return 0;
+  dim3 grid((npoints + 255) / 256, c < 64 ? c : 64, b);
+  hipLaunchKernelGGL(gather_points_grad_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, n, npoints,
+                     grad_out, idx, grad_points);
+  return LAUNCH_STATUS();
+}
+
+int furthest_point_sampling_kernel_wrapper(int b, int n, int m, const float *dataset, float *temp,
+                                           int *idxs, slide_stream_t stream) {
+  if (b <= 0 || m <= 0 || n <= 0) return 0;
+  const int bs = opt_n_threads(n);
+  const int lg = ilog2(bs);
+  const int L = (n + bs - 1) / bs;
+  hipStream_t s = (hipStream_t)stream;
+  const int use_lds = (size_t)n * 12 <= 60000;
+  const size_t shm = use_lds ? (size_t)n * 12 : 0;
+#define FPS_LAUNCH(PPT, NT)                                                                               \
+  hipLaunchKernelGGL((fps_kernel<PPT, NT>), dim3(b), dim3(NT), shm, s, n, m, bs, lg, L, use_lds, dataset, \
+                     temp, idxs)
+  if (n <= 64) FPS_LAUNCH(1, 64);
+  else if (n <= 256) FPS_LAUNCH(1, 256);
+  else if (n <= 512) FPS_LAUNCH(2, 256);
+  else if (n <= 1024) FPS_LAUNCH(4, 256);
+  else if (n <= 2048) FPS_LAUNCH(8, 256);
+  else if (n <= 4096) FPS_LAUNCH(16, 256);
+  else if (n <= 8192) FPS_LAUNCH(32, 256);
+  else
+    hipLaunchKernelGGL(fps_kernel_large, dim3(b), dim3(1024), 0, s, n, m, bs, lg, L, dataset, temp, idxs);
+#undef FPS_LAUNCH
+  return LAUNCH_STATUS();
+}
+
+int query_ball_point_kernel_wrapper(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                                    const float *xyz, int *idx, int *counts, slide_stream_t stream) {
+  if (b <= 0 || m <= 0) return 0;
+  const float radius2 = radius * radius;
+  hipLaunchKernelGGL(ball_query_kernel, dim3((m + 255) / 256, b), dim3(256), 0, (hipStream_t)stream, n, m,
+                     radius2, nsample, new_xyz, xyz, idx, counts);
+  return LAUNCH_STATUS();
+}
+
+static inline int pick_cchunk(int c, int blocks_other) {
+  // enough workgroups to cover 256 CUs several times over, but keep >= 8 channels per thread
+  int chunks = (2048 + blocks_other - 1) / blocks_other;
+  if (chunks < 1) chunks = 1;
+  int cchunk = (c + chunks - 1) / chunks;
+  if (cchunk < 8) cchunk = c < 8 ? c : 8;
+  return cchunk;
+}
+
+int group_points_kernel_wrapper(int b, int c, int n, int npoints, int nsample, const float *points,
+                                const int *idx, float *out, slide_stream_t stream) {
+  const int slots = npoints * nsample;
+  if (b <= 0 || c <= 0 || slots <= 0) return 0;
+  const int gx = (slots + 255) / 256;
+  const int cchunk = pick_cchunk(c, gx * b);
+  hipLaunchKernelGGL(group_points_kernel, dim3(gx, (c + cchunk - 1) / cchunk, b), dim3(256), 0,
+                     (hipStream_t)stream, c, n, slots, cchunk, points, idx, out);
+  return LAUNCH_STATUS();
+}
+
+int group_points_grad_kernel_wrapper(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                                     const int *idx, float *grad_points, slide_stream_t stream) {
+  const int slots = npoints * nsample;
+  if (b <= 0 || c <= 0 || slots <= 0) return 0;
+  const int gx = (slots + 255) / 256;
+  const int cchunk = pick_cchunk(c, gx * b);
+  hipLaunchKernelGGL(group_points_grad_kernel, dim3(gx, (c + cchunk - 1) / cchunk, b), dim3(256), 0,
+                     (hipStream_t)stream, c, n, slots, cchunk, grad_out, idx, grad_points);
+  return LAUNCH_STATUS();
+}
+
+int three_nn_kernel_wrapper(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                            int *idx, slide_stream_t stream) {
+  if (b <= 0 || n <= 0) return 0;
+  hipLaunchKernelGGL(three_nn_kernel, dim3((n + 255) / 256, b), dim3(256), 0, (hipStream_t)stream, n, m,
+                     unknown, known, dist2, idx);
+  return LAUNCH_STATUS();
+}
+
+int three_interpolate_kernel_wrapper(int b, int c, int m, int n, const float *points, const int *idx,
+                                     const float *weight, float *out, slide_stream_t stream) {
+  if (b <= 0 || c <= 0 || n <= 0) return 0;
+  const int gx = (n + 255) / 256;
+  const int cchunk = pick_cchunk(c, gx * b);
+  hipLaunchKernelGGL(three_interpolate_kernel, dim3(gx, (c + cchunk - 1) / cchunk, b), dim3(256), 0,
+                     (hipStream_t)stream, c, m, n, cchunk, points, idx, weight, out);
+  return LAUNCH_STATUS();
+}
+
+int three_interpolate_grad_kernel_wrapper(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                          const float *weight, float *grad_points, slide_stream_t stream) {
+  if (b <= 0 || c <= 0 || n <= 0) return 0;
+  const int gx = (n + 255) / 256;
+  const int cchunk = pick_cchunk(c, gx * b);
+  hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3(gx, (c + cchunk - 1) / cchunk, b), dim3(256), 0,
+                     (hipStream_t)stream, c, n, m, cchunk, grad_out, idx, weight, grad_points);
+  return LAUNCH_STATUS();
+}
+
+int slide_knn_points(int b, int n1, int n2, int K, const float *p1, const float *p2, const int64_t *lengths2,
+                     float *dists, int64_t *idx, slide_stream_t stream) {
+  if (b <= 0 || n1 <= 0 || K <= 0) return 0;
+  if (K > 64) return -2;
+  hipStream_t s = (hipStream_t)stream;
+#define KNN_LAUNCH(NT)                                                                                   \
+  hipLaunchKernelGGL((knn_kernel<NT>), dim3((n1 + NT - 1) / NT, b), dim3(NT),                              \
+                     (size_t)KNN_TILE * 12 + (size_t)K * NT * 8, s, n1, n2, K, p1, p2, lengths2, dists, idx)
+  if (K <= 16 && n1 > 64) KNN_LAUNCH(256);
+  else if (K <= 32 && n1 > 64) KNN_LAUNCH(128);
+  else KNN_LAUNCH(64);
+#undef KNN_LAUNCH
+  return LAUNCH_STATUS();
+}
+
+int slide_knn_gather(int b, int n2, int u, int n1, int K, const float *x, const int64_t *idx, float *out,
+                     slide_stream_t stream) {
+  const size_t total = (size_t)b * n1 * K * u;
+  if (total == 0) return 0;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(knn_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n2, u, total,
+                     x, idx, out, n1 * K);
+  return LAUNCH_STATUS();
+}
+
+}  // extern "C"

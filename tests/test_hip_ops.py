@@ -1,0 +1,135 @@
+"""GPU parity: the HIP `_ext` operators (through the C-ABI) vs the CPU oracle -- bit-exact indices,
+exact gathers; golden fixtures + larger seeded cases + size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N(t):
+    return t.cpu().numpy()
+
+
+def test_device_is_gfx950(gpu_device):
+    from slide_amd._lib import lib
+    assert lib().slide_hip_device_ok() == 1
+
+
+def test_fps_golden_and_random(gpu_device):
+    from slide_amd import _ext
+    g = load_golden("golden_ops.npz")
+    for ci in range(int(g["n_fps"])):
+        p = g["fps%d_in" % ci]
+        idx = _ext.furthest_point_sampling(T(p, gpu_device), g["fps%d_idx" % ci].shape[1])
+        assert np.array_equal(N(idx), g["fps%d_idx" % ci]), ci
+    assert np.array_equal(N(_ext.furthest_point_sampling(T(g["fps_grid_in"], gpu_device), 100)), g["fps_grid_idx"])
+    rs = np.random.RandomState(5)
+    for (B, n, m) in [(4, 2048, 512), (2, 4096, 300), (2, 8192, 128), (1, 9000, 64), (3, 513, 513), (2, 1, 1),
+                      (64, 256, 128)]:
+        p = rs.uniform(-1, 1, (B, n, 3)).astype(np.float32)
+        p[:, n // 2] = p[:, 0]          # duplicate -> exact ties
+        if n > 8:
+            p[:, 3] = 0.001             # inside the origin ball
+        ref = O.furthest_point_sampling(p, m)
+        got = N(_ext.furthest_point_sampling(T(p, gpu_device), m))
+        assert np.array_equal(got, ref), (B, n, m)
+    # property: FPS of a set is a permutation prefix -> indices unique while distinct points remain
+    p = rs.uniform(-1, 1, (8, 1024, 3)).astype(np.float32) + 2.0
+    got = N(_ext.furthest_point_sampling(T(p, gpu_device), 1024))
+    assert all(len(set(r.tolist())) == 1024 for r in got)
+
+
+def test_ball_query(gpu_device):
+    from slide_amd import _ext
+    g = load_golden("golden_ops.npz")
+    for ci in range(int(g["n_bq"])):
+        idx, cnt = _ext.ball_query(T(g["bq%d_new" % ci], gpu_device), T(g["bq%d_xyz" % ci], gpu_device),
+                                   float(g["bq%d_r" % ci]), int(g["bq%d_ns" % ci]))
+        assert np.array_equal(N(idx), g["bq%d_idx" % ci]) and np.array_equal(N(cnt), g["bq%d_cnt" % ci]), ci
+    rs = np.random.RandomState(6)
+    xyz = rs.uniform(-1, 1, (3, 5000, 3)).astype(np.float32)
+    q = rs.uniform(-1.2, 1.2, (3, 700, 3)).astype(np.float32)
+    ri, rc = O.ball_query(q, xyz, 0.1, 32)
+    idx, cnt = _ext.ball_query(T(q, gpu_device), T(xyz, gpu_device), 0.1, 32)
+    assert np.array_equal(N(idx), ri) and np.array_equal(N(cnt), rc)
+
+
+def test_gather_group_interpolate(gpu_device):
+    from slide_amd import _ext
+    rs = np.random.RandomState(7)
+    for (B, C, n, m) in [(2, 3, 256, 128), (4, 51, 16, 16), (2, 256, 1024, 256), (1, 1, 5, 9)]:
+        pts = rs.standard_normal((B, C, n)).astype(np.float32)
+        idx = rs.randint(0, n, (B, m)).astype(np.int32)
+        assert np.array_equal(N(_ext.gather_points(T(pts, gpu_device), T(idx, gpu_device))), O.gather_points(pts, idx))
+        G = rs.standard_normal((B, C, m)).astype(np.float32)
+        assert np.allclose(N(_ext.gather_points_grad(T(G, gpu_device), T(idx, gpu_device), n)),
+                           O.gather_points_grad(G, idx, n), atol=1e-4)
+    for (B, C, n, npnt, ns) in [(4, 51, 16, 16, 16), (2, 256, 16, 16, 16), (2, 64, 256, 128, 32), (1, 128, 1024, 256, 32),
+                                (2, 3, 7, 5, 3)]:
+        pts = rs.standard_normal((B, C, n)).astype(np.float32)
+        idx = rs.randint(0, n, (B, npnt, ns)).astype(np.int32)
+        assert np.array_equal(N(_ext.group_points(T(pts, gpu_device), T(idx, gpu_device))), O.group_points(pts, idx))
+        G = rs.standard_normal((B, C, npnt, ns)).astype(np.float32)
+        assert np.allclose(N(_ext.group_points_grad(T(G, gpu_device), T(idx, gpu_device), n)),
+                           O.group_points_grad(G, idx, n), atol=1e-3)
+    for (B, C, m, n) in [(2, 64, 100, 300), (1, 7, 3, 5), (2, 128, 256, 1024)]:
+        pts = rs.standard_normal((B, C, m)).astype(np.float32)
+        idx = rs.randint(0, m, (B, n, 3)).astype(np.int32)
+        w = rs.uniform(0, 1, (B, n, 3)).astype(np.float32)
+        assert np.array_equal(N(_ext.three_interpolate(T(pts, gpu_device), T(idx, gpu_device), T(w, gpu_device))),
+                              O.three_interpolate(pts, idx, w))
+        G = rs.standard_normal((B, C, n)).astype(np.float32)
+        assert np.allclose(N(_ext.three_interpolate_grad(T(G, gpu_device), T(idx, gpu_device), T(w, gpu_device), m)),
+                           O.three_interpolate_grad(G, idx, w, m), atol=1e-3)
+
+
+def test_three_nn(gpu_device):
+    from slide_amd import _ext
+    g = load_golden("golden_ops.npz")
+    for ci in range(int(g["n_tn"])):
+        d, i = _ext.three_nn(T(g["tn%d_u" % ci], gpu_device), T(g["tn%d_k" % ci], gpu_device))
+        assert np.array_equal(N(i), g["tn%d_i" % ci]) and np.array_equal(N(d), g["tn%d_d" % ci]), ci
+    rs = np.random.RandomState(8)
+    u = rs.uniform(-1, 1, (2, 3000, 3)).astype(np.float32); k = rs.uniform(-1, 1, (2, 2500, 3)).astype(np.float32)
+    rd, ri = O.three_nn(u, k)
+    d, i = _ext.three_nn(T(u, gpu_device), T(k, gpu_device))
+    assert np.array_equal(N(i), ri) and np.array_equal(N(d), rd)
+
+
+def test_knn(gpu_device):
+    from slide_amd import _ext
+    g = load_golden("golden_ops.npz")
+    for ci in range(int(g["n_knn"])):
+        d, i = _ext.knn_points(T(g["knn%d_p1" % ci], gpu_device), T(g["knn%d_p2" % ci], gpu_device), int(g["knn%d_K" % ci]))
+        assert np.array_equal(N(i), g["knn%d_i" % ci]) and np.array_equal(N(d), g["knn%d_d" % ci]), ci
+    rs = np.random.RandomState(9)
+    p1 = rs.uniform(-1, 1, (2, 1000, 3)).astype(np.float32); p2 = rs.uniform(-1, 1, (2, 4096, 3)).astype(np.float32)
+    for K in (1, 8, 32, 64):
+        rd, ri = O.knn_points(p1, p2, K)
+        d, i = _ext.knn_points(T(p1, gpu_device), T(p2, gpu_device), K)
+        assert np.array_equal(N(i), ri) and np.array_equal(N(d), rd), K
+    l2 = np.array([5, 100], np.int64)
+    rd, ri = O.knn_points(p1, p2, 8, l2)
+    d, i = _ext.knn_points(T(p1, gpu_device), T(p2, gpu_device), 8, torch.from_numpy(l2))
+    assert np.array_equal(N(i), ri) and np.array_equal(N(d), rd)
+    x = rs.standard_normal((2, 4096, 11)).astype(np.float32)
+    assert np.array_equal(N(_ext.knn_gather(T(x, gpu_device), i)), O.knn_gather(x, ri))
+
+
+def test_error_behaviour(gpu_device):
+    from slide_amd import _ext
+    with pytest.raises(RuntimeError, match="contiguous"):
+        _ext.gather_points(torch.zeros(1, 8, 3, device=gpu_device).transpose(1, 2),
+                           torch.zeros(1, 2, dtype=torch.int32, device=gpu_device))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        _ext.gather_points(torch.zeros(1, 3, 8, device=gpu_device), torch.zeros(1, 2, dtype=torch.int32))
+    with pytest.raises(RuntimeError, match="float tensor"):
+        _ext.three_nn(torch.zeros(1, 3, 3, device=gpu_device).double(), torch.zeros(1, 3, 3, device=gpu_device))
