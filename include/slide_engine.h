@@ -1,0 +1,98 @@
+/*
+ * slide_engine.h -- C-ABI of the fused latent-DDPM denoiser engine in libslide_hip.so.
+ *
+ * What it replaces: one reverse-diffusion step of the reference =
+ *   PointNet2CloudCondition.forward (pointnet2/models/pointnet2_with_pcld_condition.py:286-489; ~80 torch
+ *   module launches: Mlp_plus_t_emb pointnet2_ops/pointnet2_modules.py:119-176, AttentionModule
+ *   pointnet2_ops/attention.py:70-96, QueryAndGroup / group_knn pointnet2_ops/pointnet2_utils.py:368-524)
+ *   + the DDPM update (pointnet2/util.py:247-253, pointnet2/diffusion_utils/diffusion.py:58-95).
+ * Here a step is a short list of `SlideOp` launches (a "plan") that the host builds once and replays,
+ * eagerly or from a captured hipGraph.  All activations are channel-minor fp32 matrices
+ * [B*npx][ld] resident in HBM; 1x1 convolutions are MFMA contractions with GroupNorm / ReLU /
+ * t-embedding / residual fused into the epilogue.
+ *
+ * All pointers are DEVICE pointers unless stated.  Status: 0 = ok, else hipError_t (or <0 for bad args).
+ */
+#ifndef SLIDE_ENGINE_H
+#define SLIDE_ENGINE_H
+
+#include <stdint.h>
+
+#include "slide_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* epilogue modes of one 32-channel output block */
+enum { SLIDE_EPI_RAW = 0, SLIDE_EPI_NORM = 1, SLIDE_EPI_STATS = 2 };
+enum { SLIDE_F_PRE_RELU = 1, SLIDE_F_POST_RELU = 2 };
+/* MFMA precision of a GEMM: exact fp32 (v_mfma_f32_32x32x2_f32) or fp16 inputs / fp32 accumulate
+ * (v_mfma_f32_32x32x16_f16) */
+enum { SLIDE_PREC_F32 = 0, SLIDE_PREC_F16 = 1 };
+
+/* One per 32 output channels of a GEMM; an array of these lives in DEVICE memory.
+ * y = acc + bias; PRE_RELU; [NORM: GroupNorm over (group of `gs` physical channels x the npx rows of
+ * one sample) for the first n_norm channels of the block]; POST_RELU; + addvec[b]; + residual[row];
+ * stored to out (each input row replicated out_bcast times).  STATS additionally emits per-sample
+ * channel sums / sums of squares (x stats_scale) for a later slide FINALIZE_GN. */
+typedef struct SlideEpi {
+  int32_t mode, flags, gs, n_norm;
+  float inv_count, stats_scale;
+  int32_t out_ld, out_bcast;
+  int32_t res_ld, addvec_bs, stats_bs, pad0;
+  const float *bias;     /* [32] or NULL */
+  const float *gamma;    /* [32] (NORM) */
+  const float *beta;     /* [32] (NORM) */
+  const float *addvec;   /* addvec[b*addvec_bs + c] or NULL */
+  const float *residual; /* residual[row*res_ld + c] or NULL */
+  float *out;            /* out[(row*out_bcast + k)*out_ld + c] */
+  float *stats_sum;      /* stats_sum[b*stats_bs + c] (STATS) */
+  float *stats_sq;
+} SlideEpi;
+
+enum {
+  SLIDE_OP_GEMM = 1,        /* p: X, W, epi, in_scale, in_shift   i: rows, x_ld, k_pad, n_cob, npx_log2, in_bs, prec */
+  SLIDE_OP_PREP_POINTS = 2, /* p: x, xyz, feat0, knn_idx, knn_d2   i: B, cx, ldf           (16 points / sample) */
+  SLIDE_OP_ASSEMBLE_SA = 3, /* p: xyz, feat, knn_idx, g            i: B, C, ldf, ldg, K */
+  SLIDE_OP_ASSEMBLE_FP = 4, /* p: xyz, feat, knn_idx, knn_d2, g    i: B, C, ldf, ldg, K */
+  SLIDE_OP_FINALIZE_GN = 5, /* p: sum, sq, gid, gstart, gend, gamma, beta, scale, shift  i: B, C, bs   f: inv_count */
+  SLIDE_OP_ATTN_COMBINE = 6,/* p: S, V, out   i: B*np, C, ldS, ldV, ldo, K */
+  SLIDE_OP_COPY_COLS = 7,   /* p: src, dst    i: rows, n, src_ld, dst_ld */
+  SLIDE_OP_TEMB = 8,        /* p: ts(or NULL), t_dev, w1,b1,w2,b2, wfc, bfc, out, freq   i: nsamp, t_dim, n_out  (weights [in][out]) */
+  SLIDE_OP_COND = 9,        /* p: label(int64), class_emb, wfc, bfc, out           i: B, dim, n_out */
+  SLIDE_OP_UPDATE_POS = 10, /* p: x, eps, noise(or NULL), t_dev, c_eps, sqrt_alpha, sigma  i: n_elem, -, seed_lo, seed_hi */
+  SLIDE_OP_UPDATE_FEAT = 11,/* p: x, eps, noise(or NULL), t_dev, keypoint, c_recip, c_recipm1, c1, c2, c_std  i: n_pts, C, kdim, seed_lo, seed_hi  f: clamp */
+  SLIDE_OP_ADVANCE_T = 12,  /* p: t_dev  (t_dev[0] -= 1; t_dev[1] += 1) */
+  SLIDE_OP_HEAD_GATHER = 13 /* reserved */
+};
+
+typedef struct SlideOp {
+  int32_t kind;
+  int32_t i[11];
+  float f[4];
+  void *p[10];
+} SlideOp;
+
+/* launches ops[0..n) in order on `stream` (HOST array).  Safe inside hipGraph stream capture. */
+SLIDE_API int slide_run_ops(const SlideOp *ops, int n, slide_stream_t stream);
+
+/* hipGraph helpers: capture everything launched on `stream` between begin/end, replay it later. */
+SLIDE_API int slide_graph_begin(slide_stream_t stream);
+SLIDE_API int slide_graph_end(slide_stream_t stream, void **graph_exec_out);
+SLIDE_API int slide_graph_launch(void *graph_exec, slide_stream_t stream);
+SLIDE_API int slide_graph_destroy(void *graph_exec);
+
+/* HIP-event timing on an arbitrary stream (torch.cuda.Event only sees torch's current stream) */
+SLIDE_API int slide_event_create(void **ev);
+SLIDE_API int slide_event_record(void *ev, slide_stream_t stream);
+SLIDE_API int slide_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
+SLIDE_API int slide_event_destroy(void *ev);
+
+SLIDE_API int slide_sizeof_epi(void);
+SLIDE_API int slide_sizeof_op(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,800 @@
+// engine.hip -- fused latent-DDPM denoiser kernels for gfx950 (C-ABI: include/slide_engine.h).
+//
+// Data layout: every activation is a channel-minor fp32 matrix [B*npx][ld] in HBM (npx = 256 for the
+// set-abstraction blocks: 16 points x 16 neighbours; 128 for the kNN-feature-propagation blocks; 16 for
+// per-point tensors).  A 1x1 convolution is D[co][row] = sum_k W[co][k] X[row][k] on the matrix cores:
+//   * fp32 mode: v_mfma_f32_32x32x2_f32  (bit-exact fp32 fma chain; parity mode)
+//   * fp16 mode: v_mfma_f32_32x32x16_f16 (fp16 operands, fp32 accumulate; throughput mode)
+// W is the A operand (rows = output channels), X the B operand (columns = points), so each lane ends up
+// with 4 consecutive channels of one point -> 16-byte channel-minor stores, and the 16 neighbours of a point
+// sit in 16 adjacent lanes.  One workgroup (4 waves, 64-wide) owns 256 rows = whole samples, so the
+// GroupNorm statistics of a sample never leave the workgroup: bias, ReLU, GroupNorm, t-embedding /
+// class-embedding add and the residual are all applied in the epilogue.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/slide_engine.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TM = 256;  // rows per workgroup
+constexpr int TN = 64;   // output channels per workgroup (two 32-blocks)
+constexpr int BK = 32;   // K chunk staged through LDS
+constexpr float GN_EPS = 1e-5f;
+
+template <int PREC> struct TileT;
+template <> struct TileT<SLIDE_PREC_F32> { using T = float; static constexpr int LDK = 36; };     // 144 B rows
+template <> struct TileT<SLIDE_PREC_F16> { using T = _Float16; static constexpr int LDK = 40; };  //  80 B rows
+
+struct GemmArgs {
+  const float *X;
+  const void *W;
+  const SlideEpi *epi;
+  const float *in_scale, *in_shift;
+  int rows, x_ld, k_pad, n_cob, in_bs;
+};
+
+// sum over aligned groups of W lanes (16 or 32); every lane of the group gets the total
+template <int W>
+__device__ __forceinline__ float lane_group_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // xor 1
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // xor 2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
+  if (W == 32) v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));      // xor 16
+  return v;
+}
+
+template <int PREC, int NPXL>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
+  using T = typename TileT<PREC>::T;
+  constexpr int LDK = TileT<PREC>::LDK;
+  constexpr int NPX = 1 << NPXL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T *const sbase = reinterpret_cast<T *>(smem_raw);
+  constexpr int STAGE = (TM + TN) * LDK;
+
+  const int ntc = (a.n_cob + 1) >> 1;
+  const int ntr = (a.rows + TM - 1) / TM;
+  // XCD-aware mapping: workgroup id % 8 picks the XCD (observed dispatch rule); all channel tiles of one
+  // row tile share that XCD's L2, so the X panel is fetched from HBM once.
+  const int xcd = blockIdx.x & 7, q0 = blockIdx.x >> 3;
+  const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;
+  if (tr >= ntr) return;
+  const int row0 = tr * TM, cob0 = tc * 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 xr[8];
+  float4 wr[2];  // fp32: two float4 ; fp16: wr[0] reinterpreted as 8 halfs
+  const int xr_row = tid >> 3, xr_c = (tid & 7) * 4;
+
+  auto load_chunk = [&](int kc) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int grow = row0 + p * 32 + xr_row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (grow < a.rows) {
+        v = *reinterpret_cast<const float4 *>(a.X + (size_t)grow * a.x_ld + kc * BK + xr_c);
+        if (a.in_scale) {
+          const size_t o = (size_t)(grow >> NPXL) * a.in_bs + kc * BK + xr_c;
+          const float4 sc = *reinterpret_cast<const float4 *>(a.in_scale + o);
+          const float4 sh = *reinterpret_cast<const float4 *>(a.in_shift + o);
+          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        }
+      }
+      xr[p] = v;
+    }
+    if (PREC == SLIDE_PREC_F32) {
+      const float *W = reinterpret_cast<const float *>(a.W);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int gco = cob0 * 32 + p * 32 + xr_row;
+        wr[p] = gco < a.n_cob * 32
+                    ? *reinterpret_cast<const float4 *>(W + (size_t)gco * a.k_pad + kc * BK + xr_c)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+      const _Float16 *W = reinterpret_cast<const _Float16 *>(a.W);
+      const int gco = cob0 * 32 + (tid >> 2);
+      wr[0] = gco < a.n_cob * 32
+                  ? *reinterpret_cast<const float4 *>(W + (size_t)gco * a.k_pad + kc * BK + (tid & 3) * 8)
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_chunk = [&](int s) {
+    T *Xs = sbase + s * STAGE;
+    T *Ws = Xs + TM * LDK;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int r = p * 32 + xr_row;
+      if (PREC == SLIDE_PREC_F32) {
+        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(Xs) + r * LDK + xr_c) = xr[p];
+      } else {
+        f16x4 h;
+        h[0] = (_Float16)xr[p].x; h[1] = (_Float16)xr[p].y; h[2] = (_Float16)xr[p].z; h[3] = (_Float16)xr[p].w;
+        *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(Xs) + r * LDK + xr_c) = h;
+      }
+    }
+    if (PREC == SLIDE_PREC_F32) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(Ws) + (p * 32 + xr_row) * LDK + xr_c) = wr[p];
+    } else {
+      *reinterpret_cast<float4 *>(reinterpret_cast<_Float16 *>(Ws) + (tid >> 2) * LDK + (tid & 3) * 8) = wr[0];
+    }
+  };
+  auto compute = [&](int s) {
+    const T *Xs = sbase + s * STAGE;
+    const T *Ws = Xs + TM * LDK;
+    if (PREC == SLIDE_PREC_F32) {
+      const float *Xf = reinterpret_cast<const float *>(Xs);
+      const float *Wf = reinterpret_cast<const float *>(Ws);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 af[2], bf[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+          af[cb] = *reinterpret_cast<const float4 *>(Wf + (cb * 32 + col) * LDK + q * 8 + half * 4);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+          bf[rb] = *reinterpret_cast<const float4 *>(Xf + (wave * 64 + rb * 32 + col) * LDK + q * 8 + half * 4);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) {
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb].x, bf[rb].x, acc[cb][rb], 0, 0, 0);
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb].y, bf[rb].y, acc[cb][rb], 0, 0, 0);
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb].z, bf[rb].z, acc[cb][rb], 0, 0, 0);
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb].w, bf[rb].w, acc[cb][rb], 0, 0, 0);
+          }
+      }
+    } else {
+      const _Float16 *Xh = reinterpret_cast<const _Float16 *>(Xs);
+      const _Float16 *Wh = reinterpret_cast<const _Float16 *>(Ws);
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        f16x8 af[2], bf[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+          af[cb] = *reinterpret_cast<const f16x8 *>(Wh + (cb * 32 + col) * LDK + st * 16 + half * 8);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+          bf[rb] = *reinterpret_cast<const f16x8 *>(Xh + (wave * 64 + rb * 32 + col) * LDK + st * 16 + half * 8);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb)
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb], bf[rb], acc[cb][rb], 0, 0, 0);
+      }
+    }
+  };
+
+  const int nk = a.k_pad / BK;
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    if (kc + 1 < nk) load_chunk(kc + 1);
+    compute(kc & 1);
+    if (kc + 1 < nk) store_chunk((kc + 1) & 1);
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------------------------------ epilogue
+  float *red = reinterpret_cast<float *>(smem_raw);  // [wave 4][cb 2][half 2][r 16][2]   (tiles are dead now)
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int cobi = cob0 + cb;
+    if (cobi >= a.n_cob) continue;  // uniform per workgroup
+    const SlideEpi *e = a.epi + cobi;
+    const int mode = e->mode, flags = e->flags;
+    float v[2][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float bia = e->bias ? e->bias[c] : 0.f;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        float t = acc[cb][rb][r] + bia;
+        if (flags & SLIDE_F_PRE_RELU) t = fmaxf(t, 0.f);
+        v[rb][r] = t;
+      }
+    }
+    if (mode != SLIDE_EPI_RAW) {
+      // NSCOPE = number of independent sample scopes per wave (NPX=16: one per row block)
+      constexpr int NSCOPE = (NPXL >= 6) ? 1 : 2;
+#pragma unroll
+      for (int sc = 0; sc < NSCOPE; ++sc) {
+        float s[16], ss[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (NSCOPE == 1) {
+            s[r] = v[0][r] + v[1][r];
+            ss[r] = v[0][r] * v[0][r] + v[1][r] * v[1][r];
+            s[r] = lane_group_sum<32>(s[r]);
+            ss[r] = lane_group_sum<32>(ss[r]);
+          } else {
+            s[r] = lane_group_sum<(NPX < 32 ? NPX : 32)>(v[sc][r]);
+            ss[r] = lane_group_sum<(NPX < 32 ? NPX : 32)>(v[sc][r] * v[sc][r]);
+          }
+        }
+        if (NPXL >= 7) {  // the sample spans several waves: exchange through LDS (fixed order -> deterministic)
+          constexpr int WPS = NPX / 64;  // waves per sample (2 or 4)
+          if (col == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              red[(((wave * 2 + cb) * 2 + half) * 16 + r) * 2 + 0] = s[r];
+              red[(((wave * 2 + cb) * 2 + half) * 16 + r) * 2 + 1] = ss[r];
+            }
+          }
+          __syncthreads();
+          const int w0 = (wave / WPS) * WPS;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WPS; ++w) {
+              t0 += red[((((w0 + w) * 2 + cb) * 2 + half) * 16 + r) * 2 + 0];
+              t1 += red[((((w0 + w) * 2 + cb) * 2 + half) * 16 + r) * 2 + 1];
+            }
+            s[r] = t0; ss[r] = t1;
+          }
+        }
+        if (mode == SLIDE_EPI_STATS) {
+          const int rb_w = (NSCOPE == 1) ? 0 : sc;
+          const int row = row0 + wave * 64 + rb_w * 32 + col;
+          const bool writer = (NPXL >= 7) ? ((wave % (NPX / 64)) == 0 && col == 0)
+                                          : ((col & ((NPX < 32 ? NPX : 32) - 1)) == 0);
+          if (writer && row < a.rows) {
+            const size_t b = (size_t)(row >> NPXL);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
+              e->stats_sum[b * e->stats_bs + c] = s[r] * e->stats_scale;
+              e->stats_sq[b * e->stats_bs + c] = ss[r] * e->stats_scale;
+            }
+          }
+        } else {  // SLIDE_EPI_NORM: channel sums -> group sums (groups of gs physical channels, gs | 32)
+          const int gs = e->gs;
+          float gsum[16], gsq[16];
+          if (gs == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { gsum[r] = s[r]; gsq[r] = ss[r]; }
+          } else if (gs == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { gsum[r] = s[r] + s[r ^ 1]; gsq[r] = ss[r] + ss[r ^ 1]; }
+          } else {
+            float Q[4], QQ[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              Q[q] = (s[4 * q] + s[4 * q + 1]) + (s[4 * q + 2] + s[4 * q + 3]);
+              QQ[q] = (ss[4 * q] + ss[4 * q + 1]) + (ss[4 * q + 2] + ss[4 * q + 3]);
+            }
+            if (gs >= 8) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                Q[q] += __shfl_xor(Q[q], 32);
+                QQ[q] += __shfl_xor(QQ[q], 32);
+              }
+            }
+            if (gs == 16) {
+              const float p0 = Q[0] + Q[1], p1 = Q[2] + Q[3], pp0 = QQ[0] + QQ[1], pp1 = QQ[2] + QQ[3];
+              Q[0] = Q[1] = p0; Q[2] = Q[3] = p1; QQ[0] = QQ[1] = pp0; QQ[2] = QQ[3] = pp1;
+            } else if (gs == 32) {
+              const float p = (Q[0] + Q[1]) + (Q[2] + Q[3]), pp = (QQ[0] + QQ[1]) + (QQ[2] + QQ[3]);
+              Q[0] = Q[1] = Q[2] = Q[3] = p; QQ[0] = QQ[1] = QQ[2] = QQ[3] = pp;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { gsum[r] = Q[r >> 2]; gsq[r] = QQ[r >> 2]; }
+          }
+          const float inv_count = e->inv_count;
+          const int n_norm = e->n_norm;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (c < n_norm) {
+              const float mean = gsum[r] * inv_count;
+              const float var = fmaxf(gsq[r] * inv_count - mean * mean, 0.f);
+              const float rstd = 1.0f / sqrtf(var + GN_EPS);
+              const float g = e->gamma[c] * rstd, bt = e->beta[c] - mean * g;
+              if (NSCOPE == 1) {
+                v[0][r] = v[0][r] * g + bt;
+                v[1][r] = v[1][r] * g + bt;
+              } else {
+                v[sc][r] = v[sc][r] * g + bt;
+              }
+            }
+          }
+        }
+      }
+    }
+    // store: 4 consecutive channels per lane and quad -> 16-byte stores
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int row = row0 + wave * 64 + rb * 32 + col;
+      if (row >= a.rows) continue;
+      const size_t b = (size_t)(row >> NPXL);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = 8 * q + 4 * half;
+        float4 y = make_float4(v[rb][4 * q], v[rb][4 * q + 1], v[rb][4 * q + 2], v[rb][4 * q + 3]);
+        if (flags & SLIDE_F_POST_RELU) {
+          y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+        }
+        if (e->addvec) {
+          const float4 t = *reinterpret_cast<const float4 *>(e->addvec + b * e->addvec_bs + c0);
+          y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+        }
+        if (e->residual) {
+          const float4 t = *reinterpret_cast<const float4 *>(e->residual + (size_t)row * e->res_ld + c0);
+          y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+        }
+        const int bc = e->out_bcast;
+        for (int k = 0; k < bc; ++k)
+          *reinterpret_cast<float4 *>(e->out + ((size_t)row * bc + k) * e->out_ld + c0) = y;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ points
+__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+#pragma clang fp contract(off)
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+// Per sample (16 latent points): split x into xyz + features [x[3:], xyz] (attach_position_to_input_feature,
+// pointnet2_with_pcld_condition.py:332-346) and build the full 16x16 neighbour table sorted by
+// (squared distance, index) -- the K=16 and K=8 queries of every SA / FP level are prefixes of it
+// (knn_points semantics, oracle/ops_cpu.c ora_knn_points).
+__global__ __launch_bounds__(256) void prep_points_kernel(int cx, int ldf, const float *__restrict__ x,
+                                                          float *__restrict__ xyz, float *__restrict__ feat0,
+                                                          int *__restrict__ kidx, float *__restrict__ kd2) {
+  __shared__ float sp[48];
+  __shared__ float sd[16][17];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float *xb = x + (size_t)b * 16 * cx;
+  if (tid < 48) {
+    const float v = xb[(tid / 3) * cx + tid % 3];
+    sp[tid] = v;
+    xyz[(size_t)b * 48 + tid] = v;
+  }
+  const int nf = cx - 3;
+  for (int e = tid; e < 16 * cx; e += 256) {
+    const int p = e / cx, c = e % cx;
+    feat0[((size_t)b * 16 + p) * ldf + c] = c < nf ? xb[p * cx + 3 + c] : xb[p * cx + (c - nf)];
+  }
+  __syncthreads();
+  const int i = tid >> 4, j = tid & 15;
+  const float d = sqdist3(sp[i * 3], sp[i * 3 + 1], sp[i * 3 + 2], sp[j * 3], sp[j * 3 + 1], sp[j * 3 + 2]);
+  sd[i][j] = d;
+  __syncthreads();
+  int rank = 0;
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) {
+    const float o = sd[i][jj];
+    rank += (o < d || (o == d && jj < j)) ? 1 : 0;
+  }
+  kidx[((size_t)b * 16 + i) * 16 + rank] = j;
+  kd2[((size_t)b * 16 + i) * 16 + rank] = d;
+}
+
+// QueryAndGroup feature assembly ('nn', use_xyz, abs + center coordinates; pointnet2_utils.py:383-430):
+// g[b][p*K+k][:] = [feat[nbr][0:C], xyz[nbr]-xyz[p], xyz[nbr], xyz[p], 0-pad]
+__global__ __launch_bounds__(256) void assemble_sa_kernel(int C, int ldf, int ldg, int K,
+                                                          const float *__restrict__ xyz, const float *__restrict__ feat,
+                                                          const int *__restrict__ kidx, float *__restrict__ g) {
+#pragma clang fp contract(off)
+  const int b = blockIdx.x;
+  const int npx = 16 * K;
+  const float *px = xyz + (size_t)b * 48;
+  for (int e = blockIdx.y * 256 + threadIdx.x; e < npx * ldg; e += gridDim.y * 256) {
+    const int pxl = e / ldg, c = e - pxl * ldg;
+    const int p = pxl / K, k = pxl - p * K;
+    const int nb = kidx[((size_t)b * 16 + p) * 16 + k];
+    float v = 0.f;
+    if (c < C) v = feat[((size_t)b * 16 + nb) * ldf + c];
+    else if (c < C + 3) v = px[nb * 3 + (c - C)] - px[p * 3 + (c - C)];
+    else if (c < C + 6) v = px[nb * 3 + (c - C - 3)];
+    else if (c < C + 9) v = px[p * 3 + (c - C - 6)];
+    g[((size_t)b * npx + pxl) * ldg + c] = v;
+  }
+}
+
+// group_knn feature assembly (pointnet2_utils.py:497-524):
+// g[b][p*K+k][:] = [feat[nbr][0:C], d2, w, xyz[nbr], xyz[nbr]-xyz[p], xyz[p], 0-pad], w from squared distances
+__global__ __launch_bounds__(256) void assemble_fp_kernel(int C, int ldf, int ldg, int K,
+                                                          const float *__restrict__ xyz, const float *__restrict__ feat,
+                                                          const int *__restrict__ kidx, const float *__restrict__ kd2,
+                                                          float *__restrict__ g) {
+#pragma clang fp contract(off)
+  const int b = blockIdx.x;
+  const int npx = 16 * K;
+  const float *px = xyz + (size_t)b * 48;
+  for (int e = blockIdx.y * 256 + threadIdx.x; e < npx * ldg; e += gridDim.y * 256) {
+    const int pxl = e / ldg, c = e - pxl * ldg;
+    const int p = pxl / K, k = pxl - p * K;
+    const size_t o = ((size_t)b * 16 + p) * 16;
+    const int nb = kidx[o + k];
+    float v = 0.f;
+    if (c < C) v = feat[((size_t)b * 16 + nb) * ldf + c];
+    else if (c == C) v = kd2[o + k];
+    else if (c == C + 1) {
+      float norm = 0.f;
+      for (int kk = 0; kk < K; ++kk) norm += 1.0f / (kd2[o + kk] + 1e-8f);
+      v = (1.0f / (kd2[o + k] + 1e-8f)) / norm;
+    } else if (c < C + 5) v = px[nb * 3 + (c - C - 2)];
+    else if (c < C + 8) v = px[nb * 3 + (c - C - 5)] - px[p * 3 + (c - C - 5)];
+    else if (c < C + 11) v = px[p * 3 + (c - C - 8)];
+    g[((size_t)b * npx + pxl) * ldg + c] = v;
+  }
+}
+
+// GroupNorm over a channel-concatenated tensor whose groups straddle producers (attention weight_conv.1,
+// attention.py:45-47): per-sample channel sums -> per-channel scale / shift applied by the consumer GEMM.
+__global__ __launch_bounds__(256) void finalize_gn_kernel(int B, int C, int bs, float inv_count,
+                                                          const float *__restrict__ sum, const float *__restrict__ sq,
+                                                          const int *__restrict__ gid, const int *__restrict__ gstart,
+                                                          const int *__restrict__ gend, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float *__restrict__ scale,
+                                                          float *__restrict__ shift) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * C) return;
+  const int b = e / C, c = e - b * C;
+  const int g = gid[c];
+  float sc = 1.f, sh = 0.f;
+  if (g >= 0) {
+    float S = 0.f, SS = 0.f;
+    for (int cc = gstart[g]; cc < gend[g]; ++cc) {
+      S += sum[(size_t)b * bs + cc];
+      SS += sq[(size_t)b * bs + cc];
+    }
+    const float mean = S * inv_count;
+    const float var = fmaxf(SS * inv_count - mean * mean, 0.f);
+    const float rstd = 1.0f / sqrtf(var + GN_EPS);
+    sc = gamma[c] * rstd;
+    sh = beta[c] - mean * sc;
+  }
+  scale[(size_t)b * bs + c] = sc;
+  shift[(size_t)b * bs + c] = sh;
+}
+
+// out[bp][c] = sum_k softmax_k(S[bp*K+k][c]) * V[bp*K+k][c]     (attention.py:90-95, mask == all ones)
+template <int K>
+__global__ __launch_bounds__(256) void attn_combine_kernel(int nbp, int C, int ldS, int ldV, int ldo,
+                                                           const float *__restrict__ S, const float *__restrict__ V,
+                                                           float *__restrict__ out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= nbp * C) return;
+  const int bp = e / C, c = e - bp * C;
+  float s[K];
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    s[k] = S[((size_t)bp * K + k) * ldS + c];
+    m = fmaxf(m, s[k]);
+  }
+  float den = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    s[k] = expf(s[k] - m);
+    den += s[k];
+  }
+  float o = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) o += V[((size_t)bp * K + k) * ldV + c] * (s[k] / den);
+  out[(size_t)bp * ldo + c] = o;
+}
+
+__global__ __launch_bounds__(256) void copy_cols_kernel(int rows, int n, int src_ld, int dst_ld,
+                                                        const float *__restrict__ src, float *__restrict__ dst) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= rows * n) return;
+  const int r = e / n, c = e - r * n;
+  dst[(size_t)r * dst_ld + c] = src[(size_t)r * src_ld + c];
+}
+
+__device__ __forceinline__ float swishf(float x) { return x * (1.0f / (1.0f + expf(-x))); }
+
+// t-embedding path (pointnet2_ssg_sem.py:14-31 + pointnet2_with_pcld_condition.py:354-359) followed by every
+// Mlp_plus_t_emb.fc (pointnet2_modules.py:139-143), one workgroup per distinct timestep.
+// Weights are stored input-major ([in][out]) so lanes read consecutive outputs.
+__global__ __launch_bounds__(256) void temb_kernel(int t_dim, int n_out, const float *__restrict__ ts,
+                                                   const int *__restrict__ t_dev, const float *__restrict__ freq,
+                                                   const float *__restrict__ w1, const float *__restrict__ b1,
+                                                   const float *__restrict__ w2, const float *__restrict__ b2,
+                                                   const float *__restrict__ wfc, const float *__restrict__ bfc,
+                                                   float *__restrict__ out) {
+  extern __shared__ float sm[];
+  float *emb = sm;               // t_dim
+  float *h1 = sm + t_dim;        // 4*t_dim
+  float *h2 = h1 + 4 * t_dim;    // 4*t_dim
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float t = ts ? ts[b] : (float)t_dev[0];
+  const int hd = t_dim / 2, H = 4 * t_dim;
+  for (int k = tid; k < hd; k += 256) {
+    const float arg = t * freq[k];
+    emb[k] = sinf(arg);
+    emb[hd + k] = cosf(arg);
+  }
+  __syncthreads();
+  for (int j = tid; j < H; j += 256) {
+    float acc = b1[j];
+    for (int k = 0; k < t_dim; ++k) acc += emb[k] * w1[(size_t)k * H + j];
+    h1[j] = swishf(acc);
+  }
+  __syncthreads();
+  for (int j = tid; j < H; j += 256) {
+    float acc = b2[j];
+    for (int k = 0; k < H; ++k) acc += h1[k] * w2[(size_t)k * H + j];
+    h2[j] = swishf(acc);
+  }
+  __syncthreads();
+  for (int j = tid; j < n_out; j += 256) {
+    float acc = bfc[j];
+    for (int k = 0; k < H; ++k) acc += h2[k] * wfc[(size_t)k * n_out + j];
+    out[(size_t)b * n_out + j] = acc;
+  }
+}
+
+// class embedding lookup (pointnet2_with_pcld_condition.py:363-365) + every Mlp_plus_t_emb.fc_condition
+__global__ __launch_bounds__(256) void cond_kernel(int dim, int n_out, const int64_t *__restrict__ label,
+                                                   const float *__restrict__ class_emb, const float *__restrict__ wfc,
+                                                   const float *__restrict__ bfc, float *__restrict__ out) {
+  extern __shared__ float sm[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float *ce = class_emb + (size_t)label[b] * dim;
+  for (int k = tid; k < dim; k += 256) sm[k] = ce[k];
+  __syncthreads();
+  for (int j = tid; j < n_out; j += 256) {
+    float acc = bfc[j];
+    for (int k = 0; k < dim; ++k) acc += sm[k] * wfc[(size_t)k * n_out + j];
+    out[(size_t)b * n_out + j] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ DDPM updates
+// Philox4x32-10 counter RNG + Box-Muller (used when no explicit noise tensor is supplied)
+__device__ __forceinline__ void philox_round(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t k0,
+                                             uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1,
+                 n3 = (uint32_t)p0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__device__ __forceinline__ float philox_normal(uint32_t seed_lo, uint32_t seed_hi, uint32_t step, uint32_t elem) {
+  uint32_t c0 = elem, c1 = step, c2 = 0x243F6A88u, c3 = 0x85A308D3u, k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  const float u1 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+// sampling() update (pointnet2/util.py:247-253): x = (x - c_eps[t]*eps)/sqrt_alpha[t]; t>0: x += sigma[t]*z
+__global__ __launch_bounds__(256) void update_pos_kernel(int n, uint32_t seed_lo, uint32_t seed_hi, float *__restrict__ x,
+                                                         const float *__restrict__ eps, const float *__restrict__ noise,
+                                                         const int *__restrict__ t_dev, const float *__restrict__ c_eps,
+                                                         const float *__restrict__ sqrt_alpha,
+                                                         const float *__restrict__ sigma) {
+#pragma clang fp contract(off)
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int t = t_dev[0], step = t_dev[1];
+  float v = (x[e] - c_eps[t] * eps[e]) / sqrt_alpha[t];
+  if (t > 0) {
+    const float z = noise ? noise[(size_t)step * n + e] : philox_normal(seed_lo, seed_hi, (uint32_t)step, (uint32_t)e);
+    v = v + sigma[t] * z;
+  }
+  x[e] = v;
+}
+
+// denoising_step (pointnet2/diffusion_utils/diffusion.py:58-95) with the key-point channels re-clamped to the
+// condition (:383-385): x0 = rc*x - rm1*eps [clamp]; mean = c1*x0 + c2*x; x = mean + [t>0] std*z
+__global__ __launch_bounds__(256) void update_feat_kernel(int npts, int C, int kdim, float clamp, uint32_t seed_lo,
+                                                          uint32_t seed_hi, float *__restrict__ x,
+                                                          const float *__restrict__ eps, const float *__restrict__ noise,
+                                                          const int *__restrict__ t_dev, const float *__restrict__ keypoint,
+                                                          const float *__restrict__ rc, const float *__restrict__ rm1,
+                                                          const float *__restrict__ c1, const float *__restrict__ c2,
+                                                          const float *__restrict__ stdv) {
+#pragma clang fp contract(off)
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= npts * C) return;
+  const int p = e / C, c = e - p * C;
+  if (c < kdim) {
+    x[e] = keypoint[(size_t)p * kdim + c];
+    return;
+  }
+  const int t = t_dev[0], step = t_dev[1];
+  const float xv = x[e];
+  float x0 = rc[t] * xv - rm1[t] * eps[e];
+  if (clamp > 0.f) x0 = fminf(fmaxf(x0, -clamp), clamp);
+  float v = c1[t] * x0 + c2[t] * xv;
+  if (t > 0) {
+    const float z = noise ? noise[(size_t)step * npts * C + e]
+                          : philox_normal(seed_lo, seed_hi, (uint32_t)step, (uint32_t)e);
+    v = v + stdv[t] * z;
+  }
+  x[e] = v;
+}
+
+__global__ void advance_t_kernel(int *t_dev) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    t_dev[0] -= 1;
+    t_dev[1] += 1;
+  }
+}
+
+template <int PREC, int NPXL>
+int launch_gemm(const GemmArgs &a, hipStream_t s) {
+  constexpr int LDK = TileT<PREC>::LDK;
+  const size_t shm = 2 * (size_t)(TM + TN) * LDK * sizeof(typename TileT<PREC>::T);
+  const int ntc = (a.n_cob + 1) >> 1, ntr = (a.rows + TM - 1) / TM;
+  const int grid = ((ntr + 7) / 8) * 8 * ntc;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<PREC, NPXL>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel<PREC, NPXL>), dim3(grid), dim3(256), shm, s, a);
+  return (int)hipGetLastError();
+}
+
+int run_gemm(const SlideOp &o, hipStream_t s) {
+  GemmArgs a;
+  a.X = (const float *)o.p[0]; a.W = o.p[1]; a.epi = (const SlideEpi *)o.p[2];
+  a.in_scale = (const float *)o.p[3]; a.in_shift = (const float *)o.p[4];
+  a.rows = o.i[0]; a.x_ld = o.i[1]; a.k_pad = o.i[2]; a.n_cob = o.i[3]; a.in_bs = o.i[5];
+  const int npxl = o.i[4], prec = o.i[6];
+  if (a.k_pad % BK || a.x_ld % 4 || a.rows <= 0 || a.n_cob <= 0) return -3;
+#define CASE(P, L) if (prec == P && npxl == L) return launch_gemm<P, L>(a, s)
+  CASE(SLIDE_PREC_F32, 4); CASE(SLIDE_PREC_F32, 7); CASE(SLIDE_PREC_F32, 8);
+  CASE(SLIDE_PREC_F16, 4); CASE(SLIDE_PREC_F16, 7); CASE(SLIDE_PREC_F16, 8);
+#undef CASE
+  return -4;
+}
+
+int run_op(const SlideOp &o, hipStream_t s) {
+  switch (o.kind) {
+    case SLIDE_OP_GEMM:
+      return run_gemm(o, s);
+    case SLIDE_OP_PREP_POINTS:
+      hipLaunchKernelGGL(prep_points_kernel, dim3(o.i[0]), dim3(256), 0, s, o.i[1], o.i[2], (const float *)o.p[0],
+                         (float *)o.p[1], (float *)o.p[2], (int *)o.p[3], (float *)o.p[4]);
+      break;
+    case SLIDE_OP_ASSEMBLE_SA: {
+      const int work = 16 * o.i[4] * o.i[3];
+      hipLaunchKernelGGL(assemble_sa_kernel, dim3(o.i[0], (work + 4095) / 4096), dim3(256), 0, s, o.i[1], o.i[2],
+                         o.i[3], o.i[4], (const float *)o.p[0], (const float *)o.p[1], (const int *)o.p[2],
+                         (float *)o.p[3]);
+      break;
+    }
+    case SLIDE_OP_ASSEMBLE_FP: {
+      const int work = 16 * o.i[4] * o.i[3];
+      hipLaunchKernelGGL(assemble_fp_kernel, dim3(o.i[0], (work + 4095) / 4096), dim3(256), 0, s, o.i[1], o.i[2],
+                         o.i[3], o.i[4], (const float *)o.p[0], (const float *)o.p[1], (const int *)o.p[2],
+                         (const float *)o.p[3], (float *)o.p[4]);
+      break;
+    }
+    case SLIDE_OP_FINALIZE_GN:
+      hipLaunchKernelGGL(finalize_gn_kernel, dim3((o.i[0] * o.i[1] + 255) / 256), dim3(256), 0, s, o.i[0], o.i[1],
+                         o.i[2], o.f[0], (const float *)o.p[0], (const float *)o.p[1], (const int *)o.p[2],
+                         (const int *)o.p[3], (const int *)o.p[4], (const float *)o.p[5], (const float *)o.p[6],
+                         (float *)o.p[7], (float *)o.p[8]);
+      break;
+    case SLIDE_OP_ATTN_COMBINE: {
+      const int n = o.i[0] * o.i[1];
+      if (o.i[5] == 16)
+        hipLaunchKernelGGL(attn_combine_kernel<16>, dim3((n + 255) / 256), dim3(256), 0, s, o.i[0], o.i[1], o.i[2],
+                           o.i[3], o.i[4], (const float *)o.p[0], (const float *)o.p[1], (float *)o.p[2]);
+      else if (o.i[5] == 8)
+        hipLaunchKernelGGL(attn_combine_kernel<8>, dim3((n + 255) / 256), dim3(256), 0, s, o.i[0], o.i[1], o.i[2],
+                           o.i[3], o.i[4], (const float *)o.p[0], (const float *)o.p[1], (float *)o.p[2]);
+      else
+        return -5;
+      break;
+    }
+    case SLIDE_OP_COPY_COLS:
+      hipLaunchKernelGGL(copy_cols_kernel, dim3((o.i[0] * o.i[1] + 255) / 256), dim3(256), 0, s, o.i[0], o.i[1],
+                         o.i[2], o.i[3], (const float *)o.p[0], (float *)o.p[1]);
+      break;
+    case SLIDE_OP_TEMB:
+      hipLaunchKernelGGL(temb_kernel, dim3(o.i[0]), dim3(256), (size_t)o.i[1] * 9 * sizeof(float), s, o.i[1], o.i[2],
+                         (const float *)o.p[0], (const int *)o.p[1], (const float *)o.p[9], (const float *)o.p[2],
+                         (const float *)o.p[3], (const float *)o.p[4], (const float *)o.p[5], (const float *)o.p[6],
+                         (const float *)o.p[7], (float *)o.p[8]);
+      break;
+    case SLIDE_OP_COND:
+      hipLaunchKernelGGL(cond_kernel, dim3(o.i[0]), dim3(256), (size_t)o.i[1] * sizeof(float), s, o.i[1], o.i[2],
+                         (const int64_t *)o.p[0], (const float *)o.p[1], (const float *)o.p[2], (const float *)o.p[3],
+                         (float *)o.p[4]);
+      break;
+    case SLIDE_OP_UPDATE_POS:
+      hipLaunchKernelGGL(update_pos_kernel, dim3((o.i[0] + 255) / 256), dim3(256), 0, s, o.i[0], (uint32_t)o.i[2],
+                         (uint32_t)o.i[3], (float *)o.p[0], (const float *)o.p[1], (const float *)o.p[2],
+                         (const int *)o.p[3], (const float *)o.p[4], (const float *)o.p[5], (const float *)o.p[6]);
+      break;
+    case SLIDE_OP_UPDATE_FEAT:
+      hipLaunchKernelGGL(update_feat_kernel, dim3((o.i[0] * o.i[1] + 255) / 256), dim3(256), 0, s, o.i[0], o.i[1],
+                         o.i[2], o.f[0], (uint32_t)o.i[3], (uint32_t)o.i[4], (float *)o.p[0], (const float *)o.p[1],
+                         (const float *)o.p[2], (const int *)o.p[3], (const float *)o.p[4], (const float *)o.p[5],
+                         (const float *)o.p[6], (const float *)o.p[7], (const float *)o.p[8], (const float *)o.p[9]);
+      break;
+    case SLIDE_OP_ADVANCE_T:
+      hipLaunchKernelGGL(advance_t_kernel, dim3(1), dim3(64), 0, s, (int *)o.p[0]);
+      break;
+    default:
+      return -1;
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int slide_run_ops(const SlideOp *ops, int n, slide_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  for (int i = 0; i < n; ++i) {
+    const int st = run_op(ops[i], s);
+    if (st != 0) return st > 0 ? st : st * 1000 - i;
+  }
+  return 0;
+}
+
+int slide_graph_begin(slide_stream_t stream) {
+  return (int)hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
+}
+int slide_graph_end(slide_stream_t stream, void **graph_exec_out) {
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture((hipStream_t)stream, &g);
+  if (e != hipSuccess) return (int)e;
+  hipGraphExec_t ex = nullptr;
+  e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  hipGraphDestroy(g);
+  if (e != hipSuccess) return (int)e;
+  *graph_exec_out = (void *)ex;
+  return 0;
+}
+int slide_graph_launch(void *graph_exec, slide_stream_t stream) {
+  return (int)hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream);
+}
+int slide_graph_destroy(void *graph_exec) { return (int)hipGraphExecDestroy((hipGraphExec_t)graph_exec); }
+
+int slide_event_create(void **ev) {
+  hipEvent_t e;
+  const hipError_t st = hipEventCreate(&e);
+  *ev = (void *)e;
+  return (int)st;
+}
+int slide_event_record(void *ev, slide_stream_t stream) { return (int)hipEventRecord((hipEvent_t)ev, (hipStream_t)stream); }
+int slide_event_elapsed_ms(void *start, void *stop, float *ms) {
+  hipError_t st = hipEventSynchronize((hipEvent_t)stop);
+  if (st != hipSuccess) return (int)st;
+  return (int)hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+}
+int slide_event_destroy(void *ev) { return (int)hipEventDestroy((hipEvent_t)ev); }
+
+int slide_sizeof_epi(void) { return (int)sizeof(SlideEpi); }
+int slide_sizeof_op(void) { return (int)sizeof(SlideOp); }
+
+}  // extern "C"

@@ -1,0 +1,485 @@
+"""Host side of the fused denoiser engine (include/slide_engine.h).
+
+`DenoiserEngine` turns a reference `pointnet_config` + a reference-named state dict
+ into a *plan*: packed MFMA weights, per-32-channel epilogue tables and a
+flat list of `SlideOp` launches that computes PointNet2CloudCondition.forward
+(pointnet2/models/pointnet2_with_pcld_condition.py:286-489) for the configuration family every shipped
+DDPM config uses (16 latent points, 'nn' grouping, kNN feature propagation, attention, GroupNorm,
+bias, res_connect, no condition cloud).  The plan is replayed eagerly or from a captured hipGraph.
+
+torch is used for device memory and streams only; all arithmetic runs in libslide_hip.so.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from ._lib import SlideHipError, check, lib
+
+EPI_RAW, EPI_NORM, EPI_STATS = 0, 1, 2
+F_PRE_RELU, F_POST_RELU = 1, 2
+PREC = {"fp32": 0, "fp16": 1}
+(OP_GEMM, OP_PREP_POINTS, OP_ASSEMBLE_SA, OP_ASSEMBLE_FP, OP_FINALIZE_GN, OP_ATTN_COMBINE, OP_COPY_COLS, OP_TEMB,
+ OP_COND, OP_UPDATE_POS, OP_UPDATE_FEAT, OP_ADVANCE_T) = range(1, 13)
+
+
+class SlideEpi(ctypes.Structure):
+    _fields_ = [("mode", ctypes.c_int32), ("flags", ctypes.c_int32), ("gs", ctypes.c_int32), ("n_norm", ctypes.c_int32),
+                ("inv_count", ctypes.c_float), ("stats_scale", ctypes.c_float),
+                ("out_ld", ctypes.c_int32), ("out_bcast", ctypes.c_int32),
+                ("res_ld", ctypes.c_int32), ("addvec_bs", ctypes.c_int32), ("stats_bs", ctypes.c_int32),
+                ("pad0", ctypes.c_int32),
+                ("bias", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
+                ("addvec", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("stats_sum", ctypes.c_void_p), ("stats_sq", ctypes.c_void_p)]
+
+
+class SlideOp(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("i", ctypes.c_int32 * 11), ("f", ctypes.c_float * 4),
+                ("p", ctypes.c_void_p * 10)]
+
+
+def ru(x, m=32):
+    return (x + m - 1) // m * m
+
+
+def make_op(kind, i=(), f=(), p=()):
+    o = SlideOp()
+    o.kind = kind
+    for k, v in enumerate(i):
+        o.i[k] = int(v)
+    for k, v in enumerate(f):
+        o.f[k] = float(v)
+    for k, v in enumerate(p):
+        o.p[k] = None if v is None else int(v)
+    return o
+
+
+def gn_layout(C):
+    """MyGroupNorm(min(32, C), C) (pointnet2_modules.py:24-42): the first n_norm = C - C % G channels are
+    normalised in G groups, the rest pass through.  Returns the PHYSICAL channel layout the engine uses so that
+    every group is a power-of-two run inside one 32-channel block:
+    (phys_index[c] for logical c, C_phys, n_norm_phys, gs_phys, gs_logical)."""
+    G = min(32, C)
+    n_norm = C - C % G
+    gs = n_norm // G
+    gs_p = 1
+    while gs_p < gs:
+        gs_p *= 2
+    assert gs_p <= 32, "GroupNorm group size > 32 not supported by the epilogue"
+    idx = np.empty(C, np.int64)
+    for c in range(C):
+        idx[c] = (c // gs) * gs_p + c % gs if c < n_norm else G * gs_p + (c - n_norm)
+    return idx, int(G * gs_p + (C - n_norm)), int(G * gs_p), int(gs_p), int(gs)
+
+
+class _Arena:
+    """keeps device tensors alive and hands out raw pointers"""
+
+    def __init__(self, device):
+        self.device = device
+        self.keep = []
+
+    def zeros(self, *shape, dtype=torch.float32):
+        t = torch.zeros(*shape, device=self.device, dtype=dtype)
+        self.keep.append(t)
+        return t
+
+    def put(self, arr, dtype=None):
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        if dtype is not None:
+            t = t.to(dtype)
+        t = t.to(self.device)
+        self.keep.append(t)
+        return t
+
+
+class DenoiserEngine:
+    NP = 16  # latent points per sample
+
+    def __init__(self, hp, state_dict, batch, device, prec="fp32", per_sample_t=True):
+        lib()  # fail loudly if the HIP library is missing
+        # a plan may be BUILT on the CPU device (structure / FLOP checks in the CPU tests); it can only RUN on a GPU
+        self.hp, self.B, self.device = hp, int(batch), device
+        self.prec = PREC[prec]
+        self.per_sample_t = per_sample_t
+        self.sd = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)).astype(np.float32)
+                   for k, v in state_dict.items()}
+        arch = hp["architecture"]
+        assert not hp.get("include_local_feature", True) and not hp.get("include_global_feature", False)
+        assert arch["neighbor_definition"] == "nn" and arch.get("use_knn_FP", False) and not arch.get("include_grouper", False)
+        assert hp["attach_position_to_input_feature"] and hp["include_abs_coordinate"] and hp.get("include_center_coordinate", False)
+        assert hp["bias"] and hp["res_connect"] and not hp["bn_first"] and hp.get("bn", True)
+        assert all(n >= self.NP for n in arch["npoint"]), "engine is specialised to N == npoint == 16 (no FPS)"
+        assert all(ns >= self.NP for ns in arch["nsample"]) and arch["K"] == 8
+        self.cx = 3 + hp["in_fea_dim"]
+        self.out_dim = hp["out_dim"]
+        self.t_dim = hp["t_dim"]
+        self.A = _Arena(device)
+        self.ops = []
+        self._tvec = []   # (name, width) of every Mlp .fc           -> offsets into the t vector
+        self._cvec = []   # (name, width) of every Mlp .fc_condition -> offsets into the condition vector
+        self._build()
+
+    # ------------------------------------------------------------------ small helpers
+    def _w(self, name):
+        w = self.sd[name]
+        return w.reshape(w.shape[0], -1)
+
+    def _buf(self, rows, ch):
+        return self.A.zeros(rows, ru(ch))
+
+    def _tvec_off(self, prefix, width):
+        off = sum(w for _, w in self._tvec)
+        self._tvec.append((prefix, width))
+        return off
+
+    def _cvec_off(self, prefix, width):
+        off = sum(w for _, w in self._cvec)
+        self._cvec.append((prefix, width))
+        return off
+
+    def _gemm(self, X, npx_log2, segs, in_cols=None, in_affine=None, k_logical=None):
+        """X: input buffer [rows][ld].  segs: list of dicts describing consecutive output segments:
+             w (O,I) bias (O) | out (tensor) out_coff | mode flags | gn=(gamma,beta) for NORM | layout (gn_layout) |
+             addvec=(tensor, off, bs) | residual tensor | bcast | stats=(sum,sq tensors, coff, scale)
+           in_cols: physical column index of every logical input channel (None = identity)."""
+        rows, ld = X.shape
+        npx = 1 << npx_log2
+        wrows, tables = [], []
+        vec_list = []
+        for sg in segs:
+            w = sg["w"]
+            O, I = w.shape
+            lay = sg.get("layout")
+            if lay is None:
+                oidx, Op, n_norm_p, gs_p, gs_l = np.arange(O), O, 0, 1, 1
+            else:
+                oidx, Op, n_norm_p, gs_p, gs_l = lay
+            Opad = ru(Op)
+            wp = np.zeros((Opad, ld), np.float32)
+            cols = np.arange(I) if in_cols is None else in_cols
+            wp[np.ix_(oidx, cols)] = w
+            wrows.append(wp)
+            vec = np.zeros((3, Opad), np.float32)
+            if sg.get("bias") is not None:
+                vec[0, oidx] = sg["bias"]
+            if sg.get("gn") is not None:
+                gam, bet = sg["gn"]
+                nn = gam.shape[0]
+                vec[1, oidx[:nn]] = gam
+                vec[2, oidx[:nn]] = bet
+            vec_list.append((vec, sg, Opad, n_norm_p, gs_p, gs_l))
+        W = np.concatenate(wrows, axis=0)
+        Wd = self.A.put(W, torch.float16 if self.prec == 1 else torch.float32)
+        n_cob = W.shape[0] // 32
+        epis = (SlideEpi * n_cob)()
+        blk = 0
+        for vec, sg, Opad, n_norm_p, gs_p, gs_l in vec_list:
+            vd = self.A.put(vec)
+            out = sg["out"]
+            coff = sg.get("out_coff", 0)
+            bcast = sg.get("bcast", 1)
+            assert out.shape[1] >= coff + Opad and coff % 4 == 0, (out.shape, coff, Opad)
+            assert out.shape[0] == rows * bcast, (out.shape, rows, bcast)
+            for j in range(Opad // 32):
+                e = epis[blk]
+                e.mode = sg.get("mode", EPI_RAW)
+                e.flags = sg.get("flags", 0)
+                e.gs = gs_p
+                e.n_norm = int(min(32, max(0, n_norm_p - 32 * j)))
+                e.inv_count = 1.0 / (gs_l * npx)
+                e.out_ld = out.shape[1]
+                e.out_bcast = bcast
+                e.bias = vd.data_ptr() + 4 * (32 * j)
+                e.gamma = vd.data_ptr() + 4 * (Opad + 32 * j)
+                e.beta = vd.data_ptr() + 4 * (2 * Opad + 32 * j)
+                e.out = out.data_ptr() + 4 * (coff + 32 * j)
+                if sg.get("addvec") is not None:
+                    t, off, bs = sg["addvec"]
+                    assert off % 4 == 0 and bs % 4 == 0
+                    e.addvec = t.data_ptr() + 4 * (off + 32 * j)
+                    e.addvec_bs = bs
+                if sg.get("residual") is not None:
+                    r = sg["residual"]
+                    assert r.shape[0] == rows and r.shape[1] >= Opad
+                    e.residual = r.data_ptr() + 4 * (32 * j)
+                    e.res_ld = r.shape[1]
+                if sg.get("stats") is not None:
+                    ssum, ssq, scoff, scale = sg["stats"]
+                    e.stats_sum = ssum.data_ptr() + 4 * (scoff + 32 * j)
+                    e.stats_sq = ssq.data_ptr() + 4 * (scoff + 32 * j)
+                    e.stats_bs = ssum.shape[1]
+                    e.stats_scale = scale
+                blk += 1
+        ed = self.A.put(np.frombuffer(bytes(epis), dtype=np.uint8).copy())
+        sc = sh = None
+        in_bs = 0
+        if in_affine is not None:
+            sc, sh = in_affine
+            in_bs = sc.shape[1]
+            assert in_bs == ld
+        self.ops.append(make_op(OP_GEMM, i=(rows, ld, ld, n_cob, npx_log2, in_bs, self.prec),
+                                p=(X.data_ptr(), Wd.data_ptr(), ed.data_ptr(),
+                                   None if sc is None else sc.data_ptr(), None if sh is None else sh.data_ptr())))
+        self.flops += 2 * rows * sum(int(s["w"].size) for s in segs)
+
+    # ------------------------------------------------------------------ blocks
+    def _mlp_segments(self, pfx, tvec, cvec, out1, res_out):
+        """first_mlp + res_connect segments of Mlp_plus_t_emb (pointnet2_modules.py:119-176) sharing one input"""
+        sd = self.sd
+        c1 = sd[pfx + ".first_mlp.0.weight"].shape[0]
+        first = dict(w=self._w(pfx + ".first_mlp.0.weight"), bias=sd[pfx + ".first_mlp.0.bias"], mode=EPI_NORM,
+                     flags=F_POST_RELU, layout=gn_layout(c1), out=out1,
+                     gn=(sd[pfx + ".first_mlp.1.group_norm.weight"], sd[pfx + ".first_mlp.1.group_norm.bias"]))
+        if (pfx + ".fc.weight") in sd:
+            first["addvec"] = (tvec, self._tvec_off(pfx + ".fc", c1), self._t_bs)
+        assert (pfx + ".res_connect.weight") in sd, "identity res_connect (mlp_spec[0]==mlp_spec[-1]) not planned"
+        res = dict(w=self._w(pfx + ".res_connect.weight"), bias=sd[pfx + ".res_connect.bias"], mode=EPI_RAW, out=res_out)
+        return first, res
+
+    def _mlp_tail(self, pfx, npx_log2, h1, cvec, r, final_out, final_coff=0):
+        """second_mlp (+fc_condition) [+ rest_mlp] + residual, writing the module output"""
+        sd = self.sd
+        rows = h1.shape[0]
+        has_rest = (pfx + ".rest_mlp.0.weight") in sd
+        c2 = sd[pfx + ".second_mlp.0.weight"].shape[0]
+        seg = dict(w=self._w(pfx + ".second_mlp.0.weight"), bias=sd[pfx + ".second_mlp.0.bias"], mode=EPI_NORM,
+                   flags=F_POST_RELU, layout=gn_layout(c2),
+                   gn=(sd[pfx + ".second_mlp.1.group_norm.weight"], sd[pfx + ".second_mlp.1.group_norm.bias"]))
+        if (pfx + ".fc_condition.weight") in sd:
+            seg["addvec"] = (cvec, self._cvec_off(pfx + ".fc_condition", c2), self._c_bs)
+        if has_rest:
+            h2 = self._buf(rows, c2)
+            seg["out"] = h2
+            self._gemm(h1, npx_log2, [seg])
+            c3 = sd[pfx + ".rest_mlp.0.weight"].shape[0]
+            seg3 = dict(w=self._w(pfx + ".rest_mlp.0.weight"), bias=sd[pfx + ".rest_mlp.0.bias"], mode=EPI_NORM,
+                        flags=F_POST_RELU, layout=gn_layout(c3), residual=r, out=final_out, out_coff=final_coff,
+                        gn=(sd[pfx + ".rest_mlp.1.group_norm.weight"], sd[pfx + ".rest_mlp.1.group_norm.bias"]))
+            self._gemm(h2, npx_log2, [seg3])
+        else:
+            seg["residual"] = r
+            seg["out"] = final_out
+            seg["out_coff"] = final_coff
+            self._gemm(h1, npx_log2, [seg])
+
+    def _attention(self, apfx, npx_log2, K, g, q_in, mo, mlp_first, mlp_res, out, out_ld_buf):
+        """AttentionModule (attention.py:35-96).  g: grouped input [B*npx][ldg]; q_in: query features [B*16][ld];
+        mo: the Mlp output buffer (values input), produced by the caller AFTER the shared first GEMM.
+        Returns a closure continuing after the caller has produced `mo`."""
+        sd, B = self.sd, self.B
+        rows = g.shape[0]
+        npx = 1 << npx_log2
+        C1 = sd[apfx + ".feat_conv.weight"].shape[0]
+        C2 = sd[apfx + ".grouped_feat_conv.weight"].shape[0]
+        inter = sd[apfx + ".weight_conv.2.weight"].shape[0]
+        cout = sd[apfx + ".weight_conv.5.weight"].shape[0]
+        C1p = ru(C1)
+        ldT = C1p + ru(C2)
+        T = self.A.zeros(rows, ldT)
+        ssum, ssq = self.A.zeros(B, ldT), self.A.zeros(B, ldT)
+        kseg = dict(w=self._w(apfx + ".grouped_feat_conv.weight"), bias=sd[apfx + ".grouped_feat_conv.bias"],
+                    mode=EPI_STATS, flags=F_PRE_RELU, out=T, out_coff=C1p, stats=(ssum, ssq, C1p, 1.0))
+        # shared-input GEMM: [first_mlp | res_connect | grouped_feat_conv]
+        self._gemm(g, npx_log2, [mlp_first, mlp_res, kseg])
+        qseg = dict(w=self._w(apfx + ".feat_conv.weight"), bias=sd[apfx + ".feat_conv.bias"], mode=EPI_STATS,
+                    flags=F_PRE_RELU, out=T, out_coff=0, bcast=K, stats=(ssum, ssq, 0, float(K)))
+        self._gemm(q_in, 4, [qseg])
+
+        def finish():
+            # GroupNorm over the concatenation [q | k] (weight_conv.1): groups may straddle the two producers
+            Ct = C1 + C2
+            G = min(32, Ct)
+            n_norm = Ct - Ct % G
+            gs = n_norm // G
+            phys = np.array([c if c < C1 else C1p + (c - C1) for c in range(Ct)], np.int64)
+            gid = np.full(ldT, -1, np.int32)
+            gam, bet = np.zeros(ldT, np.float32), np.zeros(ldT, np.float32)
+            gid[phys[:n_norm]] = np.arange(n_norm) // gs
+            gam[phys[:n_norm]] = sd[apfx + ".weight_conv.1.group_norm.weight"]
+            bet[phys[:n_norm]] = sd[apfx + ".weight_conv.1.group_norm.bias"]
+            gstart = np.array([phys[gq * gs] for gq in range(G)], np.int32)
+            gend = np.array([phys[(gq + 1) * gs - 1] + 1 for gq in range(G)], np.int32)
+            scale, shift = self.A.zeros(B, ldT), self.A.zeros(B, ldT)
+            d = [self.A.put(a) for a in (gid, gstart, gend, gam, bet)]
+            self.ops.append(make_op(OP_FINALIZE_GN, i=(B, ldT, ldT), f=(1.0 / (gs * npx),),
+                                    p=(ssum.data_ptr(), ssq.data_ptr(), d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(),
+                                       d[3].data_ptr(), d[4].data_ptr(), scale.data_ptr(), shift.data_ptr())))
+            lay = gn_layout(inter)
+            u = self.A.zeros(rows, ru(lay[1]))
+            self._gemm(T, npx_log2, [dict(w=self._w(apfx + ".weight_conv.2.weight"), bias=sd[apfx + ".weight_conv.2.bias"],
+                                          mode=EPI_NORM, flags=F_PRE_RELU, layout=lay, out=u,
+                                          gn=(sd[apfx + ".weight_conv.4.group_norm.weight"],
+                                              sd[apfx + ".weight_conv.4.group_norm.bias"]))],
+                       in_cols=phys, in_affine=(scale, shift))
+            S = self._buf(rows, cout)
+            self._gemm(u, npx_log2, [dict(w=self._w(apfx + ".weight_conv.5.weight"), bias=sd[apfx + ".weight_conv.5.bias"],
+                                          mode=EPI_RAW, out=S)], in_cols=lay[0])
+            V = self._buf(rows, cout)
+            self._gemm(mo, npx_log2, [dict(w=self._w(apfx + ".feat_out_conv.0.weight"), bias=sd[apfx + ".feat_out_conv.0.bias"],
+                                           mode=EPI_NORM, flags=F_POST_RELU, layout=gn_layout(cout), out=V,
+                                           gn=(sd[apfx + ".feat_out_conv.1.group_norm.weight"],
+                                               sd[apfx + ".feat_out_conv.1.group_norm.bias"]))])
+            assert cout % 4 == 0
+            self.ops.append(make_op(OP_ATTN_COMBINE, i=(rows // K, cout, S.shape[1], V.shape[1], out.shape[1], K),
+                                    p=(S.data_ptr(), V.data_ptr(), out.data_ptr())))
+        return finish, cout
+
+    def _sa_module(self, i, feat_in, C):
+        sd, B = self.sd, self.B
+        pfx = "SA_modules.%d" % i
+        mp, ap = pfx + ".mlps.0", pfx + ".attention_modules.0"
+        K = 16
+        rows = B * 16 * K
+        Cg = C + 9
+        assert sd[mp + ".first_mlp.0.weight"].shape[1] == Cg
+        g = self._buf(rows, Cg)
+        self.ops.append(make_op(OP_ASSEMBLE_SA, i=(B, C, feat_in.shape[1], g.shape[1], K),
+                                p=(self.xyz.data_ptr(), feat_in.data_ptr(), self.kidx.data_ptr(), g.data_ptr())))
+        c1 = sd[mp + ".first_mlp.0.weight"].shape[0]
+        c_last = sd[mp + ".res_connect.weight"].shape[0]
+        h1, r, mo = self._buf(rows, c1), self._buf(rows, c_last), self._buf(rows, c_last)
+        first, res = self._mlp_segments(mp, self.tvec, self.cvec, h1, r)
+        out = self._buf(B * 16, c_last)
+        finish, cout = self._attention(ap, 8, K, g, feat_in, mo, first, res, out, None)
+        self._mlp_tail(mp, 8, h1, self.cvec, r, mo)
+        finish()
+        return out, cout
+
+    def _fp_module(self, j, U, CU, Kf, C2, out_buf=None):
+        """PointnetKnnFPModule.forward (pointnet2_modules.py:771-873).  U: unknown (skip) features, Kf: known features."""
+        sd, B = self.sd, self.B
+        pfx = "FP_modules.%d" % j
+        m1, m2, ap = pfx + ".mlp1", pfx + ".mlp2", pfx + ".attention_module"
+        K = 8
+        rows = B * 16 * K
+        Cg = C2 + 11
+        assert sd[m1 + ".first_mlp.0.weight"].shape[1] == Cg
+        g = self._buf(rows, Cg)
+        self.ops.append(make_op(OP_ASSEMBLE_FP, i=(B, C2, Kf.shape[1], g.shape[1], K),
+                                p=(self.xyz.data_ptr(), Kf.data_ptr(), self.kidx.data_ptr(), self.kd2.data_ptr(),
+                                   g.data_ptr())))
+        c1 = sd[m1 + ".first_mlp.0.weight"].shape[0]
+        c_last = sd[m1 + ".res_connect.weight"].shape[0]
+        h1, r, mo = self._buf(rows, c1), self._buf(rows, c_last), self._buf(rows, c_last)
+        first, res = self._mlp_segments(m1, self.tvec, self.cvec, h1, r)
+        # mlp2 input: [interpolated (c_last) | unknown feats (CU) | xyz (3)]  (pointnet2_modules.py:842-855)
+        zin = c_last + CU + 3
+        assert sd[m2 + ".first_mlp.0.weight"].shape[1] == zin
+        Z = self._buf(B * 16, zin)
+        finish, cout = self._attention(ap, 7, K, g, U, mo, first, res, Z, None)
+        self._mlp_tail(m1, 7, h1, self.cvec, r, mo)
+        finish()
+        self.ops.append(make_op(OP_COPY_COLS, i=(B * 16, CU, U.shape[1], Z.shape[1]),
+                                p=(U.data_ptr(), Z.data_ptr() + 4 * c_last)))
+        self.ops.append(make_op(OP_COPY_COLS, i=(B * 16, 3, 3, Z.shape[1]),
+                                p=(self.xyz.data_ptr(), Z.data_ptr() + 4 * (c_last + CU))))
+        n1 = sd[m2 + ".first_mlp.0.weight"].shape[0]
+        n2 = sd[m2 + ".res_connect.weight"].shape[0]
+        hz, rz = self._buf(B * 16, n1), self._buf(B * 16, n2)
+        f2, r2 = self._mlp_segments(m2, self.tvec, self.cvec, hz, rz)
+        self._gemm(Z, 4, [f2, r2])
+        out = out_buf if out_buf is not None else self._buf(B * 16, n2)
+        self._mlp_tail(m2, 4, hz, self.cvec, rz, out)
+        return out, n2
+
+    # ------------------------------------------------------------------ whole network
+    def _build(self):
+        hp, sd, B, A = self.hp, self.sd, self.B, self.A
+        arch = hp["architecture"]
+        self.flops = 0
+        # persistent I/O + per-step state
+        self.x = A.zeros(B, 16, self.cx)
+        self.ts = A.zeros(B)
+        self.label = A.zeros(B, dtype=torch.int64)
+        self.t_dev = A.zeros(2, dtype=torch.int32)
+        self.xyz = A.zeros(B * 16, 3)
+        C0 = self.cx  # in_fea_dim + 3 (position attached as feature)
+        self.feat0 = self._buf(B * 16, C0)
+        self.kidx = A.zeros(B * 16, 16, dtype=torch.int32)
+        self.kd2 = A.zeros(B * 16, 16)
+        # t / condition vectors: widths are only known after the walk, so allocate generously and fix up below
+        n_fc = sum(v.shape[0] for k, v in sd.items() if k.endswith(".fc.weight"))
+        n_fcc = sum(v.shape[0] for k, v in sd.items() if k.endswith(".fc_condition.weight"))
+        self._t_bs = n_fc if self.per_sample_t else 0
+        self._c_bs = n_fcc
+        self.tvec = A.zeros(B if self.per_sample_t else 1, n_fc)
+        self.cvec = A.zeros(B, n_fcc)
+        temb_slot = len(self.ops)
+        self.ops.append(None)  # TEMB placeholder (needs the .fc order of the walk)
+        self.ops.append(make_op(OP_PREP_POINTS, i=(B, self.cx, self.feat0.shape[1]),
+                                p=(self.x.data_ptr(), self.xyz.data_ptr(), self.feat0.data_ptr(), self.kidx.data_ptr(),
+                                   self.kd2.data_ptr())))
+        feats, chans = [self.feat0], [C0]
+        for i in range(len(arch["npoint"])):
+            o, c = self._sa_module(i, feats[i], chans[i])
+            feats.append(o); chans.append(c)
+        nfp = len(arch["decoder_feature_dim"]) - 1
+        dec0 = None
+        for i in range(-1, -(nfp + 1), -1):
+            j = nfp + i
+            out_buf = None
+            if j == 0:  # the last FP module writes straight into the head's input [features | xyz]
+                n2 = sd["FP_modules.0.mlp2.res_connect.weight"].shape[0]
+                dec0 = self._buf(B * 16, n2 + 3)
+                out_buf = dec0
+            o, c = self._fp_module(j, feats[i - 1], chans[i - 1], feats[i], chans[i], out_buf)
+            feats[i - 1], chans[i - 1] = o, c
+        # output head fc_lyaer (pointnet2_with_pcld_condition.py:480-483): conv -> GN(32,128) -> ReLU -> conv
+        c = chans[0]
+        self.ops.append(make_op(OP_COPY_COLS, i=(B * 16, 3, 3, dec0.shape[1]),
+                                p=(self.xyz.data_ptr(), dec0.data_ptr() + 4 * c)))
+        hh = self._buf(B * 16, sd["fc_lyaer.0.weight"].shape[0])
+        assert sd["fc_lyaer.0.weight"].shape[1] == c + 3
+        self._gemm(dec0, 4, [dict(w=self._w("fc_lyaer.0.weight"), bias=sd["fc_lyaer.0.bias"], mode=EPI_NORM,
+                                  flags=F_POST_RELU, layout=gn_layout(sd["fc_lyaer.0.weight"].shape[0]), out=hh,
+                                  gn=(sd["fc_lyaer.1.weight"], sd["fc_lyaer.1.bias"]))])
+        self.eps_pad = self._buf(B * 16, self.out_dim)
+        self._gemm(hh, 4, [dict(w=self._w("fc_lyaer.3.weight"), bias=sd["fc_lyaer.3.bias"], mode=EPI_RAW, out=self.eps_pad)])
+        self.eps = A.zeros(B, 16, self.out_dim)
+        self.ops.append(make_op(OP_COPY_COLS, i=(B * 16, self.out_dim, self.eps_pad.shape[1], self.out_dim),
+                                p=(self.eps_pad.data_ptr(), self.eps.data_ptr())))
+        # t-embedding MLP + all .fc layers, class embedding + all .fc_condition layers (input-major weights)
+        assert sum(w for _, w in self._tvec) == n_fc and sum(w for _, w in self._cvec) == n_fcc
+        half = self.t_dim // 2
+        cfreq = np.float32(np.log(10000) / (half - 1))
+        freq = np.exp(np.arange(half, dtype=np.float32) * -cfreq).astype(np.float32)
+        wfc = np.concatenate([sd[p + ".weight"] for p, _ in self._tvec], axis=0)      # (n_fc, 4*t_dim)
+        bfc = np.concatenate([sd[p + ".bias"] for p, _ in self._tvec], axis=0)
+        d = [A.put(a) for a in (sd["fc_t1.weight"].T, sd["fc_t1.bias"], sd["fc_t2.weight"].T, sd["fc_t2.bias"], wfc.T,
+                                bfc, freq)]
+        self.ops[temb_slot] = make_op(
+            OP_TEMB, i=(B if self.per_sample_t else 1, self.t_dim, n_fc),
+            p=(self.ts.data_ptr() if self.per_sample_t else None, self.t_dev.data_ptr(), d[0].data_ptr(), d[1].data_ptr(),
+               d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), d[5].data_ptr(), self.tvec.data_ptr(), d[6].data_ptr()))
+        wc = np.concatenate([sd[p + ".weight"] for p, _ in self._cvec], axis=0)
+        bc = np.concatenate([sd[p + ".bias"] for p, _ in self._cvec], axis=0)
+        dc = [A.put(a) for a in (sd["class_emb.weight"], wc.T, bc)]
+        self.cond_op = make_op(OP_COND, i=(B, sd["class_emb.weight"].shape[1], n_fcc),
+                               p=(self.label.data_ptr(), dc[0].data_ptr(), dc[1].data_ptr(), dc[2].data_ptr(),
+                                  self.cvec.data_ptr()))
+        self.step_ops = (SlideOp * len(self.ops))(*self.ops)
+        self.cond_ops = (SlideOp * 1)(self.cond_op)
+
+    # ------------------------------------------------------------------ execution
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(self, ops_array, n=None):
+        if self.x.device.type != "cuda":
+            raise SlideHipError("DenoiserEngine plans only run on a GPU; there is no CPU fallback")
+        check(lib().slide_run_ops(ops_array, len(ops_array) if n is None else n, self._stream()), "slide_run_ops")
+
+    def set_label(self, label):
+        self.label.copy_(torch.as_tensor(label).to(self.device, torch.int64).reshape(self.B))
+        self.run(self.cond_ops)
+
+    def forward(self, x, ts, label):
+        """PointNet2CloudCondition.forward(pointcloud=x, ts=ts, label=label) -> (B,16,out_dim)."""
+        assert self.per_sample_t, "engine was built for a shared device-side timestep"
+        self.x.copy_(torch.as_tensor(x).to(self.device, torch.float32).reshape(self.x.shape))
+        self.ts.copy_(torch.as_tensor(ts).to(self.device, torch.float32).reshape(self.B))
+        self.set_label(label)
+        self.run(self.step_ops)
+        return self.eps.clone()
