@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""bench.py -- latent shapes/sec of the position + feature DDPM sampling hot path on N MI355X.
+
+Workload (BASELINE.json configs[1]/[2], per GPU): batch 256 latent-point sets (16 points each);
+  step = ONE reverse-diffusion step of the position DDPM (airplane config, 3-dim)  +
+         ONE reverse-diffusion step of the feature DDPM (chair config, 48-dim feature + 3-dim key points)
+  over the whole batch: denoiser forward + DDPM update + in-kernel noise, replayed from a hipGraph.
+A generated shape needs 1000 + 1000 such steps, so  value = n_gpus * batch / (1000 * seconds_per_step).
+`--steps 1000` is therefore exactly one complete generation of the batch.  Synthetic random-init weights,
+synthetic key points, inputs resident in HBM.  N > 1: one process per GPU (torchrun), batch shards are
+independent (weak scaling), one RCCL all-gather of the (B,16,51) latents closes the timed region.
+
+Extra objects on the JSON line:
+  roofline     the dominant kernel (MFMA GEMM of the feature denoiser's 256-row blocks): algorithmic FLOPs of
+               those launches / their device time, measured with HIP events on the launch stream in an
+               instrumented eager replay right after the timed region (the timed region itself is a graph replay)
+  cpu_baseline the numpy/C oracle ("port" of the reference algorithm; the reference has no CPU path for its native
+               ops) timed on the host cores on a bounded sample of the same workload
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}  # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(batch=4, budget_s=20.0):
+    from oracle import denoiser_np as D
+    from slide_amd import configs, model_spec
+    from slide_amd.synth import synth_keypoints, synth_state_dict
+    rs = np.random.RandomState(0)
+    per = {}
+    for name, cfg in (("pos", configs.position_ddpm_config()), ("feat", configs.feature_ddpm_config())):
+        hp = cfg["pointnet_config"]
+        sd = synth_state_dict(model_spec.denoiser_param_spec(hp))
+        x = rs.standard_normal((batch, 16, 3 + hp["in_fea_dim"])).astype(np.float32)
+        x[:, :, :3] = synth_keypoints(batch)
+        ts = np.full((batch,), 500, np.float32)
+        label = np.zeros((batch,), np.int64)
+        D.denoiser_forward(hp, sd, x, ts, label)  # warm
+        n, t0 = 0, time.time()
+        while time.time() - t0 < budget_s / 2 or n < 2:
+            D.denoiser_forward(hp, sd, x, ts, label)
+            n += 1
+        per[name] = (time.time() - t0) / n
+    sec_per_step = per["pos"] + per["feat"]
+    return {"value": batch / (1000.0 * sec_per_step), "unit": "shapes/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "numpy/C oracle denoiser forward (pos+feat), batch %d, %.3f+%.3f s/step, extrapolated x1000 steps"
+                      % (batch, per["pos"], per["feat"])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=256, help="latent shapes per GPU (BASELINE configs[1]/[2]: 256)")
+    ap.add_argument("--prec", default="fp16", choices=["fp16", "fp32"], help="MFMA operand type (fp32 accumulate)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from slide_amd import configs, model_spec
+    from slide_amd._lib import check, lib
+    from slide_amd.diffusion import FeatureSampler, PositionSampler
+    from slide_amd.engine import OP_GEMM
+    from slide_amd.synth import synth_keypoints, synth_state_dict
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B = a.batch
+
+    pc, fc = configs.position_ddpm_config(), configs.feature_ddpm_config()
+    sd_p = synth_state_dict(model_spec.denoiser_param_spec(pc["pointnet_config"]))
+    sd_f = synth_state_dict(model_spec.denoiser_param_spec(fc["pointnet_config"]))
+    pos = PositionSampler(pc["pointnet_config"], sd_p, B, dev, pc["diffusion_config"], prec=a.prec, seed=1000 + rank)
+    feat = FeatureSampler(fc["pointnet_config"], sd_f, B, dev, fc["standard_diffusion_config"], prec=a.prec,
+                          seed=2000 + rank)
+    rs = np.random.RandomState(rank)
+    kp = synth_keypoints(B, seed=rank)
+
+    def reset():
+        pos.begin(np.zeros(B, np.int64), rs.standard_normal((B, 16, 3)).astype(np.float32))
+        feat.begin(np.full(B, 4, np.int64), kp, rs.standard_normal((B, 16, 51)).astype(np.float32))
+
+    def run(n):  # n reverse steps of each DDPM; chains restart from fresh noise every 1000 steps
+        done = 0
+        while done < n:
+            k = min(n - done, 1000)
+            reset()
+            pos.advance(k)
+            feat.advance(k)
+            done += k
+
+    def sync_all():
+        pos.stream.synchronize(); feat.stream.synchronize(); torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    run(max(a.warmup, 1))
+    gathered = [torch.empty(B, 16, 51, device=dev) for _ in range(world)] if world > 1 else None
+    sync_all()
+    t0 = time.perf_counter()
+    run(a.steps)
+    if world > 1:  # the single collective of the path: all ranks' latents (835 KB / rank at B=256)
+        feat.stream.synchronize()
+        dist.all_gather(gathered, feat.engine.x.reshape(B, 16, 51))
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    final = feat.state()
+    finite = bool(torch.isfinite(final).all().item()) and bool(torch.isfinite(pos.state()).all().item())
+    ms_per_step = dt * 1e3 / a.steps
+    value = world * B / (1000.0 * (ms_per_step / 1e3))
+
+    out = {"metric": "latent shapes/sec (pos+feat DDPM, 1000 steps, 16 pts)", "value": round(value, 3),
+           "unit": "shapes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f16 MFMA operands, f32 accumulate/activations" if a.prec == "fp16" else "f32", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[1]+[2]: airplane position DDPM (16x3) + chair feature DDPM (16x51), "
+                                  "batch %d per GPU; 1 step = one reverse step of each; shape = 1000+1000 steps" % B,
+                      "batch_per_gpu": B, "prec": a.prec, "launches_per_step": pos.n_launches + feat.n_launches,
+                      "finite": finite}}
+
+    if rank == 0 and not a.no_roofline:
+        L = lib()
+        f = feat
+        with torch.cuda.stream(f.stream):
+            n = len(f.step_ops)
+            ms = (ctypes.c_float * n)()
+            tot = np.zeros(n)
+            reps = 5
+            feat.begin(np.full(B, 4, np.int64), kp, rs.standard_normal((B, 16, 51)).astype(np.float32))
+            for _ in range(reps):
+                check(L.slide_run_ops_timed(f.step_ops, n, ctypes.c_void_p(f.stream.cuda_stream), ms), "run_ops_timed")
+                tot += np.array(list(ms))
+        tot /= reps
+        flops = f.engine.gemm_flops  # per GEMM op, algorithmic (logical channels), whole batch
+        dom = [i for i in range(n) if f.step_ops[i].kind == OP_GEMM and f.step_ops[i].i[4] == 8]
+        dflops = sum(flops[i] for i in dom)
+        dms = sum(tot[i] for i in dom)
+        ach = dflops / (dms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.prec], "unit": "TFLOP/s",
+                           "frac": round(ach / PEAK_TFLOPS[a.prec], 4), "traffic": None,
+                           "kernel": "gemm_kernel<%s,256-row samples> (feature denoiser, %d launches/step, avg %.1f us)"
+                                     % (a.prec, len(dom), 1e3 * dms / len(dom)),
+                           "step_ms_eager_sum": round(float(tot.sum()), 4),
+                           "gemm_ms_per_step_all": round(float(sum(tot[i] for i in range(n) if f.step_ops[i].kind == OP_GEMM)), 4)}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

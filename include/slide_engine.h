@@ -77,6 +77,10 @@ typedef struct SlideOp {
 /* launches ops[0..n) in order on `stream` (HOST array).  Safe inside hipGraph stream capture. */
 SLIDE_API int slide_run_ops(const SlideOp *ops, int n, slide_stream_t stream);
 
+/* same, eagerly, with a HIP event recorded on `stream` between consecutive launches; ms_out[i] (HOST, n floats)
+ * receives the device time of ops[i].  Synchronises.  For per-kernel roofline figures, never on a timed path. */
+SLIDE_API int slide_run_ops_timed(const SlideOp *ops, int n, slide_stream_t stream, float *ms_out);
+
 /* hipGraph helpers: capture everything launched on `stream` between begin/end, replay it later. */
 SLIDE_API int slide_graph_begin(slide_stream_t stream);
 SLIDE_API int slide_graph_end(slide_stream_t stream, void **graph_exec_out);

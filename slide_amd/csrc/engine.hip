@@ -651,8 +651,8 @@ int launch_gemm(const GemmArgs &a, hipStream_t s) {
   const int grid = ((ntr + 7) / 8) * 8 * ntc;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<PREC, NPXL>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<PREC, NPXL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr_set = true;
   }
   hipLaunchKernelGGL((gemm_kernel<PREC, NPXL>), dim3(grid), dim3(256), shm, s, a);
@@ -761,6 +761,26 @@ int slide_run_ops(const SlideOp *ops, int n, slide_stream_t stream) {
   return 0;
 }
 
+// Eager replay with a HIP event between consecutive launches (recorded on the launch stream): ms_out[i] = device
+// time of ops[i].  Used by bench.py for the per-kernel roofline figure; not used on the timed path.
+int slide_run_ops_timed(const SlideOp *ops, int n, slide_stream_t stream, float *ms_out) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= 0 || n > 4096) return -6;
+  hipEvent_t *ev = new hipEvent_t[n + 1];
+  int st = 0;
+  for (int i = 0; i <= n; ++i) st |= (int)hipEventCreate(&ev[i]);
+  if (st == 0) st = (int)hipEventRecord(ev[0], s);
+  for (int i = 0; i < n && st == 0; ++i) {
+    st = run_op(ops[i], s);
+    if (st == 0) st = (int)hipEventRecord(ev[i + 1], s);
+  }
+  if (st == 0) st = (int)hipEventSynchronize(ev[n]);
+  for (int i = 0; i < n && st == 0; ++i) st = (int)hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]);
+  for (int i = 0; i <= n; ++i) (void)hipEventDestroy(ev[i]);
+  delete[] ev;
+  return st;
+}
+
 int slide_graph_begin(slide_stream_t stream) {
   return (int)hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
 }
@@ -770,7 +790,7 @@ int slide_graph_end(slide_stream_t stream, void **graph_exec_out) {
   if (e != hipSuccess) return (int)e;
   hipGraphExec_t ex = nullptr;
   e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-  hipGraphDestroy(g);
+  (void)hipGraphDestroy(g);
   if (e != hipSuccess) return (int)e;
   *graph_exec_out = (void *)ex;
   return 0;

@@ -106,6 +106,16 @@ class _GraphedSampler:
             e.x.copy_(torch.as_tensor(x).to(self.device, torch.float32).reshape(e.x.shape))
             e.t_dev.copy_(torch.tensor([t_start, 0], dtype=torch.int32))
 
+    def advance(self, n_steps):
+        """replay n reverse steps from the current device-side state (no host sync)"""
+        self._run_steps(n_steps)
+
+    def state(self):
+        with torch.cuda.stream(self.stream):
+            out = self.engine.x.clone()
+        self.stream.synchronize()
+        return out
+
     def __del__(self):
         try:
             if self.graph is not None:
@@ -136,13 +146,14 @@ class PositionSampler(_GraphedSampler):
         """reverse steps t = t_start .. t_start-n_steps+1 (defaults: T-1 .. 0) starting from x_T; returns x."""
         t_start = self.T - 1 if t_start is None else t_start
         n_steps = t_start + 1 if n_steps is None else n_steps
+        self.begin(label, x_T, t_start)
+        self.advance(n_steps)
+        return self.state()
+
+    def begin(self, label, x_T, t_start=None):
         with torch.cuda.stream(self.stream):
             self.engine.set_label(label)
-            self._set_state(x_T, t_start)
-            self._run_steps(n_steps)
-            out = self.engine.x.clone()
-        self.stream.synchronize()
-        return out
+            self._set_state(x_T, self.T - 1 if t_start is None else t_start)
 
 
 class FeatureSampler(_GraphedSampler):
@@ -173,15 +184,15 @@ class FeatureSampler(_GraphedSampler):
     def sample(self, label, keypoint, x_T, t_start=None, n_steps=None):
         t_start = self.T - 1 if t_start is None else t_start
         n_steps = t_start + 1 if n_steps is None else n_steps
+        self.begin(label, keypoint, x_T, t_start)
+        self.advance(n_steps)
+        return self.state()  # the key-point channels are re-clamped to the condition by every update (:395-397)
+
+    def begin(self, label, keypoint, x_T, t_start=None):
         with torch.cuda.stream(self.stream):
             kp = torch.as_tensor(keypoint).to(self.device, torch.float32).reshape(self.B, 16, self.kdim)
             x = torch.as_tensor(x_T).to(self.device, torch.float32).reshape(self.B, 16, -1).clone()
             x[:, :, :self.kdim] = kp  # diffusion.py:383-385
             self.keypoint.copy_(kp.reshape(self.B * 16, self.kdim))
             self.engine.set_label(label)
-            self._set_state(x, t_start)
-            self._run_steps(n_steps)
-            out = self.engine.x.clone()
-            out[:, :, :self.kdim] = kp
-        self.stream.synchronize()
-        return out
+            self._set_state(x, self.T - 1 if t_start is None else t_start)

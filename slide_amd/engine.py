@@ -219,6 +219,7 @@ class DenoiserEngine:
             sc, sh = in_affine
             in_bs = sc.shape[1]
             assert in_bs == ld
+        self.gemm_flops[len(self.ops)] = 2 * rows * sum(int(s["w"].size) for s in segs)
         self.ops.append(make_op(OP_GEMM, i=(rows, ld, ld, n_cob, npx_log2, in_bs, self.prec),
                                 p=(X.data_ptr(), Wd.data_ptr(), ed.data_ptr(),
                                    None if sc is None else sc.data_ptr(), None if sh is None else sh.data_ptr())))
@@ -389,6 +390,7 @@ class DenoiserEngine:
         hp, sd, B, A = self.hp, self.sd, self.B, self.A
         arch = hp["architecture"]
         self.flops = 0
+        self.gemm_flops = {}
         # persistent I/O + per-step state
         self.x = A.zeros(B, 16, self.cx)
         self.ts = A.zeros(B)
