@@ -26,39 +26,45 @@ extern "C" {
 
 /* epilogue modes of one 32-channel output block */
 enum { SLIDE_EPI_RAW = 0, SLIDE_EPI_NORM = 1, SLIDE_EPI_STATS = 2 };
-enum { SLIDE_F_PRE_RELU = 1, SLIDE_F_POST_RELU = 2 };
+enum { SLIDE_F_PRE_RELU = 1, SLIDE_F_POST_RELU = 2, SLIDE_F_OUT_F32 = 4 };
 /* MFMA precision of a GEMM: exact fp32 (v_mfma_f32_32x32x2_f32) or fp16 inputs / fp32 accumulate
  * (v_mfma_f32_32x32x16_f16) */
 enum { SLIDE_PREC_F32 = 0, SLIDE_PREC_F16 = 1 };
 
 /* One per 32 output channels of a GEMM; an array of these lives in DEVICE memory.
- * y = acc + bias; PRE_RELU; [NORM: GroupNorm over (group of `gs` physical channels x the npx rows of
- * one sample) for the first n_norm channels of the block]; POST_RELU; + addvec[b]; + residual[row];
- * stored to out (each input row replicated out_bcast times).  STATS additionally emits per-sample
- * channel sums / sums of squares (x stats_scale) for a later slide FINALIZE_GN. */
+ *   y = acc + bias + pre_add[row >> pre_add_shift];  PRE_RELU;
+ *   [NORM: GroupNorm over (group of `gs` physical channels x the npx rows of one sample) for the first n_norm
+ *    channels of the block];  POST_RELU;  + addvec[b] (row addvec_idx[0] of a table when addvec_idx != NULL);
+ *   + residual[row];  stored to out (activation storage type, or fp32 with SLIDE_F_OUT_F32).
+ * STATS instead emits per-sample channel sums / sums of squares (x stats_scale) for a later FINALIZE_GN and stores
+ * the un-normalised value.  Activation pointers (pre_add, residual, out) are fp32 or fp16 according to the GEMM's
+ * precision; bias / gamma / beta / addvec / stats are always fp32. */
 typedef struct SlideEpi {
   int32_t mode, flags, gs, n_norm;
   float inv_count, stats_scale;
-  int32_t out_ld, out_bcast;
-  int32_t res_ld, addvec_bs, stats_bs, pad0;
-  const float *bias;     /* [32] or NULL */
-  const float *gamma;    /* [32] (NORM) */
-  const float *beta;     /* [32] (NORM) */
-  const float *addvec;   /* addvec[b*addvec_bs + c] or NULL */
-  const float *residual; /* residual[row*res_ld + c] or NULL */
-  float *out;            /* out[(row*out_bcast + k)*out_ld + c] */
-  float *stats_sum;      /* stats_sum[b*stats_bs + c] (STATS) */
+  int32_t out_ld, res_ld;
+  int32_t addvec_bs, stats_bs, pre_add_ld, pre_add_shift;
+  int32_t addvec_idx_stride, pad0;
+  const float *bias;          /* [32] or NULL */
+  const float *gamma;         /* [32] (NORM) */
+  const float *beta;          /* [32] (NORM) */
+  const float *addvec;        /* addvec[idx*addvec_idx_stride + b*addvec_bs + c] or NULL */
+  const int32_t *addvec_idx;  /* device scalar (the current timestep) or NULL */
+  const void *residual;       /* residual[row*res_ld + c] or NULL */
+  const void *pre_add;        /* pre_add[(row >> pre_add_shift)*pre_add_ld + c] or NULL */
+  void *out;                  /* out[row*out_ld + c] */
+  float *stats_sum;           /* stats_sum[b*stats_bs + c] (STATS) */
   float *stats_sq;
 } SlideEpi;
 
 enum {
-  SLIDE_OP_GEMM = 1,        /* p: X, W, epi, in_scale, in_shift   i: rows, x_ld, k_pad, n_cob, npx_log2, in_bs, prec */
-  SLIDE_OP_PREP_POINTS = 2, /* p: x, xyz, feat0, knn_idx, knn_d2   i: B, cx, ldf           (16 points / sample) */
-  SLIDE_OP_ASSEMBLE_SA = 3, /* p: xyz, feat, knn_idx, g            i: B, C, ldf, ldg, K */
-  SLIDE_OP_ASSEMBLE_FP = 4, /* p: xyz, feat, knn_idx, knn_d2, g    i: B, C, ldf, ldg, K */
+  SLIDE_OP_GEMM = 1,        /* p: X, W, epi, in_scale, in_shift   i: rows, x_ld, k_pad, n_cob, npx_log2, in_bs, prec, cbw(2|4) */
+  SLIDE_OP_PREP_POINTS = 2, /* p: x, xyz, feat0, knn_idx, knn_d2   i: B, cx, ldf, prec     (16 points / sample) */
+  SLIDE_OP_ASSEMBLE_SA = 3, /* p: xyz, feat, knn_idx, g            i: B, C, ldf, ldg, K, prec */
+  SLIDE_OP_ASSEMBLE_FP = 4, /* p: xyz, feat, knn_idx, knn_d2, g    i: B, C, ldf, ldg, K, prec */
   SLIDE_OP_FINALIZE_GN = 5, /* p: sum, sq, gid, gstart, gend, gamma, beta, scale, shift  i: B, C, bs   f: inv_count */
-  SLIDE_OP_ATTN_COMBINE = 6,/* p: S, V, out   i: B*np, C, ldS, ldV, ldo, K */
-  SLIDE_OP_COPY_COLS = 7,   /* p: src, dst    i: rows, n, src_ld, dst_ld */
+  SLIDE_OP_ATTN_COMBINE = 6,/* p: S, V, out   i: B*np, C, ldS, ldV, ldo, K, prec */
+  SLIDE_OP_COPY_COLS = 7,   /* p: src, dst    i: rows, n, src_ld, dst_ld, src_is_f16, dst_is_f16 */
   SLIDE_OP_TEMB = 8,        /* p: ts(or NULL), t_dev, w1,b1,w2,b2, wfc, bfc, out, freq   i: nsamp, t_dim, n_out  (weights [in][out]) */
   SLIDE_OP_COND = 9,        /* p: label(int64), class_emb, wfc, bfc, out           i: B, dim, n_out */
   SLIDE_OP_UPDATE_POS = 10, /* p: x, eps, noise(or NULL), t_dev, c_eps, sqrt_alpha, sigma  i: n_elem, -, seed_lo, seed_hi */

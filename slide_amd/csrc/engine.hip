@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/slide_engine.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -21,17 +23,19 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int TM = 256;  // rows per workgroup
-constexpr int TN = 64;   // output channels per workgroup (two 32-blocks)
+constexpr int TM = 256;  // rows per workgroup (whole samples: 1 x 256, 2 x 128 or 16 x 16 rows)
 constexpr int BK = 32;   // K chunk staged through LDS
 constexpr float GN_EPS = 1e-5f;
 
+// PREC selects BOTH the MFMA operand type and the storage type of every activation matrix in HBM:
+//   fp32: float activations,   v_mfma_f32_32x32x2_f32   (exact; parity mode)
+//   fp16: _Float16 activations, v_mfma_f32_32x32x16_f16 (fp32 accumulate and fp32 epilogue math; throughput mode)
 template <int PREC> struct TileT;
-template <> struct TileT<SLIDE_PREC_F32> { using T = float; static constexpr int LDK = 36; };     // 144 B rows
-template <> struct TileT<SLIDE_PREC_F16> { using T = _Float16; static constexpr int LDK = 40; };  //  80 B rows
+template <> struct TileT<SLIDE_PREC_F32> { using T = float; static constexpr int LDK = 36; static constexpr int EPL = 4; };
+template <> struct TileT<SLIDE_PREC_F16> { using T = _Float16; static constexpr int LDK = 40; static constexpr int EPL = 8; };
 
 struct GemmArgs {
-  const float *X;
+  const void *X;
   const void *W;
   const SlideEpi *epi;
   const float *in_scale, *in_shift;
@@ -49,92 +53,121 @@ __device__ __forceinline__ float lane_group_sum(float v) {
   return v;
 }
 
-template <int PREC, int NPXL>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
+// Epilogue descriptors are staged in LDS and read back through readfirstlane: every field lands in an SGPR, every
+// branch on it is a scalar branch, and the pointers are known GLOBAL (address space 1) so the compiler neither
+// re-loads descriptor fields after each store (aliasing) nor falls back to flat accesses.
+#define GLOBAL_AS __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ GLOBAL_AS T *gptr(uint64_t v) { return (GLOBAL_AS T *)v; }
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gload4(const GLOBAL_AS float *p) {
+  const f32x4v v = *reinterpret_cast<const GLOBAL_AS f32x4v *>(p);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ float4 gload4(const GLOBAL_AS _Float16 *p) {
+  const f16x4 h = *reinterpret_cast<const GLOBAL_AS f16x4 *>(p);
+  return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+__device__ __forceinline__ void gstore4(GLOBAL_AS float *p, float4 v) {
+  f32x4v o; o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  *reinterpret_cast<GLOBAL_AS f32x4v *>(p) = o;
+}
+__device__ __forceinline__ void gstore4(GLOBAL_AS _Float16 *p, float4 v) {
+  f16x4 h;
+  h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+  *reinterpret_cast<GLOBAL_AS f16x4 *>(p) = h;
+}
+
+template <typename T> __device__ __forceinline__ float4 load4(const T *p);
+template <> __device__ __forceinline__ float4 load4<float>(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+template <> __device__ __forceinline__ float4 load4<_Float16>(const _Float16 *p) {
+  const f16x4 h = *reinterpret_cast<const f16x4 *>(p);
+  return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+template <typename T> __device__ __forceinline__ void store4(T *p, float4 v);
+template <> __device__ __forceinline__ void store4<float>(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+template <> __device__ __forceinline__ void store4<_Float16>(_Float16 *p, float4 v) {
+  f16x4 h;
+  h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+  *reinterpret_cast<f16x4 *>(p) = h;
+}
+
+// CBW = 32-channel output blocks per wave; the workgroup tile is 256 rows x (32*CBW) channels: the four waves
+// split the rows (64 each) and share the W panel, so every X element fetched from L2/HBM feeds 32*CBW MACs.
+template <int PREC, int NPXL, int CBW>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
   using T = typename TileT<PREC>::T;
   constexpr int LDK = TileT<PREC>::LDK;
+  constexpr int EPL = TileT<PREC>::EPL;   // elements per 16-byte load
+  constexpr int TPR = BK / EPL;           // threads per tile row
+  constexpr int RPP = 256 / TPR;          // rows per pass
+  constexpr int TN = 32 * CBW;
+  constexpr int XP = TM / RPP, WP = TN / RPP;
   constexpr int NPX = 1 << NPXL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T *const sbase = reinterpret_cast<T *>(smem_raw);
   constexpr int STAGE = (TM + TN) * LDK;
 
-  const int ntc = (a.n_cob + 1) >> 1;
+  const int ntc = (a.n_cob + CBW - 1) / CBW;
   const int ntr = (a.rows + TM - 1) / TM;
   // XCD-aware mapping: workgroup id % 8 picks the XCD (observed dispatch rule); all channel tiles of one
   // row tile share that XCD's L2, so the X panel is fetched from HBM once.
   const int xcd = blockIdx.x & 7, q0 = blockIdx.x >> 3;
   const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;
   if (tr >= ntr) return;
-  const int row0 = tr * TM, cob0 = tc * 2;
+  const int row0 = tr * TM, cob0 = tc * CBW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
+  const T *X = reinterpret_cast<const T *>(a.X);
+  const T *W = reinterpret_cast<const T *>(a.W);
 
-  f32x16 acc[2][2];
+  f32x16 acc[CBW][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < CBW; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 xr[8];
-  float4 wr[2];  // fp32: two float4 ; fp16: wr[0] reinterpreted as 8 halfs
-  const int xr_row = tid >> 3, xr_c = (tid & 7) * 4;
+  float4 xr[XP], wr[WP];  // raw 16-byte pieces in flight
+  const int l_row = tid / TPR, l_c = (tid % TPR) * EPL;
 
   auto load_chunk = [&](int kc) {
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int grow = row0 + p * 32 + xr_row;
+    for (int p = 0; p < XP; ++p) {
+      const int grow = row0 + p * RPP + l_row;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (grow < a.rows) {
-        v = *reinterpret_cast<const float4 *>(a.X + (size_t)grow * a.x_ld + kc * BK + xr_c);
-        if (a.in_scale) {
-          const size_t o = (size_t)(grow >> NPXL) * a.in_bs + kc * BK + xr_c;
-          const float4 sc = *reinterpret_cast<const float4 *>(a.in_scale + o);
-          const float4 sh = *reinterpret_cast<const float4 *>(a.in_shift + o);
-          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        v = *reinterpret_cast<const float4 *>(X + (size_t)grow * a.x_ld + kc * BK + l_c);
+        if (a.in_scale) {  // consumer-side GroupNorm affine (only the attention weight_conv.2 GEMMs)
+          const size_t o = (size_t)(grow >> NPXL) * a.in_bs + kc * BK + l_c;
+          if (PREC == SLIDE_PREC_F32) {
+            const float4 sc = *reinterpret_cast<const float4 *>(a.in_scale + o);
+            const float4 sh = *reinterpret_cast<const float4 *>(a.in_shift + o);
+            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+          } else {
+            f16x8 h = *reinterpret_cast<f16x8 *>(&v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = (_Float16)((float)h[j] * a.in_scale[o + j] + a.in_shift[o + j]);
+            v = *reinterpret_cast<float4 *>(&h);
+          }
         }
       }
       xr[p] = v;
     }
-    if (PREC == SLIDE_PREC_F32) {
-      const float *W = reinterpret_cast<const float *>(a.W);
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int gco = cob0 * 32 + p * 32 + xr_row;
-        wr[p] = gco < a.n_cob * 32
-                    ? *reinterpret_cast<const float4 *>(W + (size_t)gco * a.k_pad + kc * BK + xr_c)
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    } else {
-      const _Float16 *W = reinterpret_cast<const _Float16 *>(a.W);
-      const int gco = cob0 * 32 + (tid >> 2);
-      wr[0] = gco < a.n_cob * 32
-                  ? *reinterpret_cast<const float4 *>(W + (size_t)gco * a.k_pad + kc * BK + (tid & 3) * 8)
-                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < WP; ++p) {
+      const int gco = cob0 * 32 + p * RPP + l_row;
+      wr[p] = gco < a.n_cob * 32 ? *reinterpret_cast<const float4 *>(W + (size_t)gco * a.k_pad + kc * BK + l_c)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto store_chunk = [&](int s) {
     T *Xs = sbase + s * STAGE;
     T *Ws = Xs + TM * LDK;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int r = p * 32 + xr_row;
-      if (PREC == SLIDE_PREC_F32) {
-        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(Xs) + r * LDK + xr_c) = xr[p];
-      } else {
-        f16x4 h;
-        h[0] = (_Float16)xr[p].x; h[1] = (_Float16)xr[p].y; h[2] = (_Float16)xr[p].z; h[3] = (_Float16)xr[p].w;
-        *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(Xs) + r * LDK + xr_c) = h;
-      }
-    }
-    if (PREC == SLIDE_PREC_F32) {
+    for (int p = 0; p < XP; ++p) *reinterpret_cast<float4 *>(Xs + (p * RPP + l_row) * LDK + l_c) = xr[p];
 #pragma unroll
-      for (int p = 0; p < 2; ++p)
-        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(Ws) + (p * 32 + xr_row) * LDK + xr_c) = wr[p];
-    } else {
-      *reinterpret_cast<float4 *>(reinterpret_cast<_Float16 *>(Ws) + (tid >> 2) * LDK + (tid & 3) * 8) = wr[0];
-    }
+    for (int p = 0; p < WP; ++p) *reinterpret_cast<float4 *>(Ws + (p * RPP + l_row) * LDK + l_c) = wr[p];
   };
   auto compute = [&](int s) {
     const T *Xs = sbase + s * STAGE;
@@ -144,15 +177,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
       const float *Wf = reinterpret_cast<const float *>(Ws);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float4 af[2], bf[2];
+        float4 af[CBW], bf[2];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < CBW; ++cb)
           af[cb] = *reinterpret_cast<const float4 *>(Wf + (cb * 32 + col) * LDK + q * 8 + half * 4);
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
           bf[rb] = *reinterpret_cast<const float4 *>(Xf + (wave * 64 + rb * 32 + col) * LDK + q * 8 + half * 4);
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
           for (int rb = 0; rb < 2; ++rb) {
             acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb].x, bf[rb].x, acc[cb][rb], 0, 0, 0);
@@ -166,21 +199,41 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
       const _Float16 *Wh = reinterpret_cast<const _Float16 *>(Ws);
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
-        f16x8 af[2], bf[2];
+        f16x8 af[CBW], bf[2];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < CBW; ++cb)
           af[cb] = *reinterpret_cast<const f16x8 *>(Wh + (cb * 32 + col) * LDK + st * 16 + half * 8);
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
           bf[rb] = *reinterpret_cast<const f16x8 *>(Xh + (wave * 64 + rb * 32 + col) * LDK + st * 16 + half * 8);
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
           for (int rb = 0; rb < 2; ++rb)
             acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb], bf[rb], acc[cb][rb], 0, 0, 0);
       }
     }
   };
+
+  constexpr int EPI_DW = (int)(sizeof(SlideEpi) / 4);
+  static_assert(sizeof(SlideEpi) == 136, "descriptor layout is read by dword index below");
+  uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + 2 * (size_t)STAGE * sizeof(T));
+  for (int i = tid; i < CBW * EPI_DW; i += 256) {
+    const int cobi = cob0 + i / EPI_DW;
+    epi_lds[i] = cobi < a.n_cob ? reinterpret_cast<const uint32_t *>(a.epi + cobi)[i % EPI_DW] : 0u;
+  }
+  // ... and the per-channel epilogue vectors [cb][bias | gamma | beta][32]
+  float *const vec_lds = reinterpret_cast<float *>(epi_lds + CBW * EPI_DW + (CBW * EPI_DW) % 4);
+  for (int i = tid; i < CBW * 96; i += 256) {
+    const int cobi = cob0 + i / 96, which = (i % 96) >> 5, c = i & 31;
+    float val = 0.f;
+    if (cobi < a.n_cob) {
+      const SlideEpi *ed = a.epi + cobi;
+      const float *src = which == 0 ? ed->bias : (which == 1 ? ed->gamma : ed->beta);
+      if (src) val = src[c];
+    }
+    vec_lds[i] = val;
+  }
 
   const int nk = a.k_pad / BK;
   load_chunk(0);
@@ -194,122 +247,148 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
   }
 
   // ------------------------------------------------------------------------------------------ epilogue
-  float *red = reinterpret_cast<float *>(smem_raw);  // [wave 4][cb 2][half 2][r 16][2]   (tiles are dead now)
+  float *red = reinterpret_cast<float *>(smem_raw);  // [wave 4][cb CBW][half 2][r 16][2]   (tiles are dead now)
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
+  for (int cb = 0; cb < CBW; ++cb) {
     const int cobi = cob0 + cb;
     if (cobi >= a.n_cob) continue;  // uniform per workgroup
-    const SlideEpi *e = a.epi + cobi;
-    const int mode = e->mode, flags = e->flags;
+    auto rd = [&](int k) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)epi_lds[cb * EPI_DW + k]); };
+    auto rdp = [&](int k) { return (uint64_t)rd(k) | ((uint64_t)rd(k + 1) << 32); };
+    const int mode = (int)rd(0), flags = (int)rd(1), e_gs = (int)rd(2), e_n_norm = (int)rd(3);
+    const float e_inv_count = __uint_as_float(rd(4)), e_stats_scale = __uint_as_float(rd(5));
+    const int e_out_ld = (int)rd(6), e_res_ld = (int)rd(7), e_addvec_bs = (int)rd(8), e_stats_bs = (int)rd(9),
+              e_pre_ld = (int)rd(10), e_pre_shift = (int)rd(11), e_idx_stride = (int)rd(12);
+    const GLOBAL_AS float *e_addvec = gptr<const float>(rdp(20));
+    const float *v_bias = vec_lds + cb * 96, *v_gamma = v_bias + 32, *v_beta = v_bias + 64;
+    const GLOBAL_AS int *e_addvec_idx = gptr<const int>(rdp(22));
+    const GLOBAL_AS T *resid = gptr<const T>(rdp(24)), *pre = gptr<const T>(rdp(26));
+    const uint64_t e_out = rdp(28);
+    GLOBAL_AS float *e_stats_sum = gptr<float>(rdp(30)), *e_stats_sq = gptr<float>(rdp(32));
     float v[2][16];
+    {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float bia = e->bias ? e->bias[c] : 0.f;
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = 8 * q + 4 * half;
+        const float4 bia = *reinterpret_cast<const float4 *>(v_bias + c0);
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        float t = acc[cb][rb][r] + bia;
-        if (flags & SLIDE_F_PRE_RELU) t = fmaxf(t, 0.f);
-        v[rb][r] = t;
+        for (int rb = 0; rb < 2; ++rb) {
+          float4 t = make_float4(acc[cb][rb][4 * q] + bia.x, acc[cb][rb][4 * q + 1] + bia.y,
+                                 acc[cb][rb][4 * q + 2] + bia.z, acc[cb][rb][4 * q + 3] + bia.w);
+          if (pre) {  // per-point term shared by the K neighbours of a point (query half of attention weight_conv.2)
+            const int row = row0 + wave * 64 + rb * 32 + col;
+            if (row < a.rows) {
+              const float4 u = gload4(pre + (size_t)(row >> e_pre_shift) * e_pre_ld + c0);
+              t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+          }
+          if (flags & SLIDE_F_PRE_RELU) {
+            t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
+          }
+          v[rb][4 * q] = t.x; v[rb][4 * q + 1] = t.y; v[rb][4 * q + 2] = t.z; v[rb][4 * q + 3] = t.w;
+        }
       }
     }
-    if (mode != SLIDE_EPI_RAW) {
-      // NSCOPE = number of independent sample scopes per wave (NPX=16: one per row block)
-      constexpr int NSCOPE = (NPXL >= 6) ? 1 : 2;
+    // NSCOPE = number of independent sample scopes per wave (NPX=16: one per 32-row block, two samples each)
+    constexpr int NSCOPE = (NPXL >= 6) ? 1 : 2;
+    constexpr int LG = NPX < 32 ? NPX : 32;  // lanes (rows) of one sample inside a row block
+    constexpr int WPS = NPX / 64;            // waves per sample when a sample spans waves (2 or 4)
+    // sums `NV` per-lane partials over the rows of the lane's sample: lanes -> (row blocks) -> waves via LDS
+    auto reduce_rows = [&](auto nv_tag, float *s, float *ss) {
+      constexpr int NV = decltype(nv_tag)::value;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        s[i] = lane_group_sum<LG>(s[i]);
+        ss[i] = lane_group_sum<LG>(ss[i]);
+      }
+      if (NPXL >= 7) {  // fixed summation order -> deterministic
+        if (col == 0) {
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            red[(((wave * CBW + cb) * 2 + half) * 16 + i) * 2 + 0] = s[i];
+            red[(((wave * CBW + cb) * 2 + half) * 16 + i) * 2 + 1] = ss[i];
+          }
+        }
+        __syncthreads();
+        const int w0 = (wave / (WPS > 0 ? WPS : 1)) * (WPS > 0 ? WPS : 1);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+          for (int w = 0; w < (WPS > 0 ? WPS : 1); ++w) {
+            t0 += red[((((w0 + w) * CBW + cb) * 2 + half) * 16 + i) * 2 + 0];
+            t1 += red[((((w0 + w) * CBW + cb) * 2 + half) * 16 + i) * 2 + 1];
+          }
+          s[i] = t0; ss[i] = t1;
+        }
+      }
+    };
+    if (mode == SLIDE_EPI_STATS) {
 #pragma unroll
       for (int sc = 0; sc < NSCOPE; ++sc) {
         float s[16], ss[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          if (NSCOPE == 1) {
-            s[r] = v[0][r] + v[1][r];
-            ss[r] = v[0][r] * v[0][r] + v[1][r] * v[1][r];
-            s[r] = lane_group_sum<32>(s[r]);
-            ss[r] = lane_group_sum<32>(ss[r]);
-          } else {
-            s[r] = lane_group_sum<(NPX < 32 ? NPX : 32)>(v[sc][r]);
-            ss[r] = lane_group_sum<(NPX < 32 ? NPX : 32)>(v[sc][r] * v[sc][r]);
-          }
+          if (NSCOPE == 1) { s[r] = v[0][r] + v[1][r]; ss[r] = v[0][r] * v[0][r] + v[1][r] * v[1][r]; }
+          else { s[r] = v[sc][r]; ss[r] = v[sc][r] * v[sc][r]; }
         }
-        if (NPXL >= 7) {  // the sample spans several waves: exchange through LDS (fixed order -> deterministic)
-          constexpr int WPS = NPX / 64;  // waves per sample (2 or 4)
-          if (col == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              red[(((wave * 2 + cb) * 2 + half) * 16 + r) * 2 + 0] = s[r];
-              red[(((wave * 2 + cb) * 2 + half) * 16 + r) * 2 + 1] = ss[r];
-            }
-          }
-          __syncthreads();
-          const int w0 = (wave / WPS) * WPS;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float t0 = 0.f, t1 = 0.f;
-#pragma unroll
-            for (int w = 0; w < WPS; ++w) {
-              t0 += red[((((w0 + w) * 2 + cb) * 2 + half) * 16 + r) * 2 + 0];
-              t1 += red[((((w0 + w) * 2 + cb) * 2 + half) * 16 + r) * 2 + 1];
-            }
-            s[r] = t0; ss[r] = t1;
-          }
-        }
-        if (mode == SLIDE_EPI_STATS) {
-          const int rb_w = (NSCOPE == 1) ? 0 : sc;
-          const int row = row0 + wave * 64 + rb_w * 32 + col;
-          const bool writer = (NPXL >= 7) ? ((wave % (NPX / 64)) == 0 && col == 0)
-                                          : ((col & ((NPX < 32 ? NPX : 32) - 1)) == 0);
-          if (writer && row < a.rows) {
-            const size_t b = (size_t)(row >> NPXL);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
-              e->stats_sum[b * e->stats_bs + c] = s[r] * e->stats_scale;
-              e->stats_sq[b * e->stats_bs + c] = ss[r] * e->stats_scale;
-            }
-          }
-        } else {  // SLIDE_EPI_NORM: channel sums -> group sums (groups of gs physical channels, gs | 32)
-          const int gs = e->gs;
-          float gsum[16], gsq[16];
-          if (gs == 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { gsum[r] = s[r]; gsq[r] = ss[r]; }
-          } else if (gs == 2) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { gsum[r] = s[r] + s[r ^ 1]; gsq[r] = ss[r] + ss[r ^ 1]; }
-          } else {
-            float Q[4], QQ[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              Q[q] = (s[4 * q] + s[4 * q + 1]) + (s[4 * q + 2] + s[4 * q + 3]);
-              QQ[q] = (ss[4 * q] + ss[4 * q + 1]) + (ss[4 * q + 2] + ss[4 * q + 3]);
-            }
-            if (gs >= 8) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                Q[q] += __shfl_xor(Q[q], 32);
-                QQ[q] += __shfl_xor(QQ[q], 32);
-              }
-            }
-            if (gs == 16) {
-              const float p0 = Q[0] + Q[1], p1 = Q[2] + Q[3], pp0 = QQ[0] + QQ[1], pp1 = QQ[2] + QQ[3];
-              Q[0] = Q[1] = p0; Q[2] = Q[3] = p1; QQ[0] = QQ[1] = pp0; QQ[2] = QQ[3] = pp1;
-            } else if (gs == 32) {
-              const float p = (Q[0] + Q[1]) + (Q[2] + Q[3]), pp = (QQ[0] + QQ[1]) + (QQ[2] + QQ[3]);
-              Q[0] = Q[1] = Q[2] = Q[3] = p; QQ[0] = QQ[1] = QQ[2] = QQ[3] = pp;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { gsum[r] = Q[r >> 2]; gsq[r] = QQ[r >> 2]; }
-          }
-          const float inv_count = e->inv_count;
-          const int n_norm = e->n_norm;
+        reduce_rows(std::integral_constant<int, 16>(), s, ss);
+        const int row = row0 + wave * 64 + ((NSCOPE == 1) ? 0 : sc) * 32 + col;
+        const bool writer = (NPXL >= 7) ? ((wave % (WPS > 0 ? WPS : 1)) == 0 && col == 0) : ((col & (LG - 1)) == 0);
+        if (writer && row < a.rows) {
+          const size_t b = (size_t)(row >> NPXL);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (c < n_norm) {
-              const float mean = gsum[r] * inv_count;
-              const float var = fmaxf(gsq[r] * inv_count - mean * mean, 0.f);
-              const float rstd = 1.0f / sqrtf(var + GN_EPS);
-              const float g = e->gamma[c] * rstd, bt = e->beta[c] - mean * g;
+            e_stats_sum[b * e_stats_bs + c] = s[r] * e_stats_scale;
+            e_stats_sq[b * e_stats_bs + c] = ss[r] * e_stats_scale;
+          }
+        }
+      }
+    } else if (mode == SLIDE_EPI_NORM) {
+      // GroupNorm: groups of gs PHYSICAL channels (gs | 32).  Fold the lane's 16 channels into its groups BEFORE the
+      // cross-lane reduction: SH = log2(channels of one group held by this lane) -> 16 >> SH values to reduce.
+      auto norm_path = [&](auto sh_tag) {
+        constexpr int SH = decltype(sh_tag)::value;
+        constexpr int NV = 16 >> SH;
+#pragma unroll
+        for (int sc = 0; sc < NSCOPE; ++sc) {
+          float s[NV], ss[NV];
+#pragma unroll
+          for (int i = 0; i < NV; ++i) { s[i] = 0.f; ss[i] = 0.f; }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (NSCOPE == 1) {
+              s[r >> SH] += v[0][r] + v[1][r];
+              ss[r >> SH] += v[0][r] * v[0][r] + v[1][r] * v[1][r];
+            } else {
+              s[r >> SH] += v[sc][r];
+              ss[r >> SH] += v[sc][r] * v[sc][r];
+            }
+          }
+          reduce_rows(std::integral_constant<int, NV>(), s, ss);
+          if (SH == 2 && e_gs >= 8) {  // groups wider than a lane's quad: both lane halves, then quads
+#pragma unroll
+            for (int i = 0; i < NV; ++i) { s[i] += __shfl_xor(s[i], 32); ss[i] += __shfl_xor(ss[i], 32); }
+            if (e_gs == 16) {
+              const float p0 = s[0] + s[1], p1 = s[2] + s[3], q0_ = ss[0] + ss[1], q1_ = ss[2] + ss[3];
+              s[0] = s[1] = p0; s[2] = s[3] = p1; ss[0] = ss[1] = q0_; ss[2] = ss[3] = q1_;
+            } else if (e_gs == 32) {
+              const float p = (s[0] + s[1]) + (s[2] + s[3]), q_ = (ss[0] + ss[1]) + (ss[2] + ss[3]);
+              s[0] = s[1] = s[2] = s[3] = p; ss[0] = ss[1] = ss[2] = ss[3] = q_;
+            }
+          }
+          float mean[NV], rstd[NV];
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            mean[i] = s[i] * e_inv_count;
+            const float var = fmaxf(ss[i] * e_inv_count - mean[i] * mean[i], 0.f);
+            rstd[i] = __builtin_amdgcn_rsqf(var + GN_EPS);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (c < e_n_norm) {
+              const float g = v_gamma[c] * rstd[r >> SH], bt = v_beta[c] - mean[r >> SH] * g;
               if (NSCOPE == 1) {
                 v[0][r] = v[0][r] * g + bt;
                 v[1][r] = v[1][r] * g + bt;
@@ -319,9 +398,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
             }
           }
         }
-      }
+      };
+      if (e_gs >= 4) norm_path(std::integral_constant<int, 2>());
+      else if (e_gs == 2) norm_path(std::integral_constant<int, 1>());
+      else norm_path(std::integral_constant<int, 0>());
     }
-    // store: 4 consecutive channels per lane and quad -> 16-byte stores
+    // store: 4 consecutive channels per lane and quad -> 16-byte (fp32) / 8-byte (fp16) channel-minor stores
+    const GLOBAL_AS float *addv = e_addvec;
+    if (addv && e_addvec_idx) addv += (size_t)e_addvec_idx[0] * e_idx_stride;  // row t of a per-timestep table
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
       const int row = row0 + wave * 64 + rb * 32 + col;
@@ -334,17 +418,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         if (flags & SLIDE_F_POST_RELU) {
           y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
         }
-        if (e->addvec) {
-          const float4 t = *reinterpret_cast<const float4 *>(e->addvec + b * e->addvec_bs + c0);
+        if (addv) {
+          const float4 t = gload4(addv + b * e_addvec_bs + c0);
           y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
         }
-        if (e->residual) {
-          const float4 t = *reinterpret_cast<const float4 *>(e->residual + (size_t)row * e->res_ld + c0);
+        if (resid) {
+          const float4 t = gload4(resid + (size_t)row * e_res_ld + c0);
           y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
         }
-        const int bc = e->out_bcast;
-        for (int k = 0; k < bc; ++k)
-          *reinterpret_cast<float4 *>(e->out + ((size_t)row * bc + k) * e->out_ld + c0) = y;
+        if (flags & SLIDE_F_OUT_F32)
+          gstore4(gptr<float>(e_out) + (size_t)row * e_out_ld + c0, y);
+        else
+          gstore4(gptr<T>(e_out) + (size_t)row * e_out_ld + c0, y);
       }
     }
   }
@@ -361,8 +446,9 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
 // pointnet2_with_pcld_condition.py:332-346) and build the full 16x16 neighbour table sorted by
 // (squared distance, index) -- the K=16 and K=8 queries of every SA / FP level are prefixes of it
 // (knn_points semantics, oracle/ops_cpu.c ora_knn_points).
+template <typename T>
 __global__ __launch_bounds__(256) void prep_points_kernel(int cx, int ldf, const float *__restrict__ x,
-                                                          float *__restrict__ xyz, float *__restrict__ feat0,
+                                                          float *__restrict__ xyz, T *__restrict__ feat0,
                                                           int *__restrict__ kidx, float *__restrict__ kd2) {
   __shared__ float sp[48];
   __shared__ float sd[16][17];
@@ -376,7 +462,7 @@ __global__ __launch_bounds__(256) void prep_points_kernel(int cx, int ldf, const
   const int nf = cx - 3;
   for (int e = tid; e < 16 * cx; e += 256) {
     const int p = e / cx, c = e % cx;
-    feat0[((size_t)b * 16 + p) * ldf + c] = c < nf ? xb[p * cx + 3 + c] : xb[p * cx + (c - nf)];
+    feat0[((size_t)b * 16 + p) * ldf + c] = (T)(c < nf ? xb[p * cx + 3 + c] : xb[p * cx + (c - nf)]);
   }
   __syncthreads();
   const int i = tid >> 4, j = tid & 15;
@@ -395,9 +481,10 @@ __global__ __launch_bounds__(256) void prep_points_kernel(int cx, int ldf, const
 
 // QueryAndGroup feature assembly ('nn', use_xyz, abs + center coordinates; pointnet2_utils.py:383-430):
 // g[b][p*K+k][:] = [feat[nbr][0:C], xyz[nbr]-xyz[p], xyz[nbr], xyz[p], 0-pad]
+template <typename T>
 __global__ __launch_bounds__(256) void assemble_sa_kernel(int C, int ldf, int ldg, int K,
-                                                          const float *__restrict__ xyz, const float *__restrict__ feat,
-                                                          const int *__restrict__ kidx, float *__restrict__ g) {
+                                                          const float *__restrict__ xyz, const T *__restrict__ feat,
+                                                          const int *__restrict__ kidx, T *__restrict__ g) {
 #pragma clang fp contract(off)
   const int b = blockIdx.x;
   const int npx = 16 * K;
@@ -407,20 +494,21 @@ __global__ __launch_bounds__(256) void assemble_sa_kernel(int C, int ldf, int ld
     const int p = pxl / K, k = pxl - p * K;
     const int nb = kidx[((size_t)b * 16 + p) * 16 + k];
     float v = 0.f;
-    if (c < C) v = feat[((size_t)b * 16 + nb) * ldf + c];
+    if (c < C) v = (float)feat[((size_t)b * 16 + nb) * ldf + c];
     else if (c < C + 3) v = px[nb * 3 + (c - C)] - px[p * 3 + (c - C)];
     else if (c < C + 6) v = px[nb * 3 + (c - C - 3)];
     else if (c < C + 9) v = px[p * 3 + (c - C - 6)];
-    g[((size_t)b * npx + pxl) * ldg + c] = v;
+    g[((size_t)b * npx + pxl) * ldg + c] = (T)v;
   }
 }
 
 // group_knn feature assembly (pointnet2_utils.py:497-524):
 // g[b][p*K+k][:] = [feat[nbr][0:C], d2, w, xyz[nbr], xyz[nbr]-xyz[p], xyz[p], 0-pad], w from squared distances
+template <typename T>
 __global__ __launch_bounds__(256) void assemble_fp_kernel(int C, int ldf, int ldg, int K,
-                                                          const float *__restrict__ xyz, const float *__restrict__ feat,
+                                                          const float *__restrict__ xyz, const T *__restrict__ feat,
                                                           const int *__restrict__ kidx, const float *__restrict__ kd2,
-                                                          float *__restrict__ g) {
+                                                          T *__restrict__ g) {
 #pragma clang fp contract(off)
   const int b = blockIdx.x;
   const int npx = 16 * K;
@@ -431,7 +519,7 @@ __global__ __launch_bounds__(256) void assemble_fp_kernel(int C, int ldf, int ld
     const size_t o = ((size_t)b * 16 + p) * 16;
     const int nb = kidx[o + k];
     float v = 0.f;
-    if (c < C) v = feat[((size_t)b * 16 + nb) * ldf + c];
+    if (c < C) v = (float)feat[((size_t)b * 16 + nb) * ldf + c];
     else if (c == C) v = kd2[o + k];
     else if (c == C + 1) {
       float norm = 0.f;
@@ -440,7 +528,7 @@ __global__ __launch_bounds__(256) void assemble_fp_kernel(int C, int ldf, int ld
     } else if (c < C + 5) v = px[nb * 3 + (c - C - 2)];
     else if (c < C + 8) v = px[nb * 3 + (c - C - 5)] - px[p * 3 + (c - C - 5)];
     else if (c < C + 11) v = px[p * 3 + (c - C - 8)];
-    g[((size_t)b * npx + pxl) * ldg + c] = v;
+    g[((size_t)b * npx + pxl) * ldg + c] = (T)v;
   }
 }
 
@@ -474,10 +562,10 @@ __global__ __launch_bounds__(256) void finalize_gn_kernel(int B, int C, int bs, 
 }
 
 // out[bp][c] = sum_k softmax_k(S[bp*K+k][c]) * V[bp*K+k][c]     (attention.py:90-95, mask == all ones)
-template <int K>
+template <int K, typename T>
 __global__ __launch_bounds__(256) void attn_combine_kernel(int nbp, int C, int ldS, int ldV, int ldo,
-                                                           const float *__restrict__ S, const float *__restrict__ V,
-                                                           float *__restrict__ out) {
+                                                           const T *__restrict__ S, const T *__restrict__ V,
+                                                           T *__restrict__ out) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= nbp * C) return;
   const int bp = e / C, c = e - bp * C;
@@ -485,7 +573,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(int nbp, int C, int l
   float m = -INFINITY;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    s[k] = S[((size_t)bp * K + k) * ldS + c];
+    s[k] = (float)S[((size_t)bp * K + k) * ldS + c];
     m = fmaxf(m, s[k]);
   }
   float den = 0.f;
@@ -495,17 +583,19 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(int nbp, int C, int l
     den += s[k];
   }
   float o = 0.f;
+  const float inv = 1.0f / den;
 #pragma unroll
-  for (int k = 0; k < K; ++k) o += V[((size_t)bp * K + k) * ldV + c] * (s[k] / den);
-  out[(size_t)bp * ldo + c] = o;
+  for (int k = 0; k < K; ++k) o += (float)V[((size_t)bp * K + k) * ldV + c] * (s[k] * inv);
+  out[(size_t)bp * ldo + c] = (T)o;
 }
 
+template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void copy_cols_kernel(int rows, int n, int src_ld, int dst_ld,
-                                                        const float *__restrict__ src, float *__restrict__ dst) {
+                                                        const TS *__restrict__ src, TD *__restrict__ dst) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= rows * n) return;
   const int r = e / n, c = e - r * n;
-  dst[(size_t)r * dst_ld + c] = src[(size_t)r * src_ld + c];
+  dst[(size_t)r * dst_ld + c] = (TD)(float)src[(size_t)r * src_ld + c];
 }
 
 __device__ __forceinline__ float swishf(float x) { return x * (1.0f / (1.0f + expf(-x))); }
@@ -532,23 +622,23 @@ __global__ __launch_bounds__(256) void temb_kernel(int t_dim, int n_out, const f
     emb[hd + k] = cosf(arg);
   }
   __syncthreads();
-  for (int j = tid; j < H; j += 256) {
-    float acc = b1[j];
-    for (int k = 0; k < t_dim; ++k) acc += emb[k] * w1[(size_t)k * H + j];
-    h1[j] = swishf(acc);
-  }
+  // input-major weights: lanes read consecutive outputs; 8 loads in flight per thread (the dims are multiples of 8)
+  auto gemv = [&](const float *__restrict__ in, int n_in, const float *__restrict__ w, int n_o, int j) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int k = 0; k < n_in; k += 8) {
+      const float w0 = w[(size_t)(k + 0) * n_o + j], w1_ = w[(size_t)(k + 1) * n_o + j], w2_ = w[(size_t)(k + 2) * n_o + j],
+                  w3 = w[(size_t)(k + 3) * n_o + j], w4 = w[(size_t)(k + 4) * n_o + j], w5 = w[(size_t)(k + 5) * n_o + j],
+                  w6 = w[(size_t)(k + 6) * n_o + j], w7 = w[(size_t)(k + 7) * n_o + j];
+      a0 += in[k] * w0; a1 += in[k + 1] * w1_; a2 += in[k + 2] * w2_; a3 += in[k + 3] * w3;
+      a0 += in[k + 4] * w4; a1 += in[k + 5] * w5; a2 += in[k + 6] * w6; a3 += in[k + 7] * w7;
+    }
+    return (a0 + a1) + (a2 + a3);
+  };
+  for (int j = tid; j < H; j += 256) h1[j] = swishf(b1[j] + gemv(emb, t_dim, w1, H, j));
   __syncthreads();
-  for (int j = tid; j < H; j += 256) {
-    float acc = b2[j];
-    for (int k = 0; k < H; ++k) acc += h1[k] * w2[(size_t)k * H + j];
-    h2[j] = swishf(acc);
-  }
+  for (int j = tid; j < H; j += 256) h2[j] = swishf(b2[j] + gemv(h1, H, w2, H, j));
   __syncthreads();
-  for (int j = tid; j < n_out; j += 256) {
-    float acc = bfc[j];
-    for (int k = 0; k < H; ++k) acc += h2[k] * wfc[(size_t)k * n_out + j];
-    out[(size_t)b * n_out + j] = acc;
-  }
+  for (int j = tid; j < n_out; j += 256) out[(size_t)b * n_out + j] = bfc[j] + gemv(h2, H, wfc, n_out, j);
 }
 
 // class embedding lookup (pointnet2_with_pcld_condition.py:363-365) + every Mlp_plus_t_emb.fc_condition
@@ -643,32 +733,33 @@ __global__ void advance_t_kernel(int *t_dev) {
   }
 }
 
-template <int PREC, int NPXL>
+template <int PREC, int NPXL, int CBW>
 int launch_gemm(const GemmArgs &a, hipStream_t s) {
   constexpr int LDK = TileT<PREC>::LDK;
-  const size_t shm = 2 * (size_t)(TM + TN) * LDK * sizeof(typename TileT<PREC>::T);
-  const int ntc = (a.n_cob + 1) >> 1, ntr = (a.rows + TM - 1) / TM;
+  const size_t shm = 2 * (size_t)(TM + 32 * CBW) * LDK * sizeof(typename TileT<PREC>::T) + CBW * (sizeof(SlideEpi) + 96 * 4) + 16;
+  const int ntc = (a.n_cob + CBW - 1) / CBW, ntr = (a.rows + TM - 1) / TM;
   const int grid = ((ntr + 7) / 8) * 8 * ntc;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<PREC, NPXL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<PREC, NPXL, CBW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<PREC, NPXL>), dim3(grid), dim3(256), shm, s, a);
+  hipLaunchKernelGGL((gemm_kernel<PREC, NPXL, CBW>), dim3(grid), dim3(256), shm, s, a);
   return (int)hipGetLastError();
 }
 
 int run_gemm(const SlideOp &o, hipStream_t s) {
   GemmArgs a;
-  a.X = (const float *)o.p[0]; a.W = o.p[1]; a.epi = (const SlideEpi *)o.p[2];
+  a.X = o.p[0]; a.W = o.p[1]; a.epi = (const SlideEpi *)o.p[2];
   a.in_scale = (const float *)o.p[3]; a.in_shift = (const float *)o.p[4];
   a.rows = o.i[0]; a.x_ld = o.i[1]; a.k_pad = o.i[2]; a.n_cob = o.i[3]; a.in_bs = o.i[5];
-  const int npxl = o.i[4], prec = o.i[6];
-  if (a.k_pad % BK || a.x_ld % 4 || a.rows <= 0 || a.n_cob <= 0) return -3;
-#define CASE(P, L) if (prec == P && npxl == L) return launch_gemm<P, L>(a, s)
-  CASE(SLIDE_PREC_F32, 4); CASE(SLIDE_PREC_F32, 7); CASE(SLIDE_PREC_F32, 8);
-  CASE(SLIDE_PREC_F16, 4); CASE(SLIDE_PREC_F16, 7); CASE(SLIDE_PREC_F16, 8);
+  const int npxl = o.i[4], prec = o.i[6], cbw = o.i[7];
+  if (a.k_pad % BK || a.x_ld % 8 || a.rows <= 0 || a.n_cob <= 0) return -3;
+#define CASE(P, L, C) if (prec == P && npxl == L && cbw == C) return launch_gemm<P, L, C>(a, s)
+  CASE(SLIDE_PREC_F32, 4, 2); CASE(SLIDE_PREC_F32, 7, 2); CASE(SLIDE_PREC_F32, 8, 2);
+  CASE(SLIDE_PREC_F16, 4, 2); CASE(SLIDE_PREC_F16, 7, 2); CASE(SLIDE_PREC_F16, 8, 2);
+  CASE(SLIDE_PREC_F16, 4, 4); CASE(SLIDE_PREC_F16, 7, 4); CASE(SLIDE_PREC_F16, 8, 4);
 #undef CASE
   return -4;
 }
@@ -678,21 +769,35 @@ int run_op(const SlideOp &o, hipStream_t s) {
     case SLIDE_OP_GEMM:
       return run_gemm(o, s);
     case SLIDE_OP_PREP_POINTS:
-      hipLaunchKernelGGL(prep_points_kernel, dim3(o.i[0]), dim3(256), 0, s, o.i[1], o.i[2], (const float *)o.p[0],
-                         (float *)o.p[1], (float *)o.p[2], (int *)o.p[3], (float *)o.p[4]);
+      if (o.i[3] == SLIDE_PREC_F16)
+        hipLaunchKernelGGL(prep_points_kernel<_Float16>, dim3(o.i[0]), dim3(256), 0, s, o.i[1], o.i[2],
+                           (const float *)o.p[0], (float *)o.p[1], (_Float16 *)o.p[2], (int *)o.p[3], (float *)o.p[4]);
+      else
+        hipLaunchKernelGGL(prep_points_kernel<float>, dim3(o.i[0]), dim3(256), 0, s, o.i[1], o.i[2],
+                           (const float *)o.p[0], (float *)o.p[1], (float *)o.p[2], (int *)o.p[3], (float *)o.p[4]);
       break;
     case SLIDE_OP_ASSEMBLE_SA: {
       const int work = 16 * o.i[4] * o.i[3];
-      hipLaunchKernelGGL(assemble_sa_kernel, dim3(o.i[0], (work + 4095) / 4096), dim3(256), 0, s, o.i[1], o.i[2],
-                         o.i[3], o.i[4], (const float *)o.p[0], (const float *)o.p[1], (const int *)o.p[2],
-                         (float *)o.p[3]);
+      if (o.i[5] == SLIDE_PREC_F16)
+        hipLaunchKernelGGL(assemble_sa_kernel<_Float16>, dim3(o.i[0], (work + 4095) / 4096), dim3(256), 0, s, o.i[1],
+                           o.i[2], o.i[3], o.i[4], (const float *)o.p[0], (const _Float16 *)o.p[1], (const int *)o.p[2],
+                           (_Float16 *)o.p[3]);
+      else
+        hipLaunchKernelGGL(assemble_sa_kernel<float>, dim3(o.i[0], (work + 4095) / 4096), dim3(256), 0, s, o.i[1],
+                           o.i[2], o.i[3], o.i[4], (const float *)o.p[0], (const float *)o.p[1], (const int *)o.p[2],
+                           (float *)o.p[3]);
       break;
     }
     case SLIDE_OP_ASSEMBLE_FP: {
       const int work = 16 * o.i[4] * o.i[3];
-      hipLaunchKernelGGL(assemble_fp_kernel, dim3(o.i[0], (work + 4095) / 4096), dim3(256), 0, s, o.i[1], o.i[2],
-                         o.i[3], o.i[4], (const float *)o.p[0], (const float *)o.p[1], (const int *)o.p[2],
-                         (const float *)o.p[3], (float *)o.p[4]);
+      if (o.i[5] == SLIDE_PREC_F16)
+        hipLaunchKernelGGL(assemble_fp_kernel<_Float16>, dim3(o.i[0], (work + 4095) / 4096), dim3(256), 0, s, o.i[1],
+                           o.i[2], o.i[3], o.i[4], (const float *)o.p[0], (const _Float16 *)o.p[1], (const int *)o.p[2],
+                           (const float *)o.p[3], (_Float16 *)o.p[4]);
+      else
+        hipLaunchKernelGGL(assemble_fp_kernel<float>, dim3(o.i[0], (work + 4095) / 4096), dim3(256), 0, s, o.i[1],
+                           o.i[2], o.i[3], o.i[4], (const float *)o.p[0], (const float *)o.p[1], (const int *)o.p[2],
+                           (const float *)o.p[3], (float *)o.p[4]);
       break;
     }
     case SLIDE_OP_FINALIZE_GN:
@@ -703,20 +808,30 @@ int run_op(const SlideOp &o, hipStream_t s) {
       break;
     case SLIDE_OP_ATTN_COMBINE: {
       const int n = o.i[0] * o.i[1];
-      if (o.i[5] == 16)
-        hipLaunchKernelGGL(attn_combine_kernel<16>, dim3((n + 255) / 256), dim3(256), 0, s, o.i[0], o.i[1], o.i[2],
-                           o.i[3], o.i[4], (const float *)o.p[0], (const float *)o.p[1], (float *)o.p[2]);
-      else if (o.i[5] == 8)
-        hipLaunchKernelGGL(attn_combine_kernel<8>, dim3((n + 255) / 256), dim3(256), 0, s, o.i[0], o.i[1], o.i[2],
-                           o.i[3], o.i[4], (const float *)o.p[0], (const float *)o.p[1], (float *)o.p[2]);
-      else
-        return -5;
+      const dim3 g((n + 255) / 256), blk(256);
+#define ATTN(KK, TT)                                                                                              \
+  hipLaunchKernelGGL((attn_combine_kernel<KK, TT>), g, blk, 0, s, o.i[0], o.i[1], o.i[2], o.i[3], o.i[4],         \
+                     (const TT *)o.p[0], (const TT *)o.p[1], (TT *)o.p[2])
+      if (o.i[5] == 16 && o.i[6] == SLIDE_PREC_F16) ATTN(16, _Float16);
+      else if (o.i[5] == 16) ATTN(16, float);
+      else if (o.i[5] == 8 && o.i[6] == SLIDE_PREC_F16) ATTN(8, _Float16);
+      else if (o.i[5] == 8) ATTN(8, float);
+      else return -5;
+#undef ATTN
       break;
     }
-    case SLIDE_OP_COPY_COLS:
-      hipLaunchKernelGGL(copy_cols_kernel, dim3((o.i[0] * o.i[1] + 255) / 256), dim3(256), 0, s, o.i[0], o.i[1],
-                         o.i[2], o.i[3], (const float *)o.p[0], (float *)o.p[1]);
+    case SLIDE_OP_COPY_COLS: {
+      const dim3 g((o.i[0] * o.i[1] + 255) / 256), blk(256);
+#define CPY(TS, TD)                                                                                               \
+  hipLaunchKernelGGL((copy_cols_kernel<TS, TD>), g, blk, 0, s, o.i[0], o.i[1], o.i[2], o.i[3], (const TS *)o.p[0], \
+                     (TD *)o.p[1])
+      if (o.i[4] && o.i[5]) CPY(_Float16, _Float16);
+      else if (o.i[4]) CPY(_Float16, float);
+      else if (o.i[5]) CPY(float, _Float16);
+      else CPY(float, float);
+#undef CPY
       break;
+    }
     case SLIDE_OP_TEMB:
       hipLaunchKernelGGL(temb_kernel, dim3(o.i[0]), dim3(256), (size_t)o.i[1] * 9 * sizeof(float), s, o.i[1], o.i[2],
                          (const float *)o.p[0], (const int *)o.p[1], (const float *)o.p[9], (const float *)o.p[2],

