@@ -236,15 +236,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
   }
 
   const int nk = a.k_pad / BK;
-  load_chunk(0);
+#ifdef SLIDE_STAGGER
+  const int koff = (tc * 5 + tr * 3) % nk;
+#define KIDX(k) (((k) + koff) % nk)
+#else
+#define KIDX(k) (k)
+#endif
+  load_chunk(KIDX(0));
   store_chunk(0);
   __syncthreads();
   for (int kc = 0; kc < nk; ++kc) {
-    if (kc + 1 < nk) load_chunk(kc + 1);
+    if (kc + 1 < nk) load_chunk(KIDX(kc + 1));
     compute(kc & 1);
     if (kc + 1 < nk) store_chunk((kc + 1) & 1);
     __syncthreads();
   }
+#undef KIDX
 
   // ------------------------------------------------------------------------------------------ epilogue
   float *red = reinterpret_cast<float *>(smem_raw);  // [wave 4][cb CBW][half 2][r 16][2]   (tiles are dead now)

@@ -1,0 +1,62 @@
+"""Turn gpurun_out/prof_<tag>/ (tools/rocprof_run.sh) into small tracked summaries under profiles/."""
+import collections
+import csv
+import os
+import re
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join("gpurun_out", "prof_" + tag)
+dst = "profiles"
+os.makedirs(dst, exist_ok=True)
+
+
+def short(n):
+    n = n.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+    if n.startswith("_ZN12_GLOBAL__N_1"):
+        m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-z_]+)", n)
+        n = (m.group(1) if m else n) + ("<f16>" if "DF16_" in n else "")
+    return n.split("(")[0][:70]
+
+
+rows = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
+with open(os.path.join(dst, tag + "_kernel_stats.md"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats (%s): `python bench.py --steps 100 --warmup 5 --no-cpu-baseline`\n\n" % tag)
+    bl = os.path.join(src, "bench.log")
+    if os.path.exists(bl):
+        for line in open(bl):
+            if line.startswith('{"metric"'):
+                f.write("bench line under the profiler:\n\n```\n" + line.strip() + "\n```\n\n")
+    f.write("| kernel | calls | total ms | avg us | % | min us | max us |\n|---|---|---|---|---|---|---|\n")
+    for r in rows[:25]:
+        f.write("| %s | %s | %.2f | %.1f | %s | %.1f | %.1f |\n" % (
+            short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"],
+            float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
+
+
+def pmc(path, name):
+    acc = collections.defaultdict(lambda: [0.0, 0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != name:
+            continue
+        a = acc[short(r["Kernel_Name"])]
+        a[0] += float(r["Counter_Value"]); a[1] += 1
+        a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    return acc
+
+
+fp = os.path.join(src, "pmc_fetch", "fetch_counter_collection.csv")
+wp = os.path.join(src, "pmc_write", "write_counter_collection.csv")
+if os.path.exists(fp) and os.path.exists(wp):
+    fa, wa = pmc(fp, "FETCH_SIZE"), pmc(wp, "WRITE_SIZE")
+    with open(os.path.join(dst, tag + "_hbm_pmc.md"), "w") as f:
+        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python tools/profile_ops.py --reps 2`\n\n"
+                "Units: KiB per dispatch as reported by rocprofv3.  On gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x\n"
+                "(MI355X_MICROARCH.md, HBM section): the `fetch x2` column applies that correction.\n\n"
+                "| kernel | dispatches | FETCH KiB/disp | fetch x2 KiB | WRITE KiB/disp | avg us |\n|---|---|---|---|---|---|\n")
+        keys = [k for k in fa if any(t in k for t in ("gemm", "assemble", "attn", "copy", "prep", "update", "finalize"))]
+        for k in sorted(keys, key=lambda k: -fa[k][0]):
+            w = wa.get(k, [0, 1, 0])
+            f.write("| %s | %d | %.0f | %.0f | %.0f | %.1f |\n" % (k, fa[k][1], fa[k][0] / fa[k][1], 2 * fa[k][0] / fa[k][1],
+                                                               w[0] / max(w[1], 1), fa[k][2] / fa[k][1]))
+print("written", sorted(os.listdir(dst)))
