@@ -70,7 +70,7 @@ enum {
   SLIDE_OP_UPDATE_POS = 10, /* p: x, eps, noise(or NULL), t_dev, c_eps, sqrt_alpha, sigma  i: n_elem, -, seed_lo, seed_hi */
   SLIDE_OP_UPDATE_FEAT = 11,/* p: x, eps, noise(or NULL), t_dev, keypoint, c_recip, c_recipm1, c1, c2, c_std  i: n_pts, C, kdim, seed_lo, seed_hi  f: clamp */
   SLIDE_OP_ADVANCE_T = 12,  /* p: t_dev  (t_dev[0] -= 1; t_dev[1] += 1) */
-  SLIDE_OP_HEAD_GATHER = 13 /* reserved */
+  SLIDE_OP_GROUPNORM_NCHW = 13 /* p: x, gamma, beta, y (NCHW fp32)   i: B, C, HW, G, n_norm, relu  (module-level path) */
 };
 
 typedef struct SlideOp {

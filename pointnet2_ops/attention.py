@@ -1,0 +1,98 @@
+"""`pointnet2_ops.attention` (reference pointnet2_ops_lib/pointnet2_ops/attention.py): MyGroupNorm (:6-23),
+AttentionModule (:35-96, vector attention over the K neighbours), GlobalAttentionModule (:98-155) -- same constructor
+signatures and state-dict names; convolutions / GroupNorm run on HIP kernels (slide_amd.nn_ops)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from slide_amd.nn_ops import HipConv1x1, HipGroupNorm
+
+
+class MyGroupNorm(nn.Module):
+    def __init__(self, num_groups, num_channels):
+        super().__init__()
+        self.num_channels = num_channels - num_channels % num_groups
+        self.num_groups = num_groups
+        self.group_norm = HipGroupNorm(self.num_groups, self.num_channels)
+
+    def forward(self, x, relu=False):
+        return self.group_norm(x, relu=relu)  # tail channels (position info) pass through un-normalised
+
+
+def count_to_mask(count, K):
+    mask = torch.arange(K, device=count.device, dtype=count.dtype)
+    B, npoint = count.size()
+    return mask.repeat(B, npoint).view(B, npoint, -1) < count.unsqueeze(-1)
+
+
+class _Seq(nn.Sequential):
+    pass
+
+
+class AttentionModule(nn.Module):
+    def __init__(self, C_in1, C_in2, C1, C2, C_out, attention_bn=True, transform_grouped_feat_out=True,
+                 last_activation=True):
+        super().__init__()
+        C1, C2 = max(C1, 32), max(C2, 32)
+        self.feat_conv = HipConv1x1(C_in1, C1)
+        self.grouped_feat_conv = HipConv1x1(C_in2, C2)
+        inter_C = min(C1 + C2, C_out)
+        if attention_bn:
+            self.weight_conv = nn.Sequential(nn.ReLU(inplace=True), MyGroupNorm(min(32, C1 + C2), C1 + C2),
+                                             HipConv1x1(C1 + C2, inter_C), nn.ReLU(inplace=True),
+                                             MyGroupNorm(min(32, inter_C), inter_C), HipConv1x1(inter_C, C_out))
+        else:
+            self.weight_conv = nn.Sequential(nn.ReLU(inplace=True), HipConv1x1(C1 + C2, inter_C), nn.ReLU(inplace=True),
+                                             HipConv1x1(inter_C, C_out))
+        self.transform_grouped_feat_out = transform_grouped_feat_out
+        if transform_grouped_feat_out:
+            layers = [HipConv1x1(C_out, C_out)]
+            if last_activation:
+                if attention_bn:
+                    layers.append(MyGroupNorm(min(32, C_out), C_out))
+                layers.append(nn.ReLU(inplace=True))
+            self.feat_out_conv = nn.Sequential(*layers)
+
+    def forward(self, feat, grouped_feat, grouped_feat_out, count):
+        K = grouped_feat.shape[-1]
+        feat1 = self.feat_conv(feat.unsqueeze(-1)).expand(-1, -1, -1, K)
+        grouped_feat1 = self.grouped_feat_conv(grouped_feat)
+        scores = self.weight_conv(torch.cat([feat1, grouped_feat1], dim=1))
+        if not (isinstance(count, str) and count == "all"):
+            count = torch.clamp(count, min=1)
+            mask = count_to_mask(count, K).unsqueeze(1).float()
+            scores = scores * mask + (-1e9) * (1 - mask)
+        weight = F.softmax(scores, dim=-1)
+        if self.transform_grouped_feat_out:
+            grouped_feat_out = self.feat_out_conv(grouped_feat_out)
+        return (grouped_feat_out * weight).sum(dim=-1)
+
+
+class GlobalAttentionModule(nn.Module):
+    def __init__(self, C, additional_dim=0, attention_bn=True, last_activation=True):
+        super().__init__()
+        self.key_conv = HipConv1x1(C + additional_dim, C)
+        self.query_conv = HipConv1x1(C + additional_dim, C)
+        layers = [HipConv1x1(C + additional_dim, C)]
+        if last_activation:
+            if attention_bn:
+                layers.append(MyGroupNorm(min(32, C), C))
+            layers.append(nn.ReLU(inplace=True))
+        self.value_conv = nn.Sequential(*layers)
+        if attention_bn:
+            self.weight_conv = nn.Sequential(nn.ReLU(inplace=True), MyGroupNorm(min(32, 2 * C), 2 * C), HipConv1x1(2 * C, C),
+                                             nn.ReLU(inplace=True), MyGroupNorm(min(32, C), C), HipConv1x1(C, C))
+        else:
+            self.weight_conv = nn.Sequential(nn.ReLU(inplace=True), HipConv1x1(2 * C, C), nn.ReLU(inplace=True),
+                                             HipConv1x1(C, C))
+
+    def forward(self, feat):
+        _, _, N = feat.size()
+        key = self.key_conv(feat.unsqueeze(-1)).squeeze(-1)
+        query = self.query_conv(feat.unsqueeze(-1)).squeeze(-1)
+        value = self.value_conv(feat.unsqueeze(-1)).squeeze(-1)
+        key = key.unsqueeze(-2).expand(-1, -1, N, -1)
+        query = query.unsqueeze(-1).expand(-1, -1, -1, N)
+        score = self.weight_conv(torch.cat([query, key], dim=1).contiguous())
+        weight = F.softmax(score, dim=-1)
+        return (value.unsqueeze(-1) * weight).sum(dim=-1)

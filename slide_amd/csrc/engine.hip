@@ -605,6 +605,42 @@ __global__ __launch_bounds__(256) void copy_cols_kernel(int rows, int n, int src
   dst[(size_t)r * dst_ld + c] = (TD)(float)src[(size_t)r * src_ld + c];
 }
 
+// Generic GroupNorm for the module-level compatibility path: x is NCHW (B, C, HW) fp32 like the reference's tensors;
+// the first n_norm channels are normalised in G groups (MyGroupNorm, pointnet2_modules.py:24-42), the rest copied.
+// One workgroup per (sample, group): a group's channels are one contiguous run of gs*HW floats.
+__global__ __launch_bounds__(256) void group_norm_nchw_kernel(int C, int HW, int G, int n_norm, int relu,
+                                                              const float *__restrict__ x, const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta, float *__restrict__ y) {
+  __shared__ float red[2][4];
+  const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+  const int gs = n_norm / G;
+  const size_t base = ((size_t)b * C + (size_t)g * gs) * HW;
+  const int n = gs * HW;
+  if (g == G) {  // pass-through tail channels
+    const size_t tb = ((size_t)b * C + n_norm) * HW;
+    for (int i = tid; i < (C - n_norm) * HW; i += 256) y[tb + i] = relu ? fmaxf(x[tb + i], 0.f) : x[tb + i];
+    return;
+  }
+  float s = 0.f, ss = 0.f;
+  for (int i = tid; i < n; i += 256) {
+    const float v = x[base + i];
+    s += v; ss += v * v;
+  }
+  for (int off = 32; off >= 1; off >>= 1) { s += __shfl_xor(s, off); ss += __shfl_xor(ss, off); }
+  if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = ss; }
+  __syncthreads();
+  s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  ss = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  const float mean = s / n;
+  const float var = fmaxf(ss / n - mean * mean, 0.f);
+  const float rstd = 1.0f / sqrtf(var + GN_EPS);
+  for (int i = tid; i < n; i += 256) {
+    const int c = g * gs + i / HW;
+    float v = (x[base + i] - mean) * rstd * gamma[c] + beta[c];
+    y[base + i] = relu ? fmaxf(v, 0.f) : v;
+  }
+}
+
 __device__ __forceinline__ float swishf(float x) { return x * (1.0f / (1.0f + expf(-x))); }
 
 // t-embedding path (pointnet2_ssg_sem.py:14-31 + pointnet2_with_pcld_condition.py:354-359) followed by every
@@ -860,6 +896,11 @@ int run_op(const SlideOp &o, hipStream_t s) {
                          o.i[2], o.f[0], (uint32_t)o.i[3], (uint32_t)o.i[4], (float *)o.p[0], (const float *)o.p[1],
                          (const float *)o.p[2], (const int *)o.p[3], (const float *)o.p[4], (const float *)o.p[5],
                          (const float *)o.p[6], (const float *)o.p[7], (const float *)o.p[8], (const float *)o.p[9]);
+      break;
+    case SLIDE_OP_GROUPNORM_NCHW:  // i: B, C, HW, G, n_norm, relu   p: x, gamma, beta, y
+      hipLaunchKernelGGL(group_norm_nchw_kernel, dim3(o.i[3] + (o.i[4] < o.i[1] ? 1 : 0), o.i[0]), dim3(256), 0, s, o.i[1],
+                         o.i[2], o.i[3], o.i[4], o.i[5], (const float *)o.p[0], (const float *)o.p[1],
+                         (const float *)o.p[2], (float *)o.p[3]);
       break;
     case SLIDE_OP_ADVANCE_T:
       hipLaunchKernelGGL(advance_t_kernel, dim3(1), dim3(64), 0, s, (int *)o.p[0]);

@@ -1,0 +1,78 @@
+"""CPU: host-side logic -- config reader, built-in configs vs the reference's shipped configs (via the golden fixture),
+parameter spec, schedules, plan structure / FLOP accounting, checkpoint layout."""
+import json
+
+import numpy as np
+import torch
+
+from conftest import golden_spec, load_golden
+from slide_amd import configs, model_spec
+from slide_amd.json_reader import read_json_file
+
+
+def test_builtin_configs_match_reference_configs():
+    for name, cfg in (("pos", configs.position_ddpm_config()), ("feat", configs.feature_ddpm_config())):
+        g = load_golden("golden_denoiser_%s.npz" % name)
+        assert json.loads(str(g["config_json"])) == cfg["pointnet_config"]
+        assert dict(golden_spec(g)) == dict(model_spec.denoiser_param_spec(cfg["pointnet_config"]))
+    g = load_golden("golden_sampler_feat.npz")
+    assert json.loads(str(g["config_json"])) == configs.feature_ddpm_config()["standard_diffusion_config"]
+
+
+def test_json_reader_restores_string_lists(tmp_path):
+    p = tmp_path / "c.json"
+    p.write_text(json.dumps({"a": {"npoint": "[16, 16]", "name": "x", "cats": "['02691156']", "n": 3, "bad": "[1,"}}))
+    c = read_json_file(str(p))
+    assert c["a"]["npoint"] == [16, 16] and c["a"]["cats"] == ["02691156"] and c["a"]["name"] == "x" and c["a"]["bad"] == "[1,"
+
+
+def test_schedules_match_reference_tables():
+    from slide_amd.diffusion import calc_diffusion_hyperparams, latent_diffusion_params
+    g = load_golden("golden_sampler_pos.npz")
+    dh = calc_diffusion_hyperparams(1000, 1e-4, 0.02)
+    for k in ("Beta", "Alpha", "Alpha_bar"):
+        assert np.array_equal(dh[k], g["sched_" + k])
+    assert np.abs(dh["Sigma"] - g["sched_Sigma"]).max() <= 1.5e-8  # torch's CPU sqrt is 1 ulp low on 9 entries
+    g = load_golden("golden_sampler_feat.npz")
+    dp = latent_diffusion_params(json.loads(str(g["config_json"])))
+    for k in ("logvar", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1", "posterior_mean_coef2"):
+        assert np.array_equal(dp[k], g["sched_" + k])
+
+
+def test_plan_structure_and_flops():
+    """the plan can be built without a GPU; its GEMMs cover every conv MAC of the reference network, minus the
+    query half of attention weight_conv.2 which is evaluated per point instead of per neighbour"""
+    from slide_amd.engine import OP_GEMM, DenoiserEngine
+    from slide_amd.synth import synth_state_dict
+    for cfg, conv_macs in ((configs.position_ddpm_config(), 38977024 - 471040), (configs.feature_ddpm_config(), None)):
+        hp = cfg["pointnet_config"]
+        sd = synth_state_dict(model_spec.denoiser_param_spec(hp))
+        e = DenoiserEngine(hp, sd, 2, torch.device("cpu"), prec="fp32")
+        assert sum(1 for o in e.ops if o.kind == OP_GEMM) == 36
+        saved = 0
+        for pfx, K in (("SA_modules.0.attention_modules.0", 16), ("SA_modules.1.attention_modules.0", 16),
+                       ("FP_modules.0.attention_module", 8), ("FP_modules.1.attention_module", 8)):
+            C1 = sd[pfx + ".feat_conv.weight"].shape[0]
+            inter = sd[pfx + ".weight_conv.2.weight"].shape[0]
+            saved += C1 * inter * 16 * (K - 1)
+        if conv_macs is not None:  # SURVEY.md appendix A.1 total minus the linear (fc / fc_t) layers
+            assert e.flops // 2 // 2 + saved == conv_macs
+        try:
+            e.forward(np.zeros((2, 16, e.cx)), np.zeros(2), np.zeros(2))
+            assert False, "a plan must not run without a GPU"
+        except RuntimeError:
+            pass
+
+
+def test_checkpoint_layout(tmp_path):
+    from slide_amd.checkpoint import load_denoiser_state
+    from slide_amd.synth import synth_state_dict
+    hp = configs.position_ddpm_config()["pointnet_config"]
+    spec = model_spec.denoiser_param_spec(hp)
+    sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(spec).items()}
+    ema = {k: v + 1 for k, v in list(sd.items())[:5]}
+    f = tmp_path / "pointnet_ckpt_1.pkl"
+    torch.save({"model_state_dict": sd, "ema_state_list": [{}, ema], "iter": 1}, str(f))
+    out = load_denoiser_state(hp, str(f), ema_idx=1)
+    k0 = list(ema)[0]
+    assert np.array_equal(out[k0], ema[k0].numpy()) and np.array_equal(out["fc_lyaer.3.bias"], sd["fc_lyaer.3.bias"].numpy())
