@@ -136,7 +136,7 @@ def main():
     out = {"metric": "latent shapes/sec (pos+feat DDPM, 1000 steps, 16 pts)", "value": round(value, 3),
            "unit": "shapes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f16 MFMA operands, f32 accumulate/activations" if a.prec == "fp16" else "f32", "data": "synthetic",
+           "dtype": "f16 (MFMA operands + activation storage; f32 accumulate, norm statistics, softmax)" if a.prec == "fp16" else "f32", "data": "synthetic",
            "config": {"workload": "BASELINE configs[1]+[2]: airplane position DDPM (16x3) + chair feature DDPM (16x51), "
                                   "batch %d per GPU; 1 step = one reverse step of each; shape = 1000+1000 steps" % B,
                       "batch_per_gpu": B, "prec": a.prec, "launches_per_step": pos.n_launches + feat.n_launches,
@@ -156,14 +156,17 @@ def main():
                 tot += np.array(list(ms))
         tot /= reps
         flops = f.engine.gemm_flops  # per GEMM op, algorithmic (logical channels), whole batch
-        dom = [i for i in range(n) if f.step_ops[i].kind == OP_GEMM and f.step_ops[i].i[4] == 8]
+        cbw_dom = 4 if a.prec == "fp16" else 2  # the rocprofv3 kernel name: gemm_kernel<PREC, 8, CBW>
+        dom = [i for i in range(n) if f.step_ops[i].kind == OP_GEMM and f.step_ops[i].i[4] == 8 and f.step_ops[i].i[7] == cbw_dom]
         dflops = sum(flops[i] for i in dom)
         dms = sum(tot[i] for i in dom)
         ach = dflops / (dms * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.prec], "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_TFLOPS[a.prec], 4), "traffic": None,
-                           "kernel": "gemm_kernel<%s,256-row samples> (feature denoiser, %d launches/step, avg %.1f us)"
-                                     % (a.prec, len(dom), 1e3 * dms / len(dom)),
+                           "kernel": "gemm_kernel<%d, 8, %d> (%s MFMA, 256-row samples, 32*%d-channel tiles; feature denoiser: "
+                                     "%d launches/step, avg %.1f us)" % (1 if a.prec == "fp16" else 0, cbw_dom, a.prec, cbw_dom,
+                                                                         len(dom), 1e3 * dms / len(dom)),
+                           "flops_per_step_dominant": dflops,
                            "step_ms_eager_sum": round(float(tot.sum()), 4),
                            "gemm_ms_per_step_all": round(float(sum(tot[i] for i in range(n) if f.step_ops[i].kind == OP_GEMM)), 4)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
