@@ -58,7 +58,7 @@ typedef struct SlideEpi {
 } SlideEpi;
 
 enum {
-  SLIDE_OP_GEMM = 1,        /* p: X, W, epi, in_scale, in_shift   i: rows, x_ld, k_pad, n_cob, npx_log2, in_bs, prec, cbw(2|4) */
+  SLIDE_OP_GEMM = 1,        /* p: X, W, epi, in_scale, in_shift   i: rows, x_ld, k_pad, n_cob, npx_log2, in_bs, prec, cbw(2|4), lds_dma(0|1: fp16, no in_scale) */
   SLIDE_OP_PREP_POINTS = 2, /* p: x, xyz, feat0, knn_idx, knn_d2   i: B, cx, ldf, prec     (16 points / sample) */
   SLIDE_OP_ASSEMBLE_SA = 3, /* p: xyz, feat, knn_idx, g            i: B, C, ldf, ldg, K, prec */
   SLIDE_OP_ASSEMBLE_FP = 4, /* p: xyz, feat, knn_idx, knn_d2, g    i: B, C, ldf, ldg, K, prec */

@@ -93,137 +93,18 @@ template <> __device__ __forceinline__ void store4<_Float16>(_Float16 *p, float4
 
 // CBW = 32-channel output blocks per wave; the workgroup tile is 256 rows x (32*CBW) channels: the four waves
 // split the rows (64 each) and share the W panel, so every X element fetched from L2/HBM feeds 32*CBW MACs.
-template <int PREC, int NPXL, int CBW>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
-  using T = typename TileT<PREC>::T;
-  constexpr int LDK = TileT<PREC>::LDK;
-  constexpr int EPL = TileT<PREC>::EPL;   // elements per 16-byte load
-  constexpr int TPR = BK / EPL;           // threads per tile row
-  constexpr int RPP = 256 / TPR;          // rows per pass
-  constexpr int TN = 32 * CBW;
-  constexpr int XP = TM / RPP, WP = TN / RPP;
-  constexpr int NPX = 1 << NPXL;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T *const sbase = reinterpret_cast<T *>(smem_raw);
-  constexpr int STAGE = (TM + TN) * LDK;
+constexpr int EPI_DW = (int)(sizeof(SlideEpi) / 4);
+static_assert(sizeof(SlideEpi) == 136, "descriptor layout is read by dword index in gemm_epilogue");
 
-  const int ntc = (a.n_cob + CBW - 1) / CBW;
-  const int ntr = (a.rows + TM - 1) / TM;
-  // XCD-aware mapping: workgroup id % 8 picks the XCD (observed dispatch rule); all channel tiles of one
-  // row tile share that XCD's L2, so the X panel is fetched from HBM once.
-  const int xcd = blockIdx.x & 7, q0 = blockIdx.x >> 3;
-  const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;
-  if (tr >= ntr) return;
-  const int row0 = tr * TM, cob0 = tc * CBW;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, col = lane & 31;
-  const T *X = reinterpret_cast<const T *>(a.X);
-  const T *W = reinterpret_cast<const T *>(a.W);
-
-  f32x16 acc[CBW][2];
-#pragma unroll
-  for (int i = 0; i < CBW; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  float4 xr[XP], wr[WP];  // raw 16-byte pieces in flight
-  const int l_row = tid / TPR, l_c = (tid % TPR) * EPL;
-
-  auto load_chunk = [&](int kc) {
-#pragma unroll
-    for (int p = 0; p < XP; ++p) {
-      const int grow = row0 + p * RPP + l_row;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (grow < a.rows) {
-        v = *reinterpret_cast<const float4 *>(X + (size_t)grow * a.x_ld + kc * BK + l_c);
-        if (a.in_scale) {  // consumer-side GroupNorm affine (only the attention weight_conv.2 GEMMs)
-          const size_t o = (size_t)(grow >> NPXL) * a.in_bs + kc * BK + l_c;
-          if (PREC == SLIDE_PREC_F32) {
-            const float4 sc = *reinterpret_cast<const float4 *>(a.in_scale + o);
-            const float4 sh = *reinterpret_cast<const float4 *>(a.in_shift + o);
-            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-          } else {
-            f16x8 h = *reinterpret_cast<f16x8 *>(&v);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) h[j] = (_Float16)((float)h[j] * a.in_scale[o + j] + a.in_shift[o + j]);
-            v = *reinterpret_cast<float4 *>(&h);
-          }
-        }
-      }
-      xr[p] = v;
-    }
-#pragma unroll
-    for (int p = 0; p < WP; ++p) {
-      const int gco = cob0 * 32 + p * RPP + l_row;
-      wr[p] = gco < a.n_cob * 32 ? *reinterpret_cast<const float4 *>(W + (size_t)gco * a.k_pad + kc * BK + l_c)
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto store_chunk = [&](int s) {
-    T *Xs = sbase + s * STAGE;
-    T *Ws = Xs + TM * LDK;
-#pragma unroll
-    for (int p = 0; p < XP; ++p) *reinterpret_cast<float4 *>(Xs + (p * RPP + l_row) * LDK + l_c) = xr[p];
-#pragma unroll
-    for (int p = 0; p < WP; ++p) *reinterpret_cast<float4 *>(Ws + (p * RPP + l_row) * LDK + l_c) = wr[p];
-  };
-  auto compute = [&](int s) {
-    const T *Xs = sbase + s * STAGE;
-    const T *Ws = Xs + TM * LDK;
-    if (PREC == SLIDE_PREC_F32) {
-      const float *Xf = reinterpret_cast<const float *>(Xs);
-      const float *Wf = reinterpret_cast<const float *>(Ws);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float4 af[CBW], bf[2];
-#pragma unroll
-        for (int cb = 0; cb < CBW; ++cb)
-          af[cb] = *reinterpret_cast<const float4 *>(Wf + (cb * 32 + col) * LDK + q * 8 + half * 4);
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-          bf[rb] = *reinterpret_cast<const float4 *>(Xf + (wave * 64 + rb * 32 + col) * LDK + q * 8 + half * 4);
-#pragma unroll
-        for (int cb = 0; cb < CBW; ++cb)
-#pragma unroll
-          for (int rb = 0; rb < 2; ++rb) {
-            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb].x, bf[rb].x, acc[cb][rb], 0, 0, 0);
-            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb].y, bf[rb].y, acc[cb][rb], 0, 0, 0);
-            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb].z, bf[rb].z, acc[cb][rb], 0, 0, 0);
-            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb].w, bf[rb].w, acc[cb][rb], 0, 0, 0);
-          }
-      }
-    } else {
-      const _Float16 *Xh = reinterpret_cast<const _Float16 *>(Xs);
-      const _Float16 *Wh = reinterpret_cast<const _Float16 *>(Ws);
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        f16x8 af[CBW], bf[2];
-#pragma unroll
-        for (int cb = 0; cb < CBW; ++cb)
-          af[cb] = *reinterpret_cast<const f16x8 *>(Wh + (cb * 32 + col) * LDK + st * 16 + half * 8);
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-          bf[rb] = *reinterpret_cast<const f16x8 *>(Xh + (wave * 64 + rb * 32 + col) * LDK + st * 16 + half * 8);
-#pragma unroll
-        for (int cb = 0; cb < CBW; ++cb)
-#pragma unroll
-          for (int rb = 0; rb < 2; ++rb)
-            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb], bf[rb], acc[cb][rb], 0, 0, 0);
-      }
-    }
-  };
-
-  constexpr int EPI_DW = (int)(sizeof(SlideEpi) / 4);
-  static_assert(sizeof(SlideEpi) == 136, "descriptor layout is read by dword index below");
-  uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + 2 * (size_t)STAGE * sizeof(T));
+// copies the CBW epilogue descriptors of this workgroup and their per-channel vectors [cb][bias | gamma | beta][32]
+// into LDS (visible after the caller's next barrier)
+template <int CBW>
+__device__ __forceinline__ void stage_epilogue_tables(const GemmArgs &a, int cob0, int tid, uint32_t *epi_lds,
+                                                      float *vec_lds) {
   for (int i = tid; i < CBW * EPI_DW; i += 256) {
     const int cobi = cob0 + i / EPI_DW;
     epi_lds[i] = cobi < a.n_cob ? reinterpret_cast<const uint32_t *>(a.epi + cobi)[i % EPI_DW] : 0u;
   }
-  // ... and the per-channel epilogue vectors [cb][bias | gamma | beta][32]
-  float *const vec_lds = reinterpret_cast<float *>(epi_lds + CBW * EPI_DW + (CBW * EPI_DW) % 4);
   for (int i = tid; i < CBW * 96; i += 256) {
     const int cobi = cob0 + i / 96, which = (i % 96) >> 5, c = i & 31;
     float val = 0.f;
@@ -234,27 +115,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
     }
     vec_lds[i] = val;
   }
+}
 
-  const int nk = a.k_pad / BK;
-#ifdef SLIDE_STAGGER
-  const int koff = (tc * 5 + tr * 3) % nk;
-#define KIDX(k) (((k) + koff) % nk)
-#else
-#define KIDX(k) (k)
-#endif
-  load_chunk(KIDX(0));
-  store_chunk(0);
-  __syncthreads();
-  for (int kc = 0; kc < nk; ++kc) {
-    if (kc + 1 < nk) load_chunk(KIDX(kc + 1));
-    compute(kc & 1);
-    if (kc + 1 < nk) store_chunk((kc + 1) & 1);
-    __syncthreads();
-  }
-#undef KIDX
-
-  // ------------------------------------------------------------------------------------------ epilogue
-  float *red = reinterpret_cast<float *>(smem_raw);  // [wave 4][cb CBW][half 2][r 16][2]   (tiles are dead now)
+// Shared epilogue of the GEMM kernels: acc[cb][rb] holds D[co][row] in the 32x32 MFMA C layout (lane: row = lane & 31,
+// reg r: co = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  `red` = 4*CBW*2*16*2 floats of LDS scratch (the dead tiles).
+template <int PREC, int NPXL, int CBW>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[CBW][2], int row0, int cob0, int wave,
+                                              int half, int col, const uint32_t *epi_lds, const float *vec_lds,
+                                              float *red) {
+  using T = typename TileT<PREC>::T;
+  constexpr int NPX = 1 << NPXL;
 #pragma unroll
   for (int cb = 0; cb < CBW; ++cb) {
     const int cobi = cob0 + cb;
@@ -442,6 +312,293 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
   }
 }
 
+template <int PREC, int NPXL, int CBW>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
+  using T = typename TileT<PREC>::T;
+  constexpr int LDK = TileT<PREC>::LDK;
+  constexpr int EPL = TileT<PREC>::EPL;   // elements per 16-byte load
+  constexpr int TPR = BK / EPL;           // threads per tile row
+  constexpr int RPP = 256 / TPR;          // rows per pass
+  constexpr int TN = 32 * CBW;
+  constexpr int XP = TM / RPP, WP = TN / RPP;
+  constexpr int NPX = 1 << NPXL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T *const sbase = reinterpret_cast<T *>(smem_raw);
+  constexpr int STAGE = (TM + TN) * LDK;
+
+  const int ntc = (a.n_cob + CBW - 1) / CBW;
+  const int ntr = (a.rows + TM - 1) / TM;
+  // XCD-aware mapping: workgroup id % 8 picks the XCD (observed dispatch rule); all channel tiles of one
+  // row tile share that XCD's L2, so the X panel is fetched from HBM once.
+  const int xcd = blockIdx.x & 7, q0 = blockIdx.x >> 3;
+  const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;
+  if (tr >= ntr) return;
+  const int row0 = tr * TM, cob0 = tc * CBW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const T *X = reinterpret_cast<const T *>(a.X);
+  const T *W = reinterpret_cast<const T *>(a.W);
+
+  f32x16 acc[CBW][2];
+#pragma unroll
+  for (int i = 0; i < CBW; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 xr[XP], wr[WP];  // raw 16-byte pieces in flight
+  const int l_row = tid / TPR, l_c = (tid % TPR) * EPL;
+
+  auto load_chunk = [&](int kc) {
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      const int grow = row0 + p * RPP + l_row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (grow < a.rows) {
+        v = *reinterpret_cast<const float4 *>(X + (size_t)grow * a.x_ld + kc * BK + l_c);
+        if (a.in_scale) {  // consumer-side GroupNorm affine (only the attention weight_conv.2 GEMMs)
+          const size_t o = (size_t)(grow >> NPXL) * a.in_bs + kc * BK + l_c;
+          if (PREC == SLIDE_PREC_F32) {
+            const float4 sc = *reinterpret_cast<const float4 *>(a.in_scale + o);
+            const float4 sh = *reinterpret_cast<const float4 *>(a.in_shift + o);
+            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+          } else {
+            f16x8 h = *reinterpret_cast<f16x8 *>(&v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = (_Float16)((float)h[j] * a.in_scale[o + j] + a.in_shift[o + j]);
+            v = *reinterpret_cast<float4 *>(&h);
+          }
+        }
+      }
+      xr[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < WP; ++p) {
+      const int gco = cob0 * 32 + p * RPP + l_row;
+      wr[p] = gco < a.n_cob * 32 ? *reinterpret_cast<const float4 *>(W + (size_t)gco * a.k_pad + kc * BK + l_c)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_chunk = [&](int s) {
+    T *Xs = sbase + s * STAGE;
+    T *Ws = Xs + TM * LDK;
+#pragma unroll
+    for (int p = 0; p < XP; ++p) *reinterpret_cast<float4 *>(Xs + (p * RPP + l_row) * LDK + l_c) = xr[p];
+#pragma unroll
+    for (int p = 0; p < WP; ++p) *reinterpret_cast<float4 *>(Ws + (p * RPP + l_row) * LDK + l_c) = wr[p];
+  };
+  auto compute = [&](int s) {
+    const T *Xs = sbase + s * STAGE;
+    const T *Ws = Xs + TM * LDK;
+    if (PREC == SLIDE_PREC_F32) {
+      const float *Xf = reinterpret_cast<const float *>(Xs);
+      const float *Wf = reinterpret_cast<const float *>(Ws);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 af[CBW], bf[2];
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb)
+          af[cb] = *reinterpret_cast<const float4 *>(Wf + (cb * 32 + col) * LDK + q * 8 + half * 4);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+          bf[rb] = *reinterpret_cast<const float4 *>(Xf + (wave * 64 + rb * 32 + col) * LDK + q * 8 + half * 4);
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) {
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb].x, bf[rb].x, acc[cb][rb], 0, 0, 0);
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb].y, bf[rb].y, acc[cb][rb], 0, 0, 0);
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb].z, bf[rb].z, acc[cb][rb], 0, 0, 0);
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb].w, bf[rb].w, acc[cb][rb], 0, 0, 0);
+          }
+      }
+    } else {
+      const _Float16 *Xh = reinterpret_cast<const _Float16 *>(Xs);
+      const _Float16 *Wh = reinterpret_cast<const _Float16 *>(Ws);
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        f16x8 af[CBW], bf[2];
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb)
+          af[cb] = *reinterpret_cast<const f16x8 *>(Wh + (cb * 32 + col) * LDK + st * 16 + half * 8);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+          bf[rb] = *reinterpret_cast<const f16x8 *>(Xh + (wave * 64 + rb * 32 + col) * LDK + st * 16 + half * 8);
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb)
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb], bf[rb], acc[cb][rb], 0, 0, 0);
+      }
+    }
+  };
+
+  uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + 2 * (size_t)STAGE * sizeof(T));
+  float *const vec_lds = reinterpret_cast<float *>(epi_lds + CBW * EPI_DW + (CBW * EPI_DW) % 4);
+  stage_epilogue_tables<CBW>(a, cob0, tid, epi_lds, vec_lds);
+
+  const int nk = a.k_pad / BK;
+#ifdef SLIDE_STAGGER
+  const int koff = (tc * 5 + tr * 3) % nk;
+#define KIDX(k) (((k) + koff) % nk)
+#else
+#define KIDX(k) (k)
+#endif
+  load_chunk(KIDX(0));
+  store_chunk(0);
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    if (kc + 1 < nk) load_chunk(KIDX(kc + 1));
+    compute(kc & 1);
+    if (kc + 1 < nk) store_chunk((kc + 1) & 1);
+    __syncthreads();
+  }
+#undef KIDX
+
+  gemm_epilogue<PREC, NPXL, CBW>(a, acc, row0, cob0, wave, half, col, epi_lds, vec_lds, reinterpret_cast<float *>(smem_raw));
+}
+
+// ------------------------------------------------------------------------------------------------ LDS-DMA GEMM
+// fp16 throughput variant of gemm_kernel (no consumer-side affine): the X / W chunks go HBM/L2 -> LDS directly with
+// `global_load_lds_dwordx4` (no VGPR staging), NST chunks deep, so many more bytes are in flight per CU than a
+// register-staged prefetch allows.  An LDS-DMA instruction writes lane-linearly (base + 16 B x lane), so a stage is an
+// unpadded [rows][32] fp16 image (64 B rows) and bank conflicts are avoided by swizzling on the SOURCE side: slot
+// (lane & 3) of row r receives the 16-byte piece p = slot ^ ((r >> 2) & 3); fragment reads apply the same XOR
+// (conflict-free for ds_read_b128's 16-lane groups).  One raw s_barrier per chunk; counted vmcnt keeps NST-2 chunks in
+// flight across it.
+// AFF: consumer-side GroupNorm affine (attention weight_conv.2): the per-(sample, channel) scale / shift vectors of the
+// workgroup's samples are staged once in LDS (fp16) and applied in fp32 to the X fragments between LDS and MFMA.
+template <int NPXL, int CBW, int NST, int BKT, bool AFF>
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
+  using T = _Float16;
+  constexpr int TN = 32 * CBW;
+  constexpr int RT = TM + TN;              // tile rows per stage (X rows then W rows)
+  constexpr int ROWB = BKT * 2;            // bytes per tile row (64 or 128 = one full cache line)
+  constexpr int PPR = ROWB / 16;           // 16-byte pieces per row (4 or 8)
+  constexpr int RPI = 64 / PPR;            // rows per LDS-DMA instruction (16 or 8)
+  constexpr int NI = RT / RPI;             // LDS-DMA instructions per stage
+  constexpr int LPW = NI / 4;              // per wave
+  constexpr int STAGE_B = RT * ROWB;       // bytes
+  constexpr int SWS = BKT == 32 ? 2 : 1;   // swizzle: slot = piece ^ ((row >> SWS) & (PPR - 1))
+  static_assert(NI % 4 == 0, "tile rows must split evenly over the four waves");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+  const int ntc = (a.n_cob + CBW - 1) / CBW;
+  const int ntr = (a.rows + TM - 1) / TM;
+  const int xcd = blockIdx.x & 7, q0 = blockIdx.x >> 3;
+  const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;
+  if (tr >= ntr) return;
+  const int row0 = tr * TM, cob0 = tc * CBW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+
+  uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + (size_t)NST * STAGE_B);
+  float *const vec_lds = reinterpret_cast<float *>(epi_lds + CBW * EPI_DW + (CBW * EPI_DW) % 4);
+  stage_epilogue_tables<CBW>(a, cob0, tid, epi_lds, vec_lds);
+  constexpr int NSAMP = (1 << NPXL) >= TM ? 1 : TM >> NPXL;  // samples per workgroup
+  _Float16 *const aff_lds = reinterpret_cast<_Float16 *>(vec_lds + CBW * 96);  // [sample][scale | shift][k_pad]
+  if (AFF) {
+    static_assert(!AFF || NPXL >= 6, "the affine variant assumes one sample per wave");
+    for (int i = tid; i < NSAMP * a.k_pad; i += 256) {
+      const int sm = i / a.k_pad, k = i - sm * a.k_pad;
+      int b = (row0 >> NPXL) + sm;
+      const int nb = a.rows >> NPXL;
+      b = b < nb ? b : nb - 1;
+      aff_lds[(sm * 2 + 0) * a.k_pad + k] = (_Float16)a.in_scale[(size_t)b * a.in_bs + k];
+      aff_lds[(sm * 2 + 1) * a.k_pad + k] = (_Float16)a.in_shift[(size_t)b * a.in_bs + k];
+    }
+  }
+  const _Float16 *const aff_w = aff_lds + (size_t)((wave * 64) >> NPXL) * 2 * a.k_pad;  // this wave's sample
+
+  // per-lane source pointers of this wave's LPW instructions (chunk 0); out-of-range rows are clamped to a valid row:
+  // they only feed accumulator rows / channel blocks that are never stored
+  const T *gp[LPW];
+#pragma unroll
+  for (int j = 0; j < LPW; ++j) {
+    const int trow = RPI * (j * 4 + wave) + lane / PPR;
+    const int piece = (lane % PPR) ^ ((trow >> SWS) & (PPR - 1));
+    if (trow < TM) {
+      int grow = row0 + trow;
+      grow = grow < a.rows ? grow : a.rows - 1;
+      gp[j] = reinterpret_cast<const T *>(a.X) + (size_t)grow * a.x_ld + piece * 8;
+    } else {
+      int gco = cob0 * 32 + (trow - TM);
+      gco = gco < a.n_cob * 32 ? gco : a.n_cob * 32 - 1;
+      gp[j] = reinterpret_cast<const T *>(a.W) + (size_t)gco * a.k_pad + piece * 8;
+    }
+  }
+  auto issue = [&](int kc, int st) {
+#pragma unroll
+    for (int j = 0; j < LPW; ++j) {
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(gp[j] + kc * BKT),
+                                       (__attribute__((address_space(3))) void *)(smem_raw + (size_t)st * STAGE_B +
+                                                                                  (j * 4 + wave) * 1024),
+                                       16, 0, 0);
+    }
+  };
+
+  f32x16 acc[CBW][2];
+#pragma unroll
+  for (int i = 0; i < CBW; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // row base offsets and swizzle keys of this lane's fragment rows (bytes inside a stage)
+  int wrow[CBW], wkey[CBW], xrow[2], xkey[2];
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb) {
+    const int trow = TM + cb * 32 + col;
+    wrow[cb] = trow * ROWB; wkey[cb] = (trow >> SWS) & (PPR - 1);
+  }
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const int trow = wave * 64 + rb * 32 + col;
+    xrow[rb] = trow * ROWB; xkey[rb] = (trow >> SWS) & (PPR - 1);
+  }
+
+  const int nk = a.k_pad / BKT;
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0)
+    if (s0 < nk) issue(s0, s0);
+  for (int kc = 0; kc < nk; ++kc) {
+    // chunk kc must have landed; up to NST-2 younger chunks may stay in flight (fewer in the tail -> drain)
+    if (kc + NST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kc + NST - 1 < nk) issue(kc + NST - 1, (kc + NST - 1) % NST);  // overwrites the stage consumed at kc-1
+    const unsigned char *sb = smem_raw + (size_t)(kc % NST) * STAGE_B;
+#pragma unroll
+    for (int st2 = 0; st2 < BKT / 16; ++st2) {
+      f16x8 af[CBW], bf[2];
+      const int piece = st2 * 2 + half;
+#pragma unroll
+      for (int cb = 0; cb < CBW; ++cb) af[cb] = *reinterpret_cast<const f16x8 *>(sb + wrow[cb] + ((piece ^ wkey[cb]) << 4));
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) bf[rb] = *reinterpret_cast<const f16x8 *>(sb + xrow[rb] + ((piece ^ xkey[rb]) << 4));
+      if (AFF) {
+        const f16x8 sc = *reinterpret_cast<const f16x8 *>(aff_w + kc * BKT + piece * 8);
+        const f16x8 sh = *reinterpret_cast<const f16x8 *>(aff_w + a.k_pad + kc * BKT + piece * 8);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bf[rb][j] = (_Float16)((float)bf[rb][j] * (float)sc[j] + (float)sh[j]);
+      }
+#pragma unroll
+      for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+          acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb], bf[rb], acc[cb][rb], 0, 0, 0);
+    }
+  }
+  __syncthreads();  // every wave is done with the tiles before `red` reuses them
+
+  gemm_epilogue<SLIDE_PREC_F16, NPXL, CBW>(a, acc, row0, cob0, wave, half, col, epi_lds, vec_lds,
+                                           reinterpret_cast<float *>(smem_raw));
+}
+
 // ------------------------------------------------------------------------------------------------ points
 __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
 #pragma clang fp contract(off)
@@ -488,54 +645,56 @@ __global__ __launch_bounds__(256) void prep_points_kernel(int cx, int ldf, const
 
 // QueryAndGroup feature assembly ('nn', use_xyz, abs + center coordinates; pointnet2_utils.py:383-430):
 // g[b][p*K+k][:] = [feat[nbr][0:C], xyz[nbr]-xyz[p], xyz[nbr], xyz[p], 0-pad]
-template <typename T>
-__global__ __launch_bounds__(256) void assemble_sa_kernel(int C, int ldf, int ldg, int K,
-                                                          const float *__restrict__ xyz, const T *__restrict__ feat,
-                                                          const int *__restrict__ kidx, T *__restrict__ g) {
-#pragma clang fp contract(off)
-  const int b = blockIdx.x;
-  const int npx = 16 * K;
-  const float *px = xyz + (size_t)b * 48;
-  for (int e = blockIdx.y * 256 + threadIdx.x; e < npx * ldg; e += gridDim.y * 256) {
-    const int pxl = e / ldg, c = e - pxl * ldg;
-    const int p = pxl / K, k = pxl - p * K;
-    const int nb = kidx[((size_t)b * 16 + p) * 16 + k];
-    float v = 0.f;
-    if (c < C) v = (float)feat[((size_t)b * 16 + nb) * ldf + c];
-    else if (c < C + 3) v = px[nb * 3 + (c - C)] - px[p * 3 + (c - C)];
-    else if (c < C + 6) v = px[nb * 3 + (c - C - 3)];
-    else if (c < C + 9) v = px[p * 3 + (c - C - 6)];
-    g[((size_t)b * npx + pxl) * ldg + c] = (T)v;
-  }
-}
-
-// group_knn feature assembly (pointnet2_utils.py:497-524):
+// group_knn feature assembly (pointnet2_utils.py:497-524), FP = true:
 // g[b][p*K+k][:] = [feat[nbr][0:C], d2, w, xyz[nbr], xyz[nbr]-xyz[p], xyz[p], 0-pad], w from squared distances
-template <typename T>
-__global__ __launch_bounds__(256) void assemble_fp_kernel(int C, int ldf, int ldg, int K,
-                                                          const float *__restrict__ xyz, const T *__restrict__ feat,
-                                                          const int *__restrict__ kidx, const float *__restrict__ kd2,
-                                                          T *__restrict__ g) {
+// One thread moves 8 channels (16 bytes in fp16): the gathered feature rows are copied as whole vectors, only the
+// chunk that holds the coordinate channels is assembled element-wise.
+template <typename T, bool FP>
+__global__ __launch_bounds__(256) void assemble_kernel(int C, int ldf, int ldg, int K, const float *__restrict__ xyz,
+                                                       const T *__restrict__ feat, const int *__restrict__ kidx,
+                                                       const float *__restrict__ kd2, T *__restrict__ g) {
 #pragma clang fp contract(off)
   const int b = blockIdx.x;
   const int npx = 16 * K;
+  const int nch = ldg / 8;
   const float *px = xyz + (size_t)b * 48;
-  for (int e = blockIdx.y * 256 + threadIdx.x; e < npx * ldg; e += gridDim.y * 256) {
-    const int pxl = e / ldg, c = e - pxl * ldg;
+  for (int e = blockIdx.y * 256 + threadIdx.x; e < npx * nch; e += gridDim.y * 256) {
+    const int pxl = e / nch, c0 = (e - pxl * nch) * 8;
     const int p = pxl / K, k = pxl - p * K;
     const size_t o = ((size_t)b * 16 + p) * 16;
     const int nb = kidx[o + k];
-    float v = 0.f;
-    if (c < C) v = (float)feat[((size_t)b * 16 + nb) * ldf + c];
-    else if (c == C) v = kd2[o + k];
-    else if (c == C + 1) {
-      float norm = 0.f;
-      for (int kk = 0; kk < K; ++kk) norm += 1.0f / (kd2[o + kk] + 1e-8f);
-      v = (1.0f / (kd2[o + k] + 1e-8f)) / norm;
-    } else if (c < C + 5) v = px[nb * 3 + (c - C - 2)];
-    else if (c < C + 8) v = px[nb * 3 + (c - C - 5)] - px[p * 3 + (c - C - 5)];
-    else if (c < C + 11) v = px[p * 3 + (c - C - 8)];
-    g[((size_t)b * npx + pxl) * ldg + c] = (T)v;
+    const T *frow = feat + ((size_t)b * 16 + nb) * ldf;
+    T *dst = g + ((size_t)b * npx + pxl) * ldg + c0;
+    if (c0 + 8 <= C && sizeof(T) * ldf % 16 == 0) {
+      if (sizeof(T) == 2) {
+        *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(frow + c0);
+      } else {
+        *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(frow + c0);
+        *reinterpret_cast<float4 *>(dst + 4) = *reinterpret_cast<const float4 *>(frow + c0 + 4);
+      }
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j;
+      float v = 0.f;
+      if (c < C) v = (float)frow[c];
+      else if (!FP) {
+        if (c < C + 3) v = px[nb * 3 + (c - C)] - px[p * 3 + (c - C)];
+        else if (c < C + 6) v = px[nb * 3 + (c - C - 3)];
+        else if (c < C + 9) v = px[p * 3 + (c - C - 6)];
+      } else {
+        if (c == C) v = kd2[o + k];
+        else if (c == C + 1) {
+          float norm = 0.f;
+          for (int kk = 0; kk < K; ++kk) norm += 1.0f / (kd2[o + kk] + 1e-8f);
+          v = (1.0f / (kd2[o + k] + 1e-8f)) / norm;
+        } else if (c < C + 5) v = px[nb * 3 + (c - C - 2)];
+        else if (c < C + 8) v = px[nb * 3 + (c - C - 5)] - px[p * 3 + (c - C - 5)];
+        else if (c < C + 11) v = px[p * 3 + (c - C - 8)];
+      }
+      dst[j] = (T)v;
+    }
   }
 }
 
@@ -792,13 +951,45 @@ int launch_gemm(const GemmArgs &a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+template <int NPXL, int CBW, int NST, int BKT, bool AFF>
+int launch_gemm_glds(const GemmArgs &a, hipStream_t s) {
+  constexpr int NSAMP = (1 << NPXL) >= TM ? 1 : TM >> NPXL;
+  const size_t shm = (size_t)NST * (TM + 32 * CBW) * BKT * 2 + CBW * (sizeof(SlideEpi) + 96 * 4) + 16 +
+                     (AFF ? (size_t)NSAMP * 2 * a.k_pad * 2 : 0);
+  if (shm > 80 * 1024 && BKT == 32) return -8;  // two workgroups per CU must fit
+  const int ntc = (a.n_cob + CBW - 1) / CBW, ntr = (a.rows + TM - 1) / TM;
+  const int grid = ((ntr + 7) / 8) * 8 * ntc;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_glds_kernel<NPXL, CBW, NST, BKT, AFF>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024 * (BKT / 32));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_glds_kernel<NPXL, CBW, NST, BKT, AFF>), dim3(grid), dim3(256), shm, s, a);
+  return (int)hipGetLastError();
+}
+
 int run_gemm(const SlideOp &o, hipStream_t s) {
   GemmArgs a;
   a.X = o.p[0]; a.W = o.p[1]; a.epi = (const SlideEpi *)o.p[2];
   a.in_scale = (const float *)o.p[3]; a.in_shift = (const float *)o.p[4];
   a.rows = o.i[0]; a.x_ld = o.i[1]; a.k_pad = o.i[2]; a.n_cob = o.i[3]; a.in_bs = o.i[5];
-  const int npxl = o.i[4], prec = o.i[6], cbw = o.i[7];
+  const int npxl = o.i[4], prec = o.i[6], cbw = o.i[7], glds = o.i[8];
   if (a.k_pad % BK || a.x_ld % 8 || a.rows <= 0 || a.n_cob <= 0) return -3;
+  if (glds) {
+    if (prec != SLIDE_PREC_F16) return -7;
+    // i[9]: 0 = BK 32, three stages (two workgroups / CU); 1 = BK 64 (full 128-B lines), three stages (one / CU)
+    const int wide = o.i[9] && (a.k_pad % 64 == 0) && !a.in_scale;
+#define GCASE(L, C)                                                                                        \
+  if (npxl == L && cbw == C)                                                                               \
+    return wide ? launch_gemm_glds<L, C, 3, 64, false>(a, s) : launch_gemm_glds<L, C, 3, 32, false>(a, s)
+#define ACASE(L, C) if (npxl == L && cbw == C) return launch_gemm_glds<L, C, 3, 32, true>(a, s)
+    if (a.in_scale) { ACASE(7, 2); ACASE(8, 2); ACASE(7, 4); ACASE(8, 4); return -4; }
+    GCASE(4, 2); GCASE(7, 2); GCASE(8, 2); GCASE(4, 4); GCASE(7, 4); GCASE(8, 4);
+#undef ACASE
+#undef GCASE
+    return -4;
+  }
 #define CASE(P, L, C) if (prec == P && npxl == L && cbw == C) return launch_gemm<P, L, C>(a, s)
   CASE(SLIDE_PREC_F32, 4, 2); CASE(SLIDE_PREC_F32, 7, 2); CASE(SLIDE_PREC_F32, 8, 2);
   CASE(SLIDE_PREC_F16, 4, 2); CASE(SLIDE_PREC_F16, 7, 2); CASE(SLIDE_PREC_F16, 8, 2);
@@ -819,28 +1010,19 @@ int run_op(const SlideOp &o, hipStream_t s) {
         hipLaunchKernelGGL(prep_points_kernel<float>, dim3(o.i[0]), dim3(256), 0, s, o.i[1], o.i[2],
                            (const float *)o.p[0], (float *)o.p[1], (float *)o.p[2], (int *)o.p[3], (float *)o.p[4]);
       break;
-    case SLIDE_OP_ASSEMBLE_SA: {
-      const int work = 16 * o.i[4] * o.i[3];
-      if (o.i[5] == SLIDE_PREC_F16)
-        hipLaunchKernelGGL(assemble_sa_kernel<_Float16>, dim3(o.i[0], (work + 4095) / 4096), dim3(256), 0, s, o.i[1],
-                           o.i[2], o.i[3], o.i[4], (const float *)o.p[0], (const _Float16 *)o.p[1], (const int *)o.p[2],
-                           (_Float16 *)o.p[3]);
-      else
-        hipLaunchKernelGGL(assemble_sa_kernel<float>, dim3(o.i[0], (work + 4095) / 4096), dim3(256), 0, s, o.i[1],
-                           o.i[2], o.i[3], o.i[4], (const float *)o.p[0], (const float *)o.p[1], (const int *)o.p[2],
-                           (float *)o.p[3]);
-      break;
-    }
+    case SLIDE_OP_ASSEMBLE_SA:
     case SLIDE_OP_ASSEMBLE_FP: {
-      const int work = 16 * o.i[4] * o.i[3];
-      if (o.i[5] == SLIDE_PREC_F16)
-        hipLaunchKernelGGL(assemble_fp_kernel<_Float16>, dim3(o.i[0], (work + 4095) / 4096), dim3(256), 0, s, o.i[1],
-                           o.i[2], o.i[3], o.i[4], (const float *)o.p[0], (const _Float16 *)o.p[1], (const int *)o.p[2],
-                           (const float *)o.p[3], (_Float16 *)o.p[4]);
-      else
-        hipLaunchKernelGGL(assemble_fp_kernel<float>, dim3(o.i[0], (work + 4095) / 4096), dim3(256), 0, s, o.i[1],
-                           o.i[2], o.i[3], o.i[4], (const float *)o.p[0], (const float *)o.p[1], (const int *)o.p[2],
-                           (const float *)o.p[3], (float *)o.p[4]);
+      const bool fp = o.kind == SLIDE_OP_ASSEMBLE_FP;
+      const int work = 16 * o.i[4] * (o.i[3] / 8);
+      const dim3 g(o.i[0], (work + 1023) / 1024), blk(256);
+      const float *kd2 = fp ? (const float *)o.p[3] : nullptr;
+      void *dst = fp ? o.p[4] : o.p[3];
+#define ASM(TT, FPB)                                                                                                  \
+  hipLaunchKernelGGL((assemble_kernel<TT, FPB>), g, blk, 0, s, o.i[1], o.i[2], o.i[3], o.i[4], (const float *)o.p[0], \
+                     (const TT *)o.p[1], (const int *)o.p[2], kd2, (TT *)dst)
+      if (o.i[5] == SLIDE_PREC_F16) { if (fp) ASM(_Float16, true); else ASM(_Float16, false); }
+      else { if (fp) ASM(float, true); else ASM(float, false); }
+#undef ASM
       break;
     }
     case SLIDE_OP_FINALIZE_GN:

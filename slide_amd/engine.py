@@ -110,6 +110,9 @@ class DenoiserEngine:
         self.t_table = int(t_table)
         assert per_sample_t or t_table > 0
         self.adt = torch.float16 if self.prec == 1 else torch.float32  # activation storage type
+        import os as _os
+        self.use_glds = _os.environ.get("SLIDE_GLDS", "1") != "0"  # LDS-DMA GEMM variant for fp16 GEMMs
+        self.glds_nst = int(_os.environ.get("SLIDE_GLDS_WIDE", "0"))  # 1: 64-deep K chunks (full cache lines)
         self.sd = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)).astype(np.float32)
                    for k, v in state_dict.items()}
         arch = hp["architecture"]
@@ -241,7 +244,8 @@ class DenoiserEngine:
         ntr = (rows + 255) // 256
         cbw = 4 if (self.prec == 1 and n_cob >= 4 and ntr * ((n_cob + 3) // 4) >= 512) else 2
         self.gemm_flops[len(self.ops)] = 2 * rows * sum(int(s["w"].size) for s in segs)
-        self.ops.append(make_op(OP_GEMM, i=(rows, ld, ld, n_cob, npx_log2, in_bs, self.prec, cbw),
+        glds = int(self.use_glds and self.prec == 1 and (sc is None or npx_log2 >= 7))
+        self.ops.append(make_op(OP_GEMM, i=(rows, ld, ld, n_cob, npx_log2, in_bs, self.prec, cbw, glds, self.glds_nst),
                                 p=(X.data_ptr(), Wd.data_ptr(), ed.data_ptr(),
                                    None if sc is None else sc.data_ptr() + 4 * aff_off,
                                    None if sh is None else sh.data_ptr() + 4 * aff_off)))

@@ -15,6 +15,8 @@ class Mini(E.DenoiserEngine):
         self.adt = torch.float16 if self.prec == 1 else torch.float32
         self.A = E._Arena(dev); self.ops = []; self.flops = 0; self.gemm_flops = {}
         self.per_sample_t = True
+        self.use_glds = os.environ.get('SLIDE_GLDS', '1') != '0'
+        self.glds_nst = int(os.environ.get('SLIDE_GLDS_WIDE', '0'))
 
 
 def bench(rows, npxl, K, N, mode, prec="fp16", extras=(), reps=20):
