@@ -70,6 +70,7 @@ enum {
   SLIDE_OP_UPDATE_POS = 10, /* p: x, eps, noise(or NULL), t_dev, c_eps, sqrt_alpha, sigma  i: n_elem, -, seed_lo, seed_hi */
   SLIDE_OP_UPDATE_FEAT = 11,/* p: x, eps, noise(or NULL), t_dev, keypoint, c_recip, c_recipm1, c1, c2, c_std  i: n_pts, C, kdim, seed_lo, seed_hi  f: clamp */
   SLIDE_OP_ADVANCE_T = 12,  /* p: t_dev  (t_dev[0] -= 1; t_dev[1] += 1) */
+  SLIDE_OP_SYNC = 14,       /* i: from_lane, to_lane -- lane `to` waits for everything issued so far on lane `from` */
   SLIDE_OP_GROUPNORM_NCHW = 13 /* p: x, gamma, beta, y (NCHW fp32)   i: B, C, HW, G, n_norm, relu  (module-level path) */
 };
 
@@ -82,6 +83,10 @@ typedef struct SlideOp {
 
 /* launches ops[0..n) in order on `stream` (HOST array).  Safe inside hipGraph stream capture. */
 SLIDE_API int slide_run_ops(const SlideOp *ops, int n, slide_stream_t stream);
+/* two-lane variant: op.i[10] (0/1) picks the stream, SLIDE_OP_SYNC orders the lanes; independent branches of a plan
+ * (e.g. the query / score branch and the value branch of an attention block) then overlap, eagerly or as parallel
+ * branches of a captured hipGraph (capture on stream0; every lane must be joined back into lane 0 at the end). */
+SLIDE_API int slide_run_ops2(const SlideOp *ops, int n, slide_stream_t stream0, slide_stream_t stream1);
 
 /* same, eagerly, with a HIP event recorded on `stream` between consecutive launches; ms_out[i] (HOST, n floats)
  * receives the device time of ops[i].  Synchronises.  For per-kernel roofline figures, never on a timed path. */

@@ -1097,10 +1097,31 @@ int run_op(const SlideOp &o, hipStream_t s) {
 
 extern "C" {
 
-int slide_run_ops(const SlideOp *ops, int n, slide_stream_t stream) {
-  hipStream_t s = (hipStream_t)stream;
+int slide_run_ops(const SlideOp *ops, int n, slide_stream_t stream) { return slide_run_ops2(ops, n, stream, stream); }
+
+// Two-lane replay: op.i[10] selects the lane (stream); SLIDE_OP_SYNC(from, to) makes lane `to` wait for everything
+// issued so far on lane `from` (event record + stream wait -> a plain edge when captured into a hipGraph).
+int slide_run_ops2(const SlideOp *ops, int n, slide_stream_t stream0, slide_stream_t stream1) {
+  hipStream_t ss[2] = {(hipStream_t)stream0, (hipStream_t)stream1};
+  static hipEvent_t pool[256];
+  static int pool_n = 0, pool_next = 0;
   for (int i = 0; i < n; ++i) {
-    const int st = run_op(ops[i], s);
+    const SlideOp &o = ops[i];
+    if (o.kind == SLIDE_OP_SYNC) {
+      const int from = o.i[0] & 1, to = o.i[1] & 1;
+      if (ss[from] == ss[to]) continue;
+      if (pool_n < 256) {
+        if (hipEventCreateWithFlags(&pool[pool_n], hipEventDisableTiming) != hipSuccess) return -9;
+        ++pool_n;
+      }
+      hipEvent_t ev = pool[pool_next % pool_n];
+      pool_next = (pool_next + 1) % 256;
+      hipError_t e = hipEventRecord(ev, ss[from]);
+      if (e == hipSuccess) e = hipStreamWaitEvent(ss[to], ev, 0);
+      if (e != hipSuccess) return (int)e;
+      continue;
+    }
+    const int st = run_op(o, ss[o.i[10] & 1]);
     if (st != 0) return st > 0 ? st : st * 1000 - i;
   }
   return 0;
@@ -1116,7 +1137,7 @@ int slide_run_ops_timed(const SlideOp *ops, int n, slide_stream_t stream, float 
   for (int i = 0; i <= n; ++i) st |= (int)hipEventCreate(&ev[i]);
   if (st == 0) st = (int)hipEventRecord(ev[0], s);
   for (int i = 0; i < n && st == 0; ++i) {
-    st = run_op(ops[i], s);
+    if (ops[i].kind != SLIDE_OP_SYNC) st = run_op(ops[i], s);  // single-stream replay: syncs are no-ops
     if (st == 0) st = (int)hipEventRecord(ev[i + 1], s);
   }
   if (st == 0) st = (int)hipEventSynchronize(ev[n]);

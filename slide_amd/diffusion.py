@@ -64,6 +64,7 @@ class _GraphedSampler:
         self.B, self.device = int(batch), device
         self.use_graph = use_graph
         self.stream = torch.cuda.Stream(device=device)
+        self.stream2 = torch.cuda.Stream(device=device)  # second lane of the plan (independent branches overlap)
         self.graph = None
         self.step_ops = None
 
@@ -81,19 +82,20 @@ class _GraphedSampler:
         L = lib()
         with torch.cuda.stream(self.stream):
             s = ctypes.c_void_p(self.stream.cuda_stream)
+            s2 = ctypes.c_void_p(self.stream2.cuda_stream)
             if not self.use_graph:
                 for _ in range(n_steps):
-                    check(L.slide_run_ops(self.step_ops, len(self.step_ops), s), "slide_run_ops")
+                    check(L.slide_run_ops2(self.step_ops, len(self.step_ops), s, s2), "slide_run_ops")
                 return
             if self.graph is None:
                 # warm-up outside capture (first-use attribute calls are not capturable), then restore the state
                 x0, t0 = e.x.clone(), e.t_dev.clone()
-                check(L.slide_run_ops(self.step_ops, len(self.step_ops), s), "slide_run_ops")
-                self.stream.synchronize()
+                check(L.slide_run_ops2(self.step_ops, len(self.step_ops), s, s2), "slide_run_ops")
+                self.stream.synchronize(); self.stream2.synchronize()
                 e.x.copy_(x0); e.t_dev.copy_(t0)
                 self.stream.synchronize()
                 check(L.slide_graph_begin(s), "graph_begin")
-                st = L.slide_run_ops(self.step_ops, len(self.step_ops), s)
+                st = L.slide_run_ops2(self.step_ops, len(self.step_ops), s, s2)
                 g = ctypes.c_void_p()
                 st2 = L.slide_graph_end(s, ctypes.byref(g))
                 check(st, "slide_run_ops(capture)"); check(st2, "graph_end")

@@ -21,6 +21,7 @@ F_PRE_RELU, F_POST_RELU, F_OUT_F32 = 1, 2, 4
 PREC = {"fp32": 0, "fp16": 1}
 (OP_GEMM, OP_PREP_POINTS, OP_ASSEMBLE_SA, OP_ASSEMBLE_FP, OP_FINALIZE_GN, OP_ATTN_COMBINE, OP_COPY_COLS, OP_TEMB,
  OP_COND, OP_UPDATE_POS, OP_UPDATE_FEAT, OP_ADVANCE_T) = range(1, 13)
+OP_SYNC = 14
 
 
 class SlideEpi(ctypes.Structure):
@@ -127,6 +128,8 @@ class DenoiserEngine:
         self.t_dim = hp["t_dim"]
         self.A = _Arena(device)
         self.ops = []
+        self._lane = 0
+        self.two_lanes = _os.environ.get("SLIDE_TWO_LANES", "0") != "0"  # measured: no gain at batch 256
         self._tvec = []   # (name, width) of every Mlp .fc           -> offsets into the t vector
         self._cvec = []   # (name, width) of every Mlp .fc_condition -> offsets into the condition vector
         self._build()
@@ -138,6 +141,14 @@ class DenoiserEngine:
 
     def _buf(self, rows, ch, dtype=None):
         return self.A.zeros(rows, ru(ch), dtype=self.adt if dtype is None else dtype)
+
+    def _emit(self, op):
+        op.i[10] = self._lane if self.two_lanes else 0
+        self.ops.append(op)
+
+    def _sync(self, frm, to):
+        if self.two_lanes:
+            self.ops.append(make_op(OP_SYNC, i=(frm, to)))
 
     def _tvec_off(self, prefix, width):
         off = sum(w for _, w in self._tvec)
@@ -245,7 +256,7 @@ class DenoiserEngine:
         cbw = 4 if (self.prec == 1 and n_cob >= 4 and ntr * ((n_cob + 3) // 4) >= 512) else 2
         self.gemm_flops[len(self.ops)] = 2 * rows * sum(int(s["w"].size) for s in segs)
         glds = int(self.use_glds and self.prec == 1 and (sc is None or npx_log2 >= 7))
-        self.ops.append(make_op(OP_GEMM, i=(rows, ld, ld, n_cob, npx_log2, in_bs, self.prec, cbw, glds, self.glds_nst),
+        self._emit(make_op(OP_GEMM, i=(rows, ld, ld, n_cob, npx_log2, in_bs, self.prec, cbw, glds, self.glds_nst),
                                 p=(X.data_ptr(), Wd.data_ptr(), ed.data_ptr(),
                                    None if sc is None else sc.data_ptr() + 4 * aff_off,
                                    None if sh is None else sh.data_ptr() + 4 * aff_off)))
@@ -316,14 +327,20 @@ class DenoiserEngine:
         ssum, ssq = self.A.zeros(B, ldT), self.A.zeros(B, ldT)
         kseg = dict(w=self._w(apfx + ".grouped_feat_conv.weight"), bias=sd[apfx + ".grouped_feat_conv.bias"],
                     mode=EPI_STATS, flags=F_PRE_RELU, out=Tk, stats=(ssum, ssq, C1p, 1.0))
-        # shared-input GEMM: [first_mlp | res_connect | grouped_feat_conv]
-        self._gemm(g, npx_log2, [mlp_first, mlp_res, kseg])
+        # lane 1 (query / score branch) forks here: it only needs the module inputs
+        self._sync(0, 1)
+        self._lane = 1
         qseg = dict(w=self._w(apfx + ".feat_conv.weight"), bias=sd[apfx + ".feat_conv.bias"], mode=EPI_STATS,
                     flags=F_PRE_RELU, out=Tq, stats=(ssum, ssq, 0, float(K)))
         self._gemm(q_in, 4, [qseg])
+        self._lane = 0
+        # shared-input GEMM: [first_mlp | res_connect | grouped_feat_conv]
+        self._gemm(g, npx_log2, [mlp_first, mlp_res, kseg])
+        self._sync(0, 1)  # the key statistics are ready
 
-        def finish():
-            # GroupNorm over the concatenation [q | k] (weight_conv.1): groups may straddle the two producers
+        def finish_scores():
+            # lane 1.  GroupNorm over the concatenation [q | k] (weight_conv.1): groups may straddle the two producers
+            self._lane = 1
             Ct = C1 + C2
             G = min(32, Ct)
             n_norm = Ct - Ct % G
@@ -338,7 +355,7 @@ class DenoiserEngine:
             gend = np.array([phys[(gq + 1) * gs - 1] + 1 for gq in range(G)], np.int32)
             scale, shift = self.A.zeros(B, ldT), self.A.zeros(B, ldT)
             d = [self.A.put(a) for a in (gid, gstart, gend, gam, bet)]
-            self.ops.append(make_op(OP_FINALIZE_GN, i=(B, ldT, ldT), f=(1.0 / (gs * npx),),
+            self._emit(make_op(OP_FINALIZE_GN, i=(B, ldT, ldT), f=(1.0 / (gs * npx),),
                                     p=(ssum.data_ptr(), ssq.data_ptr(), d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(),
                                        d[3].data_ptr(), d[4].data_ptr(), scale.data_ptr(), shift.data_ptr())))
             lay = gn_layout(inter)
@@ -357,15 +374,21 @@ class DenoiserEngine:
             S = self._buf(rows, cout)
             self._gemm(u, npx_log2, [dict(w=self._w(apfx + ".weight_conv.5.weight"), bias=sd[apfx + ".weight_conv.5.bias"],
                                           mode=EPI_RAW, out=S)], in_cols=lay[0])
+            self._lane = 0
+            return S
+
+        def finish(S):
+            # lane 0 (value branch), then the join
             V = self._buf(rows, cout)
             self._gemm(mo, npx_log2, [dict(w=self._w(apfx + ".feat_out_conv.0.weight"), bias=sd[apfx + ".feat_out_conv.0.bias"],
                                            mode=EPI_NORM, flags=F_POST_RELU, layout=gn_layout(cout), out=V,
                                            gn=(sd[apfx + ".feat_out_conv.1.group_norm.weight"],
                                                sd[apfx + ".feat_out_conv.1.group_norm.bias"]))])
             assert out.dtype == self.adt
-            self.ops.append(make_op(OP_ATTN_COMBINE, i=(rows // K, cout, S.shape[1], V.shape[1], out.shape[1], K, self.prec),
+            self._sync(1, 0)
+            self._emit(make_op(OP_ATTN_COMBINE, i=(rows // K, cout, S.shape[1], V.shape[1], out.shape[1], K, self.prec),
                                     p=(S.data_ptr(), V.data_ptr(), out.data_ptr())))
-        return finish, cout
+        return (finish_scores, finish), cout
 
     def _sa_module(self, i, feat_in, C):
         sd, B = self.sd, self.B
@@ -376,16 +399,17 @@ class DenoiserEngine:
         Cg = C + 9
         assert sd[mp + ".first_mlp.0.weight"].shape[1] == Cg
         g = self._buf(rows, Cg)
-        self.ops.append(make_op(OP_ASSEMBLE_SA, i=(B, C, feat_in.shape[1], g.shape[1], K, self.prec),
+        self._emit(make_op(OP_ASSEMBLE_SA, i=(B, C, feat_in.shape[1], g.shape[1], K, self.prec),
                                 p=(self.xyz.data_ptr(), feat_in.data_ptr(), self.kidx.data_ptr(), g.data_ptr())))
         c1 = sd[mp + ".first_mlp.0.weight"].shape[0]
         c_last = sd[mp + ".res_connect.weight"].shape[0]
         h1, r, mo = self._buf(rows, c1), self._buf(rows, c_last), self._buf(rows, c_last)
         first, res = self._mlp_segments(mp, self.tvec, self.cvec, h1, r)
         out = self._buf(B * 16, c_last)
-        finish, cout = self._attention(ap, 8, K, g, feat_in, mo, first, res, out, None)
-        self._mlp_tail(mp, 8, h1, self.cvec, r, mo)
-        finish()
+        (scores, finish), cout = self._attention(ap, 8, K, g, feat_in, mo, first, res, out, None)
+        S = scores()                                  # lane 1: finalize, P, weight_conv.2, weight_conv.5
+        self._mlp_tail(mp, 8, h1, self.cvec, r, mo)   # lane 0: second / rest mlp
+        finish(S)                                     # lane 0: values; join; softmax-combine
         return out, cout
 
     def _fp_module(self, j, U, CU, Kf, C2, out_buf=None):
@@ -398,7 +422,7 @@ class DenoiserEngine:
         Cg = C2 + 11
         assert sd[m1 + ".first_mlp.0.weight"].shape[1] == Cg
         g = self._buf(rows, Cg)
-        self.ops.append(make_op(OP_ASSEMBLE_FP, i=(B, C2, Kf.shape[1], g.shape[1], K, self.prec),
+        self._emit(make_op(OP_ASSEMBLE_FP, i=(B, C2, Kf.shape[1], g.shape[1], K, self.prec),
                                 p=(self.xyz.data_ptr(), Kf.data_ptr(), self.kidx.data_ptr(), self.kd2.data_ptr(),
                                    g.data_ptr())))
         c1 = sd[m1 + ".first_mlp.0.weight"].shape[0]
@@ -409,13 +433,14 @@ class DenoiserEngine:
         zin = c_last + CU + 3
         assert sd[m2 + ".first_mlp.0.weight"].shape[1] == zin
         Z = self._buf(B * 16, zin)
-        finish, cout = self._attention(ap, 7, K, g, U, mo, first, res, Z, None)
+        (scores, finish), cout = self._attention(ap, 7, K, g, U, mo, first, res, Z, None)
+        S = scores()
         self._mlp_tail(m1, 7, h1, self.cvec, r, mo)
-        finish()
+        finish(S)
         es = Z.element_size()
-        self.ops.append(make_op(OP_COPY_COLS, i=(B * 16, CU, U.shape[1], Z.shape[1], int(self.prec == 1), int(self.prec == 1)),
+        self._emit(make_op(OP_COPY_COLS, i=(B * 16, CU, U.shape[1], Z.shape[1], int(self.prec == 1), int(self.prec == 1)),
                                 p=(U.data_ptr(), Z.data_ptr() + es * c_last)))
-        self.ops.append(make_op(OP_COPY_COLS, i=(B * 16, 3, 3, Z.shape[1], 0, int(self.prec == 1)),
+        self._emit(make_op(OP_COPY_COLS, i=(B * 16, 3, 3, Z.shape[1], 0, int(self.prec == 1)),
                                 p=(self.xyz.data_ptr(), Z.data_ptr() + es * (c_last + CU))))
         n1 = sd[m2 + ".first_mlp.0.weight"].shape[0]
         n2 = sd[m2 + ".res_connect.weight"].shape[0]
@@ -454,7 +479,7 @@ class DenoiserEngine:
         if self.per_sample_t:
             temb_slot = len(self.ops)
             self.ops.append(None)  # TEMB placeholder (needs the .fc order of the walk)
-        self.ops.append(make_op(OP_PREP_POINTS, i=(B, self.cx, self.feat0.shape[1], self.prec),
+        self._emit(make_op(OP_PREP_POINTS, i=(B, self.cx, self.feat0.shape[1], self.prec),
                                 p=(self.x.data_ptr(), self.xyz.data_ptr(), self.feat0.data_ptr(), self.kidx.data_ptr(),
                                    self.kd2.data_ptr())))
         feats, chans = [self.feat0], [C0]
@@ -474,7 +499,7 @@ class DenoiserEngine:
             feats[i - 1], chans[i - 1] = o, c
         # output head fc_lyaer (pointnet2_with_pcld_condition.py:480-483): conv -> GN(32,128) -> ReLU -> conv
         c = chans[0]
-        self.ops.append(make_op(OP_COPY_COLS, i=(B * 16, 3, 3, dec0.shape[1], 0, int(self.prec == 1)),
+        self._emit(make_op(OP_COPY_COLS, i=(B * 16, 3, 3, dec0.shape[1], 0, int(self.prec == 1)),
                                 p=(self.xyz.data_ptr(), dec0.data_ptr() + dec0.element_size() * c)))
         hh = self._buf(B * 16, sd["fc_lyaer.0.weight"].shape[0])
         assert sd["fc_lyaer.0.weight"].shape[1] == c + 3
@@ -484,7 +509,7 @@ class DenoiserEngine:
         self.eps_pad = self._buf(B * 16, self.out_dim, dtype=torch.float32)
         self._gemm(hh, 4, [dict(w=self._w("fc_lyaer.3.weight"), bias=sd["fc_lyaer.3.bias"], mode=EPI_RAW, out=self.eps_pad)])
         self.eps = A.zeros(B, 16, self.out_dim)
-        self.ops.append(make_op(OP_COPY_COLS, i=(B * 16, self.out_dim, self.eps_pad.shape[1], self.out_dim, 0, 0),
+        self._emit(make_op(OP_COPY_COLS, i=(B * 16, self.out_dim, self.eps_pad.shape[1], self.out_dim, 0, 0),
                                 p=(self.eps_pad.data_ptr(), self.eps.data_ptr())))
         # t-embedding MLP + all .fc layers, class embedding + all .fc_condition layers (input-major weights)
         assert sum(w for _, w in self._tvec) == n_fc and sum(w for _, w in self._cvec) == n_fcc
@@ -523,7 +548,10 @@ class DenoiserEngine:
     def run(self, ops_array, n=None):
         if self.x.device.type != "cuda":
             raise SlideHipError("DenoiserEngine plans only run on a GPU; there is no CPU fallback")
-        check(lib().slide_run_ops(ops_array, len(ops_array) if n is None else n, self._stream()), "slide_run_ops")
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.x.device)
+        check(lib().slide_run_ops2(ops_array, len(ops_array) if n is None else n, self._stream(),
+                                   ctypes.c_void_p(self._side.cuda_stream)), "slide_run_ops2")
 
     def prepare(self):
         """sampler mode: fill the per-timestep t-embedding table (once)"""
