@@ -258,9 +258,11 @@ def denoiser_forward(hp, sd, pointcloud, ts, label):
         pc = np.concatenate([pc, pc[:, :, 0:3]], axis=2)  # :332-334 (scale_factor == 1)
     xyz = np.ascontiguousarray(pc[..., 0:3])
     features = np.ascontiguousarray(pc[..., 3:].transpose(0, 2, 1)) if pc.shape[-1] > 3 else None
-    t_emb = calc_t_emb(ts, hp["t_dim"])
-    t_emb = swish(linear(t_emb, sd["fc_t1.weight"], sd["fc_t1.bias"]))
-    t_emb = swish(linear(t_emb, sd["fc_t2.weight"], sd["fc_t2.bias"]))
+    t_emb = None
+    if ts is not None and hp["include_t"]:
+        t_emb = calc_t_emb(ts, hp["t_dim"])
+        t_emb = swish(linear(t_emb, sd["fc_t1.weight"], sd["fc_t1.bias"]))
+        t_emb = swish(linear(t_emb, sd["fc_t2.weight"], sd["fc_t2.bias"]))
     class_emb = sd["class_emb.weight"][label.astype(np.int64)].astype(F32)
 
     l_xyz, l_features = [xyz], [features]
@@ -272,11 +274,81 @@ def denoiser_forward(hp, sd, pointcloud, ts, label):
     for i in range(-1, -(nfp + 1), -1):
         l_features[i - 1] = knn_fp_module(l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i], sd,
                                           "FP_modules.%d" % (nfp + i), arch["K"], t_emb, class_emb)
+    if not hp.get("transform_output", True):  # :484-485: per-point features (autoencoder decoder levels)
+        return np.ascontiguousarray(l_features[0].transpose(0, 2, 1)).astype(F32)
     out = np.concatenate([l_features[0], xyz.transpose(0, 2, 1)], axis=1)
     out = conv1x1(out, sd["fc_lyaer.0.weight"], sd["fc_lyaer.0.bias"])
     out = relu(group_norm(out, 32, sd["fc_lyaer.1.weight"], sd["fc_lyaer.1.bias"]))
     out = conv1x1(out, sd["fc_lyaer.3.weight"], sd["fc_lyaer.3.bias"])
     return np.ascontiguousarray(out.transpose(0, 2, 1)).astype(F32)
+
+
+# ----------------------------------------------------------------------------- autoencoder decode (config 5)
+def feature_map_module(xyz, features, new_xyz, feats_at_new_xyz, sd, prefix, K):
+    """FeatureMapModule.forward (OPS/pointnet2_modules.py:642-663): cross-set kNN grouping (subset=False) -> Mlp (no t /
+    condition) -> attention with the new points' own features as queries."""
+    grouped, _, _ = query_and_group(xyz, new_xyz, features, 0, K, "nn", True, True, True, subset=False)
+    out = mlp_plus_t_emb(grouped, sd, prefix + ".mlp")
+    return attention_module(feats_at_new_xyz, grouped, out, sd, prefix + ".attention_module")
+
+
+def point_upsample(coarse, displacement, factor, output_scale):
+    """P2/models/point_upsample_module.py:4-46, first_refine_coarse_points False (all shipped decoder configs)"""
+    B, N, Fd = coarse.shape
+    grid = (displacement * F32(1 / np.sqrt(factor))).reshape(B, N, factor, Fd)
+    return np.ascontiguousarray((coarse[:, :, None, :] + grid * F32(output_scale)).reshape(B, N * factor, Fd)).astype(F32)
+
+
+def upsample_points(hp, sd, prefix, final_feature, new_xyz, fps_start=None):
+    """PointUpsampleDecoder.upsample_points (P2/models/point_upsample_decoder.py:149-182)"""
+    up = hp["upsampling_setting"]
+    assert not up["first_refine_coarse_points"]
+    x = np.concatenate([final_feature, new_xyz], axis=2).transpose(0, 2, 1)
+    split = conv1x1(x, sd[prefix + ".fc_layer.weight"], sd[prefix + ".fc_layer.bias"]).transpose(0, 2, 1)
+    in_dim = hp.get("in_position_and_normal_dim", hp["out_dim"])
+    coarse = new_xyz[:, :, :in_dim]
+    if in_dim < hp["out_dim"]:
+        coarse = np.concatenate([coarse, np.zeros(coarse.shape[:2] + (hp["out_dim"] - in_dim,), F32)], axis=2)
+    pts = point_upsample(coarse.astype(F32), split, up["point_upsample_factor"], up["output_scale_factor"])
+    if pts.shape[1] > up["num_output_points"]:
+        pts, _ = ops.sample_farthest_points(pts, up["num_output_points"], fps_start)
+    return pts.astype(F32)
+
+
+def decode_level(cfg, sd, pfx, xyz_prev, feats_prev, new_xyz, label, fps_start=None):
+    """PointUpsampleDecoder.forward (P2/models/point_upsample_decoder.py:184-190) for a level whose feature extractor is
+    a PointNet2CloudCondition: -> (features at new_xyz [extracted | mapped], upsampled points)"""
+    sub = {k[len(pfx) + len(".feature_extractor."):]: v for k, v in sd.items() if k.startswith(pfx + ".feature_extractor.")}
+    out = denoiser_forward(cfg, sub, new_xyz, None, label)
+    mapped = feature_map_module(xyz_prev[:, :, :3], np.ascontiguousarray(feats_prev.transpose(0, 2, 1)),
+                                np.ascontiguousarray(new_xyz[:, :, :3]), out.transpose(0, 2, 1), sd, pfx + ".feature_mapper",
+                                cfg["feature_mapper_setting"]["nsample"])
+    feats = np.concatenate([out, mapped.transpose(0, 2, 1)], axis=2).astype(F32)
+    return feats, upsample_points(cfg, sd, pfx, feats, new_xyz, fps_start)
+
+
+def autoencoder_decode(decoder_cfgs, sd, keypoint, feature, label, fps_start=None):
+    """PointAutoencoder.decode (P2/models/autoencoder.py:42-45) + KeypointDecoder.forward (P2/models/keypoint_decoder.py:
+    25-36); the random FPS start index is an explicit argument.  -> [keypoints, level1, level2, level3]"""
+    new_xyz = upsample_points(decoder_cfgs[0], sd, "keypoint_encoder", feature, keypoint, fps_start)
+    l_xyz, feats = [keypoint[:, :, :3], new_xyz], feature
+    for i, cfg in enumerate(decoder_cfgs[1:]):
+        feats, pts = decode_level(cfg, sd, "decoder.decoders.%d" % i, l_xyz[i], feats, l_xyz[i + 1], label, fps_start)
+        l_xyz.append(pts)
+    return l_xyz
+
+
+def match_point_sets(a, b):
+    """max 6-d distance between every point of a (N,C) and its nearest (xyz) point of b, and whether the matching is a
+    bijection -- FPS *selection order* is fragile under 1e-7 perturbations, the selected SET is not"""
+    d = ((a[:, None, :3].astype(np.float64) - b[None, :, :3].astype(np.float64)) ** 2).sum(-1)
+    j = d.argmin(1)
+    return float(np.abs(a - b[j]).max()), len(set(j.tolist())) == a.shape[0]
+
+
+def chamfer(a, b):
+    d = ((a[:, None, :3].astype(np.float64) - b[None, :, :3].astype(np.float64)) ** 2).sum(-1)
+    return float(d.min(1).mean() + d.min(0).mean())
 
 
 # ----------------------------------------------------------------------------- samplers

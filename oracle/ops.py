@@ -155,3 +155,16 @@ def knn_gather(x, idx):
     out = np.zeros((b, n1, K, u), np.float32)
     lib().ora_knn_gather(b, n2, u, n1, K, xp, ip, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
     return out
+
+
+def sample_farthest_points(points, K, start_idx=None):
+    """-> (selected points (B,K,C), idx int64 (B,K)); FPS runs on the first three channels"""
+    pts3, pp = _f(points[:, :, 0:3])
+    b, n, _ = pts3.shape
+    idx = np.zeros((b, K), np.int32)
+    sp = None
+    if start_idx is not None:
+        start_idx, sp = _i(start_idx)
+    lib().ora_sample_farthest_points(b, n, int(K), pp, sp, idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    idx = idx.astype(np.int64)
+    return np.take_along_axis(np.asarray(points), idx[..., None], axis=1), idx

@@ -294,3 +294,31 @@ ORA_API void ora_knn_gather(int b, int n2, int u, int n1, int K, const float *x,
                sizeof(float) * (size_t)u);
       }
 }
+
+/* pytorch3d 0.7.0 `sample_farthest_points` (third-party; call site pointnet2/models/point_upsample_decoder.py:178-180):
+ * plain iterative farthest point sampling -- no near-origin skip, first index = start[b] (random in the reference,
+ * hence parity there is distributional only), running min of squared distances, argmax with ties -> lowest index
+ * (this repo's definition). */
+ORA_API void ora_sample_farthest_points(int b, int n, int K, const float *points, const int *start, int *idx) {
+  float *md = (float *)malloc(sizeof(float) * (size_t)n);
+  for (int bi = 0; bi < b; ++bi) {
+    const float *p = points + (size_t)bi * n * 3;
+    int *o = idx + (size_t)bi * K;
+    for (int k = 0; k < n; ++k) md[k] = 1e10f;
+    int old = start ? start[bi] : 0;
+    o[0] = old;
+    for (int j = 1; j < K; ++j) {
+      float best = -1.0f;
+      int besti = 0;
+      for (int k = 0; k < n; ++k) {
+        const float d = sqdist3(p[k * 3], p[k * 3 + 1], p[k * 3 + 2], p[old * 3], p[old * 3 + 1], p[old * 3 + 2]);
+        const float d2 = d < md[k] ? d : md[k];
+        md[k] = d2;
+        if (d2 > best) { best = d2; besti = k; }
+      }
+      old = besti;
+      o[j] = old;
+    }
+  }
+  free(md);
+}

@@ -62,8 +62,10 @@ class PointNet2CloudCondition(nn.Module):
                                                        K=arch.get("K", 3), first_conv=False,
                                                        include_grouper=arch.get("include_grouper", False),
                                                        radius=arch["radius"][i], nsample=arch["nsample"][i], **common))
-        self.fc_lyaer = nn.Sequential(HipConv1x1(d[0] + 3, 128, bias=hp["bias"], ndim=1), HipGroupNorm(32, 128), nn.ReLU(True),
-                                      HipConv1x1(128, hp["out_dim"], ndim=1))
+        self.transform_output = hp.get("transform_output", True)
+        if self.transform_output:
+            self.fc_lyaer = nn.Sequential(HipConv1x1(d[0] + 3, 128, bias=hp["bias"], ndim=1), HipGroupNorm(32, 128),
+                                          nn.ReLU(True), HipConv1x1(128, hp["out_dim"], ndim=1))
         self._engines = {}
 
     def _break_up_pc(self, pc):
@@ -88,6 +90,8 @@ class PointNet2CloudCondition(nn.Module):
         for i in range(-1, -(len(self.FP_modules) + 1), -1):
             l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i], t_emb=t_emb,
                                                    condition_emb=cond)
+        if not self.transform_output:  # feature-extractor use (autoencoder decoder levels): per-point features
+            return l_features[0].transpose(1, 2).contiguous()
         out = torch.cat([l_features[0], xyz.transpose(1, 2)], dim=1)
         h = self.fc_lyaer[0](out)
         h = self.fc_lyaer[1](h, relu=True)

@@ -186,3 +186,25 @@ def knn_gather(x, idx):
     out = torch.empty((B, N1, K, U), device=x.device, dtype=torch.float32)
     check(lib().slide_knn_gather(B, N2, U, N1, K, ptr(x), ptr(idx), ptr(out), stream_of()), "knn_gather")
     return out
+
+
+def sample_farthest_points(points, lengths=None, K=50, random_start_point=False, start_idx=None):
+    """pytorch3d.ops.sample_farthest_points counterpart (call site point_upsample_decoder.py:178-180):
+    -> (selected points (B,K,C), idx int64 (B,K)).  FPS on points[..., :3]; `random_start_point` draws the first index
+    from torch's device generator (the reference's results are therefore only distributionally reproducible)."""
+    assert lengths is None
+    _need_gpu(points)
+    xyz = points[:, :, 0:3].contiguous().float()
+    B, N, _ = xyz.shape
+    if start_idx is None and random_start_point:
+        start_idx = torch.randint(0, N, (B,), device=points.device)
+    sp = None
+    if start_idx is not None:
+        start_idx = start_idx.to(device=points.device, dtype=torch.int32).contiguous()
+        sp = ptr(start_idx)
+    idx = torch.zeros((B, K), device=points.device, dtype=torch.int32)
+    tmp = torch.full((B, N), 1e10, device=points.device, dtype=torch.float32)
+    check(lib().slide_sample_farthest_points(B, N, int(K), ptr(xyz), sp, ptr(tmp), ptr(idx), stream_of()),
+          "sample_farthest_points")
+    idx = idx.long()
+    return torch.gather(points, 1, idx.unsqueeze(-1).expand(-1, -1, points.shape[2])), idx

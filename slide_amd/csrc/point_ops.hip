@@ -61,8 +61,8 @@ __device__ __forceinline__ int fps_unrank(unsigned r, int bs, int lg, int L) {
 }
 
 template <int PPT, int NT>
-__global__ __launch_bounds__(NT) void fps_kernel(int n, int m, int bs, int lg, int L, int use_lds,
-                                                 const float *__restrict__ dataset,
+__global__ __launch_bounds__(NT) void fps_kernel(int n, int m, int bs, int lg, int L, int use_lds, int skip_origin,
+                                                 const int *__restrict__ start, const float *__restrict__ dataset,
                                                  float *__restrict__ temp, int *__restrict__ idxs) {
   extern __shared__ __attribute__((aligned(16))) float spts[];
   __shared__ unsigned long long wkeys[2][NT / 64 > 0 ? NT / 64 : 1];
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(NT) void fps_kernel(int n, int m, int bs, int lg, i
       pz[i] = dataset[k * 3 + 2];
       td[i] = temp[k];
       const float mag = fmaf(pz[i], pz[i], fmaf(py[i], py[i], px[i] * px[i]));
-      valid[i] = !((double)mag <= 1e-3);  // sampling_gpu.cu:100-101 (double literal)
+      valid[i] = !skip_origin || !((double)mag <= 1e-3);  // sampling_gpu.cu:100-101 (double literal)
       low[i] = 0xFFFFFFFFu - fps_rank(k, bs, lg, L);
       if (use_lds) {
         spts[k * 3 + 0] = px[i];
@@ -97,8 +97,8 @@ __global__ __launch_bounds__(NT) void fps_kernel(int n, int m, int bs, int lg, i
     }
   }
   const float *src = use_lds ? spts : dataset;
-  int old = 0;
-  if (tid == 0) idxs[0] = 0;
+  int old = start ? start[b] : 0;
+  if (tid == 0) idxs[0] = old;
   __syncthreads();
   for (int j = 1; j < m; ++j) {
     const float x1 = src[old * 3 + 0], y1 = src[old * 3 + 1], z1 = src[old * 3 + 2];
@@ -141,7 +141,8 @@ __global__ __launch_bounds__(NT) void fps_kernel(int n, int m, int bs, int lg, i
 }
 
 // n > 8192: running distances stay in global memory (rarely used; decode tops out at 4096 points)
-__global__ __launch_bounds__(1024) void fps_kernel_large(int n, int m, int bs, int lg, int L,
+__global__ __launch_bounds__(1024) void fps_kernel_large(int n, int m, int bs, int lg, int L, int skip_origin,
+                                                         const int *__restrict__ start,
                                                          const float *__restrict__ dataset,
                                                          float *__restrict__ temp, int *__restrict__ idxs) {
   __shared__ unsigned long long wkeys[2][16];
@@ -149,15 +150,15 @@ __global__ __launch_bounds__(1024) void fps_kernel_large(int n, int m, int bs, i
   dataset += (size_t)b * n * 3;
   temp += (size_t)b * n;
   idxs += (size_t)b * m;
-  int old = 0;
-  if (tid == 0) idxs[0] = 0;
+  int old = start ? start[b] : 0;
+  if (tid == 0) idxs[0] = old;
   for (int j = 1; j < m; ++j) {
     const float x1 = dataset[old * 3 + 0], y1 = dataset[old * 3 + 1], z1 = dataset[old * 3 + 2];
     unsigned long long best = 0ull;
     for (int k = tid; k < n; k += 1024) {
       const float x2 = dataset[k * 3 + 0], y2 = dataset[k * 3 + 1], z2 = dataset[k * 3 + 2];
       const float mag = fmaf(z2, z2, fmaf(y2, y2, x2 * x2));
-      if ((double)mag <= 1e-3) continue;
+      if (skip_origin && (double)mag <= 1e-3) continue;
       const float d2 = fminf(sqdist3(x2, y2, z2, x1, y1, z1), temp[k]);
       temp[k] = d2;
       const unsigned long long key = ((unsigned long long)(__float_as_uint(d2) + 1u) << 32) |
@@ -461,18 +462,15 @@ int gather_points_grad_kernel_wrapper(int b, int c, int n, int npoints, const fl
   return LAUNCH_STATUS();
 }
 
-int furthest_point_sampling_kernel_wrapper(int b, int n, int m, const float *dataset, float *temp,
-                                           int *idxs, slide_stream_t stream) {
-  if (b <= 0 || m <= 0 || n <= 0) return 0;
-  const int bs = opt_n_threads(n);
+static int fps_launch(int b, int n, int m, int bs, int skip_origin, const int *start, const float *dataset,
+                      float *temp, int *idxs, hipStream_t s) {
   const int lg = ilog2(bs);
   const int L = (n + bs - 1) / bs;
-  hipStream_t s = (hipStream_t)stream;
   const int use_lds = (size_t)n * 12 <= 60000;
   const size_t shm = use_lds ? (size_t)n * 12 : 0;
-#define FPS_LAUNCH(PPT, NT)                                                                               \
-  hipLaunchKernelGGL((fps_kernel<PPT, NT>), dim3(b), dim3(NT), shm, s, n, m, bs, lg, L, use_lds, dataset, \
-                     temp, idxs)
+#define FPS_LAUNCH(PPT, NT)                                                                                   \
+  hipLaunchKernelGGL((fps_kernel<PPT, NT>), dim3(b), dim3(NT), shm, s, n, m, bs, lg, L, use_lds, skip_origin, \
+                     start, dataset, temp, idxs)
   if (n <= 64) FPS_LAUNCH(1, 64);
   else if (n <= 256) FPS_LAUNCH(1, 256);
   else if (n <= 512) FPS_LAUNCH(2, 256);
@@ -481,9 +479,23 @@ int furthest_point_sampling_kernel_wrapper(int b, int n, int m, const float *dat
   else if (n <= 4096) FPS_LAUNCH(16, 256);
   else if (n <= 8192) FPS_LAUNCH(32, 256);
   else
-    hipLaunchKernelGGL(fps_kernel_large, dim3(b), dim3(1024), 0, s, n, m, bs, lg, L, dataset, temp, idxs);
+    hipLaunchKernelGGL(fps_kernel_large, dim3(b), dim3(1024), 0, s, n, m, bs, lg, L, skip_origin, start, dataset, temp,
+                       idxs);
 #undef FPS_LAUNCH
   return LAUNCH_STATUS();
+}
+
+int furthest_point_sampling_kernel_wrapper(int b, int n, int m, const float *dataset, float *temp, int *idxs,
+                                           slide_stream_t stream) {
+  if (b <= 0 || m <= 0 || n <= 0) return 0;
+  return fps_launch(b, n, m, opt_n_threads(n), 1, nullptr, dataset, temp, idxs, (hipStream_t)stream);
+}
+
+int slide_sample_farthest_points(int b, int n, int K, const float *points, const int *start_idx, float *temp, int *idx,
+                                 slide_stream_t stream) {
+  if (b <= 0 || K <= 0 || n <= 0) return 0;
+  // plain FPS: no near-origin skip; ties -> lowest index (rank == k with a virtual block size of 1)
+  return fps_launch(b, n, K, 1, 0, start_idx, points, temp, idx, (hipStream_t)stream);
 }
 
 int query_ball_point_kernel_wrapper(int b, int n, int m, float radius, int nsample, const float *new_xyz,

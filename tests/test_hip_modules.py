@@ -81,3 +81,54 @@ def test_denoiser_module_path_and_state_dict(gpu_device, name):
         assert np.abs(y - ref).max() <= 2e-4 * np.abs(ref).max(), k
         yf = net(x, ts=ts, label=lab, fused=True).cpu().numpy()
         assert np.abs(yf - ref).max() <= 2e-4 * np.abs(ref).max(), k
+
+
+def test_autoencoder_decode_matches_reference(gpu_device):
+    """config 5: latents -> 256 -> 1024 -> 2048 x 6 on the HIP module path vs the reference's decode (FPS start index 0)."""
+    sys.path.insert(0, os.path.join(REPO, "pointnet2"))
+    from models.autoencoder import PointAutoencoder
+    from oracle import denoiser_np as D
+    g = load_golden("golden_decode.npz")
+    decs = json.loads(str(g["decoder_configs_json"]))
+    spec = golden_spec(g)
+    ae = PointAutoencoder(None, decs, apply_kl_regularization=True)
+    assert {k: tuple(v.shape) for k, v in ae.state_dict().items()} == dict(spec)  # decode-side checkpoint compatibility
+    vals = synth_state_dict([("ae." + n, s) for n, s in spec])
+    ae.load_state_dict({n: torch.from_numpy(vals["ae." + n]) for n, _ in spec})
+    ae = ae.to(gpu_device).eval()
+    d = gpu_device
+    kp, feat, lab = T(g["keypoint"], d), T(g["feature"], d), T(g["label"], d)
+    B = kp.shape[0]
+    start = torch.zeros(B, dtype=torch.int32, device=d)
+    l1 = ae.keypoint_encoder.upsample_points(feat, kp, start)
+    assert np.abs(l1.cpu().numpy() - g["level1"]).max() <= 1e-5
+    # level by level, each fed with the reference's previous level (FPS selection order is perturbation-fragile)
+    f2, l2 = ae.decoder.decoders[0](kp, feat, T(g["level1"], d), label=lab, fps_start_idx=start)
+    f3, l3 = ae.decoder.decoders[1](T(g["level1"], d)[:, :, :3].contiguous(), f2, T(g["level2"], d), label=lab, fps_start_idx=start)
+    for b in range(B):
+        err, bij = D.match_point_sets(l2[b].cpu().numpy(), g["level2"][b])
+        assert bij and err <= 1e-4, ("level2", err)
+        err, bij = D.match_point_sets(l3[b].cpu().numpy(), g["level3"][b])
+        assert bij and err <= 1e-4, ("level3", err)
+    # end to end (own previous levels, own FPS order): Chamfer vs the reference cloud
+    full = ae.decode(kp, feat, label=lab, fps_start_idx=start).cpu().numpy()
+    assert full.shape == (B, 2048, 6)
+    cd = max(D.chamfer(full[b], g["level3"][b]) for b in range(B))
+    print("decode end-to-end Chamfer (sum of both directions, squared) vs reference: %.3e" % cd)
+    assert cd <= 1e-5
+    # random-start variant runs and stays on the same surface
+    full_r = ae.decode(kp, feat, label=lab).cpu().numpy()
+    assert max(D.chamfer(full_r[b], g["level3"][b]) for b in range(B)) <= 1e-3
+
+
+def test_sample_farthest_points(gpu_device):
+    from oracle import ops as O
+    from slide_amd import _ext
+    rs = np.random.RandomState(4)
+    for (B, n, K) in [(2, 512, 256), (3, 2048, 1024), (1, 4096, 2048), (2, 100, 100)]:
+        p = rs.uniform(-1, 1, (B, n, 6)).astype(np.float32)
+        p[:, 5] = p[:, 1]
+        start = rs.randint(0, n, B).astype(np.int32)
+        ro, ri = O.sample_farthest_points(p, K, start)
+        go, gi = _ext.sample_farthest_points(T(p, gpu_device), K=K, start_idx=torch.from_numpy(start))
+        assert np.array_equal(gi.cpu().numpy(), ri) and np.array_equal(go.cpu().numpy(), ro)

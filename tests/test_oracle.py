@@ -238,3 +238,23 @@ def test_feature_sampler_against_reference():
                            t_start=int(g["tail_curr_step"]) - 1)
     assert ns.count == int(g["tail_ndraws"])
     assert np.abs(x - g["tail_x0"]).max() <= 1e-3 * np.abs(g["tail_x0"]).max()
+
+
+def test_autoencoder_decode_against_reference():
+    """PointAutoencoder.decode levels (config 5) vs the reference's output.  Farthest-point-sampling SELECTION ORDER is
+    fragile under 1e-7 perturbations (the selected set is not), so levels are compared as point sets, each level fed with
+    the reference's previous-level points."""
+    g = load_golden("golden_decode.npz")
+    decs = json.loads(str(g["decoder_configs_json"]))
+    spec = golden_spec(g)
+    vals = synth_state_dict([("ae." + n, s) for n, s in spec])
+    sd = {n: vals["ae." + n] for n, _ in spec}
+    kp, feat, lab = g["keypoint"][:1], g["feature"][:1], g["label"][:1]
+    l1 = D.upsample_points(decs[0], sd, "keypoint_encoder", feat, kp)
+    assert np.abs(l1 - g["level1"][:1]).max() <= 1e-6
+    f2, l2 = D.decode_level(decs[1], sd, "decoder.decoders.0", kp, feat, g["level1"][:1], lab)
+    err, bij = D.match_point_sets(l2[0], g["level2"][0])
+    assert bij and err <= 1e-5, err
+    f3, l3 = D.decode_level(decs[2], sd, "decoder.decoders.1", g["level1"][:1], f2, g["level2"][:1], lab)
+    err, bij = D.match_point_sets(l3[0], g["level3"][0])
+    assert bij and err <= 1e-5 and l3.shape == (1, 2048, 6), err

@@ -269,6 +269,33 @@ def gen_blocks(out):
     print("blocks done")
 
 
+def gen_decode(out, B=2):
+    """PointAutoencoder.decode of the reference (airplane AE config) on synthetic latents; FPS start index 0 (shim)"""
+    from data_utils.json_reader import read_json_file, autoencoder_read_config
+    from models.autoencoder import PointAutoencoder
+    d = CFG + "autoencoder_configs/"
+    cfg = read_json_file(d + "config_autoencoder_s3_kl_1e-5_16_keypoints_latent_dim_16_32_normal_weight_0_0_0.1_with_augm_kp_noise_0.04_airplane.json")
+    enc, decs = autoencoder_read_config(d, cfg)
+    ae = PointAutoencoder(enc, decs, apply_kl_regularization=True, kl_weight=1e-5)
+    spec_all = [(k, tuple(v.shape)) for k, v in ae.state_dict().items()]
+    vals = synth_state_dict([("ae." + n, s) for n, s in spec_all])
+    ae.load_state_dict({n: torch.from_numpy(vals["ae." + n]) for n, _ in spec_all})
+    ae.eval()
+    spec = [(n, s) for n, s in spec_all if n.startswith("keypoint_encoder.fc_layer") or n.startswith("decoder.")]
+    rs = np.random.RandomState(31)
+    kp = synth_keypoints(B, 16, seed=9)
+    feat = (0.5 * rs.standard_normal((B, 16, 48))).astype(np.float32)
+    label = np.zeros(B, np.int64)
+    with torch.no_grad():
+        new_xyz = ae.keypoint_encoder.upsample_points(torch.from_numpy(feat), torch.from_numpy(kp))
+        l_xyz = ae.decoder(torch.from_numpy(kp), torch.from_numpy(feat), new_xyz, ts=None, label=torch.from_numpy(label))
+    res = {"keypoint": kp, "feature": feat, "label": label, "decoder_configs_json": np.array(json.dumps(decs)),
+           "level1": l_xyz[1].numpy(), "level2": l_xyz[2].numpy(), "level3": l_xyz[3].numpy()}
+    res["spec_names"], res["spec_shapes"] = spec_arrays(spec)
+    np.savez_compressed(os.path.join(out, "golden_decode.npz"), **res)
+    print("decode", [tuple(x.shape) for x in l_xyz], "params", sum(int(np.prod(s)) for _, s in spec))
+
+
 def gen_ops(out):
     from oracle import ops as O
     rs = np.random.RandomState(3)
@@ -337,7 +364,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.manual_seed(0)
-    want = set(a.only.split(",")) if a.only else {"ops", "blocks", "pos", "feat"}
+    want = set(a.only.split(",")) if a.only else {"ops", "blocks", "pos", "feat", "decode"}
     if "ops" in want:
         gen_ops(a.out)
     if "blocks" in want:
@@ -348,3 +375,5 @@ if __name__ == "__main__":
     if "feat" in want:
         net, cfg = gen_denoiser("feat", FEAT_CFG, a.out)
         gen_sampler_feat(net, cfg, a.out)
+    if "decode" in want:
+        gen_decode(a.out)

@@ -58,18 +58,9 @@ def install():
         return torch.from_numpy(O.knn_gather(_n(x), _n(idx)))
 
     def sample_farthest_points(points, lengths=None, K=50, random_start_point=False):
-        # plain FPS (no near-origin skip), deterministic start 0 here; parity-unpinned in the reference
-        p = _n(points).astype(np.float64)
-        B, N, _ = p.shape
-        idx = np.zeros((B, K), np.int64)
-        for b in range(B):
-            d = np.full(N, np.inf)
-            cur = 0
-            for j in range(K):
-                idx[b, j] = cur
-                d = np.minimum(d, ((p[b] - p[b, cur]) ** 2).sum(-1))
-                cur = int(np.argmax(d))
-        out = np.take_along_axis(_n(points), idx[..., None], axis=1)
+        # plain fp32 FPS from the oracle; start index 0 (the reference's random start makes its result
+        # non-reproducible: "parity unpinned", compared distributionally)
+        out, idx = O.sample_farthest_points(_n(points), K, None)
         return torch.from_numpy(out), torch.from_numpy(idx)
 
     def masked_gather(points, idx):
