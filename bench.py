@@ -4,7 +4,8 @@
 Workload (BASELINE.json configs[1]/[2], per GPU): batch 256 latent-point sets (16 points each);
   step = ONE reverse-diffusion step of the position DDPM (airplane config, 3-dim)  +
          ONE reverse-diffusion step of the feature DDPM (chair config, 48-dim feature + 3-dim key points)
-  over the whole batch: denoiser forward + DDPM update + in-kernel noise, replayed from a hipGraph.
+  over the whole batch: denoiser forward + DDPM update + in-kernel noise; the two plans are the two parallel branches of
+  ONE hipGraph per step (in steady-state generation batch i's feature chain overlaps batch i+1's position chain).
 A generated shape needs 1000 + 1000 such steps, so  value = n_gpus * batch / (1000 * seconds_per_step).
 `--steps 1000` is therefore exactly one complete generation of the batch.  Synthetic random-init weights,
 synthetic key points, inputs resident in HBM.  N > 1: one process per GPU (torchrun), batch shards are
@@ -72,7 +73,7 @@ def main():
     import torch.distributed as dist
     from slide_amd import configs, model_spec
     from slide_amd._lib import check, lib
-    from slide_amd.diffusion import FeatureSampler, PositionSampler
+    from slide_amd.diffusion import FeatureSampler, JointSampler, PositionSampler
     from slide_amd.engine import OP_GEMM
     from slide_amd.synth import synth_keypoints, synth_state_dict
 
@@ -93,6 +94,7 @@ def main():
     pos = PositionSampler(pc["pointnet_config"], sd_p, B, dev, pc["diffusion_config"], prec=a.prec, seed=1000 + rank)
     feat = FeatureSampler(fc["pointnet_config"], sd_f, B, dev, fc["standard_diffusion_config"], prec=a.prec,
                           seed=2000 + rank)
+    joint = JointSampler(pos, feat)  # one hipGraph per step: the two plans are its two parallel branches
     rs = np.random.RandomState(rank)
     kp = synth_keypoints(B, seed=rank)
 
@@ -105,8 +107,7 @@ def main():
         while done < n:
             k = min(n - done, 1000)
             reset()
-            pos.advance(k)
-            feat.advance(k)
+            joint.advance(k)
             done += k
 
     def sync_all():
@@ -156,17 +157,28 @@ def main():
                 tot += np.array(list(ms))
         tot /= reps
         flops = f.engine.gemm_flops  # per GEMM op, algorithmic (logical channels), whole batch
-        cbw_dom = 4 if a.prec == "fp16" else 2  # the rocprofv3 kernel name: gemm_kernel<PREC, 8, CBW>
-        dom = [i for i in range(n) if f.step_ops[i].kind == OP_GEMM and f.step_ops[i].i[4] == 8 and f.step_ops[i].i[7] == cbw_dom]
+        # dominant kernel = the 256-row-sample, 128-channel-tile GEMM of the feature denoiser.  rocprofv3 name:
+        #   fp16: gemm_glds_kernel<8, 4, 3, 32, false>   fp32: gemm_kernel<0, 8, 2>
+        cbw_dom = 4 if a.prec == "fp16" else 2
+        def is_dom(o):
+            return (o.kind == OP_GEMM and o.i[4] == 8 and o.i[7] == cbw_dom and (a.prec == "fp32" or (o.i[8] == 1 and not o.p[3])))
+        dom = [i for i in range(n) if is_dom(f.step_ops[i])]
+        kname = "gemm_glds_kernel<8, 4, 3, 32, false>" if a.prec == "fp16" else "gemm_kernel<0, 8, 2>"
         dflops = sum(flops[i] for i in dom)
         dms = sum(tot[i] for i in dom)
         ach = dflops / (dms * 1e-3) / 1e12
+        traffic, tsrc = None, None
+        pj = os.path.join(REPO, "profiles", "hbm_pmc_latest.json")  # written by tools/rocprof_summarize.py from PMC passes
+        if os.path.exists(pj):
+            pm = json.load(open(pj))
+            if kname in pm.get("kernels", {}):
+                traffic = pm["kernels"][kname]["hbm_bytes_per_launch"]
+                tsrc = pm["source"]
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.prec], "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_TFLOPS[a.prec], 4), "traffic": None,
-                           "kernel": "gemm_kernel<%d, 8, %d> (%s MFMA, 256-row samples, 32*%d-channel tiles; feature denoiser: "
-                                     "%d launches/step, avg %.1f us)" % (1 if a.prec == "fp16" else 0, cbw_dom, a.prec, cbw_dom,
-                                                                         len(dom), 1e3 * dms / len(dom)),
-                           "flops_per_step_dominant": dflops,
+                           "frac": round(ach / PEAK_TFLOPS[a.prec], 4), "traffic": traffic, "traffic_source": tsrc,
+                           "kernel": "%s (%s MFMA, 256-row samples x 128-channel tiles; feature denoiser: %d launches/step, "
+                                     "avg %.1f us)" % (kname, a.prec, len(dom), 1e3 * dms / max(len(dom), 1)),
+                           "flops_per_launch_avg": dflops / max(len(dom), 1),
                            "step_ms_eager_sum": round(float(tot.sum()), 4),
                            "gemm_ms_per_step_all": round(float(sum(tot[i] for i in range(n) if f.step_ops[i].kind == OP_GEMM)), 4)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

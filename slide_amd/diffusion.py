@@ -199,3 +199,51 @@ class FeatureSampler(_GraphedSampler):
             self.keypoint.copy_(kp.reshape(self.B * 16, self.kdim))
             self.engine.set_label(label)
             self._set_state(x, self.T - 1 if t_start is None else t_start)
+
+
+class JointSampler:
+    """One reverse step of the position chain and one of the feature chain as TWO PARALLEL BRANCHES of a single hipGraph
+    (lane 0 = feature plan, lane 1 = position plan): in steady-state generation batch i's feature chain runs while batch
+    i+1's position chain does, and the position plan's tiny latency-bound kernels fill the tails of the feature plan's
+    large ones.  Both chains advance by the same number of steps per call."""
+
+    def __init__(self, pos, feat):
+        from .engine import OP_SYNC
+        self.pos, self.feat = pos, feat
+        ops = [make_op(OP_SYNC, i=(0, 1))]
+        for o in pos.step_ops:
+            c = SlideOp.from_buffer_copy(o)
+            if c.kind != OP_SYNC:
+                c.i[10] = 1
+            ops.append(c)
+        ops += [SlideOp.from_buffer_copy(o) for o in feat.step_ops]
+        ops.append(make_op(OP_SYNC, i=(1, 0)))
+        self.step_ops = (SlideOp * len(ops))(*ops)
+        self.graph = None
+        self.stream, self.stream2 = feat.stream, pos.stream
+
+    def advance(self, n_steps):
+        L = lib()
+        # everything queued on the position stream (begin()) must precede the joint graph, which runs on the feature stream
+        self.stream.wait_stream(self.stream2)
+        with torch.cuda.stream(self.stream):
+            s, s2 = ctypes.c_void_p(self.stream.cuda_stream), ctypes.c_void_p(self.stream2.cuda_stream)
+            if self.graph is None:
+                e1, e2 = self.pos.engine, self.feat.engine
+                keep = [e1.x.clone(), e1.t_dev.clone(), e2.x.clone(), e2.t_dev.clone()]
+                check(L.slide_run_ops2(self.step_ops, len(self.step_ops), s, s2), "slide_run_ops2")
+                self.stream.synchronize(); self.stream2.synchronize()
+                e1.x.copy_(keep[0]); e1.t_dev.copy_(keep[1]); e2.x.copy_(keep[2]); e2.t_dev.copy_(keep[3])
+                self.stream.synchronize()
+                check(L.slide_graph_begin(s), "graph_begin")
+                st = L.slide_run_ops2(self.step_ops, len(self.step_ops), s, s2)
+                g = ctypes.c_void_p()
+                st2 = L.slide_graph_end(s, ctypes.byref(g))
+                check(st, "slide_run_ops2(capture)"); check(st2, "graph_end")
+                self.graph = g
+            for _ in range(n_steps):
+                check(L.slide_graph_launch(self.graph, s), "graph_launch")
+        self.stream2.wait_stream(self.stream)
+
+    def synchronize(self):
+        self.stream.synchronize(); self.stream2.synchronize()

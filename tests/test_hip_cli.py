@@ -1,0 +1,65 @@
+"""GPU: the two generation CLIs end to end (random-init weights, configs written in the reference's JSON format with
+string-encoded lists), npz schema of the reference harness (mesh_evaluation.py:135-150)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO, load_golden
+from slide_amd import configs
+
+pytestmark = pytest.mark.gpu
+
+
+def _stringify(d):
+    out = {}
+    for k, v in d.items():
+        out[k] = _stringify(v) if isinstance(v, dict) else (str(v) if isinstance(v, list) else v)
+    return out
+
+
+def test_generation_clis(gpu_device, tmp_path):
+    cdir = tmp_path / "configs" / "a" / "b"
+    os.makedirs(cdir)
+    pc = configs.position_ddpm_config()
+    pc["shapenet_psr_dataset_config"] = {"dataset": "shapenet_psr_dataset", "categories": ["02691156"], "num_keypoints": 16}
+    pc["train_config"] = {"task": "keypoint_generation", "dataset": "shapenet_psr_dataset"}
+    pos_cfg = cdir / "pos.json"
+    pos_cfg.write_text(json.dumps(_stringify(pc)))
+    env = dict(os.environ, PYTHONPATH=REPO)
+    cli = os.path.join(REPO, "pointnet2", "sampling_and_inference")
+    out1 = tmp_path / "gen"
+    r = subprocess.run([sys.executable, os.path.join(cli, "point_cloud_generation.py"), "-c", str(pos_cfg), "--random_init",
+                        "--num_samples", "6", "--batch_size", "4", "--save_dir", str(out1)], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    kpf = out1 / "shapenet_psr_generated_data_16_pts.npz"
+    d = np.load(kpf)
+    assert set(d.files) == {"points", "label", "category", "category_name", "timing"}
+    assert d["points"].shape == (6, 16, 3) and np.isfinite(d["points"]).all() and (d["label"] == 0).all()
+    assert d["category"][0] == "02691156" and d["category_name"][0] == "airplane" and d["timing"].shape == (6,)
+    # feature DDPM + decode; the autoencoder config points to one encoder + three decoder level files
+    g = load_golden("golden_decode.npz")
+    decs = json.loads(str(g["decoder_configs_json"]))
+    ae_dir = tmp_path / "configs" / "ae"
+    os.makedirs(ae_dir / "lv")
+    for i, dcfg in enumerate(decs):
+        (ae_dir / "lv" / ("d%d.json" % i)).write_text(json.dumps({"pointnet_config": _stringify(dcfg)}))
+    (ae_dir / "lv" / "enc.json").write_text(json.dumps({"pointnet_config": {"architecture": {"feature_dim": "[32, 64, 128, 256, 256]"}}}))
+    (ae_dir / "ae.json").write_text(json.dumps({"pointnet_config": {"apply_kl_regularization": True, "encoder_config_file": "lv/enc.json",
+                                                                  "decoder_config_file": "['lv/d0.json', 'lv/d1.json', 'lv/d2.json']"}}))
+    fc = configs.feature_ddpm_config()
+    fc["autoencoder_config"] = {"config_file": str(ae_dir / "ae.json"), "ckpt": "unused"}
+    feat_cfg = cdir / "feat.json"
+    feat_cfg.write_text(json.dumps(_stringify(fc)))
+    out2 = tmp_path / "gen2"
+    r = subprocess.run([sys.executable, os.path.join(cli, "latent_ddpm_keypoint_conditional_generation.py"), "-c", str(feat_cfg),
+                        "--random_init", "--keypoint_file", str(kpf), "--batch_size", "4", "--save_dir", str(out2), "--decode",
+                        "--save_keypoint_feature"], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d2 = np.load(out2 / "shapenet_psr_generated_data_2048_pts.npz")
+    assert {"points", "normals", "label", "category", "category_name", "timing", "keypoint", "keypoint_feature"} <= set(d2.files)
+    assert d2["points"].shape == (6, 2048, 3) and d2["normals"].shape == (6, 2048, 3) and d2["keypoint_feature"].shape == (6, 16, 48)
+    assert np.isfinite(d2["points"]).all() and np.allclose(d2["keypoint"], d["points"])

@@ -144,3 +144,30 @@ def test_inkernel_rng_statistics(gpu_device):
     # per-element spread across the batch is dominated by sigma*z
     z = (x1 - x1.mean(axis=0, keepdims=True)) / smp.dh["Sigma"][999]
     assert abs(z.std() - 1.0) < 0.15
+
+
+def test_joint_graph_equals_separate_chains(gpu_device):
+    """position + feature plans as two parallel branches of ONE hipGraph give bit-identical states to the two samplers run
+    one after the other (same explicit noise)"""
+    from slide_amd import configs
+    from slide_amd.diffusion import FeatureSampler, JointSampler, PositionSampler
+    _, hp_p, sd_p = _load("pos")
+    _, hp_f, sd_f = _load("feat")
+    B, n = 5, 6
+    rs = np.random.RandomState(11)
+    xp, xf = rs.standard_normal((B, 16, 3)).astype(np.float32), rs.standard_normal((B, 16, 51)).astype(np.float32)
+    kp = rs.uniform(-0.7, 0.7, (B, 16, 3)).astype(np.float32)
+    npos, nfeat = rs.standard_normal((n, B, 16, 3)).astype(np.float32), rs.standard_normal((n, B, 16, 51)).astype(np.float32)
+    lab_p, lab_f = np.zeros(B, np.int64), np.full(B, 4, np.int64)
+    fcfg = configs.feature_ddpm_config()["standard_diffusion_config"]
+    for prec in ("fp32", "fp16"):
+        pos = PositionSampler(hp_p, sd_p, B, gpu_device, _pos_cfg(), prec=prec, noise=npos)
+        feat = FeatureSampler(hp_f, sd_f, B, gpu_device, fcfg, prec=prec, noise=nfeat)
+        want_p = pos.sample(lab_p, xp, n_steps=n).cpu().numpy()
+        want_f = feat.sample(lab_f, kp, xf, n_steps=n).cpu().numpy()
+        joint = JointSampler(pos, feat)
+        pos.begin(lab_p, xp); feat.begin(lab_f, kp, xf)
+        joint.advance(n)
+        joint.synchronize()
+        assert np.array_equal(pos.state().cpu().numpy(), want_p), prec
+        assert np.array_equal(feat.state().cpu().numpy(), want_f), prec

@@ -59,4 +59,13 @@ if os.path.exists(fp) and os.path.exists(wp):
             w = wa.get(k, [0, 1, 0])
             f.write("| %s | %d | %.0f | %.0f | %.0f | %.1f |\n" % (k, fa[k][1], fa[k][0] / fa[k][1], 2 * fa[k][0] / fa[k][1],
                                                                w[0] / max(w[1], 1), fa[k][2] / fa[k][1]))
+    import json
+    kern = {}
+    for k in fa:
+        if "gemm" in k:
+            w = wa.get(k, [0, 1, 0])
+            kern[k] = {"hbm_bytes_per_launch": int(1024 * (2 * fa[k][0] / fa[k][1] + w[0] / max(w[1], 1))),
+                       "fetch_kib_x2": 2 * fa[k][0] / fa[k][1], "write_kib": w[0] / max(w[1], 1), "dispatches": fa[k][1]}
+    json.dump({"source": "profiles/%s_hbm_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH x2 gfx950 "
+                         "correction)" % tag, "kernels": kern}, open(os.path.join(dst, "hbm_pmc_latest.json"), "w"), indent=1)
 print("written", sorted(os.listdir(dst)))

@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from slide_amd import configs, model_spec
-from slide_amd.diffusion import FeatureSampler, PositionSampler
+from slide_amd.diffusion import FeatureSampler, JointSampler, PositionSampler
 from slide_amd.synth import synth_keypoints, synth_state_dict
 dev = torch.device("cuda:0"); B = int(os.environ.get("B", 256)); prec = os.environ.get("PREC", "fp16")
 pc, fc = configs.position_ddpm_config(), configs.feature_ddpm_config()
@@ -17,7 +17,9 @@ def reset():
 def sync():
     pos.stream.synchronize(); feat.stream.synchronize(); torch.cuda.synchronize()
 N = 300
-for name, fn in (("feat", lambda: feat.advance(N)), ("pos", lambda: pos.advance(N)), ("both", lambda: (pos.advance(N), feat.advance(N)))):
+joint = JointSampler(pos, feat)
+for name, fn in (("feat", lambda: feat.advance(N)), ("pos", lambda: pos.advance(N)), ("both", lambda: (pos.advance(N), feat.advance(N))),
+                 ("joint", lambda: joint.advance(N))):
     reset(); fn(); sync(); reset(); sync()
     t0 = time.perf_counter(); fn(); sync(); dt = time.perf_counter() - t0
     print("%-5s %.3f ms/step" % (name, dt * 1e3 / N))
