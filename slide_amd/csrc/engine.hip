@@ -20,6 +20,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -75,6 +78,12 @@ __device__ __forceinline__ void gstore4(GLOBAL_AS _Float16 *p, float4 v) {
   f16x4 h;
   h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
   *reinterpret_cast<GLOBAL_AS f16x4 *>(p) = h;
+}
+
+// v_permlane32_swap: a[lanes 32..63] <-> b[lanes 0..31].  Written as asm: the builtin's second result was folded into
+// the first by this toolchain when both fed conversions (residual path), silently corrupting quads 2p+1.
+__device__ __forceinline__ void lane32_swap(uint32_t &a, uint32_t &b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
 
 template <typename T> __device__ __forceinline__ float4 load4(const T *p);
@@ -141,36 +150,50 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     const GLOBAL_AS T *resid = gptr<const T>(rdp(24)), *pre = gptr<const T>(rdp(26));
     const uint64_t e_out = rdp(28);
     GLOBAL_AS float *e_stats_sum = gptr<float>(rdp(30)), *e_stats_sq = gptr<float>(rdp(32));
-    float v[2][16];
+    // v[rb][i] = channel pair i of the lane: channels cpair(i) = 8 (i >> 1) + 4 half + 2 (i & 1) and +1.  Everything
+    // below is written on pairs so that it compiles to packed fp32 VALU ops (v_pk_add/mul/fma_f32): the epilogue's VALU
+    // instruction count, not MFMA, bounds the small-K launches (rocprofv3 SQ_INSTS_VALU vs SQ_INSTS_MFMA).
+    f32x2 v[2][8];
     {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c0 = 8 * q + 4 * half;
-        const float4 bia = *reinterpret_cast<const float4 *>(v_bias + c0);
+      for (int i = 0; i < 8; ++i) {
+        const int c0 = 8 * (i >> 1) + 4 * half + 2 * (i & 1);
+        const f32x2 bia = *reinterpret_cast<const f32x2 *>(v_bias + c0);
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-          float4 t = make_float4(acc[cb][rb][4 * q] + bia.x, acc[cb][rb][4 * q + 1] + bia.y,
-                                 acc[cb][rb][4 * q + 2] + bia.z, acc[cb][rb][4 * q + 3] + bia.w);
-          if (pre) {  // per-point term shared by the K neighbours of a point (query half of attention weight_conv.2)
-            const int row = row0 + wave * 64 + rb * 32 + col;
-            if (row < a.rows) {
-              const float4 u = gload4(pre + (size_t)(row >> e_pre_shift) * e_pre_ld + c0);
-              t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+          f32x2 t = {acc[cb][rb][2 * i], acc[cb][rb][2 * i + 1]};
+          t += bia;
+          v[rb][i] = t;
+        }
+      }
+      if (pre) {  // per-point term shared by the K neighbours of a point (query half of attention weight_conv.2)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          const int row = row0 + wave * 64 + rb * 32 + col;
+          if (row < a.rows) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float4 u = gload4(pre + (size_t)(row >> e_pre_shift) * e_pre_ld + 8 * q + 4 * half);
+              v[rb][2 * q] += f32x2{u.x, u.y};
+              v[rb][2 * q + 1] += f32x2{u.z, u.w};
             }
           }
-          if (flags & SLIDE_F_PRE_RELU) {
-            t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
-          }
-          v[rb][4 * q] = t.x; v[rb][4 * q + 1] = t.y; v[rb][4 * q + 2] = t.z; v[rb][4 * q + 3] = t.w;
         }
+      }
+      if (flags & SLIDE_F_PRE_RELU) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[rb][i] = __builtin_elementwise_max(v[rb][i], f32x2{0.f, 0.f});
       }
     }
     // NSCOPE = number of independent sample scopes per wave (NPX=16: one per 32-row block, two samples each)
     constexpr int NSCOPE = (NPXL >= 6) ? 1 : 2;
     constexpr int LG = NPX < 32 ? NPX : 32;  // lanes (rows) of one sample inside a row block
-    constexpr int WPS = NPX / 64;            // waves per sample when a sample spans waves (2 or 4)
-    // sums `NV` per-lane partials over the rows of the lane's sample: lanes -> (row blocks) -> waves via LDS
-    auto reduce_rows = [&](auto nv_tag, float *s, float *ss) {
+    constexpr int WPS = NPXL >= 7 ? NPX / 64 : 1;  // waves per sample when a sample spans waves (2 or 4)
+    // sums `NV` per-lane partials over the rows of the lane's sample: lanes -> (row blocks) -> waves via LDS.
+    // XH: also fold the other lane half in (groups wider than one half's quad).
+    auto reduce_rows = [&](auto nv_tag, float *s, float *ss, bool xh) {
       constexpr int NV = decltype(nv_tag)::value;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -180,23 +203,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
       if (NPXL >= 7) {  // fixed summation order -> deterministic
         if (col == 0) {
 #pragma unroll
-          for (int i = 0; i < NV; ++i) {
-            red[(((wave * CBW + cb) * 2 + half) * 16 + i) * 2 + 0] = s[i];
-            red[(((wave * CBW + cb) * 2 + half) * 16 + i) * 2 + 1] = ss[i];
-          }
+          for (int i = 0; i < NV; ++i)
+            *reinterpret_cast<f32x2 *>(red + (((wave * CBW + cb) * 2 + half) * 16 + i) * 2) = f32x2{s[i], ss[i]};
         }
         __syncthreads();
-        const int w0 = (wave / (WPS > 0 ? WPS : 1)) * (WPS > 0 ? WPS : 1);
+        const int w0 = (wave / WPS) * WPS;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-          float t0 = 0.f, t1 = 0.f;
+          f32x2 t = {0.f, 0.f};
 #pragma unroll
-          for (int w = 0; w < (WPS > 0 ? WPS : 1); ++w) {
-            t0 += red[((((w0 + w) * CBW + cb) * 2 + half) * 16 + i) * 2 + 0];
-            t1 += red[((((w0 + w) * CBW + cb) * 2 + half) * 16 + i) * 2 + 1];
+          for (int w = 0; w < WPS; ++w)
+            t += *reinterpret_cast<const f32x2 *>(red + ((((w0 + w) * CBW + cb) * 2 + half) * 16 + i) * 2);
+          if (xh) {
+#pragma unroll
+            for (int w = 0; w < WPS; ++w)
+              t += *reinterpret_cast<const f32x2 *>(red + ((((w0 + w) * CBW + cb) * 2 + (half ^ 1)) * 16 + i) * 2);
           }
-          s[i] = t0; ss[i] = t1;
+          s[i] = t[0]; ss[i] = t[1];
         }
+      } else if (xh) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { s[i] += __shfl_xor(s[i], 32); ss[i] += __shfl_xor(ss[i], 32); }
       }
     };
     if (mode == SLIDE_EPI_STATS) {
@@ -204,13 +231,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
       for (int sc = 0; sc < NSCOPE; ++sc) {
         float s[16], ss[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (NSCOPE == 1) { s[r] = v[0][r] + v[1][r]; ss[r] = v[0][r] * v[0][r] + v[1][r] * v[1][r]; }
-          else { s[r] = v[sc][r]; ss[r] = v[sc][r] * v[sc][r]; }
+        for (int i = 0; i < 8; ++i) {
+          f32x2 t, tt;
+          if (NSCOPE == 1) { t = v[0][i] + v[1][i]; tt = __builtin_elementwise_fma(v[0][i], v[0][i], v[1][i] * v[1][i]); }
+          else { t = v[sc][i]; tt = v[sc][i] * v[sc][i]; }
+          s[2 * i] = t[0]; s[2 * i + 1] = t[1]; ss[2 * i] = tt[0]; ss[2 * i + 1] = tt[1];
         }
-        reduce_rows(std::integral_constant<int, 16>(), s, ss);
+        reduce_rows(std::integral_constant<int, 16>(), s, ss, false);
         const int row = row0 + wave * 64 + ((NSCOPE == 1) ? 0 : sc) * 32 + col;
-        const bool writer = (NPXL >= 7) ? ((wave % (WPS > 0 ? WPS : 1)) == 0 && col == 0) : ((col & (LG - 1)) == 0);
+        const bool writer = (NPXL >= 7) ? ((wave % WPS) == 0 && col == 0) : ((col & (LG - 1)) == 0);
         if (writer && row < a.rows) {
           const size_t b = (size_t)(row >> NPXL);
 #pragma unroll
@@ -230,26 +259,38 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
 #pragma unroll
         for (int sc = 0; sc < NSCOPE; ++sc) {
           float s[NV], ss[NV];
+          if constexpr (SH == 2) {
 #pragma unroll
-          for (int i = 0; i < NV; ++i) { s[i] = 0.f; ss[i] = 0.f; }
+            for (int q = 0; q < 4; ++q) {
+              f32x2 t, tt;
+              if (NSCOPE == 1) {
+                t = (v[0][2 * q] + v[1][2 * q]) + (v[0][2 * q + 1] + v[1][2 * q + 1]);
+                tt = v[0][2 * q] * v[0][2 * q];
+                tt = __builtin_elementwise_fma(v[1][2 * q], v[1][2 * q], tt);
+                tt = __builtin_elementwise_fma(v[0][2 * q + 1], v[0][2 * q + 1], tt);
+                tt = __builtin_elementwise_fma(v[1][2 * q + 1], v[1][2 * q + 1], tt);
+              } else {
+                t = v[sc][2 * q] + v[sc][2 * q + 1];
+                tt = __builtin_elementwise_fma(v[sc][2 * q], v[sc][2 * q], v[sc][2 * q + 1] * v[sc][2 * q + 1]);
+              }
+              s[q] = t[0] + t[1]; ss[q] = tt[0] + tt[1];
+            }
+          } else {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            if (NSCOPE == 1) {
-              s[r >> SH] += v[0][r] + v[1][r];
-              ss[r >> SH] += v[0][r] * v[0][r] + v[1][r] * v[1][r];
-            } else {
-              s[r >> SH] += v[sc][r];
-              ss[r >> SH] += v[sc][r] * v[sc][r];
+            for (int i = 0; i < 8; ++i) {
+              f32x2 t, tt;
+              if (NSCOPE == 1) { t = v[0][i] + v[1][i]; tt = __builtin_elementwise_fma(v[0][i], v[0][i], v[1][i] * v[1][i]); }
+              else { t = v[sc][i]; tt = v[sc][i] * v[sc][i]; }
+              if constexpr (SH == 1) { s[i] = t[0] + t[1]; ss[i] = tt[0] + tt[1]; }
+              else { s[(2 * i) >> SH] = t[0]; s[(2 * i + 1) >> SH] = t[1]; ss[(2 * i) >> SH] = tt[0]; ss[(2 * i + 1) >> SH] = tt[1]; }
             }
           }
-          reduce_rows(std::integral_constant<int, NV>(), s, ss);
-          if (SH == 2 && e_gs >= 8) {  // groups wider than a lane's quad: both lane halves, then quads
-#pragma unroll
-            for (int i = 0; i < NV; ++i) { s[i] += __shfl_xor(s[i], 32); ss[i] += __shfl_xor(ss[i], 32); }
+          reduce_rows(std::integral_constant<int, NV>(), s, ss, SH == 2 && e_gs >= 8);
+          if (SH == 2 && e_gs >= 16) {  // groups wider than both halves of a quad: fold quads
             if (e_gs == 16) {
               const float p0 = s[0] + s[1], p1 = s[2] + s[3], q0_ = ss[0] + ss[1], q1_ = ss[2] + ss[3];
               s[0] = s[1] = p0; s[2] = s[3] = p1; ss[0] = ss[1] = q0_; ss[2] = ss[3] = q1_;
-            } else if (e_gs == 32) {
+            } else {
               const float p = (s[0] + s[1]) + (s[2] + s[3]), q_ = (ss[0] + ss[1]) + (ss[2] + ss[3]);
               s[0] = s[1] = s[2] = s[3] = p; ss[0] = ss[1] = ss[2] = ss[3] = q_;
             }
@@ -262,16 +303,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
             rstd[i] = __builtin_amdgcn_rsqf(var + GN_EPS);
           }
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (c < e_n_norm) {
-              const float g = v_gamma[c] * rstd[r >> SH], bt = v_beta[c] - mean[r >> SH] * g;
-              if (NSCOPE == 1) {
-                v[0][r] = v[0][r] * g + bt;
-                v[1][r] = v[1][r] * g + bt;
-              } else {
-                v[sc][r] = v[sc][r] * g + bt;
-              }
+          for (int i = 0; i < 8; ++i) {
+            const int c0 = 8 * (i >> 1) + 4 * half + 2 * (i & 1);
+            const f32x2 gam = *reinterpret_cast<const f32x2 *>(v_gamma + c0);
+            const f32x2 bet = *reinterpret_cast<const f32x2 *>(v_beta + c0);
+            const f32x2 rs = {rstd[(2 * i) >> SH], rstd[(2 * i + 1) >> SH]};
+            const f32x2 mu = {mean[(2 * i) >> SH], mean[(2 * i + 1) >> SH]};
+            f32x2 g = gam * rs;
+            f32x2 bt = __builtin_elementwise_fma(-mu, g, bet);
+            if (e_n_norm < 32) {  // MyGroupNorm leaves the last C % G channels as they are
+              if (c0 >= e_n_norm) { g[0] = 1.f; bt[0] = 0.f; }
+              if (c0 + 1 >= e_n_norm) { g[1] = 1.f; bt[1] = 0.f; }
+            }
+            if (NSCOPE == 1) {
+              v[0][i] = __builtin_elementwise_fma(v[0][i], g, bt);
+              v[1][i] = __builtin_elementwise_fma(v[1][i], g, bt);
+            } else {
+              v[sc][i] = __builtin_elementwise_fma(v[sc][i], g, bt);
             }
           }
         }
@@ -280,33 +328,74 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
       else if (e_gs == 2) norm_path(std::integral_constant<int, 1>());
       else norm_path(std::integral_constant<int, 0>());
     }
-    // store: 4 consecutive channels per lane and quad -> 16-byte (fp32) / 8-byte (fp16) channel-minor stores
+    // store.  A lane holds 4 consecutive channels per quad q (channels 8q + 4*half).  fp32 rows go out as they are
+    // (16 B per lane).  For fp16 rows an 8-byte store per lane would touch only 16 B of every row per instruction,
+    // which the memory system writes at half the rate of wider row pieces (tools/store_pattern.hip: 3.1 vs 5.2 TB/s):
+    // v_permlane32_swap trades quads 2p+1 / 2p between the lane halves so that lane (col, half) owns the 8 channels
+    // 16p + 8*half .. +7 and issues 16-byte stores (32 B per row and instruction).  The residual is read the same way.
     const GLOBAL_AS float *addv = e_addvec;
     if (addv && e_addvec_idx) addv += (size_t)e_addvec_idx[0] * e_idx_stride;  // row t of a per-timestep table
+    constexpr bool kHalf = std::is_same<T, _Float16>::value;
+    const bool wide16 = kHalf && !(flags & SLIDE_F_OUT_F32);
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
       const int row = row0 + wave * 64 + rb * 32 + col;
-      if (row >= a.rows) continue;
+      const bool ok = row < a.rows;  // identical in both lane halves
       const size_t b = (size_t)(row >> NPXL);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c0 = 8 * q + 4 * half;
-        float4 y = make_float4(v[rb][4 * q], v[rb][4 * q + 1], v[rb][4 * q + 2], v[rb][4 * q + 3]);
-        if (flags & SLIDE_F_POST_RELU) {
-          y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+      for (int p = 0; p < 2; ++p) {  // quads 2p and 2p+1
+        float4 y[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int q = 2 * p + j;
+          f32x2 lo = v[rb][2 * q], hi = v[rb][2 * q + 1];
+          if (flags & SLIDE_F_POST_RELU) {
+            lo = __builtin_elementwise_max(lo, f32x2{0.f, 0.f});
+            hi = __builtin_elementwise_max(hi, f32x2{0.f, 0.f});
+          }
+          if (addv && ok) {
+            const float4 t = gload4(addv + b * e_addvec_bs + 8 * q + 4 * half);
+            lo += f32x2{t.x, t.y}; hi += f32x2{t.z, t.w};
+          }
+          y[j] = make_float4(lo[0], lo[1], hi[0], hi[1]);
         }
-        if (addv) {
-          const float4 t = gload4(addv + b * e_addvec_bs + c0);
-          y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+        if constexpr (kHalf) if (wide16) {
+          if (resid) {
+            u32x4 w = {0u, 0u, 0u, 0u};
+            if (ok) w = *(const GLOBAL_AS u32x4 *)(resid + (size_t)row * e_res_ld + 16 * p + 8 * half);
+            uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+            lane32_swap(w0, w2);
+            lane32_swap(w1, w3);
+            const f16x2 a0 = __builtin_bit_cast(f16x2, w0), a1 = __builtin_bit_cast(f16x2, w1);
+            const f16x2 b0 = __builtin_bit_cast(f16x2, w2), b1 = __builtin_bit_cast(f16x2, w3);
+            y[0].x += (float)a0[0]; y[0].y += (float)a0[1]; y[0].z += (float)a1[0]; y[0].w += (float)a1[1];
+            y[1].x += (float)b0[0]; y[1].y += (float)b0[1]; y[1].z += (float)b1[0]; y[1].w += (float)b1[1];
+          }
+          f16x2 a0, a1, b0, b1;
+          a0[0] = (_Float16)y[0].x; a0[1] = (_Float16)y[0].y; a1[0] = (_Float16)y[0].z; a1[1] = (_Float16)y[0].w;
+          b0[0] = (_Float16)y[1].x; b0[1] = (_Float16)y[1].y; b1[0] = (_Float16)y[1].z; b1[1] = (_Float16)y[1].w;
+          uint32_t ua0 = __builtin_bit_cast(uint32_t, a0), ua1 = __builtin_bit_cast(uint32_t, a1);
+          uint32_t ub0 = __builtin_bit_cast(uint32_t, b0), ub1 = __builtin_bit_cast(uint32_t, b1);
+          lane32_swap(ua0, ub0);
+          lane32_swap(ua1, ub1);
+          u32x4 o = {ua0, ua1, ub0, ub1};
+          if (ok) *(GLOBAL_AS u32x4 *)(gptr<_Float16>(e_out) + (size_t)row * e_out_ld + 16 * p + 8 * half) = o;
+          continue;
         }
-        if (resid) {
-          const float4 t = gload4(resid + (size_t)row * e_res_ld + c0);
-          y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+        if (ok) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int c0 = 8 * (2 * p + j) + 4 * half;
+            if (resid) {
+              const float4 t = gload4(resid + (size_t)row * e_res_ld + c0);
+              y[j].x += t.x; y[j].y += t.y; y[j].z += t.z; y[j].w += t.w;
+            }
+            if (flags & SLIDE_F_OUT_F32)
+              gstore4(gptr<float>(e_out) + (size_t)row * e_out_ld + c0, y[j]);
+            else
+              gstore4(gptr<T>(e_out) + (size_t)row * e_out_ld + c0, y[j]);
+          }
         }
-        if (flags & SLIDE_F_OUT_F32)
-          gstore4(gptr<float>(e_out) + (size_t)row * e_out_ld + c0, y);
-        else
-          gstore4(gptr<T>(e_out) + (size_t)row * e_out_ld + c0, y);
       }
     }
   }

@@ -255,6 +255,10 @@ class DenoiserEngine:
         ntr = (rows + 255) // 256
         cbw = 4 if (self.prec == 1 and n_cob >= 4 and ntr * ((n_cob + 3) // 4) >= 512) else 2
         self.gemm_flops[len(self.ops)] = 2 * rows * sum(int(s["w"].size) for s in segs)
+        esz = X.element_size()
+        rd = rows * ld * esz + W.size * esz + sum(rows * v[2] * esz for v in vec_list if v[1].get("residual") is not None)
+        wr = sum(rows * v[2] * v[1]["out"].element_size() for v in vec_list if v[1].get("mode", EPI_RAW) != EPI_STATS)
+        self.gemm_bytes[len(self.ops)] = (rd, wr)  # algorithmic HBM bytes (read, written) of this launch
         glds = int(self.use_glds and self.prec == 1 and (sc is None or npx_log2 >= 7))
         self._emit(make_op(OP_GEMM, i=(rows, ld, ld, n_cob, npx_log2, in_bs, self.prec, cbw, glds, self.glds_nst),
                                 p=(X.data_ptr(), Wd.data_ptr(), ed.data_ptr(),
@@ -457,6 +461,7 @@ class DenoiserEngine:
         arch = hp["architecture"]
         self.flops = 0
         self.gemm_flops = {}
+        self.gemm_bytes = {}
         # persistent I/O + per-step state
         self.x = A.zeros(B, 16, self.cx)
         self.ts = A.zeros(B)

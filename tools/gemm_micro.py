@@ -15,6 +15,7 @@ class Mini(E.DenoiserEngine):
         self.adt = torch.float16 if self.prec == 1 else torch.float32
         self.A = E._Arena(dev); self.ops = []; self.flops = 0; self.gemm_flops = {}
         self.per_sample_t = True
+        self.two_lanes = False; self._lane = 0; self.gemm_bytes = {}
         self.use_glds = os.environ.get('SLIDE_GLDS', '1') != '0'
         self.glds_nst = int(os.environ.get('SLIDE_GLDS_WIDE', '0'))
 
@@ -52,6 +53,11 @@ def bench(rows, npxl, K, N, mode, prec="fp16", extras=(), reps=20):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:  # rows,npxl,K,N,mode[,extras...]   e.g. 65536,8,64,448,1
+        for spec in sys.argv[1:]:
+            f = spec.split(",")
+            bench(int(f[0]), int(f[1]), int(f[2]), int(f[3]), int(f[4]), "fp16", tuple(f[5:]), reps=10)
+        sys.exit(0)
     for prec in ["fp16"]:
         for mode in (E.EPI_RAW, E.EPI_STATS, E.EPI_NORM):
             bench(4096, 4, 128, 128, mode, prec)

@@ -32,12 +32,13 @@ with torch.cuda.stream(s.stream):
         check(lib().slide_run_ops_timed(s.step_ops, n, ctypes.c_void_p(s.stream.cuda_stream), ms), "timed")
         if r: tot += np.array(list(ms))
 tot /= a.reps
-print("%3s %-7s %8s %7s %6s %6s %6s %8s %8s" % ("#", "kind", "us", "rows", "K", "N", "npx", "GFLOP", "TFLOP/s"))
+print("%3s %-7s %8s %7s %6s %6s %6s %8s %8s %8s %8s %8s" % ("#", "kind", "us", "rows", "K", "N", "npx", "GFLOP", "TFLOP/s", "rdMB", "wrMB", "GB/s"))
 for i in range(n):
     o = s.step_ops[i]
     if o.kind == 1:
         fl = s.engine.gemm_flops[i]
-        print("%3d %-7s %8.1f %7d %6d %6d %6d %8.2f %8.1f" % (i, "GEMM", tot[i] * 1e3, o.i[0], o.i[2], o.i[3] * 32, 1 << o.i[4], fl / 1e9, fl / (tot[i] * 1e-3) / 1e12))
+        rd, wr = s.engine.gemm_bytes[i]
+        print("%3d %-7s %8.1f %7d %6d %6d %6d %8.2f %8.1f %8.1f %8.1f %8.0f" % (i, "GEMM", tot[i] * 1e3, o.i[0], o.i[2], o.i[3] * 32, 1 << o.i[4], fl / 1e9, fl / (tot[i] * 1e-3) / 1e12, rd / 1e6, wr / 1e6, (rd + wr) / (tot[i] * 1e-3) / 1e9))
     else:
         print("%3d %-7s %8.1f" % (i, names.get(o.kind, "?"), tot[i] * 1e3))
 print("total us %.1f  gemm us %.1f" % (tot.sum() * 1e3, sum(tot[i] for i in range(n) if s.step_ops[i].kind == 1) * 1e3))
