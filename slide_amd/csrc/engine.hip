@@ -134,10 +134,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
                                               float *red) {
   using T = typename TileT<PREC>::T;
   constexpr int NPX = 1 << NPXL;
-#pragma unroll
-  for (int cb = 0; cb < CBW; ++cb) {
+  // PH = 0: everything for channel block cb.  Samples spanning several waves (NPX >= 128) exchange their statistics
+  // through LDS: PH = 1 (bias, partial sums -> LDS) for all blocks, ONE workgroup barrier, then PH = 2 (totals,
+  // normalisation, stores) -- instead of a barrier per channel block.
+  auto process = [&](const int cb, auto ph_tag) {
+    constexpr int PH = decltype(ph_tag)::value;
     const int cobi = cob0 + cb;
-    if (cobi >= a.n_cob) continue;  // uniform per workgroup
+    if (cobi >= a.n_cob) return;  // uniform per workgroup
     auto rd = [&](int k) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)epi_lds[cb * EPI_DW + k]); };
     auto rdp = [&](int k) { return (uint64_t)rd(k) | ((uint64_t)rd(k + 1) << 32); };
     const int mode = (int)rd(0), flags = (int)rd(1), e_gs = (int)rd(2), e_n_norm = (int)rd(3);
@@ -150,11 +153,45 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     const GLOBAL_AS T *resid = gptr<const T>(rdp(24)), *pre = gptr<const T>(rdp(26));
     const uint64_t e_out = rdp(28);
     GLOBAL_AS float *e_stats_sum = gptr<float>(rdp(30)), *e_stats_sq = gptr<float>(rdp(32));
+    // global reads of the store phase, issued first so that their latency overlaps the statistics / normalisation work
+    constexpr bool kHalf = std::is_same<T, _Float16>::value;
+    const bool wide16 = kHalf && !(flags & SLIDE_F_OUT_F32);
+    const GLOBAL_AS float *addv = e_addvec;
+    constexpr int NA = NPXL >= 6 ? 1 : 2;  // a wave's 64 rows belong to one sample when NPX >= 64
+    float4 apre[NA][4];
+    u32x4 rpre[2][2];
+    if (PH != 1) {
+      if (addv && e_addvec_idx) addv += (size_t)e_addvec_idx[0] * e_idx_stride;  // row t of a per-timestep table
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const int row = row0 + wave * 64 + rb * 32 + col;
+        const bool ok = row < a.rows;
+        if (rb < NA) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            apre[rb][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (addv && ok) apre[rb][q] = gload4(addv + (size_t)(row >> NPXL) * e_addvec_bs + 8 * q + 4 * half);
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          rpre[rb][p] = u32x4{0u, 0u, 0u, 0u};
+          if constexpr (kHalf)
+            if (wide16 && resid && ok)
+              rpre[rb][p] = *(const GLOBAL_AS u32x4 *)(resid + (size_t)row * e_res_ld + 16 * p + 8 * half);
+        }
+      }
+    }
     // v[rb][i] = channel pair i of the lane: channels cpair(i) = 8 (i >> 1) + 4 half + 2 (i & 1) and +1.  Everything
     // below is written on pairs so that it compiles to packed fp32 VALU ops (v_pk_add/mul/fma_f32): the epilogue's VALU
     // instruction count, not MFMA, bounds the small-K launches (rocprofv3 SQ_INSTS_VALU vs SQ_INSTS_MFMA).
     f32x2 v[2][8];
-    {
+    if (PH == 2) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[rb][i] = f32x2{acc[cb][rb][2 * i], acc[cb][rb][2 * i + 1]};
+    } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int c0 = 8 * (i >> 1) + 4 * half + 2 * (i & 1);
@@ -186,6 +223,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
 #pragma unroll
           for (int i = 0; i < 8; ++i) v[rb][i] = __builtin_elementwise_max(v[rb][i], f32x2{0.f, 0.f});
       }
+      if (PH == 1) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { acc[cb][rb][2 * i] = v[rb][i][0]; acc[cb][rb][2 * i + 1] = v[rb][i][1]; }
+      }
     }
     // NSCOPE = number of independent sample scopes per wave (NPX=16: one per 32-row block, two samples each)
     constexpr int NSCOPE = (NPXL >= 6) ? 1 : 2;
@@ -195,18 +238,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     // XH: also fold the other lane half in (groups wider than one half's quad).
     auto reduce_rows = [&](auto nv_tag, float *s, float *ss, bool xh) {
       constexpr int NV = decltype(nv_tag)::value;
+      if (PH != 2) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        s[i] = lane_group_sum<LG>(s[i]);
-        ss[i] = lane_group_sum<LG>(ss[i]);
+        for (int i = 0; i < NV; ++i) {
+          s[i] = lane_group_sum<LG>(s[i]);
+          ss[i] = lane_group_sum<LG>(ss[i]);
+        }
       }
       if (NPXL >= 7) {  // fixed summation order -> deterministic
-        if (col == 0) {
+        if (PH != 2 && col == 0) {
 #pragma unroll
           for (int i = 0; i < NV; ++i)
             *reinterpret_cast<f32x2 *>(red + (((wave * CBW + cb) * 2 + half) * 16 + i) * 2) = f32x2{s[i], ss[i]};
         }
-        __syncthreads();
+        if (PH == 0) __syncthreads();
+        if (PH == 1) return;
         const int w0 = (wave / WPS) * WPS;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -230,14 +276,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
 #pragma unroll
       for (int sc = 0; sc < NSCOPE; ++sc) {
         float s[16], ss[16];
+        if (PH != 2) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          f32x2 t, tt;
-          if (NSCOPE == 1) { t = v[0][i] + v[1][i]; tt = __builtin_elementwise_fma(v[0][i], v[0][i], v[1][i] * v[1][i]); }
-          else { t = v[sc][i]; tt = v[sc][i] * v[sc][i]; }
-          s[2 * i] = t[0]; s[2 * i + 1] = t[1]; ss[2 * i] = tt[0]; ss[2 * i + 1] = tt[1];
+          for (int i = 0; i < 8; ++i) {
+            f32x2 t, tt;
+            if (NSCOPE == 1) { t = v[0][i] + v[1][i]; tt = __builtin_elementwise_fma(v[0][i], v[0][i], v[1][i] * v[1][i]); }
+            else { t = v[sc][i]; tt = v[sc][i] * v[sc][i]; }
+            s[2 * i] = t[0]; s[2 * i + 1] = t[1]; ss[2 * i] = tt[0]; ss[2 * i + 1] = tt[1];
+          }
         }
         reduce_rows(std::integral_constant<int, 16>(), s, ss, false);
+        if (PH == 1) continue;
         const int row = row0 + wave * 64 + ((NSCOPE == 1) ? 0 : sc) * 32 + col;
         const bool writer = (NPXL >= 7) ? ((wave % WPS) == 0 && col == 0) : ((col & (LG - 1)) == 0);
         if (writer && row < a.rows) {
@@ -259,7 +308,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
 #pragma unroll
         for (int sc = 0; sc < NSCOPE; ++sc) {
           float s[NV], ss[NV];
-          if constexpr (SH == 2) {
+          if constexpr (PH == 2) {
+          } else if constexpr (SH == 2) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               f32x2 t, tt;
@@ -286,6 +336,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
             }
           }
           reduce_rows(std::integral_constant<int, NV>(), s, ss, SH == 2 && e_gs >= 8);
+          if (PH == 1) continue;
           if (SH == 2 && e_gs >= 16) {  // groups wider than both halves of a quad: fold quads
             if (e_gs == 16) {
               const float p0 = s[0] + s[1], p1 = s[2] + s[3], q0_ = ss[0] + ss[1], q1_ = ss[2] + ss[3];
@@ -328,20 +379,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
       else if (e_gs == 2) norm_path(std::integral_constant<int, 1>());
       else norm_path(std::integral_constant<int, 0>());
     }
+    if (PH == 1) return;
     // store.  A lane holds 4 consecutive channels per quad q (channels 8q + 4*half).  fp32 rows go out as they are
     // (16 B per lane).  For fp16 rows an 8-byte store per lane would touch only 16 B of every row per instruction,
     // which the memory system writes at half the rate of wider row pieces (tools/store_pattern.hip: 3.1 vs 5.2 TB/s):
     // v_permlane32_swap trades quads 2p+1 / 2p between the lane halves so that lane (col, half) owns the 8 channels
     // 16p + 8*half .. +7 and issues 16-byte stores (32 B per row and instruction).  The residual is read the same way.
-    const GLOBAL_AS float *addv = e_addvec;
-    if (addv && e_addvec_idx) addv += (size_t)e_addvec_idx[0] * e_idx_stride;  // row t of a per-timestep table
-    constexpr bool kHalf = std::is_same<T, _Float16>::value;
-    const bool wide16 = kHalf && !(flags & SLIDE_F_OUT_F32);
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
       const int row = row0 + wave * 64 + rb * 32 + col;
       const bool ok = row < a.rows;  // identical in both lane halves
-      const size_t b = (size_t)(row >> NPXL);
 #pragma unroll
       for (int p = 0; p < 2; ++p) {  // quads 2p and 2p+1
         float4 y[2];
@@ -353,16 +400,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
             lo = __builtin_elementwise_max(lo, f32x2{0.f, 0.f});
             hi = __builtin_elementwise_max(hi, f32x2{0.f, 0.f});
           }
-          if (addv && ok) {
-            const float4 t = gload4(addv + b * e_addvec_bs + 8 * q + 4 * half);
+          if (addv) {
+            const float4 t = apre[rb < NA ? rb : 0][q];
             lo += f32x2{t.x, t.y}; hi += f32x2{t.z, t.w};
           }
           y[j] = make_float4(lo[0], lo[1], hi[0], hi[1]);
         }
         if constexpr (kHalf) if (wide16) {
           if (resid) {
-            u32x4 w = {0u, 0u, 0u, 0u};
-            if (ok) w = *(const GLOBAL_AS u32x4 *)(resid + (size_t)row * e_res_ld + 16 * p + 8 * half);
+            const u32x4 w = rpre[rb][p];
             uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
             lane32_swap(w0, w2);
             lane32_swap(w1, w3);
@@ -398,6 +444,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
         }
       }
     }
+  };
+  if (NPXL >= 7) {
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb) process(cb, std::integral_constant<int, 1>());
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb) process(cb, std::integral_constant<int, 2>());
+  } else {
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb) process(cb, std::integral_constant<int, 0>());
   }
 }
 
@@ -1045,13 +1101,14 @@ int launch_gemm_glds(const GemmArgs &a, hipStream_t s) {
   constexpr int NSAMP = (1 << NPXL) >= TM ? 1 : TM >> NPXL;
   const size_t shm = (size_t)NST * (TM + 32 * CBW) * BKT * 2 + CBW * (sizeof(SlideEpi) + 96 * 4) + 16 +
                      (AFF ? (size_t)NSAMP * 2 * a.k_pad * 2 : 0);
-  if (shm > 80 * 1024 && BKT == 32) return -8;  // two workgroups per CU must fit
+  if (shm > 80 * 1024 && BKT == 32 && NST <= 3) return -8;  // two workgroups per CU must fit
+  if (shm > 160 * 1024) return -8;
   const int ntc = (a.n_cob + CBW - 1) / CBW, ntr = (a.rows + TM - 1) / TM;
   const int grid = ((ntr + 7) / 8) * 8 * ntc;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_glds_kernel<NPXL, CBW, NST, BKT, AFF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024 * (BKT / 32));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, NST > 3 ? 160 * 1024 : 84 * 1024 * (BKT / 32));
     attr_set = true;
   }
   hipLaunchKernelGGL((gemm_glds_kernel<NPXL, CBW, NST, BKT, AFF>), dim3(grid), dim3(256), shm, s, a);
@@ -1073,6 +1130,11 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
   if (npxl == L && cbw == C)                                                                               \
     return wide ? launch_gemm_glds<L, C, 3, 64, false>(a, s) : launch_gemm_glds<L, C, 3, 32, false>(a, s)
 #define ACASE(L, C) if (npxl == L && cbw == C) return launch_gemm_glds<L, C, 3, 32, true>(a, s)
+    // launches of at most one workgroup per CU (the 16-row per-point GEMMs) are bound by the latency of their K loop:
+    // a 7-stage ring keeps five chunks in flight instead of one
+    if (npxl == 4 && cbw == 2 && !a.in_scale && !wide &&
+        ((a.rows + TM - 1) / TM) * ((a.n_cob + 1) / 2) <= 256 && a.k_pad >= 128)
+      return launch_gemm_glds<4, 2, 7, 32, false>(a, s);
     if (a.in_scale) { ACASE(7, 2); ACASE(8, 2); ACASE(7, 4); ACASE(8, 4); return -4; }
     GCASE(4, 2); GCASE(7, 2); GCASE(8, 2); GCASE(4, 4); GCASE(7, 4); GCASE(8, 4);
 #undef ACASE
