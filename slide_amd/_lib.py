@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libslide_hip.so")
+# SLIDE_HIP_LIB: developer knob for A/B timing of two builds of the same library (tools/ab_build.sh)
+LIB_PATH = os.environ.get("SLIDE_HIP_LIB") or os.path.join(_HERE, "libslide_hip.so")
 _lib = None
 
 EXPORTS = [

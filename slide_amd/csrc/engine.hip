@@ -43,7 +43,16 @@ struct GemmArgs {
   const SlideEpi *epi;
   const float *in_scale, *in_shift;
   int rows, x_ld, k_pad, n_cob, in_bs;
+  unsigned long long *dbg;  // optional per-workgroup timeline (tools/gemm_timeline.py): 16 x 100 MHz stamps per workgroup
 };
+#ifdef SLIDE_TIMELINE  // instrumented build only (tools/gemm_timeline.py); the product library carries no stamps
+#define SLIDE_STAMP(a, k)                                                                     \
+  do {                                                                                        \
+    if ((a).dbg && threadIdx.x == 0) (a).dbg[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); \
+  } while (0)
+#else
+#define SLIDE_STAMP(a, k) do { } while (0)
+#endif
 
 // sum over aligned groups of W lanes (16 or 32); every lane of the group gets the total
 template <int W>
@@ -153,6 +162,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     const GLOBAL_AS T *resid = gptr<const T>(rdp(24)), *pre = gptr<const T>(rdp(26));
     const uint64_t e_out = rdp(28);
     GLOBAL_AS float *e_stats_sum = gptr<float>(rdp(30)), *e_stats_sq = gptr<float>(rdp(32));
+    if (PH == 2 && cb == 0) SLIDE_STAMP(a, 8);
     // global reads of the store phase, issued first so that their latency overlaps the statistics / normalisation work
     constexpr bool kHalf = std::is_same<T, _Float16>::value;
     const bool wide16 = kHalf && !(flags & SLIDE_F_OUT_F32);
@@ -380,6 +390,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
       else norm_path(std::integral_constant<int, 0>());
     }
     if (PH == 1) return;
+    if (PH == 2 && cb == 0) SLIDE_STAMP(a, 9);
     // store.  A lane holds 4 consecutive channels per quad q (channels 8q + 4*half).  fp32 rows go out as they are
     // (16 B per lane).  For fp16 rows an 8-byte store per lane would touch only 16 B of every row per instruction,
     // which the memory system writes at half the rate of wider row pieces (tools/store_pattern.hip: 3.1 vs 5.2 TB/s):
@@ -444,11 +455,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
         }
       }
     }
+    if (PH == 2 && cb == 0) SLIDE_STAMP(a, 10);
   };
   if (NPXL >= 7) {
 #pragma unroll
     for (int cb = 0; cb < CBW; ++cb) process(cb, std::integral_constant<int, 1>());
+    SLIDE_STAMP(a, 3);
     __syncthreads();
+    SLIDE_STAMP(a, 4);
 #pragma unroll
     for (int cb = 0; cb < CBW; ++cb) process(cb, std::integral_constant<int, 2>());
   } else {
@@ -638,6 +652,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
 
+  SLIDE_STAMP(a, 0);
   uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + (size_t)NST * STAGE_B);
   float *const vec_lds = reinterpret_cast<float *>(epi_lds + CBW * EPI_DW + (CBW * EPI_DW) % 4);
   stage_epilogue_tables<CBW>(a, cob0, tid, epi_lds, vec_lds);
@@ -708,6 +723,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
 #pragma unroll
   for (int s0 = 0; s0 < NST - 1; ++s0)
     if (s0 < nk) issue(s0, s0);
+  SLIDE_STAMP(a, 1);
   for (int kc = 0; kc < nk; ++kc) {
     // chunk kc must have landed; up to NST-2 younger chunks may stay in flight (fewer in the tail -> drain)
     if (kc + NST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPW) : "memory");
@@ -739,9 +755,17 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
     }
   }
   __syncthreads();  // every wave is done with the tiles before `red` reuses them
+  SLIDE_STAMP(a, 2);
 
   gemm_epilogue<SLIDE_PREC_F16, NPXL, CBW>(a, acc, row0, cob0, wave, half, col, epi_lds, vec_lds,
                                            reinterpret_cast<float *>(smem_raw));
+  SLIDE_STAMP(a, 5);
+#ifdef SLIDE_TIMELINE
+  if (a.dbg) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SLIDE_STAMP(a, 6);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ points
@@ -1119,6 +1143,7 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
   GemmArgs a;
   a.X = o.p[0]; a.W = o.p[1]; a.epi = (const SlideEpi *)o.p[2];
   a.in_scale = (const float *)o.p[3]; a.in_shift = (const float *)o.p[4];
+  a.dbg = (unsigned long long *)o.p[5];
   a.rows = o.i[0]; a.x_ld = o.i[1]; a.k_pad = o.i[2]; a.n_cob = o.i[3]; a.in_bs = o.i[5];
   const int npxl = o.i[4], prec = o.i[6], cbw = o.i[7], glds = o.i[8];
   if (a.k_pad % BK || a.x_ld % 8 || a.rows <= 0 || a.n_cob <= 0) return -3;

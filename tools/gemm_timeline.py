@@ -1,0 +1,61 @@
+"""Per-workgroup timeline of one GEMM launch (100 MHz stamps written by the kernel when SlideOp.p[5] is set).
+usage: python tools/gemm_timeline.py rows,npxl,K,N,mode[,extras]   (same case syntax as tools/gemm_micro.py)
+stamps: 0 start | 1 tables staged + ring primed | 2 K loop done | 3 partial statistics published | 4 barrier passed |
+        5 stores issued | 6 stores retired"""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from slide_amd import engine as E
+from slide_amd._lib import check, lib
+import gemm_micro as G
+
+for spec in sys.argv[1:]:
+    f = spec.split(",")
+    rows, npxl, K, N, mode = (int(x) for x in f[:5])
+    extras = tuple(f[5:])
+    B = rows >> npxl
+    m = G.Mini(B, "fp16")
+    rs = np.random.RandomState(0)
+    X = m.A.put(rs.standard_normal((rows, K)).astype(np.float32), m.adt)
+    out = m._buf(rows, N)
+    seg = dict(w=rs.standard_normal((N, K)).astype(np.float32) / np.sqrt(K), bias=rs.standard_normal(N).astype(np.float32),
+               mode=mode, out=out)
+    if mode == E.EPI_NORM:
+        seg.update(flags=E.F_POST_RELU, layout=E.gn_layout(N), gn=(np.ones(N, np.float32), np.zeros(N, np.float32)))
+    if mode == E.EPI_STATS:
+        seg.update(flags=E.F_PRE_RELU, stats=(m.A.zeros(B, E.ru(N)), m.A.zeros(B, E.ru(N)), 0, 1.0))
+    if "res" in extras:
+        seg["residual"] = m._buf(rows, N)
+    if "addvec" in extras:
+        seg["addvec"] = (m.A.zeros(B, E.ru(N)), 0, E.ru(N), None, 0)
+    m._gemm(X, npxl, [seg])
+    op = m.ops[0]
+    nwg = 8192
+    dbg = torch.zeros(nwg * 16, dtype=torch.int64, device=G.dev)
+    op.p[5] = dbg.data_ptr()
+    ops = (E.SlideOp * 1)(op)
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        check(lib().slide_run_ops(ops, 1, s), "run")
+    torch.cuda.synchronize()
+    t = dbg.cpu().numpy().reshape(nwg, 16).astype(np.float64)
+    t = t[t[:, 0] > 0]
+    t0 = t[:, 0].min()
+    t = (t - t0) / 100.0  # us
+    print("case %s: %d workgroups, launch span %.1f us" % (spec, len(t), t[:, 6].max()))
+    names = ["start", "primed", "kloop", "stats", "barrier", "stored", "retired"]
+    order = np.argsort(t[:, 0])
+    first = t[order[: len(t) // 4]]
+    for lab, sel in (("all", t), ("first quarter (by start)", first)):
+        d = np.diff(sel[:, :7], axis=1)
+        print("  %-26s start@%.1f  " % (lab, sel[:, 0].mean()) +
+              "  ".join("%s %.2f" % (names[i + 1], d[:, i].mean()) for i in range(6)) + "  | total %.2f" % (sel[:, 6] - sel[:, 0]).mean())
+    # concurrency: how many WGs alive over time
+    ev = np.concatenate([np.stack([t[:, 0], np.ones(len(t))], 1), np.stack([t[:, 6], -np.ones(len(t))], 1)])
+    ev = ev[np.argsort(ev[:, 0])]
+    alive = np.cumsum(ev[:, 1])
+    print("  max concurrent workgroups %d" % alive.max())
+    if t[:, 8].max() > 0:  # finer stamps inside phase 2 of channel block 0
+        print("  phase 2, block 0: descriptors %.2f  totals+normalise %.2f  convert+store %.2f  (us, mean)" % (
+            (t[:, 8] - t[:, 4]).mean(), (t[:, 9] - t[:, 8]).mean(), (t[:, 10] - t[:, 9]).mean()))
