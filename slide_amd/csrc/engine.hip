@@ -43,6 +43,7 @@ struct GemmArgs {
   const SlideEpi *epi;
   const float *in_scale, *in_shift;
   int rows, x_ld, k_pad, n_cob, in_bs;
+  int stagger;              // start delay (10 ns units) of the workgroups in odd wave slots, 0 = none
   unsigned long long *dbg;  // optional per-workgroup timeline (tools/gemm_timeline.py): 16 x 100 MHz stamps per workgroup
 };
 #ifdef SLIDE_TIMELINE  // instrumented build only (tools/gemm_timeline.py); the product library carries no stamps
@@ -143,6 +144,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
                                               float *red) {
   using T = typename TileT<PREC>::T;
   constexpr int NPX = 1 << NPXL;
+  float *const gsh = red + 256 * CBW;  // [cb][sample][scale | shift][32], behind the partial sums
   // PH = 0: everything for channel block cb.  Samples spanning several waves (NPX >= 128) exchange their statistics
   // through LDS: PH = 1 (bias, partial sums -> LDS) for all blocks, ONE workgroup barrier, then PH = 2 (totals,
   // normalisation, stores) -- instead of a barrier per channel block.
@@ -203,14 +205,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
         for (int i = 0; i < 8; ++i) v[rb][i] = f32x2{acc[cb][rb][2 * i], acc[cb][rb][2 * i + 1]};
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c0 = 8 * (i >> 1) + 4 * half + 2 * (i & 1);
-        const f32x2 bia = *reinterpret_cast<const f32x2 *>(v_bias + c0);
+      for (int q = 0; q < 4; ++q) {
+        const float4 bia = *reinterpret_cast<const float4 *>(v_bias + 8 * q + 4 * half);
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-          f32x2 t = {acc[cb][rb][2 * i], acc[cb][rb][2 * i + 1]};
-          t += bia;
-          v[rb][i] = t;
+          v[rb][2 * q] = f32x2{acc[cb][rb][4 * q], acc[cb][rb][4 * q + 1]} + f32x2{bia.x, bia.y};
+          v[rb][2 * q + 1] = f32x2{acc[cb][rb][4 * q + 2], acc[cb][rb][4 * q + 3]} + f32x2{bia.z, bia.w};
         }
       }
       if (pre) {  // per-point term shared by the K neighbours of a point (query half of attention weight_conv.2)
@@ -282,7 +282,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
         for (int i = 0; i < NV; ++i) { s[i] += __shfl_xor(s[i], 32); ss[i] += __shfl_xor(ss[i], 32); }
       }
     };
-    if (mode == SLIDE_EPI_STATS) {
+    if (mode == SLIDE_EPI_STATS && PH == 2) {
+      // sums already written by finalize_stats; the raw values are stored below
+    } else if (mode == SLIDE_EPI_STATS) {
 #pragma unroll
       for (int sc = 0; sc < NSCOPE; ++sc) {
         float s[16], ss[16];
@@ -309,6 +311,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
           }
         }
       }
+    } else if (mode == SLIDE_EPI_NORM && PH == 2) {
+      // per-(sample, channel) scale g = gamma * rstd and shift beta - mean * g, prepared by finalize_stats
+      const float *gp = gsh + ((cb * 2 + (WPS == 2 ? (wave >> 1) : 0)) * 2) * 32 + 4 * half;
+      float4 g4[4], b4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        g4[q] = *reinterpret_cast<const float4 *>(gp + 8 * q);
+        b4[q] = *reinterpret_cast<const float4 *>(gp + 32 + 8 * q);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          v[rb][2 * q] = __builtin_elementwise_fma(v[rb][2 * q], f32x2{g4[q].x, g4[q].y}, f32x2{b4[q].x, b4[q].y});
+          v[rb][2 * q + 1] = __builtin_elementwise_fma(v[rb][2 * q + 1], f32x2{g4[q].z, g4[q].w}, f32x2{b4[q].z, b4[q].w});
+        }
     } else if (mode == SLIDE_EPI_NORM) {
       // GroupNorm: groups of gs PHYSICAL channels (gs | 32).  Fold the lane's 16 channels into its groups BEFORE the
       // cross-lane reduction: SH = log2(channels of one group held by this lane) -> 16 >> SH values to reduce.
@@ -347,6 +365,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
           }
           reduce_rows(std::integral_constant<int, NV>(), s, ss, SH == 2 && e_gs >= 8);
           if (PH == 1) continue;
+          if (PH == 2 && cb == 0) SLIDE_STAMP(a, 11);
           if (SH == 2 && e_gs >= 16) {  // groups wider than both halves of a quad: fold quads
             if (e_gs == 16) {
               const float p0 = s[0] + s[1], p1 = s[2] + s[3], q0_ = ss[0] + ss[1], q1_ = ss[2] + ss[3];
@@ -363,6 +382,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
             const float var = fmaxf(ss[i] * e_inv_count - mean[i] * mean[i], 0.f);
             rstd[i] = __builtin_amdgcn_rsqf(var + GN_EPS);
           }
+          if (PH == 2 && cb == 0) SLIDE_STAMP(a, 12);
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int c0 = 8 * (i >> 1) + 4 * half + 2 * (i & 1);
@@ -457,12 +477,70 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     }
     if (PH == 2 && cb == 0) SLIDE_STAMP(a, 10);
   };
+  // Between the phases ONE wave per channel block (wave == cb) turns the partial sums of the sample's waves into what
+  // phase 2 needs, one channel per lane: STATS -> the per-(sample, channel) sums in global memory; NORM -> scale and
+  // shift per (sample, channel) in LDS.  (Fixed summation order: deterministic.)
+  auto finalize_stats = [&](const int cb) {
+    constexpr int WPSF = NPXL >= 7 ? (1 << NPXL) / 64 : 1;
+    const int cobi = cob0 + cb;
+    if (cobi >= a.n_cob) return;
+    auto rd = [&](int k) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)epi_lds[cb * EPI_DW + k]); };
+    auto rdp = [&](int k) { return (uint64_t)rd(k) | ((uint64_t)rd(k + 1) << 32); };
+    const int mode = (int)rd(0);
+    if (mode == SLIDE_EPI_RAW) return;
+    if (WPSF == 4 && half) return;                    // one sample per workgroup: the upper lane half has nothing to do
+    const int smp = WPSF == 2 ? half : 0, w0 = smp * WPSF;
+    const int c = col, hh = (c >> 2) & 1, q = c >> 3, j = c & 3;
+    auto part = [&](int w, int h2, int slot) {
+      return *reinterpret_cast<const f32x2 *>(red + ((((w0 + w) * CBW + cb) * 2 + h2) * 16 + slot) * 2);
+    };
+    if (mode == SLIDE_EPI_STATS) {
+      f32x2 t = {0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < WPSF; ++w) t += part(w, hh, 4 * q + j);
+      const int row = row0 + smp * NPX;
+      if (row < a.rows) {
+        const float scale = __uint_as_float(rd(5));
+        const size_t o = (size_t)(row >> NPXL) * (int)rd(9) + c;
+        gptr<float>(rdp(30))[o] = t[0] * scale;
+        gptr<float>(rdp(32))[o] = t[1] * scale;
+      }
+      return;
+    }
+    const int gs = (int)rd(2), n_norm = (int)rd(3);
+    const float inv_count = __uint_as_float(rd(4));
+    int slot0, nslot = 1, nh = 1, h0 = hh;
+    if (gs >= 4) {
+      slot0 = q;
+      if (gs >= 8) { nh = 2; h0 = 0; }
+      if (gs >= 16) { nslot = gs >> 3; slot0 = (q / nslot) * nslot; }
+    } else if (gs == 2) {
+      slot0 = 2 * q + (j >> 1);
+    } else {
+      slot0 = 4 * q + j;
+    }
+    f32x2 t = {0.f, 0.f};
+    for (int w = 0; w < WPSF; ++w)
+      for (int h2 = 0; h2 < nh; ++h2)
+        for (int sl = 0; sl < nslot; ++sl) t += part(w, h0 + h2, slot0 + sl);
+    const float mean = t[0] * inv_count;
+    const float var = fmaxf(t[1] * inv_count - mean * mean, 0.f);
+    float g = vec_lds[cb * 96 + 32 + c] * __builtin_amdgcn_rsqf(var + GN_EPS);
+    float bt = vec_lds[cb * 96 + 64 + c] - mean * g;
+    if (c >= n_norm) { g = 1.f; bt = 0.f; }  // MyGroupNorm leaves the last C % G channels as they are
+    gsh[((cb * 2 + smp) * 2 + 0) * 32 + c] = g;
+    gsh[((cb * 2 + smp) * 2 + 1) * 32 + c] = bt;
+  };
   if (NPXL >= 7) {
 #pragma unroll
     for (int cb = 0; cb < CBW; ++cb) process(cb, std::integral_constant<int, 1>());
     SLIDE_STAMP(a, 3);
     __syncthreads();
     SLIDE_STAMP(a, 4);
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb)
+      if (wave == cb) finalize_stats(cb);
+    __syncthreads();
 #pragma unroll
     for (int cb = 0; cb < CBW; ++cb) process(cb, std::integral_constant<int, 2>());
   } else {
@@ -652,6 +730,15 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
 
+  if (a.stagger && wave == 0) {
+    // two workgroups share a CU; started together they stay in lockstep (both in the K loop, then both in the
+    // VALU-bound epilogue).  Delaying the one in the odd wave slot makes one's epilogue overlap the other's K loop.
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_ID.WAVE_ID
+    if (slot & 1) {
+      const unsigned long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < (unsigned long long)a.stagger) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   SLIDE_STAMP(a, 0);
   uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + (size_t)NST * STAGE_B);
   float *const vec_lds = reinterpret_cast<float *>(epi_lds + CBW * EPI_DW + (CBW * EPI_DW) % 4);
@@ -1144,6 +1231,7 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
   a.X = o.p[0]; a.W = o.p[1]; a.epi = (const SlideEpi *)o.p[2];
   a.in_scale = (const float *)o.p[3]; a.in_shift = (const float *)o.p[4];
   a.dbg = (unsigned long long *)o.p[5];
+  a.stagger = (int)(o.f[0] * 100.f);
   a.rows = o.i[0]; a.x_ld = o.i[1]; a.k_pad = o.i[2]; a.n_cob = o.i[3]; a.in_bs = o.i[5];
   const int npxl = o.i[4], prec = o.i[6], cbw = o.i[7], glds = o.i[8];
   if (a.k_pad % BK || a.x_ld % 8 || a.rows <= 0 || a.n_cob <= 0) return -3;

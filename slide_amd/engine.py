@@ -10,6 +10,7 @@ bias, res_connect, no condition cloud).  The plan is replayed eagerly or from a 
 torch is used for device memory and streams only; all arithmetic runs in libslide_hip.so.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -257,10 +258,11 @@ class DenoiserEngine:
         self.gemm_flops[len(self.ops)] = 2 * rows * sum(int(s["w"].size) for s in segs)
         esz = X.element_size()
         rd = rows * ld * esz + W.size * esz + sum(rows * v[2] * esz for v in vec_list if v[1].get("residual") is not None)
-        wr = sum(rows * v[2] * v[1]["out"].element_size() for v in vec_list if v[1].get("mode", EPI_RAW) != EPI_STATS)
+        wr = sum(rows * v[2] * v[1]["out"].element_size() for v in vec_list)
         self.gemm_bytes[len(self.ops)] = (rd, wr)  # algorithmic HBM bytes (read, written) of this launch
         glds = int(self.use_glds and self.prec == 1 and (sc is None or npx_log2 >= 7))
         self._emit(make_op(OP_GEMM, i=(rows, ld, ld, n_cob, npx_log2, in_bs, self.prec, cbw, glds, self.glds_nst),
+                           f=(float(os.environ.get('SLIDE_STAGGER_US', '0')),),
                                 p=(X.data_ptr(), Wd.data_ptr(), ed.data_ptr(),
                                    None if sc is None else sc.data_ptr() + 4 * aff_off,
                                    None if sh is None else sh.data_ptr() + 4 * aff_off)))

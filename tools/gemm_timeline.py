@@ -2,9 +2,21 @@
 usage: python tools/gemm_timeline.py rows,npxl,K,N,mode[,extras]   (same case syntax as tools/gemm_micro.py)
 stamps: 0 start | 1 tables staged + ring primed | 2 K loop done | 3 partial statistics published | 4 barrier passed |
         5 stores issued | 6 stores retired"""
-import ctypes, os, sys
+import ctypes, os, subprocess, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+LIBT = os.path.join(ROOT, "build_tmp", "libT.so")
+if "--build" in sys.argv:  # instrumented copy of the library (-DSLIDE_TIMELINE); run this part where hipcc is
+    sys.argv.remove("--build")
+    os.makedirs(os.path.dirname(LIBT), exist_ok=True)
+    F = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DSLIDE_TIMELINE"]
+    subprocess.check_call(F + ["-ffp-contract=off", "-c", ROOT + "/slide_amd/csrc/point_ops.hip", "-o", ROOT + "/build_tmp/pT.o"], stderr=subprocess.DEVNULL)
+    subprocess.check_call(F + ["-mllvm", "-pragma-unroll-threshold=100000", "-c", ROOT + "/slide_amd/csrc/engine.hip", "-o", ROOT + "/build_tmp/eT.o"], stderr=subprocess.DEVNULL)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIBT, ROOT + "/build_tmp/pT.o", ROOT + "/build_tmp/eT.o"])
+    if len(sys.argv) == 1:
+        sys.exit(0)
+os.environ["SLIDE_HIP_LIB"] = LIBT
 import torch
 from slide_amd import engine as E
 from slide_amd._lib import check, lib
@@ -59,3 +71,6 @@ for spec in sys.argv[1:]:
     if t[:, 8].max() > 0:  # finer stamps inside phase 2 of channel block 0
         print("  phase 2, block 0: descriptors %.2f  totals+normalise %.2f  convert+store %.2f  (us, mean)" % (
             (t[:, 8] - t[:, 4]).mean(), (t[:, 9] - t[:, 8]).mean(), (t[:, 10] - t[:, 9]).mean()))
+        if t[:, 11].max() > 0:
+            print("     early loads + totals from LDS %.2f  mean/rstd %.2f  scale+fma %.2f" % (
+                (t[:, 11] - t[:, 8]).mean(), (t[:, 12] - t[:, 11]).mean(), (t[:, 9] - t[:, 12]).mean()))
