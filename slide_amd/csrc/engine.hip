@@ -43,6 +43,8 @@ struct GemmArgs {
   const SlideEpi *epi;
   const float *in_scale, *in_shift;
   int rows, x_ld, k_pad, n_cob, in_bs;
+  int shm_bytes;            // dynamic LDS of the launch (its last 16 bytes hold the persistent mode's tile index)
+  int *sched;               // persistent-mode tile counters (9 ints, zero), or nullptr
   int stagger;              // start delay (10 ns units) of the workgroups in odd wave slots, 0 = none
   unsigned long long *dbg;  // optional per-workgroup timeline (tools/gemm_timeline.py): 16 x 100 MHz stamps per workgroup
 };
@@ -148,7 +150,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
   // PH = 0: everything for channel block cb.  Samples spanning several waves (NPX >= 128) exchange their statistics
   // through LDS: PH = 1 (bias, partial sums -> LDS) for all blocks, ONE workgroup barrier, then PH = 2 (totals,
   // normalisation, stores) -- instead of a barrier per channel block.
-  auto process = [&](const int cb, auto ph_tag) {
+  auto process = [&](const int cb, auto ph_tag) __attribute__((always_inline)) {
     constexpr int PH = decltype(ph_tag)::value;
     const int cobi = cob0 + cb;
     if (cobi >= a.n_cob) return;  // uniform per workgroup
@@ -246,7 +248,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     constexpr int WPS = NPXL >= 7 ? NPX / 64 : 1;  // waves per sample when a sample spans waves (2 or 4)
     // sums `NV` per-lane partials over the rows of the lane's sample: lanes -> (row blocks) -> waves via LDS.
     // XH: also fold the other lane half in (groups wider than one half's quad).
-    auto reduce_rows = [&](auto nv_tag, float *s, float *ss, bool xh) {
+    auto reduce_rows = [&](auto nv_tag, float *s, float *ss, bool xh) __attribute__((always_inline)) {
       constexpr int NV = decltype(nv_tag)::value;
       if (PH != 2) {
 #pragma unroll
@@ -330,7 +332,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     } else if (mode == SLIDE_EPI_NORM) {
       // GroupNorm: groups of gs PHYSICAL channels (gs | 32).  Fold the lane's 16 channels into its groups BEFORE the
       // cross-lane reduction: SH = log2(channels of one group held by this lane) -> 16 >> SH values to reduce.
-      auto norm_path = [&](auto sh_tag) {
+      auto norm_path = [&](auto sh_tag) __attribute__((always_inline)) {
         constexpr int SH = decltype(sh_tag)::value;
         constexpr int NV = 16 >> SH;
 #pragma unroll
@@ -416,71 +418,94 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     // which the memory system writes at half the rate of wider row pieces (tools/store_pattern.hip: 3.1 vs 5.2 TB/s):
     // v_permlane32_swap trades quads 2p+1 / 2p between the lane halves so that lane (col, half) owns the 8 channels
     // 16p + 8*half .. +7 and issues 16-byte stores (32 B per row and instruction).  The residual is read the same way.
+    // Pass 1 consumes every value that came from a global load (t-embedding rows, residual); pass 2 only converts and
+    // stores.  Kept apart -- and compiled without the loaded operands when a block has none -- because any wait for a
+    // load placed between stores is a vmcnt(0): it would also wait for the stores issued so far, one full write round
+    // trip per row block.
+    const float relu_lo = (flags & SLIDE_F_POST_RELU) ? 0.f : -3.0e38f;
+    auto store_phase = [&](auto addv_tag, auto res_tag) __attribute__((always_inline)) {
+      constexpr bool HA = decltype(addv_tag)::value, HR = decltype(res_tag)::value;
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-      const int row = row0 + wave * 64 + rb * 32 + col;
-      const bool ok = row < a.rows;  // identical in both lane halves
+      for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {  // quads 2p and 2p+1
-        float4 y[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int q = 2 * p + j;
+        for (int q = 0; q < 4; ++q) {
           f32x2 lo = v[rb][2 * q], hi = v[rb][2 * q + 1];
-          if (flags & SLIDE_F_POST_RELU) {
-            lo = __builtin_elementwise_max(lo, f32x2{0.f, 0.f});
-            hi = __builtin_elementwise_max(hi, f32x2{0.f, 0.f});
-          }
-          if (addv) {
+          // ReLU without a branch per quad: clamp from below by 0 or by -FLT_MAX (v_med3_f32, one op per value)
+          lo[0] = __builtin_amdgcn_fmed3f(lo[0], relu_lo, 3.0e38f); lo[1] = __builtin_amdgcn_fmed3f(lo[1], relu_lo, 3.0e38f);
+          hi[0] = __builtin_amdgcn_fmed3f(hi[0], relu_lo, 3.0e38f); hi[1] = __builtin_amdgcn_fmed3f(hi[1], relu_lo, 3.0e38f);
+          if constexpr (HA) {
             const float4 t = apre[rb < NA ? rb : 0][q];
             lo += f32x2{t.x, t.y}; hi += f32x2{t.z, t.w};
           }
-          y[j] = make_float4(lo[0], lo[1], hi[0], hi[1]);
+          v[rb][2 * q] = lo; v[rb][2 * q + 1] = hi;
         }
-        if constexpr (kHalf) if (wide16) {
-          if (resid) {
-            const u32x4 w = rpre[rb][p];
-            uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-            lane32_swap(w0, w2);
-            lane32_swap(w1, w3);
-            const f16x2 a0 = __builtin_bit_cast(f16x2, w0), a1 = __builtin_bit_cast(f16x2, w1);
-            const f16x2 b0 = __builtin_bit_cast(f16x2, w2), b1 = __builtin_bit_cast(f16x2, w3);
-            y[0].x += (float)a0[0]; y[0].y += (float)a0[1]; y[0].z += (float)a1[0]; y[0].w += (float)a1[1];
-            y[1].x += (float)b0[0]; y[1].y += (float)b0[1]; y[1].z += (float)b1[0]; y[1].w += (float)b1[1];
-          }
-          f16x2 a0, a1, b0, b1;
-          a0[0] = (_Float16)y[0].x; a0[1] = (_Float16)y[0].y; a1[0] = (_Float16)y[0].z; a1[1] = (_Float16)y[0].w;
-          b0[0] = (_Float16)y[1].x; b0[1] = (_Float16)y[1].y; b1[0] = (_Float16)y[1].z; b1[1] = (_Float16)y[1].w;
-          uint32_t ua0 = __builtin_bit_cast(uint32_t, a0), ua1 = __builtin_bit_cast(uint32_t, a1);
-          uint32_t ub0 = __builtin_bit_cast(uint32_t, b0), ub1 = __builtin_bit_cast(uint32_t, b1);
-          lane32_swap(ua0, ub0);
-          lane32_swap(ua1, ub1);
-          u32x4 o = {ua0, ua1, ub0, ub1};
-          if (ok) *(GLOBAL_AS u32x4 *)(gptr<_Float16>(e_out) + (size_t)row * e_out_ld + 16 * p + 8 * half) = o;
-          continue;
-        }
-        if (ok) {
+        if constexpr (HR && kHalf) {
+          if (wide16) {
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int c0 = 8 * (2 * p + j) + 4 * half;
-            if (resid) {
-              const float4 t = gload4(resid + (size_t)row * e_res_ld + c0);
-              y[j].x += t.x; y[j].y += t.y; y[j].z += t.z; y[j].w += t.w;
+            for (int p = 0; p < 2; ++p) {
+              const u32x4 w = rpre[rb][p];
+              uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+              lane32_swap(w0, w2);
+              lane32_swap(w1, w3);
+              const f16x2 a0 = __builtin_bit_cast(f16x2, w0), a1 = __builtin_bit_cast(f16x2, w1);
+              const f16x2 b0 = __builtin_bit_cast(f16x2, w2), b1 = __builtin_bit_cast(f16x2, w3);
+              v[rb][4 * p] += f32x2{(float)a0[0], (float)a0[1]};
+              v[rb][4 * p + 1] += f32x2{(float)a1[0], (float)a1[1]};
+              v[rb][4 * p + 2] += f32x2{(float)b0[0], (float)b0[1]};
+              v[rb][4 * p + 3] += f32x2{(float)b1[0], (float)b1[1]};
             }
-            if (flags & SLIDE_F_OUT_F32)
-              gstore4(gptr<float>(e_out) + (size_t)row * e_out_ld + c0, y[j]);
-            else
-              gstore4(gptr<T>(e_out) + (size_t)row * e_out_ld + c0, y[j]);
           }
         }
       }
-    }
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const int row = row0 + wave * 64 + rb * 32 + col;
+        const bool ok = row < a.rows;  // identical in both lane halves
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {  // quads 2p and 2p+1
+          if constexpr (kHalf) if (wide16) {
+            f16x2 a0 = __builtin_convertvector(v[rb][4 * p], f16x2), a1 = __builtin_convertvector(v[rb][4 * p + 1], f16x2);
+            f16x2 b0 = __builtin_convertvector(v[rb][4 * p + 2], f16x2), b1 = __builtin_convertvector(v[rb][4 * p + 3], f16x2);
+            uint32_t ua0 = __builtin_bit_cast(uint32_t, a0), ua1 = __builtin_bit_cast(uint32_t, a1);
+            uint32_t ub0 = __builtin_bit_cast(uint32_t, b0), ub1 = __builtin_bit_cast(uint32_t, b1);
+            lane32_swap(ua0, ub0);
+            lane32_swap(ua1, ub1);
+            u32x4 o = {ua0, ua1, ub0, ub1};
+#if !defined(SLIDE_ABL) || SLIDE_ABL != 1
+            if (ok) *(GLOBAL_AS u32x4 *)(gptr<_Float16>(e_out) + (size_t)row * e_out_ld + 16 * p + 8 * half) = o;
+#else
+            if (ok && o[0] == 0x12345678u) *(GLOBAL_AS u32x4 *)(gptr<_Float16>(e_out) + (size_t)row * e_out_ld + 16 * p + 8 * half) = o;
+#endif
+            continue;
+          }
+          if (ok) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int q = 2 * p + j, c0 = 8 * q + 4 * half;
+              float4 y = make_float4(v[rb][2 * q][0], v[rb][2 * q][1], v[rb][2 * q + 1][0], v[rb][2 * q + 1][1]);
+              if constexpr (HR) {
+                const float4 t = gload4(resid + (size_t)row * e_res_ld + c0);
+                y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+              }
+              if (flags & SLIDE_F_OUT_F32)
+                gstore4(gptr<float>(e_out) + (size_t)row * e_out_ld + c0, y);
+              else
+                gstore4(gptr<T>(e_out) + (size_t)row * e_out_ld + c0, y);
+            }
+          }
+        }
+      }
+    };
+    using TT = std::true_type;
+    using FF = std::false_type;
+    if (addv) { if (resid) store_phase(TT(), TT()); else store_phase(TT(), FF()); }
+    else { if (resid) store_phase(FF(), TT()); else store_phase(FF(), FF()); }
     if (PH == 2 && cb == 0) SLIDE_STAMP(a, 10);
   };
   // Between the phases ONE wave per channel block (wave == cb) turns the partial sums of the sample's waves into what
   // phase 2 needs, one channel per lane: STATS -> the per-(sample, channel) sums in global memory; NORM -> scale and
   // shift per (sample, channel) in LDS.  (Fixed summation order: deterministic.)
-  auto finalize_stats = [&](const int cb) {
+  auto finalize_stats = [&](const int cb) __attribute__((always_inline)) {
     constexpr int WPSF = NPXL >= 7 ? (1 << NPXL) / 64 : 1;
     const int cobi = cob0 + cb;
     if (cobi >= a.n_cob) return;
@@ -531,6 +556,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     gsh[((cb * 2 + smp) * 2 + 0) * 32 + c] = g;
     gsh[((cb * 2 + smp) * 2 + 1) * 32 + c] = bt;
   };
+#if defined(SLIDE_ABL) && SLIDE_ABL == 3
+  if (NPXL >= 7 && a.rows > 0) return;
+#endif
   if (NPXL >= 7) {
 #pragma unroll
     for (int cb = 0; cb < CBW; ++cb) process(cb, std::integral_constant<int, 1>());
@@ -541,6 +569,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     for (int cb = 0; cb < CBW; ++cb)
       if (wave == cb) finalize_stats(cb);
     __syncthreads();
+#if defined(SLIDE_ABL) && SLIDE_ABL == 2
+    if (a.rows > 0) return;
+#endif
 #pragma unroll
     for (int cb = 0; cb < CBW; ++cb) process(cb, std::integral_constant<int, 2>());
   } else {
@@ -707,7 +738,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
 // AFF: consumer-side GroupNorm affine (attention weight_conv.2): the per-(sample, channel) scale / shift vectors of the
 // workgroup's samples are staged once in LDS (fp16) and applied in fp32 to the X fragments between LDS and MFMA.
 template <int NPXL, int CBW, int NST, int BKT, bool AFF>
-__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
+__device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem_raw, const int tr, const int tc) {
   using T = _Float16;
   constexpr int TN = 32 * CBW;
   constexpr int RT = TM + TN;              // tile rows per stage (X rows then W rows)
@@ -719,26 +750,11 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
   constexpr int STAGE_B = RT * ROWB;       // bytes
   constexpr int SWS = BKT == 32 ? 2 : 1;   // swizzle: slot = piece ^ ((row >> SWS) & (PPR - 1))
   static_assert(NI % 4 == 0, "tile rows must split evenly over the four waves");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
-  const int ntc = (a.n_cob + CBW - 1) / CBW;
-  const int ntr = (a.rows + TM - 1) / TM;
-  const int xcd = blockIdx.x & 7, q0 = blockIdx.x >> 3;
-  const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;
-  if (tr >= ntr) return;
   const int row0 = tr * TM, cob0 = tc * CBW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
 
-  if (a.stagger && wave == 0) {
-    // two workgroups share a CU; started together they stay in lockstep (both in the K loop, then both in the
-    // VALU-bound epilogue).  Delaying the one in the odd wave slot makes one's epilogue overlap the other's K loop.
-    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_ID.WAVE_ID
-    if (slot & 1) {
-      const unsigned long long t0 = wall_clock64();
-      while (wall_clock64() - t0 < (unsigned long long)a.stagger) __builtin_amdgcn_s_sleep(32);
-    }
-  }
   SLIDE_STAMP(a, 0);
   uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + (size_t)NST * STAGE_B);
   float *const vec_lds = reinterpret_cast<float *>(epi_lds + CBW * EPI_DW + (CBW * EPI_DW) % 4);
@@ -853,6 +869,53 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
     SLIDE_STAMP(a, 6);
   }
 #endif
+}
+
+// Scheduler.  a.sched == nullptr: one tile per workgroup (grid = tiles).  Otherwise PERSISTENT: 2 workgroups per CU
+// pull tiles from per-XCD counters (tile columns of one row tile stay on one XCD's L2), so workgroups drift out of
+// phase instead of all bursting their loads, then all bursting their stores, and there is no last partial round.
+// The workgroup in the odd wave slot of a CU starts `stagger` later so that the pair begins half a tile apart.
+// sched[0..7] = next tile per XCD, sched[8] = finished workgroups; the last one to finish re-arms the counters.
+template <int NPXL, int CBW, int NST, int BKT, bool AFF>
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int ntc = (a.n_cob + CBW - 1) / CBW;
+  const int ntr = (a.rows + TM - 1) / TM;
+  const int xcd = blockIdx.x & 7;
+  if (!a.sched) {
+    const int q0 = blockIdx.x >> 3;
+    const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;
+    if (tr >= ntr) return;
+    glds_tile<NPXL, CBW, NST, BKT, AFF>(a, smem_raw, tr, tc);
+    return;
+  }
+  const int my_tiles = ((ntr - xcd + 7) / 8) * ntc;  // row tiles tr = xcd, xcd + 8, ...
+  volatile int *const s_tile = reinterpret_cast<volatile int *>(smem_raw + a.shm_bytes - 16);
+  if (a.stagger && threadIdx.x < 64) {
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_ID.WAVE_ID
+    if (slot & 1) {
+      const unsigned long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < (unsigned long long)a.stagger) __builtin_amdgcn_s_sleep(32);
+    }
+  }
+  for (;;) {
+    if (threadIdx.x == 0) *s_tile = atomicAdd(&a.sched[xcd], 1);
+    __syncthreads();
+    const int t = __builtin_amdgcn_readfirstlane(*s_tile);
+    if (t >= my_tiles) break;
+#ifdef SLIDE_TIMELINE
+    GemmArgs a2 = a;  // stamps indexed by tile instead of by workgroup
+    if (a.dbg) a2.dbg = a.dbg + ((long long)(xcd + 8 * t) - (long long)blockIdx.x) * 16;
+    glds_tile<NPXL, CBW, NST, BKT, AFF>(a2, smem_raw, (t / ntc) * 8 + xcd, t % ntc);
+#else
+    glds_tile<NPXL, CBW, NST, BKT, AFF>(a, smem_raw, (t / ntc) * 8 + xcd, t % ntc);
+#endif
+    __syncthreads();  // the epilogue's LDS reads are done before the next tile's tables / DMAs / s_tile land
+  }
+  if (threadIdx.x == 0 && atomicAdd(&a.sched[8], 1) == (int)gridDim.x - 1) {
+#pragma unroll
+    for (int x = 0; x < 9; ++x) a.sched[x] = 0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ points
@@ -1210,19 +1273,23 @@ int launch_gemm(const GemmArgs &a, hipStream_t s) {
 template <int NPXL, int CBW, int NST, int BKT, bool AFF>
 int launch_gemm_glds(const GemmArgs &a, hipStream_t s) {
   constexpr int NSAMP = (1 << NPXL) >= TM ? 1 : TM >> NPXL;
-  const size_t shm = (size_t)NST * (TM + 32 * CBW) * BKT * 2 + CBW * (sizeof(SlideEpi) + 96 * 4) + 16 +
+  const size_t shm = (size_t)NST * (TM + 32 * CBW) * BKT * 2 + CBW * (sizeof(SlideEpi) + 96 * 4) + 32 +
                      (AFF ? (size_t)NSAMP * 2 * a.k_pad * 2 : 0);
   if (shm > 80 * 1024 && BKT == 32 && NST <= 3) return -8;  // two workgroups per CU must fit
   if (shm > 160 * 1024) return -8;
   const int ntc = (a.n_cob + CBW - 1) / CBW, ntr = (a.rows + TM - 1) / TM;
-  const int grid = ((ntr + 7) / 8) * 8 * ntc;
+  int grid = ((ntr + 7) / 8) * 8 * ntc;
+  GemmArgs b = a;
+  b.shm_bytes = (int)((shm + 15) & ~(size_t)15);
+  if (b.sched && grid > 512 && NST <= 3) grid = 512;  // persistent: two resident workgroups per CU pull the tiles
+  else b.sched = nullptr;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_glds_kernel<NPXL, CBW, NST, BKT, AFF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, NST > 3 ? 160 * 1024 : 84 * 1024 * (BKT / 32));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<NPXL, CBW, NST, BKT, AFF>), dim3(grid), dim3(256), shm, s, a);
+  hipLaunchKernelGGL((gemm_glds_kernel<NPXL, CBW, NST, BKT, AFF>), dim3(grid), dim3(256), (size_t)b.shm_bytes, s, b);
   return (int)hipGetLastError();
 }
 
@@ -1232,6 +1299,7 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
   a.in_scale = (const float *)o.p[3]; a.in_shift = (const float *)o.p[4];
   a.dbg = (unsigned long long *)o.p[5];
   a.stagger = (int)(o.f[0] * 100.f);
+  a.sched = (int *)o.p[7];
   a.rows = o.i[0]; a.x_ld = o.i[1]; a.k_pad = o.i[2]; a.n_cob = o.i[3]; a.in_bs = o.i[5];
   const int npxl = o.i[4], prec = o.i[6], cbw = o.i[7], glds = o.i[8];
   if (a.k_pad % BK || a.x_ld % 8 || a.rows <= 0 || a.n_cob <= 0) return -3;

@@ -151,6 +151,10 @@ class DenoiserEngine:
         if self.two_lanes:
             self.ops.append(make_op(OP_SYNC, i=(frm, to)))
 
+    def _sched(self):
+        """tile counters of one persistent GEMM launch (9 ints, zero; the kernel re-arms them itself)"""
+        return self.A.put(np.zeros(16, np.int32))
+
     def _tvec_off(self, prefix, width):
         off = sum(w for _, w in self._tvec)
         self._tvec.append((prefix, width))
@@ -265,7 +269,8 @@ class DenoiserEngine:
                            f=(float(os.environ.get('SLIDE_STAGGER_US', '0')),),
                                 p=(X.data_ptr(), Wd.data_ptr(), ed.data_ptr(),
                                    None if sc is None else sc.data_ptr() + 4 * aff_off,
-                                   None if sh is None else sh.data_ptr() + 4 * aff_off)))
+                                   None if sh is None else sh.data_ptr() + 4 * aff_off, None, None,
+                                   self._sched().data_ptr() if self.persistent else None)))
         self.flops += 2 * rows * sum(int(s["w"].size) for s in segs)
 
     # ------------------------------------------------------------------ blocks
@@ -464,6 +469,7 @@ class DenoiserEngine:
         self.flops = 0
         self.gemm_flops = {}
         self.gemm_bytes = {}
+        self.persistent = os.environ.get('SLIDE_PERSISTENT', '0') != '0'
         # persistent I/O + per-step state
         self.x = A.zeros(B, 16, self.cx)
         self.ts = A.zeros(B)

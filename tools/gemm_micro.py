@@ -16,6 +16,7 @@ class Mini(E.DenoiserEngine):
         self.A = E._Arena(dev); self.ops = []; self.flops = 0; self.gemm_flops = {}
         self.per_sample_t = True
         self.two_lanes = False; self._lane = 0; self.gemm_bytes = {}
+        self.persistent = os.environ.get('SLIDE_PERSISTENT', '0') != '0'
         self.use_glds = os.environ.get('SLIDE_GLDS', '1') != '0'
         self.glds_nst = int(os.environ.get('SLIDE_GLDS_WIDE', '0'))
 
