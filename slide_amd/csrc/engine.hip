@@ -119,14 +119,14 @@ static_assert(sizeof(SlideEpi) == 136, "descriptor layout is read by dword index
 
 // copies the CBW epilogue descriptors of this workgroup and their per-channel vectors [cb][bias | gamma | beta][32]
 // into LDS (visible after the caller's next barrier)
-template <int CBW>
+template <int CBW, int NT = 256>
 __device__ __forceinline__ void stage_epilogue_tables(const GemmArgs &a, int cob0, int tid, uint32_t *epi_lds,
                                                       float *vec_lds) {
-  for (int i = tid; i < CBW * EPI_DW; i += 256) {
+  for (int i = tid; i < CBW * EPI_DW; i += NT) {
     const int cobi = cob0 + i / EPI_DW;
     epi_lds[i] = cobi < a.n_cob ? reinterpret_cast<const uint32_t *>(a.epi + cobi)[i % EPI_DW] : 0u;
   }
-  for (int i = tid; i < CBW * 96; i += 256) {
+  for (int i = tid; i < CBW * 96; i += NT) {
     const int cobi = cob0 + i / 96, which = (i % 96) >> 5, c = i & 31;
     float val = 0.f;
     if (cobi < a.n_cob) {
@@ -737,30 +737,35 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
 // flight across it.
 // AFF: consumer-side GroupNorm affine (attention weight_conv.2): the per-(sample, channel) scale / shift vectors of the
 // workgroup's samples are staged once in LDS (fp16) and applied in fp32 to the X fragments between LDS and MFMA.
-template <int NPXL, int CBW, int NST, int BKT, bool AFF>
+// WC = 1: four waves, tile 256 rows x 32*CBW channels.  WC = 2: eight waves, tile 256 rows x 64*CBW channels -- wave
+// (wr, wc) owns rows 64*wr.. and channel half wc, so the X chunk is fetched once per 64*CBW channels (less L2 -> LDS
+// traffic per MAC, half as many prologues); each channel half runs the 4-wave epilogue on its own LDS tables.
+template <int NPXL, int CBW, int NST, int BKT, bool AFF, int WC = 1>
 __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem_raw, const int tr, const int tc) {
   using T = _Float16;
-  constexpr int TN = 32 * CBW;
+  constexpr int NW = 4 * WC, NT = 256 * WC;  // waves, threads
+  constexpr int TN = 32 * CBW * WC;
   constexpr int RT = TM + TN;              // tile rows per stage (X rows then W rows)
   constexpr int ROWB = BKT * 2;            // bytes per tile row (64 or 128 = one full cache line)
   constexpr int PPR = ROWB / 16;           // 16-byte pieces per row (4 or 8)
   constexpr int RPI = 64 / PPR;            // rows per LDS-DMA instruction (16 or 8)
   constexpr int NI = RT / RPI;             // LDS-DMA instructions per stage
-  constexpr int LPW = NI / 4;              // per wave
+  constexpr int LPW = NI / NW;             // per wave
   constexpr int STAGE_B = RT * ROWB;       // bytes
   constexpr int SWS = BKT == 32 ? 2 : 1;   // swizzle: slot = piece ^ ((row >> SWS) & (PPR - 1))
-  static_assert(NI % 4 == 0, "tile rows must split evenly over the four waves");
+  static_assert(NI % NW == 0, "tile rows must split evenly over the waves");
+  static_assert(!AFF || WC == 1, "the affine variant is four-wave only");
 
-  const int row0 = tr * TM, cob0 = tc * CBW;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = tr * TM, cob0 = tc * CBW * WC;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wave = wv & 3, wc = wv >> 2;
   const int half = lane >> 5, col = lane & 31;
 
   SLIDE_STAMP(a, 0);
   uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + (size_t)NST * STAGE_B);
-  float *const vec_lds = reinterpret_cast<float *>(epi_lds + CBW * EPI_DW + (CBW * EPI_DW) % 4);
-  stage_epilogue_tables<CBW>(a, cob0, tid, epi_lds, vec_lds);
+  float *const vec_lds = reinterpret_cast<float *>(epi_lds + CBW * WC * EPI_DW + (CBW * WC * EPI_DW) % 4);
+  stage_epilogue_tables<CBW * WC, NT>(a, cob0, tid, epi_lds, vec_lds);
   constexpr int NSAMP = (1 << NPXL) >= TM ? 1 : TM >> NPXL;  // samples per workgroup
-  _Float16 *const aff_lds = reinterpret_cast<_Float16 *>(vec_lds + CBW * 96);  // [sample][scale | shift][k_pad]
+  _Float16 *const aff_lds = reinterpret_cast<_Float16 *>(vec_lds + CBW * WC * 96);  // [sample][scale | shift][k_pad]
   if (AFF) {
     static_assert(!AFF || NPXL >= 6, "the affine variant assumes one sample per wave");
     for (int i = tid; i < NSAMP * a.k_pad; i += 256) {
@@ -779,7 +784,7 @@ __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem
   const T *gp[LPW];
 #pragma unroll
   for (int j = 0; j < LPW; ++j) {
-    const int trow = RPI * (j * 4 + wave) + lane / PPR;
+    const int trow = RPI * (j * NW + wv) + lane / PPR;
     const int piece = (lane % PPR) ^ ((trow >> SWS) & (PPR - 1));
     if (trow < TM) {
       int grow = row0 + trow;
@@ -796,7 +801,7 @@ __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem
     for (int j = 0; j < LPW; ++j) {
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(gp[j] + kc * BKT),
                                        (__attribute__((address_space(3))) void *)(smem_raw + (size_t)st * STAGE_B +
-                                                                                  (j * 4 + wave) * 1024),
+                                                                                  (j * NW + wv) * 1024),
                                        16, 0, 0);
     }
   };
@@ -813,7 +818,7 @@ __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem
   int wrow[CBW], wkey[CBW], xrow[2], xkey[2];
 #pragma unroll
   for (int cb = 0; cb < CBW; ++cb) {
-    const int trow = TM + cb * 32 + col;
+    const int trow = TM + (wc * CBW + cb) * 32 + col;
     wrow[cb] = trow * ROWB; wkey[cb] = (trow >> SWS) & (PPR - 1);
   }
 #pragma unroll
@@ -860,8 +865,9 @@ __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem
   __syncthreads();  // every wave is done with the tiles before `red` reuses them
   SLIDE_STAMP(a, 2);
 
-  gemm_epilogue<SLIDE_PREC_F16, NPXL, CBW>(a, acc, row0, cob0, wave, half, col, epi_lds, vec_lds,
-                                           reinterpret_cast<float *>(smem_raw));
+  gemm_epilogue<SLIDE_PREC_F16, NPXL, CBW>(a, acc, row0, cob0 + wc * CBW, wave, half, col, epi_lds + wc * CBW * EPI_DW,
+                                           vec_lds + wc * CBW * 96,
+                                           reinterpret_cast<float *>(smem_raw) + wc * (256 + 128) * CBW);
   SLIDE_STAMP(a, 5);
 #ifdef SLIDE_TIMELINE
   if (a.dbg) {
@@ -918,6 +924,18 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
   }
 }
 
+// eight-wave variant (one tile per workgroup, one workgroup per CU: its deeper ring needs the LDS of two)
+template <int NPXL, int CBW, int NST>
+__global__ __launch_bounds__(512, 2) void gemm_glds8_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int ntc = (a.n_cob + 2 * CBW - 1) / (2 * CBW);
+  const int ntr = (a.rows + TM - 1) / TM;
+  const int xcd = blockIdx.x & 7, q0 = blockIdx.x >> 3;
+  const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;
+  if (tr >= ntr) return;
+  glds_tile<NPXL, CBW, NST, 32, false, 2>(a, smem_raw, tr, tc);
+}
+
 // ------------------------------------------------------------------------------------------------ points
 __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
 #pragma clang fp contract(off)
@@ -969,16 +987,32 @@ __global__ __launch_bounds__(256) void prep_points_kernel(int cx, int ldf, const
 // One thread moves 8 channels (16 bytes in fp16): the gathered feature rows are copied as whole vectors, only the
 // chunk that holds the coordinate channels is assembled element-wise.
 template <typename T, bool FP>
-__global__ __launch_bounds__(256) void assemble_kernel(int C, int ldf, int ldg, int K, const float *__restrict__ xyz,
+__global__ __launch_bounds__(256) void assemble_kernel(int C, int ldf, int ldg, int K, int nch_log2, int bulk_blocks,
+                                                       const float *__restrict__ xyz,
                                                        const T *__restrict__ feat, const int *__restrict__ kidx,
                                                        const float *__restrict__ kd2, T *__restrict__ g) {
 #pragma clang fp contract(off)
+  // one thread per (row, 16-byte piece), no integer division.  Blocks y < bulk_blocks copy the whole-vector pieces of
+  // the gathered feature rows (piece = low `nch_log2` bits of the thread id); the remaining blocks assemble the pieces
+  // that hold coordinate channels element-wise -- kept in separate waves so the copy waves never diverge into that path.
   const int b = blockIdx.x;
   const int npx = 16 * K;
   const int nch = ldg / 8;
+  const int nbulk = (sizeof(T) * ldf % 16 == 0) ? C / 8 : 0, ntail = nch - nbulk;
   const float *px = xyz + (size_t)b * 48;
-  for (int e = blockIdx.y * 256 + threadIdx.x; e < npx * nch; e += gridDim.y * 256) {
-    const int pxl = e / nch, c0 = (e - pxl * nch) * 8;
+  {
+    int pxl, c0;
+    if ((int)blockIdx.y < bulk_blocks) {
+      const int e = blockIdx.y * 256 + threadIdx.x;
+      pxl = e >> nch_log2;
+      c0 = (e & ((1 << nch_log2) - 1)) * 8;
+      if (pxl >= npx || c0 >= nbulk * 8) return;
+    } else {
+      const int e = (blockIdx.y - bulk_blocks) * 256 + threadIdx.x;
+      pxl = e / ntail;
+      c0 = (nbulk + (e - pxl * ntail)) * 8;
+      if (pxl >= npx) return;
+    }
     const int p = pxl / K, k = pxl - p * K;
     const size_t o = ((size_t)b * 16 + p) * 16;
     const int nb = kidx[o + k];
@@ -991,7 +1025,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(int C, int ldf, int ldg, 
         *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(frow + c0);
         *reinterpret_cast<float4 *>(dst + 4) = *reinterpret_cast<const float4 *>(frow + c0 + 4);
       }
-      continue;
+      return;
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1293,6 +1327,25 @@ int launch_gemm_glds(const GemmArgs &a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+template <int NPXL, int CBW, int NST>
+int launch_gemm_glds8(const GemmArgs &a, hipStream_t s) {
+  const size_t shm = (size_t)NST * (TM + 64 * CBW) * 32 * 2 + 2 * CBW * (sizeof(SlideEpi) + 96 * 4) + 32;
+  if (shm > 160 * 1024) return -8;
+  const int ntc = (a.n_cob + 2 * CBW - 1) / (2 * CBW), ntr = (a.rows + TM - 1) / TM;
+  const int grid = ((ntr + 7) / 8) * 8 * ntc;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_glds8_kernel<NPXL, CBW, NST>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  GemmArgs b = a;
+  b.sched = nullptr;
+  b.shm_bytes = (int)shm;
+  hipLaunchKernelGGL((gemm_glds8_kernel<NPXL, CBW, NST>), dim3(grid), dim3(512), shm, s, b);
+  return (int)hipGetLastError();
+}
+
 int run_gemm(const SlideOp &o, hipStream_t s) {
   GemmArgs a;
   a.X = o.p[0]; a.W = o.p[1]; a.epi = (const SlideEpi *)o.p[2];
@@ -1306,7 +1359,7 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
   if (glds) {
     if (prec != SLIDE_PREC_F16) return -7;
     // i[9]: 0 = BK 32, three stages (two workgroups / CU); 1 = BK 64 (full 128-B lines), three stages (one / CU)
-    const int wide = o.i[9] && (a.k_pad % 64 == 0) && !a.in_scale;
+    const int wide = o.i[9] == 1 && (a.k_pad % 64 == 0) && !a.in_scale;
 #define GCASE(L, C)                                                                                        \
   if (npxl == L && cbw == C)                                                                               \
     return wide ? launch_gemm_glds<L, C, 3, 64, false>(a, s) : launch_gemm_glds<L, C, 3, 32, false>(a, s)
@@ -1316,6 +1369,12 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
     if (npxl == 4 && cbw == 2 && !a.in_scale && !wide &&
         ((a.rows + TM - 1) / TM) * ((a.n_cob + 1) / 2) <= 256 && a.k_pad >= 128)
       return launch_gemm_glds<4, 2, 7, 32, false>(a, s);
+    // wide outputs: eight-wave 256 x 256 tiles when the channel blocks fill them and enough tiles remain for the chip
+    if (o.i[9] == 2 && cbw == 4 && !a.in_scale && a.n_cob % 8 == 0 &&
+        ((a.rows + TM - 1) / TM) * (a.n_cob / 8) >= 256) {
+      if (npxl == 8) return launch_gemm_glds8<8, 4, 4>(a, s);
+      if (npxl == 7) return launch_gemm_glds8<7, 4, 4>(a, s);
+    }
     if (a.in_scale) { ACASE(7, 2); ACASE(8, 2); ACASE(7, 4); ACASE(8, 4); return -4; }
     GCASE(4, 2); GCASE(7, 2); GCASE(8, 2); GCASE(4, 4); GCASE(7, 4); GCASE(8, 4);
 #undef ACASE
@@ -1345,12 +1404,18 @@ int run_op(const SlideOp &o, hipStream_t s) {
     case SLIDE_OP_ASSEMBLE_SA:
     case SLIDE_OP_ASSEMBLE_FP: {
       const bool fp = o.kind == SLIDE_OP_ASSEMBLE_FP;
-      const int work = 16 * o.i[4] * (o.i[3] / 8);
-      const dim3 g(o.i[0], (work + 1023) / 1024), blk(256);
+      // bulk (whole 16-byte pieces of the gathered rows) and tail (coordinate pieces) blocks, see the kernel
+      const int esz = o.i[5] == SLIDE_PREC_F16 ? 2 : 4;
+      const int nch = o.i[3] / 8, nbulk = (esz * o.i[2] % 16 == 0) ? o.i[1] / 8 : 0, ntail = nch - nbulk;
+      int nch_log2 = 0;
+      while ((1 << nch_log2) < nbulk) ++nch_log2;
+      const int bulk_blocks = nbulk ? (((16 * o.i[4]) << nch_log2) + 255) / 256 : 0;
+      const int tail_blocks = (16 * o.i[4] * ntail + 255) / 256;
+      const dim3 g(o.i[0], bulk_blocks + tail_blocks), blk(256);
       const float *kd2 = fp ? (const float *)o.p[3] : nullptr;
       void *dst = fp ? o.p[4] : o.p[3];
 #define ASM(TT, FPB)                                                                                                  \
-  hipLaunchKernelGGL((assemble_kernel<TT, FPB>), g, blk, 0, s, o.i[1], o.i[2], o.i[3], o.i[4], (const float *)o.p[0], \
+  hipLaunchKernelGGL((assemble_kernel<TT, FPB>), g, blk, 0, s, o.i[1], o.i[2], o.i[3], o.i[4], nch_log2, bulk_blocks, (const float *)o.p[0], \
                      (const TT *)o.p[1], (const int *)o.p[2], kd2, (TT *)dst)
       if (o.i[5] == SLIDE_PREC_F16) { if (fp) ASM(_Float16, true); else ASM(_Float16, false); }
       else { if (fp) ASM(float, true); else ASM(float, false); }
