@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="latent shapes per GPU (BASELINE configs[1]/[2]: 256)")
     ap.add_argument("--prec", default="fp16", choices=["fp16", "fp32"], help="MFMA operand type (fp32 accumulate)")
+    ap.add_argument("--sub-batches", type=int, default=2,
+                    help="independent sub-batches of the per-GPU batch replayed concurrently (scheduling only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -73,7 +75,7 @@ def main():
     import torch.distributed as dist
     from slide_amd import configs, model_spec
     from slide_amd._lib import check, lib
-    from slide_amd.diffusion import FeatureSampler, JointSampler, PositionSampler
+    from slide_amd.diffusion import FeatureSampler, JointSampler, PositionSampler, SplitJointSampler
     from slide_amd.engine import OP_GEMM
     from slide_amd.synth import synth_keypoints, synth_state_dict
 
@@ -91,16 +93,23 @@ def main():
     pc, fc = configs.position_ddpm_config(), configs.feature_ddpm_config()
     sd_p = synth_state_dict(model_spec.denoiser_param_spec(pc["pointnet_config"]))
     sd_f = synth_state_dict(model_spec.denoiser_param_spec(fc["pointnet_config"]))
-    pos = PositionSampler(pc["pointnet_config"], sd_p, B, dev, pc["diffusion_config"], prec=a.prec, seed=1000 + rank)
-    feat = FeatureSampler(fc["pointnet_config"], sd_f, B, dev, fc["standard_diffusion_config"], prec=a.prec,
-                          seed=2000 + rank)
-    joint = JointSampler(pos, feat)  # one hipGraph per step: the two plans are its two parallel branches
+    P = max(1, min(a.sub_batches, B))
+    sizes = [B // P + (1 if i < B % P else 0) for i in range(P)]
+    subs = []
+    for i, b in enumerate(sizes):
+        p_ = PositionSampler(pc["pointnet_config"], sd_p, b, dev, pc["diffusion_config"], prec=a.prec,
+                             seed=1000 + rank * 16 + i)
+        f_ = FeatureSampler(fc["pointnet_config"], sd_f, b, dev, fc["standard_diffusion_config"], prec=a.prec,
+                            seed=2000 + rank * 16 + i)
+        subs.append((p_, f_, JointSampler(p_, f_), synth_keypoints(b, seed=rank * 16 + i)))
+    pos, feat, kp = subs[0][0], subs[0][1], subs[0][3]  # sub-batch 0 also serves the roofline leg below
+    joint = SplitJointSampler([s_[2] for s_ in subs])  # one hipGraph per sub-batch and step, two branches each
     rs = np.random.RandomState(rank)
-    kp = synth_keypoints(B, seed=rank)
 
     def reset():
-        pos.begin(np.zeros(B, np.int64), rs.standard_normal((B, 16, 3)).astype(np.float32))
-        feat.begin(np.full(B, 4, np.int64), kp, rs.standard_normal((B, 16, 51)).astype(np.float32))
+        for (p_, f_, _, k_), b in zip(subs, sizes):
+            p_.begin(np.zeros(b, np.int64), rs.standard_normal((b, 16, 3)).astype(np.float32))
+            f_.begin(np.full(b, 4, np.int64), k_, rs.standard_normal((b, 16, 51)).astype(np.float32))
 
     def run(n):  # n reverse steps of each DDPM; chains restart from fresh noise every 1000 steps
         done = 0
@@ -111,7 +120,9 @@ def main():
             done += k
 
     def sync_all():
-        pos.stream.synchronize(); feat.stream.synchronize(); torch.cuda.synchronize(dev)
+        for p_, f_, _, _ in subs:
+            p_.stream.synchronize(); f_.stream.synchronize()
+        torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
 
@@ -121,16 +132,17 @@ def main():
     t0 = time.perf_counter()
     run(a.steps)
     if world > 1:  # the single collective of the path: all ranks' latents (835 KB / rank at B=256)
-        feat.stream.synchronize()
-        dist.all_gather(gathered, feat.engine.x.reshape(B, 16, 51))
+        for _, f_, _, _ in subs:
+            f_.stream.synchronize()
+        dist.all_gather(gathered, torch.cat([f_.engine.x.reshape(-1, 16, 51) for _, f_, _, _ in subs], 0))
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    final = feat.state()
-    finite = bool(torch.isfinite(final).all().item()) and bool(torch.isfinite(pos.state()).all().item())
+    finite = all(bool(torch.isfinite(f_.state()).all().item()) and bool(torch.isfinite(p_.state()).all().item())
+                 for p_, f_, _, _ in subs)
     ms_per_step = dt * 1e3 / a.steps
     value = world * B / (1000.0 * (ms_per_step / 1e3))
 
@@ -140,7 +152,8 @@ def main():
            "dtype": "f16 (MFMA operands + activation storage; f32 accumulate, norm statistics, softmax)" if a.prec == "fp16" else "f32", "data": "synthetic",
            "config": {"workload": "BASELINE configs[1]+[2]: airplane position DDPM (16x3) + chair feature DDPM (16x51), "
                                   "batch %d per GPU; 1 step = one reverse step of each; shape = 1000+1000 steps" % B,
-                      "batch_per_gpu": B, "prec": a.prec, "launches_per_step": pos.n_launches + feat.n_launches,
+                      "batch_per_gpu": B, "sub_batches": sizes, "prec": a.prec,
+                      "launches_per_step": P * (pos.n_launches + feat.n_launches),
                       "finite": finite}}
 
     if rank == 0 and not a.no_roofline:
@@ -151,7 +164,8 @@ def main():
             ms = (ctypes.c_float * n)()
             tot = np.zeros(n)
             reps = 5
-            feat.begin(np.full(B, 4, np.int64), kp, rs.standard_normal((B, 16, 51)).astype(np.float32))
+            b0 = sizes[0]
+            feat.begin(np.full(b0, 4, np.int64), kp, rs.standard_normal((b0, 16, 51)).astype(np.float32))
             for _ in range(reps):
                 check(L.slide_run_ops_timed(f.step_ops, n, ctypes.c_void_p(f.stream.cuda_stream), ms), "run_ops_timed")
                 tot += np.array(list(ms))

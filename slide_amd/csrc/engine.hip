@@ -281,7 +281,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
         }
       } else if (xh) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) { s[i] += __shfl_xor(s[i], 32); ss[i] += __shfl_xor(ss[i], 32); }
+        for (int i = 0; i < NV; ++i) {  // other lane half: v_permlane32_swap of (s, ss) -- pure VALU, no LDS round trip
+          uint32_t ta = __float_as_uint(s[i]), tb = __float_as_uint(ss[i]);
+          // after the swap: ta = [s.lo | ss.lo -> hi lanes], tb = [s.hi -> lo lanes | ss.hi]
+          lane32_swap(ta, tb);
+          const float mine_s = s[i], mine_ss = ss[i];
+          // lo lanes: other half's s is in tb;   hi lanes: other half's ss is in ta
+          // second swap of the pair (ss, s) gives the remaining two
+          uint32_t tc = __float_as_uint(mine_ss), td = __float_as_uint(mine_s);
+          lane32_swap(tc, td);
+          // tc = [ss.lo | s.lo -> hi lanes], td = [ss.hi -> lo lanes | s.hi]
+          s[i] = mine_s + (half ? __uint_as_float(tc) : __uint_as_float(tb));
+          ss[i] = mine_ss + (half ? __uint_as_float(ta) : __uint_as_float(td));
+        }
       }
     };
     if (mode == SLIDE_EPI_STATS && PH == 2) {

@@ -222,28 +222,63 @@ class JointSampler:
         self.graph = None
         self.stream, self.stream2 = feat.stream, pos.stream
 
-    def advance(self, n_steps):
+    def _prepare(self):
+        """orders the joint graph behind everything queued on the position stream and captures it on first use"""
         L = lib()
         # everything queued on the position stream (begin()) must precede the joint graph, which runs on the feature stream
         self.stream.wait_stream(self.stream2)
+        if self.graph is not None:
+            return
         with torch.cuda.stream(self.stream):
             s, s2 = ctypes.c_void_p(self.stream.cuda_stream), ctypes.c_void_p(self.stream2.cuda_stream)
-            if self.graph is None:
-                e1, e2 = self.pos.engine, self.feat.engine
-                keep = [e1.x.clone(), e1.t_dev.clone(), e2.x.clone(), e2.t_dev.clone()]
-                check(L.slide_run_ops2(self.step_ops, len(self.step_ops), s, s2), "slide_run_ops2")
-                self.stream.synchronize(); self.stream2.synchronize()
-                e1.x.copy_(keep[0]); e1.t_dev.copy_(keep[1]); e2.x.copy_(keep[2]); e2.t_dev.copy_(keep[3])
-                self.stream.synchronize()
-                check(L.slide_graph_begin(s), "graph_begin")
-                st = L.slide_run_ops2(self.step_ops, len(self.step_ops), s, s2)
-                g = ctypes.c_void_p()
-                st2 = L.slide_graph_end(s, ctypes.byref(g))
-                check(st, "slide_run_ops2(capture)"); check(st2, "graph_end")
-                self.graph = g
-            for _ in range(n_steps):
-                check(L.slide_graph_launch(self.graph, s), "graph_launch")
+            e1, e2 = self.pos.engine, self.feat.engine
+            keep = [e1.x.clone(), e1.t_dev.clone(), e2.x.clone(), e2.t_dev.clone()]
+            check(L.slide_run_ops2(self.step_ops, len(self.step_ops), s, s2), "slide_run_ops2")
+            self.stream.synchronize(); self.stream2.synchronize()
+            e1.x.copy_(keep[0]); e1.t_dev.copy_(keep[1]); e2.x.copy_(keep[2]); e2.t_dev.copy_(keep[3])
+            self.stream.synchronize()
+            check(L.slide_graph_begin(s), "graph_begin")
+            st = L.slide_run_ops2(self.step_ops, len(self.step_ops), s, s2)
+            g = ctypes.c_void_p()
+            st2 = L.slide_graph_end(s, ctypes.byref(g))
+            check(st, "slide_run_ops2(capture)"); check(st2, "graph_end")
+            self.graph = g
+
+    def _launch(self):
+        check(lib().slide_graph_launch(self.graph, ctypes.c_void_p(self.stream.cuda_stream)), "graph_launch")
+
+    def _finish(self):
         self.stream2.wait_stream(self.stream)
+
+    def advance(self, n_steps):
+        self._prepare()
+        for _ in range(n_steps):
+            self._launch()
+        self._finish()
 
     def synchronize(self):
         self.stream.synchronize(); self.stream2.synchronize()
+
+
+class SplitJointSampler:
+    """A batch processed as P independent sub-batches, each a JointSampler on its own pair of streams, their per-step
+    graphs launched round-robin.  The sub-batches are independent objects of the partition (no exchange), so this is
+    pure scheduling: while one sub-batch sits in its latency-bound kernels (16-row per-point GEMMs, normalisation
+    finalisers, the position plan) the other's wide GEMMs have the CUs, which a single dependent chain cannot do.
+    Measured at batch 256 on one MI355X: 2 sub-batches 1.34 ms/step vs 1.46 (one), 3 and 4 are slower."""
+
+    def __init__(self, joints):
+        self.joints = list(joints)
+
+    def advance(self, n_steps):
+        for j in self.joints:
+            j._prepare()
+        for _ in range(n_steps):
+            for j in self.joints:
+                j._launch()
+        for j in self.joints:
+            j._finish()
+
+    def synchronize(self):
+        for j in self.joints:
+            j.synchronize()
