@@ -1,6 +1,7 @@
 """Drop-in counterpart of the reference's native module `pointnet2_ops._ext`
 (_ext-src/src/bindings.cpp:6-19): the same nine functions, argument order, dtypes, output
-allocation (zeros / FPS scratch 1e10) and error behaviour (RuntimeError on non-contiguous /
+allocation (zeros where an op leaves elements unwritten -- ball_query, the grads, three_nn, FPS -- and the FPS scratch
+1e10; the three forward gathers write every element, so their outputs are allocated uninitialised) and error behaviour (RuntimeError on non-contiguous /
 wrong dtype / CPU tensors: _ext-src/include/utils.h:5-25, sampling.cpp:21-34), implemented on
 hand-written gfx950 HIP kernels through the C-ABI in include/slide_hip.h.
 
@@ -43,7 +44,8 @@ def gather_points(points, idx):
     _chk_contig(points, "points"); _chk_contig(idx, "idx"); _chk_float(points, "points"); _chk_int(idx, "idx")
     if points.is_cuda:
         _chk_cuda(idx, "idx")
-    out = torch.zeros((points.size(0), points.size(1), idx.size(1)), device=points.device, dtype=torch.float32)
+    # the kernel writes every element: the reference's zero fill would only add a second pass over the output
+    out = torch.empty((points.size(0), points.size(1), idx.size(1)), device=points.device, dtype=torch.float32)
     _need_gpu(points)
     check(lib().gather_points_kernel_wrapper(points.size(0), points.size(1), points.size(2), idx.size(1),
                                              ptr(points), ptr(idx), ptr(out), stream_of()), "gather_points")
@@ -95,7 +97,7 @@ def three_interpolate(points, idx, weight):
     _chk_float(points, "points"); _chk_int(idx, "idx"); _chk_float(weight, "weight")
     if points.is_cuda:
         _chk_cuda(idx, "idx"); _chk_cuda(weight, "weight")
-    out = torch.zeros((points.size(0), points.size(1), idx.size(1)), device=points.device, dtype=torch.float32)
+    out = torch.empty((points.size(0), points.size(1), idx.size(1)), device=points.device, dtype=torch.float32)
     _need_gpu(points)
     check(lib().three_interpolate_kernel_wrapper(points.size(0), points.size(1), points.size(2), idx.size(1),
                                                  ptr(points), ptr(idx), ptr(weight), ptr(out), stream_of()),
@@ -137,7 +139,7 @@ def group_points(points, idx):
     _chk_contig(points, "points"); _chk_contig(idx, "idx"); _chk_float(points, "points"); _chk_int(idx, "idx")
     if points.is_cuda:
         _chk_cuda(idx, "idx")
-    out = torch.zeros((points.size(0), points.size(1), idx.size(1), idx.size(2)), device=points.device,
+    out = torch.empty((points.size(0), points.size(1), idx.size(1), idx.size(2)), device=points.device,
                       dtype=torch.float32)
     _need_gpu(points)
     check(lib().group_points_kernel_wrapper(points.size(0), points.size(1), points.size(2), idx.size(1), idx.size(2),

@@ -31,6 +31,23 @@ __global__ void gather_points_kernel(int c, int n, int m, const float *__restric
     out[((size_t)b * c + l) * m + j] = points[((size_t)b * c + l) * n + a];
 }
 
+// Four consecutive outputs per thread: the index quad is read once (16 B), every channel costs four 4-byte gathers
+// (the point row is L2-/L1-resident) and ONE 16-byte non-temporal store -- the stores are what the op moves through HBM.
+typedef float pf4 __attribute__((ext_vector_type(4)));
+typedef int pi4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void gather_points_v4_kernel(int c, int n, int m, const float *__restrict__ points,
+                                                               const int *__restrict__ idx, float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (j >= m) return;
+  const pi4 a = *reinterpret_cast<const pi4 *>(idx + (size_t)b * m + j);
+  for (int l = blockIdx.y; l < c; l += gridDim.y) {
+    const float *p = points + ((size_t)b * c + l) * n;
+    const pf4 v = {p[a[0]], p[a[1]], p[a[2]], p[a[3]]};
+    __builtin_nontemporal_store(v, reinterpret_cast<pf4 *>(out + ((size_t)b * c + l) * m + j));
+  }
+}
+
 // grad_points[b,c,idx[b,j]] += grad_out[b,c,j]   (sampling_gpu.cu:34-47)
 __global__ void gather_points_grad_kernel(int c, int n, int m, const float *__restrict__ grad_out,
                                           const int *__restrict__ idx, float *__restrict__ grad_points) {
@@ -238,6 +255,65 @@ __global__ __launch_bounds__(256) void group_points_kernel(int c, int n, int slo
   for (int l = l0; l < l1; ++l) o[(size_t)l * slots + s] = p[(size_t)l * n + ii];
 }
 
+__global__ __launch_bounds__(256) void group_points_v4_kernel(int c, int n, int slots, int cchunk,
+                                                              const float *__restrict__ points,
+                                                              const int *__restrict__ idx, float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int s = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (s >= slots) return;
+  const pi4 ii = *reinterpret_cast<const pi4 *>(idx + (size_t)b * slots + s);
+  const int l0 = blockIdx.y * cchunk, l1 = min(c, l0 + cchunk);
+  const float *p = points + (size_t)b * c * n;
+  float *o = out + (size_t)b * c * slots + s;
+#pragma unroll 2
+  for (int l = l0; l < l1; ++l) {
+    const float *pl = p + (size_t)l * n;
+    const pf4 v = {pl[ii[0]], pl[ii[1]], pl[ii[2]], pl[ii[3]]};
+    __builtin_nontemporal_store(v, reinterpret_cast<pf4 *>(o + (size_t)l * slots));
+  }
+}
+
+// Row-in-LDS gather (group_points, and gather_points = the ns == 1 case): a block owns QPT*1024 consecutive output slots
+// of one batch element -- their indices stay in registers -- and walks a chunk of channels.  Per channel the n-float point
+// row is staged in LDS with coalesced 16-byte loads (read from L2 once per block instead of 4 bytes per gathered element),
+// gathered with ds_read_b32, and written with 16-byte non-temporal stores: the op then moves little more than its
+// output through HBM.  QPT = index quads per thread.
+template <int QPT>
+__global__ __launch_bounds__(256) void group_points_lds_kernel(int c, int n, int slots, int cchunk,
+                                                               const float *__restrict__ points,
+                                                               const int *__restrict__ idx, float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float row[];
+  const int b = blockIdx.z;
+  const int s0 = blockIdx.x * (QPT * 1024);
+  pi4 ii[QPT];
+#pragma unroll
+  for (int q = 0; q < QPT; ++q) {
+    const int s = s0 + (q * 256 + threadIdx.x) * 4;
+    ii[q] = s < slots ? *reinterpret_cast<const pi4 *>(idx + (size_t)b * slots + s) : pi4{0, 0, 0, 0};
+  }
+  const int l0 = blockIdx.y * cchunk, l1 = min(c, l0 + cchunk);
+  const float *p = points + (size_t)b * c * n;
+  float *o = out + (size_t)b * c * slots;
+  for (int l = l0; l < l1; ++l) {
+    __syncthreads();  // the previous channel's gathers are done
+    const float *pl = p + (size_t)l * n;
+    if ((n & 3) == 0) {
+      for (int i = threadIdx.x * 4; i < n; i += 1024) *reinterpret_cast<pf4 *>(row + i) = *reinterpret_cast<const pf4 *>(pl + i);
+    } else {
+      for (int i = threadIdx.x; i < n; i += 256) row[i] = pl[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < QPT; ++q) {
+      const int s = s0 + (q * 256 + threadIdx.x) * 4;
+      if (s < slots) {
+        const pf4 v = {row[ii[q][0]], row[ii[q][1]], row[ii[q][2]], row[ii[q][3]]};
+        __builtin_nontemporal_store(v, reinterpret_cast<pf4 *>(o + (size_t)l * slots + s));
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void group_points_grad_kernel(int c, int n, int slots, int cchunk,
                                                                 const float *__restrict__ grad_out,
                                                                 const int *__restrict__ idx,
@@ -318,6 +394,85 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, in
   for (int l = l0; l < l1; ++l) {
     const float *pl = p + (size_t)l * m;
     o[(size_t)l * n + j] = fmaf(pl[i3], w3, fmaf(pl[i2], w2, pl[i1] * w1));
+  }
+}
+
+__global__ __launch_bounds__(256) void three_interpolate_v4_kernel(int c, int m, int n, int cchunk,
+                                                                   const float *__restrict__ points,
+                                                                   const int *__restrict__ idx,
+                                                                   const float *__restrict__ weight,
+                                                                   float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (j >= n) return;
+  const pi4 *id = reinterpret_cast<const pi4 *>(idx + ((size_t)b * n + j) * 3);
+  const pf4 *w = reinterpret_cast<const pf4 *>(weight + ((size_t)b * n + j) * 3);
+  const pi4 ia = id[0], ib = id[1], ic = id[2];  // (i1 i2 i3 | i1') (i2' i3' | i1'' i2'') (i3'' | i1''' i2''' i3''')
+  const pf4 wa = w[0], wb = w[1], wc = w[2];
+  const int l0 = blockIdx.y * cchunk, l1 = min(c, l0 + cchunk);
+  const float *p = points + (size_t)b * c * m;
+  float *o = out + (size_t)b * c * n + j;
+#pragma unroll 2
+  for (int l = l0; l < l1; ++l) {
+    const float *pl = p + (size_t)l * m;
+    pf4 v;
+    v[0] = fmaf(pl[ia[2]], wa[2], fmaf(pl[ia[1]], wa[1], pl[ia[0]] * wa[0]));
+    v[1] = fmaf(pl[ib[1]], wb[1], fmaf(pl[ib[0]], wb[0], pl[ia[3]] * wa[3]));
+    v[2] = fmaf(pl[ic[0]], wc[0], fmaf(pl[ib[3]], wb[3], pl[ib[2]] * wb[2]));
+    v[3] = fmaf(pl[ic[3]], wc[3], fmaf(pl[ic[2]], wc[2], pl[ic[1]] * wc[1]));
+    __builtin_nontemporal_store(v, reinterpret_cast<pf4 *>(o + (size_t)l * n));
+  }
+}
+
+// three_interpolate with the m-float feature row of the current channel staged in LDS (same scheme as
+// group_points_lds_kernel): 2 output quads per thread, their 24 indices and weights in registers.
+__global__ __launch_bounds__(256) void three_interpolate_lds_kernel(int c, int m, int n, int cchunk,
+                                                                    const float *__restrict__ points,
+                                                                    const int *__restrict__ idx,
+                                                                    const float *__restrict__ weight,
+                                                                    float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float row[];
+  const int b = blockIdx.z;
+  const int j0 = blockIdx.x * 2048;
+  pi4 ia[2], ib[2], ic[2];
+  pf4 wa[2], wb[2], wc[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int j = j0 + (q * 256 + threadIdx.x) * 4;
+    if (j < n) {
+      const pi4 *id = reinterpret_cast<const pi4 *>(idx + ((size_t)b * n + j) * 3);
+      const pf4 *w = reinterpret_cast<const pf4 *>(weight + ((size_t)b * n + j) * 3);
+      ia[q] = id[0]; ib[q] = id[1]; ic[q] = id[2];
+      wa[q] = w[0]; wb[q] = w[1]; wc[q] = w[2];
+    } else {
+      ia[q] = ib[q] = ic[q] = pi4{0, 0, 0, 0};
+      wa[q] = wb[q] = wc[q] = pf4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const int l0 = blockIdx.y * cchunk, l1 = min(c, l0 + cchunk);
+  const float *p = points + (size_t)b * c * m;
+  float *o = out + (size_t)b * c * n;
+  for (int l = l0; l < l1; ++l) {
+    __syncthreads();
+    const float *pl = p + (size_t)l * m;
+    if ((m & 3) == 0) {
+      for (int i = threadIdx.x * 4; i < m; i += 1024) *reinterpret_cast<pf4 *>(row + i) = *reinterpret_cast<const pf4 *>(pl + i);
+    } else {
+      for (int i = threadIdx.x; i < m; i += 256) row[i] = pl[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int j = j0 + (q * 256 + threadIdx.x) * 4;
+      if (j < n) {
+        pf4 v;
+        v[0] = fmaf(row[ia[q][2]], wa[q][2], fmaf(row[ia[q][1]], wa[q][1], row[ia[q][0]] * wa[q][0]));
+        v[1] = fmaf(row[ib[q][1]], wb[q][1], fmaf(row[ib[q][0]], wb[q][0], row[ia[q][3]] * wa[q][3]));
+        v[2] = fmaf(row[ic[q][0]], wc[q][0], fmaf(row[ib[q][3]], wb[q][3], row[ib[q][2]] * wb[q][2]));
+        v[3] = fmaf(row[ic[q][3]], wc[q][3], fmaf(row[ic[q][2]], wc[q][2], row[ic[q][1]] * wc[q][1]));
+        __builtin_nontemporal_store(v, reinterpret_cast<pf4 *>(o + (size_t)l * n + j));
+      }
+    }
   }
 }
 
@@ -444,9 +599,37 @@ int slide_hip_device_ok(void) {
   return a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0';
 }
 
+static inline int pick_cchunk(int c, int blocks_other);
+static int launch_group_lds(int b, int c, int n, int slots, const float *points, const int *idx, float *out,
+                            hipStream_t stream) {
+  const int qpt = slots >= 4096 ? 4 : (slots >= 2048 ? 2 : 1);
+  const int gx = (slots + qpt * 1024 - 1) / (qpt * 1024);
+  int chunks = (1024 + gx * b - 1) / (gx * b);  // >= 4 blocks per CU overall; long channel walks amortise the index reads
+  chunks = chunks < 1 ? 1 : (chunks > c ? c : chunks);
+  const int cchunk = (c + chunks - 1) / chunks;
+  const dim3 grid(gx, (c + cchunk - 1) / cchunk, b);
+  const size_t shm = (size_t)((n + 3) & ~3) * 4;
+#define GL(Q)                                                                                                        \
+  hipLaunchKernelGGL((group_points_lds_kernel<Q>), grid, dim3(256), shm, stream, c, n, slots, cchunk, points, idx, out)
+  if (qpt == 4) GL(4); else if (qpt == 2) GL(2); else GL(1);
+#undef GL
+  return LAUNCH_STATUS();
+}
+
 int gather_points_kernel_wrapper(int b, int c, int n, int npoints, const float *points, const int *idx,
                                  float *out, slide_stream_t stream) {
   if (b <= 0 || c <= 0 || npoints <= 0) return 0;
+  if (npoints % 4 == 0 && (((uintptr_t)idx | (uintptr_t)out | (uintptr_t)points) & 15) == 0 && n <= 16384 && npoints >= 1024) {
+    return launch_group_lds(b, c, n, npoints, points, idx, out, (hipStream_t)stream);  // gather = grouping with ns = 1
+  }
+  if (npoints % 4 == 0 && (((uintptr_t)idx | (uintptr_t)out) & 15) == 0) {
+    const int gx = (npoints / 4 + 255) / 256;
+    int gy = (2048 + gx * b - 1) / (gx * b);  // enough blocks for the chip, each walking a strided set of channels
+    gy = gy < 1 ? 1 : (gy > c ? c : gy);
+    hipLaunchKernelGGL(gather_points_v4_kernel, dim3(gx, gy, b), dim3(256), 0, (hipStream_t)stream, c, n, npoints,
+                       points, idx, out);
+    return LAUNCH_STATUS();
+  }
   dim3 grid((npoints + 255) / 256, c < 64 ? c : 64, b);
   hipLaunchKernelGGL(gather_points_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, n, npoints, points,
                      idx, out);
@@ -520,6 +703,16 @@ int group_points_kernel_wrapper(int b, int c, int n, int npoints, int nsample, c
                                 const int *idx, float *out, slide_stream_t stream) {
   const int slots = npoints * nsample;
   if (b <= 0 || c <= 0 || slots <= 0) return 0;
+  if (slots % 4 == 0 && (((uintptr_t)idx | (uintptr_t)out | (uintptr_t)points) & 15) == 0 && n <= 16384 && slots >= 2048) {
+    return launch_group_lds(b, c, n, slots, points, idx, out, (hipStream_t)stream);
+  }
+  if (slots % 4 == 0 && (((uintptr_t)idx | (uintptr_t)out) & 15) == 0) {
+    const int gx = (slots / 4 + 255) / 256;
+    const int cchunk = pick_cchunk(c, gx * b);
+    hipLaunchKernelGGL(group_points_v4_kernel, dim3(gx, (c + cchunk - 1) / cchunk, b), dim3(256), 0,
+                       (hipStream_t)stream, c, n, slots, cchunk, points, idx, out);
+    return LAUNCH_STATUS();
+  }
   const int gx = (slots + 255) / 256;
   const int cchunk = pick_cchunk(c, gx * b);
   hipLaunchKernelGGL(group_points_kernel, dim3(gx, (c + cchunk - 1) / cchunk, b), dim3(256), 0,
@@ -549,6 +742,23 @@ int three_nn_kernel_wrapper(int b, int n, int m, const float *unknown, const flo
 int three_interpolate_kernel_wrapper(int b, int c, int m, int n, const float *points, const int *idx,
                                      const float *weight, float *out, slide_stream_t stream) {
   if (b <= 0 || c <= 0 || n <= 0) return 0;
+  if (n % 4 == 0 && (((uintptr_t)idx | (uintptr_t)weight | (uintptr_t)out | (uintptr_t)points) & 15) == 0 && m <= 16384 &&
+      n >= 2048) {
+    const int gx = (n + 2047) / 2048;
+    int chunks = (1024 + gx * b - 1) / (gx * b);
+    chunks = chunks < 1 ? 1 : (chunks > c ? c : chunks);
+    const int cchunk = (c + chunks - 1) / chunks;
+    hipLaunchKernelGGL(three_interpolate_lds_kernel, dim3(gx, (c + cchunk - 1) / cchunk, b), dim3(256),
+                       (size_t)((m + 3) & ~3) * 4, (hipStream_t)stream, c, m, n, cchunk, points, idx, weight, out);
+    return LAUNCH_STATUS();
+  }
+  if (n % 4 == 0 && (((uintptr_t)idx | (uintptr_t)weight | (uintptr_t)out) & 15) == 0) {
+    const int gx = (n / 4 + 255) / 256;
+    const int cchunk = pick_cchunk(c, gx * b);
+    hipLaunchKernelGGL(three_interpolate_v4_kernel, dim3(gx, (c + cchunk - 1) / cchunk, b), dim3(256), 0,
+                       (hipStream_t)stream, c, m, n, cchunk, points, idx, weight, out);
+    return LAUNCH_STATUS();
+  }
   const int gx = (n + 255) / 256;
   const int cchunk = pick_cchunk(c, gx * b);
   hipLaunchKernelGGL(three_interpolate_kernel, dim3(gx, (c + cchunk - 1) / cchunk, b), dim3(256), 0,

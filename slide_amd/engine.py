@@ -258,7 +258,7 @@ class DenoiserEngine:
         assert X.dtype == self.adt
         # wide (128-channel) tiles only when the grid still covers the 256 CUs at least twice
         ntr = (rows + 255) // 256
-        cbw = 4 if (self.prec == 1 and n_cob >= 4 and ntr * ((n_cob + 3) // 4) >= 512) else 2
+        cbw = 4 if (self.prec == 1 and n_cob >= 4 and ntr * ((n_cob + 3) // 4) >= int(os.environ.get('SLIDE_CBW4_TILES', '256'))) else 2
         self.gemm_flops[len(self.ops)] = 2 * rows * sum(int(s["w"].size) for s in segs)
         esz = X.element_size()
         rd = rows * ld * esz + W.size * esz + sum(rows * v[2] * esz for v in vec_list if v[1].get("residual") is not None)
