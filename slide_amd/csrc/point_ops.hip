@@ -77,6 +77,39 @@ __device__ __forceinline__ int fps_unrank(unsigned r, int bs, int lg, int L) {
   return (int)(kk * (unsigned)bs + t);
 }
 
+// max of a 64-bit key over the wave, result in every lane: DPP row operations inside each row of 16 lanes (no LDS
+// round trip per step as with ds_bpermute shuffles), one ds_swizzle across the rows of a half, scalar lanes 0 / 32 last.
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#define SLIDE_KEY_STEP(MOVE)                                                      \
+  {                                                                                \
+    const unsigned hi = (unsigned)(MOVE((int)(v >> 32)));                          \
+    const unsigned lo = (unsigned)(MOVE((int)(unsigned)v));                        \
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;              \
+    v = o > v ? o : v;                                                             \
+  }
+#define SLIDE_DPP_B1(x) __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true)
+#define SLIDE_DPP_4E(x) __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true)
+#define SLIDE_DPP_141(x) __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true)
+#define SLIDE_DPP_140(x) __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true)
+#define SLIDE_SWZ_16(x) __builtin_amdgcn_ds_swizzle(x, 0x401F)
+  SLIDE_KEY_STEP(SLIDE_DPP_B1)
+  SLIDE_KEY_STEP(SLIDE_DPP_4E)
+  SLIDE_KEY_STEP(SLIDE_DPP_141)
+  SLIDE_KEY_STEP(SLIDE_DPP_140)
+  SLIDE_KEY_STEP(SLIDE_SWZ_16)
+#undef SLIDE_KEY_STEP
+#undef SLIDE_DPP_B1
+#undef SLIDE_DPP_4E
+#undef SLIDE_DPP_141
+#undef SLIDE_DPP_140
+#undef SLIDE_SWZ_16
+  const unsigned long long a = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), 0) << 32) |
+                               (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 0);
+  const unsigned long long c = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), 32) << 32) |
+                               (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 32);
+  return a > c ? a : c;
+}
+
 template <int PPT, int NT>
 __global__ __launch_bounds__(NT) void fps_kernel(int n, int m, int bs, int lg, int L, int use_lds, int skip_origin,
                                                  const int *__restrict__ start, const float *__restrict__ dataset,
@@ -131,13 +164,7 @@ __global__ __launch_bounds__(NT) void fps_kernel(int n, int m, int bs, int lg, i
         best = key > best ? key : best;
       }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const unsigned hi = __shfl_xor((unsigned)(best >> 32), off);
-      const unsigned lo = __shfl_xor((unsigned)best, off);
-      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-      best = o > best ? o : best;
-    }
+    best = wave_max_u64(best);
     if (NT > 64) {
       if ((tid & 63) == 0) wkeys[j & 1][tid >> 6] = best;
       __syncthreads();
@@ -182,12 +209,7 @@ __global__ __launch_bounds__(1024) void fps_kernel_large(int n, int m, int bs, i
                                      (unsigned long long)(0xFFFFFFFFu - fps_rank(k, bs, lg, L));
       best = key > best ? key : best;
     }
-    for (int off = 32; off >= 1; off >>= 1) {
-      const unsigned hi = __shfl_xor((unsigned)(best >> 32), off);
-      const unsigned lo = __shfl_xor((unsigned)best, off);
-      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-      best = o > best ? o : best;
-    }
+    best = wave_max_u64(best);
     if ((tid & 63) == 0) wkeys[j & 1][tid >> 6] = best;
     __syncthreads();
     for (int w = 0; w < 16; ++w) {
