@@ -67,8 +67,8 @@ enum {
   SLIDE_OP_COPY_COLS = 7,   /* p: src, dst    i: rows, n, src_ld, dst_ld, src_is_f16, dst_is_f16 */
   SLIDE_OP_TEMB = 8,        /* p: ts(or NULL), t_dev, w1,b1,w2,b2, wfc, bfc, out, freq   i: nsamp, t_dim, n_out  (weights [in][out]) */
   SLIDE_OP_COND = 9,        /* p: label(int64), class_emb, wfc, bfc, out           i: B, dim, n_out */
-  SLIDE_OP_UPDATE_POS = 10, /* p: x, eps, noise(or NULL), t_dev, c_eps, sqrt_alpha, sigma  i: n_elem, -, seed_lo, seed_hi */
-  SLIDE_OP_UPDATE_FEAT = 11,/* p: x, eps, noise(or NULL), t_dev, keypoint, c_recip, c_recipm1, c1, c2, c_std  i: n_pts, C, kdim, seed_lo, seed_hi  f: clamp */
+  SLIDE_OP_UPDATE_POS = 10, /* p: x, eps, noise(or NULL), t_dev, c_eps, sqrt_alpha, sigma  i: n_elem, eps_ld (0 = compact rows of 3), seed_lo, seed_hi */
+  SLIDE_OP_UPDATE_FEAT = 11,/* p: x, eps, noise(or NULL), t_dev, keypoint, c_recip, c_recipm1, c1, c2, c_std  i: n_pts, C, kdim, seed_lo, seed_hi, eps_ld (0 = C)  f: clamp */
   SLIDE_OP_ADVANCE_T = 12,  /* p: t_dev  (t_dev[0] -= 1; t_dev[1] += 1) */
   SLIDE_OP_SYNC = 14,       /* i: from_lane, to_lane -- lane `to` waits for everything issued so far on lane `from` */
   SLIDE_OP_GROUPNORM_NCHW = 13 /* p: x, gamma, beta, y (NCHW fp32)   i: B, C, HW, G, n_norm, relu  (module-level path) */

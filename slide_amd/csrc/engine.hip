@@ -1245,7 +1245,7 @@ __device__ __forceinline__ float philox_normal(uint32_t seed_lo, uint32_t seed_h
 }
 
 // sampling() update (pointnet2/util.py:247-253): x = (x - c_eps[t]*eps)/sqrt_alpha[t]; t>0: x += sigma[t]*z
-__global__ __launch_bounds__(256) void update_pos_kernel(int n, uint32_t seed_lo, uint32_t seed_hi, float *__restrict__ x,
+__global__ __launch_bounds__(256) void update_pos_kernel(int n, int eps_ld, uint32_t seed_lo, uint32_t seed_hi, float *__restrict__ x,
                                                          const float *__restrict__ eps, const float *__restrict__ noise,
                                                          const int *__restrict__ t_dev, const float *__restrict__ c_eps,
                                                          const float *__restrict__ sqrt_alpha,
@@ -1254,7 +1254,8 @@ __global__ __launch_bounds__(256) void update_pos_kernel(int n, uint32_t seed_lo
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
   const int t = t_dev[0], step = t_dev[1];
-  float v = (x[e] - c_eps[t] * eps[e]) / sqrt_alpha[t];
+  const int ep = eps_ld ? (e / 3) * eps_ld + e % 3 : e;  // eps rows may be padded (the plan's last GEMM output)
+  float v = (x[e] - c_eps[t] * eps[ep]) / sqrt_alpha[t];
   if (t > 0) {
     const float z = noise ? noise[(size_t)step * n + e] : philox_normal(seed_lo, seed_hi, (uint32_t)step, (uint32_t)e);
     v = v + sigma[t] * z;
@@ -1264,7 +1265,7 @@ __global__ __launch_bounds__(256) void update_pos_kernel(int n, uint32_t seed_lo
 
 // denoising_step (pointnet2/diffusion_utils/diffusion.py:58-95) with the key-point channels re-clamped to the
 // condition (:383-385): x0 = rc*x - rm1*eps [clamp]; mean = c1*x0 + c2*x; x = mean + [t>0] std*z
-__global__ __launch_bounds__(256) void update_feat_kernel(int npts, int C, int kdim, float clamp, uint32_t seed_lo,
+__global__ __launch_bounds__(256) void update_feat_kernel(int npts, int C, int kdim, int eps_ld, float clamp, uint32_t seed_lo,
                                                           uint32_t seed_hi, float *__restrict__ x,
                                                           const float *__restrict__ eps, const float *__restrict__ noise,
                                                           const int *__restrict__ t_dev, const float *__restrict__ keypoint,
@@ -1281,7 +1282,7 @@ __global__ __launch_bounds__(256) void update_feat_kernel(int npts, int C, int k
   }
   const int t = t_dev[0], step = t_dev[1];
   const float xv = x[e];
-  float x0 = rc[t] * xv - rm1[t] * eps[e];
+  float x0 = rc[t] * xv - rm1[t] * eps[eps_ld ? (size_t)p * eps_ld + c : (size_t)e];
   if (clamp > 0.f) x0 = fminf(fmaxf(x0, -clamp), clamp);
   float v = c1[t] * x0 + c2[t] * xv;
   if (t > 0) {
@@ -1477,13 +1478,13 @@ int run_op(const SlideOp &o, hipStream_t s) {
                          (float *)o.p[4]);
       break;
     case SLIDE_OP_UPDATE_POS:
-      hipLaunchKernelGGL(update_pos_kernel, dim3((o.i[0] + 255) / 256), dim3(256), 0, s, o.i[0], (uint32_t)o.i[2],
+      hipLaunchKernelGGL(update_pos_kernel, dim3((o.i[0] + 255) / 256), dim3(256), 0, s, o.i[0], o.i[1], (uint32_t)o.i[2],
                          (uint32_t)o.i[3], (float *)o.p[0], (const float *)o.p[1], (const float *)o.p[2],
                          (const int *)o.p[3], (const float *)o.p[4], (const float *)o.p[5], (const float *)o.p[6]);
       break;
     case SLIDE_OP_UPDATE_FEAT:
       hipLaunchKernelGGL(update_feat_kernel, dim3((o.i[0] * o.i[1] + 255) / 256), dim3(256), 0, s, o.i[0], o.i[1],
-                         o.i[2], o.f[0], (uint32_t)o.i[3], (uint32_t)o.i[4], (float *)o.p[0], (const float *)o.p[1],
+                         o.i[2], o.i[5], o.f[0], (uint32_t)o.i[3], (uint32_t)o.i[4], (float *)o.p[0], (const float *)o.p[1],
                          (const float *)o.p[2], (const int *)o.p[3], (const float *)o.p[4], (const float *)o.p[5],
                          (const float *)o.p[6], (const float *)o.p[7], (const float *)o.p[8], (const float *)o.p[9]);
       break;

@@ -68,11 +68,23 @@ class _GraphedSampler:
         self.graph = None
         self.step_ops = None
 
-    def _finish_plan(self, update_op):
+    def _finish_plan(self, update_op, fixed_xyz=False):
+        """step plan = the denoiser plan minus its output compaction (the update reads the padded rows) and, when the
+        coordinates are a fixed condition (feature DDPM: key points), minus the copies of the coordinate columns, which
+        then run once per batch in begin() -- then the update and the device-side t -= 1"""
         e = self.engine
-        ops = list(e.ops) + [update_op, make_op(OP_ADVANCE_T, p=(e.t_dev.data_ptr(),))]
+        hoisted = set(e.xyz_copy_idx) if fixed_xyz else set()
+        drop = hoisted | {e.eps_copy_idx}
+        ops = [o for i, o in enumerate(e.ops) if i not in drop]
+        ops += [update_op, make_op(OP_ADVANCE_T, p=(e.t_dev.data_ptr(),))]
         self.step_ops = (SlideOp * len(ops))(*ops)
         self.n_launches = len(ops)
+        # once per batch: everything up to the last hoisted copy that the copies depend on (the point preparation)
+        self.begin_ops = None
+        if hoisted:
+            from .engine import OP_PREP_POINTS
+            b_ops = [o for i, o in enumerate(e.ops) if o.kind == OP_PREP_POINTS or i in hoisted]
+            self.begin_ops = (SlideOp * len(b_ops))(*b_ops)
         if self.device.type == "cuda":
             e.prepare()
             torch.cuda.synchronize(self.device)  # plan tensors / tables were filled on the default stream
@@ -140,8 +152,8 @@ class PositionSampler(_GraphedSampler):
         self.noise = None if noise is None else e.A.put(np.asarray(noise, F32).reshape(len(noise), -1))
         n = self.B * 16 * 3
         assert e.cx == 3 and e.out_dim == 3
-        self._finish_plan(make_op(OP_UPDATE_POS, i=(n, 0, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF),
-                                  p=(e.x.data_ptr(), e.eps.data_ptr(), None if self.noise is None else self.noise.data_ptr(),
+        self._finish_plan(make_op(OP_UPDATE_POS, i=(n, e.eps_pad.shape[1], seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF),
+                                  p=(e.x.data_ptr(), e.eps_pad.data_ptr(), None if self.noise is None else self.noise.data_ptr(),
                                      e.t_dev.data_ptr(), self.tabs[0].data_ptr(), self.tabs[1].data_ptr(),
                                      self.tabs[2].data_ptr())))
 
@@ -177,12 +189,12 @@ class FeatureSampler(_GraphedSampler):
         self.kdim = keypoint_dim
         assert e.out_dim == e.cx
         self._finish_plan(make_op(OP_UPDATE_FEAT, i=(self.B * 16, e.cx, keypoint_dim, seed & 0xFFFFFFFF,
-                                                     (seed >> 32) & 0xFFFFFFFF),
+                                                     (seed >> 32) & 0xFFFFFFFF, e.eps_pad.shape[1]),
                                   f=(float(dp["data_clamp_range"]),),
-                                  p=(e.x.data_ptr(), e.eps.data_ptr(), None if self.noise is None else self.noise.data_ptr(),
+                                  p=(e.x.data_ptr(), e.eps_pad.data_ptr(), None if self.noise is None else self.noise.data_ptr(),
                                      e.t_dev.data_ptr(), self.keypoint.data_ptr(), self.tabs[0].data_ptr(),
                                      self.tabs[1].data_ptr(), self.tabs[2].data_ptr(), self.tabs[3].data_ptr(),
-                                     self.tabs[4].data_ptr())))
+                                     self.tabs[4].data_ptr())), fixed_xyz=keypoint_dim == 3)
 
     def sample(self, label, keypoint, x_T, t_start=None, n_steps=None):
         t_start = self.T - 1 if t_start is None else t_start
@@ -199,6 +211,8 @@ class FeatureSampler(_GraphedSampler):
             self.keypoint.copy_(kp.reshape(self.B * 16, self.kdim))
             self.engine.set_label(label)
             self._set_state(x, self.T - 1 if t_start is None else t_start)
+            if self.begin_ops is not None:  # coordinate columns of the key points: constant over the chain
+                self.engine.run(self.begin_ops)
 
 
 class JointSampler:

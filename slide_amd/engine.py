@@ -451,6 +451,7 @@ class DenoiserEngine:
         es = Z.element_size()
         self._emit(make_op(OP_COPY_COLS, i=(B * 16, CU, U.shape[1], Z.shape[1], int(self.prec == 1), int(self.prec == 1)),
                                 p=(U.data_ptr(), Z.data_ptr() + es * c_last)))
+        self.xyz_copy_idx.append(len(self.ops))  # loop-invariant when the coordinates are a fixed condition
         self._emit(make_op(OP_COPY_COLS, i=(B * 16, 3, 3, Z.shape[1], 0, int(self.prec == 1)),
                                 p=(self.xyz.data_ptr(), Z.data_ptr() + es * (c_last + CU))))
         n1 = sd[m2 + ".first_mlp.0.weight"].shape[0]
@@ -469,6 +470,7 @@ class DenoiserEngine:
         self.flops = 0
         self.gemm_flops = {}
         self.gemm_bytes = {}
+        self.xyz_copy_idx = []
         self.persistent = os.environ.get('SLIDE_PERSISTENT', '0') != '0'
         # persistent I/O + per-step state
         self.x = A.zeros(B, 16, self.cx)
@@ -512,6 +514,7 @@ class DenoiserEngine:
             feats[i - 1], chans[i - 1] = o, c
         # output head fc_lyaer (pointnet2_with_pcld_condition.py:480-483): conv -> GN(32,128) -> ReLU -> conv
         c = chans[0]
+        self.xyz_copy_idx.append(len(self.ops))
         self._emit(make_op(OP_COPY_COLS, i=(B * 16, 3, 3, dec0.shape[1], 0, int(self.prec == 1)),
                                 p=(self.xyz.data_ptr(), dec0.data_ptr() + dec0.element_size() * c)))
         hh = self._buf(B * 16, sd["fc_lyaer.0.weight"].shape[0])
@@ -522,6 +525,7 @@ class DenoiserEngine:
         self.eps_pad = self._buf(B * 16, self.out_dim, dtype=torch.float32)
         self._gemm(hh, 4, [dict(w=self._w("fc_lyaer.3.weight"), bias=sd["fc_lyaer.3.bias"], mode=EPI_RAW, out=self.eps_pad)])
         self.eps = A.zeros(B, 16, self.out_dim)
+        self.eps_copy_idx = len(self.ops)  # samplers read eps_pad directly and drop this op
         self._emit(make_op(OP_COPY_COLS, i=(B * 16, self.out_dim, self.eps_pad.shape[1], self.out_dim, 0, 0),
                                 p=(self.eps_pad.data_ptr(), self.eps.data_ptr())))
         # t-embedding MLP + all .fc layers, class embedding + all .fc_condition layers (input-major weights)
