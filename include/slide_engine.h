@@ -58,7 +58,7 @@ typedef struct SlideEpi {
 } SlideEpi;
 
 enum {
-  SLIDE_OP_GEMM = 1,        /* p: X, W, epi, in_scale, in_shift   i: rows, x_ld, k_pad, n_cob, npx_log2, in_bs, prec, cbw(2|4), lds_dma(0|1: fp16, no in_scale) */
+  SLIDE_OP_GEMM = 1,        /* p: X, W, epi, in_scale, in_shift, [5] timeline buffer (instrumented builds only, else NULL), [7] 9 zeroed ints for the optional persistent tile scheduler (NULL = one tile per workgroup); f[0]: start stagger in us for the persistent mode; i[9]: 0 = default ring, 1 = 64-deep chunks, 2 = eight-wave 256x256 tiles   i: rows, x_ld, k_pad, n_cob, npx_log2, in_bs, prec, cbw(2|4), lds_dma(0|1: fp16, no in_scale) */
   SLIDE_OP_PREP_POINTS = 2, /* p: x, xyz, feat0, knn_idx, knn_d2   i: B, cx, ldf, prec     (16 points / sample) */
   SLIDE_OP_ASSEMBLE_SA = 3, /* p: xyz, feat, knn_idx, g            i: B, C, ldf, ldg, K, prec */
   SLIDE_OP_ASSEMBLE_FP = 4, /* p: xyz, feat, knn_idx, knn_d2, g    i: B, C, ldf, ldg, K, prec */
