@@ -140,8 +140,9 @@ __device__ __forceinline__ void stage_epilogue_tables(const GemmArgs &a, int cob
 
 // Shared epilogue of the GEMM kernels: acc[cb][rb] holds D[co][row] in the 32x32 MFMA C layout (lane: row = lane & 31,
 // reg r: co = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  `red` = 4*CBW*2*16*2 floats of LDS scratch (the dead tiles).
-template <int PREC, int NPXL, int CBW>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[CBW][2], int row0, int cob0, int wave,
+// RB = 32-row blocks per wave (2; 1 for the split-K small-launch kernel, whose waves own one block each).
+template <int PREC, int NPXL, int CBW, int RB = 2>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[CBW][RB], int row0, int cob0, int wave,
                                               int half, int col, const uint32_t *epi_lds, const float *vec_lds,
                                               float *red) {
   using T = typename TileT<PREC>::T;
@@ -171,13 +172,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     constexpr bool kHalf = std::is_same<T, _Float16>::value;
     const bool wide16 = kHalf && !(flags & SLIDE_F_OUT_F32);
     const GLOBAL_AS float *addv = e_addvec;
-    constexpr int NA = NPXL >= 6 ? 1 : 2;  // a wave's 64 rows belong to one sample when NPX >= 64
+    static_assert(RB == 2 || NPXL < 6, "one row block per wave only for samples of at most 32 rows");
+    constexpr int NA = NPXL >= 6 ? 1 : RB;  // a wave's 64 rows belong to one sample when NPX >= 64
     float4 apre[NA][4];
-    u32x4 rpre[2][2];
+    u32x4 rpre[RB][2];
     if (PH != 1) {
       if (addv && e_addvec_idx) addv += (size_t)e_addvec_idx[0] * e_idx_stride;  // row t of a per-timestep table
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
+      for (int rb = 0; rb < RB; ++rb) {
         const int row = row0 + wave * 64 + rb * 32 + col;
         const bool ok = row < a.rows;
         if (rb < NA) {
@@ -199,10 +201,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     // v[rb][i] = channel pair i of the lane: channels cpair(i) = 8 (i >> 1) + 4 half + 2 (i & 1) and +1.  Everything
     // below is written on pairs so that it compiles to packed fp32 VALU ops (v_pk_add/mul/fma_f32): the epilogue's VALU
     // instruction count, not MFMA, bounds the small-K launches (rocprofv3 SQ_INSTS_VALU vs SQ_INSTS_MFMA).
-    f32x2 v[2][8];
+    f32x2 v[RB][8];
     if (PH == 2) {
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
+      for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[rb][i] = f32x2{acc[cb][rb][2 * i], acc[cb][rb][2 * i + 1]};
     } else {
@@ -210,14 +212,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
       for (int q = 0; q < 4; ++q) {
         const float4 bia = *reinterpret_cast<const float4 *>(v_bias + 8 * q + 4 * half);
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+        for (int rb = 0; rb < RB; ++rb) {
           v[rb][2 * q] = f32x2{acc[cb][rb][4 * q], acc[cb][rb][4 * q + 1]} + f32x2{bia.x, bia.y};
           v[rb][2 * q + 1] = f32x2{acc[cb][rb][4 * q + 2], acc[cb][rb][4 * q + 3]} + f32x2{bia.z, bia.w};
         }
       }
       if (pre) {  // per-point term shared by the K neighbours of a point (query half of attention weight_conv.2)
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+        for (int rb = 0; rb < RB; ++rb) {
           const int row = row0 + wave * 64 + rb * 32 + col;
           if (row < a.rows) {
 #pragma unroll
@@ -231,19 +233,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
       }
       if (flags & SLIDE_F_PRE_RELU) {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
           for (int i = 0; i < 8; ++i) v[rb][i] = __builtin_elementwise_max(v[rb][i], f32x2{0.f, 0.f});
       }
       if (PH == 1) {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
           for (int i = 0; i < 8; ++i) { acc[cb][rb][2 * i] = v[rb][i][0]; acc[cb][rb][2 * i + 1] = v[rb][i][1]; }
       }
     }
     // NSCOPE = number of independent sample scopes per wave (NPX=16: one per 32-row block, two samples each)
-    constexpr int NSCOPE = (NPXL >= 6) ? 1 : 2;
+    constexpr int NSCOPE = (NPXL >= 6) ? 1 : RB;
     constexpr int LG = NPX < 32 ? NPX : 32;  // lanes (rows) of one sample inside a row block
     constexpr int WPS = NPXL >= 7 ? NPX / 64 : 1;  // waves per sample when a sample spans waves (2 or 4)
     // sums `NV` per-lane partials over the rows of the lane's sample: lanes -> (row blocks) -> waves via LDS.
@@ -306,7 +308,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             f32x2 t, tt;
-            if (NSCOPE == 1) { t = v[0][i] + v[1][i]; tt = __builtin_elementwise_fma(v[0][i], v[0][i], v[1][i] * v[1][i]); }
+            if constexpr (NSCOPE == 1 && RB == 2) { t = v[0][i] + v[1][i]; tt = __builtin_elementwise_fma(v[0][i], v[0][i], v[1][i] * v[1][i]); }
             else { t = v[sc][i]; tt = v[sc][i] * v[sc][i]; }
             s[2 * i] = t[0]; s[2 * i + 1] = t[1]; ss[2 * i] = tt[0]; ss[2 * i + 1] = tt[1];
           }
@@ -337,7 +339,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+        for (int rb = 0; rb < RB; ++rb) {
           v[rb][2 * q] = __builtin_elementwise_fma(v[rb][2 * q], f32x2{g4[q].x, g4[q].y}, f32x2{b4[q].x, b4[q].y});
           v[rb][2 * q + 1] = __builtin_elementwise_fma(v[rb][2 * q + 1], f32x2{g4[q].z, g4[q].w}, f32x2{b4[q].z, b4[q].w});
         }
@@ -355,7 +357,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               f32x2 t, tt;
-              if (NSCOPE == 1) {
+              if constexpr (NSCOPE == 1 && RB == 2) {
                 t = (v[0][2 * q] + v[1][2 * q]) + (v[0][2 * q + 1] + v[1][2 * q + 1]);
                 tt = v[0][2 * q] * v[0][2 * q];
                 tt = __builtin_elementwise_fma(v[1][2 * q], v[1][2 * q], tt);
@@ -371,7 +373,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
               f32x2 t, tt;
-              if (NSCOPE == 1) { t = v[0][i] + v[1][i]; tt = __builtin_elementwise_fma(v[0][i], v[0][i], v[1][i] * v[1][i]); }
+              if constexpr (NSCOPE == 1 && RB == 2) { t = v[0][i] + v[1][i]; tt = __builtin_elementwise_fma(v[0][i], v[0][i], v[1][i] * v[1][i]); }
               else { t = v[sc][i]; tt = v[sc][i] * v[sc][i]; }
               if constexpr (SH == 1) { s[i] = t[0] + t[1]; ss[i] = tt[0] + tt[1]; }
               else { s[(2 * i) >> SH] = t[0]; s[(2 * i + 1) >> SH] = t[1]; ss[(2 * i) >> SH] = tt[0]; ss[(2 * i + 1) >> SH] = tt[1]; }
@@ -410,7 +412,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
               if (c0 >= e_n_norm) { g[0] = 1.f; bt[0] = 0.f; }
               if (c0 + 1 >= e_n_norm) { g[1] = 1.f; bt[1] = 0.f; }
             }
-            if (NSCOPE == 1) {
+            if constexpr (NSCOPE == 1 && RB == 2) {
               v[0][i] = __builtin_elementwise_fma(v[0][i], g, bt);
               v[1][i] = __builtin_elementwise_fma(v[1][i], g, bt);
             } else {
@@ -438,7 +440,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     auto store_phase = [&](auto addv_tag, auto res_tag) __attribute__((always_inline)) {
       constexpr bool HA = decltype(addv_tag)::value, HR = decltype(res_tag)::value;
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
+      for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           f32x2 lo = v[rb][2 * q], hi = v[rb][2 * q + 1];
@@ -470,7 +472,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
         }
       }
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
+      for (int rb = 0; rb < RB; ++rb) {
         const int row = row0 + wave * 64 + rb * 32 + col;
         const bool ok = row < a.rows;  // identical in both lane halves
 #pragma unroll
@@ -947,6 +949,115 @@ __global__ __launch_bounds__(512, 2) void gemm_glds8_kernel(GemmArgs a) {
   glds_tile<NPXL, CBW, NST, 32, false, 2>(a, smem_raw, tr, tc);
 }
 
+// Small launches (the 16-row per-point GEMMs: rows = 16 x batch, so a 256-row tiling yields a handful of workgroups
+// whose cost is their own serial latency).  Tile 64 rows x 64 channels; the four waves SPLIT K -- wave w takes the
+// 32-deep chunks w, w+4, ... through a private LDS-DMA ring (no workgroup barrier in the loop) -- then the partial
+// accumulators meet in LDS and every wave finishes ONE 32x32 output block (channel block w & 1, row block w >> 1)
+// through the common epilogue: the K loop and the epilogue are each ~4x shorter per wave and the grid is 4x larger.
+template <int NST>
+__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
+  using T = _Float16;
+  constexpr int NPXL = 4;
+  constexpr int STAGE_B = 128 * 64;  // 64 X rows + 64 W rows, 64 bytes each
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int ntc = (a.n_cob + 1) / 2;
+  const int tc = blockIdx.x % ntc, tr = blockIdx.x / ntc;
+  const int row0 = tr * 64, cob0 = tc * 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  unsigned char *const ring = smem_raw + (size_t)wave * NST * STAGE_B;
+  uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + (size_t)4 * NST * STAGE_B);
+  float *const vec_lds = reinterpret_cast<float *>(epi_lds + 2 * EPI_DW + (2 * EPI_DW) % 4);
+  stage_epilogue_tables<2>(a, cob0, tid, epi_lds, vec_lds);
+
+  const T *gp[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int trow = 16 * j + (lane >> 2);
+    const int piece = (lane & 3) ^ ((trow >> 2) & 3);
+    if (trow < 64) {
+      int grow = row0 + trow;
+      grow = grow < a.rows ? grow : a.rows - 1;
+      gp[j] = reinterpret_cast<const T *>(a.X) + (size_t)grow * a.x_ld + piece * 8;
+    } else {
+      int gco = cob0 * 32 + (trow - 64);
+      gco = gco < a.n_cob * 32 ? gco : a.n_cob * 32 - 1;
+      gp[j] = reinterpret_cast<const T *>(a.W) + (size_t)gco * a.k_pad + piece * 8;
+    }
+  }
+  auto issue = [&](int kc, int st) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(gp[j] + kc * 32),
+                                       (__attribute__((address_space(3))) void *)(ring + (size_t)st * STAGE_B + j * 1024),
+                                       16, 0, 0);
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int wrow[2], wkey[2], xrow[2], xkey[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int tw = 64 + i * 32 + col, tx = i * 32 + col;
+    wrow[i] = tw * 64; wkey[i] = (tw >> 2) & 3;
+    xrow[i] = tx * 64; xkey[i] = (tx >> 2) & 3;
+  }
+  const int nk = a.k_pad / 32;
+  const int mine = nk > wave ? (nk - wave + 3) / 4 : 0;  // chunks wave, wave + 4, ...
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0)
+    if (s0 < mine) issue(wave + 4 * s0, s0);
+  for (int i = 0; i < mine; ++i) {
+    // this wave's own DMA: a counted wait orders it for this wave's reads, no barrier involved
+    if (i + NST - 2 < mine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * 8) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned char *sb = ring + (size_t)(i % NST) * STAGE_B;
+    f16x8 af[2][2], bf[2][2];
+#pragma unroll
+    for (int st2 = 0; st2 < 2; ++st2) {
+      const int piece = st2 * 2 + half;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) af[st2][cb] = *reinterpret_cast<const f16x8 *>(sb + wrow[cb] + ((piece ^ wkey[cb]) << 4));
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) bf[st2][rb] = *reinterpret_cast<const f16x8 *>(sb + xrow[rb] + ((piece ^ xkey[rb]) << 4));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is free again before it is re-armed below
+    if (i + NST - 1 < mine) issue(wave + 4 * (i + NST - 1), (i + NST - 1) % NST);
+#pragma unroll
+    for (int st2 = 0; st2 < 2; ++st2)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+          acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[st2][cb], bf[st2][rb], acc[cb][rb], 0, 0, 0);
+  }
+  __syncthreads();  // rings are dead, tables are visible
+  // partial accumulators -> LDS [wave][block = cb*2+rb][reg][lane]; wave w sums block w
+  float *const part = reinterpret_cast<float *>(smem_raw);
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[(((wave * 4 + cb * 2 + rb) * 16 + r) << 6) + lane] = acc[cb][rb][r];
+  __syncthreads();
+  f32x16 one[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) t += part[(((w * 4 + wave) * 16 + r) << 6) + lane];
+    one[0][0][r] = t;
+  }
+  const int cb = wave >> 1, rb = wave & 1;  // block index wave = cb*2 + rb
+  gemm_epilogue<SLIDE_PREC_F16, NPXL, 1, 1>(a, one, row0 + rb * 32, cob0 + cb, 0, half, col, epi_lds + cb * EPI_DW,
+                                            vec_lds + cb * 96, nullptr);
+}
+
 // ------------------------------------------------------------------------------------------------ points
 __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
 #pragma clang fp contract(off)
@@ -1358,6 +1469,20 @@ int launch_gemm_glds8(const GemmArgs &a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+int launch_gemm_small(const GemmArgs &a, hipStream_t s) {
+  constexpr int NST = 3;
+  const size_t shm = (size_t)4 * NST * 8192 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32;
+  const int grid = ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_small_kernel<NST>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_small_kernel<NST>), dim3(grid), dim3(256), shm, s, a);
+  return (int)hipGetLastError();
+}
+
 int run_gemm(const SlideOp &o, hipStream_t s) {
   GemmArgs a;
   a.X = o.p[0]; a.W = o.p[1]; a.epi = (const SlideEpi *)o.p[2];
@@ -1376,6 +1501,8 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
   if (npxl == L && cbw == C)                                                                               \
     return wide ? launch_gemm_glds<L, C, 3, 64, false>(a, s) : launch_gemm_glds<L, C, 3, 32, false>(a, s)
 #define ACASE(L, C) if (npxl == L && cbw == C) return launch_gemm_glds<L, C, 3, 32, true>(a, s)
+    if (npxl == 4 && !a.in_scale && o.i[9] != 3 && ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2) <= 1024)
+      return launch_gemm_small(a, s);  // split-K small-launch kernel (i[9] == 3 keeps the 256-row kernels, for A/B)
     // launches of at most one workgroup per CU (the 16-row per-point GEMMs) are bound by the latency of their K loop:
     // a 7-stage ring keeps five chunks in flight instead of one
     if (npxl == 4 && cbw == 2 && !a.in_scale && !wide &&
