@@ -954,7 +954,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds8_kernel(GemmArgs a) {
 // 32-deep chunks w, w+4, ... through a private LDS-DMA ring (no workgroup barrier in the loop) -- then the partial
 // accumulators meet in LDS and every wave finishes ONE 32x32 output block (channel block w & 1, row block w >> 1)
 // through the common epilogue: the K loop and the epilogue are each ~4x shorter per wave and the grid is 4x larger.
-template <int NST>
+template <int NST, bool AFF>
 __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
   using T = _Float16;
   constexpr int NPXL = 4;
@@ -969,6 +969,19 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
   uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + (size_t)4 * NST * STAGE_B);
   float *const vec_lds = reinterpret_cast<float *>(epi_lds + 2 * EPI_DW + (2 * EPI_DW) % 4);
   stage_epilogue_tables<2>(a, cob0, tid, epi_lds, vec_lds);
+  // AFF: consumer-side GroupNorm affine of the four samples of this tile, fp16 [sample][scale | shift][k_pad]
+  _Float16 *const aff_lds = reinterpret_cast<_Float16 *>(vec_lds + 2 * 96);
+  if (AFF) {
+    for (int i = tid; i < 4 * a.k_pad; i += 256) {
+      const int sm = i / a.k_pad, k = i - sm * a.k_pad;
+      int b = (row0 >> NPXL) + sm;
+      const int nb = a.rows >> NPXL;
+      b = b < nb ? b : nb - 1;
+      aff_lds[(sm * 2 + 0) * a.k_pad + k] = (_Float16)a.in_scale[(size_t)b * a.in_bs + k];
+      aff_lds[(sm * 2 + 1) * a.k_pad + k] = (_Float16)a.in_shift[(size_t)b * a.in_bs + k];
+    }
+    __syncthreads();
+  }
 
   const T *gp[8];
 #pragma unroll
@@ -1024,6 +1037,15 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
       for (int cb = 0; cb < 2; ++cb) af[st2][cb] = *reinterpret_cast<const f16x8 *>(sb + wrow[cb] + ((piece ^ wkey[cb]) << 4));
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) bf[st2][rb] = *reinterpret_cast<const f16x8 *>(sb + xrow[rb] + ((piece ^ xkey[rb]) << 4));
+      if (AFF) {
+        const int kc = wave + 4 * i;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          const _Float16 *ap = aff_lds + (size_t)((rb * 2 + (col >> 4)) * 2) * a.k_pad + kc * 32 + piece * 8;
+          bf[st2][rb] = __builtin_elementwise_fma(bf[st2][rb], *reinterpret_cast<const f16x8 *>(ap),
+                                                  *reinterpret_cast<const f16x8 *>(ap + a.k_pad));
+        }
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is free again before it is re-armed below
     if (i + NST - 1 < mine) issue(wave + 4 * (i + NST - 1), (i + NST - 1) % NST);
@@ -1469,18 +1491,25 @@ int launch_gemm_glds8(const GemmArgs &a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-int launch_gemm_small(const GemmArgs &a, hipStream_t s) {
-  constexpr int NST = 3;
-  const size_t shm = (size_t)4 * NST * 8192 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32;
+template <int NST, bool AFF>
+int launch_gemm_small_t(const GemmArgs &a, hipStream_t s) {
+  const size_t shm = (size_t)4 * NST * 8192 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32 + (AFF ? (size_t)4 * 2 * a.k_pad * 2 : 0);
   const int grid = ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_small_kernel<NST>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_small_kernel<NST, AFF>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_small_kernel<NST>), dim3(grid), dim3(256), shm, s, a);
+  hipLaunchKernelGGL((gemm_small_kernel<NST, AFF>), dim3(grid), dim3(256), shm, s, a);
   return (int)hipGetLastError();
+}
+
+int launch_gemm_small(const GemmArgs &a, hipStream_t s) {
+  // three stages per wave while the grid fits one workgroup per CU, two (two workgroups per CU) beyond
+  const int grid = ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2);
+  if (a.in_scale) return grid <= 256 ? launch_gemm_small_t<3, true>(a, s) : launch_gemm_small_t<2, true>(a, s);
+  return grid <= 256 ? launch_gemm_small_t<3, false>(a, s) : launch_gemm_small_t<2, false>(a, s);
 }
 
 int run_gemm(const SlideOp &o, hipStream_t s) {
@@ -1493,6 +1522,10 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
   a.rows = o.i[0]; a.x_ld = o.i[1]; a.k_pad = o.i[2]; a.n_cob = o.i[3]; a.in_bs = o.i[5];
   const int npxl = o.i[4], prec = o.i[6], cbw = o.i[7], glds = o.i[8];
   if (a.k_pad % BK || a.x_ld % 8 || a.rows <= 0 || a.n_cob <= 0) return -3;
+  // fp16 16-row launches: split-K small-launch kernel, with or without the input affine (i[9] == 3 keeps the 256-row
+  // kernels, for A/B timing)
+  if (prec == SLIDE_PREC_F16 && npxl == 4 && o.i[9] != 3 && ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2) <= 1024)
+    return launch_gemm_small(a, s);
   if (glds) {
     if (prec != SLIDE_PREC_F16) return -7;
     // i[9]: 0 = BK 32, three stages (two workgroups / CU); 1 = BK 64 (full 128-B lines), three stages (one / CU)
@@ -1501,8 +1534,6 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
   if (npxl == L && cbw == C)                                                                               \
     return wide ? launch_gemm_glds<L, C, 3, 64, false>(a, s) : launch_gemm_glds<L, C, 3, 32, false>(a, s)
 #define ACASE(L, C) if (npxl == L && cbw == C) return launch_gemm_glds<L, C, 3, 32, true>(a, s)
-    if (npxl == 4 && !a.in_scale && o.i[9] != 3 && ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2) <= 1024)
-      return launch_gemm_small(a, s);  // split-K small-launch kernel (i[9] == 3 keeps the 256-row kernels, for A/B)
     // launches of at most one workgroup per CU (the 16-row per-point GEMMs) are bound by the latency of their K loop:
     // a 7-stage ring keeps five chunks in flight instead of one
     if (npxl == 4 && cbw == 2 && !a.in_scale && !wide &&
