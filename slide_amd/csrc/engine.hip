@@ -759,7 +759,8 @@ __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem
   using T = _Float16;
   constexpr int NW = 4 * WC, NT = 256 * WC;  // waves, threads
   constexpr int TN = 32 * CBW * WC;
-  constexpr int RT = TM + TN;              // tile rows per stage (X rows then W rows)
+  constexpr int TNS = TN < 64 ? 64 : TN;   // W rows staged per chunk (a 32-channel tile stages 64: whole DMA instructions per wave)
+  constexpr int RT = TM + TNS;             // tile rows per stage (X rows then W rows)
   constexpr int ROWB = BKT * 2;            // bytes per tile row (64 or 128 = one full cache line)
   constexpr int PPR = ROWB / 16;           // 16-byte pieces per row (4 or 8)
   constexpr int RPI = 64 / PPR;            // rows per LDS-DMA instruction (16 or 8)
@@ -1452,7 +1453,7 @@ int launch_gemm(const GemmArgs &a, hipStream_t s) {
 template <int NPXL, int CBW, int NST, int BKT, bool AFF>
 int launch_gemm_glds(const GemmArgs &a, hipStream_t s) {
   constexpr int NSAMP = (1 << NPXL) >= TM ? 1 : TM >> NPXL;
-  const size_t shm = (size_t)NST * (TM + 32 * CBW) * BKT * 2 + CBW * (sizeof(SlideEpi) + 96 * 4) + 32 +
+  const size_t shm = (size_t)NST * (TM + (CBW < 2 ? 64 : 32 * CBW)) * BKT * 2 + CBW * (sizeof(SlideEpi) + 96 * 4) + 32 +
                      (AFF ? (size_t)NSAMP * 2 * a.k_pad * 2 : 0);
   if (shm > 80 * 1024 && BKT == 32 && NST <= 3) return -8;  // two workgroups per CU must fit
   if (shm > 160 * 1024) return -8;
@@ -1546,6 +1547,11 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
       if (npxl == 7) return launch_gemm_glds8<7, 4, 4>(a, s);
     }
     if (a.in_scale) { ACASE(7, 2); ACASE(8, 2); ACASE(7, 4); ACASE(8, 4); return -4; }
+    if (cbw == 1 && !wide) {
+      if (npxl == 7) return launch_gemm_glds<7, 1, 3, 32, false>(a, s);
+      if (npxl == 8) return launch_gemm_glds<8, 1, 3, 32, false>(a, s);
+      return -4;
+    }
     GCASE(4, 2); GCASE(7, 2); GCASE(8, 2); GCASE(4, 4); GCASE(7, 4); GCASE(8, 4);
 #undef ACASE
 #undef GCASE
