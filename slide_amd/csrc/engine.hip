@@ -759,7 +759,8 @@ __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem
   using T = _Float16;
   constexpr int NW = 4 * WC, NT = 256 * WC;  // waves, threads
   constexpr int TN = 32 * CBW * WC;
-  constexpr int TNS = TN < 64 ? 64 : TN;   // W rows staged per chunk (a 32-channel tile stages 64: whole DMA instructions per wave)
+  // W rows staged per chunk: TN rounded up until the stage splits into whole DMA instructions per wave
+  constexpr int TNS = ((TM + TN + 16 * NW - 1) / (16 * NW)) * (16 * NW) - TM;
   constexpr int RT = TM + TNS;             // tile rows per stage (X rows then W rows)
   constexpr int ROWB = BKT * 2;            // bytes per tile row (64 or 128 = one full cache line)
   constexpr int PPR = ROWB / 16;           // 16-byte pieces per row (4 or 8)
@@ -1475,7 +1476,8 @@ int launch_gemm_glds(const GemmArgs &a, hipStream_t s) {
 
 template <int NPXL, int CBW, int NST>
 int launch_gemm_glds8(const GemmArgs &a, hipStream_t s) {
-  const size_t shm = (size_t)NST * (TM + 64 * CBW) * 32 * 2 + 2 * CBW * (sizeof(SlideEpi) + 96 * 4) + 32;
+  constexpr int TNS8 = ((TM + 64 * CBW + 127) / 128) * 128 - TM;
+  const size_t shm = (size_t)NST * (TM + TNS8) * 32 * 2 + 2 * CBW * (sizeof(SlideEpi) + 96 * 4) + 32;
   if (shm > 160 * 1024) return -8;
   const int ntc = (a.n_cob + 2 * CBW - 1) / (2 * CBW), ntr = (a.rows + TM - 1) / TM;
   const int grid = ((ntr + 7) / 8) * 8 * ntc;
@@ -1545,6 +1547,12 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
         ((a.rows + TM - 1) / TM) * (a.n_cob / 8) >= 256) {
       if (npxl == 8) return launch_gemm_glds8<8, 4, 4>(a, s);
       if (npxl == 7) return launch_gemm_glds8<7, 4, 4>(a, s);
+    }
+    // narrow outputs on a grid that does not fill the chip: the same 256 x 64 tile on eight waves (one channel block
+    // per wave) halves each wave's epilogue
+    if (o.i[9] == 4 && cbw == 2 && !a.in_scale && ((a.rows + TM - 1) / TM) * ((a.n_cob + 1) / 2) <= 512) {
+      if (npxl == 8) return launch_gemm_glds8<8, 1, 3>(a, s);
+      if (npxl == 7) return launch_gemm_glds8<7, 1, 3>(a, s);
     }
     if (a.in_scale) { ACASE(7, 2); ACASE(8, 2); ACASE(7, 4); ACASE(8, 4); return -4; }
     if (cbw == 1 && !wide) {

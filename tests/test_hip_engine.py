@@ -72,6 +72,37 @@ def test_denoiser_larger_batch_matches_oracle(gpu_device):
     assert np.allclose(y3, y1[perm], rtol=0, atol=5e-6)  # same arithmetic per sample up to fp32 rounding
 
 
+@pytest.mark.parametrize("name", ["pos", "feat"])
+def test_full_size_properties(gpu_device, name):
+    """BASELINE batch (256 per GPU, and the 128-sample sub-batches the bench replays): size-independent properties.
+    (1) fp16 throughput mode vs fp32 parity mode of the same engine: <= 5e-3 relative L2;
+    (2) sample independence at full size: a sample's output does not depend on where in the batch it sits, nor on the
+        batch size it is launched with (256 vs 128 -- different tile shapes / kernel variants per launch);
+    (3) determinism of repeated launches."""
+    from slide_amd.engine import DenoiserEngine
+    g, hp, sd = _load(name)
+    rs = np.random.RandomState(11)
+    B, C = 256, g["x_t0"].shape[2]
+    x = rs.standard_normal((B, 16, C)).astype(np.float32)
+    ts = rs.randint(0, 1000, B).astype(np.float32)
+    label = rs.randint(0, 13, B).astype(np.int64)
+    e16 = DenoiserEngine(hp, sd, B, gpu_device, prec="fp16")
+    y16 = e16.forward(x, ts, label).cpu().numpy()
+    assert np.isfinite(y16).all()
+    assert np.array_equal(y16, e16.forward(x, ts, label).cpu().numpy())
+    e32 = DenoiserEngine(hp, sd, B, gpu_device, prec="fp32")
+    y32 = e32.forward(x, ts, label).cpu().numpy()
+    rel = float(np.linalg.norm(y16 - y32) / np.linalg.norm(y32))
+    assert rel <= 5e-3, rel
+    perm = rs.permutation(B)
+    yp = e16.forward(x[perm], ts[perm], label[perm]).cpu().numpy()
+    # per-sample arithmetic is identical wherever the sample sits (GroupNorm statistics are per sample)
+    assert np.abs(yp - y16[perm]).max() <= 2e-3 * np.abs(y16).max()
+    eh = DenoiserEngine(hp, sd, 128, gpu_device, prec="fp16")
+    yh = eh.forward(x[:128], ts[:128], label[:128]).cpu().numpy()
+    assert np.abs(yh - y16[:128]).max() <= 2e-3 * np.abs(y16).max()
+
+
 def _pos_cfg():
     return {"T": 1000, "beta_0": 0.0001, "beta_T": 0.02}
 
