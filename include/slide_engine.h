@@ -71,7 +71,8 @@ enum {
   SLIDE_OP_UPDATE_FEAT = 11,/* p: x, eps, noise(or NULL), t_dev, keypoint, c_recip, c_recipm1, c1, c2, c_std  i: n_pts, C, kdim, seed_lo, seed_hi, eps_ld (0 = C)  f: clamp */
   SLIDE_OP_ADVANCE_T = 12,  /* p: t_dev  (t_dev[0] -= 1; t_dev[1] += 1) */
   SLIDE_OP_SYNC = 14,       /* i: from_lane, to_lane -- lane `to` waits for everything issued so far on lane `from` */
-  SLIDE_OP_GROUPNORM_NCHW = 13 /* p: x, gamma, beta, y (NCHW fp32)   i: B, C, HW, G, n_norm, relu  (module-level path) */
+  SLIDE_OP_GROUPNORM_NCHW = 13,/* p: x, gamma, beta, y (NCHW fp32)   i: B, C, HW, G, n_norm, relu  (module-level path) */
+  SLIDE_OP_TRANSPOSE = 15   /* p: in, out (fp32)   i: B, R, C, in_ld, out_ld, in_batch_stride, out_batch_stride: out[b][c][r] = in[b][r][c] (module-level path: NCHW <-> row-major) */
 };
 
 typedef struct SlideOp {

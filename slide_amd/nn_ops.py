@@ -11,6 +11,7 @@ from ._lib import check, lib
 from .engine import EPI_RAW, OP_GEMM, SlideEpi, SlideOp, make_op, ru
 
 OP_GROUPNORM_NCHW = 13
+OP_TRANSPOSE = 15
 
 
 def _stream():
@@ -76,8 +77,19 @@ class HipConv1x1(nn.Module):
         key = (rows, self.weight._version, self.weight.data_ptr())
         if key not in self._plans:
             self._plans = {key: _GemmPlan(self.weight, self.bias, rows, x.device)}
+        plan = self._plans[key]
+        P = rows // B
+        if P > 1 and x.dtype == torch.float32 and x.is_contiguous() and B * C * P < 2 ** 31 and rows * plan.op_ < 2 ** 31:
+            # NCHW -> [pixel][channel] and back with the LDS-tiled transpose kernel (torch's strided copies took
+            # half of the decode path's time)
+            _run(make_op(OP_TRANSPOSE, i=(B, C, P, P, plan.kp, C * P, P * plan.kp), p=(x.data_ptr(), plan.x.data_ptr())))
+            _run(plan.op)
+            out = torch.empty((B, self.out_channels) + tuple(sp), device=x.device, dtype=torch.float32)
+            _run(make_op(OP_TRANSPOSE, i=(B, P, self.out_channels, plan.op_, P, P * plan.op_, self.out_channels * P),
+                         p=(plan.y.data_ptr(), out.data_ptr())))
+            return out
         x2 = x.reshape(B, C, -1).permute(0, 2, 1).reshape(rows, C)
-        y = self._plans[key](x2)
+        y = plan(x2)
         return y.reshape(B, -1, self.out_channels).permute(0, 2, 1).reshape((B, self.out_channels) + tuple(sp)).contiguous()
 
 
