@@ -84,7 +84,7 @@ def shared_mlp(x, sd, prefix):
     return relu(x)
 
 
-def mlp_plus_t_emb(feature, sd, prefix, t_emb=None, cond_emb=None):
+def mlp_plus_t_emb(feature, sd, prefix, t_emb=None, cond_emb=None, second_cond_emb=None, res_connect=True):
     """Mlp_plus_t_emb.forward (OPS/pointnet2_modules.py:119-176)."""
     h = shared_mlp(feature, sd, prefix + ".first_mlp")
     if (prefix + ".fc.weight") in sd:
@@ -97,6 +97,12 @@ def mlp_plus_t_emb(feature, sd, prefix, t_emb=None, cond_emb=None):
                        sd[prefix + ".fc_condition.bias"])[:, :, None, None]
     if (prefix + ".rest_mlp.0.weight") in sd:
         h = shared_mlp(h, sd, prefix + ".rest_mlp")
+    if (prefix + ".fc_second_condition.weight") in sd:  # :163-168, after rest_mlp
+        assert second_cond_emb is not None
+        h = h + linear(second_cond_emb, sd[prefix + ".fc_second_condition.weight"],
+                       sd[prefix + ".fc_second_condition.bias"])[:, :, None, None]
+    if not res_connect:  # Pnet2Stage builds its Mlps with res_connect=False (P2/models/pnet.py:10-25)
+        return h.astype(F32)
     if (prefix + ".res_connect.weight") in sd:
         h = h + conv1x1(feature, sd[prefix + ".res_connect.weight"], sd.get(prefix + ".res_connect.bias"))
     else:
@@ -125,7 +131,8 @@ def attention_module(feat, grouped_feat, grouped_feat_out, sd, prefix, count=Non
         scores = scores * mask + F32(-1e9) * (1 - mask)
     weight = softmax_last(scores)
     v = conv1x1(grouped_feat_out, sd[prefix + ".feat_out_conv.0.weight"], sd[prefix + ".feat_out_conv.0.bias"])
-    v = relu(my_group_norm(v, sd, prefix + ".feat_out_conv.1"))
+    if (prefix + ".feat_out_conv.1.group_norm.weight") in sd:  # last_activation (OPS/attention.py:62-66)
+        v = relu(my_group_norm(v, sd, prefix + ".feat_out_conv.1"))
     return (v * weight).sum(axis=-1, dtype=F32).astype(F32)
 
 
@@ -213,7 +220,7 @@ def group_knn(x, y, feats_at_y_t, K):
     return np.ascontiguousarray(new.transpose(0, 3, 1, 2)).astype(F32)
 
 
-def sa_module(xyz, features, sd, prefix, npoint, nsample, t_emb, cond_emb):
+def sa_module(xyz, features, sd, prefix, npoint, nsample, t_emb, cond_emb, second_cond_emb=None):
     """_PointnetSAModuleBase.forward (OPS/pointnet2_modules.py:222-292), one grouper,
     attention aggregation."""
     if xyz.shape[1] <= npoint:
@@ -224,7 +231,7 @@ def sa_module(xyz, features, sd, prefix, npoint, nsample, t_emb, cond_emb):
         new_xyz = np.ascontiguousarray(ops.gather_points(xyz_flipped, fidx).transpose(0, 2, 1))
         new_xyz_feat = ops.gather_points(features, fidx)
     grouped, _, _ = query_and_group_nn(xyz, new_xyz, features, nsample)
-    out = mlp_plus_t_emb(grouped, sd, prefix + ".mlps.0", t_emb, cond_emb)
+    out = mlp_plus_t_emb(grouped, sd, prefix + ".mlps.0", t_emb, cond_emb, second_cond_emb)
     new_features = attention_module(new_xyz_feat, grouped, out, sd, prefix + ".attention_modules.0")
     return new_xyz, new_features
 
@@ -336,6 +343,60 @@ def autoencoder_decode(decoder_cfgs, sd, keypoint, feature, label, fps_start=Non
         feats, pts = decode_level(cfg, sd, "decoder.decoders.%d" % i, l_xyz[i], feats, l_xyz[i + 1], label, fps_start)
         l_xyz.append(pts)
     return l_xyz
+
+
+# ----------------------------------------------------------------------------- autoencoder encode
+def pnet2stage(x, sd, prefix):
+    """Pnet2Stage.forward (P2/models/pnet.py:27-40), remove_last_activation False: per-point Mlp -> max-pool ->
+    [per-point | global] -> Mlp -> max-pool.  x (B,C,N) -> (B, mlp2[-1])"""
+    f = mlp_plus_t_emb(x[..., None], sd, prefix + ".mlp1", res_connect=False)
+    g = f.max(axis=2, keepdims=True)
+    f = np.concatenate([f, np.broadcast_to(g, f.shape)], axis=1)
+    f = mlp_plus_t_emb(f, sd, prefix + ".mlp2", res_connect=False)
+    return f.max(axis=2)[:, :, 0].astype(F32)
+
+
+def encoder_forward(hp, sd, pointcloud, label):
+    """PointNet2Encoder.forward (P2/models/pointnet2_feature_extractor.py:135-218), include_t False, no position
+    encoding: SA stack with FPS down-sampling and kNN grouping, class embedding (and, when configured, the Pnet2Stage
+    global feature as first condition).  -> (last-level features (B,n,C), l_xyz)"""
+    assert not hp["include_t"] and not hp.get("use_position_encoding", False)
+    pc = np.concatenate([pointcloud, pointcloud[:, :, 0:3]], axis=2) if hp["attach_position_to_input_feature"] else pointcloud
+    xyz = np.ascontiguousarray(pc[:, :, 0:3]).astype(F32)
+    features = np.ascontiguousarray(pc[:, :, 3:].transpose(0, 2, 1)).astype(F32) if pc.shape[2] > 3 else None
+    class_emb = sd["class_emb.weight"][label] if hp["include_class_condition"] else None
+    cond, second = class_emb, None
+    if hp.get("include_global_feature", False):
+        gin = xyz if hp["in_fea_dim"] == 0 else np.concatenate([xyz, pointcloud[:, :, 3:3 + hp["in_fea_dim"]]], axis=2)
+        cond, second = pnet2stage(np.ascontiguousarray(gin.transpose(0, 2, 1)), sd, "global_pnet"), class_emb
+    arch = hp["architecture"]
+    l_xyz, feats = [xyz], features
+    for i in range(len(arch["npoint"])):
+        nx, feats = sa_module(l_xyz[i], feats, sd, "SA_modules.%d" % i, arch["npoint"][i], arch["nsample"][i], None, cond, second)
+        l_xyz.append(nx)
+    return np.ascontiguousarray(feats.transpose(0, 2, 1)).astype(F32), l_xyz
+
+
+def propagate_feature(cfg, sd, pfx, xyz, features, new_xyz, label):
+    """PointUpsampleDecoder.propagate_feature (P2/models/point_upsample_decoder.py:106-147) for a level whose feature
+    extractor is a PointNet2Encoder with KL regularisation, posterior MODE (DiagonalGaussianDistribution.mode = the first
+    half of the channels, P2/data_utils/distributions.py:4-8,42-43).  -> (B,N2,C3+C4)"""
+    sub = {k[len(pfx) + len(".feature_extractor."):]: v for k, v in sd.items() if k.startswith(pfx + ".feature_extractor.")}
+    out, _ = encoder_forward(cfg, sub, new_xyz, label)
+    out = out[:, :, : out.shape[2] // 2]
+    mapped = feature_map_module(xyz[:, :, :3], np.ascontiguousarray(features.transpose(0, 2, 1)),
+                                np.ascontiguousarray(new_xyz[:, :, :3]), np.ascontiguousarray(out.transpose(0, 2, 1)), sd,
+                                pfx + ".feature_mapper", cfg["feature_mapper_setting"]["nsample"])
+    mapped = mapped.transpose(0, 2, 1)
+    mapped = mapped[:, :, : mapped.shape[2] // 2]
+    return np.concatenate([out, mapped], axis=2).astype(F32)
+
+
+def autoencoder_encode(encoder_cfg, decoder_cfgs, sd, pointcloud, keypoint, label):
+    """PointAutoencoder.encode (P2/models/autoencoder.py:37-40), sample_posterior False"""
+    enc = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    out, l_xyz = encoder_forward(encoder_cfg, enc, pointcloud, label)
+    return propagate_feature(decoder_cfgs[0], sd, "keypoint_encoder", l_xyz[-1], out, keypoint, label), out, l_xyz
 
 
 def match_point_sets(a, b):

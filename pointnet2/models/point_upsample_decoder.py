@@ -5,7 +5,10 @@ output splits every point into `point_upsample_factor` children, thinned to `num
 sampling (pytorch3d `sample_farthest_points` in the reference; slide_amd._ext.sample_farthest_points here).
 
 `decode_only=True` builds just the splitting head (`fc_layer`) -- all `PointAutoencoder.decode` needs from the key-point
-encoder level, whose feature extractor (PointNet2Encoder) belongs to the encode path."""
+encoder level.  Built in full, a level whose architecture has no `decoder_feature_dim` extracts its features with a
+`PointNet2Encoder` (the key-point encoder of the ENCODE path), and with
+`apply_kl_regularization` the extractor and the mapper emit (mean | logvar) and the level keeps the posterior mode or a
+sample (reference :93-104, pointnet2/data_utils/distributions.py:4-43)."""
 import copy
 
 import torch
@@ -13,6 +16,7 @@ import torch.nn as nn
 
 from pointnet2_ops.pointnet2_modules import FeatureMapModule
 from models.point_upsample_module import point_upsample
+from models.pointnet2_feature_extractor import PointNet2Encoder
 from models.pointnet2_with_pcld_condition import PointNet2CloudCondition
 from slide_amd import _ext as _hip
 from slide_amd.nn_ops import HipConv1x1
@@ -30,11 +34,16 @@ class PointUpsampleDecoder(nn.Module):
         up = hp["upsampling_setting"]
         self.decode_only = decode_only
         if not decode_only:
-            if not has_fp or apply_kl_regularization:
-                raise NotImplementedError("PointNet2Encoder / KL-regularised levels belong to the encode path")
-            self.feature_extractor = PointNet2CloudCondition(copy.deepcopy(hp))
+            cfg = copy.deepcopy(hp)
+            kl = 2 if apply_kl_regularization else 1  # (mean | logvar) channels, reference :37-44,56-60
+            if has_fp:
+                cfg["architecture"]["decoder_feature_dim"][0] *= kl
+                self.feature_extractor = PointNet2CloudCondition(cfg)
+            else:
+                cfg["architecture"]["feature_dim"][-1] *= kl
+                self.feature_extractor = PointNet2Encoder(cfg)
             self.feature_mapper = FeatureMapModule(
-                [in_dim] + [fm["out_dim"]] * fm["mlp_depth"], fm["radius"], fm["nsample"], use_xyz=hp["model.use_xyz"],
+                [in_dim] + [fm["out_dim"] * kl] * fm["mlp_depth"], fm["radius"], fm["nsample"], use_xyz=hp["model.use_xyz"],
                 include_abs_coordinate=hp["include_abs_coordinate"],
                 include_center_coordinate=hp.get("include_center_coordinate", False), bn=hp["bn"], bn_first=hp["bn_first"],
                 bias=hp["bias"], res_connect=hp["res_connect"], first_conv=False, first_conv_in_channel=0,
@@ -54,10 +63,24 @@ class PointUpsampleDecoder(nn.Module):
         if self.decode_only:
             raise NotImplementedError("this level was built decode-only")
         out = self.feature_extractor(new_xyz, ts=ts, label=label)
+        if isinstance(out, tuple):  # PointNet2Encoder returns (features, l_xyz, l_features)
+            out = out[0]
+        if self.apply_kl_regularization:
+            out = self._posterior(out, sample_posterior)
         mapped = self.feature_mapper(xyz, features.transpose(1, 2).contiguous(), new_xyz[:, :, 0:3].contiguous(), subset=False,
                                      record_neighbor_stats=False, pooling=None,
-                                     features_at_new_xyz=out.transpose(1, 2).contiguous())
-        return torch.cat([out, mapped.transpose(1, 2)], dim=2), None
+                                     features_at_new_xyz=out.transpose(1, 2).contiguous()).transpose(1, 2)
+        if self.apply_kl_regularization:
+            mapped = self._posterior(mapped, sample_posterior)
+        return torch.cat([out, mapped], dim=2), None
+
+    @staticmethod
+    def _posterior(parameters, sample):
+        """DiagonalGaussianDistribution over the channel halves of (B,N,2C): mode, or mean + std * N(0,1)"""
+        mean, logvar = torch.chunk(parameters, 2, dim=2)
+        if not sample:
+            return mean.contiguous()
+        return mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * torch.randn_like(mean)
 
     def upsample_points(self, final_feature, new_xyz, fps_start_idx=None):
         hp, up = self.hparams, self.upsampling_setting
@@ -79,5 +102,5 @@ class PointUpsampleDecoder(nn.Module):
 
     @torch.no_grad()
     def forward(self, xyz, features, new_xyz, ts=None, label=None, sample_posterior=True, fps_start_idx=None):
-        feat, _ = self.propagate_feature(xyz, features, new_xyz, ts=ts, label=label)
+        feat, _ = self.propagate_feature(xyz, features, new_xyz, ts=ts, label=label, sample_posterior=sample_posterior)
         return feat, self.upsample_points(feat, new_xyz, fps_start_idx)

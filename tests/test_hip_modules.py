@@ -121,6 +121,39 @@ def test_autoencoder_decode_matches_reference(gpu_device):
     assert max(D.chamfer(full_r[b], g["level3"][b]) for b in range(B)) <= 1e-3
 
 
+def test_autoencoder_encode_matches_reference(gpu_device):
+    """2048 x 6 cloud -> PointNet2Encoder (FPS 1024/256/64/32, kNN-32 SA stack) -> key-point encoder ->
+    (B,16,48) latent features, HIP module path vs the reference's `PointAutoencoder.encode` (posterior mode).  FPS runs on
+    the INPUT coordinates only, so the selected points are bit-exact and the features compare element-wise."""
+    sys.path.insert(0, os.path.join(REPO, "pointnet2"))
+    from models.autoencoder import PointAutoencoder
+    g = load_golden("golden_encode.npz")
+    enc, decs = json.loads(str(g["encoder_config_json"])), json.loads(str(g["decoder_configs_json"]))
+    spec = golden_spec(g)
+    ae = PointAutoencoder(enc, decs, apply_kl_regularization=True)
+    have = {k: tuple(v.shape) for k, v in ae.state_dict().items()}
+    assert {k: v for k, v in have.items() if k.startswith(("encoder.", "keypoint_encoder."))} == dict(spec)  # checkpoint keys
+    vals = synth_state_dict([("ae." + n, s) for n, s in spec])
+    ae.load_state_dict({n: torch.from_numpy(vals["ae." + n]) for n, _ in spec}, strict=False)
+    ae = ae.to(gpu_device).eval()
+    d = gpu_device
+    pc, kp, lab = T(g["pointcloud"], d), T(g["keypoint"], d), T(g["label"], d)
+    out, l_xyz, _ = ae.encoder(pc, ts=None, label=lab)
+    assert np.array_equal(l_xyz[-1].cpu().numpy(), g["encoder_xyz_last"])  # four FPS levels, bit-exact selections
+    ref = g["encoder_out"]
+    assert np.abs(out.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+    feat = ae.encode(pc, kp, ts=None, label=lab, sample_posterior=False).cpu().numpy()
+    ref = g["feature_at_keypoint"]
+    assert feat.shape == ref.shape == (pc.shape[0], 16, 48)
+    assert np.abs(feat - ref).max() <= 2e-4 * np.abs(ref).max(), np.abs(feat - ref).max()
+    # the sampled posterior differs from the mode by std * N(0,1) only
+    fs = ae.encode(pc, kp, ts=None, label=lab, sample_posterior=True).cpu().numpy()
+    assert np.isfinite(fs).all() and fs.shape == ref.shape
+    # encode -> decode round trip runs end to end on the module path
+    rec = ae.decode(kp, T(feat, d), label=lab, fps_start_idx=torch.zeros(pc.shape[0], dtype=torch.int32, device=d))
+    assert rec.shape == (pc.shape[0], 2048, 6) and bool(torch.isfinite(rec).all())
+
+
 def test_sample_farthest_points(gpu_device):
     from oracle import ops as O
     from slide_amd import _ext

@@ -258,3 +258,18 @@ def test_autoencoder_decode_against_reference():
     f3, l3 = D.decode_level(decs[2], sd, "decoder.decoders.1", g["level1"][:1], f2, g["level2"][:1], lab)
     err, bij = D.match_point_sets(l3[0], g["level3"][0])
     assert bij and err <= 1e-5 and l3.shape == (1, 2048, 6), err
+
+
+def test_autoencoder_encode_matches_reference():
+    """PointAutoencoder.encode of the oracle vs the reference's output on the committed golden input:
+    PointNet2Encoder incl. four FPS levels (bit-exact selections) and kNN-32 grouping, Pnet2Stage global feature and
+    second condition inside the key-point encoder, KL posterior mode."""
+    g = load_golden("golden_encode.npz")
+    enc, decs = json.loads(str(g["encoder_config_json"])), json.loads(str(g["decoder_configs_json"]))
+    spec = golden_spec(g)
+    vals = synth_state_dict([("ae." + n, s) for n, s in spec])
+    sd = {n: vals["ae." + n] for n, _ in spec}
+    feat, out, l_xyz = D.autoencoder_encode(enc, decs, sd, g["pointcloud"][:1], g["keypoint"][:1], g["label"][:1])
+    assert np.array_equal(l_xyz[-1], g["encoder_xyz_last"][:1])
+    assert np.abs(out - g["encoder_out"][:1]).max() <= 2e-5 * np.abs(g["encoder_out"]).max()
+    assert np.abs(feat - g["feature_at_keypoint"][:1]).max() <= 2e-5 * np.abs(g["feature_at_keypoint"]).max()

@@ -296,6 +296,45 @@ def gen_decode(out, B=2):
     print("decode", [tuple(x.shape) for x in l_xyz], "params", sum(int(np.prod(s)) for _, s in spec))
 
 
+def gen_encode(out, B=2, N=2048):
+    """PointAutoencoder.encode of the reference (airplane AE config, posterior mode) on a synthetic surface-like cloud:
+    PointNet2Encoder (FPS 2048 -> 1024 -> 256 -> 64 -> 32, kNN-32 SA stack) + keypoint_encoder.propagate_feature."""
+    from data_utils.json_reader import read_json_file, autoencoder_read_config
+    from models.autoencoder import PointAutoencoder
+    d = CFG + "autoencoder_configs/"
+    cfg = read_json_file(d + "config_autoencoder_s3_kl_1e-5_16_keypoints_latent_dim_16_32_normal_weight_0_0_0.1_with_augm_kp_noise_0.04_airplane.json")
+    enc, decs = autoencoder_read_config(d, cfg)
+    ae = PointAutoencoder(enc, decs, apply_kl_regularization=True, kl_weight=1e-5)
+    spec_all = [(k, tuple(v.shape)) for k, v in ae.state_dict().items()]
+    vals = synth_state_dict([("ae." + n, s) for n, s in spec_all])
+    ae.load_state_dict({n: torch.from_numpy(vals["ae." + n]) for n, _ in spec_all})
+    ae.eval()
+    spec = [(n, s) for n, s in spec_all if n.startswith("encoder.") or n.startswith("keypoint_encoder.")]
+    rs = np.random.RandomState(41)
+    # points on a few random ellipsoid shells in [-1,1]^3 with unit normals (in_fea_dim = 3)
+    u = rs.standard_normal((B, N, 3)).astype(np.float32)
+    u /= np.linalg.norm(u, axis=2, keepdims=True)
+    radii = rs.uniform(0.3, 0.9, (B, 1, 3)).astype(np.float32)
+    pts = (u * radii).astype(np.float32)
+    nrm = u / radii
+    nrm = (nrm / np.linalg.norm(nrm, axis=2, keepdims=True)).astype(np.float32)
+    pc = np.concatenate([pts, nrm], axis=2).astype(np.float32)
+    from oracle import ops as O
+    kidx = O.furthest_point_sampling(pts, 16)
+    kp = np.take_along_axis(pts, kidx[..., None].astype(np.int64), axis=1).astype(np.float32)
+    label = np.zeros(B, np.int64)
+    with torch.no_grad():
+        out_e, l_xyz, _ = ae.encoder(torch.from_numpy(pc), ts=None, label=torch.from_numpy(label))
+        feat = ae.encode(torch.from_numpy(pc), torch.from_numpy(kp), ts=None, label=torch.from_numpy(label),
+                         sample_posterior=False)
+    res = {"pointcloud": pc, "keypoint": kp, "label": label, "encoder_config_json": np.array(json.dumps(enc)),
+           "decoder_configs_json": np.array(json.dumps(decs)), "encoder_out": out_e.numpy(),
+           "encoder_xyz_last": l_xyz[-1].numpy(), "feature_at_keypoint": feat.numpy()}
+    res["spec_names"], res["spec_shapes"] = spec_arrays(spec)
+    np.savez_compressed(os.path.join(out, "golden_encode.npz"), **res)
+    print("encode", tuple(out_e.shape), tuple(feat.shape), "params", sum(int(np.prod(s)) for _, s in spec))
+
+
 def gen_ops(out):
     from oracle import ops as O
     rs = np.random.RandomState(3)
@@ -364,7 +403,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.manual_seed(0)
-    want = set(a.only.split(",")) if a.only else {"ops", "blocks", "pos", "feat", "decode"}
+    want = set(a.only.split(",")) if a.only else {"ops", "blocks", "pos", "feat", "decode", "encode"}
     if "ops" in want:
         gen_ops(a.out)
     if "blocks" in want:
@@ -377,3 +416,5 @@ if __name__ == "__main__":
         gen_sampler_feat(net, cfg, a.out)
     if "decode" in want:
         gen_decode(a.out)
+    if "encode" in want:
+        gen_encode(a.out)
