@@ -63,3 +63,29 @@ def test_generation_clis(gpu_device, tmp_path):
     assert {"points", "normals", "label", "category", "category_name", "timing", "keypoint", "keypoint_feature"} <= set(d2.files)
     assert d2["points"].shape == (6, 2048, 3) and d2["normals"].shape == (6, 2048, 3) and d2["keypoint_feature"].shape == (6, 16, 48)
     assert np.isfinite(d2["points"]).all() and np.allclose(d2["keypoint"], d["points"])
+    # autoencoder_decode_keypoint.py on that file (reference flags / schemas), then the encode -> decode round trip
+    ge = load_golden("golden_encode.npz")
+    (ae_dir / "lv" / "enc_full.json").write_text(json.dumps({"pointnet_config": _stringify(json.loads(str(ge["encoder_config_json"])))}))
+    (ae_dir / "ae_full.json").write_text(json.dumps({"pointnet_config": {"apply_kl_regularization": True, "kl_weight": 1e-5,
+                                                                       "encoder_config_file": "lv/enc_full.json",
+                                                                       "decoder_config_file": "['lv/d0.json', 'lv/d1.json', 'lv/d2.json']"}}))
+    out3 = tmp_path / "rec"
+    r = subprocess.run([sys.executable, os.path.join(cli, "autoencoder_decode_keypoint.py"), "-c", str(ae_dir / "ae_full.json"),
+                        "--random_init", "--dataset_path", str(out2 / "shapenet_psr_generated_data_2048_pts.npz"),
+                        "--save_dir", str(out3), "--batch_size", "4"], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d3 = np.load(out3 / "reconstructed_pcd.npz")
+    assert set(d3.files) == {"points", "normals", "label", "category", "category_name", "keypoint"}
+    assert d3["points"].shape == (6, 2048, 3) and np.isfinite(d3["points"]).all() and np.allclose(d3["keypoint"], d["points"])
+    vis = out3 / "reconstructed_pcd_visualization"
+    assert (vis / "pcd_000_label_00_airplane.xyz").exists() and (vis / "pcd_005_label_00_airplane_keypoint.xyz").exists()
+    assert np.loadtxt(vis / "pcd_000_label_00_airplane.xyz").shape == (2048, 6)
+    src = tmp_path / "clouds.npz"
+    np.savez(src, points=ge["pointcloud"][:, :, :3], normals=ge["pointcloud"][:, :, 3:], keypoint=ge["keypoint"], label=ge["label"])
+    out4 = tmp_path / "rec2"
+    r = subprocess.run([sys.executable, os.path.join(cli, "autoencoder_decode_keypoint.py"), "-c", str(ae_dir / "ae_full.json"),
+                        "--random_init", "--encode_from", str(src), "--save_dir", str(out4), "--batch_size", "2"],
+                       env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d4 = np.load(out4 / "reconstructed_pcd.npz")
+    assert d4["keypoint_feature"].shape == (2, 16, 48) and d4["points"].shape == (2, 2048, 3) and np.isfinite(d4["points"]).all()
