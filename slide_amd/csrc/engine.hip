@@ -970,21 +970,6 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
   unsigned char *const ring = smem_raw + (size_t)wave * NST * STAGE_B;
   uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + (size_t)4 * NST * STAGE_B);
   float *const vec_lds = reinterpret_cast<float *>(epi_lds + 2 * EPI_DW + (2 * EPI_DW) % 4);
-  stage_epilogue_tables<2>(a, cob0, tid, epi_lds, vec_lds);
-  // AFF: consumer-side GroupNorm affine of the four samples of this tile, fp16 [sample][scale | shift][k_pad]
-  _Float16 *const aff_lds = reinterpret_cast<_Float16 *>(vec_lds + 2 * 96);
-  if (AFF) {
-    for (int i = tid; i < 4 * a.k_pad; i += 256) {
-      const int sm = i / a.k_pad, k = i - sm * a.k_pad;
-      int b = (row0 >> NPXL) + sm;
-      const int nb = a.rows >> NPXL;
-      b = b < nb ? b : nb - 1;
-      aff_lds[(sm * 2 + 0) * a.k_pad + k] = (_Float16)a.in_scale[(size_t)b * a.in_bs + k];
-      aff_lds[(sm * 2 + 1) * a.k_pad + k] = (_Float16)a.in_shift[(size_t)b * a.in_bs + k];
-    }
-    __syncthreads();
-  }
-
   const T *gp[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -1026,6 +1011,22 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
 #pragma unroll
   for (int s0 = 0; s0 < NST - 1; ++s0)
     if (s0 < mine) issue(wave + 4 * s0, s0);
+  // tables (and the affine vectors) are staged behind the primed rings: their latency overlaps the first chunks'
+  stage_epilogue_tables<2>(a, cob0, tid, epi_lds, vec_lds);
+  // AFF: consumer-side GroupNorm affine of the four samples of this tile, fp16 [sample][scale | shift][k_pad]
+  _Float16 *const aff_lds = reinterpret_cast<_Float16 *>(vec_lds + 2 * 96);
+  if (AFF) {
+    for (int i = tid; i < 4 * a.k_pad; i += 256) {
+      const int sm = i / a.k_pad, k = i - sm * a.k_pad;
+      int b = (row0 >> NPXL) + sm;
+      const int nb = a.rows >> NPXL;
+      b = b < nb ? b : nb - 1;
+      aff_lds[(sm * 2 + 0) * a.k_pad + k] = (_Float16)a.in_scale[(size_t)b * a.in_bs + k];
+      aff_lds[(sm * 2 + 1) * a.k_pad + k] = (_Float16)a.in_shift[(size_t)b * a.in_bs + k];
+    }
+    __syncthreads();
+  }
+
   for (int i = 0; i < mine; ++i) {
     // this wave's own DMA: a counted wait orders it for this wave's reads, no barrier involved
     if (i + NST - 2 < mine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * 8) : "memory");
