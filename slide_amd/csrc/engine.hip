@@ -558,10 +558,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     } else {
       slot0 = 4 * q + j;
     }
-    f32x2 t = {0.f, 0.f};
-    for (int w = 0; w < WPSF; ++w)
-      for (int h2 = 0; h2 < nh; ++h2)
-        for (int sl = 0; sl < nslot; ++sl) t += part(w, h0 + h2, slot0 + sl);
+    // fully unrolled per group shape so that the LDS reads of a lane issue back to back (a runtime-bounded loop
+    // serialises them behind one another's latency)
+    auto sum_parts = [&](auto nh_tag, auto ns_tag) __attribute__((always_inline)) {
+      constexpr int NH = decltype(nh_tag)::value, NS = decltype(ns_tag)::value;
+      f32x2 acc2 = {0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < WPSF; ++w)
+#pragma unroll
+        for (int h2 = 0; h2 < NH; ++h2)
+#pragma unroll
+          for (int sl = 0; sl < NS; ++sl) acc2 += part(w, h0 + h2, slot0 + sl);
+      return acc2;
+    };
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I4 = std::integral_constant<int, 4>;
+    f32x2 t;
+    if (nh == 1) t = sum_parts(I1(), I1());
+    else if (nslot == 1) t = sum_parts(I2(), I1());
+    else if (nslot == 2) t = sum_parts(I2(), I2());
+    else t = sum_parts(I2(), I4());
     const float mean = t[0] * inv_count;
     const float var = fmaxf(t[1] * inv_count - mean * mean, 0.f);
     float g = vec_lds[cb * 96 + 32 + c] * __builtin_amdgcn_rsqf(var + GN_EPS);
