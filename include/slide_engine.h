@@ -58,10 +58,10 @@ typedef struct SlideEpi {
 } SlideEpi;
 
 enum {
-  SLIDE_OP_GEMM = 1,        /* p: X, W, epi, in_scale, in_shift, [5] timeline buffer (instrumented builds only, else NULL), [7] 9 zeroed ints for the optional persistent tile scheduler (NULL = one tile per workgroup); f[0]: start stagger in us for the persistent mode; i[9]: 0 = default ring, 1 = 64-deep chunks, 2 = eight-wave 256x256 tiles   i: rows, x_ld, k_pad, n_cob, npx_log2, in_bs, prec, cbw(2|4), lds_dma(0|1: fp16, no in_scale) */
+  SLIDE_OP_GEMM = 1,        /* p: X, W, epi, in_scale, in_shift, [5] timeline buffer (instrumented builds only, else NULL), [7] 9 zeroed ints for the optional persistent tile scheduler (NULL = one tile per workgroup), [8] point-feature table + [9] neighbour table of the GATHER mode (first GEMM of an SA / FP block: the first f[1] 32-column chunks of X row (b, p, k) are read from row b*16 + idx[(b*16+p)*16+k] of the table with row length f[2], neighbours per point 2^f[3]; p[0] / x_ld then describe only the remaining columns); f[0]: start stagger in us for the persistent mode; i[9]: 0 = default ring, 1 = 64-deep chunks, 2 = eight-wave 256x256 tiles   i: rows, x_ld, k_pad, n_cob, npx_log2, in_bs, prec, cbw(2|4), lds_dma(0|1: fp16, no in_scale) */
   SLIDE_OP_PREP_POINTS = 2, /* p: x, xyz, feat0, knn_idx, knn_d2   i: B, cx, ldf, prec     (16 points / sample) */
-  SLIDE_OP_ASSEMBLE_SA = 3, /* p: xyz, feat, knn_idx, g            i: B, C, ldf, ldg, K, prec */
-  SLIDE_OP_ASSEMBLE_FP = 4, /* p: xyz, feat, knn_idx, knn_d2, g    i: B, C, ldf, ldg, K, prec */
+  SLIDE_OP_ASSEMBLE_SA = 3, /* p: xyz, feat, knn_idx, g            i: B, C, ldf, ldg, K, prec, c_begin (0 = all columns; else only columns >= c_begin), ld_out */
+  SLIDE_OP_ASSEMBLE_FP = 4, /* p: xyz, feat, knn_idx, knn_d2, g    i: B, C, ldf, ldg, K, prec, c_begin, ld_out */
   SLIDE_OP_FINALIZE_GN = 5, /* p: sum, sq, gid, gstart, gend, gamma, beta, scale, shift  i: B, C, bs   f: inv_count */
   SLIDE_OP_ATTN_COMBINE = 6,/* p: S, V, out   i: B*np, C, ldS, ldV, ldo, K, prec */
   SLIDE_OP_COPY_COLS = 7,   /* p: src, dst    i: rows, n, src_ld, dst_ld, src_is_f16, dst_is_f16 */

@@ -44,6 +44,9 @@ struct GemmArgs {
   const float *in_scale, *in_shift;
   int rows, x_ld, k_pad, n_cob, in_bs;
   int shm_bytes;            // dynamic LDS of the launch (its last 16 bytes hold the persistent mode's tile index)
+  const void *gfeat;        // gather mode (GAT kernels): point-feature table [B*16][g_ldf]; the first g_nsplit K chunks of X row
+  const int *gidx;          //   (b, p, k) are read from its row b*16 + gidx[(b*16 + p)*16 + k], the rest from X (x_ld = its own ld)
+  int g_ldf, g_nsplit, g_klog2;
   int *sched;               // persistent-mode tile counters (9 ints, zero), or nullptr
   int stagger;              // start delay (10 ns units) of the workgroups in odd wave slots, 0 = none
   unsigned long long *dbg;  // optional per-workgroup timeline (tools/gemm_timeline.py): 16 x 100 MHz stamps per workgroup
@@ -771,7 +774,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
 // WC = 1: four waves, tile 256 rows x 32*CBW channels.  WC = 2: eight waves, tile 256 rows x 64*CBW channels -- wave
 // (wr, wc) owns rows 64*wr.. and channel half wc, so the X chunk is fetched once per 64*CBW channels (less L2 -> LDS
 // traffic per MAC, half as many prologues); each channel half runs the 4-wave epilogue on its own LDS tables.
-template <int NPXL, int CBW, int NST, int BKT, bool AFF, int WC = 1>
+template <int NPXL, int CBW, int NST, int BKT, bool AFF, int WC = 1, bool GAT = false>
 __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem_raw, const int tr, const int tc) {
   using T = _Float16;
   constexpr int NW = 4 * WC, NT = 256 * WC;  // waves, threads
@@ -814,7 +817,11 @@ __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem
 
   // per-lane source pointers of this wave's LPW instructions (chunk 0); out-of-range rows are clamped to a valid row:
   // they only feed accumulator rows / channel blocks that are never stored
+  // GAT: the grouped input is never materialised -- the feature columns of row (sample, point, neighbour) are DMA-read
+  // straight from the neighbour's row of the point-feature table (per-lane source addresses are free), only the last
+  // chunks (coordinate channels) come from a small assembled buffer.  ga[j] serves chunks < g_nsplit, gp[j] the rest.
   const T *gp[LPW];
+  const T *ga[GAT ? LPW : 1];
 #pragma unroll
   for (int j = 0; j < LPW; ++j) {
     const int trow = RPI * (j * NW + wv) + lane / PPR;
@@ -823,16 +830,24 @@ __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem
       int grow = row0 + trow;
       grow = grow < a.rows ? grow : a.rows - 1;
       gp[j] = reinterpret_cast<const T *>(a.X) + (size_t)grow * a.x_ld + piece * 8;
+      if (GAT) {
+        const int smp = grow >> NPXL, pxl = grow & ((1 << NPXL) - 1);
+        const int nb = a.gidx[(smp * 16 + (pxl >> a.g_klog2)) * 16 + (pxl & ((1 << a.g_klog2) - 1))];
+        ga[j] = reinterpret_cast<const T *>(a.gfeat) + (size_t)(smp * 16 + nb) * a.g_ldf + piece * 8;
+        gp[j] -= (size_t)a.g_nsplit * BKT;  // chunk index kc keeps counting over the whole K
+      }
     } else {
       int gco = cob0 * 32 + (trow - TM);
       gco = gco < a.n_cob * 32 ? gco : a.n_cob * 32 - 1;
       gp[j] = reinterpret_cast<const T *>(a.W) + (size_t)gco * a.k_pad + piece * 8;
+      if (GAT) ga[j] = gp[j];
     }
   }
   auto issue = [&](int kc, int st) {
 #pragma unroll
     for (int j = 0; j < LPW; ++j) {
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(gp[j] + kc * BKT),
+      const T *src = (GAT && kc < a.g_nsplit) ? ga[GAT ? j : 0] : gp[j];
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(src + kc * BKT),
                                        (__attribute__((address_space(3))) void *)(smem_raw + (size_t)st * STAGE_B +
                                                                                   (j * NW + wv) * 1024),
                                        16, 0, 0);
@@ -914,7 +929,7 @@ __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem
 // phase instead of all bursting their loads, then all bursting their stores, and there is no last partial round.
 // The workgroup in the odd wave slot of a CU starts `stagger` later so that the pair begins half a tile apart.
 // sched[0..7] = next tile per XCD, sched[8] = finished workgroups; the last one to finish re-arms the counters.
-template <int NPXL, int CBW, int NST, int BKT, bool AFF>
+template <int NPXL, int CBW, int NST, int BKT, bool AFF, bool GAT = false>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int ntc = (a.n_cob + CBW - 1) / CBW;
@@ -924,7 +939,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
     const int q0 = blockIdx.x >> 3;
     const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;
     if (tr >= ntr) return;
-    glds_tile<NPXL, CBW, NST, BKT, AFF>(a, smem_raw, tr, tc);
+    glds_tile<NPXL, CBW, NST, BKT, AFF, 1, GAT>(a, smem_raw, tr, tc);
     return;
   }
   const int my_tiles = ((ntr - xcd + 7) / 8) * ntc;  // row tiles tr = xcd, xcd + 8, ...
@@ -944,9 +959,9 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
 #ifdef SLIDE_TIMELINE
     GemmArgs a2 = a;  // stamps indexed by tile instead of by workgroup
     if (a.dbg) a2.dbg = a.dbg + ((long long)(xcd + 8 * t) - (long long)blockIdx.x) * 16;
-    glds_tile<NPXL, CBW, NST, BKT, AFF>(a2, smem_raw, (t / ntc) * 8 + xcd, t % ntc);
+    glds_tile<NPXL, CBW, NST, BKT, AFF, 1, GAT>(a2, smem_raw, (t / ntc) * 8 + xcd, t % ntc);
 #else
-    glds_tile<NPXL, CBW, NST, BKT, AFF>(a, smem_raw, (t / ntc) * 8 + xcd, t % ntc);
+    glds_tile<NPXL, CBW, NST, BKT, AFF, 1, GAT>(a, smem_raw, (t / ntc) * 8 + xcd, t % ntc);
 #endif
     __syncthreads();  // the epilogue's LDS reads are done before the next tile's tables / DMAs / s_tile land
   }
@@ -1152,6 +1167,7 @@ __global__ __launch_bounds__(256) void prep_points_kernel(int cx, int ldf, const
 // chunk that holds the coordinate channels is assembled element-wise.
 template <typename T, bool FP>
 __global__ __launch_bounds__(256) void assemble_kernel(int C, int ldf, int ldg, int K, int nch_log2, int bulk_blocks,
+                                                       int c_begin, int ld_out,
                                                        const float *__restrict__ xyz,
                                                        const T *__restrict__ feat, const int *__restrict__ kidx,
                                                        const float *__restrict__ kd2, T *__restrict__ g) {
@@ -1169,7 +1185,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(int C, int ldf, int ldg, 
     if ((int)blockIdx.y < bulk_blocks) {
       const int e = blockIdx.y * 256 + threadIdx.x;
       pxl = e >> nch_log2;
-      c0 = (e & ((1 << nch_log2) - 1)) * 8;
+      c0 = c_begin + (e & ((1 << nch_log2) - 1)) * 8;  // c_begin > 0: the leading columns are gathered by the GEMM itself
       if (pxl >= npx || c0 >= nbulk * 8) return;
     } else {
       const int e = (blockIdx.y - bulk_blocks) * 256 + threadIdx.x;
@@ -1181,7 +1197,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(int C, int ldf, int ldg, 
     const size_t o = ((size_t)b * 16 + p) * 16;
     const int nb = kidx[o + k];
     const T *frow = feat + ((size_t)b * 16 + nb) * ldf;
-    T *dst = g + ((size_t)b * npx + pxl) * ldg + c0;
+    T *dst = g + ((size_t)b * npx + pxl) * ld_out + (c0 - c_begin);
     if (c0 + 8 <= C && sizeof(T) * ldf % 16 == 0) {
       if (sizeof(T) == 2) {
         *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(frow + c0);
@@ -1469,7 +1485,7 @@ int launch_gemm(const GemmArgs &a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-template <int NPXL, int CBW, int NST, int BKT, bool AFF>
+template <int NPXL, int CBW, int NST, int BKT, bool AFF, bool GAT = false>
 int launch_gemm_glds(const GemmArgs &a, hipStream_t s) {
   constexpr int NSAMP = (1 << NPXL) >= TM ? 1 : TM >> NPXL;
   const size_t shm = (size_t)NST * (TM + (CBW < 2 ? 64 : 32 * CBW)) * BKT * 2 + CBW * (sizeof(SlideEpi) + 96 * 4) + 32 +
@@ -1484,11 +1500,11 @@ int launch_gemm_glds(const GemmArgs &a, hipStream_t s) {
   else b.sched = nullptr;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_glds_kernel<NPXL, CBW, NST, BKT, AFF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_glds_kernel<NPXL, CBW, NST, BKT, AFF, GAT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, NST > 3 ? 160 * 1024 : 84 * 1024 * (BKT / 32));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<NPXL, CBW, NST, BKT, AFF>), dim3(grid), dim3(256), (size_t)b.shm_bytes, s, b);
+  hipLaunchKernelGGL((gemm_glds_kernel<NPXL, CBW, NST, BKT, AFF, GAT>), dim3(grid), dim3(256), (size_t)b.shm_bytes, s, b);
   return (int)hipGetLastError();
 }
 
@@ -1540,6 +1556,8 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
   a.dbg = (unsigned long long *)o.p[5];
   a.stagger = (int)(o.f[0] * 100.f);
   a.sched = (int *)o.p[7];
+  a.gfeat = o.p[8]; a.gidx = (const int *)o.p[9];
+  a.g_nsplit = (int)o.f[1]; a.g_ldf = (int)o.f[2]; a.g_klog2 = (int)o.f[3];
   a.rows = o.i[0]; a.x_ld = o.i[1]; a.k_pad = o.i[2]; a.n_cob = o.i[3]; a.in_bs = o.i[5];
   const int npxl = o.i[4], prec = o.i[6], cbw = o.i[7], glds = o.i[8];
   if (a.k_pad % BK || a.x_ld % 8 || a.rows <= 0 || a.n_cob <= 0) return -3;
@@ -1571,6 +1589,14 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
     if (o.i[9] == 4 && cbw == 2 && !a.in_scale && ((a.rows + TM - 1) / TM) * ((a.n_cob + 1) / 2) <= 512) {
       if (npxl == 8) return launch_gemm_glds8<8, 1, 3>(a, s);
       if (npxl == 7) return launch_gemm_glds8<7, 1, 3>(a, s);
+    }
+    if (a.gfeat) {  // gathered grouped input (first GEMM of an SA / FP block)
+      if (a.in_scale || wide) return -4;
+      if (npxl == 7 && cbw == 2) return launch_gemm_glds<7, 2, 3, 32, false, true>(a, s);
+      if (npxl == 8 && cbw == 2) return launch_gemm_glds<8, 2, 3, 32, false, true>(a, s);
+      if (npxl == 7 && cbw == 4) return launch_gemm_glds<7, 4, 3, 32, false, true>(a, s);
+      if (npxl == 8 && cbw == 4) return launch_gemm_glds<8, 4, 3, 32, false, true>(a, s);
+      return -4;
     }
     if (a.in_scale) { ACASE(7, 2); ACASE(8, 2); ACASE(7, 4); ACASE(8, 4); return -4; }
     if (cbw == 1 && !wide) {
@@ -1629,18 +1655,21 @@ int run_op(const SlideOp &o, hipStream_t s) {
     case SLIDE_OP_ASSEMBLE_SA:
     case SLIDE_OP_ASSEMBLE_FP: {
       const bool fp = o.kind == SLIDE_OP_ASSEMBLE_FP;
-      // bulk (whole 16-byte pieces of the gathered rows) and tail (coordinate pieces) blocks, see the kernel
+      // bulk (whole 16-byte pieces of the gathered rows) and tail (coordinate pieces) blocks, see the kernel.
+      // i[6] = c_begin (multiple of 32): only columns >= c_begin are produced, into rows of i[7] elements
       const int esz = o.i[5] == SLIDE_PREC_F16 ? 2 : 4;
+      const int c_begin = o.i[6], ld_out = o.i[6] ? o.i[7] : o.i[3];
       const int nch = o.i[3] / 8, nbulk = (esz * o.i[2] % 16 == 0) ? o.i[1] / 8 : 0, ntail = nch - nbulk;
+      const int nb_eff = nbulk - c_begin / 8 > 0 ? nbulk - c_begin / 8 : 0;
       int nch_log2 = 0;
-      while ((1 << nch_log2) < nbulk) ++nch_log2;
-      const int bulk_blocks = nbulk ? (((16 * o.i[4]) << nch_log2) + 255) / 256 : 0;
+      while ((1 << nch_log2) < nb_eff) ++nch_log2;
+      const int bulk_blocks = nb_eff ? (((16 * o.i[4]) << nch_log2) + 255) / 256 : 0;
       const int tail_blocks = (16 * o.i[4] * ntail + 255) / 256;
       const dim3 g(o.i[0], bulk_blocks + tail_blocks), blk(256);
       const float *kd2 = fp ? (const float *)o.p[3] : nullptr;
       void *dst = fp ? o.p[4] : o.p[3];
 #define ASM(TT, FPB)                                                                                                  \
-  hipLaunchKernelGGL((assemble_kernel<TT, FPB>), g, blk, 0, s, o.i[1], o.i[2], o.i[3], o.i[4], nch_log2, bulk_blocks, (const float *)o.p[0], \
+  hipLaunchKernelGGL((assemble_kernel<TT, FPB>), g, blk, 0, s, o.i[1], o.i[2], o.i[3], o.i[4], nch_log2, bulk_blocks, c_begin, ld_out, (const float *)o.p[0], \
                      (const TT *)o.p[1], (const int *)o.p[2], kd2, (TT *)dst)
       if (o.i[5] == SLIDE_PREC_F16) { if (fp) ASM(_Float16, true); else ASM(_Float16, false); }
       else { if (fp) ASM(float, true); else ASM(float, false); }

@@ -165,12 +165,15 @@ class DenoiserEngine:
         self._cvec.append((prefix, width))
         return off
 
-    def _gemm(self, X, npx_log2, segs, in_cols=None, in_affine=None, k_logical=None):
+    def _gemm(self, X, npx_log2, segs, in_cols=None, in_affine=None, k_logical=None, gather=None):
         """X: input buffer [rows][ld].  segs: list of dicts describing consecutive output segments:
              w (O,I) bias (O) | out (tensor) out_coff | mode flags | gn=(gamma,beta) for NORM | layout (gn_layout) |
              addvec=(tensor, off, bs) | residual tensor | bcast | stats=(sum,sq tensors, coff, scale)
            in_cols: physical column index of every logical input channel (None = identity)."""
         rows, ld = X.shape
+        x_ld = ld
+        if gather is not None:  # (feature table, neighbour table, K, chunks read from the table): X holds the remaining columns
+            ld = gather[3] * 32 + x_ld
         npx = 1 << npx_log2
         wrows, tables = [], []
         vec_list = []
@@ -268,12 +271,15 @@ class DenoiserEngine:
         wr = sum(rows * v[2] * v[1]["out"].element_size() for v in vec_list)
         self.gemm_bytes[len(self.ops)] = (rd, wr)  # algorithmic HBM bytes (read, written) of this launch
         glds = int(self.use_glds and self.prec == 1 and (sc is None or npx_log2 >= 7))
-        self._emit(make_op(OP_GEMM, i=(rows, ld, ld, n_cob, npx_log2, in_bs, self.prec, cbw, glds, self.glds_nst),
-                           f=(float(os.environ.get('SLIDE_STAGGER_US', '0')),),
+        gf = (0.0, 0.0, 0.0) if gather is None else (float(gather[3]), float(gather[0].shape[1]), float({8: 3, 16: 4}[gather[2]]))
+        self._emit(make_op(OP_GEMM, i=(rows, x_ld, ld, n_cob, npx_log2, in_bs, self.prec, cbw, glds, self.glds_nst),
+                           f=(float(os.environ.get('SLIDE_STAGGER_US', '0')),) + gf,
                                 p=(X.data_ptr(), Wd.data_ptr(), ed.data_ptr(),
                                    None if sc is None else sc.data_ptr() + 4 * aff_off,
                                    None if sh is None else sh.data_ptr() + 4 * aff_off, None, None,
-                                   self._sched().data_ptr() if self.persistent else None)))
+                                   self._sched().data_ptr() if self.persistent else None,
+                                   None if gather is None else gather[0].data_ptr(),
+                                   None if gather is None else gather[1].data_ptr())))
         self.flops += 2 * rows * sum(int(s["w"].size) for s in segs)
 
     # ------------------------------------------------------------------ blocks
@@ -317,7 +323,7 @@ class DenoiserEngine:
             seg["out_coff"] = final_coff
             self._gemm(h1, npx_log2, [seg])
 
-    def _attention(self, apfx, npx_log2, K, g, q_in, mo, mlp_first, mlp_res, out, out_ld_buf):
+    def _attention(self, apfx, npx_log2, K, g, q_in, mo, mlp_first, mlp_res, out, out_ld_buf, gather=None):
         """AttentionModule (attention.py:35-96).  g: grouped input [B*npx][ldg]; q_in: query features [B*16][ld];
         mo: the Mlp output buffer (values input), produced by the caller AFTER the shared first GEMM.
 
@@ -349,7 +355,7 @@ class DenoiserEngine:
         self._gemm(q_in, 4, [qseg])
         self._lane = 0
         # shared-input GEMM: [first_mlp | res_connect | grouped_feat_conv]
-        self._gemm(g, npx_log2, [mlp_first, mlp_res, kseg])
+        self._gemm(g, npx_log2, [mlp_first, mlp_res, kseg], gather=gather)
         self._sync(0, 1)  # the key statistics are ready
 
         def finish_scores():
@@ -404,6 +410,24 @@ class DenoiserEngine:
                                     p=(S.data_ptr(), V.data_ptr(), out.data_ptr())))
         return (finish_scores, finish), cout
 
+    def _grouped_input(self, kind, feat_in, C, Cg, K):
+        """the grouped input of an SA / FP block.  fp16 LDS-DMA path: only the last chunks (left-over feature columns +
+        coordinate channels) are assembled; the GEMM gathers the leading 32-column chunks from the neighbours' rows of
+        `feat_in` itself (returns (tail buffer, gather tuple)).  Otherwise the whole [rows][Cg] matrix is assembled."""
+        B = self.B
+        rows = B * 16 * K
+        ldg = ru(Cg)
+        nsplit = 0
+        if self.prec == 1 and self.use_glds and os.environ.get("SLIDE_GATHER", "1") != "0":
+            nsplit = (C // 8) * 8 // 32
+        c_begin = nsplit * 32
+        g = self.A.zeros(rows, ldg - c_begin, dtype=self.adt)
+        ptrs = (self.xyz.data_ptr(), feat_in.data_ptr(), self.kidx.data_ptr())
+        if kind == OP_ASSEMBLE_FP:
+            ptrs += (self.kd2.data_ptr(),)
+        self._emit(make_op(kind, i=(B, C, feat_in.shape[1], ldg, K, self.prec, c_begin, ldg - c_begin), p=ptrs + (g.data_ptr(),)))
+        return g, ((feat_in, self.kidx, K, nsplit) if nsplit else None), rows
+
     def _sa_module(self, i, feat_in, C):
         sd, B = self.sd, self.B
         pfx = "SA_modules.%d" % i
@@ -412,15 +436,13 @@ class DenoiserEngine:
         rows = B * 16 * K
         Cg = C + 9
         assert sd[mp + ".first_mlp.0.weight"].shape[1] == Cg
-        g = self._buf(rows, Cg)
-        self._emit(make_op(OP_ASSEMBLE_SA, i=(B, C, feat_in.shape[1], g.shape[1], K, self.prec),
-                                p=(self.xyz.data_ptr(), feat_in.data_ptr(), self.kidx.data_ptr(), g.data_ptr())))
+        g, gather, _ = self._grouped_input(OP_ASSEMBLE_SA, feat_in, C, Cg, K)
         c1 = sd[mp + ".first_mlp.0.weight"].shape[0]
         c_last = sd[mp + ".res_connect.weight"].shape[0]
         h1, r, mo = self._buf(rows, c1), self._buf(rows, c_last), self._buf(rows, c_last)
         first, res = self._mlp_segments(mp, self.tvec, self.cvec, h1, r)
         out = self._buf(B * 16, c_last)
-        (scores, finish), cout = self._attention(ap, 8, K, g, feat_in, mo, first, res, out, None)
+        (scores, finish), cout = self._attention(ap, 8, K, g, feat_in, mo, first, res, out, None, gather=gather)
         S = scores()                                  # lane 1: finalize, P, weight_conv.2, weight_conv.5
         self._mlp_tail(mp, 8, h1, self.cvec, r, mo)   # lane 0: second / rest mlp
         finish(S)                                     # lane 0: values; join; softmax-combine
@@ -435,10 +457,7 @@ class DenoiserEngine:
         rows = B * 16 * K
         Cg = C2 + 11
         assert sd[m1 + ".first_mlp.0.weight"].shape[1] == Cg
-        g = self._buf(rows, Cg)
-        self._emit(make_op(OP_ASSEMBLE_FP, i=(B, C2, Kf.shape[1], g.shape[1], K, self.prec),
-                                p=(self.xyz.data_ptr(), Kf.data_ptr(), self.kidx.data_ptr(), self.kd2.data_ptr(),
-                                   g.data_ptr())))
+        g, gather, _ = self._grouped_input(OP_ASSEMBLE_FP, Kf, C2, Cg, K)
         c1 = sd[m1 + ".first_mlp.0.weight"].shape[0]
         c_last = sd[m1 + ".res_connect.weight"].shape[0]
         h1, r, mo = self._buf(rows, c1), self._buf(rows, c_last), self._buf(rows, c_last)
@@ -447,7 +466,7 @@ class DenoiserEngine:
         zin = c_last + CU + 3
         assert sd[m2 + ".first_mlp.0.weight"].shape[1] == zin
         Z = self._buf(B * 16, zin)
-        (scores, finish), cout = self._attention(ap, 7, K, g, U, mo, first, res, Z, None)
+        (scores, finish), cout = self._attention(ap, 7, K, g, U, mo, first, res, Z, None, gather=gather)
         S = scores()
         self._mlp_tail(m1, 7, h1, self.cvec, r, mo)
         finish(S)
