@@ -95,20 +95,21 @@ def main():
     sd_f = synth_state_dict(model_spec.denoiser_param_spec(fc["pointnet_config"]))
     P = max(1, min(a.sub_batches, B))
     sizes = [B // P + (1 if i < B % P else 0) for i in range(P)]
+    # the feature plan runs as P concurrent sub-batches; the position plan (launch-bound at any size) as ONE chain over
+    # the whole batch, a parallel branch of the first sub-batch's step graph
+    pos = PositionSampler(pc["pointnet_config"], sd_p, B, dev, pc["diffusion_config"], prec=a.prec, seed=1000 + rank * 16)
     subs = []
     for i, b in enumerate(sizes):
-        p_ = PositionSampler(pc["pointnet_config"], sd_p, b, dev, pc["diffusion_config"], prec=a.prec,
-                             seed=1000 + rank * 16 + i)
         f_ = FeatureSampler(fc["pointnet_config"], sd_f, b, dev, fc["standard_diffusion_config"], prec=a.prec,
                             seed=2000 + rank * 16 + i)
-        subs.append((p_, f_, JointSampler(p_, f_), synth_keypoints(b, seed=rank * 16 + i)))
-    pos, feat, kp = subs[0][0], subs[0][1], subs[0][3]  # sub-batch 0 also serves the roofline leg below
-    joint = SplitJointSampler([s_[2] for s_ in subs])  # one hipGraph per sub-batch and step, two branches each
+        subs.append((f_, JointSampler(pos if i == 0 else None, f_), synth_keypoints(b, seed=rank * 16 + i)))
+    feat, kp = subs[0][0], subs[0][2]  # sub-batch 0 also serves the roofline leg below
+    joint = SplitJointSampler([s_[1] for s_ in subs])  # one hipGraph per sub-batch and step
     rs = np.random.RandomState(rank)
 
     def reset():
-        for (p_, f_, _, k_), b in zip(subs, sizes):
-            p_.begin(np.zeros(b, np.int64), rs.standard_normal((b, 16, 3)).astype(np.float32))
+        pos.begin(np.zeros(B, np.int64), rs.standard_normal((B, 16, 3)).astype(np.float32))
+        for (f_, _, k_), b in zip(subs, sizes):
             f_.begin(np.full(b, 4, np.int64), k_, rs.standard_normal((b, 16, 51)).astype(np.float32))
 
     def run(n):  # n reverse steps of each DDPM; chains restart from fresh noise every 1000 steps
@@ -120,8 +121,9 @@ def main():
             done += k
 
     def sync_all():
-        for p_, f_, _, _ in subs:
-            p_.stream.synchronize(); f_.stream.synchronize()
+        pos.stream.synchronize()
+        for f_, _, _ in subs:
+            f_.stream.synchronize()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -132,17 +134,17 @@ def main():
     t0 = time.perf_counter()
     run(a.steps)
     if world > 1:  # the single collective of the path: all ranks' latents (835 KB / rank at B=256)
-        for _, f_, _, _ in subs:
+        for f_, _, _ in subs:
             f_.stream.synchronize()
-        dist.all_gather(gathered, torch.cat([f_.engine.x.reshape(-1, 16, 51) for _, f_, _, _ in subs], 0))
+        dist.all_gather(gathered, torch.cat([f_.engine.x.reshape(-1, 16, 51) for f_, _, _ in subs], 0))
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    finite = all(bool(torch.isfinite(f_.state()).all().item()) and bool(torch.isfinite(p_.state()).all().item())
-                 for p_, f_, _, _ in subs)
+    finite = bool(torch.isfinite(pos.state()).all().item()) and all(bool(torch.isfinite(f_.state()).all().item())
+                                                                     for f_, _, _ in subs)
     ms_per_step = dt * 1e3 / a.steps
     value = world * B / (1000.0 * (ms_per_step / 1e3))
 
@@ -153,7 +155,7 @@ def main():
            "config": {"workload": "BASELINE configs[1]+[2]: airplane position DDPM (16x3) + chair feature DDPM (16x51), "
                                   "batch %d per GPU; 1 step = one reverse step of each; shape = 1000+1000 steps" % B,
                       "batch_per_gpu": B, "sub_batches": sizes, "prec": a.prec,
-                      "launches_per_step": P * (pos.n_launches + feat.n_launches),
+                      "launches_per_step": pos.n_launches + P * feat.n_launches,
                       "finite": finite}}
 
     if rank == 0 and not a.no_roofline:

@@ -222,19 +222,24 @@ class JointSampler:
     large ones.  Both chains advance by the same number of steps per call."""
 
     def __init__(self, pos, feat):
+        """pos may be None: the step graph then holds the feature plan alone (a further feature sub-batch of a
+        SplitJointSampler whose position chain runs unsplit beside the first one)"""
         from .engine import OP_SYNC
         self.pos, self.feat = pos, feat
-        ops = [make_op(OP_SYNC, i=(0, 1))]
-        for o in pos.step_ops:
-            c = SlideOp.from_buffer_copy(o)
-            if c.kind != OP_SYNC:
-                c.i[10] = 1
-            ops.append(c)
+        ops = []
+        if pos is not None:
+            ops.append(make_op(OP_SYNC, i=(0, 1)))
+            for o in pos.step_ops:
+                c = SlideOp.from_buffer_copy(o)
+                if c.kind != OP_SYNC:
+                    c.i[10] = 1
+                ops.append(c)
         ops += [SlideOp.from_buffer_copy(o) for o in feat.step_ops]
-        ops.append(make_op(OP_SYNC, i=(1, 0)))
+        if pos is not None:
+            ops.append(make_op(OP_SYNC, i=(1, 0)))
         self.step_ops = (SlideOp * len(ops))(*ops)
         self.graph = None
-        self.stream, self.stream2 = feat.stream, pos.stream
+        self.stream, self.stream2 = feat.stream, (pos.stream if pos is not None else feat.stream2)
 
     def _prepare(self):
         """orders the joint graph behind everything queued on the position stream and captures it on first use"""
@@ -245,11 +250,12 @@ class JointSampler:
             return
         with torch.cuda.stream(self.stream):
             s, s2 = ctypes.c_void_p(self.stream.cuda_stream), ctypes.c_void_p(self.stream2.cuda_stream)
-            e1, e2 = self.pos.engine, self.feat.engine
-            keep = [e1.x.clone(), e1.t_dev.clone(), e2.x.clone(), e2.t_dev.clone()]
+            engines = [smp.engine for smp in (self.pos, self.feat) if smp is not None]
+            keep = [(e.x.clone(), e.t_dev.clone()) for e in engines]
             check(L.slide_run_ops2(self.step_ops, len(self.step_ops), s, s2), "slide_run_ops2")
             self.stream.synchronize(); self.stream2.synchronize()
-            e1.x.copy_(keep[0]); e1.t_dev.copy_(keep[1]); e2.x.copy_(keep[2]); e2.t_dev.copy_(keep[3])
+            for e, (x0, t0) in zip(engines, keep):
+                e.x.copy_(x0); e.t_dev.copy_(t0)
             self.stream.synchronize()
             check(L.slide_graph_begin(s), "graph_begin")
             st = L.slide_run_ops2(self.step_ops, len(self.step_ops), s, s2)
@@ -279,7 +285,10 @@ class SplitJointSampler:
     graphs launched round-robin.  The sub-batches are independent objects of the partition (no exchange), so this is
     pure scheduling: while one sub-batch sits in its latency-bound kernels (16-row per-point GEMMs, normalisation
     finalisers, the position plan) the other's wide GEMMs have the CUs, which a single dependent chain cannot do.
-    Measured at batch 256 on one MI355X: 2 sub-batches 1.34 ms/step vs 1.46 (one), 3 and 4 are slower."""
+    Measured at batch 256 on one MI355X: the FEATURE plan as 2 sub-batches, 1.34 ms/step vs 1.46 (one); 3 and 4 are
+    slower.  The POSITION plan is launch-bound at any batch size (57 kernels of a few microseconds): it stays ONE chain
+    over the whole batch, a parallel branch of the first feature sub-batch's graph -- splitting it too doubles its
+    launches for no gain (1.44 -> 1.19 ms/step on the same GPU when left whole)."""
 
     def __init__(self, joints):
         self.joints = list(joints)
