@@ -1413,43 +1413,34 @@ __device__ __forceinline__ float philox_normal(uint32_t seed_lo, uint32_t seed_h
   return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
 }
 
-// sampling() update (pointnet2/util.py:247-253): x = (x - c_eps[t]*eps)/sqrt_alpha[t]; t>0: x += sigma[t]*z
-__global__ __launch_bounds__(256) void update_pos_kernel(int n, int eps_ld, uint32_t seed_lo, uint32_t seed_hi, float *__restrict__ x,
-                                                         const float *__restrict__ eps, const float *__restrict__ noise,
-                                                         const int *__restrict__ t_dev, const float *__restrict__ c_eps,
-                                                         const float *__restrict__ sqrt_alpha,
-                                                         const float *__restrict__ sigma) {
-#pragma clang fp contract(off)
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= n) return;
-  const int t = t_dev[0], step = t_dev[1];
-  const int ep = eps_ld ? (e / 3) * eps_ld + e % 3 : e;  // eps rows may be padded (the plan's last GEMM output)
-  float v = (x[e] - c_eps[t] * eps[ep]) / sqrt_alpha[t];
-  if (t > 0) {
-    const float z = noise ? noise[(size_t)step * n + e] : philox_normal(seed_lo, seed_hi, (uint32_t)step, (uint32_t)e);
-    v = v + sigma[t] * z;
+// The update kernel also advances the device-side timestep: every block read t / step at its start, so the block that
+// finishes LAST (a counter in t_dev[2]) may write t - 1 / step + 1 for the next replay -- one launch less per step.
+__device__ __forceinline__ void advance_t_last_block(int *t_dev, int t, int step) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&t_dev[2], 1) == (int)gridDim.x - 1) {
+      t_dev[2] = 0;
+      t_dev[0] = t - 1;
+      t_dev[1] = step + 1;
+    }
   }
-  x[e] = v;
 }
 
-// denoising_step (pointnet2/diffusion_utils/diffusion.py:58-95) with the key-point channels re-clamped to the
-// condition (:383-385): x0 = rc*x - rm1*eps [clamp]; mean = c1*x0 + c2*x; x = mean + [t>0] std*z
-__global__ __launch_bounds__(256) void update_feat_kernel(int npts, int C, int kdim, int eps_ld, float clamp, uint32_t seed_lo,
-                                                          uint32_t seed_hi, float *__restrict__ x,
-                                                          const float *__restrict__ eps, const float *__restrict__ noise,
-                                                          const int *__restrict__ t_dev, const float *__restrict__ keypoint,
-                                                          const float *__restrict__ rc, const float *__restrict__ rm1,
-                                                          const float *__restrict__ c1, const float *__restrict__ c2,
-                                                          const float *__restrict__ stdv) {
+__device__ __forceinline__ void update_feat_element(int e, int npts, int C, int kdim, int eps_ld, float clamp,
+                                                    uint32_t seed_lo, uint32_t seed_hi, float *__restrict__ x,
+                                                    const float *__restrict__ eps, const float *__restrict__ noise, int t,
+                                                    int step, const float *__restrict__ keypoint,
+                                                    const float *__restrict__ rc, const float *__restrict__ rm1,
+                                                    const float *__restrict__ c1, const float *__restrict__ c2,
+                                                    const float *__restrict__ stdv) {
 #pragma clang fp contract(off)
-  const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= npts * C) return;
   const int p = e / C, c = e - p * C;
   if (c < kdim) {
     x[e] = keypoint[(size_t)p * kdim + c];
     return;
   }
-  const int t = t_dev[0], step = t_dev[1];
   const float xv = x[e];
   float x0 = rc[t] * xv - rm1[t] * eps[eps_ld ? (size_t)p * eps_ld + c : (size_t)e];
   if (clamp > 0.f) x0 = fminf(fmaxf(x0, -clamp), clamp);
@@ -1460,6 +1451,43 @@ __global__ __launch_bounds__(256) void update_feat_kernel(int npts, int C, int k
     v = v + stdv[t] * z;
   }
   x[e] = v;
+}
+
+// sampling() update (pointnet2/util.py:247-253): x = (x - c_eps[t]*eps)/sqrt_alpha[t]; t>0: x += sigma[t]*z
+__global__ __launch_bounds__(256) void update_pos_kernel(int n, int eps_ld, uint32_t seed_lo, uint32_t seed_hi, float *__restrict__ x,
+                                                         const float *__restrict__ eps, const float *__restrict__ noise,
+                                                         int *__restrict__ t_dev, const float *__restrict__ c_eps,
+                                                         const float *__restrict__ sqrt_alpha,
+                                                         const float *__restrict__ sigma) {
+#pragma clang fp contract(off)
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int t = t_dev[0], step = t_dev[1];
+  if (e < n) {
+    const int ep = eps_ld ? (e / 3) * eps_ld + e % 3 : e;  // eps rows may be padded (the plan's last GEMM output)
+    float v = (x[e] - c_eps[t] * eps[ep]) / sqrt_alpha[t];
+    if (t > 0) {
+      const float z = noise ? noise[(size_t)step * n + e] : philox_normal(seed_lo, seed_hi, (uint32_t)step, (uint32_t)e);
+      v = v + sigma[t] * z;
+    }
+    x[e] = v;
+  }
+  advance_t_last_block(t_dev, t, step);
+}
+
+// denoising_step (pointnet2/diffusion_utils/diffusion.py:58-95) with the key-point channels re-clamped to the
+// condition (:383-385): x0 = rc*x - rm1*eps [clamp]; mean = c1*x0 + c2*x; x = mean + [t>0] std*z
+__global__ __launch_bounds__(256) void update_feat_kernel(int npts, int C, int kdim, int eps_ld, float clamp, uint32_t seed_lo,
+                                                          uint32_t seed_hi, float *__restrict__ x,
+                                                          const float *__restrict__ eps, const float *__restrict__ noise,
+                                                          int *__restrict__ t_dev, const float *__restrict__ keypoint,
+                                                          const float *__restrict__ rc, const float *__restrict__ rm1,
+                                                          const float *__restrict__ c1, const float *__restrict__ c2,
+                                                          const float *__restrict__ stdv) {
+#pragma clang fp contract(off)
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int t = t_dev[0], step = t_dev[1];
+  update_feat_element(e, npts, C, kdim, eps_ld, clamp, seed_lo, seed_hi, x, eps, noise, t, step, keypoint, rc, rm1, c1, c2, stdv);
+  advance_t_last_block(t_dev, t, step);
 }
 
 __global__ void advance_t_kernel(int *t_dev) {
@@ -1722,12 +1750,12 @@ int run_op(const SlideOp &o, hipStream_t s) {
     case SLIDE_OP_UPDATE_POS:
       hipLaunchKernelGGL(update_pos_kernel, dim3((o.i[0] + 255) / 256), dim3(256), 0, s, o.i[0], o.i[1], (uint32_t)o.i[2],
                          (uint32_t)o.i[3], (float *)o.p[0], (const float *)o.p[1], (const float *)o.p[2],
-                         (const int *)o.p[3], (const float *)o.p[4], (const float *)o.p[5], (const float *)o.p[6]);
+                         (int *)o.p[3], (const float *)o.p[4], (const float *)o.p[5], (const float *)o.p[6]);
       break;
     case SLIDE_OP_UPDATE_FEAT:
       hipLaunchKernelGGL(update_feat_kernel, dim3((o.i[0] * o.i[1] + 255) / 256), dim3(256), 0, s, o.i[0], o.i[1],
                          o.i[2], o.i[5], o.f[0], (uint32_t)o.i[3], (uint32_t)o.i[4], (float *)o.p[0], (const float *)o.p[1],
-                         (const float *)o.p[2], (const int *)o.p[3], (const float *)o.p[4], (const float *)o.p[5],
+                         (const float *)o.p[2], (int *)o.p[3], (const float *)o.p[4], (const float *)o.p[5],
                          (const float *)o.p[6], (const float *)o.p[7], (const float *)o.p[8], (const float *)o.p[9]);
       break;
     case SLIDE_OP_TRANSPOSE:

@@ -76,7 +76,7 @@ class _GraphedSampler:
         hoisted = set(e.xyz_copy_idx) if fixed_xyz else set()
         drop = hoisted | {e.eps_copy_idx}
         ops = [o for i, o in enumerate(e.ops) if i not in drop]
-        ops += [update_op, make_op(OP_ADVANCE_T, p=(e.t_dev.data_ptr(),))]
+        ops += [update_op]  # the update kernel's last block also advances the device-side timestep (t -= 1, step += 1)
         self.step_ops = (SlideOp * len(ops))(*ops)
         self.n_launches = len(ops)
         # once per batch: everything up to the last hoisted copy that the copies depend on (the point preparation)
@@ -119,7 +119,7 @@ class _GraphedSampler:
         e = self.engine
         with torch.cuda.stream(self.stream):
             e.x.copy_(torch.as_tensor(x).to(self.device, torch.float32).reshape(e.x.shape))
-            e.t_dev.copy_(torch.tensor([t_start, 0], dtype=torch.int32))
+            e.t_dev.copy_(torch.tensor([t_start, 0, 0, 0], dtype=torch.int32))
 
     def advance(self, n_steps):
         """replay n reverse steps from the current device-side state (no host sync)"""
