@@ -58,7 +58,7 @@ typedef struct SlideEpi {
 } SlideEpi;
 
 enum {
-  SLIDE_OP_GEMM = 1,        /* p: X, W, epi, in_scale, in_shift, [5] timeline buffer (instrumented builds only, else NULL), [7] 9 zeroed ints for the optional persistent tile scheduler (NULL = one tile per workgroup), [8] point-feature table + [9] neighbour table of the GATHER mode (first GEMM of an SA / FP block: the first f[1] 32-column chunks of X row (b, p, k) are read from row b*16 + idx[(b*16+p)*16+k] of the table with row length f[2], neighbours per point 2^f[3]; p[0] / x_ld then describe only the remaining columns); f[0]: start stagger in us for the persistent mode; i[9]: 0 = default ring, 1 = 64-deep chunks, 2 = eight-wave 256x256 tiles   i: rows, x_ld, k_pad, n_cob, npx_log2, in_bs, prec, cbw(2|4), lds_dma(0|1: fp16, no in_scale) */
+  SLIDE_OP_GEMM = 1,        /* p: X, W, epi, in_scale, in_shift, [5] timeline buffer (instrumented builds only, else NULL), [6] SlideGnFin* (16-row launches with input affine: finalise the statistics in this launch), [7] 9 zeroed ints for the optional persistent tile scheduler (NULL = one tile per workgroup), [8] point-feature table + [9] neighbour table of the GATHER mode (first GEMM of an SA / FP block: the first f[1] 32-column chunks of X row (b, p, k) are read from row b*16 + idx[(b*16+p)*16+k] of the table with row length f[2], neighbours per point 2^f[3]; p[0] / x_ld then describe only the remaining columns); f[0]: start stagger in us for the persistent mode; i[9]: 0 = default ring, 1 = 64-deep chunks, 2 = eight-wave 256x256 tiles   i: rows, x_ld, k_pad, n_cob, npx_log2, in_bs, prec, cbw(2|4), lds_dma(0|1: fp16, no in_scale) */
   SLIDE_OP_PREP_POINTS = 2, /* p: x, xyz, feat0, knn_idx, knn_d2   i: B, cx, ldf, prec     (16 points / sample) */
   SLIDE_OP_ASSEMBLE_SA = 3, /* p: xyz, feat, knn_idx, g            i: B, C, ldf, ldg, K, prec, c_begin (0 = all columns; else only columns >= c_begin), ld_out */
   SLIDE_OP_ASSEMBLE_FP = 4, /* p: xyz, feat, knn_idx, knn_d2, g    i: B, C, ldf, ldg, K, prec, c_begin, ld_out */
@@ -74,6 +74,19 @@ enum {
   SLIDE_OP_GROUPNORM_NCHW = 13,/* p: x, gamma, beta, y (NCHW fp32)   i: B, C, HW, G, n_norm, relu  (module-level path) */
   SLIDE_OP_TRANSPOSE = 15   /* p: in, out (fp32)   i: B, R, C, in_ld, out_ld, in_batch_stride, out_batch_stride: out[b][c][r] = in[b][r][c] (module-level path: NCHW <-> row-major) */
 };
+
+/* GroupNorm finalisation folded into the first consumer (fp16 small-launch GEMM with input affine, SlideOp.p[6]):
+ * per-(sample, channel) sums of a channel-concatenated tensor whose groups straddle producers -> scale / shift.
+ * The kernel computes them for the samples of its tile, uses its own channel slice and writes the full rows to
+ * scale / shift for the later consumers (what SLIDE_OP_FINALIZE_GN does as a separate launch). */
+typedef struct SlideGnFin {
+  const float *sum, *sq;           /* [B][bs] */
+  const int *gid, *gstart, *gend;  /* channel -> group (-1 = not normalised); group -> physical channel range */
+  const float *gamma, *beta;       /* [C] */
+  float *scale, *shift;            /* [B][bs] outputs */
+  float inv_count;
+  int C, bs, G;                    /* channels, row stride of sum / sq / scale / shift, number of groups (<= 32) */
+} SlideGnFin;
 
 typedef struct SlideOp {
   int32_t kind;

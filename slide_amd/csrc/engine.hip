@@ -44,6 +44,7 @@ struct GemmArgs {
   const float *in_scale, *in_shift;
   int rows, x_ld, k_pad, n_cob, in_bs;
   int shm_bytes;            // dynamic LDS of the launch (its last 16 bytes hold the persistent mode's tile index)
+  const SlideGnFin *gn_fin; // small-launch affine GEMM: finalise the GroupNorm statistics here (include/slide_engine.h)
   const void *gfeat;        // gather mode (GAT kernels): point-feature table [B*16][g_ldf]; the first g_nsplit K chunks of X row
   const int *gidx;          //   (b, p, k) are read from its row b*16 + gidx[(b*16 + p)*16 + k], the rest from X (x_ld = its own ld)
   int g_ldf, g_nsplit, g_klog2;
@@ -1048,13 +1049,60 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
   // AFF: consumer-side GroupNorm affine of the four samples of this tile, fp16 [sample][scale | shift][k_pad]
   _Float16 *const aff_lds = reinterpret_cast<_Float16 *>(vec_lds + 2 * 96);
   if (AFF) {
-    for (int i = tid; i < 4 * a.k_pad; i += 256) {
-      const int sm = i / a.k_pad, k = i - sm * a.k_pad;
-      int b = (row0 >> NPXL) + sm;
-      const int nb = a.rows >> NPXL;
-      b = b < nb ? b : nb - 1;
-      aff_lds[(sm * 2 + 0) * a.k_pad + k] = (_Float16)a.in_scale[(size_t)b * a.in_bs + k];
-      aff_lds[(sm * 2 + 1) * a.k_pad + k] = (_Float16)a.in_shift[(size_t)b * a.in_bs + k];
+    const int nb = a.rows >> NPXL;
+    if (a.gn_fin) {
+      // finalise the statistics of this tile's four samples (finalize_gn_kernel's arithmetic), keep the own channel
+      // slice for the fragments, publish the full rows for the later consumers (column tile 0 only)
+      const SlideGnFin f = *a.gn_fin;
+      const int off = (int)(a.in_scale - f.scale);
+      float *const grp = reinterpret_cast<float *>(aff_lds + (size_t)4 * 2 * a.k_pad);  // [4 samples][32 groups][mean, rstd]
+      if (tid < 128) {  // one (sample, group) per thread
+        const int sm = tid >> 5, g = tid & 31;
+        int b = (row0 >> NPXL) + sm;
+        b = b < nb ? b : nb - 1;
+        float mean = 0.f, rstd = 0.f;
+        if (g < f.G) {
+          float S = 0.f, SS = 0.f;
+          for (int cc = f.gstart[g]; cc < f.gend[g]; ++cc) {
+            S += f.sum[(size_t)b * f.bs + cc];
+            SS += f.sq[(size_t)b * f.bs + cc];
+          }
+          mean = S * f.inv_count;
+          const float var = fmaxf(SS * f.inv_count - mean * mean, 0.f);
+          rstd = 1.0f / sqrtf(var + GN_EPS);
+        }
+        grp[tid * 2] = mean;
+        grp[tid * 2 + 1] = rstd;
+      }
+      __syncthreads();
+      for (int i = tid; i < 4 * f.C; i += 256) {
+        const int sm = i / f.C, c = i - sm * f.C;
+        int b = (row0 >> NPXL) + sm;
+        b = b < nb ? b : nb - 1;
+        const int g = f.gid[c];
+        float sc = 1.f, sh = 0.f;
+        if (g >= 0) {
+          sc = f.gamma[c] * grp[(sm * 32 + g) * 2 + 1];
+          sh = f.beta[c] - grp[(sm * 32 + g) * 2] * sc;
+        }
+        if (tc == 0) {
+          f.scale[(size_t)b * f.bs + c] = sc;
+          f.shift[(size_t)b * f.bs + c] = sh;
+        }
+        const int kk = c - off;
+        if (kk >= 0 && kk < a.k_pad) {
+          aff_lds[(sm * 2 + 0) * a.k_pad + kk] = (_Float16)sc;
+          aff_lds[(sm * 2 + 1) * a.k_pad + kk] = (_Float16)sh;
+        }
+      }
+    } else {
+      for (int i = tid; i < 4 * a.k_pad; i += 256) {
+        const int sm = i / a.k_pad, k = i - sm * a.k_pad;
+        int b = (row0 >> NPXL) + sm;
+        b = b < nb ? b : nb - 1;
+        aff_lds[(sm * 2 + 0) * a.k_pad + k] = (_Float16)a.in_scale[(size_t)b * a.in_bs + k];
+        aff_lds[(sm * 2 + 1) * a.k_pad + k] = (_Float16)a.in_shift[(size_t)b * a.in_bs + k];
+      }
     }
     __syncthreads();
   }
@@ -1558,7 +1606,7 @@ int launch_gemm_glds8(const GemmArgs &a, hipStream_t s) {
 
 template <int NST, bool AFF>
 int launch_gemm_small_t(const GemmArgs &a, hipStream_t s) {
-  const size_t shm = (size_t)4 * NST * 8192 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32 + (AFF ? (size_t)4 * 2 * a.k_pad * 2 : 0);
+  const size_t shm = (size_t)4 * NST * 8192 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32 + (AFF ? (size_t)4 * 2 * a.k_pad * 2 + 1024 : 0);
   const int grid = ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2);
   static bool attr_set = false;
   if (!attr_set) {
@@ -1585,6 +1633,7 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
   a.stagger = (int)(o.f[0] * 100.f);
   a.sched = (int *)o.p[7];
   a.gfeat = o.p[8]; a.gidx = (const int *)o.p[9];
+  a.gn_fin = (const SlideGnFin *)o.p[6];
   a.g_nsplit = (int)o.f[1]; a.g_ldf = (int)o.f[2]; a.g_klog2 = (int)o.f[3];
   a.rows = o.i[0]; a.x_ld = o.i[1]; a.k_pad = o.i[2]; a.n_cob = o.i[3]; a.in_bs = o.i[5];
   const int npxl = o.i[4], prec = o.i[6], cbw = o.i[7], glds = o.i[8];
@@ -1593,6 +1642,7 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
   // kernels, for A/B timing)
   if (prec == SLIDE_PREC_F16 && npxl == 4 && o.i[9] != 3 && ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2) <= 1024)
     return launch_gemm_small(a, s);
+  if (a.gn_fin) return -10;  // only the small-launch kernel finalises statistics
   if (glds) {
     if (prec != SLIDE_PREC_F16) return -7;
     // i[9]: 0 = BK 32, three stages (two workgroups / CU); 1 = BK 64 (full 128-B lines), three stages (one / CU)

@@ -37,6 +37,11 @@ class SlideEpi(ctypes.Structure):
                 ("stats_sum", ctypes.c_void_p), ("stats_sq", ctypes.c_void_p)]
 
 
+class SlideGnFin(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("sum", "sq", "gid", "gstart", "gend", "gamma", "beta", "scale", "shift")] + [
+        ("inv_count", ctypes.c_float), ("C", ctypes.c_int32), ("bs", ctypes.c_int32), ("G", ctypes.c_int32)]
+
+
 class SlideOp(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("i", ctypes.c_int32 * 11), ("f", ctypes.c_float * 4),
                 ("p", ctypes.c_void_p * 10)]
@@ -165,7 +170,7 @@ class DenoiserEngine:
         self._cvec.append((prefix, width))
         return off
 
-    def _gemm(self, X, npx_log2, segs, in_cols=None, in_affine=None, k_logical=None, gather=None):
+    def _gemm(self, X, npx_log2, segs, in_cols=None, in_affine=None, k_logical=None, gather=None, gn_fin=None):
         """X: input buffer [rows][ld].  segs: list of dicts describing consecutive output segments:
              w (O,I) bias (O) | out (tensor) out_coff | mode flags | gn=(gamma,beta) for NORM | layout (gn_layout) |
              addvec=(tensor, off, bs) | residual tensor | bcast | stats=(sum,sq tensors, coff, scale)
@@ -276,7 +281,8 @@ class DenoiserEngine:
                            f=(float(os.environ.get('SLIDE_STAGGER_US', '0')),) + gf,
                                 p=(X.data_ptr(), Wd.data_ptr(), ed.data_ptr(),
                                    None if sc is None else sc.data_ptr() + 4 * aff_off,
-                                   None if sh is None else sh.data_ptr() + 4 * aff_off, None, None,
+                                   None if sh is None else sh.data_ptr() + 4 * aff_off, None,
+                                   None if gn_fin is None else gn_fin.data_ptr(),
                                    self._sched().data_ptr() if self.persistent else None,
                                    None if gather is None else gather[0].data_ptr(),
                                    None if gather is None else gather[1].data_ptr())))
@@ -375,15 +381,28 @@ class DenoiserEngine:
             gend = np.array([phys[(gq + 1) * gs - 1] + 1 for gq in range(G)], np.int32)
             scale, shift = self.A.zeros(B, ldT), self.A.zeros(B, ldT)
             d = [self.A.put(a) for a in (gid, gstart, gend, gam, bet)]
-            self._emit(make_op(OP_FINALIZE_GN, i=(B, ldT, ldT), f=(1.0 / (gs * npx),),
-                                    p=(ssum.data_ptr(), ssq.data_ptr(), d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(),
-                                       d[3].data_ptr(), d[4].data_ptr(), scale.data_ptr(), shift.data_ptr())))
+            # (only the small-launch kernel finalises: same grid bound as run_gemm's dispatch)
+            n_cob_p = ru(gn_layout(inter)[1]) // 32
+            fuse_fin = (self.prec == 1 and self.use_glds and os.environ.get("SLIDE_FUSE_FIN", "1") != "0" and
+                        ((B * 16 + 63) // 64) * ((n_cob_p + 1) // 2) <= 1024)
+            gn_fin = None
+            if fuse_fin:  # finalised inside the per-point query GEMM below (its small-launch kernel), one launch less
+                fin = SlideGnFin()
+                for n_, t_ in zip(("sum", "sq", "gid", "gstart", "gend", "gamma", "beta", "scale", "shift"),
+                                  (ssum, ssq, d[0], d[1], d[2], d[3], d[4], scale, shift)):
+                    setattr(fin, n_, t_.data_ptr())
+                fin.inv_count, fin.C, fin.bs, fin.G = 1.0 / (gs * npx), ldT, ldT, G
+                gn_fin = self.A.put(np.frombuffer(bytes(fin), dtype=np.uint8).copy())
+            else:
+                self._emit(make_op(OP_FINALIZE_GN, i=(B, ldT, ldT), f=(1.0 / (gs * npx),),
+                                        p=(ssum.data_ptr(), ssq.data_ptr(), d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(),
+                                           d[3].data_ptr(), d[4].data_ptr(), scale.data_ptr(), shift.data_ptr())))
             lay = gn_layout(inter)
             w2 = self._w(apfx + ".weight_conv.2.weight")
             # query half, once per point: P = W2[:, :C1] . GN(relu(q))      (no bias, raw)
             P = self.A.zeros(B * 16, ru(lay[1]), dtype=self.adt)
             self._gemm(Tq, 4, [dict(w=w2[:, :C1], mode=EPI_RAW, layout=(lay[0], lay[1], 0, 1, 1), out=P)],
-                       in_affine=(scale, shift, 0, ldT))
+                       in_affine=(scale, shift, 0, ldT), gn_fin=gn_fin)
             # neighbour half: u = GN4(relu(W2[:, C1:] . GN(relu(k)) + bias + P[point]))
             u = self.A.zeros(rows, ru(lay[1]), dtype=self.adt)
             self._gemm(Tk, npx_log2, [dict(w=w2[:, C1:], bias=sd[apfx + ".weight_conv.2.bias"], mode=EPI_NORM,
