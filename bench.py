@@ -174,12 +174,14 @@ def main():
         tot /= reps
         flops = f.engine.gemm_flops  # per GEMM op, algorithmic (logical channels), whole batch
         # dominant kernel = the 256-row-sample, 128-channel-tile GEMM of the feature denoiser.  rocprofv3 name:
-        #   fp16: gemm_glds_kernel<8, 4, 3, 32, false>   fp32: gemm_kernel<0, 8, 2>
+        #   fp16: gemm_glds_kernel<8, 4, 3, 32, false, false>   fp32: gemm_kernel<0, 8, 2>
         cbw_dom = 4 if a.prec == "fp16" else 2
         def is_dom(o):
-            return (o.kind == OP_GEMM and o.i[4] == 8 and o.i[7] == cbw_dom and (a.prec == "fp32" or (o.i[8] == 1 and not o.p[3])))
+            # (not the gather-on-load instantiation of the blocks' first GEMMs, p[8]: a different kernel in the trace)
+            return (o.kind == OP_GEMM and o.i[4] == 8 and o.i[7] == cbw_dom and
+                    (a.prec == "fp32" or (o.i[8] == 1 and not o.p[3] and not o.p[8])))
         dom = [i for i in range(n) if is_dom(f.step_ops[i])]
-        kname = "gemm_glds_kernel<8, 4, 3, 32, false>" if a.prec == "fp16" else "gemm_kernel<0, 8, 2>"
+        kname = "gemm_glds_kernel<8, 4, 3, 32, false, false>" if a.prec == "fp16" else "gemm_kernel<0, 8, 2>"
         dflops = sum(flops[i] for i in dom)
         dms = sum(tot[i] for i in dom)
         ach = dflops / (dms * 1e-3) / 1e12
