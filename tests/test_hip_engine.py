@@ -202,3 +202,36 @@ def test_joint_graph_equals_separate_chains(gpu_device):
         joint.synchronize()
         assert np.array_equal(pos.state().cpu().numpy(), want_p), prec
         assert np.array_equal(feat.state().cpu().numpy(), want_f), prec
+
+
+def test_split_sampler_equals_separate_chains(gpu_device):
+    """bench.py's arrangement -- the position plan whole, the feature plan as two sub-batches, one step graph each launched
+    round-robin (`SplitJointSampler`) -- gives bit-identical states to the three samplers run one after the other: the
+    sub-batches are independent samples, only the schedule differs."""
+    from slide_amd import configs
+    from slide_amd.diffusion import FeatureSampler, JointSampler, PositionSampler, SplitJointSampler
+    _, hp_p, sd_p = _load("pos")
+    _, hp_f, sd_f = _load("feat")
+    B, n = 6, 5
+    sizes = [4, 2]
+    rs = np.random.RandomState(23)
+    xp, xf = rs.standard_normal((B, 16, 3)).astype(np.float32), rs.standard_normal((B, 16, 51)).astype(np.float32)
+    kp = rs.uniform(-0.7, 0.7, (B, 16, 3)).astype(np.float32)
+    npos = rs.standard_normal((n, B, 16, 3)).astype(np.float32)
+    nfeat = [rs.standard_normal((n, b, 16, 51)).astype(np.float32) for b in sizes]
+    lab_p, lab_f = np.zeros(B, np.int64), np.full(B, 4, np.int64)
+    fcfg = configs.feature_ddpm_config()["standard_diffusion_config"]
+    pos = PositionSampler(hp_p, sd_p, B, gpu_device, _pos_cfg(), prec="fp16", noise=npos)
+    feats = [FeatureSampler(hp_f, sd_f, b, gpu_device, fcfg, prec="fp16", noise=nz) for b, nz in zip(sizes, nfeat)]
+    lo = [0, sizes[0]]
+    want_p = pos.sample(lab_p, xp, n_steps=n).cpu().numpy()
+    want_f = [f.sample(lab_f[l:l + b], kp[l:l + b], xf[l:l + b], n_steps=n).cpu().numpy() for f, b, l in zip(feats, sizes, lo)]
+    split = SplitJointSampler([JointSampler(pos, feats[0]), JointSampler(None, feats[1])])
+    pos.begin(lab_p, xp)
+    for f, b, l in zip(feats, sizes, lo):
+        f.begin(lab_f[l:l + b], kp[l:l + b], xf[l:l + b])
+    split.advance(n)
+    split.synchronize()
+    assert np.array_equal(pos.state().cpu().numpy(), want_p)
+    for f, w in zip(feats, want_f):
+        assert np.array_equal(f.state().cpu().numpy(), w)
