@@ -95,6 +95,10 @@ def main():
     sd_f = synth_state_dict(model_spec.denoiser_param_spec(fc["pointnet_config"]))
     P = max(1, min(a.sub_batches, B))
     sizes = [B // P + (1 if i < B % P else 0) for i in range(P)]
+    if os.environ.get("SLIDE_SUB_SIZES"):  # experiment knob: explicit sub-batch sizes, e.g. 112,144
+        sizes = [int(v) for v in os.environ["SLIDE_SUB_SIZES"].split(",")]
+        assert sum(sizes) == B
+        P = len(sizes)
     # the feature plan runs as P concurrent sub-batches; the position plan (launch-bound at any size) as ONE chain over
     # the whole batch, a parallel branch of the first sub-batch's step graph
     pos = PositionSampler(pc["pointnet_config"], sd_p, B, dev, pc["diffusion_config"], prec=a.prec, seed=1000 + rank * 16)

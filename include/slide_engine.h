@@ -72,7 +72,7 @@ enum {
   SLIDE_OP_ADVANCE_T = 12,  /* p: t_dev  (t_dev[0] -= 1; t_dev[1] += 1) */
   SLIDE_OP_SYNC = 14,       /* i: from_lane, to_lane -- lane `to` waits for everything issued so far on lane `from` */
   SLIDE_OP_GROUPNORM_NCHW = 13,/* p: x, gamma, beta, y (NCHW fp32)   i: B, C, HW, G, n_norm, relu  (module-level path) */
-  SLIDE_OP_TRANSPOSE = 15   /* p: in, out (fp32)   i: B, R, C, in_ld, out_ld, in_batch_stride, out_batch_stride: out[b][c][r] = in[b][r][c] (module-level path: NCHW <-> row-major) */
+  SLIDE_OP_TRANSPOSE = 15   /* p: in, out (fp32)   i: B, R, C, in_ld, out_ld, in_batch_stride, out_batch_stride, out_is_fp16: out[b][c][r] = in[b][r][c] (module-level path: NCHW <-> row-major) */
 };
 
 /* GroupNorm finalisation folded into the first consumer (fp16 small-launch GEMM with input affine, SlideOp.p[6]):

@@ -1697,9 +1697,10 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
 
 // batched fp32 transpose through a 32x33 LDS tile (module-level path: NCHW activations <-> the GEMM's row-major
 // [pixel][channel] matrices); coalesced on both sides
+template <typename TO>
 __global__ __launch_bounds__(256) void transpose_kernel(int R, int C, int in_ld, int out_ld, long long in_bs,
                                                         long long out_bs, const float *__restrict__ in,
-                                                        float *__restrict__ out) {
+                                                        TO *__restrict__ out) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -1714,7 +1715,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(int R, int C, int in_ld,
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = c0 + ty + 8 * i, r = r0 + tx;
-    if (r < R && c < C) out[(size_t)c * out_ld + r] = tile[tx][ty + 8 * i];
+    if (r < R && c < C) out[(size_t)c * out_ld + r] = (TO)tile[tx][ty + 8 * i];
   }
 }
 
@@ -1809,9 +1810,14 @@ int run_op(const SlideOp &o, hipStream_t s) {
                          (const float *)o.p[6], (const float *)o.p[7], (const float *)o.p[8], (const float *)o.p[9]);
       break;
     case SLIDE_OP_TRANSPOSE:
-      hipLaunchKernelGGL(transpose_kernel, dim3((o.i[2] + 31) / 32, (o.i[1] + 31) / 32, o.i[0]), dim3(256), 0, s, o.i[1],
-                         o.i[2], o.i[3], o.i[4], (long long)o.i[5], (long long)o.i[6], (const float *)o.p[0],
-                         (float *)o.p[1]);
+      if (o.i[7])  // fp16 destination (module-level throughput mode)
+        hipLaunchKernelGGL(transpose_kernel<_Float16>, dim3((o.i[2] + 31) / 32, (o.i[1] + 31) / 32, o.i[0]), dim3(256), 0, s,
+                           o.i[1], o.i[2], o.i[3], o.i[4], (long long)o.i[5], (long long)o.i[6], (const float *)o.p[0],
+                           (_Float16 *)o.p[1]);
+      else
+        hipLaunchKernelGGL(transpose_kernel<float>, dim3((o.i[2] + 31) / 32, (o.i[1] + 31) / 32, o.i[0]), dim3(256), 0, s,
+                           o.i[1], o.i[2], o.i[3], o.i[4], (long long)o.i[5], (long long)o.i[6], (const float *)o.p[0],
+                           (float *)o.p[1]);
       break;
     case SLIDE_OP_GROUPNORM_NCHW:  // i: B, C, HW, G, n_norm, relu   p: x, gamma, beta, y
       hipLaunchKernelGGL(group_norm_nchw_kernel, dim3(o.i[3] + (o.i[4] < o.i[1] ? 1 : 0), o.i[0]), dim3(256), 0, s, o.i[1],

@@ -1,14 +1,17 @@
 """HIP-backed building blocks of the module-level compatibility path (`pointnet2_ops.pointnet2_modules`):
-1x1 convolutions / linears on the MFMA GEMM (exact fp32 mode) and GroupNorm, on reference-layout (NCHW) tensors.
-Inference only.  The fused, layout-optimised path for the DDPM configs is slide_amd.engine.DenoiserEngine."""
+1x1 convolutions / linears on the MFMA GEMM and GroupNorm, on reference-layout (NCHW) tensors.  Default: exact fp32 MFMA
+(the parity mode every module-level test uses).  `SLIDE_MODULE_PREC=fp16` switches the GEMM operands (weights, the
+transposed activation copy) to fp16 with fp32 accumulation and fp32 outputs -- the throughput mode of the encode / decode
+paths.  Inference only.  The fused, layout-optimised path for the DDPM configs is slide_amd.engine.DenoiserEngine."""
 import ctypes
+import os
 
 import numpy as np
 import torch
 import torch.nn as nn
 
 from ._lib import check, lib
-from .engine import EPI_RAW, OP_GEMM, SlideEpi, SlideOp, make_op, ru
+from .engine import EPI_RAW, F_OUT_F32, OP_GEMM, SlideEpi, SlideOp, make_op, ru
 
 OP_GROUPNORM_NCHW = 13
 OP_TRANSPOSE = 15
@@ -30,26 +33,31 @@ class _GemmPlan:
         O, I = weight.shape[0], int(np.prod(weight.shape[1:]))
         self.O, self.I, self.rows = O, I, rows
         self.kp, self.op_ = ru(I), ru(O)
+        self.half = os.environ.get("SLIDE_MODULE_PREC", "fp32") == "fp16"
+        adt = torch.float16 if self.half else torch.float32
         W = torch.zeros(self.op_, self.kp, device=device, dtype=torch.float32)
         W[:O, :I] = weight.detach().reshape(O, I).float()
-        self.W = W
+        self.W = W.to(adt)
         vec = torch.zeros(self.op_, device=device, dtype=torch.float32)
         if bias is not None:
             vec[:O] = bias.detach().float()
         self.vec = vec
-        self.x = torch.zeros(rows, self.kp, device=device, dtype=torch.float32)
+        self.x = torch.zeros(rows, self.kp, device=device, dtype=adt)
         self.y = torch.zeros(rows, self.op_, device=device, dtype=torch.float32)
         n_cob = self.op_ // 32
         epis = (SlideEpi * n_cob)()
         for j in range(n_cob):
             e = epis[j]
             e.mode = EPI_RAW
+            e.flags = F_OUT_F32 if self.half else 0
             e.out_ld = self.op_
             e.bias = vec.data_ptr() + 4 * 32 * j
             e.out = self.y.data_ptr() + 4 * 32 * j
         self.epi = torch.from_numpy(np.frombuffer(bytes(epis), dtype=np.uint8).copy()).to(device)
-        self.op = make_op(OP_GEMM, i=(rows, self.kp, self.kp, n_cob, 8, 0, 0, 2),
-                          p=(self.x.data_ptr(), W.data_ptr(), self.epi.data_ptr(), None, None))
+        ntr = (rows + 255) // 256
+        cbw = 4 if (self.half and n_cob >= 4 and ntr * ((n_cob + 3) // 4) >= 256) else 2
+        self.op = make_op(OP_GEMM, i=(rows, self.kp, self.kp, n_cob, 8, 0, int(self.half), cbw, int(self.half), 0),
+                          p=(self.x.data_ptr(), self.W.data_ptr(), self.epi.data_ptr(), None, None))
 
     def __call__(self, x2d):
         self.x[:, : self.I].copy_(x2d)
@@ -82,7 +90,7 @@ class HipConv1x1(nn.Module):
         if P > 1 and x.dtype == torch.float32 and x.is_contiguous() and B * C * P < 2 ** 31 and rows * plan.op_ < 2 ** 31:
             # NCHW -> [pixel][channel] and back with the LDS-tiled transpose kernel (torch's strided copies took
             # half of the decode path's time)
-            _run(make_op(OP_TRANSPOSE, i=(B, C, P, P, plan.kp, C * P, P * plan.kp), p=(x.data_ptr(), plan.x.data_ptr())))
+            _run(make_op(OP_TRANSPOSE, i=(B, C, P, P, plan.kp, C * P, P * plan.kp, int(plan.half)), p=(x.data_ptr(), plan.x.data_ptr())))
             _run(plan.op)
             out = torch.empty((B, self.out_channels) + tuple(sp), device=x.device, dtype=torch.float32)
             _run(make_op(OP_TRANSPOSE, i=(B, P, self.out_channels, plan.op_, P, P * plan.op_, self.out_channels * P),

@@ -154,6 +154,29 @@ def test_autoencoder_encode_matches_reference(gpu_device):
     assert rec.shape == (pc.shape[0], 2048, 6) and bool(torch.isfinite(rec).all())
 
 
+def test_module_path_fp16_operands(gpu_device, monkeypatch):
+    """SLIDE_MODULE_PREC=fp16 (throughput mode of the module-level path: fp16 GEMM operands, fp32 accumulate / outputs):
+    encode within 5e-3 relative L2 of the reference, FPS selections unchanged (they depend on the input coordinates only)."""
+    monkeypatch.setenv("SLIDE_MODULE_PREC", "fp16")
+    sys.path.insert(0, os.path.join(REPO, "pointnet2"))
+    from models.autoencoder import PointAutoencoder
+    g = load_golden("golden_encode.npz")
+    enc, decs = json.loads(str(g["encoder_config_json"])), json.loads(str(g["decoder_configs_json"]))
+    spec = golden_spec(g)
+    ae = PointAutoencoder(enc, decs, apply_kl_regularization=True)
+    vals = synth_state_dict([("ae." + n, s) for n, s in spec])
+    ae.load_state_dict({n: torch.from_numpy(vals["ae." + n]) for n, _ in spec}, strict=False)
+    ae = ae.to(gpu_device).eval()
+    d = gpu_device
+    pc, kp, lab = T(g["pointcloud"], d), T(g["keypoint"], d), T(g["label"], d)
+    out, l_xyz, _ = ae.encoder(pc, ts=None, label=lab)
+    assert np.array_equal(l_xyz[-1].cpu().numpy(), g["encoder_xyz_last"])
+    feat = ae.encode(pc, kp, ts=None, label=lab, sample_posterior=False).cpu().numpy()
+    ref = g["feature_at_keypoint"]
+    rel = float(np.linalg.norm(feat - ref) / np.linalg.norm(ref))
+    assert rel <= 5e-3, rel
+
+
 def test_sample_farthest_points(gpu_device):
     from oracle import ops as O
     from slide_amd import _ext
