@@ -1075,8 +1075,10 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
         grp[tid * 2 + 1] = rstd;
       }
       __syncthreads();
-      for (int i = tid; i < 4 * f.C; i += 256) {
-        const int sm = i / f.C, c = i - sm * f.C;
+      // column tile 0 publishes all C channels; the other tiles only need their own K slice [off, off + k_pad)
+      const int c_lo = tc == 0 ? 0 : off, c_n = tc == 0 ? f.C : (a.k_pad < f.C - off ? a.k_pad : f.C - off);
+      for (int i = tid; i < 4 * c_n; i += 256) {
+        const int sm = i / c_n, c = c_lo + (i - sm * c_n);
         int b = (row0 >> NPXL) + sm;
         b = b < nb ? b : nb - 1;
         const int g = f.gid[c];
