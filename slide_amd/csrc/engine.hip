@@ -1165,6 +1165,196 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
                                             vec_lds + cb * 96, nullptr);
 }
 
+// ------------------------------------------------------------------------------------------------ attention tail
+// The end of an AttentionModule (attention.py:90-95) as ONE launch: scores S = W5 . u + b5, values
+// V = ReLU(GN(Wv . mo + bv)), out[point] = sum_k softmax_k(S) * V -- instead of two GEMMs that write S and V
+// ([rows][C] each) and a third kernel that reads them back.  MFMA operands are SWAPPED with respect to gemm_glds_kernel
+// (A = X rows, B = W rows): a lane then owns ONE channel and its registers run over rows, so GroupNorm statistics
+// and the softmax over a point's K neighbours are register loops plus one exchange between the lane halves, and
+// neither S nor V ever leaves the registers.  Tile: 256 rows x 64 channels, four waves x 64 rows; K = 2^(NPXL-4)
+// neighbours per point (16 rows of a 256-row sample, 8 of a 128-row one).
+struct AttnTailArgs {
+  const void *X1, *W1, *X2, *W2;  // scores: u [rows][x1_ld] . W5 [C][k1];  values: mo [rows][x2_ld] . Wv [C][k2]
+  const float *vec;               // [bias_s | bias_v | gamma | beta], n_cob * 32 floats each
+  void *out;                      // [rows >> (NPXL - 4)][out_ld] fp16
+  int rows, x1_ld, k1, x2_ld, k2, n_cob, gs, n_norm, out_ld;
+  float inv_count;
+};
+
+__device__ __forceinline__ float other_half(float x) {  // value of lane ^ 32
+  uint32_t a = __float_as_uint(x), b = a;
+  lane32_swap(a, b);  // a = [x.lo | x.lo in the upper lanes], b = [x.hi in the lower lanes | x.hi]
+  return __uint_as_float((threadIdx.x & 32) ? a : b);
+}
+
+template <int NPXL>
+__global__ __launch_bounds__(256, 2) void attn_tail_kernel(AttnTailArgs a) {
+  using T = _Float16;
+  constexpr int CBW = 2, NST = 3, RT = TM + 64, STAGE_B = RT * 64, LPW = RT / 16 / 4;
+  constexpr int KLOG = NPXL - 4, KN = 1 << KLOG, GPB = 32 / KN;  // neighbours per point, points per 32-row block
+  constexpr int WPS = (1 << NPXL) / 64;                            // waves per sample
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int ntc = (a.n_cob + CBW - 1) / CBW;
+  const int xcd = blockIdx.x & 7, q0 = blockIdx.x >> 3;
+  const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;
+  if (tr * TM >= a.rows) return;
+  const int row0 = tr * TM, cob0 = tc * CBW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+  float *const vec_lds = reinterpret_cast<float *>(smem_raw + (size_t)NST * STAGE_B);  // [4 vectors][CBW*32]
+  for (int i = tid; i < 4 * CBW * 32; i += 256) {
+    const int which = i / (CBW * 32), c = i - which * (CBW * 32), gc = cob0 * 32 + c;
+    vec_lds[i] = gc < a.n_cob * 32 ? a.vec[(size_t)which * a.n_cob * 32 + gc] : 0.f;
+  }
+  int wrow[CBW], wkey[CBW], xrow[2], xkey[2];
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb) {
+    const int trow = TM + cb * 32 + col;
+    wrow[cb] = trow * 64; wkey[cb] = (trow >> 2) & 3;
+  }
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const int trow = wave * 64 + rb * 32 + col;
+    xrow[rb] = trow * 64; xkey[rb] = (trow >> 2) & 3;
+  }
+  // one LDS-DMA ring GEMM: acc[cb][rb] = D[row][channel] (lane: channel col of block cb; reg r: row (r&3)+8(r>>2)+4 half)
+  auto run = [&](const void *Xp, const void *Wp, int x_ld, int k_pad, f32x16 (&acc)[CBW][2]) __attribute__((always_inline)) {
+    const T *gp[LPW];
+#pragma unroll
+    for (int j = 0; j < LPW; ++j) {
+      const int trow = 16 * (j * 4 + wave) + (lane >> 2);
+      const int piece = (lane & 3) ^ ((trow >> 2) & 3);
+      if (trow < TM) {
+        int grow = row0 + trow;
+        grow = grow < a.rows ? grow : a.rows - 1;
+        gp[j] = reinterpret_cast<const T *>(Xp) + (size_t)grow * x_ld + piece * 8;
+      } else {
+        int gco = cob0 * 32 + (trow - TM);
+        gco = gco < a.n_cob * 32 ? gco : a.n_cob * 32 - 1;
+        gp[j] = reinterpret_cast<const T *>(Wp) + (size_t)gco * k_pad + piece * 8;
+      }
+    }
+    auto issue = [&](int kc, int st) {
+#pragma unroll
+      for (int j = 0; j < LPW; ++j)
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(gp[j] + kc * 32),
+                                         (__attribute__((address_space(3))) void *)(smem_raw + (size_t)st * STAGE_B +
+                                                                                    (j * 4 + wave) * 1024),
+                                         16, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < CBW; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nk = k_pad / 32;
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0)
+      if (s0 < nk) issue(s0, s0);
+    for (int kc = 0; kc < nk; ++kc) {
+      if (kc + NST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kc + NST - 1 < nk) issue(kc + NST - 1, (kc + NST - 1) % NST);
+      const unsigned char *sb = smem_raw + (size_t)(kc % NST) * STAGE_B;
+#pragma unroll
+      for (int st2 = 0; st2 < 2; ++st2) {
+        f16x8 wf[CBW], xf[2];
+        const int piece = st2 * 2 + half;
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb) wf[cb] = *reinterpret_cast<const f16x8 *>(sb + wrow[cb] + ((piece ^ wkey[cb]) << 4));
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) xf[rb] = *reinterpret_cast<const f16x8 *>(sb + xrow[rb] + ((piece ^ xkey[rb]) << 4));
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb)
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[rb], wf[cb], acc[cb][rb], 0, 0, 0);  // rows x channels
+      }
+    }
+    __syncthreads();  // ring drained and free (also orders the staged vectors before their first use)
+  };
+  f32x16 sacc[CBW][2], vacc[CBW][2];
+  run(a.X1, a.W1, a.x1_ld, a.k1, sacc);
+  run(a.X2, a.W2, a.x2_ld, a.k2, vacc);
+
+  // ---- values: bias, GroupNorm over the sample (rows of WPS waves x the gs adjacent channel lanes), ReLU
+  float *const red = reinterpret_cast<float *>(smem_raw);  // [wave][cb][32 channels][sum, sumsq]
+  const float *b_s = vec_lds, *b_v = vec_lds + CBW * 32, *gam = vec_lds + 2 * CBW * 32, *bet = vec_lds + 3 * CBW * 32;
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb) {
+    const float bv = b_v[cb * 32 + col];
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float x = vacc[cb][rb][r] + bv;
+        vacc[cb][rb][r] = x;
+        s += x;
+        ss = fmaf(x, x, ss);
+      }
+    s += other_half(s);
+    ss += other_half(ss);
+    if (half == 0) *reinterpret_cast<f32x2 *>(red + ((wave * CBW + cb) * 32 + col) * 2) = f32x2{s, ss};
+  }
+  __syncthreads();
+  const int w0 = (wave / WPS) * WPS;
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb) {
+    f32x2 t = {0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < WPS; ++w) t += *reinterpret_cast<const f32x2 *>(red + (((w0 + w) * CBW + cb) * 32 + col) * 2);
+    float s = t[0], ss = t[1];
+    // the gs channels of a group sit in gs adjacent lanes (physical GroupNorm layout: power-of-two runs)
+    if (a.gs >= 2) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1, 0xF, 0xF, true));
+                     ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0xB1, 0xF, 0xF, true)); }
+    if (a.gs >= 4) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E, 0xF, 0xF, true));
+                     ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x4E, 0xF, 0xF, true)); }
+    if (a.gs >= 8) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x141, 0xF, 0xF, true));
+                     ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x141, 0xF, 0xF, true)); }
+    if (a.gs >= 16) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x140, 0xF, 0xF, true));
+                      ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x140, 0xF, 0xF, true)); }
+    if (a.gs >= 32) { s += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s), 0x401F));
+                      ss += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(ss), 0x401F)); }
+    const float mean = s * a.inv_count;
+    const float var = fmaxf(ss * a.inv_count - mean * mean, 0.f);
+    float g = gam[cb * 32 + col] * __builtin_amdgcn_rsqf(var + GN_EPS);
+    float bt = bet[cb * 32 + col] - mean * g;
+    if ((cob0 + cb) * 32 + col >= a.n_norm) { g = 1.f; bt = 0.f; }
+    const float bs = b_s[cb * 32 + col];
+    // ---- softmax over the K neighbour rows of every point, weighted sum of the values, one row out per point
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int pg = 0; pg < GPB; ++pg) {
+        // rows of point pg inside the 32-row block: 16 -> regs 8pg .. 8pg+7 (both halves); 8 -> regs 4pg .. 4pg+3
+        constexpr int RPG = 16 / GPB;
+        float sc[RPG], vv[RPG];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < RPG; ++j) {
+          sc[j] = sacc[cb][rb][pg * RPG + j] + bs;
+          vv[j] = fmaxf(fmaf(vacc[cb][rb][pg * RPG + j], g, bt), 0.f);
+          m = fmaxf(m, sc[j]);
+        }
+        m = fmaxf(m, other_half(m));
+        float den = 0.f, num = 0.f;
+#pragma unroll
+        for (int j = 0; j < RPG; ++j) {
+          const float e = __expf(sc[j] - m);
+          den += e;
+          num = fmaf(e, vv[j], num);
+        }
+        den += other_half(den);
+        num += other_half(num);
+        const int rbase = row0 + wave * 64 + rb * 32 + pg * KN;
+        if (half == 0 && rbase < a.rows && cob0 + cb < a.n_cob)
+          reinterpret_cast<T *>(a.out)[(size_t)(rbase >> KLOG) * a.out_ld + (cob0 + cb) * 32 + col] = (T)(num / den);
+      }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ points
 __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
 #pragma clang fp contract(off)
@@ -1721,6 +1911,29 @@ __global__ __launch_bounds__(256) void transpose_kernel(int R, int C, int in_ld,
   }
 }
 
+int run_attn_tail(const SlideOp &o, hipStream_t s) {
+  AttnTailArgs a;
+  a.X1 = o.p[0]; a.W1 = o.p[1]; a.X2 = o.p[2]; a.W2 = o.p[3]; a.out = o.p[4]; a.vec = (const float *)o.p[5];
+  a.rows = o.i[0]; a.x1_ld = o.i[1]; a.k1 = o.i[2]; a.x2_ld = o.i[3]; a.k2 = o.i[4]; a.n_cob = o.i[5];
+  a.gs = o.i[7]; a.n_norm = o.i[8]; a.out_ld = o.i[9];
+  a.inv_count = o.f[0];
+  const int npxl = o.i[6];
+  if (a.k1 % 32 || a.k2 % 32 || a.rows <= 0 || a.n_cob <= 0) return -3;
+  const size_t shm = (size_t)3 * (TM + 64) * 64 + 4 * 2 * 32 * 4 + 64;
+  const int ntc = (a.n_cob + 1) / 2, ntr = (a.rows + TM - 1) / TM;
+  const int grid = ((ntr + 7) / 8) * 8 * ntc;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_tail_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_tail_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr_set = true;
+  }
+  if (npxl == 8) hipLaunchKernelGGL(attn_tail_kernel<8>, dim3(grid), dim3(256), shm, s, a);
+  else if (npxl == 7) hipLaunchKernelGGL(attn_tail_kernel<7>, dim3(grid), dim3(256), shm, s, a);
+  else return -4;
+  return (int)hipGetLastError();
+}
+
 int run_op(const SlideOp &o, hipStream_t s) {
   switch (o.kind) {
     case SLIDE_OP_GEMM:
@@ -1811,6 +2024,8 @@ int run_op(const SlideOp &o, hipStream_t s) {
                          (const float *)o.p[2], (int *)o.p[3], (const float *)o.p[4], (const float *)o.p[5],
                          (const float *)o.p[6], (const float *)o.p[7], (const float *)o.p[8], (const float *)o.p[9]);
       break;
+    case SLIDE_OP_ATTN_TAIL:
+      return run_attn_tail(o, s);
     case SLIDE_OP_TRANSPOSE:
       if (o.i[7])  // fp16 destination (module-level throughput mode)
         hipLaunchKernelGGL(transpose_kernel<_Float16>, dim3((o.i[2] + 31) / 32, (o.i[1] + 31) / 32, o.i[0]), dim3(256), 0, s,

@@ -23,6 +23,7 @@ PREC = {"fp32": 0, "fp16": 1}
 (OP_GEMM, OP_PREP_POINTS, OP_ASSEMBLE_SA, OP_ASSEMBLE_FP, OP_FINALIZE_GN, OP_ATTN_COMBINE, OP_COPY_COLS, OP_TEMB,
  OP_COND, OP_UPDATE_POS, OP_UPDATE_FEAT, OP_ADVANCE_T) = range(1, 13)
 OP_SYNC = 14
+OP_ATTN_TAIL = 16
 
 
 class SlideEpi(ctypes.Structure):
@@ -410,6 +411,11 @@ class DenoiserEngine:
                                            gn=(sd[apfx + ".weight_conv.4.group_norm.weight"],
                                                sd[apfx + ".weight_conv.4.group_norm.bias"]))],
                        in_affine=(scale, shift, C1p, ldT))
+            vlay = gn_layout(cout)
+            if (self.prec == 1 and self.use_glds and os.environ.get("SLIDE_ATTN_TAIL", "1") != "0" and
+                    np.array_equal(vlay[0], np.arange(cout))):
+                self._lane = 0
+                return ("fused", u, lay)  # scores are computed inside the fused attention tail (finish)
             S = self._buf(rows, cout)
             self._gemm(u, npx_log2, [dict(w=self._w(apfx + ".weight_conv.5.weight"), bias=sd[apfx + ".weight_conv.5.bias"],
                                           mode=EPI_RAW, out=S)], in_cols=lay[0])
@@ -417,6 +423,31 @@ class DenoiserEngine:
             return S
 
         def finish(S):
+            if isinstance(S, tuple):  # fused tail: scores GEMM + values GEMM + softmax-weighted sum in one launch
+                _, u, lay = S
+                vlay = gn_layout(cout)
+                Cp = ru(cout)
+                w5 = np.zeros((Cp, u.shape[1]), np.float32)
+                w5[np.ix_(np.arange(cout), lay[0])] = self._w(apfx + ".weight_conv.5.weight")
+                wv_l = self._w(apfx + ".feat_out_conv.0.weight")
+                wv = np.zeros((Cp, mo.shape[1]), np.float32)
+                wv[:cout, :wv_l.shape[1]] = wv_l
+                vec = np.zeros((4, Cp), np.float32)
+                vec[0, :cout] = sd[apfx + ".weight_conv.5.bias"]
+                vec[1, :cout] = sd[apfx + ".feat_out_conv.0.bias"]
+                gam = sd[apfx + ".feat_out_conv.1.group_norm.weight"]
+                vec[2, :gam.shape[0]] = gam
+                vec[3, :gam.shape[0]] = sd[apfx + ".feat_out_conv.1.group_norm.bias"]
+                d = [self.A.put(w5, torch.float16), self.A.put(wv, torch.float16), self.A.put(vec)]
+                assert out.dtype == self.adt and u.dtype == self.adt and mo.dtype == self.adt
+                self._sync(1, 0)
+                self.flops += 2 * rows * (w5.size + wv.size)
+                self._emit(make_op(OP_ATTN_TAIL, i=(rows, u.shape[1], u.shape[1], mo.shape[1], mo.shape[1], Cp // 32, npx_log2,
+                                                    vlay[3], vlay[2], out.shape[1]),
+                                        f=(1.0 / (vlay[4] * npx),),
+                                        p=(u.data_ptr(), d[0].data_ptr(), mo.data_ptr(), d[1].data_ptr(), out.data_ptr(),
+                                           d[2].data_ptr())))
+                return
             # lane 0 (value branch), then the join
             V = self._buf(rows, cout)
             self._gemm(mo, npx_log2, [dict(w=self._w(apfx + ".feat_out_conv.0.weight"), bias=sd[apfx + ".feat_out_conv.0.bias"],
