@@ -176,7 +176,7 @@ def main():
                 check(L.slide_run_ops_timed(f.step_ops, n, ctypes.c_void_p(f.stream.cuda_stream), ms), "run_ops_timed")
                 tot += np.array(list(ms))
         tot /= reps
-        flops = f.engine.gemm_flops  # per GEMM op, algorithmic (logical channels), whole batch
+        flops = f.gemm_flops  # per GEMM op of the step plan, algorithmic (logical channels), whole sub-batch
         # dominant kernel = the 256-row-sample, 128-channel-tile GEMM of the feature denoiser.  rocprofv3 name:
         #   fp16: gemm_glds_kernel<8, 4, 3, 32, false, false>   fp32: gemm_kernel<0, 8, 2>
         cbw_dom = 4 if a.prec == "fp16" else 2

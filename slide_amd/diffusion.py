@@ -75,7 +75,11 @@ class _GraphedSampler:
         e = self.engine
         hoisted = set(e.xyz_copy_idx) if fixed_xyz else set()
         drop = hoisted | {e.eps_copy_idx}
-        ops = [o for i, o in enumerate(e.ops) if i not in drop]
+        kept = [i for i in range(len(e.ops)) if i not in drop]
+        ops = [e.ops[i] for i in kept]
+        # per-launch accounting of the engine, re-keyed by position in the step plan
+        self.gemm_flops = {j: e.gemm_flops[i] for j, i in enumerate(kept) if i in e.gemm_flops}
+        self.gemm_bytes = {j: e.gemm_bytes[i] for j, i in enumerate(kept) if i in e.gemm_bytes}
         ops += [update_op]  # the update kernel's last block also advances the device-side timestep (t -= 1, step += 1)
         self.step_ops = (SlideOp * len(ops))(*ops)
         self.n_launches = len(ops)

@@ -26,7 +26,7 @@ else:
                         c["diffusion_config"], prec=a.prec)
     s.begin(np.zeros(B, np.int64), rs.standard_normal((B, 16, 3)).astype(np.float32))
 n = len(s.step_ops); ms = (ctypes.c_float * n)(); tot = np.zeros(n)
-names = {1: "GEMM", 2: "PREP", 3: "ASM_SA", 4: "ASM_FP", 5: "FIN_GN", 6: "ATTN", 7: "COPY", 8: "TEMB", 9: "COND", 10: "UPD_P", 11: "UPD_F", 12: "ADV_T"}
+names = {16: "ATTN_TAIL", 1: "GEMM", 2: "PREP", 3: "ASM_SA", 4: "ASM_FP", 5: "FIN_GN", 6: "ATTN", 7: "COPY", 8: "TEMB", 9: "COND", 10: "UPD_P", 11: "UPD_F", 12: "ADV_T"}
 with torch.cuda.stream(s.stream):
     for r in range(a.reps + 1):
         check(lib().slide_run_ops_timed(s.step_ops, n, ctypes.c_void_p(s.stream.cuda_stream), ms), "timed")
@@ -36,8 +36,8 @@ print("%3s %-7s %8s %7s %6s %6s %6s %8s %8s %8s %8s %8s" % ("#", "kind", "us", "
 for i in range(n):
     o = s.step_ops[i]
     if o.kind == 1:
-        fl = s.engine.gemm_flops[i]
-        rd, wr = s.engine.gemm_bytes[i]
+        fl = s.gemm_flops[i]
+        rd, wr = s.gemm_bytes[i]
         print("%3d %-7s %8.1f %7d %6d %6d %6d %8.2f %8.1f %8.1f %8.1f %8.0f" % (i, "GEMM", tot[i] * 1e3, o.i[0], o.i[2], o.i[3] * 32, 1 << o.i[4], fl / 1e9, fl / (tot[i] * 1e-3) / 1e12, rd / 1e6, wr / 1e6, (rd + wr) / (tot[i] * 1e-3) / 1e9))
     else:
         print("%3d %-7s %8.1f" % (i, names.get(o.kind, "?"), tot[i] * 1e3))
