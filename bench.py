@@ -76,7 +76,7 @@ def main():
     from slide_amd import configs, model_spec
     from slide_amd._lib import check, lib
     from slide_amd.diffusion import FeatureSampler, JointSampler, PositionSampler, SplitJointSampler
-    from slide_amd.engine import OP_GEMM
+    from slide_amd.engine import OP_ATTN_TAIL, OP_GEMM
     from slide_amd.synth import synth_keypoints, synth_state_dict
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -176,19 +176,35 @@ def main():
                 check(L.slide_run_ops_timed(f.step_ops, n, ctypes.c_void_p(f.stream.cuda_stream), ms), "run_ops_timed")
                 tot += np.array(list(ms))
         tot /= reps
-        flops = f.gemm_flops  # per GEMM op of the step plan, algorithmic (logical channels), whole sub-batch
-        # dominant kernel = the 256-row-sample, 128-channel-tile GEMM of the feature denoiser.  rocprofv3 name:
-        #   fp16: gemm_glds_kernel<8, 4, 3, 32, false, false>   fp32: gemm_kernel<0, 8, 2>
-        cbw_dom = 4 if a.prec == "fp16" else 2
-        def is_dom(o):
-            # (not the gather-on-load instantiation of the blocks' first GEMMs, p[8]: a different kernel in the trace)
-            return (o.kind == OP_GEMM and o.i[4] == 8 and o.i[7] == cbw_dom and
-                    (a.prec == "fp32" or (o.i[8] == 1 and not o.p[3] and not o.p[8])))
-        dom = [i for i in range(n) if is_dom(f.step_ops[i])]
-        kname = "gemm_glds_kernel<8, 4, 3, 32, false, false>" if a.prec == "fp16" else "gemm_kernel<0, 8, 2>"
-        dflops = sum(flops[i] for i in dom)
-        dms = sum(tot[i] for i in dom)
+        flops = f.gemm_flops  # per MFMA launch of the step plan, algorithmic (logical channels), whole sub-batch
+
+        def kernel_of(o):
+            """rocprofv3 name of the kernel run_gemm / run_attn_tail (engine.hip) launches for this op (default knobs)"""
+            b = lambda v: "true" if v else "false"
+            if o.kind == OP_ATTN_TAIL:
+                return "attn_tail_kernel<%d>" % o.i[6]
+            if o.kind != OP_GEMM:
+                return None
+            rows, n_cob, npxl, cbw = o.i[0], o.i[3], o.i[4], o.i[7]
+            grid = ((rows + 63) // 64) * ((n_cob + 1) // 2)
+            if a.prec == "fp16" and npxl == 4 and grid <= 1024:
+                return "gemm_small_kernel<%d, %s>" % (3 if grid <= 256 else 2, b(o.p[3]))
+            if a.prec == "fp32" or not o.i[8]:
+                return "gemm_kernel<%d, %d, %d>" % (0 if a.prec == "fp32" else 1, npxl, cbw)
+            return "gemm_glds_kernel<%d, %d, 3, 32, %s, %s>" % (npxl, cbw, b(o.p[3]), b(o.p[8]))
+
+        # dominant kernel = the MFMA kernel with the largest share of the feature denoiser's step time, measured here
+        by_k = {}
+        for i in range(n):
+            k = kernel_of(f.step_ops[i])
+            if k is not None and i in flops:
+                e = by_k.setdefault(k, [0.0, 0.0, 0])
+                e[0] += tot[i]; e[1] += flops[i]; e[2] += 1
+        kname = max(by_k, key=lambda k: by_k[k][0])
+        dms, dflops, dn = by_k[kname]
         ach = dflops / (dms * 1e-3) / 1e12
+        mfma_ms = sum(e[0] for e in by_k.values())
+        mfma_fl = sum(e[1] for e in by_k.values())
         traffic, tsrc = None, None
         pj = os.path.join(REPO, "profiles", "hbm_pmc_latest.json")  # written by tools/rocprof_summarize.py from PMC passes
         if os.path.exists(pj):
@@ -198,11 +214,16 @@ def main():
                 tsrc = pm["source"]
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.prec], "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_TFLOPS[a.prec], 4), "traffic": traffic, "traffic_source": tsrc,
-                           "kernel": "%s (%s MFMA, 256-row samples x 128-channel tiles; feature denoiser: %d launches/step, "
-                                     "avg %.1f us)" % (kname, a.prec, len(dom), 1e3 * dms / max(len(dom), 1)),
-                           "flops_per_launch_avg": dflops / max(len(dom), 1),
+                           "kernel": "%s (%s MFMA; feature denoiser, %d samples/launch: %d launches/step, avg %.1f us, "
+                                     "%.1f%% of the step's kernel time)" % (kname, a.prec, sizes[0], dn, 1e3 * dms / dn,
+                                                                          100 * dms / tot.sum()),
+                           "flops_per_launch_avg": dflops / dn,
                            "step_ms_eager_sum": round(float(tot.sum()), 4),
-                           "gemm_ms_per_step_all": round(float(sum(tot[i] for i in range(n) if f.step_ops[i].kind == OP_GEMM)), 4)}
+                           "mfma_kernels": {k: {"launches": e[2], "ms": round(e[0], 4),
+                                                "tflops": round(e[1] / (e[0] * 1e-3) / 1e12, 1)}
+                                            for k, e in sorted(by_k.items(), key=lambda kv: -kv[1][0])},
+                           "mfma_all": {"ms": round(float(mfma_ms), 4),
+                                        "tflops": round(float(mfma_fl / (mfma_ms * 1e-3) / 1e12), 1)}}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

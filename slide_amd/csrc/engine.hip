@@ -1724,9 +1724,12 @@ __global__ __launch_bounds__(256) void update_feat_kernel(int npts, int C, int k
                                                           const float *__restrict__ c1, const float *__restrict__ c2,
                                                           const float *__restrict__ stdv) {
 #pragma clang fp contract(off)
-  const int e = blockIdx.x * 256 + threadIdx.x;
   const int t = t_dev[0], step = t_dev[1];
-  update_feat_element(e, npts, C, kdim, eps_ld, clamp, seed_lo, seed_hi, x, eps, noise, t, step, keypoint, rc, rm1, c1, c2, stdv);
+  // four elements per thread: a quarter of the blocks queue on the completion counter
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    update_feat_element(blockIdx.x * 1024 + j * 256 + threadIdx.x, npts, C, kdim, eps_ld, clamp, seed_lo, seed_hi, x, eps, noise,
+                        t, step, keypoint, rc, rm1, c1, c2, stdv);
   advance_t_last_block(t_dev, t, step);
 }
 
@@ -2019,7 +2022,7 @@ int run_op(const SlideOp &o, hipStream_t s) {
                          (int *)o.p[3], (const float *)o.p[4], (const float *)o.p[5], (const float *)o.p[6]);
       break;
     case SLIDE_OP_UPDATE_FEAT:
-      hipLaunchKernelGGL(update_feat_kernel, dim3((o.i[0] * o.i[1] + 255) / 256), dim3(256), 0, s, o.i[0], o.i[1],
+      hipLaunchKernelGGL(update_feat_kernel, dim3((o.i[0] * o.i[1] + 1023) / 1024), dim3(256), 0, s, o.i[0], o.i[1],
                          o.i[2], o.i[5], o.f[0], (uint32_t)o.i[3], (uint32_t)o.i[4], (float *)o.p[0], (const float *)o.p[1],
                          (const float *)o.p[2], (int *)o.p[3], (const float *)o.p[4], (const float *)o.p[5],
                          (const float *)o.p[6], (const float *)o.p[7], (const float *)o.p[8], (const float *)o.p[9]);

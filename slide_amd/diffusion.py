@@ -70,8 +70,9 @@ class _GraphedSampler:
 
     def _finish_plan(self, update_op, fixed_xyz=False):
         """step plan = the denoiser plan minus its output compaction (the update reads the padded rows) and, when the
-        coordinates are a fixed condition (feature DDPM: key points), minus the copies of the coordinate columns, which
-        then run once per batch in begin() -- then the update and the device-side t -= 1"""
+        coordinates are a fixed condition (feature DDPM: key points), minus the launches that read nothing but the
+        coordinates (copies of the coordinate columns, the coordinate-only tails of the grouped inputs), which then run
+        once per batch in begin() -- then the update and the device-side t -= 1"""
         e = self.engine
         hoisted = set(e.xyz_copy_idx) if fixed_xyz else set()
         drop = hoisted | {e.eps_copy_idx}
@@ -87,7 +88,9 @@ class _GraphedSampler:
         self.begin_ops = None
         if hoisted:
             from .engine import OP_PREP_POINTS
-            b_ops = [o for i, o in enumerate(e.ops) if o.kind == OP_PREP_POINTS or i in hoisted]
+            b_ops = [SlideOp.from_buffer_copy(bytes(o)) for i, o in enumerate(e.ops) if o.kind == OP_PREP_POINTS or i in hoisted]
+            for o in b_ops:
+                o.i[10] = 0  # one lane: the plan's fork / join launches are not part of this list
             self.begin_ops = (SlideOp * len(b_ops))(*b_ops)
         if self.device.type == "cuda":
             e.prepare()

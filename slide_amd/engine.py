@@ -442,6 +442,7 @@ class DenoiserEngine:
                 assert out.dtype == self.adt and u.dtype == self.adt and mo.dtype == self.adt
                 self._sync(1, 0)
                 self.flops += 2 * rows * (w5.size + wv.size)
+                self.gemm_flops[len(self.ops)] = 2 * rows * cout * (len(lay[0]) + wv_l.shape[1])  # logical channels
                 self._emit(make_op(OP_ATTN_TAIL, i=(rows, u.shape[1], u.shape[1], mo.shape[1], mo.shape[1], Cp // 32, npx_log2,
                                                     vlay[3], vlay[2], out.shape[1]),
                                         f=(1.0 / (vlay[4] * npx),),
@@ -475,6 +476,8 @@ class DenoiserEngine:
         ptrs = (self.xyz.data_ptr(), feat_in.data_ptr(), self.kidx.data_ptr())
         if kind == OP_ASSEMBLE_FP:
             ptrs += (self.kd2.data_ptr(),)
+        if nsplit and c_begin == C:  # only coordinate channels left: loop-invariant when the coordinates are a fixed condition
+            self.xyz_copy_idx.append(len(self.ops))
         self._emit(make_op(kind, i=(B, C, feat_in.shape[1], ldg, K, self.prec, c_begin, ldg - c_begin), p=ptrs + (g.data_ptr(),)))
         return g, ((feat_in, self.kidx, K, nsplit) if nsplit else None), rows
 
@@ -518,14 +521,18 @@ class DenoiserEngine:
         Z = self._buf(B * 16, zin)
         (scores, finish), cout = self._attention(ap, 7, K, g, U, mo, first, res, Z, None, gather=gather)
         S = scores()
-        self._mlp_tail(m1, 7, h1, self.cvec, r, mo)
-        finish(S)
+        # skip features and coordinates: columns of Z the attention output does not touch -- on the score lane, beside
+        # the value branch (joined by finish)
         es = Z.element_size()
+        self._lane = 1
         self._emit(make_op(OP_COPY_COLS, i=(B * 16, CU, U.shape[1], Z.shape[1], int(self.prec == 1), int(self.prec == 1)),
                                 p=(U.data_ptr(), Z.data_ptr() + es * c_last)))
         self.xyz_copy_idx.append(len(self.ops))  # loop-invariant when the coordinates are a fixed condition
         self._emit(make_op(OP_COPY_COLS, i=(B * 16, 3, 3, Z.shape[1], 0, int(self.prec == 1)),
                                 p=(self.xyz.data_ptr(), Z.data_ptr() + es * (c_last + CU))))
+        self._lane = 0
+        self._mlp_tail(m1, 7, h1, self.cvec, r, mo)
+        finish(S)
         n1 = sd[m2 + ".first_mlp.0.weight"].shape[0]
         n2 = sd[m2 + ".res_connect.weight"].shape[0]
         hz, rz = self._buf(B * 16, n1), self._buf(B * 16, n2)
