@@ -226,9 +226,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
         for (int rb = 0; rb < RB; ++rb) {
           const int row = row0 + wave * 64 + rb * 32 + col;
           if (row < a.rows) {
+            // shift >= 0: the row's point (row >> shift).  shift < 0: the row's NEIGHBOUR point, looked up in the sorted
+            // neighbour table (K = 2^-shift): per-point partial products of a block's first layer, gathered
+            size_t prow = (size_t)(row >> e_pre_shift);
+            if (e_pre_shift < 0) {
+              const int kl = -e_pre_shift, smp = row >> NPXL, pxl = row & (NPX - 1);
+              prow = (size_t)(smp * 16 + a.gidx[(smp * 16 + (pxl >> kl)) * 16 + (pxl & ((1 << kl) - 1))]);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const float4 u = gload4(pre + (size_t)(row >> e_pre_shift) * e_pre_ld + 8 * q + 4 * half);
+              const float4 u = gload4(pre + prow * e_pre_ld + 8 * q + 4 * half);
               v[rb][2 * q] += f32x2{u.x, u.y};
               v[rb][2 * q + 1] += f32x2{u.z, u.w};
             }
@@ -945,7 +952,12 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
   }
   const int my_tiles = ((ntr - xcd + 7) / 8) * ntc;  // row tiles tr = xcd, xcd + 8, ...
   volatile int *const s_tile = reinterpret_cast<volatile int *>(smem_raw + a.shm_bytes - 16);
-  if (a.stagger && threadIdx.x < 64) {
+  // a.stagger < 0: STATIC persistent schedule -- workgroup l of an XCD takes tiles l, l + n, l + 2n, ... (no counter):
+  // the store drain and the relaunch of a workgroup are overlapped by its next tile's prologue
+  const bool fixed = a.stagger < 0;
+  int next = blockIdx.x >> 3;
+  const int step = gridDim.x >> 3;
+  if (a.stagger > 0 && threadIdx.x < 64) {
     const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_ID.WAVE_ID
     if (slot & 1) {
       const unsigned long long t0 = wall_clock64();
@@ -953,9 +965,13 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
     }
   }
   for (;;) {
-    if (threadIdx.x == 0) *s_tile = atomicAdd(&a.sched[xcd], 1);
-    __syncthreads();
-    const int t = __builtin_amdgcn_readfirstlane(*s_tile);
+    int t = next;
+    next += step;
+    if (!fixed) {
+      if (threadIdx.x == 0) *s_tile = atomicAdd(&a.sched[xcd], 1);
+      __syncthreads();
+      t = __builtin_amdgcn_readfirstlane(*s_tile);
+    }
     if (t >= my_tiles) break;
 #ifdef SLIDE_TIMELINE
     GemmArgs a2 = a;  // stamps indexed by tile instead of by workgroup
@@ -966,7 +982,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
 #endif
     __syncthreads();  // the epilogue's LDS reads are done before the next tile's tables / DMAs / s_tile land
   }
-  if (threadIdx.x == 0 && atomicAdd(&a.sched[8], 1) == (int)gridDim.x - 1) {
+  if (!fixed && threadIdx.x == 0 && atomicAdd(&a.sched[8], 1) == (int)gridDim.x - 1) {
 #pragma unroll
     for (int x = 0; x < 9; ++x) a.sched[x] = 0;
   }

@@ -171,7 +171,8 @@ class DenoiserEngine:
         self._cvec.append((prefix, width))
         return off
 
-    def _gemm(self, X, npx_log2, segs, in_cols=None, in_affine=None, k_logical=None, gather=None, gn_fin=None):
+    def _gemm(self, X, npx_log2, segs, in_cols=None, in_affine=None, k_logical=None, gather=None, gn_fin=None,
+              pre_gather=None):
         """X: input buffer [rows][ld].  segs: list of dicts describing consecutive output segments:
              w (O,I) bias (O) | out (tensor) out_coff | mode flags | gn=(gamma,beta) for NORM | layout (gn_layout) |
              addvec=(tensor, off, bs) | residual tensor | bcast | stats=(sum,sq tensors, coff, scale)
@@ -247,9 +248,12 @@ class DenoiserEngine:
                     e.residual = r.data_ptr() + r.element_size() * (32 * j)
                     e.res_ld = r.shape[1]
                 if sg.get("pre_add") is not None:
-                    pa, shift = sg["pre_add"]
-                    assert pa.shape[0] == rows >> shift and pa.shape[1] >= Opad and pa.dtype == self.adt
-                    e.pre_add = pa.data_ptr() + pa.element_size() * (32 * j)
+                    pa, shift = sg["pre_add"][:2]
+                    pcoff = sg["pre_add"][2] if len(sg["pre_add"]) > 2 else 0
+                    # shift < 0: row of the NEIGHBOUR point (K = 2^-shift), through the table passed as pre_gather
+                    assert pa.shape[0] == (rows >> shift if shift >= 0 else rows >> npx_log2 << 4), (pa.shape, rows, shift)
+                    assert (shift >= 0 or pre_gather is not None) and pa.shape[1] >= pcoff + Opad and pa.dtype == self.adt
+                    e.pre_add = pa.data_ptr() + pa.element_size() * (pcoff + 32 * j)
                     e.pre_add_ld = pa.shape[1]
                     e.pre_add_shift = shift
                 if sg.get("stats") is not None:
@@ -274,19 +278,22 @@ class DenoiserEngine:
         self.gemm_flops[len(self.ops)] = 2 * rows * sum(int(s["w"].size) for s in segs)
         esz = X.element_size()
         rd = rows * ld * esz + W.size * esz + sum(rows * v[2] * esz for v in vec_list if v[1].get("residual") is not None)
+        rd += sum((rows >> max(v[1]["pre_add"][1], 0) if v[1]["pre_add"][1] >= 0 else rows >> npx_log2 << 4) * v[2] * esz
+                  for v in vec_list if v[1].get("pre_add") is not None)  # per-point tables (unique rows)
         wr = sum(rows * v[2] * v[1]["out"].element_size() for v in vec_list)
         self.gemm_bytes[len(self.ops)] = (rd, wr)  # algorithmic HBM bytes (read, written) of this launch
         glds = int(self.use_glds and self.prec == 1 and (sc is None or npx_log2 >= 7))
         gf = (0.0, 0.0, 0.0) if gather is None else (float(gather[3]), float(gather[0].shape[1]), float({8: 3, 16: 4}[gather[2]]))
         self._emit(make_op(OP_GEMM, i=(rows, x_ld, ld, n_cob, npx_log2, in_bs, self.prec, cbw, glds, self.glds_nst),
-                           f=(float(os.environ.get('SLIDE_STAGGER_US', '0')),) + gf,
+                           f=(-1.0 if self.persistent == 2 else float(os.environ.get('SLIDE_STAGGER_US', '0')),) + gf,
                                 p=(X.data_ptr(), Wd.data_ptr(), ed.data_ptr(),
                                    None if sc is None else sc.data_ptr() + 4 * aff_off,
                                    None if sh is None else sh.data_ptr() + 4 * aff_off, None,
                                    None if gn_fin is None else gn_fin.data_ptr(),
                                    self._sched().data_ptr() if self.persistent else None,
                                    None if gather is None else gather[0].data_ptr(),
-                                   None if gather is None else gather[1].data_ptr())))
+                                   (None if pre_gather is None else pre_gather.data_ptr()) if gather is None
+                                   else gather[1].data_ptr())))
         self.flops += 2 * rows * sum(int(s["w"].size) for s in segs)
 
     # ------------------------------------------------------------------ blocks
@@ -362,7 +369,36 @@ class DenoiserEngine:
         self._gemm(q_in, 4, [qseg])
         self._lane = 0
         # shared-input GEMM: [first_mlp | res_connect | grouped_feat_conv]
-        self._gemm(g, npx_log2, [mlp_first, mlp_res, kseg], gather=gather)
+        if gather is not None and gather[3] * 32 >= int(os.environ.get("SLIDE_SPLIT_FIRST", "1000000")):
+            # (opt-in, SLIDE_SPLIT_FIRST=<min feature channels>: measured neutral to -1.5 % on the feature plan -- the
+            # 256-row launch is bound by its epilogue, not by its K loop, and the per-point GEMM is one more launch)
+            # The layer is linear in its input and the leading Cf input channels of row (point, neighbour) are the
+            # NEIGHBOUR's feature row, the same for every query point: their products are evaluated once per point
+            # (a 16-row GEMM over the feature table, 1/K of the MACs) and enter the per-neighbour GEMM -- now over the
+            # coordinate channels only -- as a gathered pre-activation term.
+            tab, kidx, _, nsplit = gather
+            Cf = nsplit * 32
+            segs, ysegs, off = [], [], 0
+            for sg in (mlp_first, mlp_res, kseg):
+                lay = sg.get("layout")
+                Op = ru(sg["w"].shape[0] if lay is None else lay[1])
+                segs.append((sg, off))
+                off += Op
+            Y = self._buf(B * 16, off)
+            for sg, o_ in segs:
+                lay = sg.get("layout")
+                ysegs.append(dict(w=sg["w"][:, :Cf], mode=EPI_RAW, out=Y, out_coff=o_,
+                                  layout=None if lay is None else (lay[0], lay[1], 0, 1, 1)))
+            self._gemm(tab, 4, ysegs)
+            tails = []
+            for sg, o_ in segs:
+                t_ = dict(sg)
+                t_["w"] = sg["w"][:, Cf:]
+                t_["pre_add"] = (Y, -kshift, o_)
+                tails.append(t_)
+            self._gemm(g, npx_log2, tails, pre_gather=kidx)
+        else:
+            self._gemm(g, npx_log2, [mlp_first, mlp_res, kseg], gather=gather)
         self._sync(0, 1)  # the key statistics are ready
 
         def finish_scores():
@@ -550,7 +586,7 @@ class DenoiserEngine:
         self.gemm_flops = {}
         self.gemm_bytes = {}
         self.xyz_copy_idx = []
-        self.persistent = os.environ.get('SLIDE_PERSISTENT', '0') != '0'
+        self.persistent = int(os.environ.get('SLIDE_PERSISTENT', '0'))  # 1: tile counter per XCD, 2: static tile lists
         # persistent I/O + per-step state
         self.x = A.zeros(B, 16, self.cx)
         self.ts = A.zeros(B)

@@ -133,3 +133,36 @@ def test_error_behaviour(gpu_device):
         _ext.gather_points(torch.zeros(1, 3, 8, device=gpu_device), torch.zeros(1, 2, dtype=torch.int32))
     with pytest.raises(RuntimeError, match="float tensor"):
         _ext.three_nn(torch.zeros(1, 3, 3, device=gpu_device).double(), torch.zeros(1, 3, 3, device=gpu_device))
+
+
+def test_empty_and_degenerate_inputs(gpu_device):
+    """empty batches / zero queries return empty tensors without a launch; nsample > n, K > n and a single point follow
+    the oracle (ball_query pads with the first hit, kNN pads missing neighbours with index 0 / distance 0)"""
+    from slide_amd import _ext
+    dev = gpu_device
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
+    assert tuple(_ext.gather_points(z(0, 3, 8), z(0, 4, dt=torch.int32)).shape) == (0, 3, 4)
+    assert tuple(_ext.gather_points(z(2, 3, 8), z(2, 0, dt=torch.int32)).shape) == (2, 3, 0)
+    assert tuple(_ext.group_points(z(2, 3, 8), z(2, 0, 4, dt=torch.int32)).shape) == (2, 3, 0, 4)
+    assert tuple(_ext.furthest_point_sampling(z(0, 16, 3), 4).shape) == (0, 4)
+    idx, cnt = _ext.ball_query(z(2, 0, 3), z(2, 5, 3), 0.5, 4)
+    assert tuple(idx.shape) == (2, 0, 4) and tuple(cnt.shape) == (2, 0)
+    d, i = _ext.three_nn(z(1, 0, 3), z(1, 4, 3))
+    assert tuple(d.shape) == (1, 0, 3) and tuple(i.shape) == (1, 0, 3)
+    rs = np.random.RandomState(11)
+    xyz = rs.uniform(-1, 1, (2, 5, 3)).astype(np.float32)
+    q = rs.uniform(-1, 1, (2, 7, 3)).astype(np.float32)
+    ri, rc = O.ball_query(q, xyz, 0.8, 16)  # nsample > n
+    idx, cnt = _ext.ball_query(T(q, dev), T(xyz, dev), 0.8, 16)
+    assert np.array_equal(N(idx), ri) and np.array_equal(N(cnt), rc)
+    ri, rc = O.ball_query(q, xyz, 1e-6, 4)  # empty balls
+    idx, cnt = _ext.ball_query(T(q, dev), T(xyz, dev), 1e-6, 4)
+    assert np.array_equal(N(idx), ri) and np.array_equal(N(cnt), rc) and int(N(cnt).max()) == 0
+    rd, ri = O.knn_points(q, xyz, 8)  # K > n2
+    d, i = _ext.knn_points(T(q, dev), T(xyz, dev), 8)
+    assert np.array_equal(N(i), ri) and np.array_equal(N(d), rd)
+    one = rs.uniform(-1, 1, (3, 1, 3)).astype(np.float32)
+    assert np.array_equal(N(_ext.furthest_point_sampling(T(one, dev), 1)), O.furthest_point_sampling(one, 1))
+    rd, ri = O.three_nn(q, xyz[:, :3])  # exactly three known points
+    d, i = _ext.three_nn(T(q, dev), T(xyz[:, :3].copy(), dev))
+    assert np.array_equal(N(i), ri) and np.array_equal(N(d), rd)
