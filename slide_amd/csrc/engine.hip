@@ -812,13 +812,26 @@ __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem
   _Float16 *const aff_lds = reinterpret_cast<_Float16 *>(vec_lds + CBW * WC * 96);  // [sample][scale | shift][k_pad]
   if (AFF) {
     static_assert(!AFF || NPXL >= 6, "the affine variant assumes one sample per wave");
-    for (int i = tid; i < NSAMP * a.k_pad; i += 256) {
-      const int sm = i / a.k_pad, k = i - sm * a.k_pad;
-      int b = (row0 >> NPXL) + sm;
-      const int nb = a.rows >> NPXL;
-      b = b < nb ? b : nb - 1;
-      aff_lds[(sm * 2 + 0) * a.k_pad + k] = (_Float16)a.in_scale[(size_t)b * a.in_bs + k];
-      aff_lds[(sm * 2 + 1) * a.k_pad + k] = (_Float16)a.in_shift[(size_t)b * a.in_bs + k];
+    const int nb = a.rows >> NPXL, n_aff = NSAMP * a.k_pad;
+    for (int i0 = tid; i0 < n_aff; i0 += 1024) {  // four elements per trip, their loads issued together
+      float sc4[4], sh4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 256 * u < n_aff ? i0 + 256 * u : i0;
+        const int sm = i / a.k_pad, k = i - sm * a.k_pad;
+        int b = (row0 >> NPXL) + sm;
+        b = b < nb ? b : nb - 1;
+        sc4[u] = a.in_scale[(size_t)b * a.in_bs + k];
+        sh4[u] = a.in_shift[(size_t)b * a.in_bs + k];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 256 * u;
+        if (i >= n_aff) break;
+        const int sm = i / a.k_pad, k = i - sm * a.k_pad;
+        aff_lds[(sm * 2 + 0) * a.k_pad + k] = (_Float16)sc4[u];
+        aff_lds[(sm * 2 + 1) * a.k_pad + k] = (_Float16)sh4[u];
+      }
     }
   }
   const _Float16 *const aff_w = aff_lds + (size_t)((wave * 64) >> NPXL) * 2 * a.k_pad;  // this wave's sample
@@ -1079,9 +1092,20 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
         float mean = 0.f, rstd = 0.f;
         if (g < f.G) {
           float S = 0.f, SS = 0.f;
-          for (int cc = f.gstart[g]; cc < f.gend[g]; ++cc) {
-            S += f.sum[(size_t)b * f.bs + cc];
-            SS += f.sq[(size_t)b * f.bs + cc];
+          // eight channels per trip, loads issued together (a one-channel loop pays one L2 round trip per channel)
+          const int c_end = f.gend[g];
+          const float *ps = f.sum + (size_t)b * f.bs, *pq = f.sq + (size_t)b * f.bs;
+          for (int cc = f.gstart[g]; cc < c_end; cc += 8) {
+            float s8[8], q8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int c = cc + u < c_end ? cc + u : c_end - 1;
+              s8[u] = ps[c];
+              q8[u] = pq[c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (cc + u < c_end) { S += s8[u]; SS += q8[u]; }
           }
           mean = S * f.inv_count;
           const float var = fmaxf(SS * f.inv_count - mean * mean, 0.f);
@@ -1093,24 +1117,38 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
       __syncthreads();
       // column tile 0 publishes all C channels; the other tiles only need their own K slice [off, off + k_pad)
       const int c_lo = tc == 0 ? 0 : off, c_n = tc == 0 ? f.C : (a.k_pad < f.C - off ? a.k_pad : f.C - off);
-      for (int i = tid; i < 4 * c_n; i += 256) {
-        const int sm = i / c_n, c = c_lo + (i - sm * c_n);
-        int b = (row0 >> NPXL) + sm;
-        b = b < nb ? b : nb - 1;
-        const int g = f.gid[c];
-        float sc = 1.f, sh = 0.f;
-        if (g >= 0) {
-          sc = f.gamma[c] * grp[(sm * 32 + g) * 2 + 1];
-          sh = f.beta[c] - grp[(sm * 32 + g) * 2] * sc;
+      // four channels per thread and trip: their table loads are issued together
+      for (int i0 = tid; i0 < 4 * c_n; i0 += 1024) {
+        int gq[4];
+        float gm[4], bt[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + 256 * u < 4 * c_n ? i0 + 256 * u : i0;
+          const int c = c_lo + i % c_n;
+          gq[u] = f.gid[c]; gm[u] = f.gamma[c]; bt[u] = f.beta[c];
         }
-        if (tc == 0) {
-          f.scale[(size_t)b * f.bs + c] = sc;
-          f.shift[(size_t)b * f.bs + c] = sh;
-        }
-        const int kk = c - off;
-        if (kk >= 0 && kk < a.k_pad) {
-          aff_lds[(sm * 2 + 0) * a.k_pad + kk] = (_Float16)sc;
-          aff_lds[(sm * 2 + 1) * a.k_pad + kk] = (_Float16)sh;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + 256 * u;
+          if (i >= 4 * c_n) break;
+          const int sm = i / c_n, c = c_lo + (i - sm * c_n);
+          int b = (row0 >> NPXL) + sm;
+          b = b < nb ? b : nb - 1;
+          const int g = gq[u];
+          float sc = 1.f, sh = 0.f;
+          if (g >= 0) {
+            sc = gm[u] * grp[(sm * 32 + g) * 2 + 1];
+            sh = bt[u] - grp[(sm * 32 + g) * 2] * sc;
+          }
+          if (tc == 0) {
+            f.scale[(size_t)b * f.bs + c] = sc;
+            f.shift[(size_t)b * f.bs + c] = sh;
+          }
+          const int kk = c - off;
+          if (kk >= 0 && kk < a.k_pad) {
+            aff_lds[(sm * 2 + 0) * a.k_pad + kk] = (_Float16)sc;
+            aff_lds[(sm * 2 + 1) * a.k_pad + kk] = (_Float16)sh;
+          }
         }
       }
     } else {
