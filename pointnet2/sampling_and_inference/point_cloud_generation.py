@@ -44,10 +44,10 @@ def main():
     if a.ckpt is None and not a.random_init:
         raise SystemExit("--ckpt is required (or pass --random_init for synthetic weights)")
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL, bound to this rank's GPU
     sd = load_denoiser_state(hp, None if a.random_init else a.ckpt, a.ema_idx)
     B = a.batch_size
     smp = PositionSampler(hp, sd, B, dev, cfg["diffusion_config"], prec=a.prec, seed=a.seed + rank)
