@@ -28,15 +28,16 @@ class Swish(nn.Module):
 
 
 class MyGroupNorm(nn.Module):
-    def __init__(self, num_groups, num_channels):
+    def __init__(self, num_groups, num_channels, fused_relu=False):
         super().__init__()
         assert num_channels >= num_groups
         self.num_channels = num_channels - num_channels % num_groups
         self.num_groups = num_groups
+        self.fused_relu = fused_relu  # the ReLU that follows in the reference's Sequential, applied by the same kernel
         self.group_norm = HipGroupNorm(self.num_groups, self.num_channels)
 
     def forward(self, x):
-        return self.group_norm(x)
+        return self.group_norm(x, relu=self.fused_relu)
 
 
 def _act(activation):
@@ -54,9 +55,11 @@ def build_shared_mlp(mlp_spec: List[int], bn: bool = True, bn_first: bool = Fals
             layers.append(_act(activation))
         layers.append(HipConv1x1(mlp_spec[i - 1], mlp_spec[i], bias=bias))
         if not bn_first:
+            fuse = bn and activation == "relu"
             if bn:
-                layers.append(MyGroupNorm(min(32, mlp_spec[i]), mlp_spec[i]))
-            layers.append(_act(activation))
+                layers.append(MyGroupNorm(min(32, mlp_spec[i]), mlp_spec[i], fused_relu=fuse))
+            # (the Sequential keeps the reference's indices: the activation slot holds no parameters)
+            layers.append(nn.Identity() if fuse else _act(activation))
     return nn.Sequential(*layers)
 
 
