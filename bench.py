@@ -59,6 +59,8 @@ def cpu_baseline(batch=4, budget_s=20.0):
 
 
 def main():
+    # multi-process GPU work on this pool needs dmabuf IPC (RCCL / hipIpc* fail with the legacy mode)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
