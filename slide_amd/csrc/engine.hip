@@ -1024,6 +1024,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
   constexpr int NPXL = 4;
   constexpr int STAGE_B = 128 * 64;  // 64 X rows + 64 W rows, 64 bytes each
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  SLIDE_STAMP(a, 0);
   const int ntc = (a.n_cob + 1) / 2;
   const int tc = blockIdx.x % ntc, tr = blockIdx.x / ntc;
   const int row0 = tr * 64, cob0 = tc * 2;
@@ -1163,6 +1164,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
     __syncthreads();
   }
 
+  SLIDE_STAMP(a, 1);
   for (int i = 0; i < mine; ++i) {
     // this wave's own DMA: a counted wait orders it for this wave's reads, no barrier involved
     if (i + NST - 2 < mine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * 8) : "memory");
@@ -1197,6 +1199,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
           acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[st2][cb], bf[st2][rb], acc[cb][rb], 0, 0, 0);
   }
   __syncthreads();  // rings are dead, tables are visible
+  SLIDE_STAMP(a, 2);
   // partial accumulators -> LDS [wave][block = cb*2+rb][reg][lane]; wave w sums block w
   float *const part = reinterpret_cast<float *>(smem_raw);
 #pragma unroll
@@ -1214,9 +1217,18 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
     for (int w = 0; w < 4; ++w) t += part[(((w * 4 + wave) * 16 + r) << 6) + lane];
     one[0][0][r] = t;
   }
+  SLIDE_STAMP(a, 3);
+  SLIDE_STAMP(a, 4);
   const int cb = wave >> 1, rb = wave & 1;  // block index wave = cb*2 + rb
   gemm_epilogue<SLIDE_PREC_F16, NPXL, 1, 1>(a, one, row0 + rb * 32, cob0 + cb, 0, half, col, epi_lds + cb * EPI_DW,
                                             vec_lds + cb * 96, nullptr);
+  SLIDE_STAMP(a, 5);
+#ifdef SLIDE_TIMELINE
+  if (a.dbg) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SLIDE_STAMP(a, 6);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ attention tail
