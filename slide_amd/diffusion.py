@@ -287,6 +287,27 @@ class JointSampler:
         self.stream.synchronize(); self.stream2.synchronize()
 
 
+class OwnGraphSampler:
+    """A single chain (position or feature sampler) as a member of a SplitJointSampler: its own step graph on its own
+    stream, launched in the round-robin beside the others."""
+
+    def __init__(self, sampler):
+        self.sampler = sampler
+        self.stream = sampler.stream
+
+    def _prepare(self):
+        self.sampler._run_steps(0)  # captures the step graph on first use
+
+    def _launch(self):
+        check(lib().slide_graph_launch(self.sampler.graph, ctypes.c_void_p(self.stream.cuda_stream)), "graph_launch")
+
+    def _finish(self):
+        pass
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+
 class SplitJointSampler:
     """A batch processed as P independent sub-batches, each a JointSampler on its own pair of streams, their per-step
     graphs launched round-robin.  The sub-batches are independent objects of the partition (no exchange), so this is
