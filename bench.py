@@ -4,17 +4,19 @@
 Workload (BASELINE.json configs[1]/[2], per GPU): batch 256 latent-point sets (16 points each);
   step = ONE reverse-diffusion step of the position DDPM (airplane config, 3-dim)  +
          ONE reverse-diffusion step of the feature DDPM (chair config, 48-dim feature + 3-dim key points)
-  over the whole batch: denoiser forward + DDPM update + in-kernel noise; the two plans are the two parallel branches of
-  ONE hipGraph per step (in steady-state generation batch i's feature chain overlaps batch i+1's position chain).
+  over the whole batch: denoiser forward + DDPM update + in-kernel noise.  The position plan (one chain of 256) and the
+  feature plan (three independent sub-batches) are replayed concurrently on their own streams, each fed by its own host
+  thread (in steady-state generation batch i's feature chains overlap batch i+1's position chain); `--replay graph`
+  replays captured hipGraphs instead.
 A generated shape needs 1000 + 1000 such steps, so  value = n_gpus * batch / (1000 * seconds_per_step).
 `--steps 1000` is therefore exactly one complete generation of the batch.  Synthetic random-init weights,
 synthetic key points, inputs resident in HBM.  N > 1: one process per GPU (torchrun), batch shards are
 independent (weak scaling), one RCCL all-gather of the (B,16,51) latents closes the timed region.
 
 Extra objects on the JSON line:
-  roofline     the dominant kernel (MFMA GEMM of the feature denoiser's 256-row blocks): algorithmic FLOPs of
-               those launches / their device time, measured with HIP events on the launch stream in an
-               instrumented eager replay right after the timed region (the timed region itself is a graph replay)
+  roofline     the dominant kernel (the MFMA kernel with the largest share of a feature step's device time): algorithmic
+               FLOPs of its launches / their device time, measured with HIP events on the launch stream in an
+               instrumented eager replay right after the timed region (the timed region launches without events)
   cpu_baseline the numpy/C oracle ("port" of the reference algorithm; the reference has no CPU path for its native
                ops) timed on the host cores on a bounded sample of the same workload
 """
@@ -67,8 +69,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="latent shapes per GPU (BASELINE configs[1]/[2]: 256)")
     ap.add_argument("--prec", default="fp16", choices=["fp16", "fp32"], help="MFMA operand type (fp32 accumulate)")
-    ap.add_argument("--sub-batches", type=int, default=2,
+    ap.add_argument("--sub-batches", type=int, default=3,
                     help="independent sub-batches of the per-GPU batch replayed concurrently (scheduling only)")
+    ap.add_argument("--replay", default=os.environ.get("SLIDE_REPLAY", "threads"), choices=["threads", "eager", "graph"],
+                    help="threads: eager launches, one host thread per chain (default); eager: the same from one thread; "
+                         "graph: one captured hipGraph per chain and step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -83,7 +88,7 @@ def main():
     import torch.distributed as dist
     from slide_amd import configs, model_spec
     from slide_amd._lib import check, lib
-    from slide_amd.diffusion import FeatureSampler, JointSampler, OwnGraphSampler, PositionSampler, SplitJointSampler
+    from slide_amd.diffusion import FeatureSampler, JointSampler, OwnGraphSampler, PositionSampler, SplitJointSampler, ThreadedEagerSampler
     from slide_amd.engine import OP_ATTN_TAIL, OP_GEMM
     from slide_amd.synth import synth_keypoints, synth_state_dict
 
@@ -112,20 +117,24 @@ def main():
         P = len(sizes)
     # the feature plan runs as P concurrent sub-batches; the position plan (launch-bound at any size) as ONE chain over
     # the whole batch beside them
-    pos = PositionSampler(pc["pointnet_config"], sd_p, B, dev, pc["diffusion_config"], prec=a.prec, seed=1000 + rank * 16)
+    eager = a.replay != "graph"
+    pos = PositionSampler(pc["pointnet_config"], sd_p, B, dev, pc["diffusion_config"], prec=a.prec, seed=1000 + rank * 16,
+                          use_graph=not eager)
     # position plan: its own step graph on its own stream ("own", default: 1-1.5 % faster) or a parallel branch of the
     # first feature sub-batch's graph ("branch")
     pos_own = os.environ.get("SLIDE_POS_GRAPH", "own") == "own"
     subs = []
     for i, b in enumerate(sizes):
         f_ = FeatureSampler(fc["pointnet_config"], sd_f, b, dev, fc["standard_diffusion_config"], prec=a.prec,
-                            seed=2000 + rank * 16 + i)
+                            seed=2000 + rank * 16 + i, use_graph=not eager)
         subs.append((f_, JointSampler(pos if (i == 0 and not pos_own) else None, f_), synth_keypoints(b, seed=rank * 16 + i)))
     feat, kp = subs[0][0], subs[0][2]  # sub-batch 0 also serves the roofline leg below
-    members = [s_[1] for s_ in subs]
+    members = [OwnGraphSampler(s_[0]) if eager else s_[1] for s_ in subs]
     if pos_own:
         members.insert(int(os.environ.get("SLIDE_POS_ORDER", "1")), OwnGraphSampler(pos))
     joint = SplitJointSampler(members)  # one hipGraph per member and step, launched round-robin
+    if a.replay == "threads":
+        joint = ThreadedEagerSampler([pos] + [s_[0] for s_ in subs])
     rs = np.random.RandomState(rank)
 
     def reset():
@@ -181,7 +190,7 @@ def main():
            "dtype": "f16 (MFMA operands + activation storage; f32 accumulate, norm statistics, softmax)" if a.prec == "fp16" else "f32", "data": "synthetic",
            "config": {"workload": "BASELINE configs[1]+[2]: airplane position DDPM (16x3) + chair feature DDPM (16x51), "
                                   "batch %d per GPU; 1 step = one reverse step of each; shape = 1000+1000 steps" % B,
-                      "batch_per_gpu": B, "sub_batches": sizes, "prec": a.prec,
+                      "batch_per_gpu": B, "sub_batches": sizes, "prec": a.prec, "replay": a.replay,
                       "launches_per_step": pos.n_launches + P * feat.n_launches,
                       "finite": finite}}
 

@@ -105,6 +105,8 @@ SLIDE_API int slide_run_ops(const SlideOp *ops, int n, slide_stream_t stream);
  * (e.g. the query / score branch and the value branch of an attention block) then overlap, eagerly or as parallel
  * branches of a captured hipGraph (capture on stream0; every lane must be joined back into lane 0 at the end). */
 SLIDE_API int slide_run_ops2(const SlideOp *ops, int n, slide_stream_t stream0, slide_stream_t stream1);
+/* `reps` back-to-back eager replays of one plan (one host thread per chain / stream; no SLIDE_OP_SYNC across threads) */
+SLIDE_API int slide_run_ops_repeat(const SlideOp *ops, int n, slide_stream_t stream0, slide_stream_t stream1, int reps);
 
 /* same, eagerly, with a HIP event recorded on `stream` between consecutive launches; ms_out[i] (HOST, n floats)
  * receives the device time of ops[i].  Synchronises.  For per-kernel roofline figures, never on a timed path. */

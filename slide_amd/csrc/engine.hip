@@ -2153,6 +2153,17 @@ int slide_run_ops2(const SlideOp *ops, int n, slide_stream_t stream0, slide_stre
   return 0;
 }
 
+// `reps` eager replays of one plan in a single call: a host thread per chain can keep its stream fed without returning
+// to the interpreter between steps (plans advance their own device-side timestep).  Thread-safe for plans without
+// SLIDE_OP_SYNC on distinct streams once every kernel has been launched at least once (first-use attribute calls).
+int slide_run_ops_repeat(const SlideOp *ops, int n, slide_stream_t stream0, slide_stream_t stream1, int reps) {
+  for (int r = 0; r < reps; ++r) {
+    const int st = slide_run_ops2(ops, n, stream0, stream1);
+    if (st != 0) return st;
+  }
+  return 0;
+}
+
 // Eager replay with a HIP event between consecutive launches (recorded on the launch stream): ms_out[i] = device
 // time of ops[i].  Used by bench.py for the per-kernel roofline figure; not used on the timed path.
 int slide_run_ops_timed(const SlideOp *ops, int n, slide_stream_t stream, float *ms_out) {

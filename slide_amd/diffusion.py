@@ -299,13 +299,60 @@ class OwnGraphSampler:
         self.sampler._run_steps(0)  # captures the step graph on first use
 
     def _launch(self):
-        check(lib().slide_graph_launch(self.sampler.graph, ctypes.c_void_p(self.stream.cuda_stream)), "graph_launch")
+        smp = self.sampler
+        if smp.use_graph:
+            check(lib().slide_graph_launch(smp.graph, ctypes.c_void_p(self.stream.cuda_stream)), "graph_launch")
+        else:  # eager replay of the step plan (A/B against the graph form)
+            check(lib().slide_run_ops2(smp.step_ops, len(smp.step_ops), ctypes.c_void_p(self.stream.cuda_stream),
+                                       ctypes.c_void_p(smp.stream2.cuda_stream)), "slide_run_ops2")
 
     def _finish(self):
         pass
 
     def synchronize(self):
         self.stream.synchronize()
+
+
+class ThreadedEagerSampler:
+    """Independent chains (feature sub-batches, the position chain) replayed EAGERLY, one host thread per chain: each
+    thread hands its chain's n steps to the library in one call (slide_run_ops_repeat releases the GIL), so the chains'
+    launch queues fill concurrently and no graph is involved.  The first advance() runs on the calling thread (first-use
+    kernel attribute calls are not thread-safe)."""
+
+    def __init__(self, samplers):
+        self.samplers = list(samplers)
+        self._warm = False
+
+    def _issue(self, smp, n):
+        torch.cuda.set_device(smp.device)  # HIP's current device is per host thread
+        return lib().slide_run_ops_repeat(smp.step_ops, len(smp.step_ops), ctypes.c_void_p(smp.stream.cuda_stream),
+                                          ctypes.c_void_p(smp.stream2.cuda_stream), int(n))
+
+    def advance(self, n_steps):
+        if not self._warm:
+            self._warm = True
+            for i in range(n_steps):
+                for smp in self.samplers:
+                    check(self._issue(smp, 1), "slide_run_ops_repeat")
+            return
+        import threading
+        status = [0] * len(self.samplers)
+
+        def work(k):
+            status[k] = self._issue(self.samplers[k], n_steps)
+
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(1, len(self.samplers))]
+        for t in threads:
+            t.start()
+        work(0)
+        for t in threads:
+            t.join()
+        for st in status:
+            check(st, "slide_run_ops_repeat")
+
+    def synchronize(self):
+        for smp in self.samplers:
+            smp.stream.synchronize()
 
 
 class SplitJointSampler:

@@ -235,3 +235,57 @@ def test_split_sampler_equals_separate_chains(gpu_device):
     assert np.array_equal(pos.state().cpu().numpy(), want_p)
     for f, w in zip(feats, want_f):
         assert np.array_equal(f.state().cpu().numpy(), w)
+
+
+def test_threaded_eager_sampler_equals_separate_chains(gpu_device):
+    """bench.py's default arrangement -- the position plan and three feature sub-batches replayed eagerly, one host thread
+    per chain (`ThreadedEagerSampler`; also the position chain as its own step graph, `OwnGraphSampler`) -- gives
+    bit-identical states to the samplers run one after the other: only the schedule differs."""
+    from slide_amd import configs
+    from slide_amd.diffusion import (FeatureSampler, JointSampler, OwnGraphSampler, PositionSampler, SplitJointSampler,
+                                     ThreadedEagerSampler)
+    _, hp_p, sd_p = _load("pos")
+    _, hp_f, sd_f = _load("feat")
+    B, n = 7, 6
+    sizes = [3, 2, 2]
+    lo = [0, 3, 5]
+    rs = np.random.RandomState(29)
+    xp, xf = rs.standard_normal((B, 16, 3)).astype(np.float32), rs.standard_normal((B, 16, 51)).astype(np.float32)
+    kp = rs.uniform(-0.7, 0.7, (B, 16, 3)).astype(np.float32)
+    npos = rs.standard_normal((n, B, 16, 3)).astype(np.float32)
+    nfeat = [rs.standard_normal((n, b, 16, 51)).astype(np.float32) for b in sizes]
+    lab_p, lab_f = np.zeros(B, np.int64), np.full(B, 4, np.int64)
+    fcfg = configs.feature_ddpm_config()["standard_diffusion_config"]
+
+    def make(use_graph):
+        p = PositionSampler(hp_p, sd_p, B, gpu_device, _pos_cfg(), prec="fp16", noise=npos, use_graph=use_graph)
+        fs = [FeatureSampler(hp_f, sd_f, b, gpu_device, fcfg, prec="fp16", noise=nz, use_graph=use_graph)
+              for b, nz in zip(sizes, nfeat)]
+        return p, fs
+
+    def begin(p, fs):
+        p.begin(lab_p, xp)
+        for f, b, l in zip(fs, sizes, lo):
+            f.begin(lab_f[l:l + b], kp[l:l + b], xf[l:l + b])
+
+    pos, feats = make(True)
+    want_p = pos.sample(lab_p, xp, n_steps=n).cpu().numpy()
+    want_f = [f.sample(lab_f[l:l + b], kp[l:l + b], xf[l:l + b], n_steps=n).cpu().numpy() for f, b, l in zip(feats, sizes, lo)]
+    # graphs: the position chain as its own graph beside the feature graphs
+    begin(pos, feats)
+    split = SplitJointSampler([JointSampler(None, feats[0]), OwnGraphSampler(pos)] + [JointSampler(None, f) for f in feats[1:]])
+    split.advance(n)
+    split.synchronize()
+    assert np.array_equal(pos.state().cpu().numpy(), want_p)
+    for f, w in zip(feats, want_f):
+        assert np.array_equal(f.state().cpu().numpy(), w)
+    # eager, one host thread per chain: the first advance() runs on the caller's thread, the second on the threads
+    pe, fe = make(False)
+    thr = ThreadedEagerSampler([pe] + fe)
+    begin(pe, fe)
+    thr.advance(2)
+    thr.advance(n - 2)
+    thr.synchronize()
+    assert np.array_equal(pe.state().cpu().numpy(), want_p)
+    for f, w in zip(fe, want_f):
+        assert np.array_equal(f.state().cpu().numpy(), w)
