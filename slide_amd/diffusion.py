@@ -64,7 +64,9 @@ class _GraphedSampler:
         self.B, self.device = int(batch), device
         self.use_graph = use_graph
         self.stream = torch.cuda.Stream(device=device)
-        self.stream2 = torch.cuda.Stream(device=device)  # second lane of the plan (independent branches overlap)
+        # second lane of the plan (independent branches overlap); single-lane plans (the default) do not take a second
+        # stream: HIP spreads streams over a few hardware queues, and an idle stream still occupies a slot
+        self.stream2 = torch.cuda.Stream(device=device) if self.engine.two_lanes else self.stream
         self.graph = None
         self.step_ops = None
 

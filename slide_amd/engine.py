@@ -271,7 +271,7 @@ class DenoiserEngine:
         assert X.dtype == self.adt
         # wide (128-channel) tiles only when the grid still covers the 256 CUs at least twice
         ntr = (rows + 255) // 256
-        cbw = 4 if (self.prec == 1 and n_cob >= 4 and ntr * ((n_cob + 3) // 4) >= int(os.environ.get('SLIDE_CBW4_TILES', '256'))) else 2
+        cbw = 4 if (self.prec == 1 and n_cob >= 4 and ntr * ((n_cob + 3) // 4) >= int(os.environ.get('SLIDE_CBW4_TILES', '1000'))) else 2
         # narrow launches: 32-channel tiles double the workgroups and halve each wave's epilogue while they still fit one round
         if (self.prec == 1 and self.use_glds and sc is None and npx_log2 >= 7 and ntr * n_cob <= int(os.environ.get('SLIDE_CBW1_TILES', '0'))):
             cbw = 1
