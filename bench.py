@@ -117,12 +117,14 @@ def main():
         P = len(sizes)
     # the feature plan runs as P concurrent sub-batches; the position plan (launch-bound at any size) as ONE chain over
     # the whole batch beside them
+    if P == 1:  # one chain pair: the two plans as the two branches of one step graph (two lone streams serialise)
+        a.replay = "graph"
     eager = a.replay != "graph"
     pos = PositionSampler(pc["pointnet_config"], sd_p, B, dev, pc["diffusion_config"], prec=a.prec, seed=1000 + rank * 16,
                           use_graph=not eager)
     # position plan: its own step graph on its own stream ("own", default: 1-1.5 % faster) or a parallel branch of the
     # first feature sub-batch's graph ("branch")
-    pos_own = os.environ.get("SLIDE_POS_GRAPH", "own") == "own"
+    pos_own = os.environ.get("SLIDE_POS_GRAPH", "own") == "own" and P > 1
     subs = []
     for i, b in enumerate(sizes):
         f_ = FeatureSampler(fc["pointnet_config"], sd_f, b, dev, fc["standard_diffusion_config"], prec=a.prec,
