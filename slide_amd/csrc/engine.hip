@@ -2164,6 +2164,17 @@ int slide_run_ops_repeat(const SlideOp *ops, int n, slide_stream_t stream0, slid
   return 0;
 }
 
+// `reps` steps of several independent chains from ONE host thread, round-robin: step r of every chain is issued before
+// step r + 1 of any (chain c replays ops[c][0..n[c]) on streams[c]; single-lane plans).
+int slide_run_chains(const SlideOp *const *ops, const int *n, const slide_stream_t *streams, int n_chains, int reps) {
+  for (int r = 0; r < reps; ++r)
+    for (int c = 0; c < n_chains; ++c) {
+      const int st = slide_run_ops2(ops[c], n[c], streams[c], streams[c]);
+      if (st != 0) return st;
+    }
+  return 0;
+}
+
 // Eager replay with a HIP event between consecutive launches (recorded on the launch stream): ms_out[i] = device
 // time of ops[i].  Used by bench.py for the per-kernel roofline figure; not used on the timed path.
 int slide_run_ops_timed(const SlideOp *ops, int n, slide_stream_t stream, float *ms_out) {

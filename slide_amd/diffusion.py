@@ -357,6 +357,25 @@ class ThreadedEagerSampler:
             smp.stream.synchronize()
 
 
+class EagerChainsSampler:
+    """Independent chains replayed eagerly from ONE host thread, round-robin per step, in a single library call per
+    advance() (slide_run_chains): no graph, no interpreter work between launches."""
+
+    def __init__(self, samplers):
+        self.samplers = list(samplers)
+        k = len(self.samplers)
+        self._ops = (ctypes.c_void_p * k)(*[ctypes.cast(s_.step_ops, ctypes.c_void_p) for s_ in self.samplers])
+        self._n = (ctypes.c_int * k)(*[len(s_.step_ops) for s_ in self.samplers])
+        self._streams = (ctypes.c_void_p * k)(*[s_.stream.cuda_stream for s_ in self.samplers])
+
+    def advance(self, n_steps):
+        check(lib().slide_run_chains(self._ops, self._n, self._streams, len(self.samplers), int(n_steps)), "slide_run_chains")
+
+    def synchronize(self):
+        for smp in self.samplers:
+            smp.stream.synchronize()
+
+
 class SplitJointSampler:
     """A batch processed as P independent sub-batches, each a JointSampler on its own pair of streams, their per-step
     graphs launched round-robin.  The sub-batches are independent objects of the partition (no exchange), so this is

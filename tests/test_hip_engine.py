@@ -238,12 +238,13 @@ def test_split_sampler_equals_separate_chains(gpu_device):
 
 
 def test_threaded_eager_sampler_equals_separate_chains(gpu_device):
-    """bench.py's default arrangement -- the position plan and three feature sub-batches replayed eagerly, one host thread
-    per chain (`ThreadedEagerSampler`; also the position chain as its own step graph, `OwnGraphSampler`) -- gives
-    bit-identical states to the samplers run one after the other: only the schedule differs."""
+    """bench.py's arrangements -- the position plan and three feature sub-batches replayed eagerly round-robin from one
+    thread (`EagerChainsSampler`, the default), with one host thread per chain (`ThreadedEagerSampler`), or as one step
+    graph per chain (`OwnGraphSampler`) -- give bit-identical states to the samplers run one after the other: only the
+    schedule differs."""
     from slide_amd import configs
-    from slide_amd.diffusion import (FeatureSampler, JointSampler, OwnGraphSampler, PositionSampler, SplitJointSampler,
-                                     ThreadedEagerSampler)
+    from slide_amd.diffusion import (EagerChainsSampler, FeatureSampler, JointSampler, OwnGraphSampler, PositionSampler,
+                                     SplitJointSampler, ThreadedEagerSampler)
     _, hp_p, sd_p = _load("pos")
     _, hp_f, sd_f = _load("feat")
     B, n = 7, 6
@@ -286,6 +287,14 @@ def test_threaded_eager_sampler_equals_separate_chains(gpu_device):
     thr.advance(2)
     thr.advance(n - 2)
     thr.synchronize()
+    assert np.array_equal(pe.state().cpu().numpy(), want_p)
+    for f, w in zip(fe, want_f):
+        assert np.array_equal(f.state().cpu().numpy(), w)
+    # eager, all chains round-robin from one thread inside the library (bench.py's default)
+    begin(pe, fe)
+    rr = EagerChainsSampler([fe[0], pe] + fe[1:])
+    rr.advance(n)
+    rr.synchronize()
     assert np.array_equal(pe.state().cpu().numpy(), want_p)
     for f, w in zip(fe, want_f):
         assert np.array_equal(f.state().cpu().numpy(), w)
