@@ -5,9 +5,10 @@ Workload (BASELINE.json configs[1]/[2], per GPU): batch 256 latent-point sets (1
   step = ONE reverse-diffusion step of the position DDPM (airplane config, 3-dim)  +
          ONE reverse-diffusion step of the feature DDPM (chair config, 48-dim feature + 3-dim key points)
   over the whole batch: denoiser forward + DDPM update + in-kernel noise.  The position plan (one chain of 256) and the
-  feature plan (three independent sub-batches) are replayed concurrently on their own streams, each fed by its own host
-  thread (in steady-state generation batch i's feature chains overlap batch i+1's position chain); `--replay graph`
-  replays captured hipGraphs instead.
+  feature plan (three independent sub-batches) are replayed concurrently on their own streams, launched eagerly and
+  round-robin per step by one host thread inside the library (in steady-state generation batch i's feature chains
+  overlap batch i+1's position chain); `--replay threads` gives every chain its own host thread, `--replay graph`
+  replays captured hipGraphs.
 A generated shape needs 1000 + 1000 such steps, so  value = n_gpus * batch / (1000 * seconds_per_step).
 `--steps 1000` is therefore exactly one complete generation of the batch.  Synthetic random-init weights,
 synthetic key points, inputs resident in HBM.  N > 1: one process per GPU (torchrun), batch shards are
@@ -71,9 +72,9 @@ def main():
     ap.add_argument("--prec", default="fp16", choices=["fp16", "fp32"], help="MFMA operand type (fp32 accumulate)")
     ap.add_argument("--sub-batches", type=int, default=3,
                     help="independent sub-batches of the per-GPU batch replayed concurrently (scheduling only)")
-    ap.add_argument("--replay", default=os.environ.get("SLIDE_REPLAY", "threads"), choices=["threads", "eager", "graph"],
-                    help="threads: eager launches, one host thread per chain (default); eager: the same from one thread; "
-                         "graph: one captured hipGraph per chain and step")
+    ap.add_argument("--replay", default=os.environ.get("SLIDE_REPLAY", "eager"), choices=["eager", "threads", "graph"],
+                    help="eager: eager launches of all chains from one host thread, round-robin per step (default); "
+                         "threads: one host thread per chain; graph: one captured hipGraph per chain and step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -88,7 +89,7 @@ def main():
     import torch.distributed as dist
     from slide_amd import configs, model_spec
     from slide_amd._lib import check, lib
-    from slide_amd.diffusion import FeatureSampler, JointSampler, OwnGraphSampler, PositionSampler, SplitJointSampler, ThreadedEagerSampler
+    from slide_amd.diffusion import EagerChainsSampler, FeatureSampler, JointSampler, OwnGraphSampler, PositionSampler, SplitJointSampler, ThreadedEagerSampler
     from slide_amd.engine import OP_ATTN_TAIL, OP_GEMM
     from slide_amd.synth import synth_keypoints, synth_state_dict
 
@@ -137,6 +138,8 @@ def main():
     joint = SplitJointSampler(members)  # one hipGraph per member and step, launched round-robin
     if a.replay == "threads":
         joint = ThreadedEagerSampler([pos] + [s_[0] for s_ in subs])
+    elif a.replay == "eager":
+        joint = EagerChainsSampler([s_[0] for s_ in subs[:1]] + [pos] + [s_[0] for s_ in subs[1:]])
     rs = np.random.RandomState(rank)
 
     def reset():
