@@ -112,6 +112,8 @@ def main():
     sd_f = synth_state_dict(model_spec.denoiser_param_spec(fc["pointnet_config"]))
     P = max(1, min(a.sub_batches, B))
     sizes = [B // P + (1 if i < B % P else 0) for i in range(P)]
+    if B % 8 == 0 and B // 8 >= P:  # multiples of 8 samples: the row tiles of a launch then spread evenly over the 8 XCDs
+        sizes = [8 * ((B // 8) // P + (1 if i < (B // 8) % P else 0)) for i in range(P)]
     if os.environ.get("SLIDE_SUB_SIZES"):  # experiment knob: explicit sub-batch sizes, e.g. 112,144
         sizes = [int(v) for v in os.environ["SLIDE_SUB_SIZES"].split(",")]
         assert sum(sizes) == B
