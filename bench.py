@@ -230,6 +230,8 @@ def main():
                 return "gemm_small_kernel<%d, %s>" % (3 if grid <= 256 else 2, b(o.p[3]))
             if a.prec == "fp32" or not o.i[8]:
                 return "gemm_kernel<%d, %d, %d>" % (0 if a.prec == "fp32" else 1, npxl, cbw)
+            if cbw == 2 and not (o.p[3] and o.p[8]):
+                return "gemm_glds_occ3_kernel<%d, %s, %s>" % (npxl, b(o.p[3]), b(o.p[8]))  # three workgroups per CU
             return "gemm_glds_kernel<%d, %d, 3, 32, %s, %s>" % (npxl, cbw, b(o.p[3]), b(o.p[8]))
 
         # dominant kernel = the MFMA kernel with the largest share of the feature denoiser's step time, measured here
