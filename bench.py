@@ -227,7 +227,7 @@ def main():
             rows, n_cob, npxl, cbw = o.i[0], o.i[3], o.i[4], o.i[7]
             grid = ((rows + 63) // 64) * ((n_cob + 1) // 2)
             if a.prec == "fp16" and npxl == 4 and grid <= 1024:
-                return "gemm_small_kernel<%d, %s>" % (3 if grid <= 256 else 2, b(o.p[3]))
+                return "gemm_small_kernel<2, %s>" % b(o.p[3])
             if a.prec == "fp32" or not o.i[8]:
                 return "gemm_kernel<%d, %d, %d>" % (0 if a.prec == "fp32" else 1, npxl, cbw)
             if cbw == 2 and not (o.p[3] and o.p[8]):
