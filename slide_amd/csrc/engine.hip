@@ -1266,10 +1266,13 @@ __device__ __forceinline__ float other_half(float x) {  // value of lane ^ 32
   return __uint_as_float((threadIdx.x & 32) ? a : b);
 }
 
+#ifndef SLIDE_ATTN_NST
+#define SLIDE_ATTN_NST 3  // ring stages of the fused attention tail
+#endif
 template <int NPXL>
 __global__ __launch_bounds__(256, 2) void attn_tail_kernel(AttnTailArgs a) {
   using T = _Float16;
-  constexpr int CBW = 2, NST = 3, RT = TM + 64, STAGE_B = RT * 64, LPW = RT / 16 / 4;
+  constexpr int CBW = 2, NST = SLIDE_ATTN_NST, RT = TM + 64, STAGE_B = RT * 64, LPW = RT / 16 / 4;
   constexpr int KLOG = NPXL - 4, KN = 1 << KLOG, GPB = 32 / KN;  // neighbours per point, points per 32-row block
   constexpr int WPS = (1 << NPXL) / 64;                            // waves per sample
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -2035,7 +2038,7 @@ int run_attn_tail(const SlideOp &o, hipStream_t s) {
   a.inv_count = o.f[0];
   const int npxl = o.i[6];
   if (a.k1 % 32 || a.k2 % 32 || a.rows <= 0 || a.n_cob <= 0) return -3;
-  const size_t shm = (size_t)3 * (TM + 64) * 64 + 4 * 2 * 32 * 4 + 64;
+  const size_t shm = (size_t)SLIDE_ATTN_NST * (TM + 64) * 64 + 4 * 2 * 32 * 4 + 64;
   const int ntc = (a.n_cob + 1) / 2, ntr = (a.rows + TM - 1) / TM;
   const int grid = ((ntr + 7) / 8) * 8 * ntc;
   static bool attr_set = false;
