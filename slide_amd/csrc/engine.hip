@@ -1031,8 +1031,9 @@ __global__ __launch_bounds__(512, 2) void gemm_glds8_kernel(GemmArgs a) {
 // 32-deep chunks w, w+4, ... through a private LDS-DMA ring (no workgroup barrier in the loop) -- then the partial
 // accumulators meet in LDS and every wave finishes ONE 32x32 output block (channel block w & 1, row block w >> 1)
 // through the common epilogue: the K loop and the epilogue are each ~4x shorter per wave and the grid is 4x larger.
+// (168-VGPR budget: a wave of this kernel then shares a SIMD with two waves of the 64-channel GEMM tiles of the other chains)
 template <int NST, bool AFF>
-__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256, 3) void gemm_small_kernel(GemmArgs a) {
   using T = _Float16;
   constexpr int NPXL = 4;
   constexpr int STAGE_B = 128 * 64;  // 64 X rows + 64 W rows, 64 bytes each
