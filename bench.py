@@ -61,6 +61,17 @@ def cpu_baseline(batch=4, budget_s=20.0):
                       % (batch, per["pos"], per["feat"])}
 
 
+def relaunch_argv(gpus, argv, port=None):
+    """`python bench.py --gpus N` outside a launcher: the command line that re-runs this script as N ranks, one process
+    per GPU (the reference's launcher spawns its per-GPU workers itself too: pointnet2/distributed.py:171-182).  rank 0
+    owns stdout (the JSON line); the other ranks' stdout goes to stderr inside main()."""
+    if port is None:
+        import socket
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     # multi-process GPU work on this pool needs dmabuf IPC (RCCL / hipIpc* fail with the legacy mode)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -78,6 +89,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: spawn the ranks ourselves and pass their exit status on
+        import subprocess
+        sys.exit(subprocess.call(relaunch_argv(a.gpus, sys.argv[1:]), env=dict(os.environ)))
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints its version banner to the C
     # stdout of every rank, flushed at exit, i.e. after anything printed here): fd 1 is pointed at stderr for the whole
     # run and the JSON line goes to the saved descriptor at the very end.
@@ -96,7 +111,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (a.gpus, world))
+    # SLIDE_BENCH_SHARE_GPU=1 (test knob for 1-GPU boxes): every rank uses device 0 and the collectives run on gloo
+    share = os.environ.get("SLIDE_BENCH_SHARE_GPU", "0") != "0"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # SLIDE_FORCE_DIST=1: also take the RCCL path (init, barrier, all-gather, all-reduce) in a single-rank run
@@ -104,7 +124,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # bound to this rank's GPU
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # bound to this rank's GPU
     B = a.batch
 
     pc, fc = configs.position_ddpm_config(), configs.feature_ddpm_config()
@@ -143,11 +166,19 @@ def main():
     elif a.replay == "eager":
         joint = EagerChainsSampler([s_[0] for s_ in subs[:1]] + [pos] + [s_[0] for s_ in subs[1:]])
     rs = np.random.RandomState(rank)
+    # chain starts: x_T is drawn ON THE DEVICE (torch's Philox generator; plumbing) and labels / key points are resident,
+    # so that a restart inside the timed region costs a few launches, not a host RNG pass + four uploads (round 1's
+    # driver-timed 20-step number carried ~4 ms of that)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    lab_p = torch.zeros(B, dtype=torch.int64, device=dev)
+    lab_f = [torch.full((b,), 4, dtype=torch.int64, device=dev) for b in sizes]
+    kp_dev = [torch.as_tensor(k_, device=dev) for _, _, k_ in subs]
 
     def reset():
-        pos.begin(np.zeros(B, np.int64), rs.standard_normal((B, 16, 3)).astype(np.float32))
-        for (f_, _, k_), b in zip(subs, sizes):
-            f_.begin(np.full(b, 4, np.int64), k_, rs.standard_normal((b, 16, 51)).astype(np.float32))
+        pos.begin(lab_p, torch.randn(B, 16, 3, device=dev, generator=gen))
+        for (f_, _, _), b, l_, k_ in zip(subs, sizes, lab_f, kp_dev):
+            f_.begin(l_, k_, torch.randn(b, 16, 51, device=dev, generator=gen))
 
     def run(n):  # n reverse steps of each DDPM; chains restart from fresh noise every 1000 steps
         done = 0
@@ -163,15 +194,16 @@ def main():
             f_.stream.synchronize()
         torch.cuda.synchronize(dev)
         if use_dist:
-            dist.barrier(device_ids=[local])
+            dist.barrier() if share else dist.barrier(device_ids=[local])
 
     run(max(a.warmup, 1))
-    gathered = [torch.empty(B, 16, 51, device=dev) for _ in range(world)] if use_dist else None
+    gdev = torch.device("cpu") if share else dev
+    gathered = [torch.empty(B, 16, 51, device=gdev) for _ in range(world)] if use_dist else None
 
     def gather_latents():  # the single collective of the path: all ranks' latents (835 KB / rank at B=256)
         for f_, _, _ in subs:
             f_.stream.synchronize()
-        dist.all_gather(gathered, torch.cat([f_.engine.x.reshape(-1, 16, 51) for f_, _, _ in subs], 0))
+        dist.all_gather(gathered, torch.cat([f_.engine.x.reshape(-1, 16, 51) for f_, _, _ in subs], 0).to(gdev))
 
     if use_dist:
         gather_latents()  # untimed, like the warm-up steps: the first call builds RCCL's channels
@@ -183,7 +215,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if use_dist:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=gdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     finite = bool(torch.isfinite(pos.state()).all().item()) and all(bool(torch.isfinite(f_.state()).all().item())

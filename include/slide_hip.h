@@ -66,7 +66,7 @@ SLIDE_API int three_interpolate_grad_kernel_wrapper(int b, int c, int n, int m, 
 
 /* ------------------------------------------------------------------ Part 2: pytorch3d.ops.knn */
 /* p1 (b,n1,3), p2 (b,n2,3), lengths2 (b) int64 or NULL -> dists (b,n1,K) f32 ascending squared L2,
- * idx (b,n1,K) int64; ties -> lower index; K <= 128.  Slots beyond lengths2 stay (0, 0). */
+ * idx (b,n1,K) int64; ties -> lower index; K <= 64 (returns -2 beyond).  Slots beyond lengths2 stay (0, 0). */
 SLIDE_API int slide_knn_points(int b, int n1, int n2, int K, const float *p1, const float *p2,
                      const int64_t *lengths2, float *dists, int64_t *idx, slide_stream_t stream);
 /* x (b,n2,u), idx (b,n1,K) int64 -> out (b,n1,K,u) */

@@ -472,9 +472,11 @@ def latent_diffusion_params(cfg):
     }
 
 
-def feature_sampling(net, dp, keypoint, label, x, draw, t_start=None, t_end=0, keypoint_dim=3):
+def feature_sampling(net, dp, keypoint, label, x, draw, t_start=None, t_end=0, keypoint_dim=3, complete_x0=None,
+                     keypoint_mask=None):
     """LatentDiffusion.denoise_and_reconstruct loop (P2/diffusion_utils/diffusion.py:380-400) +
-    denoising_step (:58-95), keypoint_conditional, no local resampling, WITHOUT the decode.
+    denoising_step (:58-95), keypoint_conditional, WITHOUT the decode.  complete_x0 (B,N,3+F) + keypoint_mask (B,N):
+    the local re-sampling branch (:76-79), pred_xstart = pred_xstart*mask + complete_x0*(1-mask).
     `x` = starting state (B,N,3+F); `draw()` = randn_like(x), called EVERY step (also at t == 0
     where it is masked out, :88-91); reverse steps i = t_start .. t_end inclusive."""
     f = lambda a, t: F32(a[t])  # extract(): table cast to float32 then gathered (:31-39)
@@ -489,6 +491,9 @@ def feature_sampling(net, dp, keypoint, label, x, draw, t_start=None, t_end=0, k
         x0 = (f(dp["sqrt_recip_alphas_cumprod"], i) * x - f(dp["sqrt_recipm1_alphas_cumprod"], i) * eps).astype(F32)
         if dp["data_clamp_range"] > 0:
             x0 = np.clip(x0, -dp["data_clamp_range"], dp["data_clamp_range"]).astype(F32)
+        if complete_x0 is not None:
+            m = keypoint_mask.astype(F32)[:, :, None]
+            x0 = (x0 * m + complete_x0.astype(F32) * (1 - m)).astype(F32)
         mean = (f(dp["posterior_mean_coef1"], i) * x0 + f(dp["posterior_mean_coef2"], i) * x).astype(F32)
         mask = F32(0.0 if i == 0 else 1.0)
         x = (mean + mask * np.exp(F32(0.5) * f(dp["logvar"], i)).astype(F32) * draw()).astype(F32)

@@ -60,7 +60,7 @@ def main():
         lab = np.concatenate([lab, np.zeros(B - n, np.int64)])  # the plan is built for a fixed batch; pad the last one
         return smp.sample(lab, rs.standard_normal((B, 16, 3)).astype(np.float32))[:n]
 
-    pts, timing = generate_latents(a.num_samples, B, labels, run_batch, rank, world, gather_device=dev)
+    pts, timing = generate_latents(a.num_samples, B, labels, run_batch, rank, world, gather_device=dev, row_shape=(16, 3))
     if rank == 0:
         f = save_generated(a.save_dir, pts.cpu().numpy(), labels, np.resize(timing, a.num_samples), 16)
         print("Generated samples have been saved to", f)

@@ -1724,8 +1724,11 @@ __device__ __forceinline__ void philox_round(uint32_t &c0, uint32_t &c1, uint32_
                  n3 = (uint32_t)p0;
   c0 = n0; c1 = n1; c2 = n2; c3 = n3;
 }
-__device__ __forceinline__ float philox_normal(uint32_t seed_lo, uint32_t seed_hi, uint32_t step, uint32_t elem) {
-  uint32_t c0 = elem, c1 = step, c2 = 0x243F6A88u, c3 = 0x85A308D3u, k0 = seed_lo, k1 = seed_hi;
+// counter = (element, step, chain nonce, constant), key = seed: every chain a sampler starts (t_dev[3], bumped by the host
+// side's begin()) draws its own noise trajectory, like the reference's fresh torch.randn per batch
+__device__ __forceinline__ float philox_normal(uint32_t seed_lo, uint32_t seed_hi, uint32_t step, uint32_t elem,
+                                               uint32_t nonce) {
+  uint32_t c0 = elem, c1 = step, c2 = 0x243F6A88u ^ nonce, c3 = 0x85A308D3u, k0 = seed_lo, k1 = seed_hi;
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
     philox_round(c0, c1, c2, c3, k0, k1);
@@ -1753,7 +1756,8 @@ __device__ __forceinline__ void advance_t_last_block(int *t_dev, int t, int step
 __device__ __forceinline__ void update_feat_element(int e, int npts, int C, int kdim, int eps_ld, float clamp,
                                                     uint32_t seed_lo, uint32_t seed_hi, float *__restrict__ x,
                                                     const float *__restrict__ eps, const float *__restrict__ noise, int t,
-                                                    int step, const float *__restrict__ keypoint,
+                                                    int step, uint32_t nonce, const float *__restrict__ complete_x0,
+                                                    const float *__restrict__ kmask, const float *__restrict__ keypoint,
                                                     const float *__restrict__ rc, const float *__restrict__ rm1,
                                                     const float *__restrict__ c1, const float *__restrict__ c2,
                                                     const float *__restrict__ stdv) {
@@ -1767,10 +1771,14 @@ __device__ __forceinline__ void update_feat_element(int e, int npts, int C, int 
   const float xv = x[e];
   float x0 = rc[t] * xv - rm1[t] * eps[eps_ld ? (size_t)p * eps_ld + c : (size_t)e];
   if (clamp > 0.f) x0 = fminf(fmaxf(x0, -clamp), clamp);
+  if (complete_x0) {  // local re-sampling (diffusion.py:76-79): pred_xstart*mask + complete_x0*(1-mask), mask per point
+    const float m = kmask[p];
+    x0 = x0 * m + complete_x0[e] * (1.f - m);
+  }
   float v = c1[t] * x0 + c2[t] * xv;
   if (t > 0) {
     const float z = noise ? noise[(size_t)step * npts * C + e]
-                          : philox_normal(seed_lo, seed_hi, (uint32_t)step, (uint32_t)e);
+                          : philox_normal(seed_lo, seed_hi, (uint32_t)step, (uint32_t)e, nonce);
     v = v + stdv[t] * z;
   }
   x[e] = v;
@@ -1789,7 +1797,8 @@ __global__ __launch_bounds__(256) void update_pos_kernel(int n, int eps_ld, uint
     const int ep = eps_ld ? (e / 3) * eps_ld + e % 3 : e;  // eps rows may be padded (the plan's last GEMM output)
     float v = (x[e] - c_eps[t] * eps[ep]) / sqrt_alpha[t];
     if (t > 0) {
-      const float z = noise ? noise[(size_t)step * n + e] : philox_normal(seed_lo, seed_hi, (uint32_t)step, (uint32_t)e);
+      const float z = noise ? noise[(size_t)step * n + e]
+                            : philox_normal(seed_lo, seed_hi, (uint32_t)step, (uint32_t)e, (uint32_t)t_dev[3]);
       v = v + sigma[t] * z;
     }
     x[e] = v;
@@ -1805,14 +1814,17 @@ __global__ __launch_bounds__(256) void update_feat_kernel(int npts, int C, int k
                                                           int *__restrict__ t_dev, const float *__restrict__ keypoint,
                                                           const float *__restrict__ rc, const float *__restrict__ rm1,
                                                           const float *__restrict__ c1, const float *__restrict__ c2,
-                                                          const float *__restrict__ stdv) {
+                                                          const float *__restrict__ stdv,
+                                                          const float *__restrict__ complete_x0,
+                                                          const float *__restrict__ kmask) {
 #pragma clang fp contract(off)
   const int t = t_dev[0], step = t_dev[1];
+  const uint32_t nonce = (uint32_t)t_dev[3];
   // four elements per thread: a quarter of the blocks queue on the completion counter
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     update_feat_element(blockIdx.x * 1024 + j * 256 + threadIdx.x, npts, C, kdim, eps_ld, clamp, seed_lo, seed_hi, x, eps, noise,
-                        t, step, keypoint, rc, rm1, c1, c2, stdv);
+                        t, step, nonce, complete_x0, kmask, keypoint, rc, rm1, c1, c2, stdv);
   advance_t_last_block(t_dev, t, step);
 }
 
@@ -1823,13 +1835,24 @@ __global__ void advance_t_kernel(int *t_dev) {
   }
 }
 
+// hipFuncSetAttribute is per device: the "already raised the dynamic-LDS limit" flags are kept per device so that one
+// process may drive plans on several GPUs (first use of a kernel on each device must still happen outside stream capture
+// and from one thread, as for any lazily initialised runtime state)
+constexpr int SLIDE_MAX_DEVICES = 64;
+inline int current_device_slot() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return d >= 0 && d < SLIDE_MAX_DEVICES ? d : 0;
+}
+
 template <int PREC, int NPXL, int CBW>
 int launch_gemm(const GemmArgs &a, hipStream_t s) {
   constexpr int LDK = TileT<PREC>::LDK;
   const size_t shm = 2 * (size_t)(TM + 32 * CBW) * LDK * sizeof(typename TileT<PREC>::T) + CBW * (sizeof(SlideEpi) + 96 * 4) + 16;
   const int ntc = (a.n_cob + CBW - 1) / CBW, ntr = (a.rows + TM - 1) / TM;
   const int grid = ((ntr + 7) / 8) * 8 * ntc;
-  static bool attr_set = false;
+  static bool attr_done[SLIDE_MAX_DEVICES] = {};
+  bool &attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<PREC, NPXL, CBW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -1852,7 +1875,8 @@ int launch_gemm_glds(const GemmArgs &a, hipStream_t s) {
   b.shm_bytes = (int)((shm + 15) & ~(size_t)15);
   if (b.sched && grid > 512 && NST <= 3) grid = 512;  // persistent: two resident workgroups per CU pull the tiles
   else b.sched = nullptr;
-  static bool attr_set = false;
+  static bool attr_done[SLIDE_MAX_DEVICES] = {};
+  bool &attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_glds_kernel<NPXL, CBW, NST, BKT, AFF, GAT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, NST > 3 ? 160 * 1024 : 84 * 1024 * (BKT / 32));
@@ -1872,7 +1896,8 @@ int launch_gemm_occ3(const GemmArgs &a, hipStream_t s) {
   GemmArgs b = a;
   b.shm_bytes = (int)((shm + 15) & ~(size_t)15);
   b.sched = nullptr;
-  static bool attr_set = false;
+  static bool attr_done[SLIDE_MAX_DEVICES] = {};
+  bool &attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_glds_occ3_kernel<NPXL, AFF, GAT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 53 * 1024);
@@ -1889,7 +1914,8 @@ int launch_gemm_glds8(const GemmArgs &a, hipStream_t s) {
   if (shm > 160 * 1024) return -8;
   const int ntc = (a.n_cob + 2 * CBW - 1) / (2 * CBW), ntr = (a.rows + TM - 1) / TM;
   const int grid = ((ntr + 7) / 8) * 8 * ntc;
-  static bool attr_set = false;
+  static bool attr_done[SLIDE_MAX_DEVICES] = {};
+  bool &attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_glds8_kernel<NPXL, CBW, NST>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1906,7 +1932,8 @@ template <int NST, bool AFF>
 int launch_gemm_small_t(const GemmArgs &a, hipStream_t s) {
   const size_t shm = (size_t)4 * NST * 8192 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32 + (AFF ? (size_t)4 * 2 * a.k_pad * 2 + 1024 : 0);
   const int grid = ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2);
-  static bool attr_set = false;
+  static bool attr_done[SLIDE_MAX_DEVICES] = {};
+  bool &attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_small_kernel<NST, AFF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -2042,7 +2069,8 @@ int run_attn_tail(const SlideOp &o, hipStream_t s) {
   const size_t shm = (size_t)SLIDE_ATTN_NST * (TM + 64) * 64 + 4 * 2 * 32 * 4 + 64;
   const int ntc = (a.n_cob + 1) / 2, ntr = (a.rows + TM - 1) / TM;
   const int grid = ((ntr + 7) / 8) * 8 * ntc;
-  static bool attr_set = false;
+  static bool attr_done[SLIDE_MAX_DEVICES] = {};
+  bool &attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_tail_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_tail_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
@@ -2142,7 +2170,8 @@ int run_op(const SlideOp &o, hipStream_t s) {
       hipLaunchKernelGGL(update_feat_kernel, dim3((o.i[0] * o.i[1] + 1023) / 1024), dim3(256), 0, s, o.i[0], o.i[1],
                          o.i[2], o.i[5], o.f[0], (uint32_t)o.i[3], (uint32_t)o.i[4], (float *)o.p[0], (const float *)o.p[1],
                          (const float *)o.p[2], (int *)o.p[3], (const float *)o.p[4], (const float *)o.p[5],
-                         (const float *)o.p[6], (const float *)o.p[7], (const float *)o.p[8], (const float *)o.p[9]);
+                         (const float *)o.p[6], (const float *)o.p[7], (const float *)o.p[8], (const float *)o.p[9],
+                         (const float *)o.p[10], (const float *)o.p[11]);
       break;
     case SLIDE_OP_ATTN_TAIL:
       return run_attn_tail(o, s);
@@ -2180,8 +2209,10 @@ int slide_run_ops(const SlideOp *ops, int n, slide_stream_t stream) { return sli
 // issued so far on lane `from` (event record + stream wait -> a plain edge when captured into a hipGraph).
 int slide_run_ops2(const SlideOp *ops, int n, slide_stream_t stream0, slide_stream_t stream1) {
   hipStream_t ss[2] = {(hipStream_t)stream0, (hipStream_t)stream1};
-  static hipEvent_t pool[256];
-  static int pool_n = 0, pool_next = 0;
+  // fork / join events of the two-lane plans: one small pool per host thread (events belong to the device that was
+  // current when they were created; a thread drives one device)
+  static thread_local hipEvent_t pool[256];
+  static thread_local int pool_n = 0, pool_next = 0;
   for (int i = 0; i < n; ++i) {
     const SlideOp &o = ops[i];
     if (o.kind == SLIDE_OP_SYNC) {

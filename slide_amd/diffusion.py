@@ -125,10 +125,23 @@ class _GraphedSampler:
                 check(L.slide_graph_launch(self.graph, s), "graph_launch")
 
     def _set_state(self, x, t_start):
+        """starts a chain: state, timestep, step counter 0 and a fresh NONCE in t_dev[3] -- the in-kernel noise is keyed on
+        (seed, nonce, step, element), so consecutive chains of one sampler (the batches of a generation run) draw
+        independent noise like the reference's per-batch torch.randn (pointnet2/util.py:252, diffusion.py:88)."""
         e = self.engine
+        if not hasattr(self, "_t_init"):
+            self._t_init = {}
         with torch.cuda.stream(self.stream):
             e.x.copy_(torch.as_tensor(x).to(self.device, torch.float32).reshape(e.x.shape))
-            e.t_dev.copy_(torch.tensor([t_start, 0, 0, 0], dtype=torch.int32))
+            t0 = self._t_init.get(int(t_start))
+            if t0 is None:  # device-resident [t, step, blocks-done]: restarting a chain needs no host upload
+                t0 = self._t_init[int(t_start)] = torch.tensor([t_start, 0, 0], dtype=torch.int32).to(self.device)
+            e.t_dev[:3].copy_(t0)
+            e.t_dev[3:].add_(1)  # chain nonce (starts at 1)
+
+    def _order_after_current(self):
+        """inputs handed to begin() may have been produced on the caller's current stream"""
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
 
     def advance(self, n_steps):
         """replay n reverse steps from the current device-side state (no host sync)"""
@@ -175,6 +188,7 @@ class PositionSampler(_GraphedSampler):
         return self.state()
 
     def begin(self, label, x_T, t_start=None):
+        self._order_after_current()
         with torch.cuda.stream(self.stream):
             self.engine.set_label(label)
             self._set_state(x_T, self.T - 1 if t_start is None else t_start)
@@ -184,7 +198,7 @@ class FeatureSampler(_GraphedSampler):
     """LatentDiffusion.denoise_and_reconstruct without the decode -- pointnet2/diffusion_utils/diffusion.py:346-400."""
 
     def __init__(self, hp, state_dict, batch, device, standard_diffusion_config, prec="fp32", noise=None, seed=0,
-                 use_graph=True, keypoint_dim=3):
+                 use_graph=True, keypoint_dim=3, local_resampling=False):
         super().__init__(hp, state_dict, batch, device, prec, use_graph, standard_diffusion_config["num_diffusion_timesteps"])
         e = self.engine
         dp = latent_diffusion_params(standard_diffusion_config)
@@ -197,23 +211,42 @@ class FeatureSampler(_GraphedSampler):
         self.keypoint = e.A.zeros(self.B * 16, keypoint_dim)
         self.kdim = keypoint_dim
         assert e.out_dim == e.cx
+        # local re-sampling state: complete_x0 (B*16, 3+F) and the per-point mask (B*16); set per chain by begin()
+        self.resample = (e.A.zeros(self.B * 16, e.cx), e.A.zeros(self.B * 16)) if local_resampling else None
         self._finish_plan(make_op(OP_UPDATE_FEAT, i=(self.B * 16, e.cx, keypoint_dim, seed & 0xFFFFFFFF,
                                                      (seed >> 32) & 0xFFFFFFFF, e.eps_pad.shape[1]),
                                   f=(float(dp["data_clamp_range"]),),
                                   p=(e.x.data_ptr(), e.eps_pad.data_ptr(), None if self.noise is None else self.noise.data_ptr(),
                                      e.t_dev.data_ptr(), self.keypoint.data_ptr(), self.tabs[0].data_ptr(),
                                      self.tabs[1].data_ptr(), self.tabs[2].data_ptr(), self.tabs[3].data_ptr(),
-                                     self.tabs[4].data_ptr())), fixed_xyz=keypoint_dim == 3)
+                                     self.tabs[4].data_ptr(),
+                                     None if self.resample is None else self.resample[0].data_ptr(),
+                                     None if self.resample is None else self.resample[1].data_ptr())),
+                          fixed_xyz=keypoint_dim == 3)
 
-    def sample(self, label, keypoint, x_T, t_start=None, n_steps=None):
+    def sample(self, label, keypoint, x_T, t_start=None, n_steps=None, complete_x0=None, keypoint_mask=None):
         t_start = self.T - 1 if t_start is None else t_start
         n_steps = t_start + 1 if n_steps is None else n_steps
-        self.begin(label, keypoint, x_T, t_start)
+        self.begin(label, keypoint, x_T, t_start, complete_x0=complete_x0, keypoint_mask=keypoint_mask)
         self.advance(n_steps)
         return self.state()  # the key-point channels are re-clamped to the condition by every update (:395-397)
 
-    def begin(self, label, keypoint, x_T, t_start=None):
+    def begin(self, label, keypoint, x_T, t_start=None, complete_x0=None, keypoint_mask=None):
+        """complete_x0 (B,16,3+F) / keypoint_mask (B,16) in {0,1}: local re-sampling (diffusion.py:76-79,352-359) --
+        only the points with mask 1 are re-generated, the predicted x0 of the others is pinned to complete_x0."""
+        self._order_after_current()
+        if (complete_x0 is None) != (keypoint_mask is None):
+            raise ValueError("local resampling needs both complete_x0 and keypoint_mask")
+        if complete_x0 is not None and self.resample is None:
+            raise ValueError("this FeatureSampler was built without local_resampling=True")
         with torch.cuda.stream(self.stream):
+            if self.resample is not None:
+                cx, km = self.resample
+                if complete_x0 is None:  # plain generation on a resampling-capable sampler: mask of ones
+                    km.fill_(1.0)
+                else:
+                    cx.copy_(torch.as_tensor(complete_x0).to(self.device, torch.float32).reshape(cx.shape))
+                    km.copy_(torch.as_tensor(keypoint_mask).to(self.device, torch.float32).reshape(km.shape))
             kp = torch.as_tensor(keypoint).to(self.device, torch.float32).reshape(self.B, 16, self.kdim)
             x = torch.as_tensor(x_T).to(self.device, torch.float32).reshape(self.B, 16, -1).clone()
             x[:, :, :self.kdim] = kp  # diffusion.py:383-385

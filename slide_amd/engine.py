@@ -45,7 +45,7 @@ class SlideGnFin(ctypes.Structure):
 
 class SlideOp(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("i", ctypes.c_int32 * 11), ("f", ctypes.c_float * 4),
-                ("p", ctypes.c_void_p * 10)]
+                ("p", ctypes.c_void_p * 12)]
 
 
 def ru(x, m=32):

@@ -51,9 +51,12 @@ def all_gather_rows(local, num_samples, world_size, device=None):
     return torch.cat(rows, dim=0)
 
 
-def generate_latents(num_samples, batch_size, labels, run_batch, rank=0, world_size=1, gather_device=None):
+def generate_latents(num_samples, batch_size, labels, run_batch, rank=0, world_size=1, gather_device=None,
+                     row_shape=None, row_dtype=torch.float32):
     """Drives `run_batch(labels_np [b], lo, hi) -> (b, ...) tensor/ndarray` over this rank's slice and gathers.
-    labels: int array [num_samples].  Returns (latents [num_samples, ...] on every rank, per-sample seconds [n_local])."""
+    labels: int array [num_samples].  Returns (latents [num_samples, ...] on every rank, per-sample seconds [n_local]).
+    row_shape / row_dtype: shape of one output row, e.g. (16, 51); lets a rank whose slice is EMPTY (more ranks than
+    samples) join the all-gather without running a chain just to learn the shape."""
     start, end = shard_range(num_samples, rank, world_size)
     outs, timing = [], []
     for lo, hi in batches(start, end, batch_size):
@@ -63,11 +66,15 @@ def generate_latents(num_samples, batch_size, labels, run_batch, rank=0, world_s
             torch.cuda.synchronize(o.device)  # the reference's timer stops without a device sync (mesh_evaluation.py:126)
         timing.extend([(time.time() - t0) / (hi - lo)] * (hi - lo))
         outs.append(o)
-    if outs:
-        local = torch.cat(outs, dim=0)
-    else:  # a rank with an empty slice still takes part in the collective
-        probe = torch.as_tensor(run_batch(np.asarray(labels[:1]), 0, 1))
-        local = probe[:0]
+    local = torch.cat(outs, dim=0) if outs else None
+    if row_shape is None and world_size > 1:
+        # one tiny object collective tells a rank with an EMPTY slice (more ranks than samples) the row shape; it does
+        # not run a throw-away 1000-step chain to learn it
+        shapes = [None] * world_size
+        dist.all_gather_object(shapes, None if local is None else (tuple(local.shape[1:]), local.dtype))
+        row_shape, row_dtype = next(s_ for s_ in shapes if s_ is not None)
+    if local is None:  # a rank with an empty slice still takes part in the all-gather
+        local = torch.empty((0,) + tuple(row_shape or ()), dtype=row_dtype, device=gather_device)
     full = all_gather_rows(local, num_samples, world_size, device=gather_device)
     return full, np.asarray(timing)
 

@@ -98,7 +98,9 @@ class HipConv1x1(nn.Module):
             return out
         x2 = x.reshape(B, C, -1).permute(0, 2, 1).reshape(rows, C)
         y = plan(x2)
-        return y.reshape(B, -1, self.out_channels).permute(0, 2, 1).reshape((B, self.out_channels) + tuple(sp)).contiguous()
+        # .clone(): when the permute is a no-op view (one pixel per sample), .contiguous() would alias the plan's persistent
+        # output buffer, which the next call with the same row count overwrites
+        return y.reshape(B, -1, self.out_channels).permute(0, 2, 1).reshape((B, self.out_channels) + tuple(sp)).clone(memory_format=torch.contiguous_format)
 
 
 class HipLinear(nn.Module):

@@ -28,13 +28,25 @@ def synth_state_dict(spec, seed=0):
     return {n: synth_tensor(n, s, seed) for n, s in items}
 
 
-def synth_keypoints(batch, npoint=16, seed=0):
-    """'GT-like' synthetic key points: points on an ellipsoid
-    surface in roughly [-1,1]^3, first point the centroid (the reference prepends the centroid
-    before FPS, P2/data_utils/points_sampling.py:156-187)."""
+def synth_keypoints(batch, npoint=16, seed=0, cloud_points=2048):
+    """'GT-like' synthetic key points built the way the reference builds ground-truth key points (SURVEY.md section 8(d)
+    config 3): a `cloud_points`-point cloud in roughly [-1,1]^3 (here: seeded samples on an ellipsoid surface, the
+    stand-in for a ShapeNet surface x2), the CENTROID PREPENDED, then farthest-point sampling to `npoint` starting at the
+    centroid -- sample_keypoints(add_centroid=True) -> pytorch3d sample_farthest_points(random_start_point=False)
+    (pointnet2/data_utils/points_sampling.py:156-187; call site train_latent_ddpm.py:187-193).  Plain numpy FPS
+    (difference-form squared distances, first maximum wins); key point 0 is therefore the centroid."""
     rs = np.random.RandomState(1234 + seed)
-    v = rs.standard_normal((batch, npoint, 3))
+    v = rs.standard_normal((batch, cloud_points, 3))
     v /= np.linalg.norm(v, axis=2, keepdims=True)
     v *= np.array([0.9, 0.35, 0.6])[None, None]
-    v[:, 0] = v[:, 1:].mean(axis=1)
-    return v.astype(np.float32)
+    v += 0.02 * rs.standard_normal(v.shape)  # not a perfect quadric: breaks exact ties
+    v = v.astype(np.float32)
+    x = np.concatenate([v.mean(axis=1, keepdims=True, dtype=np.float32), v], axis=1)  # (B, P+1, 3)
+    sel = np.zeros((batch, npoint), np.int64)
+    d = np.full((batch, x.shape[1]), np.inf, np.float32)
+    ar = np.arange(batch)
+    for j in range(1, npoint):
+        last = x[ar, sel[:, j - 1]][:, None, :]
+        d = np.minimum(d, ((x - last) ** 2).sum(axis=2, dtype=np.float32))
+        sel[:, j] = d.argmax(axis=1)
+    return np.ascontiguousarray(x[ar[:, None], sel]).astype(np.float32)

@@ -38,7 +38,12 @@ def _worker(rank, world, port, n, tmp):
         idx = torch.arange(lo, hi, dtype=torch.float32)
         return (idx[:, None, None] * 100 + torch.as_tensor(lab, dtype=torch.float32)[:, None, None]).expand(hi - lo, 16, 51).clone()
 
+    calls = []
+    inner = run_batch
+    run_batch = lambda lab, lo, hi: (calls.append((lo, hi)), inner(lab, lo, hi))[1]
     full, timing = generate_latents(n, 3, labels, run_batch, rank, world)
+    s0, e0 = shard_range(n, rank, world)
+    assert calls == list(batches(s0, e0, 3))  # a rank with an empty slice runs NO batch (no throw-away probe chain)
     s, e = shard_range(n, rank, world)
     assert timing.shape == (e - s,)
     want = (torch.arange(n, dtype=torch.float32)[:, None, None] * 100 + torch.as_tensor(labels, dtype=torch.float32)[:, None, None]).expand(n, 16, 51)
@@ -55,7 +60,7 @@ def _worker(rank, world, port, n, tmp):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [11, 2])
-def test_two_rank_generation_gloo(tmp_path, n):
+@pytest.mark.parametrize("n,world", [(11, 2), (2, 2), (2, 3)])
+def test_multi_rank_generation_gloo(tmp_path, n, world):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, n, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)

@@ -76,3 +76,33 @@ def test_checkpoint_layout(tmp_path):
     out = load_denoiser_state(hp, str(f), ema_idx=1)
     k0 = list(ema)[0]
     assert np.array_equal(out[k0], ema[k0].numpy()) and np.array_equal(out["fc_lyaer.3.bias"], sd["fc_lyaer.3.bias"].numpy())
+
+
+def test_bench_self_launch_argv(monkeypatch):
+    """`python bench.py --gpus N` outside a launcher re-executes itself as N ranks under torch.distributed.run (the
+    reference's launcher spawns its per-GPU workers itself: pointnet2/distributed.py:171-182)"""
+    import importlib.util
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    argv = bench.relaunch_argv(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], port=29999)
+    assert argv[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert argv[argv.index("--nproc-per-node") + 1] == "8" and "--nnodes=1" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and argv[argv.index("--master-port") + 1] == "29999"
+    k = argv.index(os.path.join(root, "bench.py"))
+    assert argv[k + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    # main(): with --gpus 2 and no WORLD_SIZE it must spawn (not assert) and pass the child's exit status on
+    calls = []
+    import subprocess
+    monkeypatch.setattr(subprocess, "call", lambda cmd, **kw: (calls.append(cmd), 7)[1])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    try:
+        bench.main()
+        raise AssertionError("main() should have exited with the launcher's status")
+    except SystemExit as e:
+        assert e.code == 7
+    assert len(calls) == 1 and calls[0][calls[0].index("--nproc-per-node") + 1] == "2" and calls[0][-4:] == ["--gpus", "2", "--steps", "3"]

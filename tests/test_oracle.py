@@ -240,6 +240,25 @@ def test_feature_sampler_against_reference():
     assert np.abs(x - g["tail_x0"]).max() <= 1e-3 * np.abs(g["tail_x0"]).max()
 
 
+def test_feature_sampler_local_resampling_against_reference():
+    """denoise_and_reconstruct(local_resampling=True) (diffusion.py:76-79,352-359): golden recorded from the reference"""
+    g = load_golden("golden_sampler_feat_resample.npz")
+    net = _net("feat")
+    size = g["head_x"].shape
+    for tag in ("head", "short"):
+        cfg = json.loads(str(g[tag + "_config_json"]))
+        dp = D.latent_diffusion_params(cfg)
+        T, n = cfg["num_diffusion_timesteps"], int(g[tag + "_nsteps"])
+        ns = NoiseStream(g[tag + "_seed"])
+        x = D.feature_sampling(net, dp, g["keypoint"], g["label"], ns(size), lambda: ns(size), t_start=T - 1, t_end=T - n,
+                               complete_x0=g["complete_x0"], keypoint_mask=g["keypoint_mask"])
+        assert ns.count == int(g[tag + "_ndraws"])
+        assert np.abs(x - g[tag + "_x"]).max() <= 1e-3 * np.abs(g[tag + "_x"]).max(), tag
+    # the chain that ran to t = 0: unmasked points end exactly at complete_x0 (coef2[0] == 0, no noise at t == 0)
+    keep = g["keypoint_mask"] == 0
+    assert np.abs(g["short_x"][keep] - g["complete_x0"][keep]).max() <= 1e-5
+
+
 def test_autoencoder_decode_against_reference():
     """PointAutoencoder.decode levels (config 5) vs the reference's output.  Farthest-point-sampling SELECTION ORDER is
     fragile under 1e-7 perturbations (the selected set is not), so levels are compared as point sets, each level fed with

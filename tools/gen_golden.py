@@ -189,6 +189,48 @@ def gen_sampler_feat(net, cfg, out, B=2):
     print("sampler feat: head draws", res["head_ndraws"], "tail draws", res["tail_ndraws"])
 
 
+def gen_sampler_feat_resample(out, B=2):
+    """LatentDiffusion.denoise_and_reconstruct(local_resampling=True) (diffusion.py:346-359, :76-79): features are
+    re-generated only on the points with keypoint_mask == 1, the predicted x0 of the others is pinned to complete_x0.
+    Recorded: a 20-step head from x_T and the last 20 steps are not reachable with x given (the reference asserts
+    x is None in this mode), so the fixture is a 12-step chain from x_T on a diffusion object with T shrunk to 12 for the
+    tail behaviour (t = 11..0, includes the noise-free last step) plus a 20-step head at T = 1000."""
+    from diffusion_utils import diffusion as D
+    cfg = load_cfg(FEAT_CFG)
+    net, _ = build_net(cfg)
+    res = {}
+    label = torch.tensor([4, 4][:B]).long()
+    keypoint = torch.from_numpy(synth_keypoints(B, 16, seed=5))
+    rs = np.random.RandomState(77)
+    complete_x0 = np.concatenate([keypoint.numpy(), (0.5 * rs.standard_normal((B, 16, 48))).astype(np.float32)], axis=2)
+    mask = (rs.uniform(size=(B, 16)) < 0.4).astype(np.float32)
+    mask[0, 0], mask[0, 1] = 1.0, 0.0
+    res["label"], res["keypoint"], res["complete_x0"], res["keypoint_mask"] = label.numpy(), keypoint.numpy(), complete_x0, mask
+    for tag, T, nsteps, seed in (("head", 1000, 20, 505), ("short", 12, 12, 606)):
+        dcfg = copy.deepcopy(cfg["standard_diffusion_config"])
+        dcfg["num_diffusion_timesteps"] = T
+        with contextlib.redirect_stdout(io.StringIO()):
+            dm = D.LatentDiffusion(dcfg, autoencoder=None, device=torch.device("cpu"))
+        dm.decode = lambda latent, keypoint_dim, label: latent
+        ns = NoiseStream(seed)
+        o1, o2 = torch.randn, torch.randn_like
+        torch.randn = lambda *size, **k: ns(size)
+        torch.randn_like = lambda x, **k: ns(x.shape)
+        try:
+            with torch.no_grad():
+                _, kp, feat = dm.denoise_and_reconstruct(B, net, 3, (16, 51), label=label, keypoint=keypoint,
+                                                         return_keypoint_feature=True, n_steps=nsteps, local_resampling=True,
+                                                         complete_x0=torch.from_numpy(complete_x0),
+                                                         keypoint_mask=torch.from_numpy(mask))
+        finally:
+            torch.randn, torch.randn_like = o1, o2
+        res[tag + "_config_json"] = np.array(json.dumps(dcfg))
+        res[tag + "_seed"], res[tag + "_nsteps"], res[tag + "_ndraws"] = np.array(seed), np.array(nsteps), np.array(ns.count)
+        res[tag + "_x"] = torch.cat([kp, feat], dim=2).numpy()
+    np.savez_compressed(os.path.join(out, "golden_sampler_feat_resample.npz"), **res)
+    print("sampler feat resample: draws", res["head_ndraws"], res["short_ndraws"])
+
+
 def gen_blocks(out):
     """stand-alone reference modules on seeded inputs, covering branches the DDPM configs skip"""
     from pointnet2_ops import pointnet2_utils as PU
@@ -403,7 +445,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.manual_seed(0)
-    want = set(a.only.split(",")) if a.only else {"ops", "blocks", "pos", "feat", "decode", "encode"}
+    want = set(a.only.split(",")) if a.only else {"ops", "blocks", "pos", "feat", "resample", "decode", "encode"}
     if "ops" in want:
         gen_ops(a.out)
     if "blocks" in want:
@@ -414,6 +456,8 @@ if __name__ == "__main__":
     if "feat" in want:
         net, cfg = gen_denoiser("feat", FEAT_CFG, a.out)
         gen_sampler_feat(net, cfg, a.out)
+    if "resample" in want:
+        gen_sampler_feat_resample(a.out)
     if "decode" in want:
         gen_decode(a.out)
     if "encode" in want:
