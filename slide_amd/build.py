@@ -15,7 +15,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # (source, extra flags).  point_ops needs contraction OFF (bit-exact index parity with the oracle).
 # engine: the GEMM epilogue's per-channel-block loop must unroll fully (the accumulators are indexed by it; left rolled
 # they are demoted to scratch), which needs more than LLVM's default 16k-instruction cap for `#pragma unroll`.
-SOURCES = [("point_ops.hip", ["-ffp-contract=off"]), ("engine.hip", ["-mllvm", "-pragma-unroll-threshold=100000"])]
+SOURCES = [("point_ops.hip", ["-ffp-contract=off"]), ("engine.hip", ["-mllvm", "-pragma-unroll-threshold=100000"]),
+           ("resident.hip", ["-mllvm", "-pragma-unroll-threshold=100000"])]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
           "-Wno-unused-function"]
 
