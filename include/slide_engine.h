@@ -61,7 +61,7 @@ typedef struct SlideEpi {
 } SlideEpi;
 
 enum {
-  SLIDE_OP_GEMM = 1,        /* p: X, W, epi, in_scale, in_shift, [5] timeline buffer (instrumented builds only, else NULL), [6] SlideGnFin* (16-row launches with input affine: finalise the statistics in this launch), [7] 9 zeroed ints for the optional persistent tile scheduler (NULL = one tile per workgroup), [8] point-feature table + [9] neighbour table of the GATHER mode (first GEMM of an SA / FP block: the first f[1] 32-column chunks of X row (b, p, k) are read from row b*16 + idx[(b*16+p)*16+k] of the table with row length f[2], neighbours per point 2^f[3]; p[0] / x_ld then describe only the remaining columns; with p[8] NULL, p[9] is the neighbour table of gathered pre_add terms, SlideEpi.pre_add_shift < 0); f[0]: start stagger in us for the persistent mode; i[9]: 0 = default ring, 1 = 64-deep chunks, 2 = eight-wave 256x256 tiles   i: rows, x_ld, k_pad, n_cob, npx_log2, in_bs, prec, cbw(2|4), lds_dma(0|1: fp16, no in_scale) */
+  SLIDE_OP_GEMM = 1,        /* p: X, W, epi, in_scale, in_shift, [5] timeline buffer (instrumented builds only, else NULL), [6] SlideGnFin* (16-row launches with input affine: finalise the statistics in this launch), [7] 9 zeroed ints for the optional persistent tile scheduler (NULL = one tile per workgroup), [8] point-feature table + [9] neighbour table of the GATHER mode (first GEMM of an SA / FP block: the first f[1] 32-column chunks of X row (b, p, k) are read from row b*16 + idx[(b*16+p)*16+k] of the table with row length f[2], neighbours per point 2^f[3]; p[0] / x_ld then describe only the remaining columns; with p[8] NULL, p[9] is the neighbour table of gathered pre_add terms, SlideEpi.pre_add_shift < 0); [10] non-NULL selects the X-stationary kernel for sample-wide fp16 layers whose 256-row X tile fits the LDS (one workgroup per row tile keeps X resident and computes every column tile, the weights stream through a small LDS-DMA ring; i[9] == 5 keeps the ring kernels); f[0]: start stagger in us for the persistent mode; i[9]: 0 = default ring, 1 = 64-deep chunks, 2 = eight-wave 256x256 tiles   i: rows, x_ld, k_pad, n_cob, npx_log2, in_bs, prec, cbw(2|4), lds_dma(0|1: fp16, no in_scale) */
   SLIDE_OP_PREP_POINTS = 2, /* p: x, xyz, feat0, knn_idx, knn_d2   i: B, cx, ldf, prec     (16 points / sample) */
   SLIDE_OP_ASSEMBLE_SA = 3, /* p: xyz, feat, knn_idx, g            i: B, C, ldf, ldg, K, prec, c_begin (0 = all columns; else only columns >= c_begin), ld_out */
   SLIDE_OP_ASSEMBLE_FP = 4, /* p: xyz, feat, knn_idx, knn_d2, g    i: B, C, ldf, ldg, K, prec, c_begin, ld_out */

@@ -1,0 +1,618 @@
+// gemm_common.h -- shared device code of the fused-denoiser GEMM kernels (engine.hip, gemm_xs.hip): tile constants, the
+// argument block, lane helpers and the common epilogue (bias, per-point term, ReLU, GroupNorm, t-/class-embedding add,
+// residual, stores).  Everything lives in an anonymous namespace: each translation unit gets its own copy.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "../../include/slide_engine.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct GemmArgs {
+  const void *X;
+  const void *W;
+  const SlideEpi *epi;
+  const float *in_scale, *in_shift;
+  int rows, x_ld, k_pad, n_cob, in_bs;
+  int shm_bytes;            // dynamic LDS of the launch (its last 16 bytes hold the persistent mode's tile index)
+  const SlideGnFin *gn_fin; // small-launch affine GEMM: finalise the GroupNorm statistics here (include/slide_engine.h)
+  const void *gfeat;        // gather mode (GAT kernels): point-feature table [B*16][g_ldf]; the first g_nsplit K chunks of X row
+  const int *gidx;          //   (b, p, k) are read from its row b*16 + gidx[(b*16 + p)*16 + k], the rest from X (x_ld = its own ld)
+  int g_ldf, g_nsplit, g_klog2;
+  int *sched;               // persistent-mode tile counters (9 ints, zero), or nullptr
+  int stagger;              // start delay (10 ns units) of the workgroups in odd wave slots, 0 = none
+  unsigned long long *dbg;  // optional per-workgroup timeline (tools/gemm_timeline.py): 16 x 100 MHz stamps per workgroup
+};
+
+namespace {
+
+constexpr int TM = 256;  // rows per workgroup (whole samples: 1 x 256, 2 x 128 or 16 x 16 rows)
+constexpr int BK = 32;   // K chunk staged through LDS
+constexpr float GN_EPS = 1e-5f;
+
+// PREC selects BOTH the MFMA operand type and the storage type of every activation matrix in HBM:
+//   fp32: float activations,   v_mfma_f32_32x32x2_f32   (exact; parity mode)
+//   fp16: _Float16 activations, v_mfma_f32_32x32x16_f16 (fp32 accumulate and fp32 epilogue math; throughput mode)
+template <int PREC> struct TileT;
+template <> struct TileT<SLIDE_PREC_F32> { using T = float; static constexpr int LDK = 36; static constexpr int EPL = 4; };
+template <> struct TileT<SLIDE_PREC_F16> { using T = _Float16; static constexpr int LDK = 40; static constexpr int EPL = 8; };
+
+#ifdef SLIDE_TIMELINE  // instrumented build only (tools/gemm_timeline.py); the product library carries no stamps
+#define SLIDE_STAMP(a, k)                                                                     \
+  do {                                                                                        \
+    if ((a).dbg && threadIdx.x == 0) (a).dbg[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); \
+  } while (0)
+#else
+#define SLIDE_STAMP(a, k) do { } while (0)
+#endif
+
+// sum over aligned groups of W lanes (16 or 32); every lane of the group gets the total
+template <int W>
+__device__ __forceinline__ float lane_group_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // xor 1
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // xor 2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
+  if (W == 32) v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));      // xor 16
+  return v;
+}
+
+// Epilogue descriptors are staged in LDS and read back through readfirstlane: every field lands in an SGPR, every
+// branch on it is a scalar branch, and the pointers are known GLOBAL (address space 1) so the compiler neither
+// re-loads descriptor fields after each store (aliasing) nor falls back to flat accesses.
+#define GLOBAL_AS __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ GLOBAL_AS T *gptr(uint64_t v) { return (GLOBAL_AS T *)v; }
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gload4(const GLOBAL_AS float *p) {
+  const f32x4v v = *reinterpret_cast<const GLOBAL_AS f32x4v *>(p);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ float4 gload4(const GLOBAL_AS _Float16 *p) {
+  const f16x4 h = *reinterpret_cast<const GLOBAL_AS f16x4 *>(p);
+  return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+__device__ __forceinline__ void gstore4(GLOBAL_AS float *p, float4 v) {
+  f32x4v o; o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  *reinterpret_cast<GLOBAL_AS f32x4v *>(p) = o;
+}
+__device__ __forceinline__ void gstore4(GLOBAL_AS _Float16 *p, float4 v) {
+  f16x4 h;
+  h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+  *reinterpret_cast<GLOBAL_AS f16x4 *>(p) = h;
+}
+
+// v_permlane32_swap: a[lanes 32..63] <-> b[lanes 0..31].  Written as asm: the builtin's second result was folded into
+// the first by this toolchain when both fed conversions (residual path), silently corrupting quads 2p+1.
+__device__ __forceinline__ void lane32_swap(uint32_t &a, uint32_t &b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+
+template <typename T> __device__ __forceinline__ float4 load4(const T *p);
+template <> __device__ __forceinline__ float4 load4<float>(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+template <> __device__ __forceinline__ float4 load4<_Float16>(const _Float16 *p) {
+  const f16x4 h = *reinterpret_cast<const f16x4 *>(p);
+  return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+template <typename T> __device__ __forceinline__ void store4(T *p, float4 v);
+template <> __device__ __forceinline__ void store4<float>(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+template <> __device__ __forceinline__ void store4<_Float16>(_Float16 *p, float4 v) {
+  f16x4 h;
+  h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+  *reinterpret_cast<f16x4 *>(p) = h;
+}
+
+// CBW = 32-channel output blocks per wave; the workgroup tile is 256 rows x (32*CBW) channels: the four waves
+// split the rows (64 each) and share the W panel, so every X element fetched from L2/HBM feeds 32*CBW MACs.
+constexpr int EPI_DW = (int)(sizeof(SlideEpi) / 4);
+static_assert(sizeof(SlideEpi) == 136, "descriptor layout is read by dword index in gemm_epilogue");
+
+// copies the CBW epilogue descriptors of this workgroup and their per-channel vectors [cb][bias | gamma | beta][32]
+// into LDS (visible after the caller's next barrier)
+template <int CBW, int NT = 256>
+__device__ __forceinline__ void stage_epilogue_tables(const GemmArgs &a, int cob0, int tid, uint32_t *epi_lds,
+                                                      float *vec_lds) {
+  for (int i = tid; i < CBW * EPI_DW; i += NT) {
+    const int cobi = cob0 + i / EPI_DW;
+    epi_lds[i] = cobi < a.n_cob ? reinterpret_cast<const uint32_t *>(a.epi + cobi)[i % EPI_DW] : 0u;
+  }
+  for (int i = tid; i < CBW * 96; i += NT) {
+    const int cobi = cob0 + i / 96, which = (i % 96) >> 5, c = i & 31;
+    float val = 0.f;
+    if (cobi < a.n_cob) {
+      const SlideEpi *ed = a.epi + cobi;
+      const float *src = which == 0 ? ed->bias : (which == 1 ? ed->gamma : ed->beta);
+      if (src) val = src[c];
+    }
+    vec_lds[i] = val;
+  }
+}
+
+// Shared epilogue of the GEMM kernels: acc[cb][rb] holds D[co][row] in the 32x32 MFMA C layout (lane: row = lane & 31,
+// reg r: co = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  `red` = 4*CBW*2*16*2 floats of LDS scratch (the dead tiles).
+// RB = 32-row blocks per wave (2; 1 for the split-K small-launch kernel, whose waves own one block each).
+template <int PREC, int NPXL, int CBW, int RB = 2>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[CBW][RB], int row0, int cob0, int wave,
+                                              int half, int col, const uint32_t *epi_lds, const float *vec_lds,
+                                              float *red) {
+  using T = typename TileT<PREC>::T;
+  constexpr int NPX = 1 << NPXL;
+  float *const gsh = red + 256 * CBW;  // [cb][sample][scale | shift][32], behind the partial sums
+  // PH = 0: everything for channel block cb.  Samples spanning several waves (NPX >= 128) exchange their statistics
+  // through LDS: PH = 1 (bias, partial sums -> LDS) for all blocks, ONE workgroup barrier, then PH = 2 (totals,
+  // normalisation, stores) -- instead of a barrier per channel block.
+  auto process = [&](const int cb, auto ph_tag) __attribute__((always_inline)) {
+    constexpr int PH = decltype(ph_tag)::value;
+    const int cobi = cob0 + cb;
+    if (cobi >= a.n_cob) return;  // uniform per workgroup
+    auto rd = [&](int k) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)epi_lds[cb * EPI_DW + k]); };
+    auto rdp = [&](int k) { return (uint64_t)rd(k) | ((uint64_t)rd(k + 1) << 32); };
+    const int mode = (int)rd(0), flags = (int)rd(1), e_gs = (int)rd(2), e_n_norm = (int)rd(3);
+    const float e_inv_count = __uint_as_float(rd(4)), e_stats_scale = __uint_as_float(rd(5));
+    const int e_out_ld = (int)rd(6), e_res_ld = (int)rd(7), e_addvec_bs = (int)rd(8), e_stats_bs = (int)rd(9),
+              e_pre_ld = (int)rd(10), e_pre_shift = (int)rd(11), e_idx_stride = (int)rd(12);
+    const GLOBAL_AS float *e_addvec = gptr<const float>(rdp(20));
+    const float *v_bias = vec_lds + cb * 96, *v_gamma = v_bias + 32, *v_beta = v_bias + 64;
+    const GLOBAL_AS int *e_addvec_idx = gptr<const int>(rdp(22));
+    const GLOBAL_AS T *resid = gptr<const T>(rdp(24)), *pre = gptr<const T>(rdp(26));
+    const uint64_t e_out = rdp(28);
+    GLOBAL_AS float *e_stats_sum = gptr<float>(rdp(30)), *e_stats_sq = gptr<float>(rdp(32));
+    if (PH == 2 && cb == 0) SLIDE_STAMP(a, 8);
+    // global reads of the store phase, issued first so that their latency overlaps the statistics / normalisation work
+    constexpr bool kHalf = std::is_same<T, _Float16>::value;
+    const bool wide16 = kHalf && !(flags & SLIDE_F_OUT_F32);
+    const GLOBAL_AS float *addv = e_addvec;
+    static_assert(RB == 2 || NPXL < 6, "one row block per wave only for samples of at most 32 rows");
+    constexpr int NA = NPXL >= 6 ? 1 : RB;  // a wave's 64 rows belong to one sample when NPX >= 64
+    float4 apre[NA][4];
+    u32x4 rpre[RB][2];
+    if (PH != 1) {
+      if (addv && e_addvec_idx) addv += (size_t)e_addvec_idx[0] * e_idx_stride;  // row t of a per-timestep table
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const int row = row0 + wave * 64 + rb * 32 + col;
+        const bool ok = row < a.rows;
+        if (rb < NA) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            apre[rb][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (addv && ok) apre[rb][q] = gload4(addv + (size_t)(row >> NPXL) * e_addvec_bs + 8 * q + 4 * half);
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          rpre[rb][p] = u32x4{0u, 0u, 0u, 0u};
+          if constexpr (kHalf)
+            if (wide16 && resid && ok)
+              rpre[rb][p] = *(const GLOBAL_AS u32x4 *)(resid + (size_t)row * e_res_ld + 16 * p + 8 * half);
+        }
+      }
+    }
+    // v[rb][i] = channel pair i of the lane: channels cpair(i) = 8 (i >> 1) + 4 half + 2 (i & 1) and +1.  Everything
+    // below is written on pairs so that it compiles to packed fp32 VALU ops (v_pk_add/mul/fma_f32): the epilogue's VALU
+    // instruction count, not MFMA, bounds the small-K launches (rocprofv3 SQ_INSTS_VALU vs SQ_INSTS_MFMA).
+    f32x2 v[RB][8];
+    if (PH == 2) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[rb][i] = f32x2{acc[cb][rb][2 * i], acc[cb][rb][2 * i + 1]};
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 bia = *reinterpret_cast<const float4 *>(v_bias + 8 * q + 4 * half);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          v[rb][2 * q] = f32x2{acc[cb][rb][4 * q], acc[cb][rb][4 * q + 1]} + f32x2{bia.x, bia.y};
+          v[rb][2 * q + 1] = f32x2{acc[cb][rb][4 * q + 2], acc[cb][rb][4 * q + 3]} + f32x2{bia.z, bia.w};
+        }
+      }
+      if (pre) {  // per-point term shared by the K neighbours of a point (query half of attention weight_conv.2)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          const int row = row0 + wave * 64 + rb * 32 + col;
+          if (row < a.rows) {
+            // shift >= 0: the row's point (row >> shift).  shift < 0: the row's NEIGHBOUR point, looked up in the sorted
+            // neighbour table (K = 2^-shift): per-point partial products of a block's first layer, gathered
+            size_t prow = (size_t)(row >> e_pre_shift);
+            if (e_pre_shift < 0) {
+              const int kl = -e_pre_shift, smp = row >> NPXL, pxl = row & (NPX - 1);
+              prow = (size_t)(smp * 16 + a.gidx[(smp * 16 + (pxl >> kl)) * 16 + (pxl & ((1 << kl) - 1))]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float4 u = gload4(pre + prow * e_pre_ld + 8 * q + 4 * half);
+              v[rb][2 * q] += f32x2{u.x, u.y};
+              v[rb][2 * q + 1] += f32x2{u.z, u.w};
+            }
+          }
+        }
+      }
+      if (flags & SLIDE_F_PRE_RELU) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[rb][i] = __builtin_elementwise_max(v[rb][i], f32x2{0.f, 0.f});
+      }
+      if (PH == 1) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { acc[cb][rb][2 * i] = v[rb][i][0]; acc[cb][rb][2 * i + 1] = v[rb][i][1]; }
+      }
+    }
+    // NSCOPE = number of independent sample scopes per wave (NPX=16: one per 32-row block, two samples each)
+    constexpr int NSCOPE = (NPXL >= 6) ? 1 : RB;
+    constexpr int LG = NPX < 32 ? NPX : 32;  // lanes (rows) of one sample inside a row block
+    constexpr int WPS = NPXL >= 7 ? NPX / 64 : 1;  // waves per sample when a sample spans waves (2 or 4)
+    // sums `NV` per-lane partials over the rows of the lane's sample: lanes -> (row blocks) -> waves via LDS.
+    // XH: also fold the other lane half in (groups wider than one half's quad).
+    auto reduce_rows = [&](auto nv_tag, float *s, float *ss, bool xh) __attribute__((always_inline)) {
+      constexpr int NV = decltype(nv_tag)::value;
+      if (PH != 2) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          s[i] = lane_group_sum<LG>(s[i]);
+          ss[i] = lane_group_sum<LG>(ss[i]);
+        }
+      }
+      if (NPXL >= 7) {  // fixed summation order -> deterministic
+        if (PH != 2 && col == 0) {
+#pragma unroll
+          for (int i = 0; i < NV; ++i)
+            *reinterpret_cast<f32x2 *>(red + (((wave * CBW + cb) * 2 + half) * 16 + i) * 2) = f32x2{s[i], ss[i]};
+        }
+        if (PH == 0) __syncthreads();
+        if (PH == 1) return;
+        const int w0 = (wave / WPS) * WPS;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          f32x2 t = {0.f, 0.f};
+#pragma unroll
+          for (int w = 0; w < WPS; ++w)
+            t += *reinterpret_cast<const f32x2 *>(red + ((((w0 + w) * CBW + cb) * 2 + half) * 16 + i) * 2);
+          if (xh) {
+#pragma unroll
+            for (int w = 0; w < WPS; ++w)
+              t += *reinterpret_cast<const f32x2 *>(red + ((((w0 + w) * CBW + cb) * 2 + (half ^ 1)) * 16 + i) * 2);
+          }
+          s[i] = t[0]; ss[i] = t[1];
+        }
+      } else if (xh) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {  // other lane half: v_permlane32_swap of (s, ss) -- pure VALU, no LDS round trip
+          uint32_t ta = __float_as_uint(s[i]), tb = __float_as_uint(ss[i]);
+          // after the swap: ta = [s.lo | ss.lo -> hi lanes], tb = [s.hi -> lo lanes | ss.hi]
+          lane32_swap(ta, tb);
+          const float mine_s = s[i], mine_ss = ss[i];
+          // lo lanes: other half's s is in tb;   hi lanes: other half's ss is in ta
+          // second swap of the pair (ss, s) gives the remaining two
+          uint32_t tc = __float_as_uint(mine_ss), td = __float_as_uint(mine_s);
+          lane32_swap(tc, td);
+          // tc = [ss.lo | s.lo -> hi lanes], td = [ss.hi -> lo lanes | s.hi]
+          s[i] = mine_s + (half ? __uint_as_float(tc) : __uint_as_float(tb));
+          ss[i] = mine_ss + (half ? __uint_as_float(ta) : __uint_as_float(td));
+        }
+      }
+    };
+    if (mode == SLIDE_EPI_STATS && PH == 2) {
+      // sums already written by finalize_stats; the raw values are stored below
+    } else if (mode == SLIDE_EPI_STATS) {
+#pragma unroll
+      for (int sc = 0; sc < NSCOPE; ++sc) {
+        float s[16], ss[16];
+        if (PH != 2) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            f32x2 t, tt;
+            if constexpr (NSCOPE == 1 && RB == 2) { t = v[0][i] + v[1][i]; tt = __builtin_elementwise_fma(v[0][i], v[0][i], v[1][i] * v[1][i]); }
+            else { t = v[sc][i]; tt = v[sc][i] * v[sc][i]; }
+            s[2 * i] = t[0]; s[2 * i + 1] = t[1]; ss[2 * i] = tt[0]; ss[2 * i + 1] = tt[1];
+          }
+        }
+        reduce_rows(std::integral_constant<int, 16>(), s, ss, false);
+        if (PH == 1) continue;
+        const int row = row0 + wave * 64 + ((NSCOPE == 1) ? 0 : sc) * 32 + col;
+        const bool writer = (NPXL >= 7) ? ((wave % WPS) == 0 && col == 0) : ((col & (LG - 1)) == 0);
+        if (writer && row < a.rows) {
+          const size_t b = (size_t)(row >> NPXL);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
+            e_stats_sum[b * e_stats_bs + c] = s[r] * e_stats_scale;
+            e_stats_sq[b * e_stats_bs + c] = ss[r] * e_stats_scale;
+          }
+        }
+      }
+    } else if (mode == SLIDE_EPI_NORM && PH == 2) {
+      // per-(sample, channel) scale g = gamma * rstd and shift beta - mean * g, prepared by finalize_stats
+      const float *gp = gsh + ((cb * 2 + (WPS == 2 ? (wave >> 1) : 0)) * 2) * 32 + 4 * half;
+      float4 g4[4], b4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        g4[q] = *reinterpret_cast<const float4 *>(gp + 8 * q);
+        b4[q] = *reinterpret_cast<const float4 *>(gp + 32 + 8 * q);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          v[rb][2 * q] = __builtin_elementwise_fma(v[rb][2 * q], f32x2{g4[q].x, g4[q].y}, f32x2{b4[q].x, b4[q].y});
+          v[rb][2 * q + 1] = __builtin_elementwise_fma(v[rb][2 * q + 1], f32x2{g4[q].z, g4[q].w}, f32x2{b4[q].z, b4[q].w});
+        }
+    } else if (mode == SLIDE_EPI_NORM) {
+      // GroupNorm: groups of gs PHYSICAL channels (gs | 32).  Fold the lane's 16 channels into its groups BEFORE the
+      // cross-lane reduction: SH = log2(channels of one group held by this lane) -> 16 >> SH values to reduce.
+      auto norm_path = [&](auto sh_tag) __attribute__((always_inline)) {
+        constexpr int SH = decltype(sh_tag)::value;
+        constexpr int NV = 16 >> SH;
+#pragma unroll
+        for (int sc = 0; sc < NSCOPE; ++sc) {
+          float s[NV], ss[NV];
+          if constexpr (PH == 2) {
+          } else if constexpr (SH == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              f32x2 t, tt;
+              if constexpr (NSCOPE == 1 && RB == 2) {
+                t = (v[0][2 * q] + v[1][2 * q]) + (v[0][2 * q + 1] + v[1][2 * q + 1]);
+                tt = v[0][2 * q] * v[0][2 * q];
+                tt = __builtin_elementwise_fma(v[1][2 * q], v[1][2 * q], tt);
+                tt = __builtin_elementwise_fma(v[0][2 * q + 1], v[0][2 * q + 1], tt);
+                tt = __builtin_elementwise_fma(v[1][2 * q + 1], v[1][2 * q + 1], tt);
+              } else {
+                t = v[sc][2 * q] + v[sc][2 * q + 1];
+                tt = __builtin_elementwise_fma(v[sc][2 * q], v[sc][2 * q], v[sc][2 * q + 1] * v[sc][2 * q + 1]);
+              }
+              s[q] = t[0] + t[1]; ss[q] = tt[0] + tt[1];
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              f32x2 t, tt;
+              if constexpr (NSCOPE == 1 && RB == 2) { t = v[0][i] + v[1][i]; tt = __builtin_elementwise_fma(v[0][i], v[0][i], v[1][i] * v[1][i]); }
+              else { t = v[sc][i]; tt = v[sc][i] * v[sc][i]; }
+              if constexpr (SH == 1) { s[i] = t[0] + t[1]; ss[i] = tt[0] + tt[1]; }
+              else { s[(2 * i) >> SH] = t[0]; s[(2 * i + 1) >> SH] = t[1]; ss[(2 * i) >> SH] = tt[0]; ss[(2 * i + 1) >> SH] = tt[1]; }
+            }
+          }
+          reduce_rows(std::integral_constant<int, NV>(), s, ss, SH == 2 && e_gs >= 8);
+          if (PH == 1) continue;
+          if (PH == 2 && cb == 0) SLIDE_STAMP(a, 11);
+          if (SH == 2 && e_gs >= 16) {  // groups wider than both halves of a quad: fold quads
+            if (e_gs == 16) {
+              const float p0 = s[0] + s[1], p1 = s[2] + s[3], q0_ = ss[0] + ss[1], q1_ = ss[2] + ss[3];
+              s[0] = s[1] = p0; s[2] = s[3] = p1; ss[0] = ss[1] = q0_; ss[2] = ss[3] = q1_;
+            } else {
+              const float p = (s[0] + s[1]) + (s[2] + s[3]), q_ = (ss[0] + ss[1]) + (ss[2] + ss[3]);
+              s[0] = s[1] = s[2] = s[3] = p; ss[0] = ss[1] = ss[2] = ss[3] = q_;
+            }
+          }
+          float mean[NV], rstd[NV];
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            mean[i] = s[i] * e_inv_count;
+            const float var = fmaxf(ss[i] * e_inv_count - mean[i] * mean[i], 0.f);
+            rstd[i] = __builtin_amdgcn_rsqf(var + GN_EPS);
+          }
+          if (PH == 2 && cb == 0) SLIDE_STAMP(a, 12);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int c0 = 8 * (i >> 1) + 4 * half + 2 * (i & 1);
+            const f32x2 gam = *reinterpret_cast<const f32x2 *>(v_gamma + c0);
+            const f32x2 bet = *reinterpret_cast<const f32x2 *>(v_beta + c0);
+            const f32x2 rs = {rstd[(2 * i) >> SH], rstd[(2 * i + 1) >> SH]};
+            const f32x2 mu = {mean[(2 * i) >> SH], mean[(2 * i + 1) >> SH]};
+            f32x2 g = gam * rs;
+            f32x2 bt = __builtin_elementwise_fma(-mu, g, bet);
+            if (e_n_norm < 32) {  // MyGroupNorm leaves the last C % G channels as they are
+              if (c0 >= e_n_norm) { g[0] = 1.f; bt[0] = 0.f; }
+              if (c0 + 1 >= e_n_norm) { g[1] = 1.f; bt[1] = 0.f; }
+            }
+            if constexpr (NSCOPE == 1 && RB == 2) {
+              v[0][i] = __builtin_elementwise_fma(v[0][i], g, bt);
+              v[1][i] = __builtin_elementwise_fma(v[1][i], g, bt);
+            } else {
+              v[sc][i] = __builtin_elementwise_fma(v[sc][i], g, bt);
+            }
+          }
+        }
+      };
+      if (e_gs >= 4) norm_path(std::integral_constant<int, 2>());
+      else if (e_gs == 2) norm_path(std::integral_constant<int, 1>());
+      else norm_path(std::integral_constant<int, 0>());
+    }
+    if (PH == 1) return;
+    if (PH == 2 && cb == 0) SLIDE_STAMP(a, 9);
+    // store.  A lane holds 4 consecutive channels per quad q (channels 8q + 4*half).  fp32 rows go out as they are
+    // (16 B per lane).  For fp16 rows an 8-byte store per lane would touch only 16 B of every row per instruction,
+    // which the memory system writes at half the rate of wider row pieces (tools/store_pattern.hip: 3.1 vs 5.2 TB/s):
+    // v_permlane32_swap trades quads 2p+1 / 2p between the lane halves so that lane (col, half) owns the 8 channels
+    // 16p + 8*half .. +7 and issues 16-byte stores (32 B per row and instruction).  The residual is read the same way.
+    // Pass 1 consumes every value that came from a global load (t-embedding rows, residual); pass 2 only converts and
+    // stores.  Kept apart -- and compiled without the loaded operands when a block has none -- because any wait for a
+    // load placed between stores is a vmcnt(0): it would also wait for the stores issued so far, one full write round
+    // trip per row block.
+    const float relu_lo = (flags & SLIDE_F_POST_RELU) ? 0.f : -3.0e38f;
+    auto store_phase = [&](auto addv_tag, auto res_tag) __attribute__((always_inline)) {
+      constexpr bool HA = decltype(addv_tag)::value, HR = decltype(res_tag)::value;
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x2 lo = v[rb][2 * q], hi = v[rb][2 * q + 1];
+          // ReLU without a branch per quad: clamp from below by 0 or by -FLT_MAX (v_med3_f32, one op per value)
+          lo[0] = __builtin_amdgcn_fmed3f(lo[0], relu_lo, 3.0e38f); lo[1] = __builtin_amdgcn_fmed3f(lo[1], relu_lo, 3.0e38f);
+          hi[0] = __builtin_amdgcn_fmed3f(hi[0], relu_lo, 3.0e38f); hi[1] = __builtin_amdgcn_fmed3f(hi[1], relu_lo, 3.0e38f);
+          if constexpr (HA) {
+            const float4 t = apre[rb < NA ? rb : 0][q];
+            lo += f32x2{t.x, t.y}; hi += f32x2{t.z, t.w};
+          }
+          v[rb][2 * q] = lo; v[rb][2 * q + 1] = hi;
+        }
+        if constexpr (HR && kHalf) {
+          if (wide16) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              const u32x4 w = rpre[rb][p];
+              uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+              lane32_swap(w0, w2);
+              lane32_swap(w1, w3);
+              const f16x2 a0 = __builtin_bit_cast(f16x2, w0), a1 = __builtin_bit_cast(f16x2, w1);
+              const f16x2 b0 = __builtin_bit_cast(f16x2, w2), b1 = __builtin_bit_cast(f16x2, w3);
+              v[rb][4 * p] += f32x2{(float)a0[0], (float)a0[1]};
+              v[rb][4 * p + 1] += f32x2{(float)a1[0], (float)a1[1]};
+              v[rb][4 * p + 2] += f32x2{(float)b0[0], (float)b0[1]};
+              v[rb][4 * p + 3] += f32x2{(float)b1[0], (float)b1[1]};
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const int row = row0 + wave * 64 + rb * 32 + col;
+        const bool ok = row < a.rows;  // identical in both lane halves
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {  // quads 2p and 2p+1
+          if constexpr (kHalf) if (wide16) {
+            f16x2 a0 = __builtin_convertvector(v[rb][4 * p], f16x2), a1 = __builtin_convertvector(v[rb][4 * p + 1], f16x2);
+            f16x2 b0 = __builtin_convertvector(v[rb][4 * p + 2], f16x2), b1 = __builtin_convertvector(v[rb][4 * p + 3], f16x2);
+            uint32_t ua0 = __builtin_bit_cast(uint32_t, a0), ua1 = __builtin_bit_cast(uint32_t, a1);
+            uint32_t ub0 = __builtin_bit_cast(uint32_t, b0), ub1 = __builtin_bit_cast(uint32_t, b1);
+            lane32_swap(ua0, ub0);
+            lane32_swap(ua1, ub1);
+            u32x4 o = {ua0, ua1, ub0, ub1};
+#if !defined(SLIDE_ABL) || SLIDE_ABL != 1
+            if (ok) *(GLOBAL_AS u32x4 *)(gptr<_Float16>(e_out) + (size_t)row * e_out_ld + 16 * p + 8 * half) = o;
+#else
+            if (ok && o[0] == 0x12345678u) *(GLOBAL_AS u32x4 *)(gptr<_Float16>(e_out) + (size_t)row * e_out_ld + 16 * p + 8 * half) = o;
+#endif
+            continue;
+          }
+          if (ok) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int q = 2 * p + j, c0 = 8 * q + 4 * half;
+              float4 y = make_float4(v[rb][2 * q][0], v[rb][2 * q][1], v[rb][2 * q + 1][0], v[rb][2 * q + 1][1]);
+              if constexpr (HR) {
+                const float4 t = gload4(resid + (size_t)row * e_res_ld + c0);
+                y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+              }
+              if (flags & SLIDE_F_OUT_F32)
+                gstore4(gptr<float>(e_out) + (size_t)row * e_out_ld + c0, y);
+              else
+                gstore4(gptr<T>(e_out) + (size_t)row * e_out_ld + c0, y);
+            }
+          }
+        }
+      }
+    };
+    using TT = std::true_type;
+    using FF = std::false_type;
+    if (addv) { if (resid) store_phase(TT(), TT()); else store_phase(TT(), FF()); }
+    else { if (resid) store_phase(FF(), TT()); else store_phase(FF(), FF()); }
+    if (PH == 2 && cb == 0) SLIDE_STAMP(a, 10);
+  };
+  // Between the phases ONE wave per channel block (wave == cb) turns the partial sums of the sample's waves into what
+  // phase 2 needs, one channel per lane: STATS -> the per-(sample, channel) sums in global memory; NORM -> scale and
+  // shift per (sample, channel) in LDS.  (Fixed summation order: deterministic.)
+  auto finalize_stats = [&](const int cb) __attribute__((always_inline)) {
+    constexpr int WPSF = NPXL >= 7 ? (1 << NPXL) / 64 : 1;
+    const int cobi = cob0 + cb;
+    if (cobi >= a.n_cob) return;
+    auto rd = [&](int k) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)epi_lds[cb * EPI_DW + k]); };
+    auto rdp = [&](int k) { return (uint64_t)rd(k) | ((uint64_t)rd(k + 1) << 32); };
+    const int mode = (int)rd(0);
+    if (mode == SLIDE_EPI_RAW) return;
+    if (WPSF == 4 && half) return;                    // one sample per workgroup: the upper lane half has nothing to do
+    const int smp = WPSF == 2 ? half : 0, w0 = smp * WPSF;
+    const int c = col, hh = (c >> 2) & 1, q = c >> 3, j = c & 3;
+    auto part = [&](int w, int h2, int slot) {
+      return *reinterpret_cast<const f32x2 *>(red + ((((w0 + w) * CBW + cb) * 2 + h2) * 16 + slot) * 2);
+    };
+    if (mode == SLIDE_EPI_STATS) {
+      f32x2 t = {0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < WPSF; ++w) t += part(w, hh, 4 * q + j);
+      const int row = row0 + smp * NPX;
+      if (row < a.rows) {
+        const float scale = __uint_as_float(rd(5));
+        const size_t o = (size_t)(row >> NPXL) * (int)rd(9) + c;
+        gptr<float>(rdp(30))[o] = t[0] * scale;
+        gptr<float>(rdp(32))[o] = t[1] * scale;
+      }
+      return;
+    }
+    const int gs = (int)rd(2), n_norm = (int)rd(3);
+    const float inv_count = __uint_as_float(rd(4));
+    int slot0, nslot = 1, nh = 1, h0 = hh;
+    if (gs >= 4) {
+      slot0 = q;
+      if (gs >= 8) { nh = 2; h0 = 0; }
+      if (gs >= 16) { nslot = gs >> 3; slot0 = (q / nslot) * nslot; }
+    } else if (gs == 2) {
+      slot0 = 2 * q + (j >> 1);
+    } else {
+      slot0 = 4 * q + j;
+    }
+    // fully unrolled per group shape so that the LDS reads of a lane issue back to back (a runtime-bounded loop
+    // serialises them behind one another's latency)
+    auto sum_parts = [&](auto nh_tag, auto ns_tag) __attribute__((always_inline)) {
+      constexpr int NH = decltype(nh_tag)::value, NS = decltype(ns_tag)::value;
+      f32x2 acc2 = {0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < WPSF; ++w)
+#pragma unroll
+        for (int h2 = 0; h2 < NH; ++h2)
+#pragma unroll
+          for (int sl = 0; sl < NS; ++sl) acc2 += part(w, h0 + h2, slot0 + sl);
+      return acc2;
+    };
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I4 = std::integral_constant<int, 4>;
+    f32x2 t;
+    if (nh == 1) t = sum_parts(I1(), I1());
+    else if (nslot == 1) t = sum_parts(I2(), I1());
+    else if (nslot == 2) t = sum_parts(I2(), I2());
+    else t = sum_parts(I2(), I4());
+    const float mean = t[0] * inv_count;
+    const float var = fmaxf(t[1] * inv_count - mean * mean, 0.f);
+    float g = vec_lds[cb * 96 + 32 + c] * __builtin_amdgcn_rsqf(var + GN_EPS);
+    float bt = vec_lds[cb * 96 + 64 + c] - mean * g;
+    if (c >= n_norm) { g = 1.f; bt = 0.f; }  // MyGroupNorm leaves the last C % G channels as they are
+    gsh[((cb * 2 + smp) * 2 + 0) * 32 + c] = g;
+    gsh[((cb * 2 + smp) * 2 + 1) * 32 + c] = bt;
+  };
+#if defined(SLIDE_ABL) && SLIDE_ABL == 3
+  if (NPXL >= 7 && a.rows > 0) return;
+#endif
+  if (NPXL >= 7) {
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb) process(cb, std::integral_constant<int, 1>());
+    SLIDE_STAMP(a, 3);
+    __syncthreads();
+    SLIDE_STAMP(a, 4);
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb)
+      if (wave == cb) finalize_stats(cb);
+    __syncthreads();
+#if defined(SLIDE_ABL) && SLIDE_ABL == 2
+    if (a.rows > 0) return;
+#endif
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb) process(cb, std::integral_constant<int, 2>());
+  } else {
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb) process(cb, std::integral_constant<int, 0>());
+  }
+}
+
+}  // namespace

@@ -283,6 +283,16 @@ class DenoiserEngine:
         wr = sum(rows * v[2] * v[1]["out"].element_size() for v in vec_list)
         self.gemm_bytes[len(self.ops)] = (rd, wr)  # algorithmic HBM bytes (read, written) of this launch
         glds = int(self.use_glds and self.prec == 1 and (sc is None or npx_log2 >= 7))
+        # X-stationary kernel (csrc/gemm_xs.hip: one workgroup per row tile keeps X resident in LDS and computes every column
+        # tile, weights through a small LDS-DMA ring).  OPT-IN (SLIDE_XS=8 or 7,8): bit-identical to the ring kernels and 5x
+        # less L2->LDS traffic, but one workgroup per CU exposes the per-tile epilogue latency that three co-resident ring
+        # workgroups hide: feature chain 1.00 vs 0.94 ms/step at batch 256
+        wfrag = None
+        xs_levels = {int(v) for v in os.environ.get("SLIDE_XS", "").split(",") if v}
+        if (glds and npx_log2 in xs_levels and gn_fin is None and not (gather is not None and sc is not None)
+                and (ld // 32) * 16384 + 12 * 1024 <= 160 * 1024):
+            wfrag = Wd  # (selects the kernel; it reads the same row-major weights through a small LDS-DMA ring)
+            cbw = 4 if n_cob >= 4 and os.environ.get("SLIDE_XS_CBW", "4") == "4" else 2
         gf = (0.0, 0.0, 0.0) if gather is None else (float(gather[3]), float(gather[0].shape[1]), float({8: 3, 16: 4}[gather[2]]))
         self._emit(make_op(OP_GEMM, i=(rows, x_ld, ld, n_cob, npx_log2, in_bs, self.prec, cbw, glds, self.glds_nst),
                            f=(-1.0 if self.persistent == 2 else float(os.environ.get('SLIDE_STAGGER_US', '0')),) + gf,
@@ -293,7 +303,8 @@ class DenoiserEngine:
                                    self._sched().data_ptr() if self.persistent else None,
                                    None if gather is None else gather[0].data_ptr(),
                                    (None if pre_gather is None else pre_gather.data_ptr()) if gather is None
-                                   else gather[1].data_ptr())))
+                                   else gather[1].data_ptr(),
+                                   None if wfrag is None else wfrag.data_ptr())))
         self.flops += 2 * rows * sum(int(s["w"].size) for s in segs)
 
     # ------------------------------------------------------------------ blocks

@@ -13,7 +13,10 @@ if "--build" in sys.argv:  # instrumented copy of the library (-DSLIDE_TIMELINE)
     F = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DSLIDE_TIMELINE"]
     subprocess.check_call(F + ["-ffp-contract=off", "-c", ROOT + "/slide_amd/csrc/point_ops.hip", "-o", ROOT + "/build_tmp/pT.o"], stderr=subprocess.DEVNULL)
     subprocess.check_call(F + ["-mllvm", "-pragma-unroll-threshold=100000", "-c", ROOT + "/slide_amd/csrc/engine.hip", "-o", ROOT + "/build_tmp/eT.o"], stderr=subprocess.DEVNULL)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIBT, ROOT + "/build_tmp/pT.o", ROOT + "/build_tmp/eT.o"])
+    subprocess.check_call(F + ["-mllvm", "-pragma-unroll-threshold=100000", "-c", ROOT + "/slide_amd/csrc/gemm_xs.hip", "-o", ROOT + "/build_tmp/xT.o"], stderr=subprocess.DEVNULL)
+    subprocess.check_call(F + ["-mllvm", "-pragma-unroll-threshold=100000", "-c", ROOT + "/slide_amd/csrc/resident.hip", "-o", ROOT + "/build_tmp/rT.o"], stderr=subprocess.DEVNULL)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIBT, ROOT + "/build_tmp/pT.o", ROOT + "/build_tmp/eT.o",
+                           ROOT + "/build_tmp/xT.o", ROOT + "/build_tmp/rT.o"])
     if len(sys.argv) == 1:
         sys.exit(0)
 os.environ["SLIDE_HIP_LIB"] = LIBT
@@ -53,6 +56,14 @@ for spec in sys.argv[1:]:
     torch.cuda.synchronize()
     t = dbg.cpu().numpy().reshape(nwg, 16).astype(np.float64)
     t = t[t[:, 0] > 0]
+    if op.p[10]:  # X-stationary kernel: 0 start | 1 DMA issued, tables staged | 2 X landed | 6 / 7 first tile: K loop, epilogue done | 13 / 14 last tile
+        t0 = t[:, 0].min()
+        tt = (t - t0) / 100.0
+        m = tt.mean(axis=0)
+        print("case %s (X-stationary): %d workgroups, span %.1f us, start spread %.1f us" % (spec, len(t), tt[:, 14].max(), tt[:, 0].max()))
+        print("   issue %.2f  landed %.2f  | first tile: kloop %.2f  epilogue %.2f (stats %.2f, barrier->stores %.2f) | last tile ends %.2f: kloop done @%.2f, epilogue %.2f" % (
+            m[1] - m[0], m[2] - m[1], m[6] - m[2], m[7] - m[6], 0, 0, m[14], m[13], m[14] - m[13]))
+        continue
     t0 = t[:, 0].min()
     t = (t - t0) / 100.0  # us
     print("case %s: %d workgroups, launch span %.1f us" % (spec, len(t), t[:, 6].max()))
