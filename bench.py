@@ -95,6 +95,10 @@ def main():
     ap.add_argument("--replay", default=os.environ.get("SLIDE_REPLAY", "eager"), choices=["eager", "threads", "graph"],
                     help="eager: eager launches of all chains from one host thread, round-robin per step (default); "
                          "threads: one host thread per chain; graph: one captured hipGraph per chain and step")
+    ap.add_argument("--workload", default="default", choices=["default", "five-cat"],
+                    help="default: BASELINE configs[1]+[2] (one position + one feature weight set); five-cat: BASELINE configs[3] -- the "
+                         "256 shapes of every GPU are its contiguous shard of a five-category run (labels 0, 2, 3, 4, 6, one weight "
+                         "set per category: a chain pair per category segment), latents all-gathered")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the live fp16-vs-fp32 forward error and the fp32-mode timing")
@@ -157,39 +161,64 @@ def main():
     if P == 1:  # one chain pair: the two plans as the two branches of one step graph (two lone streams serialise)
         a.replay = "graph"
     eager = a.replay != "graph"
-    pos = PositionSampler(pc["pointnet_config"], sd_p, B, dev, pc["diffusion_config"], prec=a.prec, seed=1000 + rank * 16,
-                          use_graph=not eager)
-    # position plan: its own step graph on its own stream ("own", default: 1-1.5 % faster) or a parallel branch of the
-    # first feature sub-batch's graph ("branch")
-    pos_own = os.environ.get("SLIDE_POS_GRAPH", "own") == "own" and P > 1
-    subs = []
-    for i, b in enumerate(sizes):
-        f_ = FeatureSampler(fc["pointnet_config"], sd_f, b, dev, fc["standard_diffusion_config"], prec=a.prec,
-                            seed=2000 + rank * 16 + i, use_graph=not eager)
-        subs.append((f_, JointSampler(pos if (i == 0 and not pos_own) else None, f_), synth_keypoints(b, seed=rank * 16 + i)))
-    feat, kp = subs[0][0], subs[0][2]  # sub-batch 0 also serves the roofline leg below
-    members = [OwnGraphSampler(s_[0]) if eager else s_[1] for s_ in subs]
-    if pos_own:
-        members.insert(int(os.environ.get("SLIDE_POS_ORDER", "1")), OwnGraphSampler(pos))
-    joint = SplitJointSampler(members)  # one hipGraph per member and step, launched round-robin
-    if a.replay == "threads":
-        joint = ThreadedEagerSampler([pos] + [s_[0] for s_ in subs])
-    elif a.replay == "eager":
-        joint = EagerChainsSampler([s_[0] for s_ in subs[:1]] + [pos] + [s_[0] for s_ in subs[1:]])
+    if a.workload == "default":
+        pos = PositionSampler(pc["pointnet_config"], sd_p, B, dev, pc["diffusion_config"], prec=a.prec, seed=1000 + rank * 16,
+                              use_graph=not eager)
+        # position plan: its own step graph on its own stream ("own", default: 1-1.5 % faster) or a parallel branch of the
+        # first feature sub-batch's graph ("branch")
+        pos_own = os.environ.get("SLIDE_POS_GRAPH", "own") == "own" and P > 1
+        subs = []
+        for i, b in enumerate(sizes):
+            f_ = FeatureSampler(fc["pointnet_config"], sd_f, b, dev, fc["standard_diffusion_config"], prec=a.prec,
+                                seed=2000 + rank * 16 + i, use_graph=not eager)
+            subs.append((f_, JointSampler(pos if (i == 0 and not pos_own) else None, f_), synth_keypoints(b, seed=rank * 16 + i)))
+        feat, kp = subs[0][0], subs[0][2]  # sub-batch 0 also serves the roofline leg below
+        members = [OwnGraphSampler(s_[0]) if eager else s_[1] for s_ in subs]
+        if pos_own:
+            members.insert(int(os.environ.get("SLIDE_POS_ORDER", "1")), OwnGraphSampler(pos))
+        joint = SplitJointSampler(members)  # one hipGraph per member and step, launched round-robin
+        if a.replay == "threads":
+            joint = ThreadedEagerSampler([pos] + [s_[0] for s_ in subs])
+        elif a.replay == "eager":
+            joint = EagerChainsSampler([s_[0] for s_ in subs[:1]] + [pos] + [s_[0] for s_ in subs[1:]])
+    cat_desc = None
+    if a.workload == "five-cat":
+        # per-category weight sets (synthetic, keyed on the category id); every segment of this rank's shard is a chain pair
+        from slide_amd.generation import CategoryChains
+        spec_p, spec_f = model_spec.denoiser_param_spec(pc["pointnet_config"]), model_spec.denoiser_param_spec(fc["pointnet_config"])
+        cc = CategoryChains(B * world, rank, world, pc, fc,
+                            lambda c: (synth_state_dict(spec_p, seed=100 + c), synth_state_dict(spec_f, seed=200 + c)), dev,
+                            prec=a.prec, seed=rank + 1)
+        cat_desc = [(c, hi - lo) for c, lo, hi, _, _ in cc.chains]
+        pos_chains = [(ps, torch.full((hi - lo,), c, dtype=torch.int64, device=dev)) for c, lo, hi, ps, _ in cc.chains]
+        feat_chains = [(fs, torch.full((hi - lo,), c, dtype=torch.int64, device=dev),
+                        torch.as_tensor(synth_keypoints(hi - lo, seed=rank * 16 + k), device=dev))
+                       for k, (c, lo, hi, _, fs) in enumerate(cc.chains)]
+        order = []
+        for (ps, _), (fs, _, _) in zip(pos_chains, feat_chains):
+            order += [fs, ps]
+        joint = EagerChainsSampler(order)
+        a.replay = "eager"
+        feat, kp = feat_chains[0][0], feat_chains[0][2].cpu().numpy()
+        sizes = [fs.B for fs, _, _ in feat_chains]
+        P = len(sizes)
+    else:
+        pos_chains = [(pos, torch.zeros(B, dtype=torch.int64, device=dev))]
+        feat_chains = [(f_, torch.full((b,), 4, dtype=torch.int64, device=dev), torch.as_tensor(k_, device=dev))
+                       for (f_, _, k_), b in zip(subs, sizes)]
     rs = np.random.RandomState(rank)
     # chain starts: x_T is drawn ON THE DEVICE (torch's Philox generator; plumbing) and labels / key points are resident,
     # so that a restart inside the timed region costs a few launches, not a host RNG pass + four uploads (round 1's
     # driver-timed 20-step number carried ~4 ms of that)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
-    lab_p = torch.zeros(B, dtype=torch.int64, device=dev)
-    lab_f = [torch.full((b,), 4, dtype=torch.int64, device=dev) for b in sizes]
-    kp_dev = [torch.as_tensor(k_, device=dev) for _, _, k_ in subs]
+    lab_p = pos_chains[0][1]
 
     def reset():
-        pos.begin(lab_p, torch.randn(B, 16, 3, device=dev, generator=gen))
-        for (f_, _, _), b, l_, k_ in zip(subs, sizes, lab_f, kp_dev):
-            f_.begin(l_, k_, torch.randn(b, 16, 51, device=dev, generator=gen))
+        for p_, l_ in pos_chains:
+            p_.begin(l_, torch.randn(p_.B, 16, 3, device=dev, generator=gen))
+        for f_, l_, k_ in feat_chains:
+            f_.begin(l_, k_, torch.randn(f_.B, 16, 51, device=dev, generator=gen))
 
     state = {"left": 0}  # reverse steps left in the current chains
 
@@ -208,8 +237,9 @@ def main():
             done += k
 
     def sync_all():
-        pos.stream.synchronize()
-        for f_, _, _ in subs:
+        for p_, _ in pos_chains:
+            p_.stream.synchronize()
+        for f_, _, _ in feat_chains:
             f_.stream.synchronize()
         torch.cuda.synchronize(dev)
         if use_dist:
@@ -220,9 +250,9 @@ def main():
     gathered = [torch.empty(B, 16, 51, device=gdev) for _ in range(world)] if use_dist else None
 
     def gather_latents():  # the single collective of the path: all ranks' latents (835 KB / rank at B=256)
-        for f_, _, _ in subs:
+        for f_, _, _ in feat_chains:
             f_.stream.synchronize()
-        dist.all_gather(gathered, torch.cat([f_.engine.x.reshape(-1, 16, 51) for f_, _, _ in subs], 0).to(gdev))
+        dist.all_gather(gathered, torch.cat([f_.engine.x.reshape(-1, 16, 51) for f_, _, _ in feat_chains], 0).to(gdev))
 
     if use_dist:
         gather_latents()  # untimed, like the warm-up steps: the first call builds RCCL's channels
@@ -239,8 +269,8 @@ def main():
         tt = torch.tensor([dt], device=gdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    finite = bool(torch.isfinite(pos.state()).all().item()) and all(bool(torch.isfinite(f_.state()).all().item())
-                                                                     for f_, _, _ in subs)
+    finite = all(bool(torch.isfinite(p_.state()).all().item()) for p_, _ in pos_chains) and \
+        all(bool(torch.isfinite(f_.state()).all().item()) for f_, _, _ in feat_chains)
     ms_per_step = dt * 1e3 / a.steps
     value = world * B / (1000.0 * (ms_per_step / 1e3))
 
@@ -251,8 +281,14 @@ def main():
            "config": {"workload": "BASELINE configs[1]+[2]: airplane position DDPM (16x3) + chair feature DDPM (16x51), "
                                   "batch %d per GPU; 1 step = one reverse step of each; shape = 1000+1000 steps" % B,
                       "batch_per_gpu": B, "sub_batches": sizes, "prec": a.prec, "replay": a.replay,
-                      "launches_per_step": pos.n_launches + P * feat.n_launches,
+                      "launches_per_step": sum(p_.n_launches for p_, _ in pos_chains) + sum(f_.n_launches for f_, _, _ in feat_chains),
                       "finite": finite}}
+    if cat_desc is not None:
+        out["config"]["workload"] = ("BASELINE configs[3]: five-category run (labels 0, 2, 3, 4, 6; one position + one feature weight set "
+                                     "per category), %d shapes sharded contiguously over %d GPU(s), %d per GPU; 1 step = one reverse step "
+                                     "of every category segment's position and feature chain; latents all-gathered; shape = 1000+1000 steps"
+                                     % (B * world, world, B))
+        out["config"]["segments_rank0"] = [{"label": c, "shapes": n} for c, n in cat_desc]
 
     if rank == 0 and not a.no_roofline:
         L = lib()

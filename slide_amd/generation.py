@@ -79,6 +79,99 @@ def generate_latents(num_samples, batch_size, labels, run_batch, rank=0, world_s
     return full, np.asarray(timing)
 
 
+FIVE_CATEGORIES = (0, 2, 3, 4, 6)  # airplane, cabinet, car, chair, lamp: the categories with released checkpoints (README.md:60)
+
+
+def category_layout(total, categories=FIVE_CATEGORIES):
+    """global sample index -> category for a multi-category generation run: category-major, the first total % n categories
+    one sample longer.  Returns [(category, start, end)]."""
+    n = len(categories)
+    base, extra = divmod(int(total), n)
+    out, lo = [], 0
+    for i, c in enumerate(categories):
+        hi = lo + base + (1 if i < extra else 0)
+        out.append((int(c), lo, hi))
+        lo = hi
+    return out
+
+
+def category_segments(total, rank=0, world_size=1, categories=FIVE_CATEGORIES):
+    """the pieces of rank `rank`'s contiguous shard (shard_range: the reference's per-rank ceil-division slices) that fall into
+    each category: [(category, lo, hi)] with global indices.  Every category has its own weight set (per-category
+    checkpoints), so a rank runs one chain pair per segment -- at 2048 shapes on 8 ranks a shard spans at most 2."""
+    s, e = shard_range(total, rank, world_size)
+    return [(c, max(lo, s), min(hi, e)) for c, lo, hi in category_layout(total, categories) if max(lo, s) < min(hi, e)]
+
+
+def generate_categories(total, run_segment, rank=0, world_size=1, categories=FIVE_CATEGORIES, gather_device=None, row_shape=None,
+                        row_dtype=torch.float32):
+    """BASELINE configs[3]: `total` shapes over several categories, sharded over the ranks, position then feature DDPM per
+    segment with that category's weights, ONE all-gather of the latents at the end.
+    run_segment(category, lo, hi) -> (hi - lo, ...) tensor.  Returns (latents [total, ...] on every rank, labels [total])."""
+    outs = [torch.as_tensor(run_segment(c, lo, hi)) for c, lo, hi in category_segments(total, rank, world_size, categories)]
+    local = torch.cat(outs, dim=0) if outs else None
+    if row_shape is None and world_size > 1:
+        shapes = [None] * world_size
+        dist.all_gather_object(shapes, None if local is None else (tuple(local.shape[1:]), local.dtype))
+        row_shape, row_dtype = next(s_ for s_ in shapes if s_ is not None)
+    if local is None:
+        local = torch.empty((0,) + tuple(row_shape or ()), dtype=row_dtype, device=gather_device)
+    full = all_gather_rows(local, total, world_size, device=gather_device)
+    labels = np.concatenate([np.full(hi - lo, c, np.int64) for c, lo, hi in category_layout(total, categories)])
+    return full, labels
+
+
+class CategoryChains:
+    """The HIP samplers of one rank for a multi-category run (BASELINE configs[3]): for every segment of the rank's shard a
+    position sampler and a feature sampler built from THAT category's weights; the feature chain of a segment is
+    conditioned on the positions its position chain generated (README.md:69-73: position DDPM -> feature DDPM).
+    weights(category) -> (position state dict, feature state dict)."""
+
+    def __init__(self, total, rank, world_size, pos_cfg, feat_cfg, weights, device, prec="fp16", seed=0, categories=FIVE_CATEGORIES):
+        from .diffusion import FeatureSampler, PositionSampler
+        self.total, self.rank, self.world, self.device, self.categories = int(total), rank, world_size, device, categories
+        self.segments = category_segments(total, rank, world_size, categories)
+        self.chains = []
+        for k, (c, lo, hi) in enumerate(self.segments):
+            sd_p, sd_f = weights(c)
+            # the in-kernel noise is keyed on (seed, chain nonce, step, element): the global offset `lo` keeps the streams of
+            # different segments / ranks apart
+            ps = PositionSampler(pos_cfg["pointnet_config"], sd_p, hi - lo, device, pos_cfg["diffusion_config"], prec=prec,
+                                 seed=(seed << 24) ^ (2 * lo + 1), use_graph=False)
+            fs = FeatureSampler(feat_cfg["pointnet_config"], sd_f, hi - lo, device, feat_cfg["standard_diffusion_config"], prec=prec,
+                                seed=(seed << 24) ^ (2 * lo + 2), use_graph=False)
+            self.chains.append((c, lo, hi, ps, fs))
+
+    def run(self, gen=None, steps=None):
+        """position chain then feature chain of every segment (all `steps` reverse steps, default the full schedule); the
+        position chain of segment k + 1 runs beside the feature chain of segment k (independent streams).
+        Returns the rank's latents (n_local, 16, 3 + F) on the device."""
+        outs, pending = [], None
+        for c, lo, hi, ps, fs in self.chains:
+            n = hi - lo
+            lab = torch.full((n,), c, dtype=torch.int64, device=self.device)
+            ps.begin(lab, torch.randn(n, 16, 3, device=self.device, generator=gen))
+            ps.advance(ps.T if steps is None else steps)
+            if pending is not None:
+                outs.append(pending.state())
+            kp = ps.state()
+            cx = fs.engine.cx
+            fs.begin(lab, kp, torch.randn(n, 16, cx, device=self.device, generator=gen))
+            fs.advance(fs.T if steps is None else steps)
+            pending = fs
+        if pending is not None:
+            outs.append(pending.state())
+        return torch.cat(outs, dim=0) if outs else torch.empty(0, 16, 0, device=self.device)
+
+    def generate(self, gen=None, steps=None):
+        """-> (latents [total, 16, 3 + F] on every rank, labels [total]); one all-gather (RCCL over xGMI; gloo in the tests)"""
+        local = self.run(gen, steps)
+        base = self.segments[0][1] if self.segments else 0
+        cx = self.chains[0][4].engine.cx if self.chains else None
+        return generate_categories(self.total, lambda c, lo, hi: local[lo - base:hi - base], self.rank, self.world, self.categories,
+                                   gather_device=self.device, row_shape=None if cx is None else (16, cx))
+
+
 def save_generated(save_dir, points, labels, timing, num_points, keypoint=None, keypoint_feature=None, ckpt_info=""):
     """npz schema of mesh_evaluation.py:135-150: points,label,category,category_name,timing[,keypoint,keypoint_feature]"""
     os.makedirs(save_dir, exist_ok=True)

@@ -9,7 +9,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from slide_amd.generation import all_gather_rows, batches, generate_latents, save_generated, shard_range
+from slide_amd.generation import (FIVE_CATEGORIES, all_gather_rows, batches, category_layout, category_segments,
+                                   generate_categories, generate_latents, save_generated, shard_range)
 
 
 def test_shard_range_matches_reference_rule():
@@ -64,3 +65,43 @@ def _worker(rank, world, port, n, tmp):
 def test_multi_rank_generation_gloo(tmp_path, n, world):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
+
+
+def test_category_segments_cover_every_shard():
+    """BASELINE configs[3]: 2048 shapes, five categories (labels 0, 2, 3, 4, 6), 8 ranks: 256 per rank, <= 2 categories per rank"""
+    lay = category_layout(2048)
+    assert [c for c, _, _ in lay] == list(FIVE_CATEGORIES) and [hi - lo for _, lo, hi in lay] == [410, 410, 410, 409, 409]
+    seen = []
+    for r in range(8):
+        segs = category_segments(2048, r, 8)
+        assert 1 <= len(segs) <= 2 and sum(hi - lo for _, lo, hi in segs) == 256
+        assert segs[0][1] == 256 * r and segs[-1][2] == 256 * (r + 1)
+        seen += segs
+    for c, lo, hi in lay:  # every category's range is tiled exactly by the segments carrying its label
+        mine = sorted((a, b) for cc, a, b in seen if cc == c)
+        assert mine[0][0] == lo and mine[-1][1] == hi and all(mine[i][1] == mine[i + 1][0] for i in range(len(mine) - 1))
+    assert category_segments(3, 2, 4) == [] or sum(h - l for _, l, h in category_segments(3, 2, 4)) <= 1
+
+
+def _worker_cat(rank, world, port, total):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def run_segment(cat, lo, hi):  # stands in for (position chain -> feature chain) of one category's weight set
+        calls.append((cat, lo, hi))
+        idx = torch.arange(lo, hi, dtype=torch.float32)
+        return (idx[:, None, None] * 10 + cat).expand(hi - lo, 16, 51).clone()
+
+    full, labels = generate_categories(total, run_segment, rank, world)
+    assert calls == category_segments(total, rank, world)
+    want = (torch.arange(total, dtype=torch.float32) * 10 + torch.as_tensor(labels, dtype=torch.float32))[:, None, None].expand(total, 16, 51)
+    assert full.shape == (total, 16, 51) and torch.equal(full, want)
+    assert set(labels.tolist()) <= set(FIVE_CATEGORIES)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total,world", [(23, 2), (7, 3)])
+def test_five_category_generation_gloo(total, world):
+    mp.spawn(_worker_cat, args=(world, _free_port(), total), nprocs=world, join=True)

@@ -89,3 +89,37 @@ def test_generation_clis(gpu_device, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     d4 = np.load(out4 / "reconstructed_pcd.npz")
     assert d4["keypoint_feature"].shape == (2, 16, 48) and d4["points"].shape == (2, 2048, 3) and np.isfinite(d4["points"]).all()
+
+
+def test_five_category_end_to_end(gpu_device):
+    """BASELINE configs[3] in miniature: 11 shapes over the five released categories (labels 0, 2, 3, 4, 6), one weight set
+    per category, position DDPM -> feature DDPM conditioned on the generated positions, gathered latents"""
+    import numpy as np
+    import torch
+    from slide_amd import configs, model_spec
+    from slide_amd.generation import FIVE_CATEGORIES, CategoryChains, category_layout
+    from slide_amd.synth import synth_state_dict
+    pc, fc = configs.position_ddpm_config(), configs.feature_ddpm_config()
+    spec_p, spec_f = model_spec.denoiser_param_spec(pc["pointnet_config"]), model_spec.denoiser_param_spec(fc["pointnet_config"])
+    built = []
+
+    def weights(c):
+        built.append(c)
+        return synth_state_dict(spec_p, seed=100 + c), synth_state_dict(spec_f, seed=200 + c)
+
+    total = 11
+    ch = CategoryChains(total, 0, 1, pc, fc, weights, gpu_device, prec="fp16", seed=3)
+    assert built == list(FIVE_CATEGORIES) and [(c, lo, hi) for c, lo, hi, _, _ in ch.chains] == category_layout(total)
+    g = torch.Generator(device=gpu_device)
+    g.manual_seed(1)
+    lat, labels = ch.generate(g, steps=6)
+    lat = lat.cpu().numpy()
+    assert lat.shape == (total, 16, 51) and np.isfinite(lat).all()
+    assert labels.tolist() == [0, 0, 0, 2, 2, 3, 3, 4, 4, 6, 6]
+    # the feature chains were conditioned on the positions their position chains produced
+    for c, lo, hi, ps, fs in ch.chains:
+        assert np.array_equal(lat[lo:hi, :, :3], ps.state().cpu().numpy())
+    # different categories = different weights: the same x_T gives different positions
+    a = ch.chains[0][3].sample(np.zeros(3, np.int64), np.ones((3, 16, 3), np.float32) * 0.1, t_start=10, n_steps=2).cpu().numpy()
+    b = ch.chains[1][3].sample(np.zeros(2, np.int64), np.ones((2, 16, 3), np.float32) * 0.1, t_start=10, n_steps=2).cpu().numpy()
+    assert not np.allclose(a[:2], b)
