@@ -13,7 +13,7 @@
 #include "gemm_common.h"
 
 // gemm_xs.hip: X-stationary kernel (-8: the X tile does not fit the LDS, -4: no such instantiation)
-int slide_launch_gemm_xs(const GemmArgs &a, int npxl, int cbw, bool aff, bool gat, const void *wfrag, hipStream_t s);
+int slide_launch_gemm_xs(const GemmArgs &a, int npxl, int cbw, bool aff, bool gat, int want_occ, hipStream_t s);
 
 namespace {
 
@@ -1372,7 +1372,7 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
   if (o.p[10] && glds && prec == SLIDE_PREC_F16 && o.i[9] != 5 && (npxl == 8 || npxl == 7) && !(a.gfeat && a.in_scale)) {
     int st = -8;
     const bool aff = a.in_scale != nullptr, gat = a.gfeat != nullptr;
-    st = slide_launch_gemm_xs(a, npxl, cbw, aff, gat, o.p[10], s);
+    st = slide_launch_gemm_xs(a, npxl, cbw, aff, gat, o.i[9] >= 11 && o.i[9] <= 13 ? o.i[9] - 10 : 0, s);
     if (st != -8) return st;  // -8: the X tile does not fit the LDS -> ring kernels
   }
   if (glds) {

@@ -283,18 +283,30 @@ class DenoiserEngine:
         wr = sum(rows * v[2] * v[1]["out"].element_size() for v in vec_list)
         self.gemm_bytes[len(self.ops)] = (rd, wr)  # algorithmic HBM bytes (read, written) of this launch
         glds = int(self.use_glds and self.prec == 1 and (sc is None or npx_log2 >= 7))
-        # X-stationary kernel (csrc/gemm_xs.hip: one workgroup per row tile keeps X resident in LDS and computes every column
-        # tile, weights through a small LDS-DMA ring).  OPT-IN (SLIDE_XS=8 or 7,8): bit-identical to the ring kernels and 5x
-        # less L2->LDS traffic, but one workgroup per CU exposes the per-tile epilogue latency that three co-resident ring
-        # workgroups hide: feature chain 1.00 vs 0.94 ms/step at batch 256
+        # X-stationary kernel (csrc/gemm_xs.hip: a workgroup keeps its input resident in LDS -- for the GATHERED first layers
+        # of the SA / FP blocks only the 16-row point table + the coordinate chunk, 24 KB instead of a 144 KB X tile -- and
+        # computes several column tiles of a row tile from it, weights through a small LDS-DMA ring; bit-identical to the ring
+        # kernels, tests/test_hip_engine.py).  OPT-IN.  Measured at batch 256 (round 2): alone on the GPU
+        # the gathered layers gain (SA1 101 -> 85 us, FP1 87 -> 72 us; one feature chain 0.94 -> 0.91 ms/step), but in bench.py's
+        # arrangement (three feature sub-batches + the position chain in flight) every variant LOSES to the ring kernels:
+        # 252 / 270 / 253 shapes/s ("auto" at <= 3 / 2 / 1 workgroups per CU) vs 286 -- the ring tiles' three small
+        # workgroups per CU interleave with the other chains' kernels, these larger-footprint workgroups do not.
+        # SLIDE_XS = "" (default: off) | "auto" (gathered layers + plain layers with >= 8 column tiles per workgroup) |
+        # "7,8" (every eligible layer of those sample sizes).
         wfrag = None
-        xs_levels = {int(v) for v in os.environ.get("SLIDE_XS", "").split(",") if v}
+        xs_mode = os.environ.get("SLIDE_XS", "")
+        xs_levels = {7, 8} if xs_mode == "auto" else {int(v) for v in xs_mode.split(",") if v}
+        xs_lds = ((ld - (gather[3] * 32 if gather is not None else 0)) // 32) * 16384  # resident X rows (gathered chunks: 1 KB each)
         if (glds and npx_log2 in xs_levels and gn_fin is None and not (gather is not None and sc is not None)
-                and (ld // 32) * 16384 + 12 * 1024 <= 160 * 1024):
-            wfrag = Wd  # (selects the kernel; it reads the same row-major weights through a small LDS-DMA ring)
-            cbw = 4 if n_cob >= 4 and os.environ.get("SLIDE_XS_CBW", "4") == "4" else 2
+                and xs_lds + 20 * 1024 <= 160 * 1024):
+            if xs_mode != "auto" or gather is not None or (npx_log2 == 8 and sc is None and n_cob >= 16 and xs_lds > 96 * 1024):
+                wfrag = Wd  # (selects the kernel; it reads the same row-major weights)
+                cbw = 4 if n_cob >= 4 and os.environ.get("SLIDE_XS_CBW", "2") == "4" else 2
         gf = (0.0, 0.0, 0.0) if gather is None else (float(gather[3]), float(gather[0].shape[1]), float({8: 3, 16: 4}[gather[2]]))
-        self._emit(make_op(OP_GEMM, i=(rows, x_ld, ld, n_cob, npx_log2, in_bs, self.prec, cbw, glds, self.glds_nst),
+        knob = self.glds_nst
+        if wfrag is not None and os.environ.get("SLIDE_XS_OCC"):
+            knob = 10 + int(os.environ["SLIDE_XS_OCC"])  # cap the workgroups per CU of the X-stationary kernel (A/B timing)
+        self._emit(make_op(OP_GEMM, i=(rows, x_ld, ld, n_cob, npx_log2, in_bs, self.prec, cbw, glds, knob),
                            f=(-1.0 if self.persistent == 2 else float(os.environ.get('SLIDE_STAGGER_US', '0')),) + gf,
                                 p=(X.data_ptr(), Wd.data_ptr(), ed.data_ptr(),
                                    None if sc is None else sc.data_ptr() + 4 * aff_off,

@@ -388,18 +388,22 @@ def test_threaded_eager_sampler_equals_separate_chains(gpu_device):
 
 
 def test_x_stationary_kernel_bit_identical(gpu_device, monkeypatch):
-    """csrc/gemm_xs.hip (opt-in, SLIDE_XS=8): X tile resident in LDS, all column tiles by one workgroup -- the same MFMA /
-    epilogue arithmetic in the same order as the ring kernels, so the denoiser output must be bit-identical"""
+    """csrc/gemm_xs.hip: input resident in LDS (gathered first layers: only the point table), a workgroup computes several
+    column tiles from it -- the same MFMA / epilogue arithmetic in the same order as the ring kernels, so the denoiser output
+    must be bit-identical in every mode (default policy, every eligible layer, 128-channel tiles, capped occupancy)"""
     from slide_amd.engine import DenoiserEngine
     for name in ("pos", "feat"):
         g, hp, sd = _load(name)
         x, ts, lab = g["x_mixed"], g["ts_mixed"], g["label_mixed"]
-        monkeypatch.delenv("SLIDE_XS", raising=False)
-        ref = DenoiserEngine(hp, sd, x.shape[0], gpu_device, prec="fp16").forward(x, ts, lab).cpu().numpy()
-        for cbw in ("2", "4"):
-            monkeypatch.setenv("SLIDE_XS", "8")
+        monkeypatch.setenv("SLIDE_XS", "")  # ring kernels only
+        e0 = DenoiserEngine(hp, sd, x.shape[0], gpu_device, prec="fp16")
+        assert not any(o.kind == 1 and o.p[10] for o in e0.ops)
+        ref = e0.forward(x, ts, lab).cpu().numpy()
+        for mode, cbw, occ in (("auto", "2", ""), ("7,8", "2", ""), ("7,8", "4", "1"), ("8", "2", "2")):
+            monkeypatch.setenv("SLIDE_XS", mode)
             monkeypatch.setenv("SLIDE_XS_CBW", cbw)
+            monkeypatch.setenv("SLIDE_XS_OCC", occ) if occ else monkeypatch.delenv("SLIDE_XS_OCC", raising=False)
             e = DenoiserEngine(hp, sd, x.shape[0], gpu_device, prec="fp16")
             assert any(o.kind == 1 and o.p[10] for o in e.ops)
             got = e.forward(x, ts, lab).cpu().numpy()
-            assert np.array_equal(got, ref), (name, cbw, float(np.abs(got - ref).max()))
+            assert np.array_equal(got, ref), (name, mode, cbw, occ, float(np.abs(got - ref).max()))

@@ -1,0 +1,71 @@
+"""Builds profiles/<tag>_ops_roofline.md from rocprofv3 runs of tools/ops_roofline.py:
+   <dir>/trace (kernel trace), <dir>/fetch (--pmc FETCH_SIZE), <dir>/write (--pmc WRITE_SIZE), <dir>/manifest.json.
+Dispatches are attributed to cases through the marker kernel (arange) between cases; per case the kernel time is the MEDIAN
+duration of this repo's kernel(s) of one call.  FETCH_SIZE is doubled (gfx950 correction, MI355X_MICROARCH.md section HBM:
+it reports 1/2 of a wide coalesced stream); both counters are in KB."""
+import csv, glob, json, os, sys
+import numpy as np
+
+d, out = sys.argv[1], sys.argv[2]
+man = json.load(open(os.path.join(d, "manifest.json")))["cases"]
+OURS = ("group_points", "gather_points", "three_interpolate", "three_nn", "ball_query", "knn", "fps_kernel", "sample_farthest", "furthest")
+
+
+def split_by_marker(rows, key):
+    groups, cur = [], None
+    for r in rows:
+        name = r["Kernel_Name"]
+        if "arange" in name:
+            if cur is not None:
+                groups.append(cur)
+            cur = []
+        elif cur is not None and any(k in name for k in OURS):
+            cur.append(r)
+    return groups
+
+
+def load(sub, pattern):
+    f = glob.glob(os.path.join(d, sub, "**", pattern), recursive=True)
+    return list(csv.DictReader(open(f[0]))) if f else []
+
+
+tr = load("trace", "*kernel_trace.csv")
+tr.sort(key=lambda r: int(r["Start_Timestamp"]))
+gt = split_by_marker(tr, None)
+pm = {}
+for sub, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    rows = [r for r in load(sub, "*counter_collection.csv")]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    # one row per (dispatch, counter): keep the wanted counter, but markers carry it too
+    rows = [r for r in rows if r["Counter_Name"] == cname]
+    pm[cname] = split_by_marker(rows, None)
+assert len(gt) >= len(man), (len(gt), len(man))
+lines = ["| op | shape | kernel | us / call | algorithmic MB (r + w) | GB/s | frac of 8 TB/s | FETCHx2 + WRITE MB | note |", "|---|---|---|---|---|---|---|---|---|"]
+js = []
+for i, c in enumerate(man):
+    g_ = gt[i]
+    per_call = max(1, len(g_) // c["reps"])
+    dur = np.array([int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in g_], np.float64).reshape(c["reps"], per_call).sum(1) / 1e3
+    us = float(np.median(dur))
+    name = g_[0]["Kernel_Name"].split("(")[0][-60:] if g_ else "?"
+    alg = c["read_B"] + c["write_B"]
+    traffic = None
+    if pm["FETCH_SIZE"] and pm["WRITE_SIZE"] and i < len(pm["FETCH_SIZE"]) and i < len(pm["WRITE_SIZE"]):
+        f_ = np.median(np.array([float(r["Counter_Value"]) for r in pm["FETCH_SIZE"][i]]).reshape(c["reps"], -1).sum(1))
+        w_ = np.median(np.array([float(r["Counter_Value"]) for r in pm["WRITE_SIZE"][i]]).reshape(c["reps"], -1).sum(1))
+        traffic = (2 * f_ + w_) * 1024 / 1e6
+    note = ""
+    if "dist_evals" in c:
+        note = "%.2f T dist/s" % (c["dist_evals"] / us / 1e6)
+    if "selections" in c:
+        note = "%.2f us / selection" % (us / c["selections"])
+    if "physical_read_B" in c:
+        note = "rows touched: %.0f MB" % (c["physical_read_B"] / 1e6)
+    gbs = alg / us / 1e3
+    lines.append("| %s | %s | `%s` | %.1f | %.1f | %.0f | %.3f | %s | %s |" % (c["op"], c["shape"], name, us, alg / 1e6, gbs, gbs / 8000.0,
+                                                                          "%.1f" % traffic if traffic is not None else "-", note))
+    js.append(dict(op=c["op"], shape=c["shape"], us=round(us, 2), algorithmic_MB=round(alg / 1e6, 2), GBps=round(gbs, 1),
+                   frac=round(gbs / 8000.0, 4), traffic_MB=None if traffic is None else round(traffic, 1), note=note))
+open(out, "w").write("\n".join(lines) + "\n")
+json.dump(js, open(out.replace(".md", ".json"), "w"), indent=1)
+print("\n".join(lines))
