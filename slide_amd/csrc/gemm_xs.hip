@@ -1,6 +1,8 @@
 // gemm_xs.hip -- the X-stationary GEMM of the fused denoiser plan (dispatched by engine.hip's run_gemm).
 #include "gemm_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------ X-stationary GEMM
@@ -267,6 +269,8 @@ int launch_gemm_xs(const GemmArgs &a, int cbw_req, int want_occ, hipStream_t s) 
   const int ntc = (a.n_cob + cbw - 1) / cbw;
   // column split: enough workgroups to fill occ x 256 slots, never more than the column tiles
   int nsplit = (occ * 256 + ntr - 1) / ntr;
+  static const int split_cap = [] { const char *e = getenv("SLIDE_XS_NSPLIT"); return e ? atoi(e) : 0; }();  // experiment knob
+  if (split_cap > 0 && nsplit > split_cap) nsplit = split_cap;
   nsplit = nsplit > ntc ? ntc : nsplit;
   nsplit = nsplit < 1 ? 1 : nsplit;
   GemmArgs b = a;

@@ -123,3 +123,82 @@ def test_five_category_end_to_end(gpu_device):
     a = ch.chains[0][3].sample(np.zeros(3, np.int64), np.ones((3, 16, 3), np.float32) * 0.1, t_start=10, n_steps=2).cpu().numpy()
     b = ch.chains[1][3].sample(np.zeros(2, np.int64), np.ones((2, 16, 3), np.float32) * 0.1, t_start=10, n_steps=2).cpu().numpy()
     assert not np.allclose(a[:2], b)
+
+
+def test_released_checkpoint_layout_through_the_clis(gpu_device, tmp_path):
+    """the reference's pickle layout (train.py:243-255: model_state_dict + ema_state_list per EMA rate +
+    optimizer state) loaded by --ckpt / --ema_idx through both generation CLIs and the autoencoder checkpoint through
+    --ae_ckpt: the CLI output must equal a direct sampler run on the EMA-OVERLAID weights (and differ from the raw ones)"""
+    import torch
+    from slide_amd import model_spec
+    from slide_amd.diffusion import PositionSampler
+    from slide_amd.synth import synth_state_dict
+    pc = configs.position_ddpm_config()
+    hp = pc["pointnet_config"]
+    spec = model_spec.denoiser_param_spec(hp)
+    raw, ema0, ema1 = (synth_state_dict(spec, seed=s_) for s_ in (11, 12, 13))
+    ck = tmp_path / "pointnet_ckpt_42.pkl"
+    # EMA lists hold only trainable parameters (data_utils/ema.py:13-18): leave one tensor out of the EMA dicts on purpose
+    skip = "class_emb.weight"
+    torch.save({"model_state_dict": {k: torch.from_numpy(v) for k, v in raw.items()},
+                "ema_state_list": [{k: torch.from_numpy(v) for k, v in e_.items() if k != skip} for e_ in (ema0, ema1)],
+                "optimizer_state_dict": {}, "iter": 42, "training_time_seconds": 1.0}, ck)
+    cdir = tmp_path / "configs" / "a" / "b"
+    os.makedirs(cdir)
+    pc["shapenet_psr_dataset_config"] = {"dataset": "shapenet_psr_dataset", "categories": ["02691156"], "num_keypoints": 16}
+    pc["train_config"] = {"task": "keypoint_generation", "dataset": "shapenet_psr_dataset"}
+    (cdir / "pos.json").write_text(json.dumps(_stringify(pc)))
+    env = dict(os.environ, PYTHONPATH=REPO)
+    cli = os.path.join(REPO, "pointnet2", "sampling_and_inference")
+    out1 = tmp_path / "gen"
+    r = subprocess.run([sys.executable, os.path.join(cli, "point_cloud_generation.py"), "-c", str(cdir / "pos.json"), "--ckpt", str(ck),
+                        "--ema_idx", "1", "--num_samples", "4", "--batch_size", "4", "--save_dir", str(out1), "--seed", "5"],
+                       env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(out1 / "shapenet_psr_generated_data_16_pts.npz")["points"]
+    want_sd = dict(raw)
+    want_sd.update({k: v for k, v in ema1.items() if k != skip})
+    smp = PositionSampler(hp, want_sd, 4, gpu_device, pc["diffusion_config"], prec="fp32", seed=5)
+    xT = np.random.RandomState(5).standard_normal((4, 16, 3)).astype(np.float32)
+    want = smp.sample(np.zeros(4, np.int64), xT).cpu().numpy()
+    assert np.array_equal(got, want)
+    other = PositionSampler(hp, raw, 4, gpu_device, pc["diffusion_config"], prec="fp32", seed=5).sample(np.zeros(4, np.int64), xT).cpu().numpy()
+    assert not np.allclose(got, other)
+    # feature CLI: denoiser --ckpt (EMA 0) + autoencoder --ae_ckpt (model_state_dict of the whole autoencoder), --decode
+    fc = configs.feature_ddpm_config()
+    fspec = model_spec.denoiser_param_spec(fc["pointnet_config"])
+    fraw, fema = synth_state_dict(fspec, seed=21), synth_state_dict(fspec, seed=22)
+    fck = tmp_path / "latent_ckpt.pkl"
+    torch.save({"model_state_dict": {k: torch.from_numpy(v) for k, v in fraw.items()},
+                "ema_state_list": [{k: torch.from_numpy(v) for k, v in fema.items()}], "optimizer_state_dict": {}, "iter": 1}, fck)
+    g = load_golden("golden_decode.npz")
+    decs = json.loads(str(g["decoder_configs_json"]))
+    ae_dir = tmp_path / "configs" / "ae"
+    os.makedirs(ae_dir / "lv")
+    for i, dcfg in enumerate(decs):
+        (ae_dir / "lv" / ("d%d.json" % i)).write_text(json.dumps({"pointnet_config": _stringify(dcfg)}))
+    (ae_dir / "lv" / "enc.json").write_text(json.dumps({"pointnet_config": {"architecture": {"feature_dim": "[32, 64, 128, 256, 256]"}}}))
+    (ae_dir / "ae.json").write_text(json.dumps({"pointnet_config": {"apply_kl_regularization": True, "encoder_config_file": "lv/enc.json",
+                                                                  "decoder_config_file": "['lv/d0.json', 'lv/d1.json', 'lv/d2.json']"}}))
+    aspec = [(str(n), tuple(int(x) for x in str(s_).split(","))) for n, s_ in zip(g["spec_names"], g["spec_shapes"])]
+    avals = synth_state_dict(aspec, seed=31)
+    ack = tmp_path / "ae_ckpt.pkl"
+    # a released autoencoder checkpoint also carries encoder weights: extra keys must be ignored by the decode-only model
+    asd = {n: torch.from_numpy(v) for n, v in avals.items()}
+    asd["encoder.some_unused.weight"] = torch.zeros(3)
+    torch.save({"model_state_dict": asd, "iter": 7}, ack)
+    fc["autoencoder_config"] = {"config_file": str(ae_dir / "ae.json"), "ckpt": str(ack)}
+    (cdir / "feat.json").write_text(json.dumps(_stringify(fc)))
+    out2 = tmp_path / "gen2"
+    r = subprocess.run([sys.executable, os.path.join(cli, "latent_ddpm_keypoint_conditional_generation.py"), "-c", str(cdir / "feat.json"),
+                        "--ckpt", str(fck), "--ema_idx", "0", "--keypoint_file", str(out1 / "shapenet_psr_generated_data_16_pts.npz"),
+                        "--batch_size", "4", "--save_dir", str(out2), "--decode", "--save_keypoint_feature", "--seed", "3"],
+                       env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d2 = np.load(out2 / "shapenet_psr_generated_data_2048_pts.npz")
+    assert d2["points"].shape == (4, 2048, 3) and np.isfinite(d2["points"]).all() and np.allclose(d2["keypoint"], got)
+    from slide_amd.diffusion import FeatureSampler
+    fs = FeatureSampler(fc["pointnet_config"], fema, 4, gpu_device, fc["standard_diffusion_config"], prec="fp32", seed=3)
+    xf = np.random.RandomState(3).standard_normal((4, 16, 51)).astype(np.float32)
+    lat = fs.sample(np.zeros(4, np.int64), got, xf).cpu().numpy()
+    assert np.array_equal(d2["keypoint_feature"], lat[:, :, 3:])
