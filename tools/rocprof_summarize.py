@@ -68,4 +68,22 @@ if os.path.exists(fp) and os.path.exists(wp):
                        "fetch_kib_x2": 2 * fa[k][0] / fa[k][1], "write_kib": w[0] / max(w[1], 1), "dispatches": fa[k][1]}
     json.dump({"source": "profiles/%s_hbm_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH x2 gfx950 "
                          "correction)" % tag, "kernels": kern}, open(os.path.join(dst, "hbm_pmc_latest.json"), "w"), indent=1)
+mp = os.path.join(src, "pmc_mfma", "mfma_counter_collection.csv")
+if os.path.exists(mp):
+    names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_WAIT_ANY"]
+    acc = {n: pmc(mp, n) for n in names}
+    with open(os.path.join(dst, tag + "_mfma_pmc.md"), "w") as f:
+        f.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_ANY over "
+                "`python tools/profile_ops.py --reps 2 --batch 88` (one feature-denoiser step, every launch alone on the GPU)\n\n"
+                "MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (kernel duration x 2.4 GHz x 1024 SIMDs): the fraction of the chip's "
+                "SIMD-cycles with the matrix pipe busy while the kernel runs, priced at the MAXIMUM clock (a lower bound under DVFS; "
+                "MI355X_MICROARCH.md: the counter advances 32 per 32x32x16 MFMA, summed over all SIMDs).  "
+                "wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES: share of wave-cycles parked in s_waitcnt / barriers.\n\n"
+                "| kernel | dispatches | avg us | MFMA utilisation | VALU per MFMA | wait share |\n|---|---|---|---|---|---|\n")
+        ks = [k for k in acc["SQ_BUSY_CYCLES"] if any(t in k for t in ("gemm", "attn"))]
+        for k in sorted(ks, key=lambda k: -acc["SQ_BUSY_CYCLES"][k][2]):
+            g_ = lambda n: acc[n].get(k, [0.0, 1, 0.0])[0]
+            d = acc["SQ_BUSY_CYCLES"][k]
+            f.write("| %s | %d | %.1f | %.3f | %.1f | %.2f |\n" % (k, d[1], d[2] / d[1], g_("SQ_VALU_MFMA_BUSY_CYCLES") / max(d[2] * 2400.0 * 1024.0, 1),
+                                                                g_("SQ_INSTS_VALU") / max(g_("SQ_INSTS_MFMA"), 1), g_("SQ_WAIT_ANY") / max(g_("SQ_WAVE_CYCLES"), 1)))
 print("written", sorted(os.listdir(dst)))
