@@ -3,7 +3,8 @@
 Dispatches are attributed to cases through the marker kernel (arange) between cases; per case the kernel time is the MEDIAN
 duration of this repo's kernel(s) of one call.  FETCH_SIZE is doubled (gfx950 correction, MI355X_MICROARCH.md section HBM:
 it reports 1/2 of a wide coalesced stream); both counters are in KB."""
-import csv, glob, json, os, sys
+import csv
+import re, glob, json, os, sys
 import numpy as np
 
 d, out = sys.argv[1], sys.argv[2]
@@ -47,7 +48,8 @@ for i, c in enumerate(man):
     per_call = max(1, len(g_) // c["reps"])
     dur = np.array([int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in g_], np.float64).reshape(c["reps"], per_call).sum(1) / 1e3
     us = float(np.median(dur))
-    name = g_[0]["Kernel_Name"].split("(")[0][-60:] if g_ else "?"
+    m_ = re.search(r"(\w+)(?:<[^(]*>)?\(", g_[0]["Kernel_Name"].replace("(anonymous namespace)::", "")) if g_ else None
+    name = m_.group(1) if m_ else "?"
     alg = c["read_B"] + c["write_B"]
     traffic = None
     if pm["FETCH_SIZE"] and pm["WRITE_SIZE"] and i < len(pm["FETCH_SIZE"]) and i < len(pm["WRITE_SIZE"]):
