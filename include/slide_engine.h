@@ -76,7 +76,17 @@ enum {
   SLIDE_OP_SYNC = 14,       /* i: from_lane, to_lane -- lane `to` waits for everything issued so far on lane `from` */
   SLIDE_OP_GROUPNORM_NCHW = 13,/* p: x, gamma, beta, y (NCHW fp32)   i: B, C, HW, G, n_norm, relu  (module-level path) */
   SLIDE_OP_ATTN_TAIL = 16,  /* fp16: scores GEMM + values GEMM (GroupNorm, ReLU) + softmax-weighted sum over the neighbours in one launch.  p: u, W5, mo, Wv, out, vec [bias_s | bias_v | gamma | beta][n_cob*32]   i: rows, u_ld, k1, mo_ld, k2, n_cob, npx_log2, gs, n_norm, out_ld   f: 1 / (gs * rows per sample) */
-  SLIDE_OP_TRANSPOSE = 15   /* p: in, out (fp32)   i: B, R, C, in_ld, out_ld, in_batch_stride, out_batch_stride, out_is_fp16: out[b][c][r] = in[b][r][c] (module-level path: NCHW <-> row-major) */
+  SLIDE_OP_TRANSPOSE = 15,  /* p: in, out (fp32)   i: B, R, C, in_ld, out_ld, in_batch_stride, out_batch_stride, out_is_fp16: out[b][c][r] = in[b][r][c] (module-level path: NCHW <-> row-major) */
+  /* Row-major module-level path (rows_ops.hip): an activation is [B * S][ld] (S rows per sample, ld = channels rounded up
+   * to 32, pad columns zero), fp32 or -- i[9] = 1 -- fp16.  Replaces the reference's NCHW tensor program of
+   * Mlp_plus_t_emb / AttentionModule / QueryAndGroup('nn') / group_knn (pointnet2_modules.py:71-176, attention.py:35-96,
+   * pointnet2_utils.py:383-430, :497-524). */
+  SLIDE_OP_ROWS_FROM_NCX = 20, /* p: in (B,C,P) fp32, out rows   i: B, C, P, ld */
+  SLIDE_OP_ROWS_TO_NCX = 21,   /* p: in rows, out (B,C,P) fp32   i: B, C, P, ld */
+  SLIDE_OP_ROWS_GROUP = 22,    /* p: xyz (B,N,3), new_xyz (B,np,3), feat rows [B*N][ldf] (or NULL), idx int64 (B,np,K), d2 (B,np,K) (FP layout), out [B*np*K][ldg]   i: B, N, np, K, C, ldf, ldg, flags (1: group_knn layout [feat|d2|w|abs|rel|centre]; else [feat|rel|abs if 2|centre if 4], 8: no coordinate channels) */
+  SLIDE_OP_ROWS_GN = 23,       /* p: x, gamma, beta, addvec [B][addvec_ld] fp32 (or NULL), residual rows (or NULL), scratch (B*64*ld*2 floats), y (may be x)   i: B, S, ld, G (0 = no normalisation), n_norm, flags (1 ReLU before, 2 ReLU after), addvec_ld, res_ld */
+  SLIDE_OP_ROWS_CONCAT_QK = 24,/* p: q [rows/K][ldq], k [rows][ldk], out [rows][ldo] = relu([q | k])   i: rows, K, C1, ldq, C2, ldk, ldo */
+  SLIDE_OP_ROWS_ATTN = 25      /* p: scores [pts*K][lds], values [pts*K][ldv], out [pts][ldo]   i: pts, K, C, lds, ldv, ldo */
 };
 
 /* GroupNorm finalisation folded into the first consumer (fp16 small-launch GEMM with input affine, SlideOp.p[6]):

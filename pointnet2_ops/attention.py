@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from slide_amd import rows as R
 from slide_amd.nn_ops import HipConv1x1, HipGroupNorm
 
 
@@ -53,8 +54,34 @@ class AttentionModule(nn.Module):
                 layers.append(nn.ReLU(inplace=True))
             self.feat_out_conv = nn.Sequential(*layers)
 
+    def forward_rows(self, query, grouped, grouped_out, K):
+        """query Rows [B * np][C_in1], grouped Rows [B * np * K][C_in2], grouped_out Rows [B * np * K][C_out] -> Rows
+        [B * np][C_out]; every neighbour slot is valid (kNN grouping).  Reference :81-95 as 4-5 GEMMs, three in-place
+        normalise passes, one concat-ReLU pass and one softmax-weighted reduction over the K rows of a point."""
+        wc = list(self.weight_conv)
+        tot = R.concat_qk(R.conv(query, self.feat_conv), R.conv(grouped, self.grouped_feat_conv), K)  # wc[0]: ReLU
+        if isinstance(wc[1], MyGroupNorm):
+            R.norm_act(tot, wc[1].group_norm)
+            u = R.conv(tot, wc[2])
+            R.norm_act(u, wc[4].group_norm, pre_relu=True)
+            scores = R.conv(u, wc[5])
+        else:
+            u = R.conv(tot, wc[1])
+            R.norm_act(u, relu=True)
+            scores = R.conv(u, wc[3])
+        values = grouped_out
+        if self.transform_grouped_feat_out:
+            layers = list(self.feat_out_conv)
+            values = R.conv(grouped_out, layers[0])
+            gn = next((l.group_norm for l in layers[1:] if isinstance(l, MyGroupNorm)), None)
+            R.norm_act(values, gn, relu=any(isinstance(l, nn.ReLU) for l in layers[1:]))
+        return R.attend(scores, values, K)
+
     def forward(self, feat, grouped_feat, grouped_feat_out, count):
         K = grouped_feat.shape[-1]
+        if feat.is_cuda and isinstance(count, str) and count == "all":
+            out = self.forward_rows(R.from_ncx(feat), R.from_ncx(grouped_feat), R.from_ncx(grouped_feat_out), K)
+            return R.to_ncx(out)
         feat1 = self.feat_conv(feat.unsqueeze(-1)).expand(-1, -1, -1, K)
         grouped_feat1 = self.grouped_feat_conv(grouped_feat)
         scores = self.weight_conv(torch.cat([feat1, grouped_feat1], dim=1))

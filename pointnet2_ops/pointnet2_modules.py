@@ -3,9 +3,14 @@ reference (pointnet2_ops_lib/pointnet2_ops/pointnet2_modules.py): Swish (:17-22)
 build_shared_mlp (:44-69), Mlp_plus_t_emb (:71-176), pooling_features (:179-211), PointnetSAModule[MSG] (:213-462),
 PointnetFPModule (:465-588), FeatureMapModule (:591-663), PointnetKnnFPModule (:666-873).
 
-This is the GENERAL (any N / K / radius-or-nn) inference path: neighbour search, FPS and gathers are the HIP `_ext`
-kernels, 1x1 convolutions / linears the HIP MFMA GEMM, GroupNorm a HIP kernel; concatenation, ReLU and the softmax
-glue are torch tensor ops.  The latent-DDPM configurations run on the fused engine instead (slide_amd.engine)."""
+Two execution paths per module:
+  * ROW-MAJOR (slide_amd.rows; taken for the configurations every shipped model uses -- kNN grouping, GroupNorm after the
+    convolution, ReLU, vector attention): a grouped activation is one [B * npoint * K][channels] matrix from the grouping
+    kernel to the attention reduction; reference-layout (B, C, N) tensors exist only at the module boundary.  `forward_rows`
+    methods take / return `slide_amd.rows.Rows`.
+  * GENERAL (any radius-or-nn grouping / bn_first / swish / pooling): the reference's tensor program on NCHW tensors with HIP
+    kernels for search, FPS, gathers, 1x1 convolutions and GroupNorm; concatenation, ReLU and softmax glue are torch ops.
+The latent-DDPM configurations run on the fused engine instead (slide_amd.engine)."""
 import copy
 from typing import List
 
@@ -15,6 +20,7 @@ import torch.nn.functional as F
 
 from pointnet2_ops import pointnet2_utils
 from pointnet2_ops.attention import AttentionModule, GlobalAttentionModule
+from slide_amd import rows as R
 from slide_amd.nn_ops import HipConv1x1, HipGroupNorm, HipLinear
 
 
@@ -63,6 +69,42 @@ def build_shared_mlp(mlp_spec: List[int], bn: bool = True, bn_first: bool = Fals
     return nn.Sequential(*layers)
 
 
+def _seq_rows_ok(seq):
+    """conv -> [GroupNorm] -> [ReLU] stages only (bn_first / swish Sequentials run on the general path)"""
+    layers = [l for l in seq if not isinstance(l, nn.Identity)]
+    if not layers or not isinstance(layers[0], HipConv1x1):
+        return False
+    for a, b in zip(layers, layers[1:] + [None]):
+        if isinstance(a, HipConv1x1):
+            continue
+        if isinstance(a, MyGroupNorm) and (b is None or isinstance(b, (HipConv1x1, nn.ReLU))):
+            continue
+        if isinstance(a, nn.ReLU) and (b is None or isinstance(b, HipConv1x1)):
+            continue
+        return False
+    return True
+
+
+def _seq_rows(seq, x, addvec=None, residual=None):
+    """a shared-MLP Sequential on Rows: every stage = one GEMM + one in-place normalise / ReLU pass; the per-sample
+    embedding vector and the residual the reference adds AFTER the Sequential ride on the last stage's pass"""
+    layers = [l for l in seq if not isinstance(l, nn.Identity)]
+    i, n = 0, len(layers)
+    while i < n:
+        x = R.conv(x, layers[i])
+        i += 1
+        gn, relu = None, False
+        if i < n and isinstance(layers[i], MyGroupNorm):
+            gn, relu = layers[i].group_norm, layers[i].fused_relu
+            i += 1
+        if i < n and isinstance(layers[i], nn.ReLU):
+            relu = True
+            i += 1
+        last = i >= n
+        R.norm_act(x, gn, relu=relu, addvec=addvec if last else None, residual=residual if last else None)
+    return x
+
+
 class Mlp_plus_t_emb(nn.Module):
     def __init__(self, mlp_spec, bn, t_dim=128, include_t=True, bn_first=False, bias=False, first_conv=False,
                  first_conv_in_channel=0, res_connect=False, include_condition=False, condition_dim=128,
@@ -91,7 +133,42 @@ class Mlp_plus_t_emb(nn.Module):
         self.rest_mlp = (build_shared_mlp(mlp_spec[2:], bn, bn_first=bn_first, bias=bias, activation=activation)
                          if len(mlp_spec) > 3 else None)
 
+    def rows_ok(self):
+        return all(_seq_rows_ok(m) for m in (self.first_mlp, self.second_mlp, self.rest_mlp) if m is not None)
+
+    def _check_embeddings(self, t_emb, condition_emb, second_condition_emb):
+        if self.include_t and t_emb is None:
+            raise Exception("Should pass t_emb to the forward function")
+        if not self.include_t and t_emb is not None:
+            raise Exception("This module does not include t but t_emb is given")
+        if self.include_condition and condition_emb is None:
+            raise Exception("Should pass condition_emb to the forward function")
+        if not self.include_condition and condition_emb is not None:
+            raise Exception("This module does not include condition but condition_emb is given")
+        if self.include_second_condition and second_condition_emb is None:
+            raise Exception("Should pass second_condition_emb to the forward function")
+        if not self.include_second_condition and second_condition_emb is not None:
+            raise Exception("This module does not include condition but condition_emb is given")
+
+    def forward_rows(self, x, t_emb=None, condition_emb=None, second_condition_emb=None):
+        """x: Rows [B * S][C_in] -> Rows [B * S][mlp_spec[-1]]: 3-5 GEMMs, each followed by ONE in-place pass that
+        normalises, applies the ReLU and adds the embedding vector / the residual (reference :119-176)"""
+        self._check_embeddings(t_emb, condition_emb, second_condition_emb)
+        feat = R.conv(x, self.first_conv) if self.first_conv_bool else x
+        h = _seq_rows(self.first_mlp, feat, addvec=self.fc(t_emb) if self.include_t else None)
+        h = _seq_rows(self.second_mlp, h, addvec=self.fc_condition(condition_emb) if self.include_condition else None)
+        res = None
+        if self.res_connect_bool:
+            res = R.conv(feat, self.res_connect) if self.res_connect is not None else feat
+        vec2 = self.fc_second_condition(second_condition_emb) if self.include_second_condition else None
+        if self.rest_mlp is not None:
+            return _seq_rows(self.rest_mlp, h, addvec=vec2, residual=res)
+        return R.norm_act(h, addvec=vec2, residual=res)
+
     def forward(self, feature, t_emb=None, condition_emb=None, second_condition_emb=None):
+        if feature.is_cuda and feature.dim() == 4 and self.rows_ok():
+            out = self.forward_rows(R.from_ncx(feature), t_emb, condition_emb, second_condition_emb)
+            return R.to_ncx(out, feature.shape[2:])
         if self.first_conv_bool:
             feature = self.first_conv(feature)
         h = self.first_mlp(feature)
@@ -133,6 +210,26 @@ def pooling_features(feature, count=None, pooling="max"):
     return torch.cat([mx, pointnet2_utils.average_feature(feature[:, half_C:], count, K)], dim=1)
 
 
+def _group_flags(grouper):
+    if not grouper.use_xyz:
+        return R.GROUP_NO_XYZ
+    return (R.GROUP_ABS if grouper.include_abs_coordinate else 0) | (R.GROUP_CENTER if grouper.include_center_coordinate else 0)
+
+
+def _nn_grouper(g):
+    return isinstance(g, pointnet2_utils.QueryAndGroup) and g.neighbor_def == "nn"
+
+
+def _group_rows(grouper, xyz, new_xyz, feat, record_neighbor_stats=False):
+    """QueryAndGroup('nn') on Rows: (grouped Rows [B * npoint * K], K)"""
+    K = min(grouper.nsample, xyz.shape[1])
+    _, idx, _ = pointnet2_utils.knn.knn_points(new_xyz, xyz, K=K)
+    if record_neighbor_stats:  # every centre has exactly K neighbours under the kNN definition
+        grouper.neighbor_stats = torch.full((3,), float(K), device=xyz.device)
+        grouper.neighbor_num_quantile = torch.full((grouper.quantile.numel(),), K, dtype=torch.long, device=xyz.device)
+    return R.group(xyz, new_xyz, feat, idx, _group_flags(grouper)), K
+
+
 def _xyz_extra(use_xyz, include_abs_coordinate, include_center_coordinate):
     return (3 + (3 if include_abs_coordinate else 0) + (3 if include_center_coordinate else 0)) if use_xyz else 0
 
@@ -146,9 +243,13 @@ class _PointnetSAModuleBase(nn.Module):
 
     def forward(self, xyz, features, t_emb=None, condition_emb=None, second_condition_emb=None, subset=True,
                 record_neighbor_stats=False, pooling="max", length=None):
+        assert self.npoint is not None
+        if (xyz.is_cuda and features is not None and length is None and self.use_attention_module
+                and not self.use_global_attention_module and all(_nn_grouper(g) for g in self.groupers)
+                and all(m.rows_ok() for m in self.mlps) and xyz.shape[2] == 3):
+            return self._forward_rows(xyz, features, t_emb, condition_emb, second_condition_emb, record_neighbor_stats)
         new_features_list = []
         xyz_flipped = xyz.transpose(1, 2).contiguous()
-        assert self.npoint is not None
         if xyz.shape[1] <= self.npoint:
             new_xyz = xyz
             if self.use_attention_module:
@@ -174,6 +275,25 @@ class _PointnetSAModuleBase(nn.Module):
                 new_features = self.global_attention_modules[i](new_features)
             new_features_list.append(new_features)
         return new_xyz, torch.cat(new_features_list, dim=1)
+
+
+    def _forward_rows(self, xyz, features, t_emb, condition_emb, second_condition_emb, record_neighbor_stats):
+        """kNN grouping + Mlp + vector attention with every K-expanded tensor row-major (see slide_amd.rows)"""
+        feat = R.from_ncx(features)
+        if xyz.shape[1] <= self.npoint:
+            new_xyz, query = xyz, feat
+        else:
+            fidx = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+            new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), fidx).transpose(1, 2).contiguous()
+            query = R.gather_rows(feat, fidx)
+        outs = []
+        for grouper, mlp, att in zip(self.groupers, self.mlps, self.attention_modules):
+            grouped, K = _group_rows(grouper, xyz, new_xyz, feat, record_neighbor_stats)
+            h = mlp.forward_rows(grouped, t_emb=t_emb if self.include_t else None,
+                                 condition_emb=condition_emb if self.include_condition else None,
+                                 second_condition_emb=second_condition_emb if self.include_second_condition else None)
+            outs.append(att.forward_rows(query, grouped, h, K))
+        return new_xyz, R.to_ncx(outs[0] if len(outs) == 1 else R.concat_cols(outs))
 
 
 class PointnetSAModuleMSG(_PointnetSAModuleBase):
@@ -319,6 +439,11 @@ class FeatureMapModule(nn.Module):
 
     def forward(self, xyz, features, new_xyz, subset=False, record_neighbor_stats=True, pooling="max",
                 features_at_new_xyz=None):
+        if (xyz.is_cuda and self.use_attention_module and features_at_new_xyz is not None and _nn_grouper(self.mapper)
+                and self.mlp.rows_ok() and xyz.shape[2] == 3):
+            grouped, K = _group_rows(self.mapper, xyz, new_xyz, R.from_ncx(features), record_neighbor_stats)
+            out = self.attention_module.forward_rows(R.from_ncx(features_at_new_xyz), grouped, self.mlp.forward_rows(grouped), K)
+            return R.to_ncx(out)
         new_features, count = self.mapper(xyz, new_xyz, features, subset=subset, record_neighbor_stats=record_neighbor_stats,
                                           return_counts=True)
         out_features = self.mlp(new_features)
@@ -384,6 +509,20 @@ class PointnetKnnFPModule(nn.Module):
                 record_neighbor_stats=False, pooling="max"):
         if self.use_attention_module or self.use_global_attention_module:
             assert known is not None and unknown is not None
+        if (known is not None and unknown.is_cuda and self.use_attention_module and not self.use_global_attention_module
+                and not self.include_grouper and unknow_feats is not None and self.mlp1.rows_ok() and self.mlp2.rows_ok()
+                and unknown.shape[2] == 3):
+            # group_knn rows [feat | d2 | w | abs | rel | centre] -> mlp1 -> attention over the K known neighbours;
+            # [interpolated | skip features | xyz] -> mlp2, all row-major
+            d2, idx, _ = pointnet2_utils.knn.knn_points(unknown, known, K=self.K)
+            skip = R.from_ncx(unknow_feats)
+            grouped = R.group(known, unknown, R.from_ncx(known_feats), idx, R.GROUP_FP, d2=d2)
+            h = self.mlp1.forward_rows(grouped, condition_emb=second_condition_emb if self.include_second_condition else None)
+            interpolated = self.attention_module.forward_rows(skip, grouped, h, self.K)
+            out = self.mlp2.forward_rows(R.concat_cols([interpolated, skip, unknown]),
+                                         t_emb=t_emb if self.include_t else None,
+                                         condition_emb=condition_emb if self.include_condition else None)
+            return R.to_ncx(out)
         if known is not None:
             grouped = pointnet2_utils.group_knn(unknown, known, known_feats, self.K, transpose=True).contiguous()
             out = self.mlp1(grouped, t_emb=None,

@@ -13,6 +13,7 @@
 #include "gemm_common.h"
 
 // gemm_xs.hip: X-stationary kernel (-8: the X tile does not fit the LDS, -4: no such instantiation)
+int slide_launch_rows_op(const SlideOp &o, hipStream_t s);  // rows_ops.hip
 int slide_launch_gemm_xs(const GemmArgs &a, int npxl, int cbw, bool aff, bool gat, int want_occ, hipStream_t s);
 
 namespace {
@@ -1598,6 +1599,7 @@ int run_op(const SlideOp &o, hipStream_t s) {
       hipLaunchKernelGGL(advance_t_kernel, dim3(1), dim3(64), 0, s, (int *)o.p[0]);
       break;
     default:
+      if (o.kind >= SLIDE_OP_ROWS_FROM_NCX && o.kind <= SLIDE_OP_ROWS_ATTN) return slide_launch_rows_op(o, s);
       return -1;
   }
   return (int)hipGetLastError();

@@ -1,0 +1,377 @@
+// rows_ops.hip -- gfx950 kernels of the ROW-MAJOR module-level path (pointnet2_ops.pointnet2_modules / attention).
+//
+// The reference keeps activations as (B, C, npoint, K) tensors and runs nn.Conv2d(1x1) / GroupNorm / cat / softmax on
+// them (pointnet2_ops_lib/pointnet2_ops/pointnet2_modules.py:71-176, attention.py:35-96).  Here a grouped activation is
+// ONE matrix [B * npoint * K][ld] (ld = channels rounded up to 32, pad columns zero) that is produced row-major by the
+// grouping kernel, consumed row-major by the MFMA GEMMs, normalised in place and reduced over K by the attention
+// kernel: no layout change between layers, no concatenation copies of K-expanded tensors.  HBM-bound byte movers: one
+// thread owns 4 (GroupNorm) or 8 (grouping) consecutive channels of a row, a wave reads whole rows.
+//
+//   ROWS_FROM_NCX / ROWS_TO_NCX  module boundary: (B, C, P) fp32 <-> [B*P][ld]
+//   ROWS_GROUP    QueryAndGroup 'nn' feature assembly (pointnet2_utils.py:383-430) and group_knn (:497-524)
+//   ROWS_GN       [ReLU] GroupNorm over (group x rows of a sample) [ReLU] [+ per-sample vector] [+ residual rows]
+//   ROWS_CONCAT_QK  relu([query(point) | key(point, neighbour)])    (attention.py:86-88)
+//   ROWS_ATTN     softmax over the K neighbours + weighted sum      (attention.py:89-95)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/slide_engine.h"
+
+namespace {
+
+typedef _Float16 half_t;
+
+template <typename T, int N>
+struct alignas(sizeof(T) * N) Pack { T v[N]; };
+
+// ------------------------------------------------------------------------------------------ layout change at the boundary
+template <typename T>
+__global__ __launch_bounds__(256) void rows_from_ncx_kernel(int C, int P, int ld, const float *__restrict__ in,
+                                                            T *__restrict__ out) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.x * 32, p0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  in += (size_t)b * C * P;
+  out += (size_t)b * P * ld;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, p = p0 + tx;
+    tile[ty + 8 * i][tx] = (c < C && p < P) ? in[(size_t)c * P + p] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = p0 + ty + 8 * i, c = c0 + tx;
+    if (p < P && c < ld) out[(size_t)p * ld + c] = (T)tile[tx][ty + 8 * i];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rows_to_ncx_kernel(int C, int P, int ld, const T *__restrict__ in,
+                                                          float *__restrict__ out) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.x * 32, p0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  in += (size_t)b * P * ld;
+  out += (size_t)b * C * P;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = p0 + ty + 8 * i, c = c0 + tx;
+    if (p < P && c < C) tile[ty + 8 * i][tx] = (float)in[(size_t)p * ld + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, p = p0 + tx;
+    if (p < P && c < C) out[(size_t)c * P + p] = tile[tx][ty + 8 * i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ grouping
+// row (b, p, k) of out = [feat[b][idx[b][p][k]][0..C) | coordinate channels | 0 ...]; coordinate channels:
+//   SA  (flags & 1) == 0:  rel(3) = nbr - centre, then abs(3) if flags & 2, then centre(3) if flags & 4; none if flags & 8
+//   FP  (flags & 1):       d2, w = (1/(d2+1e-8)) / sum_k(1/(d2+1e-8)), abs(3), rel(3), centre(3)
+// feat == NULL: C = 0.  One thread per 8 output columns.
+template <typename T>
+__global__ __launch_bounds__(256) void rows_group_kernel(int N, int np, int K, int C, int ldf, int ldg, int flags,
+                                                         const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                         const T *__restrict__ feat, const int64_t *__restrict__ idx,
+                                                         const float *__restrict__ d2, T *__restrict__ out, size_t total) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int ppr = ldg >> 3;
+  const size_t row = gid / ppr;
+  const int c0 = (int)(gid - row * ppr) * 8;
+  const size_t pt = row / K;  // b * np + p
+  const int b = (int)(pt / np);
+  const int nb = (int)idx[row];
+  T *o = out + row * ldg + c0;
+  const T *f = feat + ((size_t)b * N + nb) * ldf;
+  if (c0 + 8 <= C) {
+    *reinterpret_cast<Pack<T, 8> *>(o) = *reinterpret_cast<const Pack<T, 8> *>(f + c0);
+    return;
+  }
+  Pack<T, 8> r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r.v[j] = (T)0.f;
+  if (c0 < C + 11) {  // this piece holds coordinate channels
+    const float *q = xyz + ((size_t)b * N + nb) * 3;
+    const float *ctr = new_xyz + pt * 3;
+    float cv[11];
+    int ncv;
+    if (flags & 1) {
+      const float *dd = d2 + pt * K;
+      float s = 0.f;
+      for (int k = 0; k < K; ++k) s += 1.0f / (dd[k] + 1e-8f);
+      const float dk = d2[row];
+      cv[0] = dk;
+      cv[1] = (1.0f / (dk + 1e-8f)) / s;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { cv[2 + j] = q[j]; cv[5 + j] = q[j] - ctr[j]; cv[8 + j] = ctr[j]; }
+      ncv = 11;
+    } else if (flags & 8) {
+      ncv = 0;
+    } else {
+      ncv = 3;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) cv[j] = q[j] - ctr[j];
+      if (flags & 2) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cv[ncv + j] = q[j];
+        ncv += 3;
+      }
+      if (flags & 4) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cv[ncv + j] = ctr[j];
+        ncv += 3;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j;
+      if (c < C) r.v[j] = f[c];
+      else if (c - C < ncv) {
+        float v = 0.f;
+#pragma unroll
+        for (int u = 0; u < 11; ++u) v = (c - C == u) ? cv[u] : v;
+        r.v[j] = (T)v;
+      }
+    }
+  }
+  *reinterpret_cast<Pack<T, 8> *>(o) = r;
+}
+
+// ------------------------------------------------------------------------------------------ GroupNorm on rows
+// Thread layout shared by both passes: c4n = ld / 4 threads cover one row (4 channels each), rt = 256 / c4n rows at once.
+// Pass 1: per (sample, row chunk) channel sums of x (or relu(x)) -> part[b][chunk][ld][2]; deterministic (no atomics).
+template <typename T>
+__global__ __launch_bounds__(256) void rows_gn_stats_kernel(int S, int ld, int rpc, int pre_relu, const T *__restrict__ x,
+                                                            float *__restrict__ part) {
+  __shared__ float red[256 * 8];
+  const int c4n = ld >> 2, rt = 256 / c4n;
+  const int pr = threadIdx.x / c4n, pc = threadIdx.x - pr * c4n;
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int r0 = chunk * rpc, r1 = min(S, r0 + rpc);
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  if (pr < rt) {
+    const T *xp = x + ((size_t)b * S) * ld + pc * 4;
+    for (int r = r0 + pr; r < r1; r += rt) {
+      const Pack<T, 4> v = *reinterpret_cast<const Pack<T, 4> *>(xp + (size_t)r * ld);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float f = (float)v.v[j];
+        if (pre_relu) f = fmaxf(f, 0.f);
+        s[j] += f;
+        q[j] += f * f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[(pr * ld + pc * 4 + j) * 2 + 0] = s[j];
+      red[(pr * ld + pc * 4 + j) * 2 + 1] = q[j];
+    }
+  }
+  __syncthreads();
+  float *po = part + (((size_t)b * nchunk + chunk) * ld) * 2;
+  for (int c = threadIdx.x; c < ld; c += 256) {
+    float ss = 0.f, qq = 0.f;
+    for (int r = 0; r < rt; ++r) {
+      ss += red[(r * ld + c) * 2 + 0];
+      qq += red[(r * ld + c) * 2 + 1];
+    }
+    po[c * 2 + 0] = ss;
+    po[c * 2 + 1] = qq;
+  }
+}
+
+// Pass 2: y = post_relu( norm( pre_relu(x) ) ) + addvec[b] + residual[row]; channels >= n_norm skip the normalisation.
+// G == 0: no normalisation at all (part unused) -- the plain ReLU / add epilogue of a layer without GroupNorm.
+template <typename T>
+__global__ __launch_bounds__(256) void rows_gn_apply_kernel(int S, int ld, int rpc, int nchunk_stats, int G, int n_norm,
+                                                            int flags, const T *__restrict__ x,
+                                                            const float *__restrict__ part,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta,
+                                                            const float *__restrict__ addvec, int addvec_ld,
+                                                            const T *__restrict__ res, int res_ld, T *__restrict__ y) {
+  __shared__ float lsum[1024], lsq[1024], lmean[64], lrstd[64];
+  const int c4n = ld >> 2, rt = 256 / c4n;
+  const int pr = threadIdx.x / c4n, pc = threadIdx.x - pr * c4n;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const bool pre_relu = flags & 1, post_relu = flags & 2;
+  if (G > 0) {
+    const float *pp = part + ((size_t)b * nchunk_stats * ld) * 2;
+    for (int c = threadIdx.x; c < n_norm; c += 256) {
+      float ss = 0.f, qq = 0.f;
+      for (int k = 0; k < nchunk_stats; ++k) {
+        ss += pp[((size_t)k * ld + c) * 2 + 0];
+        qq += pp[((size_t)k * ld + c) * 2 + 1];
+      }
+      lsum[c] = ss;
+      lsq[c] = qq;
+    }
+    __syncthreads();
+    const int gs = n_norm / G;
+    const float inv = 1.0f / ((float)gs * (float)S);
+    for (int g = threadIdx.x; g < G; g += 256) {
+      float ss = 0.f, qq = 0.f;
+      for (int j = 0; j < gs; ++j) {
+        ss += lsum[g * gs + j];
+        qq += lsq[g * gs + j];
+      }
+      const float mean = ss * inv;
+      const float var = fmaxf(qq * inv - mean * mean, 0.f);
+      lmean[g] = mean;
+      lrstd[g] = 1.0f / sqrtf(var + 1e-5f);
+    }
+    __syncthreads();
+  }
+  if (pr >= rt) return;
+  float sc[4], sh[4], av[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = pc * 4 + j;
+    sc[j] = 1.f;
+    sh[j] = 0.f;
+    if (G > 0 && c < n_norm) {
+      const int g = c / (n_norm / G);
+      sc[j] = gamma[c] * lrstd[g];
+      sh[j] = beta[c] - lmean[g] * sc[j];
+    }
+    av[j] = (addvec && c < addvec_ld) ? addvec[(size_t)b * addvec_ld + c] : 0.f;
+  }
+  const int r0 = chunk * rpc, r1 = min(S, r0 + rpc);
+  const size_t base = (size_t)b * S;
+  for (int r = r0 + pr; r < r1; r += rt) {
+    const size_t off = (base + r) * ld + pc * 4;
+    Pack<T, 4> v = *reinterpret_cast<const Pack<T, 4> *>(x + off);
+    Pack<T, 4> rv;
+    if (res) rv = *reinterpret_cast<const Pack<T, 4> *>(res + (base + r) * res_ld + pc * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float f = (float)v.v[j];
+      if (pre_relu) f = fmaxf(f, 0.f);
+      f = f * sc[j] + sh[j];
+      if (post_relu) f = fmaxf(f, 0.f);
+      f += av[j];
+      if (res) f += (float)rv.v[j];
+      v.v[j] = (T)f;
+    }
+    *reinterpret_cast<Pack<T, 4> *>(y + off) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ attention glue
+// out[row][0..C1) = relu(q[row / K]), out[row][C1..C1+C2) = relu(k[row]), rest 0
+template <typename T>
+__global__ __launch_bounds__(256) void rows_concat_qk_kernel(int K, int C1, int ldq, int C2, int ldk, int ldo,
+                                                             const T *__restrict__ q, const T *__restrict__ k,
+                                                             T *__restrict__ out, size_t total) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int ppr = ldo >> 2;
+  const size_t row = gid / ppr;
+  const int c0 = (int)(gid - row * ppr) * 4;
+  const T *qr = q + (row / K) * ldq;
+  const T *kr = k + row * ldk;
+  Pack<T, 4> r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + j;
+    float v = 0.f;
+    if (c < C1) v = (float)qr[c];
+    else if (c < C1 + C2) v = (float)kr[c - C1];
+    r.v[j] = (T)fmaxf(v, 0.f);
+  }
+  *reinterpret_cast<Pack<T, 4> *>(out + row * ldo + c0) = r;
+}
+
+// out[pt][c] = sum_k softmax_k(S[pt*K + k][c]) * V[pt*K + k][c]; one thread per (point, channel), consecutive threads ->
+// consecutive channels of the same rows
+template <typename T>
+__global__ __launch_bounds__(256) void rows_attn_kernel(int K, int C, int lds_, int ldv, int ldo, const T *__restrict__ Sx,
+                                                        const T *__restrict__ V, T *__restrict__ out, size_t total) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const size_t pt = gid / ldo;
+  const int c = (int)(gid - pt * ldo);
+  if (c >= C) {
+    out[gid] = (T)0.f;
+    return;
+  }
+  const T *sp = Sx + pt * K * lds_ + c;
+  const T *vp = V + pt * K * ldv + c;
+  float m = -INFINITY;
+  for (int k = 0; k < K; ++k) m = fmaxf(m, (float)sp[(size_t)k * lds_]);
+  float l = 0.f;
+  for (int k = 0; k < K; ++k) l += expf((float)sp[(size_t)k * lds_] - m);
+  const float rl = 1.0f / l;
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) acc += (float)vp[(size_t)k * ldv] * (expf((float)sp[(size_t)k * lds_] - m) * rl);
+  out[gid] = (T)acc;
+}
+
+template <typename T>
+int launch_rows(const SlideOp &o, hipStream_t s) {
+  switch (o.kind) {
+    case SLIDE_OP_ROWS_FROM_NCX: {  // i: B, C, P, ld
+      const int B = o.i[0], C = o.i[1], P = o.i[2], ld = o.i[3];
+      hipLaunchKernelGGL(rows_from_ncx_kernel<T>, dim3(ld / 32, (P + 31) / 32, B), dim3(256), 0, s, C, P, ld,
+                         (const float *)o.p[0], (T *)o.p[1]);
+      break;
+    }
+    case SLIDE_OP_ROWS_TO_NCX: {
+      const int B = o.i[0], C = o.i[1], P = o.i[2], ld = o.i[3];
+      hipLaunchKernelGGL(rows_to_ncx_kernel<T>, dim3((C + 31) / 32, (P + 31) / 32, B), dim3(256), 0, s, C, P, ld,
+                         (const T *)o.p[0], (float *)o.p[1]);
+      break;
+    }
+    case SLIDE_OP_ROWS_GROUP: {  // i: B, N, np, K, C, ldf, ldg, flags
+      const int B = o.i[0], N = o.i[1], np = o.i[2], K = o.i[3], C = o.i[4], ldf = o.i[5], ldg = o.i[6], flags = o.i[7];
+      if (ldg % 8 || (C > 0 && ldf % 8) || C + ((flags & 1) ? 11 : (flags & 8) ? 0 : 3 + ((flags & 2) ? 3 : 0) + ((flags & 4) ? 3 : 0)) > ldg) return -3;
+      const size_t total = (size_t)B * np * K * (ldg / 8);
+      hipLaunchKernelGGL(rows_group_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, N, np, K, C, ldf, ldg,
+                         flags, (const float *)o.p[0], (const float *)o.p[1], (const T *)o.p[2], (const int64_t *)o.p[3],
+                         (const float *)o.p[4], (T *)o.p[5], total);
+      break;
+    }
+    case SLIDE_OP_ROWS_GN: {  // i: B, S, ld, G, n_norm, flags, addvec_ld, res_ld   p: x, gamma, beta, addvec, residual, part, y
+      const int B = o.i[0], S = o.i[1], ld = o.i[2], G = o.i[3], n_norm = o.i[4], flags = o.i[5];
+      if (ld % 32 || ld > 1024 || G > 64 || (G > 0 && n_norm % G)) return -3;
+      const int rt = 256 / (ld / 4);
+      int nchunk = (S + rt * 8 - 1) / (rt * 8);
+      nchunk = nchunk < 1 ? 1 : nchunk > 64 ? 64 : nchunk;
+      const int rpc = (S + nchunk - 1) / nchunk;
+      nchunk = (S + rpc - 1) / rpc;
+      if (G > 0)
+        hipLaunchKernelGGL(rows_gn_stats_kernel<T>, dim3(nchunk, B), dim3(256), 0, s, S, ld, rpc, flags & 1, (const T *)o.p[0],
+                           (float *)o.p[5]);
+      hipLaunchKernelGGL(rows_gn_apply_kernel<T>, dim3(nchunk, B), dim3(256), 0, s, S, ld, rpc, nchunk, G, n_norm, flags,
+                         (const T *)o.p[0], (const float *)o.p[5], (const float *)o.p[1], (const float *)o.p[2],
+                         (const float *)o.p[3], o.i[6], (const T *)o.p[4], o.i[7], (T *)o.p[6]);
+      break;
+    }
+    case SLIDE_OP_ROWS_CONCAT_QK: {  // i: rows, K, C1, ldq, C2, ldk, ldo   p: q, k, out
+      const size_t total = (size_t)o.i[0] * (o.i[6] / 4);
+      hipLaunchKernelGGL(rows_concat_qk_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, o.i[1], o.i[2],
+                         o.i[3], o.i[4], o.i[5], o.i[6], (const T *)o.p[0], (const T *)o.p[1], (T *)o.p[2], total);
+      break;
+    }
+    case SLIDE_OP_ROWS_ATTN: {  // i: points, K, C, lds, ldv, ldo   p: S, V, out
+      const size_t total = (size_t)o.i[0] * o.i[5];
+      hipLaunchKernelGGL(rows_attn_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, o.i[1], o.i[2], o.i[3],
+                         o.i[4], o.i[5], (const T *)o.p[0], (const T *)o.p[1], (T *)o.p[2], total);
+      break;
+    }
+    default:
+      return -1;
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// called from engine.hip's op dispatcher; i[9] = 1: fp16 activations
+int slide_launch_rows_op(const SlideOp &o, hipStream_t s) {
+  return o.i[9] ? launch_rows<half_t>(o, s) : launch_rows<float>(o, s);
+}

@@ -1,0 +1,240 @@
+"""Row-major activations of the module-level path (`pointnet2_ops.pointnet2_modules`, `pointnet2_ops.attention`).
+
+The reference moves (B, C, npoint, K) tensors through nn.Conv2d(1x1) / GroupNorm / torch.cat / softmax
+(pointnet2_ops_lib/pointnet2_ops/pointnet2_modules.py:71-176, attention.py:35-96).  On MI355X those layers are HBM-bound
+and the NCHW layout forces a transpose on either side of every GEMM, so the HIP path keeps a grouped activation as ONE
+matrix `Rows.data` [B * S][ld] (S = npoint * K rows per sample, ld = channels rounded up to 32, pad columns zero; fp32,
+or fp16 with SLIDE_MODULE_PREC=fp16): the grouping kernel writes it, the MFMA GEMM reads and writes it, GroupNorm / ReLU /
+the t- and class-embedding adds / the residual run in place in one pass, and the attention kernel reduces it over K.
+Reference-layout tensors exist only at module boundaries (`from_ncx` / `to_ncx`).
+
+Everything here launches kernels of libslide_hip.so (rows_ops.hip + the engine GEMM); there is no CPU fallback."""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from ._lib import check, lib
+from .engine import EPI_RAW, OP_GEMM, SlideEpi, SlideOp, make_op, ru
+
+OP_COPY_COLS = 7
+OP_ROWS_FROM_NCX, OP_ROWS_TO_NCX, OP_ROWS_GROUP, OP_ROWS_GN, OP_ROWS_CONCAT_QK, OP_ROWS_ATTN = 20, 21, 22, 23, 24, 25
+GROUP_FP, GROUP_ABS, GROUP_CENTER, GROUP_NO_XYZ = 1, 2, 4, 8
+GN_PRE_RELU, GN_POST_RELU = 1, 2
+
+
+def half_mode():
+    return os.environ.get("SLIDE_MODULE_PREC", "fp32") == "fp16"
+
+
+def _run(op):
+    arr = (SlideOp * 1)(op)
+    check(lib().slide_run_ops(arr, 1, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "slide_run_ops")
+
+
+def _rop(kind, half, i, p):
+    i = tuple(i) + (0,) * (9 - len(i)) + (int(half),)
+    return make_op(kind, i=i, p=tuple(None if v is None else (v if isinstance(v, int) else v.data_ptr()) for v in p))
+
+
+class Rows:
+    """[B * S][ld] activation, `C` valid channels"""
+    __slots__ = ("data", "B", "S", "C")
+
+    def __init__(self, data, B, S, C):
+        assert data.dim() == 2 and data.shape[0] == B * S and data.shape[1] % 32 == 0 and data.is_contiguous()
+        self.data, self.B, self.S, self.C = data, B, S, C
+
+    @property
+    def ld(self):
+        return self.data.shape[1]
+
+    @property
+    def half(self):
+        return self.data.dtype == torch.float16
+
+    @property
+    def rows(self):
+        return self.data.shape[0]
+
+
+def _empty(rows, ld, half, device):
+    return torch.empty(rows, ld, device=device, dtype=torch.float16 if half else torch.float32)
+
+
+def from_ncx(x):
+    """(B, C, *spatial) fp32 -> Rows with S = prod(spatial)"""
+    if not x.is_cuda:
+        raise RuntimeError("CPU not supported")
+    x = x.contiguous().float()
+    B, C = x.shape[:2]
+    P = int(np.prod(x.shape[2:])) if x.dim() > 2 else 1
+    half = half_mode()
+    out = _empty(B * P, ru(C), half, x.device)
+    _run(_rop(OP_ROWS_FROM_NCX, half, (B, C, P, out.shape[1]), (x, out)))
+    return Rows(out, B, P, C)
+
+
+def to_ncx(r, spatial=None):
+    """Rows -> (B, C, *spatial) fp32"""
+    out = torch.empty((r.B, r.C) + tuple(spatial if spatial is not None else (r.S,)), device=r.data.device, dtype=torch.float32)
+    _run(_rop(OP_ROWS_TO_NCX, r.half, (r.B, r.C, r.S, r.ld), (r.data, out)))
+    return out
+
+
+def from_points(x):
+    """(B, N, C) fp32 point-major tensor -> Rows (dtype conversion + column padding only)"""
+    B, N, C = x.shape
+    x = x.contiguous().float()
+    half = half_mode()
+    out = torch.zeros(B * N, ru(C), device=x.device, dtype=torch.float16 if half else torch.float32)
+    _run(make_op(OP_COPY_COLS, i=(B * N, C, C, out.shape[1], 0, int(half)), p=(x.data_ptr(), out.data_ptr())))
+    return Rows(out, B, N, C)
+
+
+def to_points(r):
+    """Rows -> (B, S, C) fp32"""
+    out = torch.empty(r.B, r.S, r.C, device=r.data.device, dtype=torch.float32)
+    _run(make_op(OP_COPY_COLS, i=(r.rows, r.C, r.ld, r.C, int(r.half), 0), p=(r.data.data_ptr(), out.data_ptr())))
+    return out
+
+
+def concat_cols(parts):
+    """channel concatenation of Rows with equal (B, S); a part may also be a (B, S, c) fp32 tensor (coordinates)"""
+    first = next(p for p in parts if isinstance(p, Rows))
+    B, S, half, dev = first.B, first.S, first.half, first.data.device
+    widths = [p.C if isinstance(p, Rows) else p.shape[-1] for p in parts]
+    C = sum(widths)
+    out = torch.zeros(B * S, ru(C), device=dev, dtype=torch.float16 if half else torch.float32)
+    esz = out.element_size()
+    c0 = 0
+    for p, w in zip(parts, widths):
+        if isinstance(p, Rows):
+            src, sld, s16 = p.data, p.ld, int(p.half)
+        else:
+            src, sld, s16 = p.contiguous().float(), w, 0
+        _run(make_op(OP_COPY_COLS, i=(B * S, w, sld, out.shape[1], s16, int(half)), p=(src.data_ptr(), out.data_ptr() + c0 * esz)))
+        c0 += w
+    return Rows(out, B, S, C)
+
+
+# ----------------------------------------------------------------------------------------------------------- GEMM
+class _ConvPlan:
+    """packed weight + bias of one 1x1 convolution / linear for the row-major GEMM: y[rows, O] = x[rows, I] @ W^T + b"""
+
+    def __init__(self, weight, bias, half, device):
+        O, I = weight.shape[0], int(np.prod(weight.shape[1:]))
+        self.O, self.I, self.kp, self.op_ = O, I, ru(I), ru(O)
+        self.half = half
+        W = torch.zeros(self.op_, self.kp, device=device, dtype=torch.float32)
+        W[:O, :I] = weight.detach().reshape(O, I).float()
+        self.W = W.to(torch.float16 if half else torch.float32)
+        self.vec = torch.zeros(self.op_, device=device, dtype=torch.float32)
+        if bias is not None:
+            self.vec[:O] = bias.detach().float()
+        self.epis = {}  # output pointer -> device epilogue table (the caching allocator recycles a handful of addresses)
+
+    def epi(self, out):
+        key = out.data_ptr()
+        e = self.epis.get(key)
+        if e is None:
+            if len(self.epis) >= 8:
+                self.epis.clear()
+            n_cob = self.op_ // 32
+            esz = out.element_size()
+            tab = (SlideEpi * n_cob)()
+            for j in range(n_cob):
+                t = tab[j]
+                t.mode = EPI_RAW
+                t.flags = 0
+                t.out_ld = self.op_
+                t.bias = self.vec.data_ptr() + 4 * 32 * j
+                t.out = key + esz * 32 * j
+            e = torch.from_numpy(np.frombuffer(bytes(tab), dtype=np.uint8).copy()).to(out.device)
+            self.epis[key] = e
+        return e
+
+    def run(self, x):
+        assert x.ld == self.kp and x.half == self.half, (x.ld, self.kp, x.half, self.half)
+        rows = x.rows
+        out = _empty(rows, self.op_, self.half, x.data.device)
+        n_cob = self.op_ // 32
+        ntr = (rows + 255) // 256
+        cbw = 4 if (self.half and n_cob >= 4 and ntr * ((n_cob + 3) // 4) >= 256) else 2
+        _run(make_op(OP_GEMM, i=(rows, self.kp, self.kp, n_cob, 8, 0, int(self.half), cbw, int(self.half), 0),
+                     p=(x.data.data_ptr(), self.W.data_ptr(), self.epi(out).data_ptr(), None, None)))
+        return Rows(out, x.B, x.S, self.O)
+
+
+def conv(x, module):
+    """HipConv1x1 / HipLinear applied to Rows (weights re-packed when the parameter changes)"""
+    w = module.weight
+    key = (w._version, w.data_ptr(), x.half)
+    plan = module.__dict__.get("_rows_plan")
+    if plan is None or plan[0] != key:
+        plan = (key, _ConvPlan(w, module.bias, x.half, x.data.device))
+        module.__dict__["_rows_plan"] = plan
+    return plan[1].run(x)
+
+
+# ----------------------------------------------------------------------------------------------------------- fused layers
+def norm_act(x, gn=None, pre_relu=False, relu=False, addvec=None, residual=None):
+    """in place: x <- relu?(GroupNorm?(relu?(x))) + addvec[b] + residual.  gn: HipGroupNorm (num_groups over its first
+    num_channels channels, the rest pass through) or None."""
+    if gn is None and not (pre_relu or relu or addvec is not None or residual is not None):
+        return x
+    G, n_norm = (gn.num_groups, gn.num_channels) if gn is not None else (0, 0)
+    part = torch.empty(x.B * 64 * x.ld * 2, device=x.data.device, dtype=torch.float32) if G else None
+    if addvec is not None:
+        addvec = addvec.contiguous().float()
+        assert addvec.shape[0] == x.B and addvec.shape[1] <= x.ld
+    if residual is not None:
+        assert residual.rows == x.rows and residual.half == x.half and residual.ld >= x.ld
+    flags = (GN_PRE_RELU if pre_relu else 0) | (GN_POST_RELU if relu else 0)
+    _run(_rop(OP_ROWS_GN, x.half, (x.B, x.S, x.ld, G, n_norm, flags, addvec.shape[1] if addvec is not None else 0,
+                                   residual.ld if residual is not None else 0),
+              (x.data, gn.weight if G else None, gn.bias if G else None, addvec, residual.data if residual is not None else None,
+               part, x.data)))
+    return x
+
+
+def group(xyz, new_xyz, feat, idx, flags, d2=None):
+    """grouped input of an SA / feature-map block (QueryAndGroup 'nn') or of a kNN feature-propagation block (group_knn):
+    xyz (B,N,3), new_xyz (B,np,3), feat Rows [B*N] or None, idx (B,np,K) int64 -> Rows [B*np*K]"""
+    B, N = xyz.shape[:2]
+    npnt, K = idx.shape[1:]
+    C = feat.C if feat is not None else 0
+    ncoord = 11 if flags & GROUP_FP else 0 if flags & GROUP_NO_XYZ else 3 + (3 if flags & GROUP_ABS else 0) + (3 if flags & GROUP_CENTER else 0)
+    half = feat.half if feat is not None else half_mode()
+    out = _empty(B * npnt * K, ru(C + ncoord), half, xyz.device)
+    assert idx.dtype == torch.int64 and idx.is_contiguous()
+    _run(_rop(OP_ROWS_GROUP, half, (B, N, npnt, K, C, feat.ld if feat is not None else 8, out.shape[1], flags),
+              (xyz.contiguous().float(), new_xyz.contiguous().float(), feat.data if feat is not None else None, idx,
+               d2.contiguous() if d2 is not None else None, out)))
+    return Rows(out, B, npnt * K, C + ncoord)
+
+
+def gather_rows(feat, idx):
+    """feat Rows [B*N], idx (B, m) int -> Rows [B*m]: rows idx of every sample"""
+    B, m = idx.shape
+    z = torch.zeros(B, max(feat.S, m), 3, device=feat.data.device)
+    return group(z[:, :feat.S], z[:, :m], feat, idx.long().reshape(B, m, 1).contiguous(), GROUP_NO_XYZ)
+
+
+def concat_qk(q, k, K):
+    """relu([q(point) broadcast over the K neighbours | k(point, neighbour)]) -> Rows [rows of k]"""
+    assert k.rows == q.rows * K and q.half == k.half
+    C = q.C + k.C
+    out = _empty(k.rows, ru(C), k.half, k.data.device)
+    _run(_rop(OP_ROWS_CONCAT_QK, k.half, (k.rows, K, q.C, q.ld, k.C, k.ld, out.shape[1]), (q.data, k.data, out)))
+    return Rows(out, k.B, k.S, C)
+
+
+def attend(scores, values, K):
+    """softmax over the K neighbour rows of each point, weighted sum of the values -> Rows [B * S / K]"""
+    assert scores.rows == values.rows and scores.C == values.C and scores.half == values.half
+    pts = scores.rows // K
+    out = _empty(pts, ru(scores.C), scores.half, scores.data.device)
+    _run(_rop(OP_ROWS_ATTN, scores.half, (pts, K, scores.C, scores.ld, values.ld, out.shape[1]), (scores.data, values.data, out)))
+    return Rows(out, scores.B, scores.S // K, scores.C)
