@@ -1,6 +1,8 @@
 """`pointnet2_ops.attention` (reference pointnet2_ops_lib/pointnet2_ops/attention.py): MyGroupNorm (:6-23),
 AttentionModule (:35-96, vector attention over the K neighbours), GlobalAttentionModule (:98-155) -- same constructor
 signatures and state-dict names; convolutions / GroupNorm run on HIP kernels (slide_amd.nn_ops)."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -79,7 +81,7 @@ class AttentionModule(nn.Module):
 
     def forward(self, feat, grouped_feat, grouped_feat_out, count):
         K = grouped_feat.shape[-1]
-        if feat.is_cuda and isinstance(count, str) and count == "all":
+        if feat.is_cuda and isinstance(count, str) and count == "all" and os.environ.get("SLIDE_MODULE_ROWS", "1") != "0":
             out = self.forward_rows(R.from_ncx(feat), R.from_ncx(grouped_feat), R.from_ncx(grouped_feat_out), K)
             return R.to_ncx(out)
         feat1 = self.feat_conv(feat.unsqueeze(-1)).expand(-1, -1, -1, K)

@@ -12,6 +12,7 @@ Two execution paths per module:
     kernels for search, FPS, gathers, 1x1 convolutions and GroupNorm; concatenation, ReLU and softmax glue are torch ops.
 The latent-DDPM configurations run on the fused engine instead (slide_amd.engine)."""
 import copy
+import os
 from typing import List
 
 import torch
@@ -166,7 +167,7 @@ class Mlp_plus_t_emb(nn.Module):
         return R.norm_act(h, addvec=vec2, residual=res)
 
     def forward(self, feature, t_emb=None, condition_emb=None, second_condition_emb=None):
-        if feature.is_cuda and feature.dim() == 4 and self.rows_ok():
+        if _rows_enabled(feature) and feature.dim() == 4 and self.rows_ok():
             out = self.forward_rows(R.from_ncx(feature), t_emb, condition_emb, second_condition_emb)
             return R.to_ncx(out, feature.shape[2:])
         if self.first_conv_bool:
@@ -210,6 +211,11 @@ def pooling_features(feature, count=None, pooling="max"):
     return torch.cat([mx, pointnet2_utils.average_feature(feature[:, half_C:], count, K)], dim=1)
 
 
+def _rows_enabled(t):
+    """row-major fast path switch: CUDA tensors, unless SLIDE_MODULE_ROWS=0 forces the general NCHW program (A/B tests)"""
+    return t.is_cuda and os.environ.get("SLIDE_MODULE_ROWS", "1") != "0"
+
+
 def _group_flags(grouper):
     if not grouper.use_xyz:
         return R.GROUP_NO_XYZ
@@ -244,7 +250,7 @@ class _PointnetSAModuleBase(nn.Module):
     def forward(self, xyz, features, t_emb=None, condition_emb=None, second_condition_emb=None, subset=True,
                 record_neighbor_stats=False, pooling="max", length=None):
         assert self.npoint is not None
-        if (xyz.is_cuda and features is not None and length is None and self.use_attention_module
+        if (_rows_enabled(xyz) and features is not None and length is None and self.use_attention_module
                 and not self.use_global_attention_module and all(_nn_grouper(g) for g in self.groupers)
                 and all(m.rows_ok() for m in self.mlps) and xyz.shape[2] == 3):
             return self._forward_rows(xyz, features, t_emb, condition_emb, second_condition_emb, record_neighbor_stats)
@@ -439,7 +445,7 @@ class FeatureMapModule(nn.Module):
 
     def forward(self, xyz, features, new_xyz, subset=False, record_neighbor_stats=True, pooling="max",
                 features_at_new_xyz=None):
-        if (xyz.is_cuda and self.use_attention_module and features_at_new_xyz is not None and _nn_grouper(self.mapper)
+        if (_rows_enabled(xyz) and self.use_attention_module and features_at_new_xyz is not None and _nn_grouper(self.mapper)
                 and self.mlp.rows_ok() and xyz.shape[2] == 3):
             grouped, K = _group_rows(self.mapper, xyz, new_xyz, R.from_ncx(features), record_neighbor_stats)
             out = self.attention_module.forward_rows(R.from_ncx(features_at_new_xyz), grouped, self.mlp.forward_rows(grouped), K)
@@ -509,7 +515,7 @@ class PointnetKnnFPModule(nn.Module):
                 record_neighbor_stats=False, pooling="max"):
         if self.use_attention_module or self.use_global_attention_module:
             assert known is not None and unknown is not None
-        if (known is not None and unknown.is_cuda and self.use_attention_module and not self.use_global_attention_module
+        if (known is not None and _rows_enabled(unknown) and self.use_attention_module and not self.use_global_attention_module
                 and not self.include_grouper and unknow_feats is not None and self.mlp1.rows_ok() and self.mlp2.rows_ok()
                 and unknown.shape[2] == 3):
             # group_knn rows [feat | d2 | w | abs | rel | centre] -> mlp1 -> attention over the K known neighbours;

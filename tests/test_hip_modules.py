@@ -188,3 +188,67 @@ def test_sample_farthest_points(gpu_device):
         ro, ri = O.sample_farthest_points(p, K, start)
         go, gi = _ext.sample_farthest_points(T(p, gpu_device), K=K, start_idx=torch.from_numpy(start))
         assert np.array_equal(gi.cpu().numpy(), ri) and np.array_equal(go.cpu().numpy(), ro)
+
+
+def _ab(monkeypatch, fn):
+    """run fn() on the row-major fast path and on the general NCHW program"""
+    monkeypatch.setenv("SLIDE_MODULE_ROWS", "1")
+    a = fn()
+    monkeypatch.setenv("SLIDE_MODULE_ROWS", "0")
+    b = fn()
+    monkeypatch.delenv("SLIDE_MODULE_ROWS")
+    return a, b
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_row_major_path_equals_general_program(gpu_device, monkeypatch, prec):
+    """The row-major fast path (slide_amd.rows) and the general NCHW program are two implementations of the same
+    reference modules: same outputs on random weights -- multi-scale grouping, fewer points than npoint (no FPS), odd
+    channel counts (pad columns, un-normalised GroupNorm tail channels), K larger than a wave of rows, no attention bn."""
+    from pointnet2_ops import pointnet2_modules as PM
+    monkeypatch.setenv("SLIDE_MODULE_PREC", prec)
+    tol = dict(atol=2e-4, rtol=1e-4) if prec == "fp32" else dict(atol=3e-2, rtol=3e-2)
+    d = gpu_device
+    gen = torch.Generator().manual_seed(5)
+    B, N, C = 3, 200, 13
+    xyz = torch.rand(B, N, 3, generator=gen).to(d)
+    feats = torch.randn(B, C, N, generator=gen).to(d)
+    temb, cemb = torch.randn(B, 24, generator=gen).to(d), torch.randn(B, 10, generator=gen).to(d)
+
+    def randomise(m):
+        g2 = torch.Generator().manual_seed(11)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                p.copy_(torch.randn(p.shape, generator=g2) * (0.3 if p.dim() > 1 else 0.5) + (1.0 if n.endswith("group_norm.weight") else 0.0))
+        return m.to(d).eval()
+
+    for att_bn, last_act in ((True, True), (False, False)):
+        att = {"use_attention_module": True, "attention_bn": att_bn, "transform_grouped_feat_out": True, "last_activation": last_act}
+        sa = randomise(PM.PointnetSAModuleMSG(npoint=50, radii=[0, 0], nsamples=[5, 48], mlps=[[C, 20, 20, 45], [C, 16, 24, 40, 33]],
+                                              bn=True, use_xyz=True, t_dim=24, include_t=True, include_abs_coordinate=True,
+                                              include_center_coordinate=False, bias=True, res_connect=True, include_condition=True,
+                                              condition_dim=10, neighbor_def="nn", attention_setting=att))
+        (ax, af), (bx, bf) = _ab(monkeypatch, lambda: sa(xyz, feats, t_emb=temb, condition_emb=cemb))
+        assert torch.equal(ax, bx) and af.shape == (B, 45 + 33, 50)
+        assert torch.allclose(af, bf, **tol), float((af - bf).abs().max())
+    # fewer points than npoint: every point is a centre, the query features are the input features
+    sa = randomise(PM.PointnetSAModule(mlp=[C, 16, 16, 32], npoint=512, radius=0, nsample=16, bn=True, use_xyz=True,
+                                       include_t=False, include_abs_coordinate=True, include_center_coordinate=True, bias=False,
+                                       res_connect=False, neighbor_def="nn", attention_setting=att))
+    (ax, af), (bx, bf) = _ab(monkeypatch, lambda: sa(xyz, feats))
+    assert ax.shape == (B, N, 3) and torch.allclose(af, bf, **tol), float((af - bf).abs().max())
+    # kNN feature propagation: 40 known points -> 200 unknown points, skip features, t / class embeddings
+    att = {"use_attention_module": True, "attention_bn": True, "transform_grouped_feat_out": True, "last_activation": True}
+    known, kf = xyz[:, :40].contiguous(), torch.randn(B, 21, 40, generator=gen).to(d)
+    fp = randomise(PM.PointnetKnnFPModule(mlp1=[21, 24, 24, 30], mlp2=[30 + C, 36, 36], K=7, bn=True, t_dim=24, include_t=True,
+                                          bias=True, res_connect=True, include_condition=True, condition_dim=10,
+                                          include_second_condition=True, second_condition_dim=10, attention_setting=att))
+    a, b = _ab(monkeypatch, lambda: fp(xyz, known, feats, kf, t_emb=temb, condition_emb=cemb, second_condition_emb=cemb))
+    assert a.shape == (B, 36, N) and torch.allclose(a, b, **tol), float((a - b).abs().max())
+    # feature mapper of the autoencoder: features of 200 points mapped onto 16 key points
+    fm = randomise(PM.FeatureMapModule([C, 32, 32, 48], 0, 12, use_xyz=True, include_abs_coordinate=True, include_center_coordinate=True,
+                                       bn=True, bn_first=False, bias=True, res_connect=True, neighbor_def="nn",
+                                       attention_setting=att, query_feature_dim=19))
+    keypts, qf = xyz[:, 100:116].contiguous(), torch.randn(B, 19, 16, generator=gen).to(d)
+    a, b = _ab(monkeypatch, lambda: fm(xyz, feats, keypts, subset=False, record_neighbor_stats=True, features_at_new_xyz=qf))
+    assert a.shape == (B, 48, 16) and torch.allclose(a, b, **tol), float((a - b).abs().max())
