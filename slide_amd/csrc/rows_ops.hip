@@ -142,33 +142,48 @@ __global__ __launch_bounds__(256) void rows_group_kernel(int N, int np, int K, i
 }
 
 // ------------------------------------------------------------------------------------------ GroupNorm on rows
-// Thread layout shared by both passes: c4n = ld / 4 threads cover one row (4 channels each), rt = 256 / c4n rows at once.
+// Thread layout shared by both passes: a thread owns VEC = 16 bytes of consecutive channels (4 fp32 / 8 fp16), cn = ld / VEC
+// threads cover one row, rt = 256 / cn rows are in flight per workgroup step (x2 unrolled for memory-level parallelism).
 // Pass 1: per (sample, row chunk) channel sums of x (or relu(x)) -> part[b][chunk][ld][2]; deterministic (no atomics).
 template <typename T>
 __global__ __launch_bounds__(256) void rows_gn_stats_kernel(int S, int ld, int rpc, int pre_relu, const T *__restrict__ x,
                                                             float *__restrict__ part) {
-  __shared__ float red[256 * 8];
-  const int c4n = ld >> 2, rt = 256 / c4n;
-  const int pr = threadIdx.x / c4n, pc = threadIdx.x - pr * c4n;
+  constexpr int VEC = 16 / sizeof(T);
+  __shared__ float red[256 * VEC * 2];
+  const int cn = ld / VEC, rt = 256 / cn;
+  const int pr = threadIdx.x / cn, pc = threadIdx.x - pr * cn;
   const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
   const int r0 = chunk * rpc, r1 = min(S, r0 + rpc);
-  float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-  if (pr < rt) {
-    const T *xp = x + ((size_t)b * S) * ld + pc * 4;
-    for (int r = r0 + pr; r < r1; r += rt) {
-      const Pack<T, 4> v = *reinterpret_cast<const Pack<T, 4> *>(xp + (size_t)r * ld);
+  float s[VEC], q[VEC];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float f = (float)v.v[j];
-        if (pre_relu) f = fmaxf(f, 0.f);
-        s[j] += f;
-        q[j] += f * f;
+  for (int j = 0; j < VEC; ++j) s[j] = q[j] = 0.f;
+  if (pr < rt) {
+    const T *xp = x + ((size_t)b * S) * ld + pc * VEC;
+    int r = r0 + pr;
+    for (; r + rt < r1; r += 2 * rt) {
+      const Pack<T, VEC> v0 = *reinterpret_cast<const Pack<T, VEC> *>(xp + (size_t)r * ld);
+      const Pack<T, VEC> v1 = *reinterpret_cast<const Pack<T, VEC> *>(xp + (size_t)(r + rt) * ld);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float f0 = (float)v0.v[j], f1 = (float)v1.v[j];
+        if (pre_relu) { f0 = fmaxf(f0, 0.f); f1 = fmaxf(f1, 0.f); }
+        s[j] += f0; q[j] += f0 * f0;
+        s[j] += f1; q[j] += f1 * f1;
+      }
+    }
+    if (r < r1) {
+      const Pack<T, VEC> v0 = *reinterpret_cast<const Pack<T, VEC> *>(xp + (size_t)r * ld);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float f0 = (float)v0.v[j];
+        if (pre_relu) f0 = fmaxf(f0, 0.f);
+        s[j] += f0; q[j] += f0 * f0;
       }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      red[(pr * ld + pc * 4 + j) * 2 + 0] = s[j];
-      red[(pr * ld + pc * 4 + j) * 2 + 1] = q[j];
+    for (int j = 0; j < VEC; ++j) {
+      red[(pr * ld + pc * VEC + j) * 2 + 0] = s[j];
+      red[(pr * ld + pc * VEC + j) * 2 + 1] = q[j];
     }
   }
   __syncthreads();
@@ -194,9 +209,10 @@ __global__ __launch_bounds__(256) void rows_gn_apply_kernel(int S, int ld, int r
                                                             const float *__restrict__ beta,
                                                             const float *__restrict__ addvec, int addvec_ld,
                                                             const T *__restrict__ res, int res_ld, T *__restrict__ y) {
+  constexpr int VEC = 16 / sizeof(T);
   __shared__ float lsum[1024], lsq[1024], lmean[64], lrstd[64];
-  const int c4n = ld >> 2, rt = 256 / c4n;
-  const int pr = threadIdx.x / c4n, pc = threadIdx.x - pr * c4n;
+  const int cn = ld / VEC, rt = 256 / cn;
+  const int pr = threadIdx.x / cn, pc = threadIdx.x - pr * cn;
   const int b = blockIdx.y, chunk = blockIdx.x;
   const bool pre_relu = flags & 1, post_relu = flags & 2;
   if (G > 0) {
@@ -227,10 +243,10 @@ __global__ __launch_bounds__(256) void rows_gn_apply_kernel(int S, int ld, int r
     __syncthreads();
   }
   if (pr >= rt) return;
-  float sc[4], sh[4], av[4];
+  float sc[VEC], sh[VEC], av[VEC];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = pc * 4 + j;
+  for (int j = 0; j < VEC; ++j) {
+    const int c = pc * VEC + j;
     sc[j] = 1.f;
     sh[j] = 0.f;
     if (G > 0 && c < n_norm) {
@@ -242,13 +258,9 @@ __global__ __launch_bounds__(256) void rows_gn_apply_kernel(int S, int ld, int r
   }
   const int r0 = chunk * rpc, r1 = min(S, r0 + rpc);
   const size_t base = (size_t)b * S;
-  for (int r = r0 + pr; r < r1; r += rt) {
-    const size_t off = (base + r) * ld + pc * 4;
-    Pack<T, 4> v = *reinterpret_cast<const Pack<T, 4> *>(x + off);
-    Pack<T, 4> rv;
-    if (res) rv = *reinterpret_cast<const Pack<T, 4> *>(res + (base + r) * res_ld + pc * 4);
+  auto one = [&](Pack<T, VEC> v, const Pack<T, VEC> &rv) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < VEC; ++j) {
       float f = (float)v.v[j];
       if (pre_relu) f = fmaxf(f, 0.f);
       f = f * sc[j] + sh[j];
@@ -257,7 +269,27 @@ __global__ __launch_bounds__(256) void rows_gn_apply_kernel(int S, int ld, int r
       if (res) f += (float)rv.v[j];
       v.v[j] = (T)f;
     }
-    *reinterpret_cast<Pack<T, 4> *>(y + off) = v;
+    return v;
+  };
+  int r = r0 + pr;
+  for (; r + rt < r1; r += 2 * rt) {
+    const size_t o0 = (base + r) * ld + pc * VEC, o1 = (base + r + rt) * ld + pc * VEC;
+    const Pack<T, VEC> v0 = *reinterpret_cast<const Pack<T, VEC> *>(x + o0);
+    const Pack<T, VEC> v1 = *reinterpret_cast<const Pack<T, VEC> *>(x + o1);
+    Pack<T, VEC> a0 = v0, a1 = v1;
+    if (res) {
+      a0 = *reinterpret_cast<const Pack<T, VEC> *>(res + (base + r) * res_ld + pc * VEC);
+      a1 = *reinterpret_cast<const Pack<T, VEC> *>(res + (base + r + rt) * res_ld + pc * VEC);
+    }
+    *reinterpret_cast<Pack<T, VEC> *>(y + o0) = one(v0, a0);
+    *reinterpret_cast<Pack<T, VEC> *>(y + o1) = one(v1, a1);
+  }
+  if (r < r1) {
+    const size_t o0 = (base + r) * ld + pc * VEC;
+    const Pack<T, VEC> v0 = *reinterpret_cast<const Pack<T, VEC> *>(x + o0);
+    Pack<T, VEC> a0 = v0;
+    if (res) a0 = *reinterpret_cast<const Pack<T, VEC> *>(res + (base + r) * res_ld + pc * VEC);
+    *reinterpret_cast<Pack<T, VEC> *>(y + o0) = one(v0, a0);
   }
 }
 
@@ -338,7 +370,7 @@ int launch_rows(const SlideOp &o, hipStream_t s) {
     case SLIDE_OP_ROWS_GN: {  // i: B, S, ld, G, n_norm, flags, addvec_ld, res_ld   p: x, gamma, beta, addvec, residual, part, y
       const int B = o.i[0], S = o.i[1], ld = o.i[2], G = o.i[3], n_norm = o.i[4], flags = o.i[5];
       if (ld % 32 || ld > 1024 || G > 64 || (G > 0 && n_norm % G)) return -3;
-      const int rt = 256 / (ld / 4);
+      const int rt = 256 / (ld / (16 / (int)sizeof(T)));
       int nchunk = (S + rt * 8 - 1) / (rt * 8);
       nchunk = nchunk < 1 ? 1 : nchunk > 64 ? 64 : nchunk;
       const int rpc = (S + nchunk - 1) / nchunk;
