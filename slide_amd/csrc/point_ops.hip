@@ -522,101 +522,42 @@ __global__ __launch_bounds__(256) void three_interpolate_grad_kernel(int c, int 
 }
 
 // ---------------------------------------------------------------------------------------------- kNN
-// pytorch3d knn_points semantics (see oracle/ops_cpu.c ora_knn_points).  One thread per query, search
-// set LDS-tiled, the K-best list of each thread is a private column in LDS (stable insertion, strict '<').
+// pytorch3d knn_points semantics (see oracle/ops_cpu.c ora_knn_points): K nearest of the search set per query, sorted by
+// squared distance, ties -> lower index, empty slots (fewer than K search points) zero.  One thread per query, search
+// set LDS-tiled.  The per-query K-best list lives in REGISTERS as KT (= K rounded up to 4 / 8 / 16 / 32 / 64) 64-bit keys
+//     key = (float bits of d2) << 32 | index
+// d2 >= 0, so key order == (distance, index) lexicographic order; keys are compared as IEEE doubles (a non-negative
+// float pattern in the high word is a finite non-negative double with the same ordering), which makes one step of the
+// sorted insertion `lo = min(L[p], c); c = max(L[p], c)` -- two full-rate v_min/max_f64, no index shuffling, and the
+// tie rule comes for free.  Candidates that beat the current K-th distance are QUEUED per lane in LDS (8 distances are
+// evaluated per chunk from 16-byte broadcast tile reads) and the wave inserts in batches when some lane's queue runs
+// full: with immediate insertion one lane of the wave would insert while 63 wait.
 constexpr int KNN_TILE = 512;
-constexpr int KNN_Q = 16;  // queued candidates per lane between batched insertions
-template <int NT>
-__global__ __launch_bounds__(NT) void knn_kernel(int n1, int n2, int K, const float *__restrict__ p1,
-                                                 const float *__restrict__ p2,
-                                                 const int64_t *__restrict__ lengths2,
-                                                 float *__restrict__ dists, int64_t *__restrict__ idx) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *tile = smem;                              // KNN_TILE*3
-  float *dl = smem + KNN_TILE * 3;                 // [K][NT]
-  int *il = (int *)(dl + (size_t)K * NT);          // [K][NT]
-  float *qd = (float *)(il + (size_t)K * NT);      // [KNN_Q][NT] queued distances
-  int *qi = (int *)(qd + (size_t)KNN_Q * NT);      // [KNN_Q][NT] queued indices
-  const int b = blockIdx.y, tid = threadIdx.x;
-  const int i = blockIdx.x * NT + tid;
-  p2 += (size_t)b * n2 * 3;
-  const int len2 = lengths2 ? (int)lengths2[b] : n2;
-  const bool active = i < n1;
-  float ax = 0.f, ay = 0.f, az = 0.f;
-  if (active) {
-    const float *a = p1 + ((size_t)b * n1 + i) * 3;
-    ax = a[0]; ay = a[1]; az = a[2];
-  }
-  int cnt = 0, qn = 0;
-  float worst = INFINITY;
-#define DL(p) dl[(p)*NT + tid]
-#define IL(p) il[(p)*NT + tid]
-#define QD(p) qd[(p)*NT + tid]
-#define QI(p) qi[(p)*NT + tid]
-  for (int t0 = 0; t0 < len2; t0 += KNN_TILE) {
-    const int tn = min(KNN_TILE, len2 - t0);
-    __syncthreads();
-    for (int q = tid; q < tn * 3; q += NT) tile[q] = p2[(size_t)t0 * 3 + q];
-    __syncthreads();
-    // Candidates that beat the current K-th distance are QUEUED per lane (in index order) and inserted in batches when
-    // some lane's queue is full: with immediate insertion almost every candidate step has ONE lane of the wave inserting
-    // while 63 wait (the first version ran at 1/10 of the distance-evaluation rate); batched, the lanes insert together.
-    // The re-check `d < worst` at insertion time and the strict '<' keep the result identical to sequential insertion.
-    for (int k = 0; k < tn; ++k) {
-      if (active) {
-        const float d = sqdist3(ax, ay, az, tile[k * 3 + 0], tile[k * 3 + 1], tile[k * 3 + 2]);
-        if (cnt + qn < K || d < worst) {
-          QD(qn) = d;
-          QI(qn) = t0 + k;
-          ++qn;
-        }
-      }
-      if (__any(qn == KNN_Q) || (k == tn - 1 && t0 + tn >= len2)) {
-        for (int j = 0; j < qn; ++j) {
-          const float d = QD(j);
-          if (cnt == K && !(d < worst)) continue;
-          int pos = cnt < K ? cnt : K - 1;
-          while (pos > 0 && d < DL(pos - 1)) {
-            DL(pos) = DL(pos - 1);
-            IL(pos) = IL(pos - 1);
-            --pos;
-          }
-          DL(pos) = d;
-          IL(pos) = QI(j);
-          if (cnt < K) ++cnt;
-          if (cnt == K) worst = DL(K - 1);
-        }
-        qn = 0;
-      }
-    }
-  }
-  if (active) {
-    float *od = dists + ((size_t)b * n1 + i) * K;
-    int64_t *oi = idx + ((size_t)b * n1 + i) * K;
-    for (int k = 0; k < K; ++k) {
-      od[k] = k < cnt ? DL(k) : 0.f;
-      oi[k] = k < cnt ? (int64_t)IL(k) : 0;
-    }
-  }
-#undef DL
-#undef IL
-#undef QD
-#undef QI
+constexpr int KNN_CH = 8;   // candidates per distance chunk
+// queue slots per lane (a flush is due once a lane holds more than KNN_Q - KNN_CH): deeper queues amortise the long
+// insertion passes of big K better, shallow ones leave LDS for more resident waves
+constexpr int knn_queue_slots(int KT) { return KT >= 32 ? 24 : 16; }
+
+__device__ __forceinline__ double knn_key(float d, int i) {
+  return __longlong_as_double(((long long)__float_as_int(d) << 32) | (unsigned int)i);
+}
+// opaque to the compiler on purpose: as builtins every operand would first be canonicalised (one more f64 op per slot)
+__device__ __forceinline__ void knn_minmax(double &l, double &c) {
+  double hi;
+  asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(l), "v"(c));
+  asm("v_min_f64 %0, %0, %1" : "+v"(l) : "v"(c));  // in place: the list stays in its registers across the loop
+  c = hi;
 }
 
-// K <= 32: the K-best list lives in REGISTERS (KT = K rounded up to 4/8/16/32, padded with +inf) and a queued
-// candidate is inserted by a branch-free compare-and-carry pass over the list -- every lane runs the same KT steps, so
-// a batch of insertions costs the wave (longest queue) x KT x 5 VALU ops and no LDS traffic.  Same result as the
-// sequential stable insertion: a candidate goes in front of the first STRICTLY larger entry, what it displaces moves down.
 template <int NT, int KT>
-__global__ __launch_bounds__(NT) void knn_reg_kernel(int n1, int n2, int K, const float *__restrict__ p1,
+__global__ __launch_bounds__(NT) void knn_key_kernel(int n1, int n2, int K, const float *__restrict__ p1,
                                                      const float *__restrict__ p2,
                                                      const int64_t *__restrict__ lengths2,
                                                      float *__restrict__ dists, int64_t *__restrict__ idx) {
+  constexpr int KNN_Q = knn_queue_slots(KT);
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *tile = smem;                              // KNN_TILE*3
-  float *qd = smem + KNN_TILE * 3;                 // [KNN_Q][NT]
-  int *qi = (int *)(qd + (size_t)KNN_Q * NT);      // [KNN_Q][NT]
+  float4 *tile = reinterpret_cast<float4 *>(smem);                     // KNN_TILE points (x, y, z, -)
+  double *queue = reinterpret_cast<double *>(smem + KNN_TILE * 4);      // [KNN_Q + 1][NT] keys
   const int b = blockIdx.y, tid = threadIdx.x;
   const int i = blockIdx.x * NT + tid;
   p2 += (size_t)b * n2 * 3;
@@ -627,48 +568,51 @@ __global__ __launch_bounds__(NT) void knn_reg_kernel(int n1, int n2, int K, cons
     const float *a = p1 + ((size_t)b * n1 + i) * 3;
     ax = a[0]; ay = a[1]; az = a[2];
   }
-  float dl[KT];
-  int il[KT];
+  const double pad = knn_key(INFINITY, 0x7fffffff);
+  double L[KT];
 #pragma unroll
-  for (int p = 0; p < KT; ++p) { dl[p] = INFINITY; il[p] = 0; }
-  float worst = INFINITY;  // the K-th best so far (+inf while fewer than K candidates were seen)
+  for (int p = 0; p < KT; ++p) L[p] = pad;
+  float worst = INFINITY;  // the K-th best distance so far (+inf while fewer than K candidates were seen)
   int qn = 0;
   for (int t0 = 0; t0 < len2; t0 += KNN_TILE) {
     const int tn = min(KNN_TILE, len2 - t0);
     __syncthreads();
-    for (int q = tid; q < tn * 3; q += NT) tile[q] = p2[(size_t)t0 * 3 + q];
+    const int tnp = (tn + KNN_CH - 1) / KNN_CH * KNN_CH;  // padded with points at "infinity": never closer than anything
+    for (int q = tid; q < tnp; q += NT) {
+      const float *c = p2 + (size_t)(t0 + min(q, tn - 1)) * 3;
+      tile[q] = q < tn ? make_float4(c[0], c[1], c[2], 0.f) : make_float4(3e38f, 3e38f, 3e38f, 0.f);
+    }
     __syncthreads();
-    for (int k = 0; k < tn; ++k) {
-      if (active) {
-        const float d = sqdist3(ax, ay, az, tile[k * 3 + 0], tile[k * 3 + 1], tile[k * 3 + 2]);
-        if (d < worst) {
-          qd[qn * NT + tid] = d;
-          qi[qn * NT + tid] = t0 + k;
-          ++qn;
-        }
-      }
-      if (__any(qn == KNN_Q) || (k == tn - 1 && t0 + tn >= len2)) {
-        for (int j = 0; __any(j < qn); ++j) {
-          float d = j < qn ? qd[j * NT + tid] : INFINITY;
-          int id = j < qn ? qi[j * NT + tid] : 0;
-          bool ins = false;
+    float4 c[KNN_CH];  // the next chunk's points are fetched while the current chunk is queued / inserted
 #pragma unroll
-          for (int p = 0; p < KT; ++p) {
-            ins = ins || d < dl[p];
-            const float td = dl[p];
-            const int ti = il[p];
-            dl[p] = ins ? d : td;
-            il[p] = ins ? id : ti;
-            d = ins ? td : d;
-            id = ins ? ti : id;
-          }
+    for (int u = 0; u < KNN_CH; ++u) c[u] = tile[u];
+    for (int k0 = 0; k0 < tn; k0 += KNN_CH) {
+      float d[KNN_CH];
+#pragma unroll
+      for (int u = 0; u < KNN_CH; ++u) d[u] = sqdist3(ax, ay, az, c[u].x, c[u].y, c[u].z);
+      if (k0 + KNN_CH < tn) {
+#pragma unroll
+        for (int u = 0; u < KNN_CH; ++u) c[u] = tile[k0 + KNN_CH + u];
+      }
+      // branch-free queueing: every candidate's key is written to the lane's next free slot, the slot is only consumed
+      // when the candidate beats the K-th distance (slot KNN_Q is scratch for a full queue)
+#pragma unroll
+      for (int u = 0; u < KNN_CH; ++u) {
+        queue[qn * NT + tid] = knn_key(d[u], t0 + k0 + u);
+        qn += (active && d[u] < worst) ? 1 : 0;
+      }
+      const bool last = k0 + KNN_CH >= tn && t0 + tn >= len2;
+      if (__any(qn > KNN_Q - KNN_CH) || last) {
+        for (int j = 0; __any(j < qn); ++j) {
+          double c = j < qn ? queue[j * NT + tid] : pad;
+#pragma unroll
+          for (int p = 0; p < KT; ++p) knn_minmax(L[p], c);
         }
         qn = 0;
-        // K-th entry by a uniform select chain (K is a runtime value <= KT)
-        float w = dl[KT - 1];
+        double w = L[KT - 1];  // K-th entry by a uniform select chain (K is a runtime value <= KT)
 #pragma unroll
-        for (int p = KT - 2; p >= 0; --p) w = (p == K - 1) ? dl[p] : w;
-        worst = w;
+        for (int p = KT - 2; p >= 0; --p) w = (p == K - 1) ? L[p] : w;
+        worst = __int_as_float((int)(__double_as_longlong(w) >> 32));
       }
     }
   }
@@ -679,8 +623,9 @@ __global__ __launch_bounds__(NT) void knn_reg_kernel(int n1, int n2, int K, cons
 #pragma unroll
     for (int p = 0; p < KT; ++p)
       if (p < K) {
-        od[p] = p < cnt ? dl[p] : 0.f;
-        oi[p] = p < cnt ? (int64_t)il[p] : 0;
+        const long long key = __double_as_longlong(L[p]);
+        od[p] = p < cnt ? __int_as_float((int)(key >> 32)) : 0.f;
+        oi[p] = p < cnt ? (int64_t)(key & 0xffffffffLL) : 0;
       }
   }
 }
@@ -907,23 +852,18 @@ int slide_knn_points(int b, int n1, int n2, int K, const float *p1, const float 
   if (b <= 0 || n1 <= 0 || K <= 0) return 0;
   if (K > 64) return -2;
   hipStream_t s = (hipStream_t)stream;
-#define KNN_REG(NT, KT)                                                                                  \
-  hipLaunchKernelGGL((knn_reg_kernel<NT, KT>), dim3((n1 + NT - 1) / NT, b), dim3(NT),                        \
-                     (size_t)KNN_TILE * 12 + (size_t)KNN_Q * NT * 8, s, n1, n2, K, p1, p2, lengths2, dists, idx)
-  if (K <= 32) {  // register-resident K-best list
-    if (n1 > 64) {
-      if (K <= 4) KNN_REG(256, 4); else if (K <= 8) KNN_REG(256, 8); else if (K <= 16) KNN_REG(256, 16); else KNN_REG(256, 32);
-    } else {
-      if (K <= 4) KNN_REG(64, 4); else if (K <= 8) KNN_REG(64, 8); else if (K <= 16) KNN_REG(64, 16); else KNN_REG(64, 32);
-    }
-    return LAUNCH_STATUS();
+#define KNN_KEY(NT, KT)                                                                                  \
+  hipLaunchKernelGGL((knn_key_kernel<NT, KT>), dim3((n1 + NT - 1) / NT, b), dim3(NT),                      \
+                     (size_t)KNN_TILE * 16 + (size_t)(knn_queue_slots(KT) + 1) * NT * 8, s, n1, n2, K, p1, p2, lengths2, dists, idx)
+  // few queries per sample: 64-thread workgroups keep more of them on different compute units
+  if (n1 > 64) {
+    if (K <= 4) KNN_KEY(256, 4); else if (K <= 8) KNN_KEY(256, 8); else if (K <= 16) KNN_KEY(256, 16);
+    else if (K <= 32) KNN_KEY(256, 32); else KNN_KEY(128, 64);
+  } else {
+    if (K <= 4) KNN_KEY(64, 4); else if (K <= 8) KNN_KEY(64, 8); else if (K <= 16) KNN_KEY(64, 16);
+    else if (K <= 32) KNN_KEY(64, 32); else KNN_KEY(64, 64);
   }
-#undef KNN_REG
-#define KNN_LAUNCH(NT)                                                                                   \
-  hipLaunchKernelGGL((knn_kernel<NT>), dim3((n1 + NT - 1) / NT, b), dim3(NT),                              \
-                     (size_t)KNN_TILE * 12 + (size_t)(K + KNN_Q) * NT * 8, s, n1, n2, K, p1, p2, lengths2, dists, idx)
-  KNN_LAUNCH(64);  // K in (32, 64]: K-best list in LDS
-#undef KNN_LAUNCH
+#undef KNN_KEY
   return LAUNCH_STATUS();
 }
 
