@@ -212,7 +212,6 @@ def main():
     # driver-timed 20-step number carried ~4 ms of that)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
-    lab_p = pos_chains[0][1]
 
     def reset():
         for p_, l_ in pos_chains:
@@ -376,7 +375,7 @@ def main():
             f32 = FeatureSampler(fc["pointnet_config"], sd_f, B, dev, fc["standard_diffusion_config"], prec="fp32", seed=8, use_graph=True)
             j32 = JointSampler(p32, f32)
             for k_ in (2, a.fp32_steps):
-                p32.begin(lab_p, torch.randn(B, 16, 3, device=dev, generator=gen))
+                p32.begin(torch.zeros(B, dtype=torch.int64, device=dev), torch.randn(B, 16, 3, device=dev, generator=gen))
                 f32.begin(torch.full((B,), 4, dtype=torch.int64, device=dev), torch.as_tensor(synth_keypoints(B, seed=5), device=dev),
                           torch.randn(B, 16, 51, device=dev, generator=gen))
                 j32.synchronize(); torch.cuda.synchronize(dev)

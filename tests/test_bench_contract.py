@@ -39,3 +39,20 @@ def test_bench_rccl_path_single_rank(gpu_device):
     d = _run({"SLIDE_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29541", "RANK": "0", "WORLD_SIZE": "1",
               "LOCAL_RANK": "0"}, "--no-roofline")
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["finite"]
+
+
+def test_bench_five_category_workload(gpu_device):
+    """BASELINE configs[3]: the rank's 256 shapes are five per-category segments, each its own weight set and chain pair;
+    the fp32-mode leg of the `parity` object runs beside it (it once borrowed a segment-sized label vector)"""
+    d = _run({}, "--workload", "five-cat", "--no-roofline", "--fp32-steps", "4")
+    assert KEYS <= set(d) and d["value"] > 0 and d["config"]["finite"]
+    seg = d["config"]["segments_rank0"]
+    assert [e["label"] for e in seg] == [0, 2, 3, 4, 6] and sum(e["shapes"] for e in seg) == 256
+    assert d["parity"]["fp32_mode_shapes_per_s"] > 0
+
+
+def test_bench_self_launch_two_ranks_on_one_gpu(gpu_device):
+    """`python bench.py --gpus 2` with no WORLD_SIZE re-executes itself under torch.distributed.run (what the driver's N > 1
+    command line relies on); both ranks share the box's single GPU over gloo here"""
+    d = _run({"SLIDE_BENCH_SHARE_GPU": "1"}, "--gpus", "2", "--no-roofline", "--no-parity")
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["finite"] and d["scaling"] == "weak"
