@@ -1,8 +1,8 @@
 """`pointnet2_ops.attention` (reference pointnet2_ops_lib/pointnet2_ops/attention.py): MyGroupNorm (:6-23),
 AttentionModule (:35-96, vector attention over the K neighbours), GlobalAttentionModule (:98-155) -- same constructor
-signatures and state-dict names; convolutions / GroupNorm run on HIP kernels (slide_amd.nn_ops)."""
-import os
-
+signatures and state-dict names.  AttentionModule runs row-major (slide_amd.rows: GEMMs on [B * np * K][C] matrices, in-place
+GroupNorm passes, one softmax-reduction kernel); GlobalAttentionModule (N x N scores, unused by the shipped configs) is a
+tensor program over the HIP convolution / GroupNorm kernels."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -23,13 +23,8 @@ class MyGroupNorm(nn.Module):
 
 
 def count_to_mask(count, K):
-    mask = torch.arange(K, device=count.device, dtype=count.dtype)
-    B, npoint = count.size()
-    return mask.repeat(B, npoint).view(B, npoint, -1) < count.unsqueeze(-1)
-
-
-class _Seq(nn.Sequential):
-    pass
+    """(B, np) neighbour counts -> (B, np, K) bool: slot k holds a real neighbour"""
+    return torch.arange(K, device=count.device, dtype=count.dtype).expand(count.shape + (K,)) < count.unsqueeze(-1)
 
 
 class AttentionModule(nn.Module):
@@ -56,10 +51,11 @@ class AttentionModule(nn.Module):
                 layers.append(nn.ReLU(inplace=True))
             self.feat_out_conv = nn.Sequential(*layers)
 
-    def forward_rows(self, query, grouped, grouped_out, K):
+    def forward_rows(self, query, grouped, grouped_out, K, counts=None):
         """query Rows [B * np][C_in1], grouped Rows [B * np * K][C_in2], grouped_out Rows [B * np * K][C_out] -> Rows
-        [B * np][C_out]; every neighbour slot is valid (kNN grouping).  Reference :81-95 as 4-5 GEMMs, three in-place
-        normalise passes, one concat-ReLU pass and one softmax-weighted reduction over the K rows of a point."""
+        [B * np][C_out].  Reference :81-95 as 4-5 GEMMs, three in-place normalise passes, one concat-ReLU pass and one
+        softmax-weighted reduction over the K rows of a point; counts (B, np): only the first max(1, count) neighbour
+        slots of a point are real (ball query) -- the reference masks the others with -1e9 before the softmax."""
         wc = list(self.weight_conv)
         tot = R.concat_qk(R.conv(query, self.feat_conv), R.conv(grouped, self.grouped_feat_conv), K)  # wc[0]: ReLU
         if isinstance(wc[1], MyGroupNorm):
@@ -77,24 +73,17 @@ class AttentionModule(nn.Module):
             values = R.conv(grouped_out, layers[0])
             gn = next((l.group_norm for l in layers[1:] if isinstance(l, MyGroupNorm)), None)
             R.norm_act(values, gn, relu=any(isinstance(l, nn.ReLU) for l in layers[1:]))
-        return R.attend(scores, values, K)
+        return R.attend(scores, values, K, counts)
 
     def forward(self, feat, grouped_feat, grouped_feat_out, count):
+        """feat (B, C_in1, np), grouped_feat (B, C_in2, np, K), grouped_feat_out (B, C_out, np, K), count (B, np) or
+        'all' -> (B, C_out, np)"""
+        if not feat.is_cuda:
+            raise RuntimeError("CPU not supported")
         K = grouped_feat.shape[-1]
-        if feat.is_cuda and isinstance(count, str) and count == "all" and os.environ.get("SLIDE_MODULE_ROWS", "1") != "0":
-            out = self.forward_rows(R.from_ncx(feat), R.from_ncx(grouped_feat), R.from_ncx(grouped_feat_out), K)
-            return R.to_ncx(out)
-        feat1 = self.feat_conv(feat.unsqueeze(-1)).expand(-1, -1, -1, K)
-        grouped_feat1 = self.grouped_feat_conv(grouped_feat)
-        scores = self.weight_conv(torch.cat([feat1, grouped_feat1], dim=1))
-        if not (isinstance(count, str) and count == "all"):
-            count = torch.clamp(count, min=1)
-            mask = count_to_mask(count, K).unsqueeze(1).float()
-            scores = scores * mask + (-1e9) * (1 - mask)
-        weight = F.softmax(scores, dim=-1)
-        if self.transform_grouped_feat_out:
-            grouped_feat_out = self.feat_out_conv(grouped_feat_out)
-        return (grouped_feat_out * weight).sum(dim=-1)
+        out = self.forward_rows(R.from_ncx(feat), R.from_ncx(grouped_feat), R.from_ncx(grouped_feat_out), K,
+                                None if isinstance(count, str) else count)
+        return R.to_ncx(out)
 
 
 class GlobalAttentionModule(nn.Module):

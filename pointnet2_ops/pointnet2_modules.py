@@ -3,26 +3,24 @@ reference (pointnet2_ops_lib/pointnet2_ops/pointnet2_modules.py): Swish (:17-22)
 build_shared_mlp (:44-69), Mlp_plus_t_emb (:71-176), pooling_features (:179-211), PointnetSAModule[MSG] (:213-462),
 PointnetFPModule (:465-588), FeatureMapModule (:591-663), PointnetKnnFPModule (:666-873).
 
-Two execution paths per module:
-  * ROW-MAJOR (slide_amd.rows; taken for the configurations every shipped model uses -- kNN grouping, GroupNorm after the
-    convolution, ReLU, vector attention): a grouped activation is one [B * npoint * K][channels] matrix from the grouping
-    kernel to the attention reduction; reference-layout (B, C, N) tensors exist only at the module boundary.  `forward_rows`
-    methods take / return `slide_amd.rows.Rows`.
-  * GENERAL (any radius-or-nn grouping / bn_first / swish / pooling): the reference's tensor program on NCHW tensors with HIP
-    kernels for search, FPS, gathers, 1x1 convolutions and GroupNorm; concatenation, ReLU and softmax glue are torch ops.
-The latent-DDPM configurations run on the fused engine instead (slide_amd.engine)."""
-import copy
-import os
+Execution model (not the reference's): inside a module every K-expanded activation is a ROW-MAJOR matrix
+`slide_amd.rows.Rows` [B * npoint * K][channels] -- written by the grouping kernel, read and written by the MFMA GEMMs,
+normalised in place, reduced over K by the attention / pooling kernel.  A module's `forward` takes and returns the
+reference's (B, C, N) tensors and converts once at entry and exit; `forward_rows` / `rows_or_ncx` are the row-major entry
+points modules use among themselves.  Only Sequentials the row-major stage interpreter does not cover (GroupNorm BEFORE the
+convolution, swish) and GlobalAttentionModule run as tensor programs on NCHW tensors (HipConv1x1 / HipGroupNorm kernels,
+torch glue).  The latent-DDPM configurations run on the fused engine instead (slide_amd.engine)."""
 from typing import List
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from pointnet2_ops import pointnet2_utils
 from pointnet2_ops.attention import AttentionModule, GlobalAttentionModule
 from slide_amd import rows as R
 from slide_amd.nn_ops import HipConv1x1, HipGroupNorm, HipLinear
+
+_POOL_MODES = {"max": R.POOL_MAX, "avg": R.POOL_AVG, "avg_max": R.POOL_MAX_AVG, "max_avg": R.POOL_MAX_AVG}
 
 
 def swish(x):
@@ -70,39 +68,32 @@ def build_shared_mlp(mlp_spec: List[int], bn: bool = True, bn_first: bool = Fals
     return nn.Sequential(*layers)
 
 
-def _seq_rows_ok(seq):
-    """conv -> [GroupNorm] -> [ReLU] stages only (bn_first / swish Sequentials run on the general path)"""
+def _stages(seq):
+    """a shared-MLP Sequential as [(conv, group_norm or None, relu)] stages, or None when it is not of that form
+    (GroupNorm before the convolution, swish)"""
     layers = [l for l in seq if not isinstance(l, nn.Identity)]
-    if not layers or not isinstance(layers[0], HipConv1x1):
-        return False
-    for a, b in zip(layers, layers[1:] + [None]):
-        if isinstance(a, HipConv1x1):
-            continue
-        if isinstance(a, MyGroupNorm) and (b is None or isinstance(b, (HipConv1x1, nn.ReLU))):
-            continue
-        if isinstance(a, nn.ReLU) and (b is None or isinstance(b, HipConv1x1)):
-            continue
-        return False
-    return True
-
-
-def _seq_rows(seq, x, addvec=None, residual=None):
-    """a shared-MLP Sequential on Rows: every stage = one GEMM + one in-place normalise / ReLU pass; the per-sample
-    embedding vector and the residual the reference adds AFTER the Sequential ride on the last stage's pass"""
-    layers = [l for l in seq if not isinstance(l, nn.Identity)]
-    i, n = 0, len(layers)
-    while i < n:
-        x = R.conv(x, layers[i])
+    out, i = [], 0
+    while i < len(layers):
+        if not isinstance(layers[i], HipConv1x1):
+            return None
+        conv, gn, relu = layers[i], None, False
         i += 1
-        gn, relu = None, False
-        if i < n and isinstance(layers[i], MyGroupNorm):
+        if i < len(layers) and isinstance(layers[i], MyGroupNorm):
             gn, relu = layers[i].group_norm, layers[i].fused_relu
             i += 1
-        if i < n and isinstance(layers[i], nn.ReLU):
+        if i < len(layers) and isinstance(layers[i], nn.ReLU):
             relu = True
             i += 1
-        last = i >= n
-        R.norm_act(x, gn, relu=relu, addvec=addvec if last else None, residual=residual if last else None)
+        out.append((conv, gn, relu))
+    return out or None
+
+
+def _run_stages(stages, x, addvec=None, residual=None):
+    """every stage = one GEMM + one in-place normalise / ReLU pass; the per-sample embedding vector and the residual that
+    the reference adds AFTER the Sequential ride on the last stage's pass"""
+    for k, (conv, gn, relu) in enumerate(stages):
+        last = k == len(stages) - 1
+        x = R.norm_act(R.conv(x, conv), gn, relu=relu, addvec=addvec if last else None, residual=residual if last else None)
     return x
 
 
@@ -111,6 +102,7 @@ class Mlp_plus_t_emb(nn.Module):
                  first_conv_in_channel=0, res_connect=False, include_condition=False, condition_dim=128,
                  include_second_condition=False, second_condition_dim=128, activation="relu"):
         super().__init__()
+        assert len(mlp_spec) >= 3 and (len(mlp_spec) >= 4 or not include_second_condition)
         self.include_t = include_t
         if include_t:
             self.fc = HipLinear(t_dim, mlp_spec[1])
@@ -124,252 +116,218 @@ class Mlp_plus_t_emb(nn.Module):
         if first_conv:
             self.first_conv = HipConv1x1(first_conv_in_channel, mlp_spec[0], bias=bias)
         self.res_connect_bool = res_connect
-        if res_connect:
+        if res_connect:  # identity when the widths agree
             self.res_connect = None if mlp_spec[0] == mlp_spec[-1] else HipConv1x1(mlp_spec[0], mlp_spec[-1], bias=bias)
-        assert len(mlp_spec) >= 3
-        if include_second_condition:
-            assert len(mlp_spec) >= 4
-        self.first_mlp = build_shared_mlp(mlp_spec[0:2], bn, bn_first=bn_first, bias=bias, activation=activation)
-        self.second_mlp = build_shared_mlp(mlp_spec[1:3], bn, bn_first=bn_first, bias=bias, activation=activation)
-        self.rest_mlp = (build_shared_mlp(mlp_spec[2:], bn, bn_first=bn_first, bias=bias, activation=activation)
-                         if len(mlp_spec) > 3 else None)
+        kw = dict(bn_first=bn_first, bias=bias, activation=activation)
+        self.first_mlp = build_shared_mlp(mlp_spec[0:2], bn, **kw)
+        self.second_mlp = build_shared_mlp(mlp_spec[1:3], bn, **kw)
+        self.rest_mlp = build_shared_mlp(mlp_spec[2:], bn, **kw) if len(mlp_spec) > 3 else None
 
     def rows_ok(self):
-        return all(_seq_rows_ok(m) for m in (self.first_mlp, self.second_mlp, self.rest_mlp) if m is not None)
+        return all(_stages(m) is not None for m in (self.first_mlp, self.second_mlp, self.rest_mlp) if m is not None)
 
-    def _check_embeddings(self, t_emb, condition_emb, second_condition_emb):
-        if self.include_t and t_emb is None:
-            raise Exception("Should pass t_emb to the forward function")
-        if not self.include_t and t_emb is not None:
-            raise Exception("This module does not include t but t_emb is given")
-        if self.include_condition and condition_emb is None:
-            raise Exception("Should pass condition_emb to the forward function")
-        if not self.include_condition and condition_emb is not None:
-            raise Exception("This module does not include condition but condition_emb is given")
-        if self.include_second_condition and second_condition_emb is None:
-            raise Exception("Should pass second_condition_emb to the forward function")
-        if not self.include_second_condition and second_condition_emb is not None:
-            raise Exception("This module does not include condition but condition_emb is given")
+    def _embedding_vectors(self, t_emb, condition_emb, second_condition_emb):
+        """the three per-sample vectors added after first_mlp / second_mlp / rest_mlp (None where the module has none);
+        a missing or superfluous embedding is an error, as in the reference (:142-170)"""
+        vecs = []
+        for have, given, name, fc in ((self.include_t, t_emb, "t_emb", "fc"),
+                                      (self.include_condition, condition_emb, "condition_emb", "fc_condition"),
+                                      (self.include_second_condition, second_condition_emb, "second_condition_emb",
+                                       "fc_second_condition")):
+            if have and given is None:
+                raise Exception("Should pass %s to the forward function" % name)
+            if not have and given is not None:
+                raise Exception("This module does not include %s but it is given" % name)
+            vecs.append(getattr(self, fc)(given) if have else None)
+        return vecs
 
     def forward_rows(self, x, t_emb=None, condition_emb=None, second_condition_emb=None):
         """x: Rows [B * S][C_in] -> Rows [B * S][mlp_spec[-1]]: 3-5 GEMMs, each followed by ONE in-place pass that
         normalises, applies the ReLU and adds the embedding vector / the residual (reference :119-176)"""
-        self._check_embeddings(t_emb, condition_emb, second_condition_emb)
+        v_t, v_c, v_c2 = self._embedding_vectors(t_emb, condition_emb, second_condition_emb)
         feat = R.conv(x, self.first_conv) if self.first_conv_bool else x
-        h = _seq_rows(self.first_mlp, feat, addvec=self.fc(t_emb) if self.include_t else None)
-        h = _seq_rows(self.second_mlp, h, addvec=self.fc_condition(condition_emb) if self.include_condition else None)
-        res = None
+        h = _run_stages(_stages(self.first_mlp), feat, addvec=v_t)
+        h = _run_stages(_stages(self.second_mlp), h, addvec=v_c)
+        skip = None
         if self.res_connect_bool:
-            res = R.conv(feat, self.res_connect) if self.res_connect is not None else feat
-        vec2 = self.fc_second_condition(second_condition_emb) if self.include_second_condition else None
+            skip = R.conv(feat, self.res_connect) if self.res_connect is not None else feat
         if self.rest_mlp is not None:
-            return _seq_rows(self.rest_mlp, h, addvec=vec2, residual=res)
-        return R.norm_act(h, addvec=vec2, residual=res)
+            return _run_stages(_stages(self.rest_mlp), h, addvec=v_c2, residual=skip)
+        return R.norm_act(h, addvec=v_c2, residual=skip)
 
-    def forward(self, feature, t_emb=None, condition_emb=None, second_condition_emb=None):
-        if _rows_enabled(feature) and feature.dim() == 4 and self.rows_ok():
-            out = self.forward_rows(R.from_ncx(feature), t_emb, condition_emb, second_condition_emb)
-            return R.to_ncx(out, feature.shape[2:])
+    def _forward_ncx(self, feature, t_emb, condition_emb, second_condition_emb):
+        """tensor program for Sequentials outside the stage form (bn_first, swish)"""
+        v_t, v_c, v_c2 = self._embedding_vectors(t_emb, condition_emb, second_condition_emb)
         if self.first_conv_bool:
             feature = self.first_conv(feature)
         h = self.first_mlp(feature)
-        if self.include_t:
-            if t_emb is None:
-                raise Exception("Should pass t_emb to the forward function")
-            h = h + self.fc(t_emb).unsqueeze(2).unsqueeze(3)
-        elif t_emb is not None:
-            raise Exception("This module does not include t but t_emb is given")
-        h = self.second_mlp(h)
-        if self.include_condition:
-            if condition_emb is None:
-                raise Exception("Should pass condition_emb to the forward function")
-            h = h + self.fc_condition(condition_emb).unsqueeze(2).unsqueeze(3)
-        elif condition_emb is not None:
-            raise Exception("This module does not include condition but condition_emb is given")
-        if self.rest_mlp is not None:
-            h = self.rest_mlp(h)
-        if self.include_second_condition:
-            if second_condition_emb is None:
-                raise Exception("Should pass second_condition_emb to the forward function")
-            h = h + self.fc_second_condition(second_condition_emb).unsqueeze(2).unsqueeze(3)
-        elif second_condition_emb is not None:
-            raise Exception("This module does not include condition but condition_emb is given")
+        for seq, vec in ((None, v_t), (self.second_mlp, v_c), (self.rest_mlp, v_c2)):
+            if seq is not None:
+                h = seq(h)
+            if vec is not None:
+                h = h + vec[:, :, None, None]
         if self.res_connect_bool:
             h = h + (self.res_connect(feature) if self.res_connect is not None else feature)
         return h
 
+    def rows_or_ncx(self, x, spatial, **emb):
+        """Rows in, Rows out, whichever program the Sequentials allow; spatial = (npoint, K) of the rows"""
+        if self.rows_ok():
+            return self.forward_rows(x, **emb)
+        y = self._forward_ncx(R.to_ncx(x, spatial), emb.get("t_emb"), emb.get("condition_emb"), emb.get("second_condition_emb"))
+        return R.from_ncx(y)
+
+    def forward(self, feature, t_emb=None, condition_emb=None, second_condition_emb=None):
+        """feature (B, C, npoint, K) -> (B, mlp_spec[-1], npoint, K)"""
+        if not feature.is_cuda:
+            raise RuntimeError("CPU not supported")
+        if feature.dim() == 4 and self.rows_ok():
+            out = self.forward_rows(R.from_ncx(feature), t_emb, condition_emb, second_condition_emb)
+            return R.to_ncx(out, feature.shape[2:])
+        return self._forward_ncx(feature, t_emb, condition_emb, second_condition_emb)
+
+
+def pool_rows(x, K, pooling, counts=None):
+    return R.pool(x, K, _POOL_MODES[pooling], counts)
+
 
 def pooling_features(feature, count=None, pooling="max"):
-    assert pooling in ["max", "avg", "avg_max", "max_avg"]
-    K = feature.size(3)
-    if pooling == "max":
-        return F.max_pool2d(feature, kernel_size=[1, K]).squeeze(-1)
-    if pooling == "avg":
-        return pointnet2_utils.average_feature(feature, count, K)
-    half_C = int(feature.shape[1] / 2)
-    mx = F.max_pool2d(feature[:, 0:half_C], kernel_size=[1, K]).squeeze(-1)
-    return torch.cat([mx, pointnet2_utils.average_feature(feature[:, half_C:], count, K)], dim=1)
-
-
-def _rows_enabled(t):
-    """row-major fast path switch: CUDA tensors, unless SLIDE_MODULE_ROWS=0 forces the general NCHW program (A/B tests)"""
-    return t.is_cuda and os.environ.get("SLIDE_MODULE_ROWS", "1") != "0"
-
-
-def _group_flags(grouper):
-    if not grouper.use_xyz:
-        return R.GROUP_NO_XYZ
-    return (R.GROUP_ABS if grouper.include_abs_coordinate else 0) | (R.GROUP_CENTER if grouper.include_center_coordinate else 0)
-
-
-def _nn_grouper(g):
-    return isinstance(g, pointnet2_utils.QueryAndGroup) and g.neighbor_def == "nn"
-
-
-def _group_rows(grouper, xyz, new_xyz, feat, record_neighbor_stats=False):
-    """QueryAndGroup('nn') on Rows: (grouped Rows [B * npoint * K], K)"""
-    K = min(grouper.nsample, xyz.shape[1])
-    _, idx, _ = pointnet2_utils.knn.knn_points(new_xyz, xyz, K=K)
-    if record_neighbor_stats:  # every centre has exactly K neighbours under the kNN definition
-        grouper.neighbor_stats = torch.full((3,), float(K), device=xyz.device)
-        grouper.neighbor_num_quantile = torch.full((grouper.quantile.numel(),), K, dtype=torch.long, device=xyz.device)
-    return R.group(xyz, new_xyz, feat, idx, _group_flags(grouper)), K
+    """(B, C, npoint, K) -> (B, C, npoint): max over all K slots, mean over the first `count` slots, or max for the first
+    half of the channels and mean for the second ('avg_max')"""
+    assert pooling in _POOL_MODES
+    K = feature.shape[3]
+    return R.to_ncx(pool_rows(R.from_ncx(feature, half=False), K, pooling, None if isinstance(count, str) else count))
 
 
 def _xyz_extra(use_xyz, include_abs_coordinate, include_center_coordinate):
     return (3 + (3 if include_abs_coordinate else 0) + (3 if include_center_coordinate else 0)) if use_xyz else 0
 
 
-class _PointnetSAModuleBase(nn.Module):
-    def __init__(self):
-        super().__init__()
-        self.npoint = None
-        self.groupers = None
-        self.mlps = None
-
-    def forward(self, xyz, features, t_emb=None, condition_emb=None, second_condition_emb=None, subset=True,
-                record_neighbor_stats=False, pooling="max", length=None):
-        assert self.npoint is not None
-        if (_rows_enabled(xyz) and features is not None and length is None and self.use_attention_module
-                and not self.use_global_attention_module and all(_nn_grouper(g) for g in self.groupers)
-                and all(m.rows_ok() for m in self.mlps) and xyz.shape[2] == 3):
-            return self._forward_rows(xyz, features, t_emb, condition_emb, second_condition_emb, record_neighbor_stats)
-        new_features_list = []
-        xyz_flipped = xyz.transpose(1, 2).contiguous()
-        if xyz.shape[1] <= self.npoint:
-            new_xyz = xyz
-            if self.use_attention_module:
-                new_xyz_feat = features
-        else:
-            fidx = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
-            new_xyz = pointnet2_utils.gather_operation(xyz_flipped, fidx).transpose(1, 2).contiguous()
-            if self.use_attention_module:
-                new_xyz_feat = pointnet2_utils.gather_operation(features, fidx)
-        for i in range(len(self.groupers)):
-            grouped_features, count = self.groupers[i](xyz, new_xyz, features, subset=subset,
-                                                       record_neighbor_stats=record_neighbor_stats, return_counts=True,
-                                                       length=length)
-            out_features = self.mlps[i](grouped_features, t_emb=t_emb if self.include_t else None,
-                                        condition_emb=condition_emb if self.include_condition else None,
-                                        second_condition_emb=second_condition_emb if self.include_second_condition else None)
-            if self.use_attention_module:
-                new_features = self.attention_modules[i](new_xyz_feat, grouped_features, out_features, count)
-            else:
-                new_features = pooling_features(out_features, count=count, pooling=pooling)
-            if self.use_global_attention_module:
-                new_features = torch.cat([new_features, new_xyz.transpose(1, 2)], dim=1)
-                new_features = self.global_attention_modules[i](new_features)
-            new_features_list.append(new_features)
-        return new_xyz, torch.cat(new_features_list, dim=1)
+def _effective_counts(grouper, counts, length):
+    """neighbour counts a reduction over K has to honour; None when every slot is a real neighbour (kNN grouping of
+    full-length clouds), which lets the kernels skip the count reads"""
+    return None if (grouper.neighbor_def == "nn" and length is None) else counts
 
 
-    def _forward_rows(self, xyz, features, t_emb, condition_emb, second_condition_emb, record_neighbor_stats):
-        """kNN grouping + Mlp + vector attention with every K-expanded tensor row-major (see slide_amd.rows)"""
-        feat = R.from_ncx(features)
-        if xyz.shape[1] <= self.npoint:
-            new_xyz, query = xyz, feat
-        else:
-            fidx = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
-            new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), fidx).transpose(1, 2).contiguous()
-            query = R.gather_rows(feat, fidx)
-        outs = []
-        for grouper, mlp, att in zip(self.groupers, self.mlps, self.attention_modules):
-            grouped, K = _group_rows(grouper, xyz, new_xyz, feat, record_neighbor_stats)
-            h = mlp.forward_rows(grouped, t_emb=t_emb if self.include_t else None,
-                                 condition_emb=condition_emb if self.include_condition else None,
-                                 second_condition_emb=second_condition_emb if self.include_second_condition else None)
-            outs.append(att.forward_rows(query, grouped, h, K))
-        return new_xyz, R.to_ncx(outs[0] if len(outs) == 1 else R.concat_cols(outs))
+def _emb_kwargs(module, t_emb, condition_emb, second_condition_emb=None):
+    return dict(t_emb=t_emb if module.include_t else None,
+                condition_emb=condition_emb if module.include_condition else None,
+                second_condition_emb=second_condition_emb if getattr(module, "include_second_condition", False) else None)
 
 
-class PointnetSAModuleMSG(_PointnetSAModuleBase):
+class PointnetSAModuleMSG(nn.Module):
+    """set abstraction: FPS centres, one (grouper, Mlp, [attention | pooling]) branch per scale, outputs concatenated"""
+
     def __init__(self, npoint, radii, nsamples, mlps, bn=True, use_xyz=True, t_dim=128, include_t=False,
                  include_abs_coordinate=False, include_center_coordinate=False, bn_first=False, bias=False, first_conv=False,
                  first_conv_in_channel=0, res_connect=False, include_condition=False, condition_dim=128,
                  include_second_condition=False, second_condition_dim=128, neighbor_def="radius", activation="relu",
                  attention_setting=None, global_attention_setting=None):
         super().__init__()
+        assert len(radii) == len(nsamples) == len(mlps)
+        self.npoint = npoint
         self.include_t, self.t_dim = include_t, t_dim
         self.include_condition, self.condition_dim = include_condition, condition_dim
         self.include_second_condition, self.second_condition_dim = include_second_condition, second_condition_dim
-        assert len(radii) == len(nsamples) == len(mlps)
-        self.npoint = npoint
-        self.groupers, self.mlps = nn.ModuleList(), nn.ModuleList()
         self.use_attention_module = bool(attention_setting and attention_setting["use_attention_module"])
-        self.attention_modules = nn.ModuleList() if self.use_attention_module else None
         self.use_global_attention_module = bool(global_attention_setting and
                                                 global_attention_setting["use_global_attention_module"])
+        self.groupers, self.mlps = nn.ModuleList(), nn.ModuleList()
+        self.attention_modules = nn.ModuleList() if self.use_attention_module else None
         self.global_attention_modules = nn.ModuleList() if self.use_global_attention_module else None
-        extra = _xyz_extra(use_xyz, include_abs_coordinate, include_center_coordinate)
-        for i in range(len(radii)):
+        coord_ch = _xyz_extra(use_xyz, include_abs_coordinate, include_center_coordinate)
+        for radius, nsample, spec in zip(radii, nsamples, mlps):
             self.groupers.append(
-                pointnet2_utils.QueryAndGroup(radii[i], nsamples[i], use_xyz=use_xyz,
-                                              include_abs_coordinate=include_abs_coordinate,
+                pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz, include_abs_coordinate=include_abs_coordinate,
                                               include_center_coordinate=include_center_coordinate, neighbor_def=neighbor_def)
                 if npoint is not None else pointnet2_utils.GroupAll(use_xyz))
-            mlp_spec = mlps[i]
-            ori_first_conv_in_channel = copy.deepcopy(first_conv_in_channel)
-            ori_mlp_spec0 = copy.deepcopy(mlp_spec[0])
-            if first_conv:
-                first_conv_in_channel += extra
-            else:
-                mlp_spec[0] += extra
-            self.mlps.append(Mlp_plus_t_emb(mlp_spec, bn, t_dim=self.t_dim, include_t=include_t, bn_first=bn_first, bias=bias,
-                                            first_conv=first_conv, first_conv_in_channel=first_conv_in_channel,
+            # the coordinate channels enter through first_conv when there is one, else through the first MLP layer
+            # (the caller's spec list is widened in place, like the reference's)
+            point_ch = first_conv_in_channel if first_conv else spec[0]
+            grouped_ch = point_ch + coord_ch
+            if not first_conv:
+                spec[0] = grouped_ch
+            self.mlps.append(Mlp_plus_t_emb(spec, bn, t_dim=t_dim, include_t=include_t, bn_first=bn_first, bias=bias,
+                                            first_conv=first_conv, first_conv_in_channel=grouped_ch if first_conv else 0,
                                             res_connect=res_connect, include_condition=include_condition,
                                             condition_dim=condition_dim, include_second_condition=include_second_condition,
                                             second_condition_dim=second_condition_dim, activation=activation))
             if self.use_attention_module:
-                C_in1 = ori_first_conv_in_channel if first_conv else ori_mlp_spec0
-                C_in2 = first_conv_in_channel if first_conv else mlp_spec[0]
                 self.attention_modules.append(AttentionModule(
-                    C_in1, C_in2, C_in1, C_in2, mlp_spec[-1], attention_bn=attention_setting["attention_bn"],
+                    point_ch, grouped_ch, point_ch, grouped_ch, spec[-1], attention_bn=attention_setting["attention_bn"],
                     transform_grouped_feat_out=attention_setting["transform_grouped_feat_out"],
                     last_activation=attention_setting["last_activation"]))
             if self.use_global_attention_module:
                 self.global_attention_modules.append(GlobalAttentionModule(
-                    mlp_spec[-1], additional_dim=3, attention_bn=global_attention_setting["attention_bn"],
+                    spec[-1], additional_dim=3, attention_bn=global_attention_setting["attention_bn"],
                     last_activation=global_attention_setting["last_activation"]))
+            if first_conv:
+                first_conv_in_channel = grouped_ch  # (the reference accumulates the widening across scales)
+
+    def forward(self, xyz, features, t_emb=None, condition_emb=None, second_condition_emb=None, subset=True,
+                record_neighbor_stats=False, pooling="max", length=None):
+        """xyz (B, N, 3), features (B, C, N) -> (centres (B, npoint, 3), (B, sum C_out, npoint))"""
+        assert self.npoint is not None
+        if not xyz.is_cuda:
+            raise RuntimeError("CPU not supported")
+        feat = R.from_ncx(features) if features is not None else None
+        if xyz.shape[1] <= self.npoint:  # nothing to sub-sample: every point is a centre
+            centres, query = xyz, feat
+        else:
+            picked = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+            centres = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), picked).transpose(1, 2).contiguous()
+            query = R.gather_rows(feat, picked) if (self.use_attention_module and feat is not None) else None
+        emb = _emb_kwargs(self, t_emb, condition_emb, second_condition_emb)
+        outs = []
+        for i, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
+            grouped, counts, K = grouper.rows(xyz, centres, feat, subset, record_neighbor_stats, length)
+            h = mlp.rows_or_ncx(grouped, (centres.shape[1], K), **emb)
+            counts = _effective_counts(grouper, counts, length)
+            if self.use_attention_module:
+                o = self.attention_modules[i].forward_rows(query, grouped, h, K, counts)
+            else:
+                o = pool_rows(h, K, pooling, counts)
+            if self.use_global_attention_module:
+                o = R.from_ncx(self.global_attention_modules[i](torch.cat([R.to_ncx(o), centres.transpose(1, 2)], dim=1)))
+            outs.append(o)
+        return centres, R.to_ncx(outs[0] if len(outs) == 1 else R.concat_cols(outs))
 
 
 class PointnetSAModule(PointnetSAModuleMSG):
+    """single-scale set abstraction"""
+
     def __init__(self, mlp, npoint=None, radius=None, nsample=None, bn=True, use_xyz=True, t_dim=128, include_t=False,
                  include_abs_coordinate=False, include_center_coordinate=False, bn_first=False, bias=False, first_conv=False,
                  first_conv_in_channel=0, res_connect=False, include_condition=False, condition_dim=128,
                  include_second_condition=False, second_condition_dim=128, neighbor_def="radius", activation="relu",
                  attention_setting=None, global_attention_setting=None):
-        super().__init__(mlps=[mlp], npoint=npoint, radii=[radius], nsamples=[nsample], bn=bn, use_xyz=use_xyz, t_dim=t_dim,
-                         include_t=include_t, include_abs_coordinate=include_abs_coordinate,
-                         include_center_coordinate=include_center_coordinate, bn_first=bn_first, bias=bias,
-                         first_conv=first_conv, first_conv_in_channel=first_conv_in_channel, res_connect=res_connect,
-                         include_condition=include_condition, condition_dim=condition_dim,
+        super().__init__(npoint, [radius], [nsample], [mlp], bn=bn, use_xyz=use_xyz, t_dim=t_dim, include_t=include_t,
+                         include_abs_coordinate=include_abs_coordinate, include_center_coordinate=include_center_coordinate,
+                         bn_first=bn_first, bias=bias, first_conv=first_conv, first_conv_in_channel=first_conv_in_channel,
+                         res_connect=res_connect, include_condition=include_condition, condition_dim=condition_dim,
                          include_second_condition=include_second_condition, second_condition_dim=second_condition_dim,
                          neighbor_def=neighbor_def, activation=activation, attention_setting=attention_setting,
                          global_attention_setting=global_attention_setting)
 
 
+def _make_local_grouper(owner, enabled, first_conv, first_conv_in_channel, spec, radius, nsample, use_xyz,
+                        include_abs_coordinate, include_center_coordinate, neighbor_def):
+    """optional QueryAndGroup of a feature-propagation module over its own output points; returns the widened
+    first_conv_in_channel (spec[0] is widened in place when there is no first_conv)"""
+    owner.include_grouper = enabled
+    if not enabled:
+        return first_conv_in_channel
+    coord_ch = _xyz_extra(use_xyz, include_abs_coordinate, include_center_coordinate)
+    owner.grouper = pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz, include_abs_coordinate=include_abs_coordinate,
+                                                  include_center_coordinate=include_center_coordinate, neighbor_def=neighbor_def)
+    if first_conv:
+        return first_conv_in_channel + coord_ch
+    spec[0] += coord_ch
+    return first_conv_in_channel
+
+
 class PointnetFPModule(nn.Module):
-    """three_nn / three_interpolate feature propagation"""
+    """feature propagation by inverse-distance interpolation over the three nearest known points, then an Mlp"""
 
     def __init__(self, mlp, bn=True, t_dim=128, include_t=False, bn_first=False, bias=False, first_conv=False,
                  first_conv_in_channel=0, res_connect=False, include_condition=False, condition_dim=128,
@@ -379,17 +337,8 @@ class PointnetFPModule(nn.Module):
         super().__init__()
         self.include_t, self.t_dim = include_t, t_dim
         self.include_condition, self.include_second_condition = include_condition, include_second_condition
-        self.include_grouper = include_grouper
-        if include_grouper:
-            extra = _xyz_extra(use_xyz, include_abs_coordinate, include_center_coordinate)
-            if first_conv:
-                first_conv_in_channel += extra
-            else:
-                mlp[0] += extra
-            self.grouper = pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz,
-                                                         include_abs_coordinate=include_abs_coordinate,
-                                                         include_center_coordinate=include_center_coordinate,
-                                                         neighbor_def=neighbor_def)
+        first_conv_in_channel = _make_local_grouper(self, include_grouper, first_conv, first_conv_in_channel, mlp, radius, nsample,
+                                                    use_xyz, include_abs_coordinate, include_center_coordinate, neighbor_def)
         self.mlp = Mlp_plus_t_emb(mlp, bn, t_dim=t_dim, include_t=include_t, bn_first=bn_first, bias=bias,
                                   first_conv=first_conv, first_conv_in_channel=first_conv_in_channel, res_connect=res_connect,
                                   include_condition=include_condition, condition_dim=condition_dim,
@@ -398,38 +347,38 @@ class PointnetFPModule(nn.Module):
 
     def forward(self, unknown, known, unknow_feats, known_feats, t_emb=None, condition_emb=None, second_condition_emb=None,
                 record_neighbor_stats=False, pooling="max"):
-        if known is not None:
-            dist, idx = pointnet2_utils.three_nn(unknown, known)
-            dist_recip = 1.0 / (dist + 1e-8)
-            weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
-            interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+        """unknown (B, n, 3), known (B, m, 3) or None, unknow_feats (B, C1, n) or None, known_feats (B, C2, m) -> (B, C, n)"""
+        n = unknown.shape[1]
+        if known is None:  # one global feature vector, broadcast to every point
+            spread = known_feats.expand(-1, -1, n)
         else:
-            interpolated = known_feats.expand(*(list(known_feats.size()[0:2]) + [unknown.size(1)]))
-        new_features = torch.cat([interpolated, unknow_feats], dim=1) if unknow_feats is not None else interpolated
-        if self.include_grouper:
-            new_features, count = self.grouper(unknown, unknown, new_features, subset=True,
-                                               record_neighbor_stats=record_neighbor_stats, return_counts=True)
-        else:
-            new_features = new_features.unsqueeze(-1)
-        new_features = self.mlp(new_features, t_emb=t_emb if self.include_t else None,
-                                condition_emb=condition_emb if self.include_condition else None,
-                                second_condition_emb=second_condition_emb if self.include_second_condition else None)
-        if self.include_grouper:
-            return pooling_features(new_features, count=count, pooling=pooling)
-        return new_features.squeeze(-1)
+            dist, nearest = pointnet2_utils.three_nn(unknown, known)
+            w = 1.0 / (dist + 1e-8)
+            spread = pointnet2_utils.three_interpolate(known_feats, nearest, w / w.sum(dim=2, keepdim=True))
+        parts = [R.from_ncx(spread)] + ([R.from_ncx(unknow_feats)] if unknow_feats is not None else [])
+        x = parts[0] if len(parts) == 1 else R.concat_cols(parts)
+        emb = _emb_kwargs(self, t_emb, condition_emb, second_condition_emb)
+        if not self.include_grouper:
+            return R.to_ncx(self.mlp.rows_or_ncx(x, (n, 1), **emb))
+        grouped, counts, K = self.grouper.rows(unknown, unknown, x, True, record_neighbor_stats)
+        h = self.mlp.rows_or_ncx(grouped, (n, K), **emb)
+        return R.to_ncx(pool_rows(h, K, pooling, _effective_counts(self.grouper, counts, None)))
 
 
 class FeatureMapModule(nn.Module):
+    """features of a cloud mapped onto another set of points: grouping around the new points, Mlp, attention / pooling"""
+
     def __init__(self, mlp, radius, K, use_xyz=True, include_abs_coordinate=True, include_center_coordinate=False, bn=True,
                  bn_first=True, bias=True, res_connect=True, first_conv=False, first_conv_in_channel=0, neighbor_def="radius",
                  activation="relu", attention_setting=None, query_feature_dim=None):
         super().__init__()
         self.use_attention_module = bool(attention_setting and attention_setting["use_attention_module"])
-        extra = _xyz_extra(use_xyz, include_abs_coordinate, include_center_coordinate)
+        coord_ch = _xyz_extra(use_xyz, include_abs_coordinate, include_center_coordinate)
         if first_conv:
-            first_conv_in_channel += extra
+            first_conv_in_channel += coord_ch
         else:
-            mlp[0] += extra
+            mlp[0] += coord_ch
+        grouped_ch = first_conv_in_channel if first_conv else mlp[0]
         self.mlp = Mlp_plus_t_emb(mlp, bn, include_t=False, bn_first=bn_first, bias=bias, first_conv=first_conv,
                                   first_conv_in_channel=first_conv_in_channel, res_connect=res_connect,
                                   include_condition=False, activation=activation)
@@ -437,29 +386,24 @@ class FeatureMapModule(nn.Module):
                                                     include_center_coordinate=include_center_coordinate,
                                                     neighbor_def=neighbor_def)
         if self.use_attention_module:
-            C_in2 = first_conv_in_channel if first_conv else mlp[0]
-            self.attention_module = AttentionModule(query_feature_dim, C_in2, query_feature_dim, C_in2, mlp[-1],
+            self.attention_module = AttentionModule(query_feature_dim, grouped_ch, query_feature_dim, grouped_ch, mlp[-1],
                                                     attention_bn=attention_setting["attention_bn"],
                                                     transform_grouped_feat_out=attention_setting["transform_grouped_feat_out"],
                                                     last_activation=attention_setting["last_activation"])
 
     def forward(self, xyz, features, new_xyz, subset=False, record_neighbor_stats=True, pooling="max",
                 features_at_new_xyz=None):
-        if (_rows_enabled(xyz) and self.use_attention_module and features_at_new_xyz is not None and _nn_grouper(self.mapper)
-                and self.mlp.rows_ok() and xyz.shape[2] == 3):
-            grouped, K = _group_rows(self.mapper, xyz, new_xyz, R.from_ncx(features), record_neighbor_stats)
-            out = self.attention_module.forward_rows(R.from_ncx(features_at_new_xyz), grouped, self.mlp.forward_rows(grouped), K)
-            return R.to_ncx(out)
-        new_features, count = self.mapper(xyz, new_xyz, features, subset=subset, record_neighbor_stats=record_neighbor_stats,
-                                          return_counts=True)
-        out_features = self.mlp(new_features)
+        """xyz (B, N, 3) with features (B, C, N) -> features at new_xyz (B, m, 3): (B, mlp[-1], m)"""
+        grouped, counts, K = self.mapper.rows(xyz, new_xyz, R.from_ncx(features), subset, record_neighbor_stats)
+        h = self.mlp.rows_or_ncx(grouped, (new_xyz.shape[1], K))
+        counts = _effective_counts(self.mapper, counts, None)
         if self.use_attention_module:
-            return self.attention_module(features_at_new_xyz, new_features, out_features, count)
-        return pooling_features(out_features, count=count, pooling=pooling)
+            return R.to_ncx(self.attention_module.forward_rows(R.from_ncx(features_at_new_xyz), grouped, h, K, counts))
+        return R.to_ncx(pool_rows(h, K, pooling, counts))
 
 
 class PointnetKnnFPModule(nn.Module):
-    """kNN-attention feature propagation + skip concat + MLP"""
+    """feature propagation by attention (or pooling) over the K nearest known points, skip concatenation, second Mlp"""
 
     def __init__(self, mlp1, mlp2, K, bn=True, t_dim=128, include_t=False, bn_first=False, bias=False, first_conv=False,
                  first_conv_in_channel1=0, first_conv_in_channel2=0, res_connect=False, include_condition=False,
@@ -467,45 +411,39 @@ class PointnetKnnFPModule(nn.Module):
                  nsample=32, use_xyz=True, include_abs_coordinate=True, include_center_coordinate=False,
                  neighbor_def="radius", activation="relu", attention_setting=None, global_attention_setting=None):
         super().__init__()
+        self.K = K
         self.include_t, self.t_dim = include_t, t_dim
         self.include_condition, self.include_second_condition = include_condition, include_second_condition
-        self.K = K
+        self.use_attention_module = bool(attention_setting and attention_setting["use_attention_module"])
+        self.use_global_attention_module = bool(global_attention_setting and
+                                                global_attention_setting["use_global_attention_module"])
+        # stage 1 sees a known point's features + the 11 geometry channels of group_knn (d2, weight, abs, rel, centre)
         if first_conv:
             first_conv_in_channel1 += 11
         else:
-            mlp1[0] = mlp1[0] + 11
+            mlp1[0] += 11
+        grouped_ch = first_conv_in_channel1 if first_conv else mlp1[0]
         self.mlp1 = Mlp_plus_t_emb(mlp1, bn, t_dim=t_dim, include_t=False, bn_first=bn_first, bias=bias, first_conv=first_conv,
                                    first_conv_in_channel=first_conv_in_channel1, res_connect=res_connect,
                                    include_condition=include_second_condition, condition_dim=second_condition_dim,
                                    activation=activation)
-        self.use_attention_module = bool(attention_setting and attention_setting["use_attention_module"])
-        if self.use_attention_module:
-            C_in1 = first_conv_in_channel2 - mlp1[-1] if first_conv else mlp2[0] - mlp1[-1]
-            C_in2 = first_conv_in_channel1 if first_conv else mlp1[0]
-            self.attention_module = AttentionModule(C_in1, C_in2, C_in1, C_in2, mlp1[-1],
+        if self.use_attention_module:  # the query is the skip feature: what stage 2 receives minus stage 1's output
+            skip_ch = (first_conv_in_channel2 if first_conv else mlp2[0]) - mlp1[-1]
+            self.attention_module = AttentionModule(skip_ch, grouped_ch, skip_ch, grouped_ch, mlp1[-1],
                                                     attention_bn=attention_setting["attention_bn"],
                                                     transform_grouped_feat_out=attention_setting["transform_grouped_feat_out"],
                                                     last_activation=attention_setting["last_activation"])
-        self.include_grouper = include_grouper
-        if include_grouper:
-            extra = _xyz_extra(use_xyz, include_abs_coordinate, include_center_coordinate)
+        first_conv_in_channel2 = _make_local_grouper(self, include_grouper, first_conv, first_conv_in_channel2, mlp2, radius,
+                                                     nsample, use_xyz, include_abs_coordinate, include_center_coordinate,
+                                                     neighbor_def)
+        if not include_grouper:  # stage 2 sees the point's own coordinates instead
             if first_conv:
-                first_conv_in_channel2 += extra
+                first_conv_in_channel2 += 3
             else:
-                mlp2[0] += extra
-            self.grouper = pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz,
-                                                         include_abs_coordinate=include_abs_coordinate,
-                                                         include_center_coordinate=include_center_coordinate,
-                                                         neighbor_def=neighbor_def)
-        elif first_conv:
-            first_conv_in_channel2 += 3
-        else:
-            mlp2[0] = mlp2[0] + 3
+                mlp2[0] += 3
         self.mlp2 = Mlp_plus_t_emb(mlp2, bn, t_dim=t_dim, include_t=include_t, bn_first=bn_first, bias=bias,
                                    first_conv=first_conv, first_conv_in_channel=first_conv_in_channel2, res_connect=res_connect,
                                    include_condition=include_condition, condition_dim=condition_dim, activation=activation)
-        self.use_global_attention_module = bool(global_attention_setting and
-                                                global_attention_setting["use_global_attention_module"])
         if self.use_global_attention_module:
             self.global_attention_module = GlobalAttentionModule(mlp2[-1], additional_dim=3,
                                                                  attention_bn=global_attention_setting["attention_bn"],
@@ -513,43 +451,33 @@ class PointnetKnnFPModule(nn.Module):
 
     def forward(self, unknown, known, unknow_feats, known_feats, t_emb=None, condition_emb=None, second_condition_emb=None,
                 record_neighbor_stats=False, pooling="max"):
+        """unknown (B, n, 3), known (B, m, 3) or None, unknow_feats (B, C1, n) or None, known_feats (B, C2, m) -> (B, C, n)"""
+        if not unknown.is_cuda:
+            raise RuntimeError("CPU not supported")
         if self.use_attention_module or self.use_global_attention_module:
             assert known is not None and unknown is not None
-        if (known is not None and _rows_enabled(unknown) and self.use_attention_module and not self.use_global_attention_module
-                and not self.include_grouper and unknow_feats is not None and self.mlp1.rows_ok() and self.mlp2.rows_ok()
-                and unknown.shape[2] == 3):
-            # group_knn rows [feat | d2 | w | abs | rel | centre] -> mlp1 -> attention over the K known neighbours;
-            # [interpolated | skip features | xyz] -> mlp2, all row-major
-            d2, idx, _ = pointnet2_utils.knn.knn_points(unknown, known, K=self.K)
-            skip = R.from_ncx(unknow_feats)
-            grouped = R.group(known, unknown, R.from_ncx(known_feats), idx, R.GROUP_FP, d2=d2)
-            h = self.mlp1.forward_rows(grouped, condition_emb=second_condition_emb if self.include_second_condition else None)
-            interpolated = self.attention_module.forward_rows(skip, grouped, h, self.K)
-            out = self.mlp2.forward_rows(R.concat_cols([interpolated, skip, unknown]),
-                                         t_emb=t_emb if self.include_t else None,
-                                         condition_emb=condition_emb if self.include_condition else None)
-            return R.to_ncx(out)
-        if known is not None:
-            grouped = pointnet2_utils.group_knn(unknown, known, known_feats, self.K, transpose=True).contiguous()
-            out = self.mlp1(grouped, t_emb=None,
-                            condition_emb=second_condition_emb if self.include_second_condition else None)
+        n = unknown.shape[1]
+        skip = R.from_ncx(unknow_feats) if unknow_feats is not None else None
+        if known is None:
+            carried = R.from_ncx(known_feats.expand(-1, -1, n))
+        else:
+            grouped = pointnet2_utils.group_knn_rows(unknown, known, R.from_ncx(known_feats), self.K)
+            h = self.mlp1.rows_or_ncx(grouped, (n, self.K),
+                                      condition_emb=second_condition_emb if self.include_second_condition else None)
             if self.use_attention_module:
-                interpolated = self.attention_module(unknow_feats, grouped, out, count="all")
+                carried = self.attention_module.forward_rows(skip, grouped, h, self.K)
             else:
-                interpolated = pooling_features(out, count="all", pooling=pooling)
-        else:
-            interpolated = known_feats.expand(*(list(known_feats.size()[0:2]) + [unknown.size(1)]))
-        new_features = torch.cat([interpolated, unknow_feats], dim=1) if unknow_feats is not None else interpolated
+                carried = pool_rows(h, self.K, pooling)
+        parts = [carried] + ([skip] if skip is not None else [])
+        emb = dict(t_emb=t_emb if self.include_t else None, condition_emb=condition_emb if self.include_condition else None)
         if self.include_grouper:
-            new_features, count = self.grouper(unknown, unknown, new_features, subset=True,
-                                               record_neighbor_stats=record_neighbor_stats, return_counts=True)
+            x = parts[0] if len(parts) == 1 else R.concat_cols(parts)
+            regrouped, counts, K2 = self.grouper.rows(unknown, unknown, x, True, record_neighbor_stats)
+            out = pool_rows(self.mlp2.rows_or_ncx(regrouped, (n, K2), **emb), K2, pooling,
+                            _effective_counts(self.grouper, counts, None))
         else:
-            new_features = torch.cat([new_features, unknown.transpose(1, 2)], dim=1).unsqueeze(-1)
-        new_features = self.mlp2(new_features, t_emb=t_emb if self.include_t else None,
-                                 condition_emb=condition_emb if self.include_condition else None)
-        if self.include_grouper:
-            return pooling_features(new_features, count=count, pooling=pooling)
-        new_features = new_features.squeeze(-1)
+            out = self.mlp2.rows_or_ncx(R.concat_cols(parts + [unknown]), (n, 1), **emb)
+        out = R.to_ncx(out)
         if self.use_global_attention_module:
-            new_features = self.global_attention_module(torch.cat([new_features, unknown.transpose(1, 2)], dim=1))
-        return new_features
+            out = self.global_attention_module(torch.cat([out, unknown.transpose(1, 2)], dim=1))
+        return out

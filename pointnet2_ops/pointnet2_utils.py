@@ -12,6 +12,7 @@ from torch.autograd import Function
 
 import pointnet2_ops._ext as _ext
 from slide_amd import _ext as _hip
+from slide_amd import rows as _rows
 
 _KNN = collections.namedtuple("KNN", "dists idx knn")
 
@@ -26,18 +27,14 @@ knn = types.SimpleNamespace(knn_points=_knn_points, knn_gather=lambda x, idx, le
 
 
 def count_to_mask(count, K):
-    mask = torch.arange(K, device=count.device, dtype=count.dtype)
-    B, npoint = count.size()
-    mask = mask.repeat(B, npoint).view(B, npoint, -1)
-    return mask < count.unsqueeze(-1)
+    """(B, np) neighbour counts -> (B, np, K) bool: slot k holds a real neighbour (reference :36-44)"""
+    return torch.arange(K, device=count.device, dtype=count.dtype).expand(count.shape + (K,)) < count.unsqueeze(-1)
 
 
 def average_feature(feature, count, K):
-    if isinstance(count, str) and count == "all":
-        return F.avg_pool2d(feature, kernel_size=[1, feature.size(3)]).squeeze(-1)
-    count = torch.clamp(count, min=1)
-    mask = count_to_mask(count, K).unsqueeze(1)
-    return (feature * mask).sum(dim=-1) / count.unsqueeze(1)
+    """mean of (B, C, np, K) over the first `count` neighbour slots (all K for count == 'all'; reference :47-60)"""
+    counts = None if isinstance(count, str) else count
+    return _rows.to_ncx(_rows.pool(_rows.from_ncx(feature, half=False), K, _rows.POOL_AVG, counts))
 
 
 class FurthestPointSampling(Function):
@@ -133,86 +130,91 @@ ball_query = BallQuery.apply
 
 
 class QueryAndGroup(nn.Module):
-    """radius (ball query) or nn (kNN) grouping + coordinate feature assembly (reference :307-448)"""
+    """Neighbour search (ball query or kNN) + grouped-feature assembly (reference :307-448).
+
+    The search is a HIP kernel; the assembly -- gather the neighbours' features, append relative / absolute / centre
+    coordinates, substitute the centre for empty balls -- is ONE row-major kernel (slide_amd.rows.group) whose
+    [B * npoint * K][C + 3..9] matrix is what the row-major module path consumes directly (`rows`); `forward` lays it
+    out as the reference's (B, C + 3..9, npoint, K) tensor."""
 
     def __init__(self, radius, nsample, use_xyz=True, include_abs_coordinate=False, include_center_coordinate=False,
                  neighbor_def="radius"):
         super().__init__()
+        assert neighbor_def in ("radius", "nn")
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
         self.include_abs_coordinate = include_abs_coordinate
         self.include_center_coordinate = include_center_coordinate
-        self.neighbor_stats = None
-        self.quantile = torch.tensor([0, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1])
-        self.neighbor_num_quantile = None
         self.neighbor_def = neighbor_def
-        assert neighbor_def in ("radius", "nn")
+        self.neighbor_stats = None
+        self.neighbor_num_quantile = None
+        self.quantile = torch.tensor([0, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1])
+
+    def search(self, xyz, new_xyz, length=None):
+        """-> (idx (B, npoint, K) int32 [ball] / int64 [kNN], counts (B, npoint))"""
+        if self.neighbor_def == "nn":
+            K = min(self.nsample, xyz.shape[1])
+            idx = knn.knn_points(new_xyz, xyz, K=K, lengths2=length).idx
+            counts = torch.full(idx.shape[:2], float(K), device=xyz.device)
+            if length is not None:
+                counts = torch.minimum(counts, length.unsqueeze(1))
+            return idx, counts
+        if length is not None:
+            raise Exception("radius neighbor definition has not supported point clouds with different lengths")
+        return ball_query(self.radius, self.nsample, xyz, new_xyz)
+
+    def layout_flags(self):
+        if not self.use_xyz:
+            return _rows.GROUP_NO_XYZ
+        return (_rows.GROUP_ABS if self.include_abs_coordinate else 0) | (_rows.GROUP_CENTER if self.include_center_coordinate else 0)
+
+    def rows(self, xyz, new_xyz, feat=None, subset=True, record_neighbor_stats=False, length=None, half=None):
+        """feat: slide_amd.rows.Rows [B * N] or None -> (grouped Rows [B * npoint * K], counts, K)"""
+        if feat is None and not self.use_xyz:
+            raise AssertionError("Cannot have not features and not use xyz as a feature!")
+        idx, counts = self.search(xyz, new_xyz, length)
+        if record_neighbor_stats:
+            c = counts.float()
+            self.neighbor_stats = torch.stack([c.min(), c.mean(), c.max()])
+            self.neighbor_num_quantile = torch.quantile(c, self.quantile.to(c.device)).long()
+        stand_in = counts if (self.neighbor_def == "radius" and not subset) else None  # empty balls: the centre itself
+        grouped = _rows.group(xyz[..., :3], new_xyz[..., :3], feat, idx, self.layout_flags(), empty_counts=stand_in, half=half)
+        return grouped, counts, idx.shape[2]
 
     def forward(self, xyz, new_xyz, features=None, subset=True, record_neighbor_stats=False, return_counts=False,
                 length=None):
-        if self.neighbor_def == "radius":
-            if length is not None:
-                raise Exception("radius neighbor definition has not supported point clouds with different lengths")
-            idx, counts = ball_query(self.radius, self.nsample, xyz, new_xyz)
-        else:
-            num_neighbors = min(self.nsample, xyz.shape[1])
-            _, idx, _ = knn.knn_points(new_xyz, xyz, K=num_neighbors, lengths2=length)
-            idx = idx.int()
-            B, npoint, K = idx.size()
-            counts = torch.ones(B, npoint, device=new_xyz.device) * K
-            if length is not None:
-                counts = torch.minimum(counts, length.unsqueeze(1))
-        xyz_trans = xyz.transpose(1, 2).contiguous()
-        abs_xyz = grouping_operation(xyz_trans, idx)
-        new_xyz_trans = new_xyz.transpose(1, 2).unsqueeze(-1)
-        patch = (not subset) and self.neighbor_def == "radius"
-        if patch:  # empty balls: the centre itself stands in as the only neighbour, with zero features
-            have_neigh = (counts > 0).float().unsqueeze(1).unsqueeze(-1).detach()
-            no_neigh = 1 - have_neigh
-            abs_xyz = have_neigh * abs_xyz + no_neigh * new_xyz_trans
-        relative_xyz = abs_xyz - new_xyz_trans
-        grouped_xyz = torch.cat([relative_xyz, abs_xyz], dim=1) if self.include_abs_coordinate else relative_xyz
-        if self.include_center_coordinate:
-            grouped_xyz = torch.cat([grouped_xyz, new_xyz_trans.expand(-1, -1, -1, grouped_xyz.shape[3])], dim=1)
-        if features is not None:
-            grouped_features = grouping_operation(features, idx)
-            if patch:
-                grouped_features = have_neigh * grouped_features
-            new_features = torch.cat([grouped_features, grouped_xyz], dim=1) if self.use_xyz else grouped_features
-        else:
-            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
-            new_features = grouped_xyz
-        if record_neighbor_stats:
-            with torch.no_grad():
-                c = counts.float()
-                self.neighbor_stats = torch.stack([c.min(), c.mean(), c.max()])
-                self.neighbor_num_quantile = torch.quantile(c, self.quantile.to(c.device)).long()
-        return (new_features, counts) if return_counts else new_features
+        feat = _rows.from_ncx(features, half=False) if features is not None else None
+        grouped, counts, K = self.rows(xyz, new_xyz, feat, subset, record_neighbor_stats, length, half=False)
+        out = _rows.to_ncx(grouped, (new_xyz.shape[1], K))
+        return (out, counts) if return_counts else out
 
 
 class GroupAll(nn.Module):
+    """one group holding every point (reference :451-494): (B, C [+ 3], 1, N)"""
+
     def __init__(self, use_xyz=True):
         super().__init__()
         self.use_xyz = use_xyz
 
     def forward(self, xyz, new_xyz, features=None):
-        grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
+        coords = xyz.transpose(1, 2).unsqueeze(2)
         if features is None:
-            return grouped_xyz
-        grouped_features = features.unsqueeze(2)
-        return torch.cat([grouped_features, grouped_xyz], dim=1) if self.use_xyz else grouped_features
+            return coords
+        feats = features.unsqueeze(2)
+        return torch.cat([feats, coords], dim=1) if self.use_xyz else feats
+
+
+def group_knn_rows(x, y, feat_at_y, K):
+    """kNN feature propagation input on Rows: feat_at_y Rows [B * Ny] -> Rows [B * Nx * K] with the channel layout
+    [feat | d2 | w | abs | rel | centre] (reference :497-524; w = normalised inverse squared distance)"""
+    d2, idx, _ = knn.knn_points(x, y, K=K)
+    return _rows.group(y, x, feat_at_y, idx, _rows.GROUP_FP, d2=d2)
 
 
 def group_knn(x, y, features_at_y, K, transpose=False):
-    """K nearest neighbours of every x in y with [feats, d2, w, abs, rel, centre] per neighbour (reference :497-524)"""
-    feats = features_at_y.transpose(1, 2).contiguous() if transpose else features_at_y
-    dist, idx, nn_abs = knn.knn_points(x, y, K=K, return_nn=True)
-    nbr = knn.knn_gather(feats, idx)
-    x_repeat = x.unsqueeze(2).repeat(1, 1, K, 1)
-    rel = nn_abs - x_repeat
-    dist = dist.unsqueeze(3)
-    recip = 1.0 / (dist + 1e-8)
-    weight = recip / torch.sum(recip, dim=2, keepdim=True)
-    new_features = torch.cat([nbr, dist, weight, nn_abs, rel, x_repeat], dim=3)
+    """K nearest neighbours of every x in y: (B, Nx, K, C + 11), or (B, C + 11, Nx, K) with channel-first features
+    (transpose=True), as the reference returns them"""
+    feat = _rows.from_ncx(features_at_y, half=False) if transpose else _rows.from_points(features_at_y, half=False)
+    g = group_knn_rows(x, y, feat, K)
     if transpose:
-        new_features = new_features.transpose(2, 3).transpose(1, 2)
-    return new_features
+        return _rows.to_ncx(g, (x.shape[1], K))
+    return _rows.to_points(g).reshape(x.shape[0], x.shape[1], K, g.C)

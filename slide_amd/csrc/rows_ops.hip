@@ -71,12 +71,15 @@ __global__ __launch_bounds__(256) void rows_to_ncx_kernel(int C, int P, int ld, 
 // row (b, p, k) of out = [feat[b][idx[b][p][k]][0..C) | coordinate channels | 0 ...]; coordinate channels:
 //   SA  (flags & 1) == 0:  rel(3) = nbr - centre, then abs(3) if flags & 2, then centre(3) if flags & 4; none if flags & 8
 //   FP  (flags & 1):       d2, w = (1/(d2+1e-8)) / sum_k(1/(d2+1e-8)), abs(3), rel(3), centre(3)
-// feat == NULL: C = 0.  One thread per 8 output columns.
+// feat == NULL: C = 0.  flags & 16: idx is int32 (ball_query) instead of int64 (knn_points).  counts != NULL: a centre whose
+// ball is empty (counts[b][p] == 0) gets itself as its only neighbour, with zero features (QueryAndGroup subset=False,
+// pointnet2_utils.py:396-421).  One thread per 8 output columns.
 template <typename T>
 __global__ __launch_bounds__(256) void rows_group_kernel(int N, int np, int K, int C, int ldf, int ldg, int flags,
                                                          const float *__restrict__ xyz, const float *__restrict__ new_xyz,
-                                                         const T *__restrict__ feat, const int64_t *__restrict__ idx,
-                                                         const float *__restrict__ d2, T *__restrict__ out, size_t total) {
+                                                         const T *__restrict__ feat, const void *__restrict__ idx,
+                                                         const float *__restrict__ d2, const int *__restrict__ counts,
+                                                         T *__restrict__ out, size_t total) {
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= total) return;
   const int ppr = ldg >> 3;
@@ -84,10 +87,11 @@ __global__ __launch_bounds__(256) void rows_group_kernel(int N, int np, int K, i
   const int c0 = (int)(gid - row * ppr) * 8;
   const size_t pt = row / K;  // b * np + p
   const int b = (int)(pt / np);
-  const int nb = (int)idx[row];
+  const int nb = (flags & 16) ? static_cast<const int *>(idx)[row] : (int)static_cast<const int64_t *>(idx)[row];
+  const bool empty = counts && counts[pt] == 0;
   T *o = out + row * ldg + c0;
   const T *f = feat + ((size_t)b * N + nb) * ldf;
-  if (c0 + 8 <= C) {
+  if (c0 + 8 <= C && !empty) {
     *reinterpret_cast<Pack<T, 8> *>(o) = *reinterpret_cast<const Pack<T, 8> *>(f + c0);
     return;
   }
@@ -95,8 +99,8 @@ __global__ __launch_bounds__(256) void rows_group_kernel(int N, int np, int K, i
 #pragma unroll
   for (int j = 0; j < 8; ++j) r.v[j] = (T)0.f;
   if (c0 < C + 11) {  // this piece holds coordinate channels
-    const float *q = xyz + ((size_t)b * N + nb) * 3;
     const float *ctr = new_xyz + pt * 3;
+    const float *q = empty ? ctr : xyz + ((size_t)b * N + nb) * 3;
     float cv[11];
     int ncv;
     if (flags & 1) {
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256) void rows_group_kernel(int N, int np, int K, i
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = c0 + j;
-      if (c < C) r.v[j] = f[c];
+      if (c < C) r.v[j] = empty ? (T)0.f : f[c];
       else if (c - C < ncv) {
         float v = 0.f;
 #pragma unroll
@@ -320,9 +324,12 @@ __global__ __launch_bounds__(256) void rows_concat_qk_kernel(int K, int C1, int 
 
 // out[pt][c] = sum_k softmax_k(S[pt*K + k][c]) * V[pt*K + k][c]; one thread per (point, channel), consecutive threads ->
 // consecutive channels of the same rows
+// counts != NULL: only the first max(1, counts[pt]) neighbour slots take part (the reference masks the others with -1e9
+// before the softmax, attention.py:89-93: their weights are exactly 0 in fp32)
 template <typename T>
 __global__ __launch_bounds__(256) void rows_attn_kernel(int K, int C, int lds_, int ldv, int ldo, const T *__restrict__ Sx,
-                                                        const T *__restrict__ V, T *__restrict__ out, size_t total) {
+                                                        const T *__restrict__ V, const int *__restrict__ counts,
+                                                        T *__restrict__ out, size_t total) {
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= total) return;
   const size_t pt = gid / ldo;
@@ -333,6 +340,7 @@ __global__ __launch_bounds__(256) void rows_attn_kernel(int K, int C, int lds_, 
   }
   const T *sp = Sx + pt * K * lds_ + c;
   const T *vp = V + pt * K * ldv + c;
+  if (counts) K = max(1, min(K, counts[pt]));
   float m = -INFINITY;
   for (int k = 0; k < K; ++k) m = fmaxf(m, (float)sp[(size_t)k * lds_]);
   float l = 0.f;
@@ -341,6 +349,33 @@ __global__ __launch_bounds__(256) void rows_attn_kernel(int K, int C, int lds_, 
   float acc = 0.f;
   for (int k = 0; k < K; ++k) acc += (float)vp[(size_t)k * ldv] * (expf((float)sp[(size_t)k * lds_] - m) * rl);
   out[gid] = (T)acc;
+}
+
+// pooling over the K neighbour rows of a point (pooling_features, pointnet2_modules.py:179-211): mode 0 max over all K
+// slots, 1 mean over the first max(1, counts[pt]) slots (all K without counts), 2 = max for the first C / 2 channels and
+// mean for the rest
+template <typename T>
+__global__ __launch_bounds__(256) void rows_pool_kernel(int K, int C, int ldx, int ldo, int mode, const T *__restrict__ x,
+                                                        const int *__restrict__ counts, T *__restrict__ out, size_t total) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const size_t pt = gid / ldo;
+  const int c = (int)(gid - pt * ldo);
+  if (c >= C) {
+    out[gid] = (T)0.f;
+    return;
+  }
+  const T *xp = x + pt * K * ldx + c;
+  if (mode == 0 || (mode == 2 && c < C / 2)) {
+    float m = -INFINITY;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, (float)xp[(size_t)k * ldx]);
+    out[gid] = (T)m;
+  } else {
+    const int n = counts ? max(1, min(K, counts[pt])) : K;
+    float a = 0.f;
+    for (int k = 0; k < n; ++k) a += (float)xp[(size_t)k * ldx];
+    out[gid] = (T)(a / (float)n);
+  }
 }
 
 template <typename T>
@@ -363,8 +398,8 @@ int launch_rows(const SlideOp &o, hipStream_t s) {
       if (ldg % 8 || (C > 0 && ldf % 8) || C + ((flags & 1) ? 11 : (flags & 8) ? 0 : 3 + ((flags & 2) ? 3 : 0) + ((flags & 4) ? 3 : 0)) > ldg) return -3;
       const size_t total = (size_t)B * np * K * (ldg / 8);
       hipLaunchKernelGGL(rows_group_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, N, np, K, C, ldf, ldg,
-                         flags, (const float *)o.p[0], (const float *)o.p[1], (const T *)o.p[2], (const int64_t *)o.p[3],
-                         (const float *)o.p[4], (T *)o.p[5], total);
+                         flags, (const float *)o.p[0], (const float *)o.p[1], (const T *)o.p[2], (const void *)o.p[3],
+                         (const float *)o.p[4], (const int *)o.p[6], (T *)o.p[5], total);
       break;
     }
     case SLIDE_OP_ROWS_GN: {  // i: B, S, ld, G, n_norm, flags, addvec_ld, res_ld   p: x, gamma, beta, addvec, residual, part, y
@@ -392,7 +427,13 @@ int launch_rows(const SlideOp &o, hipStream_t s) {
     case SLIDE_OP_ROWS_ATTN: {  // i: points, K, C, lds, ldv, ldo   p: S, V, out
       const size_t total = (size_t)o.i[0] * o.i[5];
       hipLaunchKernelGGL(rows_attn_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, o.i[1], o.i[2], o.i[3],
-                         o.i[4], o.i[5], (const T *)o.p[0], (const T *)o.p[1], (T *)o.p[2], total);
+                         o.i[4], o.i[5], (const T *)o.p[0], (const T *)o.p[1], (const int *)o.p[3], (T *)o.p[2], total);
+      break;
+    }
+    case SLIDE_OP_ROWS_POOL: {  // i: points, K, C, ldx, ldo, mode   p: x, out, counts
+      const size_t total = (size_t)o.i[0] * o.i[4];
+      hipLaunchKernelGGL(rows_pool_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, o.i[1], o.i[2], o.i[3],
+                         o.i[4], o.i[5], (const T *)o.p[0], (const int *)o.p[2], (T *)o.p[1], total);
       break;
     }
     default:

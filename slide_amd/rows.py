@@ -19,8 +19,9 @@ from ._lib import check, lib
 from .engine import EPI_RAW, OP_GEMM, SlideEpi, SlideOp, make_op, ru
 
 OP_COPY_COLS = 7
-OP_ROWS_FROM_NCX, OP_ROWS_TO_NCX, OP_ROWS_GROUP, OP_ROWS_GN, OP_ROWS_CONCAT_QK, OP_ROWS_ATTN = 20, 21, 22, 23, 24, 25
-GROUP_FP, GROUP_ABS, GROUP_CENTER, GROUP_NO_XYZ = 1, 2, 4, 8
+OP_ROWS_FROM_NCX, OP_ROWS_TO_NCX, OP_ROWS_GROUP, OP_ROWS_GN, OP_ROWS_CONCAT_QK, OP_ROWS_ATTN, OP_ROWS_POOL = 20, 21, 22, 23, 24, 25, 26
+GROUP_FP, GROUP_ABS, GROUP_CENTER, GROUP_NO_XYZ, GROUP_IDX32 = 1, 2, 4, 8, 16
+POOL_MAX, POOL_AVG, POOL_MAX_AVG = 0, 1, 2
 GN_PRE_RELU, GN_POST_RELU = 1, 2
 
 
@@ -63,14 +64,14 @@ def _empty(rows, ld, half, device):
     return torch.empty(rows, ld, device=device, dtype=torch.float16 if half else torch.float32)
 
 
-def from_ncx(x):
-    """(B, C, *spatial) fp32 -> Rows with S = prod(spatial)"""
+def from_ncx(x, half=None):
+    """(B, C, *spatial) fp32 -> Rows with S = prod(spatial); half: storage type (default: SLIDE_MODULE_PREC)"""
     if not x.is_cuda:
         raise RuntimeError("CPU not supported")
     x = x.contiguous().float()
     B, C = x.shape[:2]
     P = int(np.prod(x.shape[2:])) if x.dim() > 2 else 1
-    half = half_mode()
+    half = half_mode() if half is None else half
     out = _empty(B * P, ru(C), half, x.device)
     _run(_rop(OP_ROWS_FROM_NCX, half, (B, C, P, out.shape[1]), (x, out)))
     return Rows(out, B, P, C)
@@ -83,11 +84,11 @@ def to_ncx(r, spatial=None):
     return out
 
 
-def from_points(x):
+def from_points(x, half=None):
     """(B, N, C) fp32 point-major tensor -> Rows (dtype conversion + column padding only)"""
     B, N, C = x.shape
     x = x.contiguous().float()
-    half = half_mode()
+    half = half_mode() if half is None else half
     out = torch.zeros(B * N, ru(C), device=x.device, dtype=torch.float16 if half else torch.float32)
     _run(make_op(OP_COPY_COLS, i=(B * N, C, C, out.shape[1], 0, int(half)), p=(x.data_ptr(), out.data_ptr())))
     return Rows(out, B, N, C)
@@ -199,19 +200,31 @@ def norm_act(x, gn=None, pre_relu=False, relu=False, addvec=None, residual=None)
     return x
 
 
-def group(xyz, new_xyz, feat, idx, flags, d2=None):
-    """grouped input of an SA / feature-map block (QueryAndGroup 'nn') or of a kNN feature-propagation block (group_knn):
-    xyz (B,N,3), new_xyz (B,np,3), feat Rows [B*N] or None, idx (B,np,K) int64 -> Rows [B*np*K]"""
+def _counts32(counts, pts):
+    if counts is None or isinstance(counts, str):
+        return None
+    c = counts.reshape(-1).to(torch.int32).contiguous()
+    assert c.numel() == pts
+    return c
+
+
+def group(xyz, new_xyz, feat, idx, flags, d2=None, empty_counts=None, half=None):
+    """grouped input of an SA / feature-map block (QueryAndGroup) or of a kNN feature-propagation block (group_knn):
+    xyz (B,N,3), new_xyz (B,np,3), feat Rows [B*N] or None, idx (B,np,K) int64 (kNN) or int32 (ball query) -> Rows
+    [B*np*K].  empty_counts (B,np): centres with count 0 become their own single neighbour with zero features."""
     B, N = xyz.shape[:2]
     npnt, K = idx.shape[1:]
     C = feat.C if feat is not None else 0
     ncoord = 11 if flags & GROUP_FP else 0 if flags & GROUP_NO_XYZ else 3 + (3 if flags & GROUP_ABS else 0) + (3 if flags & GROUP_CENTER else 0)
-    half = feat.half if feat is not None else half_mode()
+    half = feat.half if feat is not None else (half_mode() if half is None else half)
     out = _empty(B * npnt * K, ru(C + ncoord), half, xyz.device)
-    assert idx.dtype == torch.int64 and idx.is_contiguous()
+    assert idx.dtype in (torch.int64, torch.int32)
+    idx = idx.contiguous()
+    if idx.dtype == torch.int32:
+        flags |= GROUP_IDX32
     _run(_rop(OP_ROWS_GROUP, half, (B, N, npnt, K, C, feat.ld if feat is not None else 8, out.shape[1], flags),
               (xyz.contiguous().float(), new_xyz.contiguous().float(), feat.data if feat is not None else None, idx,
-               d2.contiguous() if d2 is not None else None, out)))
+               d2.contiguous() if d2 is not None else None, out, _counts32(empty_counts, B * npnt))))
     return Rows(out, B, npnt * K, C + ncoord)
 
 
@@ -231,10 +244,20 @@ def concat_qk(q, k, K):
     return Rows(out, k.B, k.S, C)
 
 
-def attend(scores, values, K):
-    """softmax over the K neighbour rows of each point, weighted sum of the values -> Rows [B * S / K]"""
+def attend(scores, values, K, counts=None):
+    """softmax over the K neighbour rows of each point (the first max(1, count) of them when counts (B, np) is given),
+    weighted sum of the values -> Rows [B * S / K]"""
     assert scores.rows == values.rows and scores.C == values.C and scores.half == values.half
     pts = scores.rows // K
     out = _empty(pts, ru(scores.C), scores.half, scores.data.device)
-    _run(_rop(OP_ROWS_ATTN, scores.half, (pts, K, scores.C, scores.ld, values.ld, out.shape[1]), (scores.data, values.data, out)))
+    _run(_rop(OP_ROWS_ATTN, scores.half, (pts, K, scores.C, scores.ld, values.ld, out.shape[1]),
+              (scores.data, values.data, out, _counts32(counts, pts))))
     return Rows(out, scores.B, scores.S // K, scores.C)
+
+
+def pool(x, K, mode, counts=None):
+    """max / mean / [max | mean] over the K neighbour rows of each point -> Rows [B * S / K]"""
+    pts = x.rows // K
+    out = _empty(pts, x.ld, x.half, x.data.device)
+    _run(_rop(OP_ROWS_POOL, x.half, (pts, K, x.C, x.ld, out.shape[1], mode), (x.data, out, _counts32(counts, pts))))
+    return Rows(out, x.B, x.S // K, x.C)

@@ -190,65 +190,139 @@ def test_sample_farthest_points(gpu_device):
         assert np.array_equal(gi.cpu().numpy(), ri) and np.array_equal(go.cpu().numpy(), ro)
 
 
-def _ab(monkeypatch, fn):
-    """run fn() on the row-major fast path and on the general NCHW program"""
-    monkeypatch.setenv("SLIDE_MODULE_ROWS", "1")
-    a = fn()
-    monkeypatch.setenv("SLIDE_MODULE_ROWS", "0")
-    b = fn()
-    monkeypatch.delenv("SLIDE_MODULE_ROWS")
-    return a, b
+def _randomise(m, dev, seed=11):
+    g2 = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=g2) * (0.3 if p.dim() > 1 else 0.5) + (1.0 if n.endswith("group_norm.weight") else 0.0))
+    return m.to(dev).eval()
+
+
+def _sd(m, prefix):
+    return {prefix + "." + k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
-def test_row_major_path_equals_general_program(gpu_device, monkeypatch, prec):
-    """The row-major fast path (slide_amd.rows) and the general NCHW program are two implementations of the same
-    reference modules: same outputs on random weights -- multi-scale grouping, fewer points than npoint (no FPS), odd
-    channel counts (pad columns, un-normalised GroupNorm tail channels), K larger than a wave of rows, no attention bn."""
+def test_row_major_modules_against_the_oracle(gpu_device, monkeypatch, prec):
+    """The row-major module programs (slide_amd.rows kernels + MFMA GEMMs) vs the numpy restatement of the reference
+    modules (oracle/denoiser_np.py) on random weights: multi-scale grouping, fewer points than npoint (no FPS), odd channel
+    counts (pad columns, un-normalised GroupNorm tail channels), 48 neighbours, kNN feature propagation with skip features,
+    the autoencoder's feature mapper."""
+    from oracle import denoiser_np as O
     from pointnet2_ops import pointnet2_modules as PM
     monkeypatch.setenv("SLIDE_MODULE_PREC", prec)
-    tol = dict(atol=2e-4, rtol=1e-4) if prec == "fp32" else dict(atol=3e-2, rtol=3e-2)
+    tol = dict(atol=3e-4, rtol=2e-4) if prec == "fp32" else dict(atol=4e-2, rtol=4e-2)
     d = gpu_device
     gen = torch.Generator().manual_seed(5)
     B, N, C = 3, 200, 13
-    xyz = torch.rand(B, N, 3, generator=gen).to(d)
-    feats = torch.randn(B, C, N, generator=gen).to(d)
-    temb, cemb = torch.randn(B, 24, generator=gen).to(d), torch.randn(B, 10, generator=gen).to(d)
-
-    def randomise(m):
-        g2 = torch.Generator().manual_seed(11)
-        with torch.no_grad():
-            for n, p in m.named_parameters():
-                p.copy_(torch.randn(p.shape, generator=g2) * (0.3 if p.dim() > 1 else 0.5) + (1.0 if n.endswith("group_norm.weight") else 0.0))
-        return m.to(d).eval()
-
-    for att_bn, last_act in ((True, True), (False, False)):
-        att = {"use_attention_module": True, "attention_bn": att_bn, "transform_grouped_feat_out": True, "last_activation": last_act}
-        sa = randomise(PM.PointnetSAModuleMSG(npoint=50, radii=[0, 0], nsamples=[5, 48], mlps=[[C, 20, 20, 45], [C, 16, 24, 40, 33]],
-                                              bn=True, use_xyz=True, t_dim=24, include_t=True, include_abs_coordinate=True,
-                                              include_center_coordinate=False, bias=True, res_connect=True, include_condition=True,
-                                              condition_dim=10, neighbor_def="nn", attention_setting=att))
-        (ax, af), (bx, bf) = _ab(monkeypatch, lambda: sa(xyz, feats, t_emb=temb, condition_emb=cemb))
-        assert torch.equal(ax, bx) and af.shape == (B, 45 + 33, 50)
-        assert torch.allclose(af, bf, **tol), float((af - bf).abs().max())
-    # fewer points than npoint: every point is a centre, the query features are the input features
-    sa = randomise(PM.PointnetSAModule(mlp=[C, 16, 16, 32], npoint=512, radius=0, nsample=16, bn=True, use_xyz=True,
-                                       include_t=False, include_abs_coordinate=True, include_center_coordinate=True, bias=False,
-                                       res_connect=False, neighbor_def="nn", attention_setting=att))
-    (ax, af), (bx, bf) = _ab(monkeypatch, lambda: sa(xyz, feats))
-    assert ax.shape == (B, N, 3) and torch.allclose(af, bf, **tol), float((af - bf).abs().max())
-    # kNN feature propagation: 40 known points -> 200 unknown points, skip features, t / class embeddings
+    xyz = torch.rand(B, N, 3, generator=gen)
+    feats = torch.randn(B, C, N, generator=gen)
+    temb, cemb = torch.randn(B, 24, generator=gen), torch.randn(B, 10, generator=gen)
+    npy = lambda t: t.detach().cpu().numpy()
     att = {"use_attention_module": True, "attention_bn": True, "transform_grouped_feat_out": True, "last_activation": True}
-    known, kf = xyz[:, :40].contiguous(), torch.randn(B, 21, 40, generator=gen).to(d)
-    fp = randomise(PM.PointnetKnnFPModule(mlp1=[21, 24, 24, 30], mlp2=[30 + C, 36, 36], K=7, bn=True, t_dim=24, include_t=True,
-                                          bias=True, res_connect=True, include_condition=True, condition_dim=10,
-                                          include_second_condition=True, second_condition_dim=10, attention_setting=att))
-    a, b = _ab(monkeypatch, lambda: fp(xyz, known, feats, kf, t_emb=temb, condition_emb=cemb, second_condition_emb=cemb))
-    assert a.shape == (B, 36, N) and torch.allclose(a, b, **tol), float((a - b).abs().max())
+
+    def close(a, b):
+        assert a.shape == b.shape and np.allclose(a, b, **tol), float(np.abs(a - b).max())
+
+    # two scales (5 and 48 neighbours), t and class embeddings, res_connect through a convolution
+    sa = _randomise(PM.PointnetSAModuleMSG(npoint=50, radii=[0, 0], nsamples=[5, 48], mlps=[[C, 20, 20, 45], [C, 16, 24, 33]],
+                                           bn=True, use_xyz=True, t_dim=24, include_t=True, include_abs_coordinate=True,
+                                           include_center_coordinate=True, bias=True, res_connect=True, include_condition=True,
+                                           condition_dim=10, neighbor_def="nn", attention_setting=att), d)
+    nx, nf = sa(xyz.to(d), feats.to(d), t_emb=temb.to(d), condition_emb=cemb.to(d))
+    sd = _sd(sa, "sa")
+    from oracle import ops as oops
+    fidx = oops.furthest_point_sampling(npy(xyz), 50)
+    ctr = np.ascontiguousarray(oops.gather_points(np.ascontiguousarray(npy(xyz).transpose(0, 2, 1)), fidx).transpose(0, 2, 1))
+    q = oops.gather_points(npy(feats), fidx)
+    want = []
+    for i, K in enumerate((5, 48)):
+        grouped, _, _ = O.query_and_group_nn(npy(xyz), ctr, npy(feats), K)
+        h = O.mlp_plus_t_emb(grouped, sd, "sa.mlps.%d" % i, npy(temb), npy(cemb))
+        want.append(O.attention_module(q, grouped, h, sd, "sa.attention_modules.%d" % i))
+    assert np.array_equal(npy(nx), ctr)
+    close(npy(nf), np.concatenate(want, axis=1))
+    # fewer points than npoint: every point is a centre, the queries are the input features; identity res_connect
+    sa = _randomise(PM.PointnetSAModule(mlp=[C, 16, 16, C + 9], npoint=512, radius=0, nsample=16, bn=True, use_xyz=True,
+                                        include_t=False, include_abs_coordinate=True, include_center_coordinate=True, bias=False,
+                                        res_connect=True, neighbor_def="nn", attention_setting=att), d)
+    nx, nf = sa(xyz.to(d), feats.to(d))
+    wx, wf = O.sa_module(npy(xyz), npy(feats), _sd(sa, "sa"), "sa", 512, 16, None, None)
+    assert nx.shape == (B, N, 3)
+    close(npy(nf), wf)
+    # kNN feature propagation: 40 known points -> 200 unknown points, skip features, t / class embeddings
+    known, kf = xyz[:, :40].contiguous(), torch.randn(B, 21, 40, generator=gen)
+    fp = _randomise(PM.PointnetKnnFPModule(mlp1=[21, 24, 24, 30], mlp2=[30 + C, 36, 36], K=7, bn=True, t_dim=24, include_t=True,
+                                           bias=True, res_connect=True, include_condition=True, condition_dim=10,
+                                           attention_setting=att), d)
+    out = fp(xyz.to(d), known.to(d), feats.to(d), kf.to(d), t_emb=temb.to(d), condition_emb=cemb.to(d))
+    close(npy(out), O.knn_fp_module(npy(xyz), npy(known), npy(feats), npy(kf), _sd(fp, "fp"), "fp", 7, npy(temb), npy(cemb)))
     # feature mapper of the autoencoder: features of 200 points mapped onto 16 key points
-    fm = randomise(PM.FeatureMapModule([C, 32, 32, 48], 0, 12, use_xyz=True, include_abs_coordinate=True, include_center_coordinate=True,
-                                       bn=True, bn_first=False, bias=True, res_connect=True, neighbor_def="nn",
-                                       attention_setting=att, query_feature_dim=19))
-    keypts, qf = xyz[:, 100:116].contiguous(), torch.randn(B, 19, 16, generator=gen).to(d)
-    a, b = _ab(monkeypatch, lambda: fm(xyz, feats, keypts, subset=False, record_neighbor_stats=True, features_at_new_xyz=qf))
-    assert a.shape == (B, 48, 16) and torch.allclose(a, b, **tol), float((a - b).abs().max())
+    fm = _randomise(PM.FeatureMapModule([C, 32, 32, 48], 0, 12, use_xyz=True, include_abs_coordinate=True,
+                                        include_center_coordinate=True, bn=True, bn_first=False, bias=True, res_connect=True,
+                                        neighbor_def="nn", attention_setting=att, query_feature_dim=19), d)
+    keypts, qf = xyz[:, 100:116].contiguous(), torch.randn(B, 19, 16, generator=gen)
+    out = fm(xyz.to(d), feats.to(d), keypts.to(d), subset=False, record_neighbor_stats=True, features_at_new_xyz=qf.to(d))
+    close(npy(out), O.feature_map_module(npy(xyz), npy(feats), npy(keypts), npy(qf), _sd(fm, "fm"), "fm", 12))
+    assert float(fm.mapper.neighbor_stats[0]) == 12.0
+
+
+def test_general_module_programs_against_torch(gpu_device):
+    """What the stage interpreter does not cover -- GroupNorm BEFORE the convolution, swish, pooling instead of attention,
+    ball-query grouping with partially filled balls -- against a plain PyTorch fp32 restatement of the same arithmetic."""
+    import torch.nn.functional as F
+    from pointnet2_ops import pointnet2_modules as PM
+    from pointnet2_ops import pointnet2_utils as PU
+    d = gpu_device
+    gen = torch.Generator().manual_seed(9)
+    B, N, C, npnt, K = 2, 96, 10, 24, 12
+    xyz = torch.rand(B, N, 3, generator=gen)
+    feats = torch.randn(B, C, N, generator=gen)
+    temb = torch.randn(B, 16, generator=gen)
+    cpu = lambda t: t.detach().cpu()
+
+    def gn(x, m):  # MyGroupNorm on a CPU tensor: tail channels pass through
+        n = m.num_channels
+        y = F.group_norm(x[:, :n], m.num_groups, cpu(m.group_norm.weight), cpu(m.group_norm.bias), 1e-5)
+        return torch.cat([y, x[:, n:]], dim=1)
+
+    def seq(s, x):
+        for l in s:
+            if isinstance(l, PM.MyGroupNorm):
+                x = gn(x, l)
+                x = F.relu(x) if l.fused_relu else x
+            elif isinstance(l, PM.HipConv1x1):
+                x = F.conv2d(x, cpu(l.weight), None if l.bias is None else cpu(l.bias))
+            elif isinstance(l, PM.Swish):
+                x = x * torch.sigmoid(x)
+            elif isinstance(l, torch.nn.ReLU):
+                x = F.relu(x)
+        return x
+
+    def mlp_ref(m, x, t):
+        h = seq(m.first_mlp, x)
+        if m.include_t:
+            h = h + F.linear(t, cpu(m.fc.weight), cpu(m.fc.bias))[:, :, None, None]
+        h = seq(m.second_mlp, h)
+        if m.rest_mlp is not None:
+            h = seq(m.rest_mlp, h)
+        if m.res_connect_bool:
+            h = h + (F.conv2d(x, cpu(m.res_connect.weight), cpu(m.res_connect.bias)) if m.res_connect is not None else x)
+        return h
+
+    for bn_first, activation, pooling in ((True, "swish", "max"), (False, "relu", "avg"), (True, "relu", "avg_max")):
+        sa = _randomise(PM.PointnetSAModule(mlp=[C, 16, 24, 30], npoint=npnt, radius=0.35, nsample=K, bn=True, use_xyz=True, t_dim=16,
+                                            include_t=True, include_abs_coordinate=True, bn_first=bn_first, bias=True,
+                                            res_connect=True, neighbor_def="radius", activation=activation), d)
+        assert sa.mlps[0].rows_ok() == (not bn_first and activation == "relu")
+        nx, nf = sa(xyz.to(d), feats.to(d), t_emb=temb.to(d), pooling=pooling)
+        grouped, counts = PU.QueryAndGroup(0.35, K, True, True, False, "radius")(xyz.to(d), nx, feats.to(d), return_counts=True)
+        counts = cpu(counts).long()
+        assert counts.min() < K and counts.max() == K  # partially filled balls are part of the case
+        h = mlp_ref(sa.mlps[0], cpu(grouped), temb)
+        mask = (torch.arange(K)[None, None, :] < counts.clamp(min=1)[:, :, None])[:, None].float()
+        avg = (h * mask).sum(-1) / counts.clamp(min=1)[:, None].float()
+        mx = h.max(dim=-1)[0]
+        half_c = h.shape[1] // 2
+        want = {"max": mx, "avg": avg, "avg_max": torch.cat([mx[:, :half_c], avg[:, half_c:]], dim=1)}[pooling]
+        assert torch.allclose(cpu(nf), want, atol=3e-4, rtol=2e-4), (bn_first, activation, pooling, float((cpu(nf) - want).abs().max()))
