@@ -237,6 +237,14 @@ __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem
   // GAT: the grouped input is never materialised -- the feature columns of row (sample, point, neighbour) are DMA-read
   // straight from the neighbour's row of the point-feature table (per-lane source addresses are free), only the last
   // chunks (coordinate channels) come from a small assembled buffer.  ga[j] serves chunks < g_nsplit, gp[j] the rest.
+  // CHUNK-MAJOR operands (BKT == 32): X [k / 32][rows][32] when x_ld == 32, W [k / 32][n_cob * 32][32] when a.w_cm -- the
+  // chunk kc of a row is then kc * (rows x 32) elements further instead of kc * 32, and the 16 rows of one DMA instruction
+  // are consecutive memory.  x_cs / w_cs: elements between consecutive chunks of one row.
+  constexpr int NXI = TM / (RPI * NW);  // instructions j < NXI carry X rows, the rest W rows
+  static_assert(TM % (RPI * NW) == 0, "X rows must fill whole DMA instructions");
+  const size_t x_cs = (BKT == 32 && a.x_ld == 32) ? (size_t)a.rows * 32 : BKT;
+  const size_t w_cs = (BKT == 32 && a.w_cm) ? (size_t)a.n_cob * 32 * 32 : BKT;
+  const int w_ld = (BKT == 32 && a.w_cm) ? 32 : a.k_pad;
   const T *gp[LPW];
   const T *ga[GAT ? LPW : 1];
 #pragma unroll
@@ -251,20 +259,21 @@ __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem
         const int smp = grow >> NPXL, pxl = grow & ((1 << NPXL) - 1);
         const int nb = a.gidx[(smp * 16 + (pxl >> a.g_klog2)) * 16 + (pxl & ((1 << a.g_klog2) - 1))];
         ga[j] = reinterpret_cast<const T *>(a.gfeat) + (size_t)(smp * 16 + nb) * a.g_ldf + piece * 8;
-        gp[j] -= (size_t)a.g_nsplit * BKT;  // chunk index kc keeps counting over the whole K
+        gp[j] -= (size_t)a.g_nsplit * x_cs;  // chunk index kc keeps counting over the whole K
       }
     } else {
       int gco = cob0 * 32 + (trow - TM);
       gco = gco < a.n_cob * 32 ? gco : a.n_cob * 32 - 1;
-      gp[j] = reinterpret_cast<const T *>(a.W) + (size_t)gco * a.k_pad + piece * 8;
+      gp[j] = reinterpret_cast<const T *>(a.W) + (size_t)gco * w_ld + piece * 8;
       if (GAT) ga[j] = gp[j];
     }
   }
   auto issue = [&](int kc, int st) {
 #pragma unroll
     for (int j = 0; j < LPW; ++j) {
-      const T *src = (GAT && kc < a.g_nsplit) ? ga[GAT ? j : 0] : gp[j];
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(src + kc * BKT),
+      const T *src = (j < NXI) ? ((GAT && kc < a.g_nsplit) ? ga[GAT ? j : 0] + (size_t)kc * BKT : gp[j] + (size_t)kc * x_cs)
+                               : gp[j] + (size_t)kc * w_cs;
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)src,
                                        (__attribute__((address_space(3))) void *)(smem_raw + (size_t)st * STAGE_B +
                                                                                   (j * NW + wv) * 1024),
                                        16, 0, 0);
@@ -654,6 +663,7 @@ struct AttnTailArgs {
   const float *vec;               // [bias_s | bias_v | gamma | beta], n_cob * 32 floats each
   void *out;                      // [rows >> (NPXL - 4)][out_ld] fp16
   int rows, x1_ld, k1, x2_ld, k2, n_cob, gs, n_norm, out_ld;
+  int w_cm;                       // both weight matrices are chunk-major [k / 32][n_cob * 32][32] (u / mo are when their ld is 32)
   float inv_count;
 };
 
@@ -697,6 +707,10 @@ __global__ __launch_bounds__(256, 2) void attn_tail_kernel(AttnTailArgs a) {
   }
   // one LDS-DMA ring GEMM: acc[cb][rb] = D[row][channel] (lane: channel col of block cb; reg r: row (r&3)+8(r>>2)+4 half)
   auto run = [&](const void *Xp, const void *Wp, int x_ld, int k_pad, f32x16 (&acc)[CBW][2]) __attribute__((always_inline)) {
+    // chunk-major operands as in glds_tile: X when x_ld == 32, the weights when a.w_cm
+    const size_t x_cs = x_ld == 32 ? (size_t)a.rows * 32 : 32;
+    const size_t w_cs = a.w_cm ? (size_t)a.n_cob * 32 * 32 : 32;
+    const int w_ld = a.w_cm ? 32 : k_pad;
     const T *gp[LPW];
 #pragma unroll
     for (int j = 0; j < LPW; ++j) {
@@ -709,13 +723,13 @@ __global__ __launch_bounds__(256, 2) void attn_tail_kernel(AttnTailArgs a) {
       } else {
         int gco = cob0 * 32 + (trow - TM);
         gco = gco < a.n_cob * 32 ? gco : a.n_cob * 32 - 1;
-        gp[j] = reinterpret_cast<const T *>(Wp) + (size_t)gco * k_pad + piece * 8;
+        gp[j] = reinterpret_cast<const T *>(Wp) + (size_t)gco * w_ld + piece * 8;
       }
     }
     auto issue = [&](int kc, int st) {
 #pragma unroll
       for (int j = 0; j < LPW; ++j)
-        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(gp[j] + kc * 32),
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(gp[j] + (size_t)kc * (j < TM / 64 ? x_cs : w_cs)),
                                          (__attribute__((address_space(3))) void *)(smem_raw + (size_t)st * STAGE_B +
                                                                                     (j * 4 + wave) * 1024),
                                          16, 0, 0);
@@ -1361,7 +1375,9 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
   a.gn_fin = (const SlideGnFin *)o.p[6];
   a.g_nsplit = (int)o.f[1]; a.g_ldf = (int)o.f[2]; a.g_klog2 = (int)o.f[3];
   a.rows = o.i[0]; a.x_ld = o.i[1]; a.k_pad = o.i[2]; a.n_cob = o.i[3]; a.in_bs = o.i[5];
-  const int npxl = o.i[4], prec = o.i[6], cbw = o.i[7], glds = o.i[8];
+  const int npxl = o.i[4], prec = o.i[6], cbw = o.i[7], glds = o.i[8] & 1;
+  a.w_cm = (o.i[8] >> 1) & 1;  // chunk-major weights (ring kernels of the 128 / 256-row samples only)
+  if (a.w_cm && (!glds || (npxl != 7 && npxl != 8) || o.p[10] || o.i[9] == 1)) return -11;
   if (a.k_pad % BK || a.x_ld % 8 || a.rows <= 0 || a.n_cob <= 0) return -3;
   // fp16 16-row launches: split-K small-launch kernel, with or without the input affine (i[9] == 3 keeps the 256-row
   // kernels, for A/B timing)
@@ -1469,6 +1485,7 @@ int run_attn_tail(const SlideOp &o, hipStream_t s) {
   a.rows = o.i[0]; a.x1_ld = o.i[1]; a.k1 = o.i[2]; a.x2_ld = o.i[3]; a.k2 = o.i[4]; a.n_cob = o.i[5];
   a.gs = o.i[7]; a.n_norm = o.i[8]; a.out_ld = o.i[9];
   a.inv_count = o.f[0];
+  a.w_cm = o.f[1] != 0.f;
   const int npxl = o.i[6];
   if (a.k1 % 32 || a.k2 % 32 || a.rows <= 0 || a.n_cob <= 0) return -3;
   const size_t shm = (size_t)SLIDE_ATTN_NST * (TM + 64) * 64 + 4 * 2 * 32 * 4 + 64;

@@ -22,6 +22,10 @@ struct GemmArgs {
   const SlideEpi *epi;
   const float *in_scale, *in_shift;
   int rows, x_ld, k_pad, n_cob, in_bs;
+  int w_cm;                 // LDS-DMA ring kernels: W is CHUNK-MAJOR [k_pad / 32][n_cob * 32][32] (X is chunk-major
+                            // [k / 32][rows][32] when x_ld == 32): a wave's 16 rows x 64 B of one LDS-DMA instruction are then
+                            // 1 KB of consecutive memory -- 2.2x the L2 -> LDS rate of 64-byte pieces of strided rows
+                            // (tools/lds_fill.hip: 33.6 vs 15.5 TB/s)
   int shm_bytes;            // dynamic LDS of the launch (its last 16 bytes hold the persistent mode's tile index)
   const SlideGnFin *gn_fin; // small-launch affine GEMM: finalise the GroupNorm statistics here (include/slide_engine.h)
   const void *gfeat;        // gather mode (GAT kernels): point-feature table [B*16][g_ldf]; the first g_nsplit K chunks of X row

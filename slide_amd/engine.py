@@ -134,6 +134,10 @@ class DenoiserEngine:
         self.out_dim = hp["out_dim"]
         self.t_dim = hp["t_dim"]
         self.A = _Arena(device)
+        # chunk-major activations / weights for the 128- and 256-row ring kernels (SLIDE_CM=0: row-major everywhere, A/B)
+        self.use_cm = (self.prec == 1 and self.use_glds and self.glds_nst != 1 and _os.environ.get("SLIDE_CM", "1") != "0"
+                       and not _os.environ.get("SLIDE_XS", ""))
+        self._cm = set()
         self.ops = []
         self._lane = 0
         self.two_lanes = _os.environ.get("SLIDE_TWO_LANES", "0") != "0"  # measured: no gain at batch 256
@@ -146,8 +150,29 @@ class DenoiserEngine:
         w = self.sd[name]
         return w.reshape(w.shape[0], -1)
 
-    def _buf(self, rows, ch, dtype=None):
-        return self.A.zeros(rows, ru(ch), dtype=self.adt if dtype is None else dtype)
+    def _buf(self, rows, ch, dtype=None, cm=False):
+        """activation matrix [rows][ld].  cm=True (fp16 LDS-DMA plans): CHUNK-MAJOR storage [ld / 32][rows][32] -- the same
+        bytes, but the 64-byte piece a ring kernel's DMA lane group fetches for row r + 1 follows the one of row r, so one
+        LDS-DMA instruction reads 1 KB of consecutive memory (2.2x the L2 -> LDS rate, tools/lds_fill.hip) and one epilogue
+        store instruction writes 2 KB of it.  Only for buffers whose every producer is a GEMM epilogue and every consumer a
+        ring-kernel loader / epilogue (pointer + leading dimension per 32-channel block express the layout: ld == 32)."""
+        t = self.A.zeros(rows, ru(ch), dtype=self.adt if dtype is None else dtype)
+        if cm and self.use_cm:
+            self._cm.add(t.data_ptr())
+        return t
+
+    def _is_cm(self, t):
+        return t.data_ptr() in self._cm
+
+    def _ldp(self, t):
+        """leading dimension as the kernels see it"""
+        return 32 if self._is_cm(t) else t.shape[1]
+
+    def _colptr(self, t, col):
+        """address of channel `col` of row 0"""
+        if self._is_cm(t):
+            return t.data_ptr() + t.element_size() * ((col // 32) * t.shape[0] * 32 + col % 32)
+        return t.data_ptr() + t.element_size() * col
 
     def _emit(self, op):
         op.i[10] = self._lane if self.two_lanes else 0
@@ -178,9 +203,10 @@ class DenoiserEngine:
              addvec=(tensor, off, bs) | residual tensor | bcast | stats=(sum,sq tensors, coff, scale)
            in_cols: physical column index of every logical input channel (None = identity)."""
         rows, ld = X.shape
-        x_ld = ld
+        x_ld = self._ldp(X)
+        assert not self._is_cm(X) or (npx_log2 >= 7 and gather is None)
         if gather is not None:  # (feature table, neighbour table, K, chunks read from the table): X holds the remaining columns
-            ld = gather[3] * 32 + x_ld
+            ld = gather[3] * 32 + ld
         npx = 1 << npx_log2
         wrows, tables = [], []
         vec_list = []
@@ -207,15 +233,19 @@ class DenoiserEngine:
                 vec[2, oidx[:nn]] = bet
             vec_list.append((vec, sg, Opad, n_norm_p, gs_p, gs_l))
         W = np.concatenate(wrows, axis=0)
-        Wd = self.A.put(W, torch.float16 if self.prec == 1 else torch.float32)
         n_cob = W.shape[0] // 32
+        # chunk-major weights [k / 32][n][32] for the ring kernels of the 128- / 256-row samples (the 16-row launches run the
+        # split-K small-launch kernel, which reads row-major weights)
+        w_cm = bool(self.use_cm and npx_log2 >= 7)
+        Wst = np.ascontiguousarray(W.reshape(W.shape[0], ld // 32, 32).transpose(1, 0, 2)) if w_cm else W
+        Wd = self.A.put(Wst, torch.float16 if self.prec == 1 else torch.float32)
         epis = (SlideEpi * n_cob)()
         blk = 0
         for vec, sg, Opad, n_norm_p, gs_p, gs_l in vec_list:
             vd = self.A.put(vec)
             out = sg["out"]
             coff = sg.get("out_coff", 0)
-            assert out.shape[1] >= coff + Opad and coff % 8 == 0, (out.shape, coff, Opad)
+            assert out.shape[1] >= coff + Opad and coff % (32 if self._is_cm(out) else 8) == 0, (out.shape, coff, Opad)
             assert out.shape[0] == rows, (out.shape, rows)
             flags = sg.get("flags", 0)
             if out.dtype == torch.float32 and self.prec == 1:
@@ -229,11 +259,11 @@ class DenoiserEngine:
                 e.gs = gs_p
                 e.n_norm = int(min(32, max(0, n_norm_p - 32 * j)))
                 e.inv_count = 1.0 / (gs_l * npx)
-                e.out_ld = out.shape[1]
+                e.out_ld = self._ldp(out)
                 e.bias = vd.data_ptr() + 4 * (32 * j)
                 e.gamma = vd.data_ptr() + 4 * (Opad + 32 * j)
                 e.beta = vd.data_ptr() + 4 * (2 * Opad + 32 * j)
-                e.out = out.data_ptr() + out.element_size() * (coff + 32 * j)
+                e.out = self._colptr(out, coff + 32 * j)
                 if sg.get("addvec") is not None:
                     t, off, bs, idx, idx_stride = sg["addvec"]
                     assert off % 4 == 0 and bs % 4 == 0 and idx_stride % 4 == 0
@@ -245,14 +275,15 @@ class DenoiserEngine:
                 if sg.get("residual") is not None:
                     r = sg["residual"]
                     assert r.shape[0] == rows and r.shape[1] >= Opad and r.dtype == self.adt
-                    e.residual = r.data_ptr() + r.element_size() * (32 * j)
-                    e.res_ld = r.shape[1]
+                    e.residual = self._colptr(r, 32 * j)
+                    e.res_ld = self._ldp(r)
                 if sg.get("pre_add") is not None:
                     pa, shift = sg["pre_add"][:2]
                     pcoff = sg["pre_add"][2] if len(sg["pre_add"]) > 2 else 0
                     # shift < 0: row of the NEIGHBOUR point (K = 2^-shift), through the table passed as pre_gather
                     assert pa.shape[0] == (rows >> shift if shift >= 0 else rows >> npx_log2 << 4), (pa.shape, rows, shift)
                     assert (shift >= 0 or pre_gather is not None) and pa.shape[1] >= pcoff + Opad and pa.dtype == self.adt
+                    assert not self._is_cm(pa)
                     e.pre_add = pa.data_ptr() + pa.element_size() * (pcoff + 32 * j)
                     e.pre_add_ld = pa.shape[1]
                     e.pre_add_shift = shift
@@ -304,9 +335,10 @@ class DenoiserEngine:
                 cbw = 4 if n_cob >= 4 and os.environ.get("SLIDE_XS_CBW", "2") == "4" else 2
         gf = (0.0, 0.0, 0.0) if gather is None else (float(gather[3]), float(gather[0].shape[1]), float({8: 3, 16: 4}[gather[2]]))
         knob = self.glds_nst
+        assert wfrag is None or not (w_cm or self._is_cm(X))
         if wfrag is not None and os.environ.get("SLIDE_XS_OCC"):
             knob = 10 + int(os.environ["SLIDE_XS_OCC"])  # cap the workgroups per CU of the X-stationary kernel (A/B timing)
-        self._emit(make_op(OP_GEMM, i=(rows, x_ld, ld, n_cob, npx_log2, in_bs, self.prec, cbw, glds, knob),
+        self._emit(make_op(OP_GEMM, i=(rows, x_ld, ld, n_cob, npx_log2, in_bs, self.prec, cbw, glds | (2 if w_cm else 0), knob),
                            f=(-1.0 if self.persistent == 2 else float(os.environ.get('SLIDE_STAGGER_US', '0')),) + gf,
                                 p=(X.data_ptr(), Wd.data_ptr(), ed.data_ptr(),
                                    None if sc is None else sc.data_ptr() + 4 * aff_off,
@@ -346,7 +378,7 @@ class DenoiserEngine:
         if (pfx + ".fc_condition.weight") in sd:
             seg["addvec"] = (cvec, self._cvec_off(pfx + ".fc_condition", c2), self._c_bs, None, 0)
         if has_rest:
-            h2 = self._buf(rows, c2)
+            h2 = self._buf(rows, c2, cm=npx_log2 >= 7)
             seg["out"] = h2
             self._gemm(h1, npx_log2, [seg])
             c3 = sd[pfx + ".rest_mlp.0.weight"].shape[0]
@@ -380,7 +412,7 @@ class DenoiserEngine:
         C1p, C2p = ru(C1), ru(C2)
         ldT = C1p + C2p                      # physical channel space of the (virtual) concatenation
         Tq = self.A.zeros(B * 16, C1p, dtype=self.adt)
-        Tk = self.A.zeros(rows, C2p, dtype=self.adt)
+        Tk = self._buf(rows, C2p, cm=True)
         ssum, ssq = self.A.zeros(B, ldT), self.A.zeros(B, ldT)
         kseg = dict(w=self._w(apfx + ".grouped_feat_conv.weight"), bias=sd[apfx + ".grouped_feat_conv.bias"],
                     mode=EPI_STATS, flags=F_PRE_RELU, out=Tk, stats=(ssum, ssq, C1p, 1.0))
@@ -464,7 +496,7 @@ class DenoiserEngine:
             self._gemm(Tq, 4, [dict(w=w2[:, :C1], mode=EPI_RAW, layout=(lay[0], lay[1], 0, 1, 1), out=P)],
                        in_affine=(scale, shift, 0, ldT), gn_fin=gn_fin)
             # neighbour half: u = GN4(relu(W2[:, C1:] . GN(relu(k)) + bias + P[point]))
-            u = self.A.zeros(rows, ru(lay[1]), dtype=self.adt)
+            u = self._buf(rows, ru(lay[1]), cm=True)
             self._gemm(Tk, npx_log2, [dict(w=w2[:, C1:], bias=sd[apfx + ".weight_conv.2.bias"], mode=EPI_NORM,
                                            flags=F_PRE_RELU, layout=lay, out=u, pre_add=(P, kshift),
                                            gn=(sd[apfx + ".weight_conv.4.group_norm.weight"],
@@ -497,14 +529,15 @@ class DenoiserEngine:
                 gam = sd[apfx + ".feat_out_conv.1.group_norm.weight"]
                 vec[2, :gam.shape[0]] = gam
                 vec[3, :gam.shape[0]] = sd[apfx + ".feat_out_conv.1.group_norm.bias"]
-                d = [self.A.put(w5, torch.float16), self.A.put(wv, torch.float16), self.A.put(vec)]
-                assert out.dtype == self.adt and u.dtype == self.adt and mo.dtype == self.adt
+                cmw = (lambda w: np.ascontiguousarray(w.reshape(w.shape[0], -1, 32).transpose(1, 0, 2))) if self.use_cm else (lambda w: w)
+                d = [self.A.put(cmw(w5), torch.float16), self.A.put(cmw(wv), torch.float16), self.A.put(vec)]
+                assert out.dtype == self.adt and u.dtype == self.adt and mo.dtype == self.adt and not self._is_cm(out)
                 self._sync(1, 0)
                 self.flops += 2 * rows * (w5.size + wv.size)
                 self.gemm_flops[len(self.ops)] = 2 * rows * cout * (len(lay[0]) + wv_l.shape[1])  # logical channels
-                self._emit(make_op(OP_ATTN_TAIL, i=(rows, u.shape[1], u.shape[1], mo.shape[1], mo.shape[1], Cp // 32, npx_log2,
+                self._emit(make_op(OP_ATTN_TAIL, i=(rows, self._ldp(u), u.shape[1], self._ldp(mo), mo.shape[1], Cp // 32, npx_log2,
                                                     vlay[3], vlay[2], out.shape[1]),
-                                        f=(1.0 / (vlay[4] * npx),),
+                                        f=(1.0 / (vlay[4] * npx), 1.0 if self.use_cm else 0.0),
                                         p=(u.data_ptr(), d[0].data_ptr(), mo.data_ptr(), d[1].data_ptr(), out.data_ptr(),
                                            d[2].data_ptr())))
                 return
@@ -551,7 +584,7 @@ class DenoiserEngine:
         g, gather, _ = self._grouped_input(OP_ASSEMBLE_SA, feat_in, C, Cg, K)
         c1 = sd[mp + ".first_mlp.0.weight"].shape[0]
         c_last = sd[mp + ".res_connect.weight"].shape[0]
-        h1, r, mo = self._buf(rows, c1), self._buf(rows, c_last), self._buf(rows, c_last)
+        h1, r, mo = self._buf(rows, c1, cm=True), self._buf(rows, c_last, cm=True), self._buf(rows, c_last, cm=True)
         first, res = self._mlp_segments(mp, self.tvec, self.cvec, h1, r)
         out = self._buf(B * 16, c_last)
         (scores, finish), cout = self._attention(ap, 8, K, g, feat_in, mo, first, res, out, None, gather=gather)
@@ -572,7 +605,7 @@ class DenoiserEngine:
         g, gather, _ = self._grouped_input(OP_ASSEMBLE_FP, Kf, C2, Cg, K)
         c1 = sd[m1 + ".first_mlp.0.weight"].shape[0]
         c_last = sd[m1 + ".res_connect.weight"].shape[0]
-        h1, r, mo = self._buf(rows, c1), self._buf(rows, c_last), self._buf(rows, c_last)
+        h1, r, mo = self._buf(rows, c1, cm=True), self._buf(rows, c_last, cm=True), self._buf(rows, c_last, cm=True)
         first, res = self._mlp_segments(m1, self.tvec, self.cvec, h1, r)
         # mlp2 input: [interpolated (c_last) | unknown feats (CU) | xyz (3)]  (pointnet2_modules.py:842-855)
         zin = c_last + CU + 3

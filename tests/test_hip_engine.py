@@ -407,3 +407,27 @@ def test_x_stationary_kernel_bit_identical(gpu_device, monkeypatch):
             assert any(o.kind == 1 and o.p[10] for o in e.ops)
             got = e.forward(x, ts, lab).cpu().numpy()
             assert np.array_equal(got, ref), (name, mode, cbw, occ, float(np.abs(got - ref).max()))
+
+
+def test_chunk_major_layout_bit_identical(gpu_device, monkeypatch):
+    """Chunk-major activations / weights ([k / 32][rows][32]: one LDS-DMA instruction reads 1 KB of consecutive memory) are a
+    pure re-layout of the K-expanded buffers between GEMM epilogues and ring-kernel loaders: the denoiser output must be
+    bit-identical to the row-major plan, with the gather-on-load first layers, the fused attention tail, and without either."""
+    from slide_amd.engine import DenoiserEngine
+    for name in ("pos", "feat"):
+        g, hp, sd = _load(name)
+        x, ts, lab = g["x_mixed"], g["ts_mixed"], g["label_mixed"]
+        for knobs in ({}, {"SLIDE_GATHER": "0"}, {"SLIDE_ATTN_TAIL": "0"}, {"SLIDE_SPLIT_FIRST": "32"}):
+            for k_, v_ in knobs.items():
+                monkeypatch.setenv(k_, v_)
+            monkeypatch.setenv("SLIDE_CM", "0")
+            e0 = DenoiserEngine(hp, sd, x.shape[0], gpu_device, prec="fp16")
+            assert not e0._cm and not any(o.kind == 1 and (o.i[8] & 2) for o in e0.ops)
+            ref = e0.forward(x, ts, lab).cpu().numpy()
+            monkeypatch.setenv("SLIDE_CM", "1")
+            e1 = DenoiserEngine(hp, sd, x.shape[0], gpu_device, prec="fp16")
+            assert e1._cm and any(o.kind == 1 and (o.i[8] & 2) for o in e1.ops)
+            got = e1.forward(x, ts, lab).cpu().numpy()
+            assert np.array_equal(got, ref), (name, knobs, float(np.abs(got - ref).max()))
+            for k_ in knobs:
+                monkeypatch.delenv(k_)

@@ -15,8 +15,9 @@ if "--build" in sys.argv:  # instrumented copy of the library (-DSLIDE_TIMELINE)
     subprocess.check_call(F + ["-mllvm", "-pragma-unroll-threshold=100000", "-c", ROOT + "/slide_amd/csrc/engine.hip", "-o", ROOT + "/build_tmp/eT.o"], stderr=subprocess.DEVNULL)
     subprocess.check_call(F + ["-mllvm", "-pragma-unroll-threshold=100000", "-c", ROOT + "/slide_amd/csrc/gemm_xs.hip", "-o", ROOT + "/build_tmp/xT.o"], stderr=subprocess.DEVNULL)
     subprocess.check_call(F + ["-mllvm", "-pragma-unroll-threshold=100000", "-c", ROOT + "/slide_amd/csrc/resident.hip", "-o", ROOT + "/build_tmp/rT.o"], stderr=subprocess.DEVNULL)
+    subprocess.check_call(F + ["-c", ROOT + "/slide_amd/csrc/rows_ops.hip", "-o", ROOT + "/build_tmp/oT.o"], stderr=subprocess.DEVNULL)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIBT, ROOT + "/build_tmp/pT.o", ROOT + "/build_tmp/eT.o",
-                           ROOT + "/build_tmp/xT.o", ROOT + "/build_tmp/rT.o"])
+                           ROOT + "/build_tmp/xT.o", ROOT + "/build_tmp/rT.o", ROOT + "/build_tmp/oT.o"])
     if len(sys.argv) == 1:
         sys.exit(0)
 os.environ["SLIDE_HIP_LIB"] = LIBT

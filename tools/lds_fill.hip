@@ -1,0 +1,205 @@
+// L2 -> LDS fill-rate micro-benchmark (authoring tool, not part of the library).
+// Every workgroup (4 waves) streams the 32-deep K chunks of a 256-row fp16 X tile + a 64-row W tile (20 KB per chunk, the
+// GEMM ring's stage image) into a two-stage LDS ring, three workgroups per CU, eight workgroups sharing each X tile like
+// the column tiles of a GEMM.  Variants: A = global_load_lds_dwordx4 (LDS-DMA, what the ring kernels use),
+// B = global_load_dwordx4 into VGPRs + ds_write_b128, C = 3 of 5 pieces by DMA and 2 through registers, D = 2 DMA + 3 reg.
+// build: hipcc --offload-arch=gfx950 -O3 tools/lds_fill.hip -o /tmp/lds_fill
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+typedef unsigned short u16;
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+struct alignas(16) v16 { unsigned int x, y, z, w; };
+
+template <int NDMA>
+__global__ __launch_bounds__(256) void fill(const u16 *__restrict__ X, const u16 *__restrict__ W, int ld, int nchunk, int reps,
+                                            unsigned int *sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // XCD-aware map (workgroup b runs on XCD b % 8): the eight column tiles of a row tile share one XCD's L2
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, ct = q & 7, rt = (q >> 3) * 8 + xcd;
+  // piece j of wave wv: rows (j * 4 + wv) * 16 + lane / 4, 16 bytes at column (lane & 3) * 8 of the chunk
+  const u16 *gp[5];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) gp[j] = X + ((size_t)rt * 256 + (j * 4 + wv) * 16 + (lane >> 2)) * ld + (lane & 3) * 8;
+  gp[4] = W + ((size_t)ct * 64 + wv * 16 + (lane >> 2)) * ld + (lane & 3) * 8;
+  constexpr int STAGE = 20 * 1024;
+  unsigned int acc = 0;
+  v16 r[5];
+  for (int rep = 0; rep < reps; ++rep) {
+    for (int kc = 0; kc < nchunk; ++kc) {
+      const int st = kc & 1;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        if (j < NDMA)
+          __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(gp[j] + kc * 32),
+                                           (LDS_AS void *)(smem + st * STAGE + (j * 4 + wv) * 1024), 16, 0, 0);
+        else
+          r[j] = *reinterpret_cast<const v16 *>(gp[j] + kc * 32);
+      }
+#pragma unroll
+      for (int j = NDMA; j < 5; ++j)
+        *reinterpret_cast<v16 *>(smem + st * STAGE + (j * 4 + wv) * 1024 + lane * 16) = r[j];
+      __builtin_amdgcn_s_waitcnt(0);  // everything of this chunk landed (the ring kernels keep one chunk in flight instead)
+      __syncthreads();
+      if ((kc & 15) == 15) acc += *reinterpret_cast<const unsigned int *>(smem + st * STAGE + threadIdx.x * 16);
+    }
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+
+// pipelined form: the loads of chunk k + 1 are in flight while chunk k is awaited (counted vmcnt), like the ring kernels
+template <int NDMA>
+__global__ __launch_bounds__(256) void fill_pipe(const u16 *__restrict__ X, const u16 *__restrict__ W, int ld, int nchunk,
+                                                 int reps, unsigned int *sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // XCD-aware map (workgroup b runs on XCD b % 8): the eight column tiles of a row tile share one XCD's L2
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, ct = q & 7, rt = (q >> 3) * 8 + xcd;
+  const u16 *gp[5];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) gp[j] = X + ((size_t)rt * 256 + (j * 4 + wv) * 16 + (lane >> 2)) * ld + (lane & 3) * 8;
+  gp[4] = W + ((size_t)ct * 64 + wv * 16 + (lane >> 2)) * ld + (lane & 3) * 8;
+  constexpr int STAGE = 20 * 1024;
+  unsigned int acc = 0;
+  v16 r[5];
+  auto issue = [&](int kc) {
+    const int st = kc & 1;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      if (j < NDMA)
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(gp[j] + kc * 32),
+                                         (LDS_AS void *)(smem + st * STAGE + (j * 4 + wv) * 1024), 16, 0, 0);
+      else
+        r[j] = *reinterpret_cast<const v16 *>(gp[j] + kc * 32);
+    }
+  };
+  for (int rep = 0; rep < reps; ++rep) {
+    issue(0);
+    for (int kc = 0; kc < nchunk; ++kc) {
+      const int st = kc & 1;
+      // register pieces of chunk kc: wait for them, park them in LDS, then put chunk kc + 1 in flight
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+#pragma unroll
+      for (int j = NDMA; j < 5; ++j)
+        *reinterpret_cast<v16 *>(smem + st * STAGE + (j * 4 + wv) * 1024 + lane * 16) = r[j];
+      __syncthreads();
+      if (kc + 1 < nchunk) issue(kc + 1);
+      if ((kc & 15) == 15) acc += *reinterpret_cast<const unsigned int *>(smem + st * STAGE + threadIdx.x * 16);
+    }
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+
+// one-stage blocking fill with RB bytes per row and chunk (64 = half a 128-byte line, 128 = whole lines, 256 = two lines):
+// does the cap move with the footprint of a request?
+template <int RB>
+__global__ __launch_bounds__(256) void fill_rb(const u16 *__restrict__ X, const u16 *__restrict__ W, int ld, int nchunk, int reps,
+                                               unsigned int *sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, ct = q & 7, rt = (q >> 3) * 8 + xcd;
+  constexpr int NROW = RB <= 128 ? 320 : 160;  // stage <= 40 KB
+  constexpr int NX = NROW * 4 / 5;
+  constexpr int LPR = RB / 16, RPI = 64 / LPR, NI = NROW / RPI / 4;  // lanes per row, rows per wave instruction, instructions per wave
+  unsigned int acc = 0;
+  for (int rep = 0; rep < reps; ++rep)
+    for (int kc = 0; kc < nchunk * 64 / RB * (320 / NROW); ++kc) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int row = (j * 4 + wv) * RPI + lane / LPR;  // 0..319: rows >= 256 are the W tile
+        const u16 *src = (row < NX ? X + ((size_t)rt * 256 + row) * ld : W + ((size_t)ct * 64 + row - NX) * ld) + (lane % LPR) * 8 +
+                         (kc % (512 * 2 / RB)) * (RB / 2);
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)src, (LDS_AS void *)(smem + (j * 4 + wv) * 1024), 16, 0, 0);
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      if ((kc & 7) == 7) acc += *reinterpret_cast<const unsigned int *>(smem + threadIdx.x * 16);
+    }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+
+// chunk-major X: [K / 32][rows][32] fp16 -- the 16 rows x 64 B of one wave instruction are 1 KB of consecutive memory;
+// same 20 KB stage image and 32-deep chunks as the ring kernels
+__global__ __launch_bounds__(256) void fill_cm(const u16 *__restrict__ X, const u16 *__restrict__ W, int rows_total, int wrows,
+                                               int nchunk, int reps, unsigned int *sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, ct = q & 7, rt = (q >> 3) * 8 + xcd;
+  const u16 *gp[5];
+  size_t cs[5];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    gp[j] = X + ((size_t)rt * 256 + (j * 4 + wv) * 16 + (lane >> 2)) * 32 + (lane & 3) * 8;
+    cs[j] = (size_t)rows_total * 32;
+  }
+  gp[4] = W + ((size_t)ct * 64 + wv * 16 + (lane >> 2)) * 32 + (lane & 3) * 8;
+  cs[4] = (size_t)wrows * 32;
+  unsigned int acc = 0;
+  for (int rep = 0; rep < reps; ++rep)
+    for (int kc = 0; kc < nchunk; ++kc) {
+      const int st = kc & 1;
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(gp[j] + kc * cs[j]),
+                                         (LDS_AS void *)(smem + st * 20480 + (j * 4 + wv) * 1024), 16, 0, 0);
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      if ((kc & 15) == 15) acc += *reinterpret_cast<const unsigned int *>(smem + st * 20480 + threadIdx.x * 16);
+    }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+template <typename F>
+void run(const char *name, F kern, int wgs, const u16 *X, const u16 *W, int ld, int nchunk, int reps, unsigned int *sink) {
+  CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 41 * 1024, 0, X, W, ld, nchunk, 1, sink);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 41 * 1024, 0, X, W, ld, nchunk, reps, sink);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  const double bytes = (double)wgs * nchunk * reps * 20480.0;
+  printf("%-28s %4d WGs: %.1f us, %.2f TB/s into LDS, %.1f KB/us/CU, %.1f B/clk/CU (2.4 GHz)\n", name, wgs, ms * 1e3,
+         bytes / ms / 1e9, bytes / (ms * 1e3) / 256 / 1024, bytes / (ms * 1e-3) / 256 / 2.4e9);
+}
+
+int main() {
+  const int ld = 544, nchunk = 16, reps = 40, ntr = 96;
+  u16 *X, *W; unsigned int *sink;
+  CK(hipMalloc(&X, (size_t)ntr * 256 * ld * 2)); CK(hipMalloc(&W, (size_t)8 * 64 * ld * 2)); CK(hipMalloc(&sink, 64));
+  CK(hipMemset(X, 0, (size_t)ntr * 256 * ld * 2)); CK(hipMemset(W, 0, (size_t)8 * 64 * ld * 2));
+  for (int wgs : {768, 512, 256}) {
+    run("A  5 DMA (blocking)", fill<5>, wgs, X, W, ld, nchunk, reps, sink);
+    run("B  5 reg (blocking)", fill<0>, wgs, X, W, ld, nchunk, reps, sink);
+    run("A' 5 DMA (pipelined)", fill_pipe<5>, wgs, X, W, ld, nchunk, reps, sink);
+    run("B' 5 reg (pipelined)", fill_pipe<0>, wgs, X, W, ld, nchunk, reps, sink);
+    run("C' 3 DMA + 2 reg", fill_pipe<3>, wgs, X, W, ld, nchunk, reps, sink);
+    run("D' 2 DMA + 3 reg", fill_pipe<2>, wgs, X, W, ld, nchunk, reps, sink);
+    run("E' 4 DMA + 1 reg", fill_pipe<4>, wgs, X, W, ld, nchunk, reps, sink);
+    {
+      auto k = fill_cm;
+      CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024));
+      hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      hipLaunchKernelGGL(k, dim3(wgs), dim3(256), 41 * 1024, 0, X, W, ntr * 256, 8 * 64, nchunk, 1, sink);
+      CK(hipDeviceSynchronize()); CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(k, dim3(wgs), dim3(256), 41 * 1024, 0, X, W, ntr * 256, 8 * 64, nchunk, reps, sink);
+      CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      const double bytes = (double)wgs * nchunk * reps * 20480.0;
+      printf("%-28s %4d WGs: %.1f us, %.2f TB/s into LDS, %.1f KB/us/CU, %.1f B/clk/CU (2.4 GHz)\n", "CM chunk-major [K/32][rows][32]", wgs,
+             ms * 1e3, bytes / ms / 1e9, bytes / (ms * 1e3) / 256 / 1024, bytes / (ms * 1e-3) / 256 / 2.4e9);
+    }
+    run("R64  one stage, 64 B/row", fill_rb<64>, wgs, X, W, ld, nchunk, reps, sink);
+    run("R128 one stage, 128 B/row", fill_rb<128>, wgs, X, W, ld, nchunk, reps, sink);
+    run("R256 one stage, 256 B/row", fill_rb<256>, wgs, X, W, ld, nchunk, reps, sink);
+  }
+  return 0;
+}
