@@ -245,6 +245,9 @@ __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem
   const size_t x_cs = (BKT == 32 && a.x_ld == 32) ? (size_t)a.rows * 32 : BKT;
   const size_t w_cs = (BKT == 32 && a.w_cm) ? (size_t)a.n_cob * 32 * 32 : BKT;
   const int w_ld = (BKT == 32 && a.w_cm) ? 32 : a.k_pad;
+  // gathered point-feature table: chunk-major [k / 32][samples * 16][32] when g_ldf == 32 -- the sixteen 64-byte pieces an
+  // instruction gathers (the neighbours of one point) then lie inside ONE KB instead of sixteen rows
+  const size_t g_cs = (GAT && BKT == 32 && a.g_ldf == 32) ? (size_t)(a.rows >> NPXL) * 16 * 32 : BKT;
   const T *gp[LPW];
   const T *ga[GAT ? LPW : 1];
 #pragma unroll
@@ -271,7 +274,7 @@ __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem
   auto issue = [&](int kc, int st) {
 #pragma unroll
     for (int j = 0; j < LPW; ++j) {
-      const T *src = (j < NXI) ? ((GAT && kc < a.g_nsplit) ? ga[GAT ? j : 0] + (size_t)kc * BKT : gp[j] + (size_t)kc * x_cs)
+      const T *src = (j < NXI) ? ((GAT && kc < a.g_nsplit) ? ga[GAT ? j : 0] + (size_t)kc * g_cs : gp[j] + (size_t)kc * x_cs)
                                : gp[j] + (size_t)kc * w_cs;
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)src,
                                        (__attribute__((address_space(3))) void *)(smem_raw + (size_t)st * STAGE_B +
@@ -662,6 +665,7 @@ struct AttnTailArgs {
   const void *X1, *W1, *X2, *W2;  // scores: u [rows][x1_ld] . W5 [C][k1];  values: mo [rows][x2_ld] . Wv [C][k2]
   const float *vec;               // [bias_s | bias_v | gamma | beta], n_cob * 32 floats each
   void *out;                      // [rows >> (NPXL - 4)][out_ld] fp16
+  void *out_cm;                   // optional second copy, chunk-major [c / 32][rows >> (NPXL - 4)][32]
   int rows, x1_ld, k1, x2_ld, k2, n_cob, gs, n_norm, out_ld;
   int w_cm;                       // both weight matrices are chunk-major [k / 32][n_cob * 32][32] (u / mo are when their ld is 32)
   float inv_count;
@@ -842,8 +846,13 @@ __global__ __launch_bounds__(256, 2) void attn_tail_kernel(AttnTailArgs a) {
         den += other_half(den);
         num += other_half(num);
         const int rbase = row0 + wave * 64 + rb * 32 + pg * KN;
-        if (half == 0 && rbase < a.rows && cob0 + cb < a.n_cob)
-          reinterpret_cast<T *>(a.out)[(size_t)(rbase >> KLOG) * a.out_ld + (cob0 + cb) * 32 + col] = (T)(num / den);
+        if (half == 0 && rbase < a.rows && cob0 + cb < a.n_cob) {
+          const T v = (T)(num / den);
+          reinterpret_cast<T *>(a.out)[(size_t)(rbase >> KLOG) * a.out_ld + (cob0 + cb) * 32 + col] = v;
+          // chunk-major copy of the per-point table for the next block's gather-on-load GEMM
+          if (a.out_cm)
+            reinterpret_cast<T *>(a.out_cm)[((size_t)(cob0 + cb) * (a.rows >> KLOG) + (rbase >> KLOG)) * 32 + col] = v;
+        }
       }
   }
 }
@@ -862,7 +871,8 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
 template <typename T>
 __global__ __launch_bounds__(256) void prep_points_kernel(int cx, int ldf, const float *__restrict__ x,
                                                           float *__restrict__ xyz, T *__restrict__ feat0,
-                                                          int *__restrict__ kidx, float *__restrict__ kd2) {
+                                                          int *__restrict__ kidx, float *__restrict__ kd2,
+                                                          T *__restrict__ feat0_cm) {
   __shared__ float sp[48];
   __shared__ float sd[16][17];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -875,7 +885,10 @@ __global__ __launch_bounds__(256) void prep_points_kernel(int cx, int ldf, const
   const int nf = cx - 3;
   for (int e = tid; e < 16 * cx; e += 256) {
     const int p = e / cx, c = e % cx;
-    feat0[((size_t)b * 16 + p) * ldf + c] = (T)(c < nf ? xb[p * cx + 3 + c] : xb[p * cx + (c - nf)]);
+    const T v = (T)(c < nf ? xb[p * cx + 3 + c] : xb[p * cx + (c - nf)]);
+    feat0[((size_t)b * 16 + p) * ldf + c] = v;
+    // second, chunk-major copy [c / 32][samples * 16][32] for the gather-on-load GEMM of the first SA block
+    if (feat0_cm) feat0_cm[((size_t)(c >> 5) * gridDim.x * 16 + (size_t)b * 16 + p) * 32 + (c & 31)] = v;
   }
   __syncthreads();
   const int i = tid >> 4, j = tid & 15;
@@ -1482,6 +1495,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(int R, int C, int in_ld,
 int run_attn_tail(const SlideOp &o, hipStream_t s) {
   AttnTailArgs a;
   a.X1 = o.p[0]; a.W1 = o.p[1]; a.X2 = o.p[2]; a.W2 = o.p[3]; a.out = o.p[4]; a.vec = (const float *)o.p[5];
+  a.out_cm = o.p[6];
   a.rows = o.i[0]; a.x1_ld = o.i[1]; a.k1 = o.i[2]; a.x2_ld = o.i[3]; a.k2 = o.i[4]; a.n_cob = o.i[5];
   a.gs = o.i[7]; a.n_norm = o.i[8]; a.out_ld = o.i[9];
   a.inv_count = o.f[0];
@@ -1511,10 +1525,12 @@ int run_op(const SlideOp &o, hipStream_t s) {
     case SLIDE_OP_PREP_POINTS:
       if (o.i[3] == SLIDE_PREC_F16)
         hipLaunchKernelGGL(prep_points_kernel<_Float16>, dim3(o.i[0]), dim3(256), 0, s, o.i[1], o.i[2],
-                           (const float *)o.p[0], (float *)o.p[1], (_Float16 *)o.p[2], (int *)o.p[3], (float *)o.p[4]);
+                           (const float *)o.p[0], (float *)o.p[1], (_Float16 *)o.p[2], (int *)o.p[3], (float *)o.p[4],
+                           (_Float16 *)o.p[5]);
       else
         hipLaunchKernelGGL(prep_points_kernel<float>, dim3(o.i[0]), dim3(256), 0, s, o.i[1], o.i[2],
-                           (const float *)o.p[0], (float *)o.p[1], (float *)o.p[2], (int *)o.p[3], (float *)o.p[4]);
+                           (const float *)o.p[0], (float *)o.p[1], (float *)o.p[2], (int *)o.p[3], (float *)o.p[4],
+                           (float *)o.p[5]);
       break;
     case SLIDE_OP_ASSEMBLE_SA:
     case SLIDE_OP_ASSEMBLE_FP: {

@@ -138,6 +138,7 @@ class DenoiserEngine:
         self.use_cm = (self.prec == 1 and self.use_glds and self.glds_nst != 1 and _os.environ.get("SLIDE_CM", "1") != "0"
                        and not _os.environ.get("SLIDE_XS", ""))
         self._cm = set()
+        self._cm_copy = {}  # per-point table (data_ptr) -> its chunk-major copy, written by the table's producer as well
         self.ops = []
         self._lane = 0
         self.two_lanes = _os.environ.get("SLIDE_TWO_LANES", "0") != "0"  # measured: no gain at batch 256
@@ -333,7 +334,10 @@ class DenoiserEngine:
             if xs_mode != "auto" or gather is not None or (npx_log2 == 8 and sc is None and n_cob >= 16 and xs_lds > 96 * 1024):
                 wfrag = Wd  # (selects the kernel; it reads the same row-major weights)
                 cbw = 4 if n_cob >= 4 and os.environ.get("SLIDE_XS_CBW", "2") == "4" else 2
-        gf = (0.0, 0.0, 0.0) if gather is None else (float(gather[3]), float(gather[0].shape[1]), float({8: 3, 16: 4}[gather[2]]))
+        gtab = None if gather is None else self._cm_copy.get(gather[0].data_ptr(), gather[0])  # chunk-major copy: g_ldf == 32
+        assert wfrag is None or gtab is None or gtab is gather[0]
+        gf = (0.0, 0.0, 0.0) if gather is None else (float(gather[3]), float(32 if gtab is not gather[0] else gather[0].shape[1]),
+                                                     float({8: 3, 16: 4}[gather[2]]))
         knob = self.glds_nst
         assert wfrag is None or not (w_cm or self._is_cm(X))
         if wfrag is not None and os.environ.get("SLIDE_XS_OCC"):
@@ -345,7 +349,7 @@ class DenoiserEngine:
                                    None if sh is None else sh.data_ptr() + 4 * aff_off, None,
                                    None if gn_fin is None else gn_fin.data_ptr(),
                                    self._sched().data_ptr() if self.persistent else None,
-                                   None if gather is None else gather[0].data_ptr(),
+                                   None if gather is None else gtab.data_ptr(),
                                    (None if pre_gather is None else pre_gather.data_ptr()) if gather is None
                                    else gather[1].data_ptr(),
                                    None if wfrag is None else wfrag.data_ptr())))
@@ -535,11 +539,14 @@ class DenoiserEngine:
                 self._sync(1, 0)
                 self.flops += 2 * rows * (w5.size + wv.size)
                 self.gemm_flops[len(self.ops)] = 2 * rows * cout * (len(lay[0]) + wv_l.shape[1])  # logical channels
+                out_cm = None
+                if self.use_cm and os.environ.get("SLIDE_CM_TABLES", "0") != "0" and npx_log2 == 8:  # (SA outputs feed gathers)
+                    out_cm = self._cm_copy[out.data_ptr()] = self.A.zeros(out.shape[0], out.shape[1], dtype=self.adt)
                 self._emit(make_op(OP_ATTN_TAIL, i=(rows, self._ldp(u), u.shape[1], self._ldp(mo), mo.shape[1], Cp // 32, npx_log2,
                                                     vlay[3], vlay[2], out.shape[1]),
                                         f=(1.0 / (vlay[4] * npx), 1.0 if self.use_cm else 0.0),
                                         p=(u.data_ptr(), d[0].data_ptr(), mo.data_ptr(), d[1].data_ptr(), out.data_ptr(),
-                                           d[2].data_ptr())))
+                                           d[2].data_ptr(), None if out_cm is None else out_cm.data_ptr())))
                 return
             # lane 0 (value branch), then the join
             V = self._buf(rows, cout)
@@ -665,9 +672,14 @@ class DenoiserEngine:
         if self.per_sample_t:
             temb_slot = len(self.ops)
             self.ops.append(None)  # TEMB placeholder (needs the .fc order of the walk)
+        # (opt-in, SLIDE_CM_TABLES=1: chunk-major second copies of the per-point tables the first layers gather from, written
+        # by prep_points / the attention tails -- measured neutral, 298-301 shapes/s either way: the gathers hit the vector cache)
+        feat0_cm = None
+        if self.use_cm and os.environ.get("SLIDE_CM_TABLES", "0") != "0":
+            feat0_cm = self._cm_copy[self.feat0.data_ptr()] = self._buf(B * 16, C0)
         self._emit(make_op(OP_PREP_POINTS, i=(B, self.cx, self.feat0.shape[1], self.prec),
                                 p=(self.x.data_ptr(), self.xyz.data_ptr(), self.feat0.data_ptr(), self.kidx.data_ptr(),
-                                   self.kd2.data_ptr())))
+                                   self.kd2.data_ptr(), None if feat0_cm is None else feat0_cm.data_ptr())))
         feats, chans = [self.feat0], [C0]
         for i in range(len(arch["npoint"])):
             o, c = self._sa_module(i, feats[i], chans[i])

@@ -417,7 +417,7 @@ def test_chunk_major_layout_bit_identical(gpu_device, monkeypatch):
     for name in ("pos", "feat"):
         g, hp, sd = _load(name)
         x, ts, lab = g["x_mixed"], g["ts_mixed"], g["label_mixed"]
-        for knobs in ({}, {"SLIDE_GATHER": "0"}, {"SLIDE_ATTN_TAIL": "0"}, {"SLIDE_SPLIT_FIRST": "32"}):
+        for knobs in ({}, {"SLIDE_CM_TABLES": "1"}, {"SLIDE_GATHER": "0"}, {"SLIDE_ATTN_TAIL": "0"}, {"SLIDE_SPLIT_FIRST": "32"}):
             for k_, v_ in knobs.items():
                 monkeypatch.setenv(k_, v_)
             monkeypatch.setenv("SLIDE_CM", "0")
