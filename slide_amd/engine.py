@@ -105,6 +105,10 @@ class _Arena:
 
 class DenoiserEngine:
     NP = 16  # latent points per sample
+    # chunk-major storage (see _buf): off unless __init__ enables it (bare plan builders in tests / tools stay row-major)
+    use_cm = False
+    _cm = frozenset()
+    _cm_copy = {}
 
     def __init__(self, hp, state_dict, batch, device, prec="fp32", per_sample_t=True, t_table=0):
         """per_sample_t=True : `forward(x, ts, label)` API, the t-embedding MLP runs every call (one workgroup / sample).
@@ -396,7 +400,22 @@ class DenoiserEngine:
             seg["out_coff"] = final_coff
             self._gemm(h1, npx_log2, [seg])
 
-    def _attention(self, apfx, npx_log2, K, g, q_in, mo, mlp_first, mlp_res, out, out_ld_buf, gather=None):
+    def _attention_query(self, apfx, K):
+        """buffers + GEMM segment of an attention block's per-point query branch (feat_conv): it depends on the block's input
+        table only, so the query GEMMs of two blocks that read the same table (an SA block and the FP block that takes the
+        same features as its skip input) are issued as ONE launch by whichever block comes first"""
+        sd, B = self.sd, self.B
+        C1 = sd[apfx + ".feat_conv.weight"].shape[0]
+        C2 = sd[apfx + ".grouped_feat_conv.weight"].shape[0]
+        ldT = ru(C1) + ru(C2)
+        Tq = self.A.zeros(B * 16, ru(C1), dtype=self.adt)
+        ssum, ssq = self.A.zeros(B, ldT), self.A.zeros(B, ldT)
+        qseg = dict(w=self._w(apfx + ".feat_conv.weight"), bias=sd[apfx + ".feat_conv.bias"], mode=EPI_STATS,
+                    flags=F_PRE_RELU, out=Tq, stats=(ssum, ssq, 0, float(K)))
+        return dict(Tq=Tq, ssum=ssum, ssq=ssq, qseg=qseg)
+
+    def _attention(self, apfx, npx_log2, K, g, q_in, mo, mlp_first, mlp_res, out, out_ld_buf, gather=None, qctx=None,
+                   extra_q=()):
         """AttentionModule (attention.py:35-96).  g: grouped input [B*npx][ldg]; q_in: query features [B*16][ld];
         mo: the Mlp output buffer (values input), produced by the caller AFTER the shared first GEMM.
 
@@ -415,18 +434,19 @@ class DenoiserEngine:
         cout = sd[apfx + ".weight_conv.5.weight"].shape[0]
         C1p, C2p = ru(C1), ru(C2)
         ldT = C1p + C2p                      # physical channel space of the (virtual) concatenation
-        Tq = self.A.zeros(B * 16, C1p, dtype=self.adt)
+        issued = qctx is not None  # the query GEMM rode on an earlier block's launch (same input table)
+        if qctx is None:
+            qctx = self._attention_query(apfx, K)
+        Tq, ssum, ssq = qctx["Tq"], qctx["ssum"], qctx["ssq"]
         Tk = self._buf(rows, C2p, cm=True)
-        ssum, ssq = self.A.zeros(B, ldT), self.A.zeros(B, ldT)
         kseg = dict(w=self._w(apfx + ".grouped_feat_conv.weight"), bias=sd[apfx + ".grouped_feat_conv.bias"],
                     mode=EPI_STATS, flags=F_PRE_RELU, out=Tk, stats=(ssum, ssq, C1p, 1.0))
         # lane 1 (query / score branch) forks here: it only needs the module inputs
         self._sync(0, 1)
-        self._lane = 1
-        qseg = dict(w=self._w(apfx + ".feat_conv.weight"), bias=sd[apfx + ".feat_conv.bias"], mode=EPI_STATS,
-                    flags=F_PRE_RELU, out=Tq, stats=(ssum, ssq, 0, float(K)))
-        self._gemm(q_in, 4, [qseg])
-        self._lane = 0
+        if not issued:
+            self._lane = 1
+            self._gemm(q_in, 4, [qctx["qseg"]] + [e["qseg"] for e in extra_q])
+            self._lane = 0
         # shared-input GEMM: [first_mlp | res_connect | grouped_feat_conv]
         if gather is not None and gather[3] * 32 >= int(os.environ.get("SLIDE_SPLIT_FIRST", "1000000")):
             # (opt-in, SLIDE_SPLIT_FIRST=<min feature channels>: measured neutral to -1.5 % on the feature plan -- the
@@ -580,7 +600,7 @@ class DenoiserEngine:
         self._emit(make_op(kind, i=(B, C, feat_in.shape[1], ldg, K, self.prec, c_begin, ldg - c_begin), p=ptrs + (g.data_ptr(),)))
         return g, ((feat_in, self.kidx, K, nsplit) if nsplit else None), rows
 
-    def _sa_module(self, i, feat_in, C):
+    def _sa_module(self, i, feat_in, C, extra_q=()):
         sd, B = self.sd, self.B
         pfx = "SA_modules.%d" % i
         mp, ap = pfx + ".mlps.0", pfx + ".attention_modules.0"
@@ -594,13 +614,13 @@ class DenoiserEngine:
         h1, r, mo = self._buf(rows, c1, cm=True), self._buf(rows, c_last, cm=True), self._buf(rows, c_last, cm=True)
         first, res = self._mlp_segments(mp, self.tvec, self.cvec, h1, r)
         out = self._buf(B * 16, c_last)
-        (scores, finish), cout = self._attention(ap, 8, K, g, feat_in, mo, first, res, out, None, gather=gather)
+        (scores, finish), cout = self._attention(ap, 8, K, g, feat_in, mo, first, res, out, None, gather=gather, extra_q=extra_q)
         S = scores()                                  # lane 1: finalize, P, weight_conv.2, weight_conv.5
         self._mlp_tail(mp, 8, h1, self.cvec, r, mo)   # lane 0: second / rest mlp
         finish(S)                                     # lane 0: values; join; softmax-combine
         return out, cout
 
-    def _fp_module(self, j, U, CU, Kf, C2, out_buf=None):
+    def _fp_module(self, j, U, CU, Kf, C2, out_buf=None, qctx=None):
         """PointnetKnnFPModule.forward (pointnet2_modules.py:771-873).  U: unknown (skip) features, Kf: known features."""
         sd, B = self.sd, self.B
         pfx = "FP_modules.%d" % j
@@ -618,7 +638,7 @@ class DenoiserEngine:
         zin = c_last + CU + 3
         assert sd[m2 + ".first_mlp.0.weight"].shape[1] == zin
         Z = self._buf(B * 16, zin)
-        (scores, finish), cout = self._attention(ap, 7, K, g, U, mo, first, res, Z, None, gather=gather)
+        (scores, finish), cout = self._attention(ap, 7, K, g, U, mo, first, res, Z, None, gather=gather, qctx=qctx)
         S = scores()
         # skip features and coordinates: columns of Z the attention output does not touch -- on the score lane, beside
         # the value branch (joined by finish)
@@ -681,10 +701,18 @@ class DenoiserEngine:
                                 p=(self.x.data_ptr(), self.xyz.data_ptr(), self.feat0.data_ptr(), self.kidx.data_ptr(),
                                    self.kd2.data_ptr(), None if feat0_cm is None else feat0_cm.data_ptr())))
         feats, chans = [self.feat0], [C0]
-        for i in range(len(arch["npoint"])):
-            o, c = self._sa_module(i, feats[i], chans[i])
+        nsa, nfp = len(arch["npoint"]), len(arch["decoder_feature_dim"]) - 1
+        # FP block j takes feats[nsa + j - nfp] as its skip / query input -- the table SA block nsa + j - nfp reads as well:
+        # its query GEMM rides on that SA block's (SLIDE_MERGE_Q=0: one launch each)
+        fp_q = {}
+        for i in range(nsa):
+            j = i + nfp - nsa
+            extra = ()
+            if 0 <= j < nfp and os.environ.get("SLIDE_MERGE_Q", "1") != "0":
+                fp_q[j] = self._attention_query("FP_modules.%d.attention_module" % j, 8)
+                extra = (fp_q[j],)
+            o, c = self._sa_module(i, feats[i], chans[i], extra_q=extra)
             feats.append(o); chans.append(c)
-        nfp = len(arch["decoder_feature_dim"]) - 1
         dec0 = None
         for i in range(-1, -(nfp + 1), -1):
             j = nfp + i
@@ -693,7 +721,7 @@ class DenoiserEngine:
                 n2 = sd["FP_modules.0.mlp2.res_connect.weight"].shape[0]
                 dec0 = self._buf(B * 16, n2 + 3)
                 out_buf = dec0
-            o, c = self._fp_module(j, feats[i - 1], chans[i - 1], feats[i], chans[i], out_buf)
+            o, c = self._fp_module(j, feats[i - 1], chans[i - 1], feats[i], chans[i], out_buf, qctx=fp_q.get(j))
             feats[i - 1], chans[i - 1] = o, c
         # output head fc_lyaer (pointnet2_with_pcld_condition.py:480-483): conv -> GN(32,128) -> ReLU -> conv
         c = chans[0]

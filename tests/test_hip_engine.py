@@ -417,11 +417,14 @@ def test_chunk_major_layout_bit_identical(gpu_device, monkeypatch):
     for name in ("pos", "feat"):
         g, hp, sd = _load(name)
         x, ts, lab = g["x_mixed"], g["ts_mixed"], g["label_mixed"]
-        for knobs in ({}, {"SLIDE_CM_TABLES": "1"}, {"SLIDE_GATHER": "0"}, {"SLIDE_ATTN_TAIL": "0"}, {"SLIDE_SPLIT_FIRST": "32"}):
+        for knobs in ({}, {"SLIDE_CM_TABLES": "1"}, {"SLIDE_GATHER": "0"}, {"SLIDE_ATTN_TAIL": "0"}, {"SLIDE_SPLIT_FIRST": "32"},
+                      {"SLIDE_MERGE_Q": "0"}):
             for k_, v_ in knobs.items():
                 monkeypatch.setenv(k_, v_)
             monkeypatch.setenv("SLIDE_CM", "0")
+            monkeypatch.setenv("SLIDE_MERGE_Q", "0")  # (the reference plan is also the one-launch-per-query-GEMM plan)
             e0 = DenoiserEngine(hp, sd, x.shape[0], gpu_device, prec="fp16")
+            monkeypatch.setenv("SLIDE_MERGE_Q", knobs.get("SLIDE_MERGE_Q", "1"))
             assert not e0._cm and not any(o.kind == 1 and (o.i[8] & 2) for o in e0.ops)
             ref = e0.forward(x, ts, lab).cpu().numpy()
             monkeypatch.setenv("SLIDE_CM", "1")

@@ -57,25 +57,45 @@ CASES = [  # rows_per_sample log2, batch, K, N, mode, extras
 ]
 
 
+def _to_cm(a):
+    """[rows][ld] -> the chunk-major image [ld / 32][rows][32], returned with the logical shape"""
+    rows, ld = a.shape
+    return np.ascontiguousarray(a.reshape(rows, ld // 32, 32).transpose(1, 0, 2)).reshape(rows, ld)
+
+
+def _from_cm(a):
+    rows, ld = a.shape
+    return np.ascontiguousarray(a.reshape(ld // 32, rows, 32).transpose(1, 0, 2)).reshape(rows, ld)
+
+
+@pytest.mark.parametrize("cm", [False, True])
 @pytest.mark.parametrize("npxl,B,K,N,mode,extras", CASES)
-def test_gemm_op_matches_numpy(gpu_device, npxl, B, K, N, mode, extras):
+def test_gemm_op_matches_numpy(gpu_device, npxl, B, K, N, mode, extras, cm):
+    """one GEMM launch with its fused epilogue vs numpy; cm: input, residual and output in chunk-major storage
+    ([k / 32][rows][32], the layout of the K-expanded activations of the fp16 plans) -- 128- / 256-row samples only"""
     import torch
     from slide_amd import engine as E
     from slide_amd._lib import check, lib
+    if cm and npxl < 7:
+        pytest.skip("16-row launches run the small-launch kernel on row-major operands")
     m = _Mini(B, "fp16", gpu_device)
+    if cm:
+        m.use_cm, m._cm = True, set()
     rs = np.random.RandomState(npxl * 1000 + K + N)
     npx = 1 << npxl
     rows = B * npx
     Xl = rs.standard_normal((rows, K)).astype(np.float32)
     ld = E.ru(K)
     Xp = np.zeros((rows, ld), np.float32); Xp[:, :K] = Xl
-    X = m.A.put(Xp, m.adt)
+    X = m.A.put(_to_cm(Xp) if cm else Xp, m.adt)
+    if cm:
+        m._cm.add(X.data_ptr())
     w = (rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
     bias = rs.standard_normal(N).astype(np.float32)
     gamma = (1 + 0.1 * rs.standard_normal(N)).astype(np.float32); beta = (0.1 * rs.standard_normal(N)).astype(np.float32)
     lay = E.gn_layout(N) if mode == E.EPI_NORM else None
     Np = E.ru(lay[1]) if lay else E.ru(N)
-    out = m._buf(rows, Np)
+    out = m._buf(rows, Np, cm=cm)
     seg = dict(w=w, bias=bias, mode=mode, out=out)
     relu = mode == E.EPI_NORM
     if mode == E.EPI_NORM:
@@ -86,8 +106,10 @@ def test_gemm_op_matches_numpy(gpu_device, npxl, B, K, N, mode, extras):
     if "res" in extras:
         resid = rs.standard_normal((rows, N)).astype(np.float32)
         rp = np.zeros((rows, Np), np.float32); rp[:, oidx] = resid
-        seg["residual"] = m.A.put(rp, m.adt)
-        resid = seg["residual"].float().cpu().numpy()[:, oidx]  # what the kernel reads (fp16-rounded)
+        seg["residual"] = m.A.put(_to_cm(rp) if cm else rp, m.adt)
+        if cm:
+            m._cm.add(seg["residual"].data_ptr())
+        resid = torch.from_numpy(rp).to(m.adt).float().numpy()[:, oidx]  # what the kernel reads (fp16-rounded)
     if "addvec" in extras:
         addvec = rs.standard_normal((B, N)).astype(np.float32)
         ap = np.zeros((B, Np), np.float32); ap[:, oidx] = addvec
@@ -96,8 +118,9 @@ def test_gemm_op_matches_numpy(gpu_device, npxl, B, K, N, mode, extras):
     ops = (E.SlideOp * 1)(*m.ops)
     check(lib().slide_run_ops(ops, 1, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "run")
     torch.cuda.synchronize()
-    got = out.float().cpu().numpy()[:, oidx]
-    Xr = X.float().cpu().numpy()[:, :K]
+    got = out.float().cpu().numpy()
+    got = (_from_cm(got) if cm else got)[:, oidx]
+    Xr = torch.from_numpy(Xp).to(m.adt).float().numpy()[:, :K]
     wr = torch.from_numpy(w).to(torch.float16).float().numpy()
     ref = _ref(Xr, wr, bias, npx, mode, lay, gamma, beta, relu, addvec, resid)
     assert np.isfinite(got).all()

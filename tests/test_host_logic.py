@@ -48,7 +48,7 @@ def test_plan_structure_and_flops():
         hp = cfg["pointnet_config"]
         sd = synth_state_dict(model_spec.denoiser_param_spec(hp))
         e = DenoiserEngine(hp, sd, 2, torch.device("cpu"), prec="fp32")
-        assert sum(1 for o in e.ops if o.kind == OP_GEMM) == 36
+        assert sum(1 for o in e.ops if o.kind == OP_GEMM) == 34  # (the two FP query GEMMs ride on the SA blocks that read the same table)
         saved = 0
         for pfx, K in (("SA_modules.0.attention_modules.0", 16), ("SA_modules.1.attention_modules.0", 16),
                        ("FP_modules.0.attention_module", 8), ("FP_modules.1.attention_module", 8)):
