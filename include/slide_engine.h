@@ -62,7 +62,7 @@ typedef struct SlideEpi {
 
 enum {
   SLIDE_OP_GEMM = 1,        /* p: X, W, epi, in_scale, in_shift, [5] timeline buffer (instrumented builds only, else NULL), [6] SlideGnFin* (16-row launches with input affine: finalise the statistics in this launch), [7] 9 zeroed ints for the optional persistent tile scheduler (NULL = one tile per workgroup), [8] point-feature table + [9] neighbour table of the GATHER mode (first GEMM of an SA / FP block: the first f[1] 32-column chunks of X row (b, p, k) are read from row b*16 + idx[(b*16+p)*16+k] of the table with row length f[2], neighbours per point 2^f[3]; p[0] / x_ld then describe only the remaining columns; with p[8] NULL, p[9] is the neighbour table of gathered pre_add terms, SlideEpi.pre_add_shift < 0); [10] non-NULL selects the X-stationary kernel for sample-wide fp16 layers whose 256-row X tile fits the LDS (one workgroup per row tile keeps X resident and computes every column tile, the weights stream through a small LDS-DMA ring; i[9] == 5 keeps the ring kernels); f[0]: start stagger in us for the persistent mode; i[9]: 0 = default ring, 1 = 64-deep chunks, 2 = eight-wave 256x256 tiles   i: rows, x_ld, k_pad, n_cob, npx_log2, in_bs, prec, cbw(2|4), lds_dma (bit 0: fp16 LDS-DMA ring kernels; bit 1: W is CHUNK-MAJOR [k_pad/32][n_cob*32][32] -- ring kernels of the 128- / 256-row samples only).  CHUNK-MAJOR X: with x_ld == 32 and k_pad > 32 the ring kernels read X as [k/32][rows][32] (chunk kc of row r at X + (kc*rows + r)*32); outputs / residuals use the same layout through SlideEpi's per-block pointer with out_ld / res_ld == 32 */
-  SLIDE_OP_PREP_POINTS = 2, /* p: x, xyz, feat0, knn_idx, knn_d2, [5] optional second copy of feat0, chunk-major [c/32][B*16][32]   i: B, cx, ldf, prec     (16 points / sample) */
+  SLIDE_OP_PREP_POINTS = 2, /* p: x, xyz, feat0, knn_idx, knn_d2, [5] optional second copy of feat0, chunk-major [c/32][B*16][32], [6] SlidePrepCopy[i[4]] (device)   i: B, cx, ldf, prec, n_copies     (16 points / sample) */
   SLIDE_OP_ASSEMBLE_SA = 3, /* p: xyz, feat, knn_idx, g            i: B, C, ldf, ldg, K, prec, c_begin (0 = all columns; else only columns >= c_begin), ld_out */
   SLIDE_OP_ASSEMBLE_FP = 4, /* p: xyz, feat, knn_idx, knn_d2, g    i: B, C, ldf, ldg, K, prec, c_begin, ld_out */
   SLIDE_OP_FINALIZE_GN = 5, /* p: sum, sq, gid, gstart, gend, gamma, beta, scale, shift  i: B, C, bs   f: inv_count */
@@ -75,7 +75,7 @@ enum {
   SLIDE_OP_ADVANCE_T = 12,  /* p: t_dev  (t_dev[0] -= 1; t_dev[1] += 1); t_dev = [t, step, blocks-done counter, chain nonce] */
   SLIDE_OP_SYNC = 14,       /* i: from_lane, to_lane -- lane `to` waits for everything issued so far on lane `from` */
   SLIDE_OP_GROUPNORM_NCHW = 13,/* p: x, gamma, beta, y (NCHW fp32)   i: B, C, HW, G, n_norm, relu  (module-level path) */
-  SLIDE_OP_ATTN_TAIL = 16,  /* fp16: scores GEMM + values GEMM (GroupNorm, ReLU) + softmax-weighted sum over the neighbours in one launch.  p: u, W5, mo, Wv, out, vec [bias_s | bias_v | gamma | beta][n_cob*32], [6] optional chunk-major copy of out [c/32][points][32] (a gather table of the next block: SLIDE_OP_GEMM f[2] == 32 reads p[8] that way)   i: rows, u_ld, k1, mo_ld, k2, n_cob, npx_log2, gs, n_norm, out_ld   f: 1 / (gs * rows per sample), [1] != 0: both weight matrices chunk-major [k/32][n_cob*32][32]; u / mo are chunk-major [k/32][rows][32] when their ld is 32 */
+  SLIDE_OP_ATTN_TAIL = 16,  /* fp16: scores GEMM + values GEMM (GroupNorm, ReLU) + softmax-weighted sum over the neighbours in one launch.  p: u, W5, mo, Wv, out, vec [bias_s | bias_v | gamma | beta][n_cob*32], [6] optional chunk-major copy of out [c/32][points][32] (a gather table of the next block: SLIDE_OP_GEMM f[2] == 32 reads p[8] that way), [7] optional copy of the first f[3] channels into another per-point buffer with leading dimension f[2]   i: rows, u_ld, k1, mo_ld, k2, n_cob, npx_log2, gs, n_norm, out_ld   f: 1 / (gs * rows per sample), [1] != 0: both weight matrices chunk-major [k/32][n_cob*32][32]; u / mo are chunk-major [k/32][rows][32] when their ld is 32 */
   SLIDE_OP_TRANSPOSE = 15,  /* p: in, out (fp32)   i: B, R, C, in_ld, out_ld, in_batch_stride, out_batch_stride, out_is_fp16: out[b][c][r] = in[b][r][c] (module-level path: NCHW <-> row-major) */
   /* Row-major module-level path (rows_ops.hip): an activation is [B * S][ld] (S rows per sample, ld = channels rounded up
    * to 32, pad columns zero), fp32 or -- i[9] = 1 -- fp16.  Replaces the reference's NCHW tensor program of
@@ -102,6 +102,14 @@ typedef struct SlideGnFin {
   float inv_count;
   int C, bs, G;                    /* channels, row stride of sum / sq / scale / shift, number of groups (<= 32) */
 } SlideGnFin;
+
+/* extra destinations of SLIDE_OP_PREP_POINTS (SlideOp.p[6], i[4] entries): the first n columns of every point's
+ * [features | xyz] row (kind 0) or its xyz (kind 1, n = 3) are also written to dst[(b*16 + p)*ld + c] (activation type) --
+ * columns of later concatenation buffers, saving their COPY launches */
+typedef struct SlidePrepCopy {
+  void *dst;
+  int32_t ld, kind, n, pad;
+} SlidePrepCopy;
 
 typedef struct SlideOp {
   int32_t kind;

@@ -666,6 +666,8 @@ struct AttnTailArgs {
   const float *vec;               // [bias_s | bias_v | gamma | beta], n_cob * 32 floats each
   void *out;                      // [rows >> (NPXL - 4)][out_ld] fp16
   void *out_cm;                   // optional second copy, chunk-major [c / 32][rows >> (NPXL - 4)][32]
+  void *out2;                     // optional copy of the first out2_n channels into another per-point buffer [..][out2_ld]
+  int out2_ld, out2_n;
   int rows, x1_ld, k1, x2_ld, k2, n_cob, gs, n_norm, out_ld;
   int w_cm;                       // both weight matrices are chunk-major [k / 32][n_cob * 32][32] (u / mo are when their ld is 32)
   float inv_count;
@@ -852,6 +854,9 @@ __global__ __launch_bounds__(256, 2) void attn_tail_kernel(AttnTailArgs a) {
           // chunk-major copy of the per-point table for the next block's gather-on-load GEMM
           if (a.out_cm)
             reinterpret_cast<T *>(a.out_cm)[((size_t)(cob0 + cb) * (a.rows >> KLOG) + (rbase >> KLOG)) * 32 + col] = v;
+          // second copy into the columns of a later concatenation buffer (the skip input of an FP block's second Mlp)
+          if (a.out2 && (cob0 + cb) * 32 + col < a.out2_n)
+            reinterpret_cast<T *>(a.out2)[(size_t)(rbase >> KLOG) * a.out2_ld + (cob0 + cb) * 32 + col] = v;
         }
       }
   }
@@ -872,7 +877,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void prep_points_kernel(int cx, int ldf, const float *__restrict__ x,
                                                           float *__restrict__ xyz, T *__restrict__ feat0,
                                                           int *__restrict__ kidx, float *__restrict__ kd2,
-                                                          T *__restrict__ feat0_cm) {
+                                                          T *__restrict__ feat0_cm, const SlidePrepCopy *__restrict__ copies,
+                                                          int n_copies) {
   __shared__ float sp[48];
   __shared__ float sd[16][17];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -889,6 +895,17 @@ __global__ __launch_bounds__(256) void prep_points_kernel(int cx, int ldf, const
     feat0[((size_t)b * 16 + p) * ldf + c] = v;
     // second, chunk-major copy [c / 32][samples * 16][32] for the gather-on-load GEMM of the first SA block
     if (feat0_cm) feat0_cm[((size_t)(c >> 5) * gridDim.x * 16 + (size_t)b * 16 + p) * 32 + (c & 31)] = v;
+  }
+  // columns of later concatenation buffers that hold nothing but this sample's features / coordinates (the skip input and
+  // the xyz columns of the FP blocks' second Mlp, the xyz columns of the head): written here instead of by COPY launches
+  for (int q = 0; q < n_copies; ++q) {
+    const SlidePrepCopy cp = copies[q];
+    T *dst = reinterpret_cast<T *>(cp.dst);
+    for (int e = tid; e < 16 * cp.n; e += 256) {
+      const int p = e / cp.n, c = e - p * cp.n;
+      const float v = cp.kind ? xb[p * cx + c] : (c < nf ? xb[p * cx + 3 + c] : xb[p * cx + (c - nf)]);
+      dst[((size_t)b * 16 + p) * cp.ld + c] = (T)v;
+    }
   }
   __syncthreads();
   const int i = tid >> 4, j = tid & 15;
@@ -1496,6 +1513,7 @@ int run_attn_tail(const SlideOp &o, hipStream_t s) {
   AttnTailArgs a;
   a.X1 = o.p[0]; a.W1 = o.p[1]; a.X2 = o.p[2]; a.W2 = o.p[3]; a.out = o.p[4]; a.vec = (const float *)o.p[5];
   a.out_cm = o.p[6];
+  a.out2 = o.p[7]; a.out2_ld = (int)o.f[2]; a.out2_n = (int)o.f[3];
   a.rows = o.i[0]; a.x1_ld = o.i[1]; a.k1 = o.i[2]; a.x2_ld = o.i[3]; a.k2 = o.i[4]; a.n_cob = o.i[5];
   a.gs = o.i[7]; a.n_norm = o.i[8]; a.out_ld = o.i[9];
   a.inv_count = o.f[0];
@@ -1526,11 +1544,11 @@ int run_op(const SlideOp &o, hipStream_t s) {
       if (o.i[3] == SLIDE_PREC_F16)
         hipLaunchKernelGGL(prep_points_kernel<_Float16>, dim3(o.i[0]), dim3(256), 0, s, o.i[1], o.i[2],
                            (const float *)o.p[0], (float *)o.p[1], (_Float16 *)o.p[2], (int *)o.p[3], (float *)o.p[4],
-                           (_Float16 *)o.p[5]);
+                           (_Float16 *)o.p[5], (const SlidePrepCopy *)o.p[6], o.i[4]);
       else
         hipLaunchKernelGGL(prep_points_kernel<float>, dim3(o.i[0]), dim3(256), 0, s, o.i[1], o.i[2],
                            (const float *)o.p[0], (float *)o.p[1], (float *)o.p[2], (int *)o.p[3], (float *)o.p[4],
-                           (float *)o.p[5]);
+                           (float *)o.p[5], (const SlidePrepCopy *)o.p[6], o.i[4]);
       break;
     case SLIDE_OP_ASSEMBLE_SA:
     case SLIDE_OP_ASSEMBLE_FP: {

@@ -103,6 +103,11 @@ class _Arena:
         return t
 
 
+class SlidePrepCopy(ctypes.Structure):
+    _fields_ = [("dst", ctypes.c_void_p), ("ld", ctypes.c_int32), ("kind", ctypes.c_int32), ("n", ctypes.c_int32),
+                ("pad", ctypes.c_int32)]
+
+
 class DenoiserEngine:
     NP = 16  # latent points per sample
     # chunk-major storage (see _buf): off unless __init__ enables it (bare plan builders in tests / tools stay row-major)
@@ -562,6 +567,7 @@ class DenoiserEngine:
                 out_cm = None
                 if self.use_cm and os.environ.get("SLIDE_CM_TABLES", "0") != "0" and npx_log2 == 8:  # (SA outputs feed gathers)
                     out_cm = self._cm_copy[out.data_ptr()] = self.A.zeros(out.shape[0], out.shape[1], dtype=self.adt)
+                self._tail_of[out.data_ptr()] = len(self.ops)
                 self._emit(make_op(OP_ATTN_TAIL, i=(rows, self._ldp(u), u.shape[1], self._ldp(mo), mo.shape[1], Cp // 32, npx_log2,
                                                     vlay[3], vlay[2], out.shape[1]),
                                         f=(1.0 / (vlay[4] * npx), 1.0 if self.use_cm else 0.0),
@@ -644,11 +650,23 @@ class DenoiserEngine:
         # the value branch (joined by finish)
         es = Z.element_size()
         self._lane = 1
-        self._emit(make_op(OP_COPY_COLS, i=(B * 16, CU, U.shape[1], Z.shape[1], int(self.prec == 1), int(self.prec == 1)),
-                                p=(U.data_ptr(), Z.data_ptr() + es * c_last)))
-        self.xyz_copy_idx.append(len(self.ops))  # loop-invariant when the coordinates are a fixed condition
-        self._emit(make_op(OP_COPY_COLS, i=(B * 16, 3, 3, Z.shape[1], 0, int(self.prec == 1)),
-                                p=(self.xyz.data_ptr(), Z.data_ptr() + es * (c_last + CU))))
+        # skip-feature columns: written by the producer of U itself where it can (the point preparation for the input
+        # features, the fused attention tail of the SA block that made U) -- a COPY launch otherwise
+        tail_idx = self._tail_of.get(U.data_ptr())
+        if self.fold_copies and U is self.feat0:
+            self._prep_copies.append((Z.data_ptr() + es * c_last, Z.shape[1], 0, CU))
+        elif self.fold_copies and tail_idx is not None:
+            t_op = self.ops[tail_idx]
+            t_op.p[7], t_op.f[2], t_op.f[3] = Z.data_ptr() + es * c_last, float(Z.shape[1]), float(CU)
+        else:
+            self._emit(make_op(OP_COPY_COLS, i=(B * 16, CU, U.shape[1], Z.shape[1], int(self.prec == 1), int(self.prec == 1)),
+                                    p=(U.data_ptr(), Z.data_ptr() + es * c_last)))
+        if self.fold_copies:
+            self._prep_copies.append((Z.data_ptr() + es * (c_last + CU), Z.shape[1], 1, 3))
+        else:
+            self.xyz_copy_idx.append(len(self.ops))  # loop-invariant when the coordinates are a fixed condition
+            self._emit(make_op(OP_COPY_COLS, i=(B * 16, 3, 3, Z.shape[1], 0, int(self.prec == 1)),
+                                    p=(self.xyz.data_ptr(), Z.data_ptr() + es * (c_last + CU))))
         self._lane = 0
         self._mlp_tail(m1, 7, h1, self.cvec, r, mo)
         finish(S)
@@ -697,6 +715,10 @@ class DenoiserEngine:
         feat0_cm = None
         if self.use_cm and os.environ.get("SLIDE_CM_TABLES", "0") != "0":
             feat0_cm = self._cm_copy[self.feat0.data_ptr()] = self._buf(B * 16, C0)
+        # COPY launches folded into the producers of their sources (SLIDE_FOLD_COPIES=0: separate launches)
+        self.fold_copies = os.environ.get("SLIDE_FOLD_COPIES", "1") != "0"
+        self._prep_copies, self._tail_of = [], {}
+        self._prep_idx = len(self.ops)
         self._emit(make_op(OP_PREP_POINTS, i=(B, self.cx, self.feat0.shape[1], self.prec),
                                 p=(self.x.data_ptr(), self.xyz.data_ptr(), self.feat0.data_ptr(), self.kidx.data_ptr(),
                                    self.kd2.data_ptr(), None if feat0_cm is None else feat0_cm.data_ptr())))
@@ -725,9 +747,12 @@ class DenoiserEngine:
             feats[i - 1], chans[i - 1] = o, c
         # output head fc_lyaer (pointnet2_with_pcld_condition.py:480-483): conv -> GN(32,128) -> ReLU -> conv
         c = chans[0]
-        self.xyz_copy_idx.append(len(self.ops))
-        self._emit(make_op(OP_COPY_COLS, i=(B * 16, 3, 3, dec0.shape[1], 0, int(self.prec == 1)),
-                                p=(self.xyz.data_ptr(), dec0.data_ptr() + dec0.element_size() * c)))
+        if self.fold_copies:
+            self._prep_copies.append((dec0.data_ptr() + dec0.element_size() * c, dec0.shape[1], 1, 3))
+        else:
+            self.xyz_copy_idx.append(len(self.ops))
+            self._emit(make_op(OP_COPY_COLS, i=(B * 16, 3, 3, dec0.shape[1], 0, int(self.prec == 1)),
+                                    p=(self.xyz.data_ptr(), dec0.data_ptr() + dec0.element_size() * c)))
         hh = self._buf(B * 16, sd["fc_lyaer.0.weight"].shape[0])
         assert sd["fc_lyaer.0.weight"].shape[1] == c + 3
         self._gemm(dec0, 4, [dict(w=self._w("fc_lyaer.0.weight"), bias=sd["fc_lyaer.0.bias"], mode=EPI_NORM,
@@ -766,6 +791,13 @@ class DenoiserEngine:
         self.cond_op = make_op(OP_COND, i=(B, sd["class_emb.weight"].shape[1], n_fcc),
                                p=(self.label.data_ptr(), dc[0].data_ptr(), dc[1].data_ptr(), dc[2].data_ptr(),
                                   self.cvec.data_ptr()))
+        if self._prep_copies:
+            tab = (SlidePrepCopy * len(self._prep_copies))()
+            for q, (dst, ld_, kind, n_) in enumerate(self._prep_copies):
+                tab[q].dst, tab[q].ld, tab[q].kind, tab[q].n = dst, ld_, kind, n_
+            self._prep_tab = A.put(np.frombuffer(bytes(tab), dtype=np.uint8).copy())
+            prep = self.ops[self._prep_idx]
+            prep.p[6], prep.i[4] = self._prep_tab.data_ptr(), len(self._prep_copies)
         self.step_ops = (SlideOp * len(self.ops))(*self.ops)
         self.cond_ops = (SlideOp * 1)(self.cond_op)
 

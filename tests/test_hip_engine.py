@@ -422,14 +422,18 @@ def test_chunk_major_layout_bit_identical(gpu_device, monkeypatch):
             for k_, v_ in knobs.items():
                 monkeypatch.setenv(k_, v_)
             monkeypatch.setenv("SLIDE_CM", "0")
-            monkeypatch.setenv("SLIDE_MERGE_Q", "0")  # (the reference plan is also the one-launch-per-query-GEMM plan)
+            monkeypatch.setenv("SLIDE_MERGE_Q", "0")  # (the reference plan is also the one-launch-per-query-GEMM plan
+            monkeypatch.setenv("SLIDE_FOLD_COPIES", "0")  # with separate COPY launches for the concatenation columns)
             e0 = DenoiserEngine(hp, sd, x.shape[0], gpu_device, prec="fp16")
+            n_copy0 = sum(1 for o in e0.ops if o.kind == 7)
             monkeypatch.setenv("SLIDE_MERGE_Q", knobs.get("SLIDE_MERGE_Q", "1"))
+            monkeypatch.setenv("SLIDE_FOLD_COPIES", "1")
             assert not e0._cm and not any(o.kind == 1 and (o.i[8] & 2) for o in e0.ops)
             ref = e0.forward(x, ts, lab).cpu().numpy()
             monkeypatch.setenv("SLIDE_CM", "1")
             e1 = DenoiserEngine(hp, sd, x.shape[0], gpu_device, prec="fp16")
             assert e1._cm and any(o.kind == 1 and (o.i[8] & 2) for o in e1.ops)
+            assert sum(1 for o in e1.ops if o.kind == 7) <= n_copy0 - 4  # skip-feature and xyz columns come from their producers
             got = e1.forward(x, ts, lab).cpu().numpy()
             assert np.array_equal(got, ref), (name, knobs, float(np.abs(got - ref).max()))
             for k_ in knobs:
