@@ -60,7 +60,7 @@ class AttentionModule(nn.Module):
         tot = R.concat_qk(R.conv(query, self.feat_conv), R.conv(grouped, self.grouped_feat_conv), K)  # wc[0]: ReLU
         if isinstance(wc[1], MyGroupNorm):
             R.norm_act(tot, wc[1].group_norm)
-            u = R.conv(tot, wc[2])
+            u = R.conv(tot, wc[2], stats="relu")
             R.norm_act(u, wc[4].group_norm, pre_relu=True)
             scores = R.conv(u, wc[5])
         else:
@@ -70,8 +70,8 @@ class AttentionModule(nn.Module):
         values = grouped_out
         if self.transform_grouped_feat_out:
             layers = list(self.feat_out_conv)
-            values = R.conv(grouped_out, layers[0])
             gn = next((l.group_norm for l in layers[1:] if isinstance(l, MyGroupNorm)), None)
+            values = R.conv(grouped_out, layers[0], stats="raw" if gn is not None else None)
             R.norm_act(values, gn, relu=any(isinstance(l, nn.ReLU) for l in layers[1:]))
         return R.attend(scores, values, K, counts)
 

@@ -93,7 +93,8 @@ def _run_stages(stages, x, addvec=None, residual=None):
     the reference adds AFTER the Sequential ride on the last stage's pass"""
     for k, (conv, gn, relu) in enumerate(stages):
         last = k == len(stages) - 1
-        x = R.norm_act(R.conv(x, conv), gn, relu=relu, addvec=addvec if last else None, residual=residual if last else None)
+        x = R.norm_act(R.conv(x, conv, stats="raw" if gn is not None else None), gn, relu=relu,
+                       addvec=addvec if last else None, residual=residual if last else None)
     return x
 
 

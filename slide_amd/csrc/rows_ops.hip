@@ -212,7 +212,9 @@ __global__ __launch_bounds__(256) void rows_gn_apply_kernel(int S, int ld, int r
                                                             const float *__restrict__ gamma,
                                                             const float *__restrict__ beta,
                                                             const float *__restrict__ addvec, int addvec_ld,
-                                                            const T *__restrict__ res, int res_ld, T *__restrict__ y) {
+                                                            const T *__restrict__ res, int res_ld, T *__restrict__ y,
+                                                            const float *__restrict__ tsum, const float *__restrict__ tsq,
+                                                            int tps) {
   constexpr int VEC = 16 / sizeof(T);
   __shared__ float lsum[1024], lsq[1024], lmean[64], lrstd[64];
   const int cn = ld / VEC, rt = 256 / cn;
@@ -223,9 +225,16 @@ __global__ __launch_bounds__(256) void rows_gn_apply_kernel(int S, int ld, int r
     const float *pp = part + ((size_t)b * nchunk_stats * ld) * 2;
     for (int c = threadIdx.x; c < n_norm; c += 256) {
       float ss = 0.f, qq = 0.f;
-      for (int k = 0; k < nchunk_stats; ++k) {
-        ss += pp[((size_t)k * ld + c) * 2 + 0];
-        qq += pp[((size_t)k * ld + c) * 2 + 1];
+      if (tsum) {  // per-256-row-tile sums published by the producing GEMM's epilogue (STATS mode): tps tiles per sample
+        for (int k = 0; k < tps; ++k) {
+          ss += tsum[((size_t)b * tps + k) * ld + c];
+          qq += tsq[((size_t)b * tps + k) * ld + c];
+        }
+      } else {
+        for (int k = 0; k < nchunk_stats; ++k) {
+          ss += pp[((size_t)k * ld + c) * 2 + 0];
+          qq += pp[((size_t)k * ld + c) * 2 + 1];
+        }
       }
       lsum[c] = ss;
       lsq[c] = qq;
@@ -410,12 +419,13 @@ int launch_rows(const SlideOp &o, hipStream_t s) {
       nchunk = nchunk < 1 ? 1 : nchunk > 64 ? 64 : nchunk;
       const int rpc = (S + nchunk - 1) / nchunk;
       nchunk = (S + rpc - 1) / rpc;
-      if (G > 0)
+      if (G > 0 && !o.p[7])
         hipLaunchKernelGGL(rows_gn_stats_kernel<T>, dim3(nchunk, B), dim3(256), 0, s, S, ld, rpc, flags & 1, (const T *)o.p[0],
                            (float *)o.p[5]);
       hipLaunchKernelGGL(rows_gn_apply_kernel<T>, dim3(nchunk, B), dim3(256), 0, s, S, ld, rpc, nchunk, G, n_norm, flags,
                          (const T *)o.p[0], (const float *)o.p[5], (const float *)o.p[1], (const float *)o.p[2],
-                         (const float *)o.p[3], o.i[6], (const T *)o.p[4], o.i[7], (T *)o.p[6]);
+                         (const float *)o.p[3], o.i[6], (const T *)o.p[4], o.i[7], (T *)o.p[6], (const float *)o.p[7],
+                         (const float *)o.p[8], o.i[8]);
       break;
     }
     case SLIDE_OP_ROWS_CONCAT_QK: {  // i: rows, K, C1, ldq, C2, ldk, ldo   p: q, k, out

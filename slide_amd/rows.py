@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from ._lib import check, lib
-from .engine import EPI_RAW, OP_GEMM, SlideEpi, SlideOp, make_op, ru
+from .engine import EPI_RAW, EPI_STATS, F_PRE_RELU, OP_GEMM, SlideEpi, SlideOp, make_op, ru
 
 OP_COPY_COLS = 7
 OP_ROWS_FROM_NCX, OP_ROWS_TO_NCX, OP_ROWS_GROUP, OP_ROWS_GN, OP_ROWS_CONCAT_QK, OP_ROWS_ATTN, OP_ROWS_POOL = 20, 21, 22, 23, 24, 25, 26
@@ -41,11 +41,13 @@ def _rop(kind, half, i, p):
 
 class Rows:
     """[B * S][ld] activation, `C` valid channels"""
-    __slots__ = ("data", "B", "S", "C")
+    __slots__ = ("data", "B", "S", "C", "stats")
 
-    def __init__(self, data, B, S, C):
+    def __init__(self, data, B, S, C, stats=None):
         assert data.dim() == 2 and data.shape[0] == B * S and data.shape[1] % 32 == 0 and data.is_contiguous()
         self.data, self.B, self.S, self.C = data, B, S, C
+        # (per-tile channel sums, sums of squares, of-relu?) published by the GEMM that produced `data`, or None
+        self.stats = stats
 
     @property
     def ld(self):
@@ -136,47 +138,61 @@ class _ConvPlan:
             self.vec[:O] = bias.detach().float()
         self.epis = {}  # output pointer -> device epilogue table (the caching allocator recycles a handful of addresses)
 
-    def epi(self, out):
-        key = out.data_ptr()
+    def epi(self, out, stats=None, pre_relu=False):
+        key = (out.data_ptr(), None if stats is None else (stats[0].data_ptr(), stats[1].data_ptr()), pre_relu)
         e = self.epis.get(key)
         if e is None:
-            if len(self.epis) >= 8:
+            if len(self.epis) >= 16:
                 self.epis.clear()
             n_cob = self.op_ // 32
             esz = out.element_size()
             tab = (SlideEpi * n_cob)()
             for j in range(n_cob):
                 t = tab[j]
-                t.mode = EPI_RAW
-                t.flags = 0
+                t.mode = EPI_RAW if stats is None else EPI_STATS
+                t.flags = F_PRE_RELU if pre_relu else 0
                 t.out_ld = self.op_
                 t.bias = self.vec.data_ptr() + 4 * 32 * j
-                t.out = key + esz * 32 * j
+                t.out = out.data_ptr() + esz * 32 * j
+                if stats is not None:
+                    t.stats_sum = stats[0].data_ptr() + 4 * 32 * j
+                    t.stats_sq = stats[1].data_ptr() + 4 * 32 * j
+                    t.stats_bs = self.op_
+                    t.stats_scale = 1.0
             e = torch.from_numpy(np.frombuffer(bytes(tab), dtype=np.uint8).copy()).to(out.device)
             self.epis[key] = e
         return e
 
-    def run(self, x):
+    def run(self, x, stats=None):
+        """stats: None | "raw" | "relu" -- also publish per-256-row-tile channel sums of the output (of its ReLU) from the
+        GEMM epilogue, for the GroupNorm that follows (saves its statistics pass); only when tiles do not straddle samples"""
         assert x.ld == self.kp and x.half == self.half, (x.ld, self.kp, x.half, self.half)
         rows = x.rows
         out = _empty(rows, self.op_, self.half, x.data.device)
+        st = None
+        if stats is not None and x.S % 256 == 0 and fused_stats():
+            st = (torch.empty(rows // 256, self.op_, device=out.device), torch.empty(rows // 256, self.op_, device=out.device))
         n_cob = self.op_ // 32
         ntr = (rows + 255) // 256
         cbw = 4 if (self.half and n_cob >= 4 and ntr * ((n_cob + 3) // 4) >= 256) else 2
         _run(make_op(OP_GEMM, i=(rows, self.kp, self.kp, n_cob, 8, 0, int(self.half), cbw, int(self.half), 0),
-                     p=(x.data.data_ptr(), self.W.data_ptr(), self.epi(out).data_ptr(), None, None)))
-        return Rows(out, x.B, x.S, self.O)
+                     p=(x.data.data_ptr(), self.W.data_ptr(), self.epi(out, st, stats == "relu").data_ptr(), None, None)))
+        return Rows(out, x.B, x.S, self.O, stats=None if st is None else (st[0], st[1], stats == "relu"))
 
 
-def conv(x, module):
-    """HipConv1x1 / HipLinear applied to Rows (weights re-packed when the parameter changes)"""
+def fused_stats():
+    return os.environ.get("SLIDE_MODULE_STATS", "1") != "0"
+
+
+def conv(x, module, stats=None):
+    """HipConv1x1 / HipLinear applied to Rows (weights re-packed when the parameter changes); stats: see _ConvPlan.run"""
     w = module.weight
     key = (w._version, w.data_ptr(), x.half)
     plan = module.__dict__.get("_rows_plan")
     if plan is None or plan[0] != key:
         plan = (key, _ConvPlan(w, module.bias, x.half, x.data.device))
         module.__dict__["_rows_plan"] = plan
-    return plan[1].run(x)
+    return plan[1].run(x, stats)
 
 
 # ----------------------------------------------------------------------------------------------------------- fused layers
@@ -186,7 +202,9 @@ def norm_act(x, gn=None, pre_relu=False, relu=False, addvec=None, residual=None)
     if gn is None and not (pre_relu or relu or addvec is not None or residual is not None):
         return x
     G, n_norm = (gn.num_groups, gn.num_channels) if gn is not None else (0, 0)
-    part = torch.empty(x.B * 64 * x.ld * 2, device=x.data.device, dtype=torch.float32) if G else None
+    st = x.stats if (G and x.stats is not None and x.stats[2] == bool(pre_relu)) else None
+    x.stats = None  # (the data changes below)
+    part = torch.empty(x.B * 64 * x.ld * 2, device=x.data.device, dtype=torch.float32) if (G and st is None) else None
     if addvec is not None:
         addvec = addvec.contiguous().float()
         assert addvec.shape[0] == x.B and addvec.shape[1] <= x.ld
@@ -194,9 +212,9 @@ def norm_act(x, gn=None, pre_relu=False, relu=False, addvec=None, residual=None)
         assert residual.rows == x.rows and residual.half == x.half and residual.ld >= x.ld
     flags = (GN_PRE_RELU if pre_relu else 0) | (GN_POST_RELU if relu else 0)
     _run(_rop(OP_ROWS_GN, x.half, (x.B, x.S, x.ld, G, n_norm, flags, addvec.shape[1] if addvec is not None else 0,
-                                   residual.ld if residual is not None else 0),
+                                   residual.ld if residual is not None else 0, x.S // 256 if st is not None else 0),
               (x.data, gn.weight if G else None, gn.bias if G else None, addvec, residual.data if residual is not None else None,
-               part, x.data)))
+               part, x.data, None if st is None else st[0], None if st is None else st[1])))
     return x
 
 
