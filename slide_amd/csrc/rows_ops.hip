@@ -307,57 +307,80 @@ __global__ __launch_bounds__(256) void rows_gn_apply_kernel(int S, int ld, int r
 }
 
 // ------------------------------------------------------------------------------------------ attention glue
-// out[row][0..C1) = relu(q[row / K]), out[row][C1..C1+C2) = relu(k[row]), rest 0
+// out[row][0..C1) = relu(q[row / K]), out[row][C1..C1+C2) = relu(k[row]), rest 0.  One thread per 16 bytes of an output
+// row; pieces that lie inside one source and are 16-byte aligned there move as one vector load (requests, not bytes, bound
+// these kernels: tools/lds_fill.hip), the pieces at the seam element-wise.
 template <typename T>
 __global__ __launch_bounds__(256) void rows_concat_qk_kernel(int K, int C1, int ldq, int C2, int ldk, int ldo,
                                                              const T *__restrict__ q, const T *__restrict__ k,
                                                              T *__restrict__ out, size_t total) {
+  constexpr int VEC = 16 / sizeof(T);
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= total) return;
-  const int ppr = ldo >> 2;
+  const int ppr = ldo / VEC;
   const size_t row = gid / ppr;
-  const int c0 = (int)(gid - row * ppr) * 4;
+  const int c0 = (int)(gid - row * ppr) * VEC;
   const T *qr = q + (row / K) * ldq;
   const T *kr = k + row * ldk;
-  Pack<T, 4> r;
+  Pack<T, VEC> r;
+  if (c0 + VEC <= C1) {
+    r = *reinterpret_cast<const Pack<T, VEC> *>(qr + c0);
+  } else if (c0 >= C1 && c0 + VEC <= C1 + C2 && (C1 % VEC) == 0) {
+    r = *reinterpret_cast<const Pack<T, VEC> *>(kr + (c0 - C1));
+  } else {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = c0 + j;
-    float v = 0.f;
-    if (c < C1) v = (float)qr[c];
-    else if (c < C1 + C2) v = (float)kr[c - C1];
-    r.v[j] = (T)fmaxf(v, 0.f);
+    for (int j = 0; j < VEC; ++j) {
+      const int c = c0 + j;
+      r.v[j] = c < C1 ? qr[c] : c < C1 + C2 ? kr[c - C1] : (T)0.f;
+    }
   }
-  *reinterpret_cast<Pack<T, 4> *>(out + row * ldo + c0) = r;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) r.v[j] = (T)fmaxf((float)r.v[j], 0.f);
+  *reinterpret_cast<Pack<T, VEC> *>(out + row * ldo + c0) = r;
 }
 
-// out[pt][c] = sum_k softmax_k(S[pt*K + k][c]) * V[pt*K + k][c]; one thread per (point, channel), consecutive threads ->
-// consecutive channels of the same rows
+// out[pt][c] = sum_k softmax_k(S[pt*K + k][c]) * V[pt*K + k][c]; one thread per (point, 16 bytes of channels): 16-byte
+// loads (the kernel is bound by memory requests, not bytes), three passes over the point's K score rows (cache hits).
 // counts != NULL: only the first max(1, counts[pt]) neighbour slots take part (the reference masks the others with -1e9
 // before the softmax, attention.py:89-93: their weights are exactly 0 in fp32)
 template <typename T>
 __global__ __launch_bounds__(256) void rows_attn_kernel(int K, int C, int lds_, int ldv, int ldo, const T *__restrict__ Sx,
                                                         const T *__restrict__ V, const int *__restrict__ counts,
                                                         T *__restrict__ out, size_t total) {
+  constexpr int VEC = 16 / sizeof(T);
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= total) return;
-  const size_t pt = gid / ldo;
-  const int c = (int)(gid - pt * ldo);
-  if (c >= C) {
-    out[gid] = (T)0.f;
-    return;
+  const int ppr = ldo / VEC;
+  const size_t pt = gid / ppr;
+  const int c0 = (int)(gid - pt * ppr) * VEC;
+  const int kk = counts ? max(1, min(K, counts[pt])) : K;
+  const T *sp = Sx + pt * K * lds_ + c0;
+  const T *vp = V + pt * K * ldv + c0;
+  float m[VEC], l[VEC], acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { m[j] = -INFINITY; l[j] = 0.f; acc[j] = 0.f; }
+  for (int k = 0; k < kk; ++k) {
+    const Pack<T, VEC> sv = *reinterpret_cast<const Pack<T, VEC> *>(sp + (size_t)k * lds_);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) m[j] = fmaxf(m[j], (float)sv.v[j]);
   }
-  const T *sp = Sx + pt * K * lds_ + c;
-  const T *vp = V + pt * K * ldv + c;
-  if (counts) K = max(1, min(K, counts[pt]));
-  float m = -INFINITY;
-  for (int k = 0; k < K; ++k) m = fmaxf(m, (float)sp[(size_t)k * lds_]);
-  float l = 0.f;
-  for (int k = 0; k < K; ++k) l += expf((float)sp[(size_t)k * lds_] - m);
-  const float rl = 1.0f / l;
-  float acc = 0.f;
-  for (int k = 0; k < K; ++k) acc += (float)vp[(size_t)k * ldv] * (expf((float)sp[(size_t)k * lds_] - m) * rl);
-  out[gid] = (T)acc;
+  for (int k = 0; k < kk; ++k) {
+    const Pack<T, VEC> sv = *reinterpret_cast<const Pack<T, VEC> *>(sp + (size_t)k * lds_);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) l[j] += expf((float)sv.v[j] - m[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) l[j] = 1.0f / l[j];
+  for (int k = 0; k < kk; ++k) {
+    const Pack<T, VEC> sv = *reinterpret_cast<const Pack<T, VEC> *>(sp + (size_t)k * lds_);
+    const Pack<T, VEC> vv = *reinterpret_cast<const Pack<T, VEC> *>(vp + (size_t)k * ldv);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] += (float)vv.v[j] * (expf((float)sv.v[j] - m[j]) * l[j]);
+  }
+  Pack<T, VEC> r;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) r.v[j] = (c0 + j < C) ? (T)acc[j] : (T)0.f;
+  *reinterpret_cast<Pack<T, VEC> *>(out + pt * ldo + c0) = r;
 }
 
 // pooling over the K neighbour rows of a point (pooling_features, pointnet2_modules.py:179-211): mode 0 max over all K
@@ -429,13 +452,13 @@ int launch_rows(const SlideOp &o, hipStream_t s) {
       break;
     }
     case SLIDE_OP_ROWS_CONCAT_QK: {  // i: rows, K, C1, ldq, C2, ldk, ldo   p: q, k, out
-      const size_t total = (size_t)o.i[0] * (o.i[6] / 4);
+      const size_t total = (size_t)o.i[0] * (o.i[6] / (16 / (int)sizeof(T)));
       hipLaunchKernelGGL(rows_concat_qk_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, o.i[1], o.i[2],
                          o.i[3], o.i[4], o.i[5], o.i[6], (const T *)o.p[0], (const T *)o.p[1], (T *)o.p[2], total);
       break;
     }
     case SLIDE_OP_ROWS_ATTN: {  // i: points, K, C, lds, ldv, ldo   p: S, V, out
-      const size_t total = (size_t)o.i[0] * o.i[5];
+      const size_t total = (size_t)o.i[0] * (o.i[5] / (16 / (int)sizeof(T)));
       hipLaunchKernelGGL(rows_attn_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, o.i[1], o.i[2], o.i[3],
                          o.i[4], o.i[5], (const T *)o.p[0], (const T *)o.p[1], (const int *)o.p[3], (T *)o.p[2], total);
       break;
