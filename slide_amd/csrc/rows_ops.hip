@@ -203,70 +203,80 @@ __global__ __launch_bounds__(256) void rows_gn_stats_kernel(int S, int ld, int r
   }
 }
 
-// Pass 2: y = post_relu( norm( pre_relu(x) ) ) + addvec[b] + residual[row]; channels >= n_norm skip the normalisation.
-// G == 0: no normalisation at all (part unused) -- the plain ReLU / add epilogue of a layer without GroupNorm.
-template <typename T>
-__global__ __launch_bounds__(256) void rows_gn_apply_kernel(int S, int ld, int rpc, int nchunk_stats, int G, int n_norm,
-                                                            int flags, const T *__restrict__ x,
-                                                            const float *__restrict__ part,
-                                                            const float *__restrict__ gamma,
-                                                            const float *__restrict__ beta,
-                                                            const float *__restrict__ addvec, int addvec_ld,
-                                                            const T *__restrict__ res, int res_ld, T *__restrict__ y,
-                                                            const float *__restrict__ tsum, const float *__restrict__ tsq,
-                                                            int tps) {
-  constexpr int VEC = 16 / sizeof(T);
+// Between the passes, once per sample: partial sums (of pass 1, or the per-tile sums a GEMM's STATS epilogue published) ->
+// scale = gamma * rstd and shift = beta - mean * scale per channel, ss[b][0 | 1][ld].  (Every workgroup of pass 2 used to
+// redo this reduction: up to 64 x ld x 2 floats read per workgroup -- as many bytes as its share of the tensor.)
+__global__ __launch_bounds__(256) void rows_gn_finalize_kernel(int S, int ld, int nchunk_stats, int G, int n_norm,
+                                                               const float *__restrict__ part,
+                                                               const float *__restrict__ gamma,
+                                                               const float *__restrict__ beta,
+                                                               const float *__restrict__ tsum, const float *__restrict__ tsq,
+                                                               int tps, float *__restrict__ ss) {
   __shared__ float lsum[1024], lsq[1024], lmean[64], lrstd[64];
+  const int b = blockIdx.x;
+  const float *pp = part + ((size_t)b * nchunk_stats * ld) * 2;
+  for (int c = threadIdx.x; c < n_norm; c += 256) {
+    float s1 = 0.f, q1 = 0.f;
+    if (tsum) {  // per-256-row-tile sums published by the producing GEMM's epilogue (STATS mode): tps tiles per sample
+      for (int k = 0; k < tps; ++k) {
+        s1 += tsum[((size_t)b * tps + k) * ld + c];
+        q1 += tsq[((size_t)b * tps + k) * ld + c];
+      }
+    } else {
+      for (int k = 0; k < nchunk_stats; ++k) {
+        s1 += pp[((size_t)k * ld + c) * 2 + 0];
+        q1 += pp[((size_t)k * ld + c) * 2 + 1];
+      }
+    }
+    lsum[c] = s1;
+    lsq[c] = q1;
+  }
+  __syncthreads();
+  const int gs = n_norm / G;
+  const float inv = 1.0f / ((float)gs * (float)S);
+  for (int g = threadIdx.x; g < G; g += 256) {
+    float s1 = 0.f, q1 = 0.f;
+    for (int j = 0; j < gs; ++j) {
+      s1 += lsum[g * gs + j];
+      q1 += lsq[g * gs + j];
+    }
+    const float mean = s1 * inv;
+    const float var = fmaxf(q1 * inv - mean * mean, 0.f);
+    lmean[g] = mean;
+    lrstd[g] = 1.0f / sqrtf(var + 1e-5f);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < ld; c += 256) {
+    float sc = 1.f, sh = 0.f;
+    if (c < n_norm) {
+      const int g = c / gs;
+      sc = gamma[c] * lrstd[g];
+      sh = beta[c] - lmean[g] * sc;
+    }
+    ss[((size_t)b * 2 + 0) * ld + c] = sc;
+    ss[((size_t)b * 2 + 1) * ld + c] = sh;
+  }
+}
+
+// Pass 2: y = post_relu( pre_relu(x) * scale + shift ) + addvec[b] + residual[row]; ss == NULL: no normalisation at all --
+// the plain ReLU / add epilogue of a layer without GroupNorm.
+template <typename T>
+__global__ __launch_bounds__(256) void rows_gn_apply_kernel(int S, int ld, int rpc, int flags, const T *__restrict__ x,
+                                                            const float *__restrict__ ss,
+                                                            const float *__restrict__ addvec, int addvec_ld,
+                                                            const T *__restrict__ res, int res_ld, T *__restrict__ y) {
+  constexpr int VEC = 16 / sizeof(T);
   const int cn = ld / VEC, rt = 256 / cn;
   const int pr = threadIdx.x / cn, pc = threadIdx.x - pr * cn;
   const int b = blockIdx.y, chunk = blockIdx.x;
   const bool pre_relu = flags & 1, post_relu = flags & 2;
-  if (G > 0) {
-    const float *pp = part + ((size_t)b * nchunk_stats * ld) * 2;
-    for (int c = threadIdx.x; c < n_norm; c += 256) {
-      float ss = 0.f, qq = 0.f;
-      if (tsum) {  // per-256-row-tile sums published by the producing GEMM's epilogue (STATS mode): tps tiles per sample
-        for (int k = 0; k < tps; ++k) {
-          ss += tsum[((size_t)b * tps + k) * ld + c];
-          qq += tsq[((size_t)b * tps + k) * ld + c];
-        }
-      } else {
-        for (int k = 0; k < nchunk_stats; ++k) {
-          ss += pp[((size_t)k * ld + c) * 2 + 0];
-          qq += pp[((size_t)k * ld + c) * 2 + 1];
-        }
-      }
-      lsum[c] = ss;
-      lsq[c] = qq;
-    }
-    __syncthreads();
-    const int gs = n_norm / G;
-    const float inv = 1.0f / ((float)gs * (float)S);
-    for (int g = threadIdx.x; g < G; g += 256) {
-      float ss = 0.f, qq = 0.f;
-      for (int j = 0; j < gs; ++j) {
-        ss += lsum[g * gs + j];
-        qq += lsq[g * gs + j];
-      }
-      const float mean = ss * inv;
-      const float var = fmaxf(qq * inv - mean * mean, 0.f);
-      lmean[g] = mean;
-      lrstd[g] = 1.0f / sqrtf(var + 1e-5f);
-    }
-    __syncthreads();
-  }
   if (pr >= rt) return;
   float sc[VEC], sh[VEC], av[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
     const int c = pc * VEC + j;
-    sc[j] = 1.f;
-    sh[j] = 0.f;
-    if (G > 0 && c < n_norm) {
-      const int g = c / (n_norm / G);
-      sc[j] = gamma[c] * lrstd[g];
-      sh[j] = beta[c] - lmean[g] * sc[j];
-    }
+    sc[j] = ss ? ss[((size_t)b * 2 + 0) * ld + c] : 1.f;
+    sh[j] = ss ? ss[((size_t)b * 2 + 1) * ld + c] : 0.f;
     av[j] = (addvec && c < addvec_ld) ? addvec[(size_t)b * addvec_ld + c] : 0.f;
   }
   const int r0 = chunk * rpc, r1 = min(S, r0 + rpc);
@@ -442,13 +452,17 @@ int launch_rows(const SlideOp &o, hipStream_t s) {
       nchunk = nchunk < 1 ? 1 : nchunk > 64 ? 64 : nchunk;
       const int rpc = (S + nchunk - 1) / nchunk;
       nchunk = (S + rpc - 1) / rpc;
+      // scratch: [B][nchunk <= 64][ld][2] partial sums, then [B][2][ld] scale / shift
+      float *ssp = G > 0 ? (float *)o.p[5] + (size_t)B * 64 * ld * 2 : nullptr;
       if (G > 0 && !o.p[7])
         hipLaunchKernelGGL(rows_gn_stats_kernel<T>, dim3(nchunk, B), dim3(256), 0, s, S, ld, rpc, flags & 1, (const T *)o.p[0],
                            (float *)o.p[5]);
-      hipLaunchKernelGGL(rows_gn_apply_kernel<T>, dim3(nchunk, B), dim3(256), 0, s, S, ld, rpc, nchunk, G, n_norm, flags,
-                         (const T *)o.p[0], (const float *)o.p[5], (const float *)o.p[1], (const float *)o.p[2],
-                         (const float *)o.p[3], o.i[6], (const T *)o.p[4], o.i[7], (T *)o.p[6], (const float *)o.p[7],
-                         (const float *)o.p[8], o.i[8]);
+      if (G > 0)
+        hipLaunchKernelGGL(rows_gn_finalize_kernel, dim3(B), dim3(256), 0, s, S, ld, nchunk, G, n_norm, (const float *)o.p[5],
+                           (const float *)o.p[1], (const float *)o.p[2], (const float *)o.p[7], (const float *)o.p[8], o.i[8],
+                           ssp);
+      hipLaunchKernelGGL(rows_gn_apply_kernel<T>, dim3(nchunk, B), dim3(256), 0, s, S, ld, rpc, flags, (const T *)o.p[0], ssp,
+                         (const float *)o.p[3], o.i[6], (const T *)o.p[4], o.i[7], (T *)o.p[6]);
       break;
     }
     case SLIDE_OP_ROWS_CONCAT_QK: {  // i: rows, K, C1, ldq, C2, ldk, ldo   p: q, k, out

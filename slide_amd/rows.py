@@ -204,7 +204,8 @@ def norm_act(x, gn=None, pre_relu=False, relu=False, addvec=None, residual=None)
     G, n_norm = (gn.num_groups, gn.num_channels) if gn is not None else (0, 0)
     st = x.stats if (G and x.stats is not None and x.stats[2] == bool(pre_relu)) else None
     x.stats = None  # (the data changes below)
-    part = torch.empty(x.B * 64 * x.ld * 2, device=x.data.device, dtype=torch.float32) if (G and st is None) else None
+    # scratch: partial sums [B][64][ld][2] (unused with producer-side statistics) + scale / shift [B][2][ld]
+    part = torch.empty(x.B * 64 * x.ld * 2 + x.B * 2 * x.ld, device=x.data.device, dtype=torch.float32) if G else None
     if addvec is not None:
         addvec = addvec.contiguous().float()
         assert addvec.shape[0] == x.B and addvec.shape[1] <= x.ld
