@@ -32,9 +32,14 @@ for spec in sys.argv[1:]:
     extras = tuple(f[5:])
     B = rows >> npxl
     m = G.Mini(B, "fp16")
+    cm = "cm" in extras and npxl >= 7  # chunk-major input / output / weights, as in the fp16 plans
+    if cm:
+        m.use_cm, m._cm = True, set()
     rs = np.random.RandomState(0)
     X = m.A.put(rs.standard_normal((rows, K)).astype(np.float32), m.adt)
-    out = m._buf(rows, N)
+    if cm:
+        m._cm.add(X.data_ptr())
+    out = m._buf(rows, N, cm=cm)
     seg = dict(w=rs.standard_normal((N, K)).astype(np.float32) / np.sqrt(K), bias=rs.standard_normal(N).astype(np.float32),
                mode=mode, out=out)
     if mode == E.EPI_NORM:

@@ -152,6 +152,41 @@ __global__ __launch_bounds__(256) void fill_cm(const u16 *__restrict__ X, const 
   if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// X straight into registers in the MFMA operand layout (no LDS for X: a wave's 64 rows are private to it), W by LDS-DMA:
+// lane (row l & 31, half l >> 5) loads the 16 bytes k = 16 s + 8 half .. +7 of its row for k16-step s; chunk-major X
+__global__ __launch_bounds__(256) void fill_xreg(const u16 *__restrict__ X, const u16 *__restrict__ W, int rows_total, int wrows,
+                                                 int nchunk, int reps, unsigned int *sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, ct = q & 7, rt = (q >> 3) * 8 + xcd;
+  const u16 *xp[2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) xp[rb] = X + ((size_t)rt * 256 + wv * 64 + rb * 32 + col) * 32 + half * 8;
+  const u16 *wp = W + ((size_t)ct * 64 + wv * 16 + (lane >> 2)) * 32 + (lane & 3) * 8;
+  const size_t xcs = (size_t)rows_total * 32, wcs = (size_t)wrows * 32;
+  unsigned int acc = 0;
+  v16 r[2][2][2];  // [buffer][rb][s]
+  auto issue = [&](int kc, int buf) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) r[buf][rb][s2] = *reinterpret_cast<const v16 *>(xp[rb] + kc * xcs + s2 * 16);
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(wp + kc * wcs), (LDS_AS void *)(smem + (kc & 1) * 4096 + wv * 1024), 16, 0, 0);
+  };
+  for (int rep = 0; rep < reps; ++rep) {
+    issue(0, 0);
+    for (int kc = 0; kc < nchunk; ++kc) {
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+      __syncthreads();
+      if (kc + 1 < nchunk) issue(kc + 1, (kc + 1) & 1);
+      const int b = kc & 1;
+      acc += r[b][0][0].x ^ r[b][0][1].y ^ r[b][1][0].z ^ r[b][1][1].w;
+      if ((kc & 15) == 15) acc += *reinterpret_cast<const unsigned int *>(smem + b * 4096 + threadIdx.x * 16);
+    }
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 template <typename F>
@@ -195,6 +230,18 @@ int main() {
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       const double bytes = (double)wgs * nchunk * reps * 20480.0;
       printf("%-28s %4d WGs: %.1f us, %.2f TB/s into LDS, %.1f KB/us/CU, %.1f B/clk/CU (2.4 GHz)\n", "CM chunk-major [K/32][rows][32]", wgs,
+             ms * 1e3, bytes / ms / 1e9, bytes / (ms * 1e3) / 256 / 1024, bytes / (ms * 1e-3) / 256 / 2.4e9);
+    }
+    {
+      auto k = fill_xreg;
+      hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      hipLaunchKernelGGL(k, dim3(wgs), dim3(256), 41 * 1024, 0, X, W, ntr * 256, 8 * 64, nchunk, 1, sink);
+      CK(hipDeviceSynchronize()); CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(k, dim3(wgs), dim3(256), 41 * 1024, 0, X, W, ntr * 256, 8 * 64, nchunk, reps, sink);
+      CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      const double bytes = (double)wgs * nchunk * reps * 20480.0;
+      printf("%-28s %4d WGs: %.1f us, %.2f TB/s, %.1f KB/us/CU, %.1f B/clk/CU (2.4 GHz)\n", "XR X->VGPR (MFMA layout) + W DMA", wgs,
              ms * 1e3, bytes / ms / 1e9, bytes / (ms * 1e3) / 256 / 1024, bytes / (ms * 1e-3) / 256 / 2.4e9);
     }
     run("R64  one stage, 64 B/row", fill_rb<64>, wgs, X, W, ld, nchunk, reps, sink);
