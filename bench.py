@@ -219,7 +219,7 @@ def main():
         for f_, l_, k_ in feat_chains:
             f_.begin(l_, k_, torch.randn(f_.B, 16, 51, device=dev, generator=gen))
 
-    state = {"left": 0}  # reverse steps left in the current chains
+    state = {"left": 0, "enq": 0.0}  # reverse steps left in the current chains; host seconds spent enqueueing launches
 
     def run(n):
         """n reverse steps of each DDPM.  A chain is 1000 steps; it is restarted from fresh device-side noise when it ends
@@ -231,7 +231,9 @@ def main():
                 reset()
                 state["left"] = 1000
             k = min(n - done, state["left"])
+            t_enq = time.perf_counter()
             joint.advance(k)
+            state["enq"] += time.perf_counter() - t_enq
             state["left"] -= k
             done += k
 
@@ -258,8 +260,10 @@ def main():
     reset()  # begin the timed chains (x_T, labels, key points, per-chain pre-computes) before the clock starts
     state["left"] = 1000
     sync_all()
+    state["enq"] = 0.0
     t0 = time.perf_counter()
     run(a.steps)
+    host_enq = state["enq"]
     if use_dist:
         gather_latents()
     sync_all()
@@ -281,6 +285,9 @@ def main():
                                   "batch %d per GPU; 1 step = one reverse step of each; shape = 1000+1000 steps" % B,
                       "batch_per_gpu": B, "sub_batches": sizes, "prec": a.prec, "replay": a.replay,
                       "launches_per_step": sum(p_.n_launches for p_, _ in pos_chains) + sum(f_.n_launches for f_, _, _ in feat_chains),
+                      # host seconds inside the launch calls of the timed region, per step: close to ms_per_step = the host
+                      # (or a full hardware queue it is blocked on) paces the run, far below = the GPU does
+                      "host_enqueue_ms_per_step": round(host_enq * 1e3 / a.steps, 4),
                       "finite": finite}}
     if cat_desc is not None:
         out["config"]["workload"] = ("BASELINE configs[3]: five-category run (labels 0, 2, 3, 4, 6; one position + one feature weight set "
