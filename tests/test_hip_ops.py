@@ -166,3 +166,62 @@ def test_empty_and_degenerate_inputs(gpu_device):
     rd, ri = O.three_nn(q, xyz[:, :3])  # exactly three known points
     d, i = _ext.three_nn(T(q, dev), T(xyz[:, :3].copy(), dev))
     assert np.array_equal(N(i), ri) and np.array_equal(N(d), rd)
+
+
+@pytest.mark.parametrize("shape", [(256, 1024, 256, 32, 128), (64, 8192, 2048, 32, 64)])
+def test_ops_full_size_properties(gpu_device, shape):
+    """SURVEY.md section 8(d) sizes, where the CPU oracle would take minutes: size-independent properties of every op,
+    checked with torch tensor arithmetic on the device (B, N, npoint, nsample, C; coordinates U(-1,1), features N(0,1))"""
+    from slide_amd import _ext
+    B, n, m, ns, C = shape
+    g = torch.Generator(device="cpu").manual_seed(0)
+    xyz = (torch.rand(B, n, 3, generator=g) * 2 - 1).to(gpu_device)
+    feats = torch.randn(B, C, n, generator=g).to(gpu_device)
+    bi = torch.arange(B, device=gpu_device)[:, None]
+    # FPS: starts at point 0, never repeats a point, and every pick is the farthest point from the picks before it
+    fidx = _ext.furthest_point_sampling(xyz, m).long()
+    assert fidx.shape == (B, m) and bool((fidx[:, 0] == 0).all())
+    assert bool((torch.sort(fidx, dim=1)[0][:, 1:] != torch.sort(fidx, dim=1)[0][:, :-1]).all())
+    new_xyz = xyz[bi, fidx]
+    sub = slice(0, 4)  # the greedy criterion on a few clouds (m x n distance matrices)
+    d = ((new_xyz[sub, :, None, :] - xyz[sub, None, :, :]) ** 2).sum(-1)              # (4, m, n)
+    run_min = torch.cummin(d, dim=1)[0]                                              # distance to the set after each pick
+    for j in (1, 2, m // 2, m - 1):
+        far = run_min[:, j - 1].max(dim=1)[0]
+        picked = run_min[:, j - 1].gather(1, fidx[sub, j:j + 1])[:, 0]
+        assert torch.allclose(picked, far, rtol=1e-6, atol=0), j
+    # gather / group: exactly the indexed elements
+    assert torch.equal(_ext.gather_points(feats, fidx.int()), feats.gather(2, fidx[:, None, :].expand(-1, C, -1)))
+    # kNN: sorted, true distances of the returned indices, and nothing outside the list is closer than its last entry
+    d2, kidx = _ext.knn_points(new_xyz, xyz, ns, None)
+    assert bool((d2[:, :, 1:] >= d2[:, :, :-1]).all()) and int(kidx.min()) >= 0 and int(kidx.max()) < n
+    nb = xyz[bi[:, :, None], kidx]                                                   # (B, m, ns, 3)
+    assert torch.allclose(((nb - new_xyz[:, :, None, :]) ** 2).sum(-1), d2, rtol=1e-5, atol=1e-7)
+    full = ((new_xyz[sub, :64, None, :] - xyz[sub, None, :, :]) ** 2).sum(-1)          # (4, 64, n)
+    kth = torch.topk(full, ns, dim=2, largest=False)[0]
+    assert torch.allclose(kth, d2[sub, :64], rtol=1e-5, atol=1e-7)
+    grouped = _ext.group_points(feats, kidx.int())
+    assert grouped.shape == (B, C, m, ns)
+    assert torch.equal(grouped[:, :, :, 0], feats.gather(2, kidx[:, None, :, 0].expand(-1, C, -1)))
+    assert torch.equal(grouped[:, :, :, ns - 1], feats.gather(2, kidx[:, None, :, ns - 1].expand(-1, C, -1)))
+    # ball query: counts within [0, ns], the first `count` slots lie inside the ball, the rest repeat the first hit
+    r = 0.12
+    bidx, cnt = _ext.ball_query(new_xyz, xyz, r, ns)
+    assert int(cnt.min()) >= 1 and int(cnt.max()) <= ns                              # a centre is inside its own ball
+    bd = ((xyz[bi[:, :, None], bidx.long()] - new_xyz[:, :, None, :]) ** 2).sum(-1)
+    assert bool((bd < r * r).all())
+    slot = torch.arange(ns, device=gpu_device)[None, None, :]
+    assert bool(((bidx == bidx[:, :, :1]) | (slot < cnt[:, :, None])).all())
+    # three_nn / three_interpolate: the three smallest distances, weights that sum to one reproduce constants, linearity
+    dist, i3 = _ext.three_nn(xyz, new_xyz)                                           # unknown = all points, known = centres
+    assert bool((dist[:, :, 1:] >= dist[:, :, :-1]).all())
+    full3 = ((xyz[sub, :64, None, :] - new_xyz[sub, None, :, :]) ** 2).sum(-1)
+    assert torch.allclose(torch.topk(full3, 3, dim=2, largest=False)[0], dist[sub, :64], rtol=1e-5, atol=1e-7)
+    w = 1.0 / (dist + 1e-8)
+    w = w / w.sum(dim=2, keepdim=True)
+    kf = torch.randn(B, C, m, generator=g).to(gpu_device)
+    kf2 = torch.randn(B, C, m, generator=g).to(gpu_device)
+    ones = _ext.three_interpolate(torch.ones(B, 2, m, device=gpu_device), i3, w)
+    assert torch.allclose(ones, torch.ones_like(ones), atol=1e-6)
+    a, b_, ab = (_ext.three_interpolate(t, i3, w) for t in (kf, kf2, kf + 2 * kf2))
+    assert torch.allclose(ab, a + 2 * b_, rtol=1e-5, atol=1e-5)
