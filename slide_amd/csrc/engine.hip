@@ -1320,7 +1320,7 @@ int launch_gemm_glds(const GemmArgs &a, hipStream_t s) {
   bool &attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_glds_kernel<NPXL, CBW, NST, BKT, AFF, GAT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, NST > 3 ? 160 * 1024 : 84 * 1024 * (BKT / 32));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (NST > 3 || BKT > 32) ? 160 * 1024 : 84 * 1024);
     attr_set = true;
   }
   hipLaunchKernelGGL((gemm_glds_kernel<NPXL, CBW, NST, BKT, AFF, GAT>), dim3(grid), dim3(256), (size_t)b.shm_bytes, s, b);
