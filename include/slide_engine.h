@@ -61,7 +61,7 @@ typedef struct SlideEpi {
 } SlideEpi;
 
 enum {
-  SLIDE_OP_GEMM = 1,        /* p: X, W, epi, in_scale, in_shift, [5] timeline buffer (instrumented builds only, else NULL), [6] SlideGnFin* (16-row launches with input affine: finalise the statistics in this launch), [7] 9 zeroed ints for the optional persistent tile scheduler (NULL = one tile per workgroup), [8] point-feature table + [9] neighbour table of the GATHER mode (first GEMM of an SA / FP block: the first f[1] 32-column chunks of X row (b, p, k) are read from row b*16 + idx[(b*16+p)*16+k] of the table with row length f[2], neighbours per point 2^f[3]; p[0] / x_ld then describe only the remaining columns; with p[8] NULL, p[9] is the neighbour table of gathered pre_add terms, SlideEpi.pre_add_shift < 0); [10] non-NULL selects the X-stationary kernel for sample-wide fp16 layers whose 256-row X tile fits the LDS (one workgroup per row tile keeps X resident and computes every column tile, the weights stream through a small LDS-DMA ring; i[9] == 5 keeps the ring kernels); f[0]: start stagger in us for the persistent mode; i[9]: 0 = default ring, 1 = 64-deep chunks, 2 = eight-wave 256x256 tiles   i: rows, x_ld, k_pad, n_cob, npx_log2, in_bs, prec, cbw(2|4), lds_dma (bit 0: fp16 LDS-DMA ring kernels; bit 1: W is CHUNK-MAJOR [k_pad/32][n_cob*32][32] -- ring kernels of the 128- / 256-row samples only).  CHUNK-MAJOR X: with x_ld == 32 and k_pad > 32 the ring kernels read X as [k/32][rows][32] (chunk kc of row r at X + (kc*rows + r)*32); outputs / residuals use the same layout through SlideEpi's per-block pointer with out_ld / res_ld == 32 */
+  SLIDE_OP_GEMM = 1,        /* p: X, W, epi, in_scale, in_shift, [5] timeline buffer (instrumented builds only, else NULL), [6] SlideGnFin* (16-row launches with input affine: finalise the statistics in this launch), [7] 9 zeroed ints for the optional persistent tile scheduler (NULL = one tile per workgroup), [8] point-feature table + [9] neighbour table of the GATHER mode (first GEMM of an SA / FP block: the first f[1] 32-column chunks of X row (b, p, k) are read from row b*16 + idx[(b*16+p)*16+k] of the table with row length f[2], neighbours per point 2^f[3]; p[0] / x_ld then describe only the remaining columns; with p[8] NULL, p[9] is the neighbour table of gathered pre_add terms, SlideEpi.pre_add_shift < 0); [11] + f[1..3] with p[3] / p[4] set and no gather: DEFERRED NORMALISATION of the module-level path -- x' = relu?(x * scale + shift) + add applied to the X fragments, p[11] = add vectors [sample][f[2]] (or NULL), f[1] = 256-row tiles per sample, f[3] = 2 * (channels of add) + (ReLU ? 1 : 0); [10] non-NULL selects the X-stationary kernel for sample-wide fp16 layers whose 256-row X tile fits the LDS (one workgroup per row tile keeps X resident and computes every column tile, the weights stream through a small LDS-DMA ring; i[9] == 5 keeps the ring kernels); f[0]: start stagger in us for the persistent mode; i[9]: 0 = default ring, 1 = 64-deep chunks, 2 = eight-wave 256x256 tiles   i: rows, x_ld, k_pad, n_cob, npx_log2, in_bs, prec, cbw(2|4), lds_dma (bit 0: fp16 LDS-DMA ring kernels; bit 1: W is CHUNK-MAJOR [k_pad/32][n_cob*32][32] -- ring kernels of the 128- / 256-row samples only).  CHUNK-MAJOR X: with x_ld == 32 and k_pad > 32 the ring kernels read X as [k/32][rows][32] (chunk kc of row r at X + (kc*rows + r)*32); outputs / residuals use the same layout through SlideEpi's per-block pointer with out_ld / res_ld == 32 */
   SLIDE_OP_PREP_POINTS = 2, /* p: x, xyz, feat0, knn_idx, knn_d2, [5] optional second copy of feat0, chunk-major [c/32][B*16][32], [6] SlidePrepCopy[i[4]] (device)   i: B, cx, ldf, prec, n_copies     (16 points / sample) */
   SLIDE_OP_ASSEMBLE_SA = 3, /* p: xyz, feat, knn_idx, g            i: B, C, ldf, ldg, K, prec, c_begin (0 = all columns; else only columns >= c_begin), ld_out */
   SLIDE_OP_ASSEMBLE_FP = 4, /* p: xyz, feat, knn_idx, knn_d2, g    i: B, C, ldf, ldg, K, prec, c_begin, ld_out */
@@ -84,7 +84,7 @@ enum {
   SLIDE_OP_ROWS_FROM_NCX = 20, /* p: in (B,C,P) fp32, out rows   i: B, C, P, ld */
   SLIDE_OP_ROWS_TO_NCX = 21,   /* p: in rows, out (B,C,P) fp32   i: B, C, P, ld */
   SLIDE_OP_ROWS_GROUP = 22,    /* p: xyz (B,N,3), new_xyz (B,np,3), feat rows [B*N][ldf] (or NULL), idx int64 (B,np,K), d2 (B,np,K) (FP layout), out [B*np*K][ldg]   i: B, N, np, K, C, ldf, ldg, flags (1: group_knn layout [feat|d2|w|abs|rel|centre]; else [feat|rel|abs if 2|centre if 4], 8: no coordinate channels, 16: idx is int32), [6] counts int32 (B,np) or NULL: a centre with count 0 stands in as its own neighbour with zero features */
-  SLIDE_OP_ROWS_GN = 23,       /* p: x, gamma, beta, addvec [B][addvec_ld] fp32 (or NULL), residual rows (or NULL), scratch (B*64*ld*2 + B*2*ld floats), y (may be x), [7] / [8] per-tile channel sums / sums of squares [B*i[8]][ld] from the producing GEMM's STATS epilogue (256-row tiles, i[8] tiles per sample) instead of a statistics pass   i: B, S, ld, G (0 = no normalisation), n_norm, flags (1 ReLU before, 2 ReLU after), addvec_ld, res_ld, tiles per sample */
+  SLIDE_OP_ROWS_GN = 23,       /* p: x, gamma, beta, addvec [B][addvec_ld] fp32 (or NULL), residual rows (or NULL), scratch (B*64*ld*2 + B*2*ld floats), y (may be x), [7] / [8] per-tile channel sums / sums of squares [B*i[8]][ld] from the producing GEMM's STATS epilogue (256-row tiles, i[8] tiles per sample) instead of a statistics pass   i: B, S, ld, G (0 = no normalisation), n_norm, flags (1 ReLU before, 2 ReLU after, 4 statistics + scale / shift only -> p[9] [B][2][ld] fp32, for a consumer GEMM with the deferred affine; 8 apply only with p[9]), addvec_ld, res_ld, tiles per sample */
   SLIDE_OP_ROWS_CONCAT_QK = 24,/* p: q [rows/K][ldq], k [rows][ldk], out [rows][ldo] = relu([q | k])   i: rows, K, C1, ldq, C2, ldk, ldo */
   SLIDE_OP_ROWS_ATTN = 25,     /* p: scores [pts*K][lds], values [pts*K][ldv], out [pts][ldo], [3] counts int32 [pts] or NULL (softmax over the first max(1,count) slots)   i: pts, K, C, lds, ldv, ldo */
   SLIDE_OP_ROWS_POOL = 26      /* p: x [pts*K][ldx], out [pts][ldo], counts int32 [pts] or NULL   i: pts, K, C, ldx, ldo, mode (0 max, 1 mean over the counted slots, 2 max for channels < C/2 and mean for the rest) */

@@ -59,9 +59,9 @@ class AttentionModule(nn.Module):
         wc = list(self.weight_conv)
         tot = R.concat_qk(R.conv(query, self.feat_conv), R.conv(grouped, self.grouped_feat_conv), K)  # wc[0]: ReLU
         if isinstance(wc[1], MyGroupNorm):
-            R.norm_act(tot, wc[1].group_norm)
+            R.norm_act(tot, wc[1].group_norm, defer=True)  # (both normalisations are applied by the GEMMs that follow)
             u = R.conv(tot, wc[2], stats="relu")
-            R.norm_act(u, wc[4].group_norm, pre_relu=True)
+            R.norm_act(u, wc[4].group_norm, pre_relu=True, defer=True)
             scores = R.conv(u, wc[5])
         else:
             u = R.conv(tot, wc[1])

@@ -88,13 +88,17 @@ def _stages(seq):
     return out or None
 
 
-def _run_stages(stages, x, addvec=None, residual=None):
-    """every stage = one GEMM + one in-place normalise / ReLU pass; the per-sample embedding vector and the residual that
-    the reference adds AFTER the Sequential ride on the last stage's pass"""
+def _run_stages(stages, x, addvec=None, residual=None, defer_last=False):
+    """every stage = one GEMM + one normalise / ReLU step; the per-sample embedding vector and the residual that the
+    reference adds AFTER the Sequential ride on the last stage's step.  A step whose only consumer is the next GEMM is
+    DEFERRED (slide_amd.rows.norm_act(defer=True)): statistics and per-sample scale / shift only, the consumer normalises
+    the raw tensor while loading it -- no pass over the K-expanded tensor at all.  defer_last: the caller feeds the result
+    straight into another convolution."""
     for k, (conv, gn, relu) in enumerate(stages):
         last = k == len(stages) - 1
         x = R.norm_act(R.conv(x, conv, stats="raw" if gn is not None else None), gn, relu=relu,
-                       addvec=addvec if last else None, residual=residual if last else None)
+                       addvec=addvec if last else None, residual=residual if last else None,
+                       defer=(not last) or (defer_last and residual is None))
     return x
 
 
@@ -147,8 +151,8 @@ class Mlp_plus_t_emb(nn.Module):
         normalises, applies the ReLU and adds the embedding vector / the residual (reference :119-176)"""
         v_t, v_c, v_c2 = self._embedding_vectors(t_emb, condition_emb, second_condition_emb)
         feat = R.conv(x, self.first_conv) if self.first_conv_bool else x
-        h = _run_stages(_stages(self.first_mlp), feat, addvec=v_t)
-        h = _run_stages(_stages(self.second_mlp), h, addvec=v_c)
+        h = _run_stages(_stages(self.first_mlp), feat, addvec=v_t, defer_last=True)
+        h = _run_stages(_stages(self.second_mlp), h, addvec=v_c, defer_last=self.rest_mlp is not None)
         skip = None
         if self.res_connect_bool:
             skip = R.conv(feat, self.res_connect) if self.res_connect is not None else feat

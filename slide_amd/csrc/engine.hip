@@ -261,32 +261,36 @@ __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem
   float *const vec_lds = reinterpret_cast<float *>(epi_lds + CBW * WC * EPI_DW + (CBW * WC * EPI_DW) % 4);
   stage_epilogue_tables<CBW * WC, NT>(a, cob0, tid, epi_lds, vec_lds);
   constexpr int NSAMP = (1 << NPXL) >= TM ? 1 : TM >> NPXL;  // samples per workgroup
-  _Float16 *const aff_lds = reinterpret_cast<_Float16 *>(vec_lds + CBW * WC * 96);  // [sample][scale | shift][k_pad]
+  _Float16 *const aff_lds = reinterpret_cast<_Float16 *>(vec_lds + CBW * WC * 96);  // [sample][scale | shift | add][k_pad]
   if (AFF) {
     static_assert(!AFF || NPXL >= 6, "the affine variant assumes one sample per wave");
-    const int nb = a.rows >> NPXL, n_aff = NSAMP * a.k_pad;
+    const int tps = a.aff_tps > 1 ? a.aff_tps : 1;
+    const int nb = (a.rows >> NPXL) / tps, n_aff = NSAMP * a.k_pad;
     for (int i0 = tid; i0 < n_aff; i0 += 1024) {  // four elements per trip, their loads issued together
-      float sc4[4], sh4[4];
+      float sc4[4], sh4[4], ad4[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = i0 + 256 * u < n_aff ? i0 + 256 * u : i0;
         const int sm = i / a.k_pad, k = i - sm * a.k_pad;
-        int b = (row0 >> NPXL) + sm;
+        int b = ((row0 >> NPXL) + sm) / tps;
         b = b < nb ? b : nb - 1;
         sc4[u] = a.in_scale[(size_t)b * a.in_bs + k];
         sh4[u] = a.in_shift[(size_t)b * a.in_bs + k];
+        ad4[u] = (a.in_add && k < a.add_n) ? a.in_add[(size_t)b * a.add_bs + k] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = i0 + 256 * u;
         if (i >= n_aff) break;
         const int sm = i / a.k_pad, k = i - sm * a.k_pad;
-        aff_lds[(sm * 2 + 0) * a.k_pad + k] = (_Float16)sc4[u];
-        aff_lds[(sm * 2 + 1) * a.k_pad + k] = (_Float16)sh4[u];
+        aff_lds[(sm * 3 + 0) * a.k_pad + k] = (_Float16)sc4[u];
+        aff_lds[(sm * 3 + 1) * a.k_pad + k] = (_Float16)sh4[u];
+        aff_lds[(sm * 3 + 2) * a.k_pad + k] = (_Float16)ad4[u];
       }
     }
   }
-  const _Float16 *const aff_w = aff_lds + (size_t)((wave * 64) >> NPXL) * 2 * a.k_pad;  // this wave's sample
+  const _Float16 *const aff_w = aff_lds + (size_t)((wave * 64) >> NPXL) * 3 * a.k_pad;  // this wave's sample
+  const bool aff_relu = AFF && a.aff_relu;
 
   f32x16 acc[CBW][2];
 #pragma unroll
@@ -331,6 +335,12 @@ __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem
         // packed fp16 fma (v_pk_fma_f16, one rounding like the fp32-then-convert form it replaces, 1/6 of the VALU ops)
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) bf[rb] = __builtin_elementwise_fma(bf[rb], sc, sh);
+        if (aff_relu) {  // deferred GroupNorm + ReLU + embedding add of the producing layer (module-level path)
+          const f16x8 ad = *reinterpret_cast<const f16x8 *>(aff_w + 2 * a.k_pad + kc * BKT + piece * 8);
+          const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) bf[rb] = __builtin_elementwise_max(bf[rb], zero) + ad;
+        }
       }
 #pragma unroll
       for (int cb = 0; cb < CBW; ++cb)
@@ -1307,7 +1317,7 @@ template <int NPXL, int CBW, int NST, int BKT, bool AFF, bool GAT = false>
 int launch_gemm_glds(const GemmArgs &a, hipStream_t s) {
   constexpr int NSAMP = (1 << NPXL) >= TM ? 1 : TM >> NPXL;
   const size_t shm = (size_t)NST * (TM + (CBW < 2 ? 64 : 32 * CBW)) * BKT * 2 + CBW * (sizeof(SlideEpi) + 96 * 4) + 32 +
-                     (AFF ? (size_t)NSAMP * 2 * a.k_pad * 2 : 0);
+                     (AFF ? (size_t)NSAMP * 3 * a.k_pad * 2 : 0);
   if (shm > 80 * 1024 && BKT == 32 && NST <= 3) return -8;  // two workgroups per CU must fit
   if (shm > 160 * 1024) return -8;
   const int ntc = (a.n_cob + CBW - 1) / CBW, ntr = (a.rows + TM - 1) / TM;
@@ -1330,7 +1340,7 @@ int launch_gemm_glds(const GemmArgs &a, hipStream_t s) {
 template <int NPXL, bool AFF, bool GAT>
 int launch_gemm_occ3(const GemmArgs &a, hipStream_t s) {
   constexpr int NSAMP = (1 << NPXL) >= TM ? 1 : TM >> NPXL;
-  const size_t shm = (size_t)2 * (TM + 64) * 32 * 2 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32 + (AFF ? (size_t)NSAMP * 2 * a.k_pad * 2 : 0);
+  const size_t shm = (size_t)2 * (TM + 64) * 32 * 2 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32 + (AFF ? (size_t)NSAMP * 3 * a.k_pad * 2 : 0);
   if (shm > 53 * 1024) return -8;  // three workgroups per CU must fit
   const int ntc = (a.n_cob + 1) / 2, ntr = (a.rows + TM - 1) / TM;
   const int grid = ((ntr + 7) / 8) * 8 * ntc;
@@ -1399,6 +1409,15 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
   GemmArgs a;
   a.X = o.p[0]; a.W = o.p[1]; a.epi = (const SlideEpi *)o.p[2];
   a.in_scale = (const float *)o.p[3]; a.in_shift = (const float *)o.p[4];
+  // deferred normalisation (no gather): p[11] = add vectors, f[1] = tiles per sample, f[2] = add_bs, f[3] = 2 * add_n + relu
+  a.in_add = nullptr; a.aff_relu = 0; a.add_bs = 0; a.add_n = 0; a.aff_tps = 1;
+  if (a.in_scale && !o.p[8]) {
+    a.in_add = (const float *)o.p[11];
+    a.aff_tps = (int)o.f[1] > 1 ? (int)o.f[1] : 1;
+    a.add_bs = (int)o.f[2];
+    a.add_n = (int)o.f[3] >> 1;
+    a.aff_relu = (int)o.f[3] & 1;
+  }
   a.dbg = (unsigned long long *)o.p[5];
   a.stagger = (int)(o.f[0] * 100.f);
   a.sched = (int *)o.p[7];

@@ -21,6 +21,12 @@ struct GemmArgs {
   const void *W;
   const SlideEpi *epi;
   const float *in_scale, *in_shift;
+  // deferred normalisation of the module-level path (ring kernels with the input affine): the producer stored the RAW
+  // convolution output, this GEMM applies x' = relu(x * scale + shift) + add while the fragments go from LDS to MFMA.
+  // aff_relu: ReLU after the affine; in_add [sample][add_bs] (first add_n channels) or NULL; aff_tps: 256-row tiles per
+  // sample (the sample of tile t is t / aff_tps; 1 in the DDPM plans)
+  const float *in_add;
+  int aff_relu, add_bs, add_n, aff_tps;
   int rows, x_ld, k_pad, n_cob, in_bs;
   int w_cm;                 // LDS-DMA ring kernels: W is CHUNK-MAJOR [k_pad / 32][n_cob * 32][32] (X is chunk-major
                             // [k / 32][rows][32] when x_ld == 32): a wave's 16 rows x 64 B of one LDS-DMA instruction are then

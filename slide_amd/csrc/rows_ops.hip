@@ -452,17 +452,20 @@ int launch_rows(const SlideOp &o, hipStream_t s) {
       nchunk = nchunk < 1 ? 1 : nchunk > 64 ? 64 : nchunk;
       const int rpc = (S + nchunk - 1) / nchunk;
       nchunk = (S + rpc - 1) / rpc;
-      // scratch: [B][nchunk <= 64][ld][2] partial sums, then [B][2][ld] scale / shift
-      float *ssp = G > 0 ? (float *)o.p[5] + (size_t)B * 64 * ld * 2 : nullptr;
-      if (G > 0 && !o.p[7])
+      // scratch: [B][nchunk <= 64][ld][2] partial sums, then [B][2][ld] scale / shift (or the caller's p[9]).
+      // flags & 4: statistics + finalisation only (the consumer GEMM applies scale / shift while it loads: deferred
+      // normalisation); flags & 8: apply only, with the scale / shift of an earlier finalise-only call in p[9]
+      float *ssp = G > 0 ? (o.p[9] ? (float *)o.p[9] : (float *)o.p[5] + (size_t)B * 64 * ld * 2) : nullptr;
+      if (G > 0 && !o.p[7] && !(flags & 8))
         hipLaunchKernelGGL(rows_gn_stats_kernel<T>, dim3(nchunk, B), dim3(256), 0, s, S, ld, rpc, flags & 1, (const T *)o.p[0],
                            (float *)o.p[5]);
-      if (G > 0)
+      if (G > 0 && !(flags & 8))
         hipLaunchKernelGGL(rows_gn_finalize_kernel, dim3(B), dim3(256), 0, s, S, ld, nchunk, G, n_norm, (const float *)o.p[5],
                            (const float *)o.p[1], (const float *)o.p[2], (const float *)o.p[7], (const float *)o.p[8], o.i[8],
                            ssp);
-      hipLaunchKernelGGL(rows_gn_apply_kernel<T>, dim3(nchunk, B), dim3(256), 0, s, S, ld, rpc, flags, (const T *)o.p[0], ssp,
-                         (const float *)o.p[3], o.i[6], (const T *)o.p[4], o.i[7], (T *)o.p[6]);
+      if (!(flags & 4))
+        hipLaunchKernelGGL(rows_gn_apply_kernel<T>, dim3(nchunk, B), dim3(256), 0, s, S, ld, rpc, flags, (const T *)o.p[0], ssp,
+                           (const float *)o.p[3], o.i[6], (const T *)o.p[4], o.i[7], (T *)o.p[6]);
       break;
     }
     case SLIDE_OP_ROWS_CONCAT_QK: {  // i: rows, K, C1, ldq, C2, ldk, ldo   p: q, k, out

@@ -22,7 +22,7 @@ OP_COPY_COLS = 7
 OP_ROWS_FROM_NCX, OP_ROWS_TO_NCX, OP_ROWS_GROUP, OP_ROWS_GN, OP_ROWS_CONCAT_QK, OP_ROWS_ATTN, OP_ROWS_POOL = 20, 21, 22, 23, 24, 25, 26
 GROUP_FP, GROUP_ABS, GROUP_CENTER, GROUP_NO_XYZ, GROUP_IDX32 = 1, 2, 4, 8, 16
 POOL_MAX, POOL_AVG, POOL_MAX_AVG = 0, 1, 2
-GN_PRE_RELU, GN_POST_RELU = 1, 2
+GN_PRE_RELU, GN_POST_RELU, GN_STATS_ONLY, GN_APPLY_ONLY = 1, 2, 4, 8
 
 
 def half_mode():
@@ -41,13 +41,17 @@ def _rop(kind, half, i, p):
 
 class Rows:
     """[B * S][ld] activation, `C` valid channels"""
-    __slots__ = ("data", "B", "S", "C", "stats")
+    __slots__ = ("data", "B", "S", "C", "stats", "pending")
 
     def __init__(self, data, B, S, C, stats=None):
         assert data.dim() == 2 and data.shape[0] == B * S and data.shape[1] % 32 == 0 and data.is_contiguous()
         self.data, self.B, self.S, self.C = data, B, S, C
         # (per-tile channel sums, sums of squares, of-relu?) published by the GEMM that produced `data`, or None
         self.stats = stats
+        # DEFERRED normalisation: `data` is still the raw convolution output; (scale / shift [B][2][ld] fp32, relu, addvec)
+        # stand for relu?(data * scale + shift) + addvec.  A following conv() applies it while it loads (no pass over the
+        # tensor); every other consumer materialises it first (`materialise`).
+        self.pending = None
 
     @property
     def ld(self):
@@ -81,6 +85,7 @@ def from_ncx(x, half=None):
 
 def to_ncx(r, spatial=None):
     """Rows -> (B, C, *spatial) fp32"""
+    materialise(r)
     out = torch.empty((r.B, r.C) + tuple(spatial if spatial is not None else (r.S,)), device=r.data.device, dtype=torch.float32)
     _run(_rop(OP_ROWS_TO_NCX, r.half, (r.B, r.C, r.S, r.ld), (r.data, out)))
     return out
@@ -98,6 +103,7 @@ def from_points(x, half=None):
 
 def to_points(r):
     """Rows -> (B, S, C) fp32"""
+    materialise(r)
     out = torch.empty(r.B, r.S, r.C, device=r.data.device, dtype=torch.float32)
     _run(make_op(OP_COPY_COLS, i=(r.rows, r.C, r.ld, r.C, int(r.half), 0), p=(r.data.data_ptr(), out.data_ptr())))
     return out
@@ -105,6 +111,9 @@ def to_points(r):
 
 def concat_cols(parts):
     """channel concatenation of Rows with equal (B, S); a part may also be a (B, S, c) fp32 tensor (coordinates)"""
+    for p in parts:
+        if isinstance(p, Rows):
+            materialise(p)
     first = next(p for p in parts if isinstance(p, Rows))
     B, S, half, dev = first.B, first.S, first.half, first.data.device
     widths = [p.C if isinstance(p, Rows) else p.shape[-1] for p in parts]
@@ -175,8 +184,18 @@ class _ConvPlan:
         n_cob = self.op_ // 32
         ntr = (rows + 255) // 256
         cbw = 4 if (self.half and n_cob >= 4 and ntr * ((n_cob + 3) // 4) >= 256) else 2
-        _run(make_op(OP_GEMM, i=(rows, self.kp, self.kp, n_cob, 8, 0, int(self.half), cbw, int(self.half), 0),
-                     p=(x.data.data_ptr(), self.W.data_ptr(), self.epi(out, st, stats == "relu").data_ptr(), None, None)))
+        sc = sh = add = None
+        f = (0.0, 0.0, 0.0, 0.0)
+        in_bs = 0
+        if x.pending is not None:  # deferred normalisation of the producing layer, applied to the fragments
+            ss, relu, addvec = x.pending
+            sc, sh, in_bs = ss.data_ptr(), ss.data_ptr() + 4 * x.ld, 2 * x.ld
+            add = None if addvec is None else addvec.data_ptr()
+            f = (0.0, float(x.S // 256), float(addvec.shape[1]) if addvec is not None else 0.0,
+                 float(2 * (addvec.shape[1] if addvec is not None else 0) + int(relu)))
+        _run(make_op(OP_GEMM, i=(rows, self.kp, self.kp, n_cob, 8, in_bs, int(self.half), cbw, int(self.half), 0), f=f,
+                     p=(x.data.data_ptr(), self.W.data_ptr(), self.epi(out, st, stats == "relu").data_ptr(), sc, sh,
+                        None, None, None, None, None, None, add)))
         return Rows(out, x.B, x.S, self.O, stats=None if st is None else (st[0], st[1], stats == "relu"))
 
 
@@ -184,8 +203,26 @@ def fused_stats():
     return os.environ.get("SLIDE_MODULE_STATS", "1") != "0"
 
 
+def deferral():
+    return half_mode() and os.environ.get("SLIDE_MODULE_DEFER", "1") != "0"
+
+
+def materialise(x):
+    """applies a deferred normalisation (one in-place pass); no-op otherwise"""
+    if x is not None and x.pending is not None:
+        ss, relu, addvec = x.pending
+        x.pending = None
+        _run(_rop(OP_ROWS_GN, x.half, (x.B, x.S, x.ld, 1, 0, GN_APPLY_ONLY | (GN_POST_RELU if relu else 0),
+                                       addvec.shape[1] if addvec is not None else 0, 0, 0),
+                  (x.data, None, None, addvec, None, None, x.data, None, None, ss)))
+    return x
+
+
 def conv(x, module, stats=None):
-    """HipConv1x1 / HipLinear applied to Rows (weights re-packed when the parameter changes); stats: see _ConvPlan.run"""
+    """HipConv1x1 / HipLinear applied to Rows (weights re-packed when the parameter changes); stats: see _ConvPlan.run.
+    A deferred normalisation of x is applied by the GEMM itself when its tiles do not straddle samples."""
+    if x.pending is not None and not (x.half and x.S % 256 == 0):
+        materialise(x)
     w = module.weight
     key = (w._version, w.data_ptr(), x.half)
     plan = module.__dict__.get("_rows_plan")
@@ -196,9 +233,14 @@ def conv(x, module, stats=None):
 
 
 # ----------------------------------------------------------------------------------------------------------- fused layers
-def norm_act(x, gn=None, pre_relu=False, relu=False, addvec=None, residual=None):
+def norm_act(x, gn=None, pre_relu=False, relu=False, addvec=None, residual=None, defer=False):
     """in place: x <- relu?(GroupNorm?(relu?(x))) + addvec[b] + residual.  gn: HipGroupNorm (num_groups over its first
-    num_channels channels, the rest pass through) or None."""
+    num_channels channels, the rest pass through) or None.
+    defer=True (the caller knows the next consumer is a conv()): only the statistics and the per-sample scale / shift are
+    computed; the tensor stays raw and the consumer GEMM normalises it while loading (x.pending).  pre_relu then requires that
+    the stored values are already the ReLU'd ones (a conv(..., stats="relu") output, or a concat_qk output)."""
+    materialise(residual)
+    assert x.pending is None
     if gn is None and not (pre_relu or relu or addvec is not None or residual is not None):
         return x
     G, n_norm = (gn.num_groups, gn.num_channels) if gn is not None else (0, 0)
@@ -212,10 +254,16 @@ def norm_act(x, gn=None, pre_relu=False, relu=False, addvec=None, residual=None)
     if residual is not None:
         assert residual.rows == x.rows and residual.half == x.half and residual.ld >= x.ld
     flags = (GN_PRE_RELU if pre_relu else 0) | (GN_POST_RELU if relu else 0)
+    ss = None
+    if defer and G and residual is None and deferral() and x.S % 256 == 0 and (st is not None or not pre_relu):
+        ss = torch.empty(x.B * 2 * x.ld, device=x.data.device, dtype=torch.float32)
+        flags |= GN_STATS_ONLY
     _run(_rop(OP_ROWS_GN, x.half, (x.B, x.S, x.ld, G, n_norm, flags, addvec.shape[1] if addvec is not None else 0,
                                    residual.ld if residual is not None else 0, x.S // 256 if st is not None else 0),
               (x.data, gn.weight if G else None, gn.bias if G else None, addvec, residual.data if residual is not None else None,
-               part, x.data, None if st is None else st[0], None if st is None else st[1])))
+               part, x.data, None if st is None else st[0], None if st is None else st[1], ss)))
+    if ss is not None:
+        x.pending = (ss, bool(relu), addvec)
     return x
 
 
@@ -231,6 +279,7 @@ def group(xyz, new_xyz, feat, idx, flags, d2=None, empty_counts=None, half=None)
     """grouped input of an SA / feature-map block (QueryAndGroup) or of a kNN feature-propagation block (group_knn):
     xyz (B,N,3), new_xyz (B,np,3), feat Rows [B*N] or None, idx (B,np,K) int64 (kNN) or int32 (ball query) -> Rows
     [B*np*K].  empty_counts (B,np): centres with count 0 become their own single neighbour with zero features."""
+    materialise(feat)
     B, N = xyz.shape[:2]
     npnt, K = idx.shape[1:]
     C = feat.C if feat is not None else 0
@@ -256,6 +305,7 @@ def gather_rows(feat, idx):
 
 def concat_qk(q, k, K):
     """relu([q(point) broadcast over the K neighbours | k(point, neighbour)]) -> Rows [rows of k]"""
+    materialise(q), materialise(k)
     assert k.rows == q.rows * K and q.half == k.half
     C = q.C + k.C
     out = _empty(k.rows, ru(C), k.half, k.data.device)
@@ -266,6 +316,7 @@ def concat_qk(q, k, K):
 def attend(scores, values, K, counts=None):
     """softmax over the K neighbour rows of each point (the first max(1, count) of them when counts (B, np) is given),
     weighted sum of the values -> Rows [B * S / K]"""
+    materialise(scores), materialise(values)
     assert scores.rows == values.rows and scores.C == values.C and scores.half == values.half
     pts = scores.rows // K
     out = _empty(pts, ru(scores.C), scores.half, scores.data.device)
@@ -276,6 +327,7 @@ def attend(scores, values, K, counts=None):
 
 def pool(x, K, mode, counts=None):
     """max / mean / [max | mean] over the K neighbour rows of each point -> Rows [B * S / K]"""
+    materialise(x)
     pts = x.rows // K
     out = _empty(pts, x.ld, x.half, x.data.device)
     _run(_rop(OP_ROWS_POOL, x.half, (pts, K, x.C, x.ld, out.shape[1], mode), (x.data, out, _counts32(counts, pts))))
