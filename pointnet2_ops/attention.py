@@ -72,7 +72,7 @@ class AttentionModule(nn.Module):
             layers = list(self.feat_out_conv)
             gn = next((l.group_norm for l in layers[1:] if isinstance(l, MyGroupNorm)), None)
             values = R.conv(grouped_out, layers[0], stats="raw" if gn is not None else None)
-            R.norm_act(values, gn, relu=any(isinstance(l, nn.ReLU) for l in layers[1:]))
+            R.norm_act(values, gn, relu=any(isinstance(l, nn.ReLU) for l in layers[1:]), defer=True)  # applied by attend()
         return R.attend(scores, values, K, counts)
 
     def forward(self, feat, grouped_feat, grouped_feat_out, count):

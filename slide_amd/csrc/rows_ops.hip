@@ -356,7 +356,8 @@ __global__ __launch_bounds__(256) void rows_concat_qk_kernel(int K, int C1, int 
 template <typename T>
 __global__ __launch_bounds__(256) void rows_attn_kernel(int K, int C, int lds_, int ldv, int ldo, const T *__restrict__ Sx,
                                                         const T *__restrict__ V, const int *__restrict__ counts,
-                                                        T *__restrict__ out, size_t total) {
+                                                        T *__restrict__ out, size_t total, const float *__restrict__ vss,
+                                                        int pps, int v_relu) {
   constexpr int VEC = 16 / sizeof(T);
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= total) return;
@@ -364,6 +365,13 @@ __global__ __launch_bounds__(256) void rows_attn_kernel(int K, int C, int lds_, 
   const size_t pt = gid / ppr;
   const int c0 = (int)(gid - pt * ppr) * VEC;
   const int kk = counts ? max(1, min(K, counts[pt])) : K;
+  // deferred normalisation of the values (vss [sample][scale | shift][ldv], pps points per sample): v' = relu?(v * scale + shift)
+  float vs[VEC], vh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    vs[j] = vss ? vss[((size_t)(pt / pps) * 2 + 0) * ldv + c0 + j] : 1.f;
+    vh[j] = vss ? vss[((size_t)(pt / pps) * 2 + 1) * ldv + c0 + j] : 0.f;
+  }
   const T *sp = Sx + pt * K * lds_ + c0;
   const T *vp = V + pt * K * ldv + c0;
   float m[VEC], l[VEC], acc[VEC];
@@ -385,7 +393,14 @@ __global__ __launch_bounds__(256) void rows_attn_kernel(int K, int C, int lds_, 
     const Pack<T, VEC> sv = *reinterpret_cast<const Pack<T, VEC> *>(sp + (size_t)k * lds_);
     const Pack<T, VEC> vv = *reinterpret_cast<const Pack<T, VEC> *>(vp + (size_t)k * ldv);
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) acc[j] += (float)vv.v[j] * (expf((float)sv.v[j] - m[j]) * l[j]);
+    for (int j = 0; j < VEC; ++j) {
+      float v = (float)vv.v[j];
+      if (vss) {
+        v = v * vs[j] + vh[j];
+        if (v_relu) v = fmaxf(v, 0.f);
+      }
+      acc[j] += v * (expf((float)sv.v[j] - m[j]) * l[j]);
+    }
   }
   Pack<T, VEC> r;
 #pragma unroll
@@ -477,7 +492,8 @@ int launch_rows(const SlideOp &o, hipStream_t s) {
     case SLIDE_OP_ROWS_ATTN: {  // i: points, K, C, lds, ldv, ldo   p: S, V, out
       const size_t total = (size_t)o.i[0] * (o.i[5] / (16 / (int)sizeof(T)));
       hipLaunchKernelGGL(rows_attn_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, o.i[1], o.i[2], o.i[3],
-                         o.i[4], o.i[5], (const T *)o.p[0], (const T *)o.p[1], (const int *)o.p[3], (T *)o.p[2], total);
+                         o.i[4], o.i[5], (const T *)o.p[0], (const T *)o.p[1], (const int *)o.p[3], (T *)o.p[2], total,
+                         (const float *)o.p[4], o.i[6] > 0 ? o.i[6] : 1, o.i[7]);
       break;
     }
     case SLIDE_OP_ROWS_POOL: {  // i: points, K, C, ldx, ldo, mode   p: x, out, counts

@@ -316,12 +316,18 @@ def concat_qk(q, k, K):
 def attend(scores, values, K, counts=None):
     """softmax over the K neighbour rows of each point (the first max(1, count) of them when counts (B, np) is given),
     weighted sum of the values -> Rows [B * S / K]"""
-    materialise(scores), materialise(values)
+    materialise(scores)
+    vss, v_relu = None, False
+    if values.pending is not None and values.pending[2] is None:  # deferred GroupNorm (+ ReLU) of the values: applied here
+        vss, v_relu, _ = values.pending
+        values.pending = None
+    else:
+        materialise(values)
     assert scores.rows == values.rows and scores.C == values.C and scores.half == values.half
     pts = scores.rows // K
     out = _empty(pts, ru(scores.C), scores.half, scores.data.device)
-    _run(_rop(OP_ROWS_ATTN, scores.half, (pts, K, scores.C, scores.ld, values.ld, out.shape[1]),
-              (scores.data, values.data, out, _counts32(counts, pts))))
+    _run(_rop(OP_ROWS_ATTN, scores.half, (pts, K, scores.C, scores.ld, values.ld, out.shape[1], scores.S // K, int(v_relu)),
+              (scores.data, values.data, out, _counts32(counts, pts), vss)))
     return Rows(out, scores.B, scores.S // K, scores.C)
 
 
