@@ -1615,6 +1615,7 @@ int run_op(const SlideOp &o, hipStream_t s) {
       break;
     }
     case SLIDE_OP_COPY_COLS: {
+      if (o.i[0] <= 0 || o.i[1] <= 0) break;  // nothing to copy (a zero-sized grid is a launch error)
       const dim3 g((o.i[0] * o.i[1] + 255) / 256), blk(256);
 #define CPY(TS, TD)                                                                                               \
   hipLaunchKernelGGL((copy_cols_kernel<TS, TD>), g, blk, 0, s, o.i[0], o.i[1], o.i[2], o.i[3], (const TS *)o.p[0], \

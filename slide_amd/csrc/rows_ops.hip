@@ -437,15 +437,18 @@ __global__ __launch_bounds__(256) void rows_pool_kernel(int K, int C, int ldx, i
 
 template <typename T>
 int launch_rows(const SlideOp &o, hipStream_t s) {
+  if (o.i[0] <= 0) return 0;  // no samples / rows / points: nothing to launch (a zero-sized grid is a launch error)
   switch (o.kind) {
     case SLIDE_OP_ROWS_FROM_NCX: {  // i: B, C, P, ld
       const int B = o.i[0], C = o.i[1], P = o.i[2], ld = o.i[3];
+      if (P <= 0) return 0;
       hipLaunchKernelGGL(rows_from_ncx_kernel<T>, dim3(ld / 32, (P + 31) / 32, B), dim3(256), 0, s, C, P, ld,
                          (const float *)o.p[0], (T *)o.p[1]);
       break;
     }
     case SLIDE_OP_ROWS_TO_NCX: {
       const int B = o.i[0], C = o.i[1], P = o.i[2], ld = o.i[3];
+      if (P <= 0 || C <= 0) return 0;
       hipLaunchKernelGGL(rows_to_ncx_kernel<T>, dim3((C + 31) / 32, (P + 31) / 32, B), dim3(256), 0, s, C, P, ld,
                          (const T *)o.p[0], (float *)o.p[1]);
       break;
@@ -454,6 +457,7 @@ int launch_rows(const SlideOp &o, hipStream_t s) {
       const int B = o.i[0], N = o.i[1], np = o.i[2], K = o.i[3], C = o.i[4], ldf = o.i[5], ldg = o.i[6], flags = o.i[7];
       if (ldg % 8 || (C > 0 && ldf % 8) || C + ((flags & 1) ? 11 : (flags & 8) ? 0 : 3 + ((flags & 2) ? 3 : 0) + ((flags & 4) ? 3 : 0)) > ldg) return -3;
       const size_t total = (size_t)B * np * K * (ldg / 8);
+      if (total == 0) return 0;
       hipLaunchKernelGGL(rows_group_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, N, np, K, C, ldf, ldg,
                          flags, (const float *)o.p[0], (const float *)o.p[1], (const T *)o.p[2], (const void *)o.p[3],
                          (const float *)o.p[4], (const int *)o.p[6], (T *)o.p[5], total);
@@ -462,6 +466,7 @@ int launch_rows(const SlideOp &o, hipStream_t s) {
     case SLIDE_OP_ROWS_GN: {  // i: B, S, ld, G, n_norm, flags, addvec_ld, res_ld   p: x, gamma, beta, addvec, residual, part, y
       const int B = o.i[0], S = o.i[1], ld = o.i[2], G = o.i[3], n_norm = o.i[4], flags = o.i[5];
       if (ld % 32 || ld > 1024 || G > 64 || (G > 0 && n_norm % G)) return -3;
+      if (S <= 0) return 0;
       const int rt = 256 / (ld / (16 / (int)sizeof(T)));
       int nchunk = (S + rt * 8 - 1) / (rt * 8);
       nchunk = nchunk < 1 ? 1 : nchunk > 64 ? 64 : nchunk;

@@ -178,6 +178,8 @@ class _ConvPlan:
         assert x.ld == self.kp and x.half == self.half, (x.ld, self.kp, x.half, self.half)
         rows = x.rows
         out = _empty(rows, self.op_, self.half, x.data.device)
+        if rows == 0:  # empty batch: nothing to launch
+            return Rows(out, x.B, x.S, self.O)
         st = None
         if stats is not None and x.S % 256 == 0 and fused_stats():
             st = (torch.empty(rows // 256, self.op_, device=out.device), torch.empty(rows // 256, self.op_, device=out.device))

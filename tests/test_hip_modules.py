@@ -326,3 +326,19 @@ def test_general_module_programs_against_torch(gpu_device):
         half_c = h.shape[1] // 2
         want = {"max": mx, "avg": avg, "avg_max": torch.cat([mx[:, :half_c], avg[:, half_c:]], dim=1)}[pooling]
         assert torch.allclose(cpu(nf), want, atol=3e-4, rtol=2e-4), (bn_first, activation, pooling, float((cpu(nf) - want).abs().max()))
+
+
+def test_empty_batch_flows_through_the_modules(gpu_device):
+    """B = 0 (the short last rank of a sharded run can be empty): every kernel launch is skipped, shapes are kept"""
+    from pointnet2_ops import pointnet2_modules as PM
+    att = {"use_attention_module": True, "attention_bn": True, "transform_grouped_feat_out": True, "last_activation": True}
+    d = gpu_device
+    sa = _randomise(PM.PointnetSAModule(mlp=[5, 16, 16, 32], npoint=8, radius=0, nsample=4, bn=True, use_xyz=True,
+                                        include_abs_coordinate=True, bias=True, res_connect=True, neighbor_def="nn",
+                                        attention_setting=att), d)
+    nx, nf = sa(torch.zeros(0, 20, 3, device=d), torch.zeros(0, 5, 20, device=d))
+    assert nx.shape == (0, 8, 3) and nf.shape == (0, 32, 8)
+    fp = _randomise(PM.PointnetKnnFPModule(mlp1=[32, 16, 16], mlp2=[16 + 5, 16, 16], K=3, bn=True, bias=True, res_connect=True,
+                                           attention_setting=att), d)
+    out = fp(torch.zeros(0, 20, 3, device=d), nx, torch.zeros(0, 5, 20, device=d), nf)
+    assert out.shape == (0, 16, 20)
