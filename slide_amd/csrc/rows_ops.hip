@@ -410,29 +410,37 @@ __global__ __launch_bounds__(256) void rows_attn_kernel(int K, int C, int lds_, 
 
 // pooling over the K neighbour rows of a point (pooling_features, pointnet2_modules.py:179-211): mode 0 max over all K
 // slots, 1 mean over the first max(1, counts[pt]) slots (all K without counts), 2 = max for the first C / 2 channels and
-// mean for the rest
+// mean for the rest.  One thread per (point, 16 bytes of channels).
 template <typename T>
 __global__ __launch_bounds__(256) void rows_pool_kernel(int K, int C, int ldx, int ldo, int mode, const T *__restrict__ x,
                                                         const int *__restrict__ counts, T *__restrict__ out, size_t total) {
+  constexpr int VEC = 16 / sizeof(T);
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= total) return;
-  const size_t pt = gid / ldo;
-  const int c = (int)(gid - pt * ldo);
-  if (c >= C) {
-    out[gid] = (T)0.f;
-    return;
+  const int ppr = ldo / VEC;
+  const size_t pt = gid / ppr;
+  const int c0 = (int)(gid - pt * ppr) * VEC;
+  const T *xp = x + pt * K * ldx + c0;
+  const int n = counts ? max(1, min(K, counts[pt])) : K;
+  float mx[VEC], sm[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { mx[j] = -INFINITY; sm[j] = 0.f; }
+  for (int k = 0; k < K; ++k) {
+    const Pack<T, VEC> v = *reinterpret_cast<const Pack<T, VEC> *>(xp + (size_t)k * ldx);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      mx[j] = fmaxf(mx[j], (float)v.v[j]);
+      if (k < n) sm[j] += (float)v.v[j];
+    }
   }
-  const T *xp = x + pt * K * ldx + c;
-  if (mode == 0 || (mode == 2 && c < C / 2)) {
-    float m = -INFINITY;
-    for (int k = 0; k < K; ++k) m = fmaxf(m, (float)xp[(size_t)k * ldx]);
-    out[gid] = (T)m;
-  } else {
-    const int n = counts ? max(1, min(K, counts[pt])) : K;
-    float a = 0.f;
-    for (int k = 0; k < n; ++k) a += (float)xp[(size_t)k * ldx];
-    out[gid] = (T)(a / (float)n);
+  Pack<T, VEC> r;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const int c = c0 + j;
+    const bool use_max = mode == 0 || (mode == 2 && c < C / 2);
+    r.v[j] = c < C ? (T)(use_max ? mx[j] : sm[j] / (float)n) : (T)0.f;
   }
+  *reinterpret_cast<Pack<T, VEC> *>(out + pt * ldo + c0) = r;
 }
 
 template <typename T>
@@ -502,7 +510,7 @@ int launch_rows(const SlideOp &o, hipStream_t s) {
       break;
     }
     case SLIDE_OP_ROWS_POOL: {  // i: points, K, C, ldx, ldo, mode   p: x, out, counts
-      const size_t total = (size_t)o.i[0] * o.i[4];
+      const size_t total = (size_t)o.i[0] * (o.i[4] / (16 / (int)sizeof(T)));
       hipLaunchKernelGGL(rows_pool_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, o.i[1], o.i[2], o.i[3],
                          o.i[4], o.i[5], (const T *)o.p[0], (const int *)o.p[2], (T *)o.p[1], total);
       break;
