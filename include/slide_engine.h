@@ -26,7 +26,14 @@ extern "C" {
 
 /* epilogue modes of one 32-channel output block */
 enum { SLIDE_EPI_RAW = 0, SLIDE_EPI_NORM = 1, SLIDE_EPI_STATS = 2 };
-enum { SLIDE_F_PRE_RELU = 1, SLIDE_F_POST_RELU = 2, SLIDE_F_OUT_F32 = 4 };
+enum { SLIDE_F_PRE_RELU = 1, SLIDE_F_POST_RELU = 2, SLIDE_F_OUT_F32 = 4,
+       /* PAIR residual (fp16 plans): the residual of row (sample, point p, slot j) is NOT a stored row but the sum of two
+        * per-point table rows, residual[sample*16 + q] + res_b[sample*16 + p] -- the first layer of an SA / FP block is linear
+        * in [neighbour features | coordinates], so its res_connect output separates into a neighbour term and a centre term.
+        * RES_PAIR: 16 x 16-row samples in NATURAL neighbour order (q = j; every point is a neighbour of every point).
+        * RES_PAIR_NBR: 16 x 8-row samples, q = nbr[(sample*16 + p)*16 + j] (the GEMM op's neighbour table) and the two
+        * per-row scalars of group_knn enter as + d2 * res_vd[c] + w * res_vw[c]. */
+       SLIDE_F_RES_PAIR = 8, SLIDE_F_RES_PAIR_NBR = 16 };
 /* MFMA precision of a GEMM: exact fp32 (v_mfma_f32_32x32x2_f32) or fp16 inputs / fp32 accumulate
  * (v_mfma_f32_32x32x16_f16) */
 enum { SLIDE_PREC_F32 = 0, SLIDE_PREC_F16 = 1 };
@@ -58,11 +65,14 @@ typedef struct SlideEpi {
   void *out;                  /* out[row*out_ld + c] */
   float *stats_sum;           /* stats_sum[b*stats_bs + c] (STATS) */
   float *stats_sq;
+  const void *res_b;          /* pair residual: centre-term table [B*16][res_ld] (activation type) */
+  const float *res_vd;        /* RES_PAIR_NBR: [32] coefficients of the squared distance ... */
+  const float *res_vw;        /* ... and of the interpolation weight for this block's channels */
 } SlideEpi;
 
 enum {
-  SLIDE_OP_GEMM = 1,        /* p: X, W, epi, in_scale, in_shift, [5] timeline buffer (instrumented builds only, else NULL), [6] SlideGnFin* (16-row launches with input affine: finalise the statistics in this launch), [7] 9 zeroed ints for the optional persistent tile scheduler (NULL = one tile per workgroup), [8] point-feature table + [9] neighbour table of the GATHER mode (first GEMM of an SA / FP block: the first f[1] 32-column chunks of X row (b, p, k) are read from row b*16 + idx[(b*16+p)*16+k] of the table with row length f[2], neighbours per point 2^f[3]; p[0] / x_ld then describe only the remaining columns; with p[8] NULL, p[9] is the neighbour table of gathered pre_add terms, SlideEpi.pre_add_shift < 0); [11] + f[1..3] with p[3] / p[4] set and no gather: DEFERRED NORMALISATION of the module-level path -- x' = relu?(x * scale + shift) + add applied to the X fragments, p[11] = add vectors [sample][f[2]] (or NULL), f[1] = 256-row tiles per sample, f[3] = 2 * (channels of add) + (ReLU ? 1 : 0); [10] non-NULL selects the X-stationary kernel for sample-wide fp16 layers whose 256-row X tile fits the LDS (one workgroup per row tile keeps X resident and computes every column tile, the weights stream through a small LDS-DMA ring; i[9] == 5 keeps the ring kernels); f[0]: start stagger in us for the persistent mode; i[9]: 0 = default ring, 1 = 64-deep chunks, 2 = eight-wave 256x256 tiles   i: rows, x_ld, k_pad, n_cob, npx_log2, in_bs, prec, cbw(2|4), lds_dma (bit 0: fp16 LDS-DMA ring kernels; bit 1: W is CHUNK-MAJOR [k_pad/32][n_cob*32][32] -- ring kernels of the 128- / 256-row samples only).  CHUNK-MAJOR X: with x_ld == 32 and k_pad > 32 the ring kernels read X as [k/32][rows][32] (chunk kc of row r at X + (kc*rows + r)*32); outputs / residuals use the same layout through SlideEpi's per-block pointer with out_ld / res_ld == 32 */
-  SLIDE_OP_PREP_POINTS = 2, /* p: x, xyz, feat0, knn_idx, knn_d2, [5] optional second copy of feat0, chunk-major [c/32][B*16][32], [6] SlidePrepCopy[i[4]] (device)   i: B, cx, ldf, prec, n_copies     (16 points / sample) */
+  SLIDE_OP_GEMM = 1,        /* ([12] / [13]: squared-distance / interpolation-weight tables fp32 [B*16][16] of a SLIDE_F_RES_PAIR_NBR residual, with [9] the neighbour table)  p: X, W, epi, in_scale, in_shift, [5] timeline buffer (instrumented builds only, else NULL), [6] SlideGnFin* (16-row launches with input affine: finalise the statistics in this launch), [7] 9 zeroed ints for the optional persistent tile scheduler (NULL = one tile per workgroup), [8] point-feature table + [9] neighbour table of the GATHER mode (first GEMM of an SA / FP block: the first f[1] 32-column chunks of X row (b, p, k) are read from row b*16 + idx[(b*16+p)*16+k] of the table with row length f[2], neighbours per point 2^f[3]; p[0] / x_ld then describe only the remaining columns; with p[8] NULL, p[9] is the neighbour table of gathered pre_add terms, SlideEpi.pre_add_shift < 0); [11] + f[1..3] with p[3] / p[4] set and no gather: DEFERRED NORMALISATION of the module-level path -- x' = relu?(x * scale + shift) + add applied to the X fragments, p[11] = add vectors [sample][f[2]] (or NULL), f[1] = 256-row tiles per sample, f[3] = 2 * (channels of add) + (ReLU ? 1 : 0); [10] non-NULL selects the X-stationary kernel for sample-wide fp16 layers whose 256-row X tile fits the LDS (one workgroup per row tile keeps X resident and computes every column tile, the weights stream through a small LDS-DMA ring; i[9] == 5 keeps the ring kernels); f[0]: start stagger in us for the persistent mode; i[9]: 0 = default ring, 1 = 64-deep chunks, 2 = eight-wave 256x256 tiles   i: rows, x_ld, k_pad, n_cob, npx_log2, in_bs, prec, cbw(2|4), lds_dma (bit 0: fp16 LDS-DMA ring kernels; bit 1: W is CHUNK-MAJOR [k_pad/32][n_cob*32][32] -- ring kernels of the 128- / 256-row samples only).  CHUNK-MAJOR X: with x_ld == 32 and k_pad > 32 the ring kernels read X as [k/32][rows][32] (chunk kc of row r at X + (kc*rows + r)*32); outputs / residuals use the same layout through SlideEpi's per-block pointer with out_ld / res_ld == 32 */
+  SLIDE_OP_PREP_POINTS = 2, /* p: x, xyz, feat0, knn_idx, knn_d2, [5] optional second copy of feat0, chunk-major [c/32][B*16][32], [6] SlidePrepCopy[i[4]] (device), [7] optional knn_w [B*16][16]: group_knn's interpolation weights of the 8 nearest (pointnet2_utils.py:510-513), 0 beyond   i: B, cx, ldf, prec, n_copies     (16 points / sample) */
   SLIDE_OP_ASSEMBLE_SA = 3, /* p: xyz, feat, knn_idx, g            i: B, C, ldf, ldg, K, prec, c_begin (0 = all columns; else only columns >= c_begin), ld_out */
   SLIDE_OP_ASSEMBLE_FP = 4, /* p: xyz, feat, knn_idx, knn_d2, g    i: B, C, ldf, ldg, K, prec, c_begin, ld_out */
   SLIDE_OP_FINALIZE_GN = 5, /* p: sum, sq, gid, gstart, gend, gamma, beta, scale, shift  i: B, C, bs   f: inv_count */
@@ -76,6 +86,27 @@ enum {
   SLIDE_OP_SYNC = 14,       /* i: from_lane, to_lane -- lane `to` waits for everything issued so far on lane `from` */
   SLIDE_OP_GROUPNORM_NCHW = 13,/* p: x, gamma, beta, y (NCHW fp32)   i: B, C, HW, G, n_norm, relu  (module-level path) */
   SLIDE_OP_ATTN_TAIL = 16,  /* fp16: scores GEMM + values GEMM (GroupNorm, ReLU) + softmax-weighted sum over the neighbours in one launch.  p: u, W5, mo, Wv, out, vec [bias_s | bias_v | gamma | beta][n_cob*32], [6] optional chunk-major copy of out [c/32][points][32] (a gather table of the next block: SLIDE_OP_GEMM f[2] == 32 reads p[8] that way), [7] optional copy of the first f[3] channels into another per-point buffer with leading dimension f[2]   i: rows, u_ld, k1, mo_ld, k2, n_cob, npx_log2, gs, n_norm, out_ld   f: 1 / (gs * rows per sample), [1] != 0: both weight matrices chunk-major [k/32][n_cob*32][32]; u / mo are chunk-major [k/32][rows][32] when their ld is 32 */
+  SLIDE_OP_GEMM_GX = 17,    /* fp16 "generated-X" GEMM of the pair decomposition (gemm_gx.hip): the first layer of an SA / FP
+                             * block is linear in [neighbour features | coordinates], so its output for row (point p, slot j) is ta[q] + tb[p]
+                             * (q = the slot's neighbour) -- the 256- / 128-row activation this GEMM consumes is never stored: a workgroup keeps
+                             * the sample's two 16-row tables in LDS and builds its MFMA B fragments from them,
+                             *   mode 0: x = max(ta[q] + tb[p] + d2 vd + w vw, 0) + add        (tables pre-normalised by SLIDE_OP_PAIR_NORM)
+                             *   mode 1: x = max(ta[q] + tb[p] + d2 vd + w vw, 0) * scale + shift
+                             * only the weights stream (LDS-DMA ring).  npx_log2 8: 16 x 16 rows in NATURAL neighbour order (q = j); 7: 16 x 8
+                             * rows, q = nbr[(b*16+p)*16+j], d2 / w = the slot's squared distance / interpolation weight (vd = vw = 0 for 8).
+                             * p: [0] ta, [1] W chunk-major [k_pad/32][n_cob*32][32], [2] epi, [3] scale, [4] shift (fp32 [b*in_bs + k], mode 1),
+                             *    [5] tb, [6] add vectors fp32 [idx*add_idx_stride + b*add_bs + k] or NULL (mode 0), [7] idx (device int) or NULL,
+                             *    [8] nbr table, [9] d2, [10] w (fp32 [B*16][16]; npx_log2 7), [11] vd | vw fp32 [b*vbs + {0, vbs/2} + k] (SLIDE_OP_PAIR_NORM's vv, column offset applied) or NULL
+                             * i: rows, t_ld (elements between table rows), k_pad, n_cob, npx_log2, in_bs, mode, add_bs, add_idx_stride, vbs */
+  SLIDE_OP_PAIR_NORM = 18,  /* per-point tables of the pair decomposition: a[q][c] = y[q][c] + wa[c] . xyz[q], b[p][c] = wb[c] . xyz[p]; for each
+                             * 32-channel block by its SlideEpi (mode, gs, n_norm, inv_count, gamma, beta, stats_*; bias already in y):
+                             *   NORM : GroupNorm statistics over the sample's (p, slot) pairs of a[q] + b[p] (+ d2 vd + w vw), folded into the
+                             *          tables: ta = a g + (beta - mean g), tb = b g, vv = (vd g | vw g) with g = gamma rstd
+                             *   STATS: per-channel sums / sums of squares of max(a[q] + b[p] + ..., 0); ta = a, tb = b, vv = (vd | vw)
+                             *   RAW  : ta = a, tb = b, vv = (vd | vw)
+                             * p: [0] y fp32 [B*16][ld], [1] xyz fp32 [B*16][3], [2] wa fp32 [ld][4], [3] wb fp32 [ld][4], [4] epi [ld/32],
+                             *    [5] ta, [6] tb (fp16 [B*16][ld]), [7] nbr table or NULL (natural order, K = 16), [8] d2, [9] w, [10] vd | vw
+                             *    fp32 [2][ld] (K = 8), [11] vv fp32 [B][2][ld] out (K = 8)      i: B, ld, K */
   SLIDE_OP_TRANSPOSE = 15,  /* p: in, out (fp32)   i: B, R, C, in_ld, out_ld, in_batch_stride, out_batch_stride, out_is_fp16: out[b][c][r] = in[b][r][c] (module-level path: NCHW <-> row-major) */
   /* Row-major module-level path (rows_ops.hip): an activation is [B * S][ld] (S rows per sample, ld = channels rounded up
    * to 32, pad columns zero), fp32 or -- i[9] = 1 -- fp16.  Replaces the reference's NCHW tensor program of
@@ -115,7 +146,7 @@ typedef struct SlideOp {
   int32_t kind;
   int32_t i[11];
   float f[4];
-  void *p[12];
+  void *p[14];
 } SlideOp;
 
 /* launches ops[0..n) in order on `stream` (HOST array).  Safe inside hipGraph stream capture. */

@@ -15,6 +15,9 @@
 // gemm_xs.hip: X-stationary kernel (-8: the X tile does not fit the LDS, -4: no such instantiation)
 int slide_launch_rows_op(const SlideOp &o, hipStream_t s);  // rows_ops.hip
 int slide_launch_gemm_xs(const GemmArgs &a, int npxl, int cbw, bool aff, bool gat, int want_occ, hipStream_t s);
+// gemm_gx.hip: generated-X GEMM and the per-point table normalisation of the pair decomposition
+int slide_launch_gemm_gx(const SlideOp &o, hipStream_t s);
+int slide_launch_pair_norm(const SlideOp &o, hipStream_t s);
 
 namespace {
 
@@ -889,9 +892,10 @@ __global__ __launch_bounds__(256) void prep_points_kernel(int cx, int ldf, const
                                                           float *__restrict__ xyz, T *__restrict__ feat0,
                                                           int *__restrict__ kidx, float *__restrict__ kd2,
                                                           T *__restrict__ feat0_cm, const SlidePrepCopy *__restrict__ copies,
-                                                          int n_copies) {
+                                                          int n_copies, float *__restrict__ kw) {
   __shared__ float sp[48];
   __shared__ float sd[16][17];
+  __shared__ float ssort[16][17];
   const int b = blockIdx.x, tid = threadIdx.x;
   const float *xb = x + (size_t)b * 16 * cx;
   if (tid < 48) {
@@ -931,6 +935,14 @@ __global__ __launch_bounds__(256) void prep_points_kernel(int cx, int ldf, const
   }
   kidx[((size_t)b * 16 + i) * 16 + rank] = j;
   kd2[((size_t)b * 16 + i) * 16 + rank] = d;
+  if (kw) {  // group_knn's interpolation weights of the 8 nearest, from SQUARED distances (pointnet2_utils.py:510-513)
+#pragma clang fp contract(off)
+    ssort[i][rank] = d;
+    __syncthreads();
+    float norm = 0.f;
+    for (int kk = 0; kk < 8; ++kk) norm += 1.0f / (ssort[i][kk] + 1e-8f);
+    kw[((size_t)b * 16 + i) * 16 + j] = j < 8 ? (1.0f / (ssort[i][j] + 1e-8f)) / norm : 0.f;
+  }
 }
 
 // QueryAndGroup feature assembly ('nn', use_xyz, abs + center coordinates; pointnet2_utils.py:383-430):
@@ -1423,6 +1435,8 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
   a.sched = (int *)o.p[7];
   a.gfeat = o.p[8]; a.gidx = (const int *)o.p[9];
   a.gn_fin = (const SlideGnFin *)o.p[6];
+  a.gx_d2 = (const float *)o.p[12]; a.gx_w = (const float *)o.p[13];  // PAIR_NBR residual (with p[9] the neighbour table)
+  a.gx_ta = a.gx_tb = nullptr; a.gx_vv = nullptr; a.gx_add_idx = nullptr;
   a.g_nsplit = (int)o.f[1]; a.g_ldf = (int)o.f[2]; a.g_klog2 = (int)o.f[3];
   a.rows = o.i[0]; a.x_ld = o.i[1]; a.k_pad = o.i[2]; a.n_cob = o.i[3]; a.in_bs = o.i[5];
   const int npxl = o.i[4], prec = o.i[6], cbw = o.i[7], glds = o.i[8] & 1;
@@ -1564,11 +1578,11 @@ int run_op(const SlideOp &o, hipStream_t s) {
       if (o.i[3] == SLIDE_PREC_F16)
         hipLaunchKernelGGL(prep_points_kernel<_Float16>, dim3(o.i[0]), dim3(256), 0, s, o.i[1], o.i[2],
                            (const float *)o.p[0], (float *)o.p[1], (_Float16 *)o.p[2], (int *)o.p[3], (float *)o.p[4],
-                           (_Float16 *)o.p[5], (const SlidePrepCopy *)o.p[6], o.i[4]);
+                           (_Float16 *)o.p[5], (const SlidePrepCopy *)o.p[6], o.i[4], (float *)o.p[7]);
       else
         hipLaunchKernelGGL(prep_points_kernel<float>, dim3(o.i[0]), dim3(256), 0, s, o.i[1], o.i[2],
                            (const float *)o.p[0], (float *)o.p[1], (float *)o.p[2], (int *)o.p[3], (float *)o.p[4],
-                           (float *)o.p[5], (const SlidePrepCopy *)o.p[6], o.i[4]);
+                           (float *)o.p[5], (const SlidePrepCopy *)o.p[6], o.i[4], (float *)o.p[7]);
       break;
     case SLIDE_OP_ASSEMBLE_SA:
     case SLIDE_OP_ASSEMBLE_FP: {
@@ -1652,6 +1666,10 @@ int run_op(const SlideOp &o, hipStream_t s) {
       break;
     case SLIDE_OP_ATTN_TAIL:
       return run_attn_tail(o, s);
+    case SLIDE_OP_GEMM_GX:
+      return slide_launch_gemm_gx(o, s);
+    case SLIDE_OP_PAIR_NORM:
+      return slide_launch_pair_norm(o, s);
     case SLIDE_OP_TRANSPOSE:
       if (o.i[7])  // fp16 destination (module-level throughput mode)
         hipLaunchKernelGGL(transpose_kernel<_Float16>, dim3((o.i[2] + 31) / 32, (o.i[1] + 31) / 32, o.i[0]), dim3(256), 0, s,

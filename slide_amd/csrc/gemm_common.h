@@ -40,6 +40,12 @@ struct GemmArgs {
   int *sched;               // persistent-mode tile counters (9 ints, zero), or nullptr
   int stagger;              // start delay (10 ns units) of the workgroups in odd wave slots, 0 = none
   unsigned long long *dbg;  // optional per-workgroup timeline (tools/gemm_timeline.py): 16 x 100 MHz stamps per workgroup
+  // pair decomposition (gemm_gx.hip; SLIDE_OP_GEMM_GX in include/slide_engine.h): per-point tables the X operand is generated
+  // from, the per-slot scalars of group_knn and their coefficient vectors; gx_d2 / gx_w also serve the PAIR_NBR residual
+  const void *gx_ta, *gx_tb;
+  const float *gx_d2, *gx_w, *gx_vv;
+  const int *gx_add_idx;
+  int gx_ld, gx_mode, gx_add_idx_stride, gx_vbs;
 };
 
 namespace {
@@ -122,7 +128,7 @@ template <> __device__ __forceinline__ void store4<_Float16>(_Float16 *p, float4
 // CBW = 32-channel output blocks per wave; the workgroup tile is 256 rows x (32*CBW) channels: the four waves
 // split the rows (64 each) and share the W panel, so every X element fetched from L2/HBM feeds 32*CBW MACs.
 constexpr int EPI_DW = (int)(sizeof(SlideEpi) / 4);
-static_assert(sizeof(SlideEpi) == 136, "descriptor layout is read by dword index in gemm_epilogue");
+static_assert(sizeof(SlideEpi) == 160, "descriptor layout is read by dword index in gemm_epilogue");
 
 // copies the CBW epilogue descriptors of this workgroup and their per-channel vectors [cb][bias | gamma | beta][32]
 // into LDS (visible after the caller's next barrier)
@@ -178,6 +184,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     // global reads of the store phase, issued first so that their latency overlaps the statistics / normalisation work
     constexpr bool kHalf = std::is_same<T, _Float16>::value;
     const bool wide16 = kHalf && !(flags & SLIDE_F_OUT_F32);
+    const bool pair = (flags & (SLIDE_F_RES_PAIR | SLIDE_F_RES_PAIR_NBR)) != 0;  // (fp16 rows, 128- / 256-row samples only)
     const GLOBAL_AS float *addv = e_addvec;
     static_assert(RB == 2 || NPXL < 6, "one row block per wave only for samples of at most 32 rows");
     constexpr int NA = NPXL >= 6 ? 1 : RB;  // a wave's 64 rows belong to one sample when NPX >= 64
@@ -196,12 +203,47 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
             if (addv && ok) apre[rb][q] = gload4(addv + (size_t)(row >> NPXL) * e_addvec_bs + 8 * q + 4 * half);
           }
         }
+        // pair residual: the row's value is the sum of two per-point table rows (+ the two per-slot terms of group_knn)
+        size_t ra_row = (size_t)row, rb_row = 0;
+        _Float16 sd2 = (_Float16)0.f, sw = (_Float16)0.f;
+        if constexpr (kHalf && NPXL >= 7) {
+          if (pair && ok) {
+            const int smp = row >> NPXL, pxl = row & (NPX - 1);
+            if (flags & SLIDE_F_RES_PAIR) {
+              ra_row = (size_t)(smp * 16 + (pxl & 15)); rb_row = (size_t)(row >> 4);
+            } else {
+              const int slot = (smp * 16 + (pxl >> 3)) * 16 + (pxl & 7);
+              ra_row = (size_t)(smp * 16 + a.gidx[slot]); rb_row = (size_t)(row >> 3);
+              sd2 = (_Float16)a.gx_d2[slot]; sw = (_Float16)a.gx_w[slot];
+            }
+          }
+        }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
           rpre[rb][p] = u32x4{0u, 0u, 0u, 0u};
           if constexpr (kHalf)
-            if (wide16 && resid && ok)
-              rpre[rb][p] = *(const GLOBAL_AS u32x4 *)(resid + (size_t)row * e_res_ld + 16 * p + 8 * half);
+            if (wide16 && resid && ok) {
+              rpre[rb][p] = *(const GLOBAL_AS u32x4 *)(resid + ra_row * e_res_ld + 16 * p + 8 * half);
+              if constexpr (NPXL >= 7) {
+                if (pair) {
+                  const u32x4 tb = *(const GLOBAL_AS u32x4 *)(gptr<const T>(rdp(34)) + rb_row * e_res_ld + 16 * p + 8 * half);
+                  f16x8 r8 = __builtin_bit_cast(f16x8, rpre[rb][p]) + __builtin_bit_cast(f16x8, tb);
+                  if (flags & SLIDE_F_RES_PAIR_NBR) {
+                    const GLOBAL_AS float *vd = gptr<const float>(rdp(36)) + 16 * p + 8 * half;
+                    const GLOBAL_AS float *vw = gptr<const float>(rdp(38)) + 16 * p + 8 * half;
+                    const float4 d0 = gload4(vd), d1 = gload4(vd + 4), w0 = gload4(vw), w1 = gload4(vw + 4);
+                    const f16x8 vd8 = {(_Float16)d0.x, (_Float16)d0.y, (_Float16)d0.z, (_Float16)d0.w,
+                                       (_Float16)d1.x, (_Float16)d1.y, (_Float16)d1.z, (_Float16)d1.w};
+                    const f16x8 vw8 = {(_Float16)w0.x, (_Float16)w0.y, (_Float16)w0.z, (_Float16)w0.w,
+                                       (_Float16)w1.x, (_Float16)w1.y, (_Float16)w1.z, (_Float16)w1.w};
+                    const f16x8 s8 = {sd2, sd2, sd2, sd2, sd2, sd2, sd2, sd2}, t8 = {sw, sw, sw, sw, sw, sw, sw, sw};
+                    r8 = __builtin_elementwise_fma(s8, vd8, r8);
+                    r8 = __builtin_elementwise_fma(t8, vw8, r8);
+                  }
+                  rpre[rb][p] = __builtin_bit_cast(u32x4, r8);
+                }
+              }
+            }
         }
       }
     }

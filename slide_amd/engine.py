@@ -18,12 +18,13 @@ import torch
 from ._lib import SlideHipError, check, lib
 
 EPI_RAW, EPI_NORM, EPI_STATS = 0, 1, 2
-F_PRE_RELU, F_POST_RELU, F_OUT_F32 = 1, 2, 4
+F_PRE_RELU, F_POST_RELU, F_OUT_F32, F_RES_PAIR, F_RES_PAIR_NBR = 1, 2, 4, 8, 16
 PREC = {"fp32": 0, "fp16": 1}
 (OP_GEMM, OP_PREP_POINTS, OP_ASSEMBLE_SA, OP_ASSEMBLE_FP, OP_FINALIZE_GN, OP_ATTN_COMBINE, OP_COPY_COLS, OP_TEMB,
  OP_COND, OP_UPDATE_POS, OP_UPDATE_FEAT, OP_ADVANCE_T) = range(1, 13)
 OP_SYNC = 14
 OP_ATTN_TAIL = 16
+OP_GEMM_GX, OP_PAIR_NORM = 17, 18
 
 
 class SlideEpi(ctypes.Structure):
@@ -35,7 +36,8 @@ class SlideEpi(ctypes.Structure):
                 ("bias", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
                 ("addvec", ctypes.c_void_p), ("addvec_idx", ctypes.c_void_p), ("residual", ctypes.c_void_p),
                 ("pre_add", ctypes.c_void_p), ("out", ctypes.c_void_p),
-                ("stats_sum", ctypes.c_void_p), ("stats_sq", ctypes.c_void_p)]
+                ("stats_sum", ctypes.c_void_p), ("stats_sq", ctypes.c_void_p),
+                ("res_b", ctypes.c_void_p), ("res_vd", ctypes.c_void_p), ("res_vw", ctypes.c_void_p)]
 
 
 class SlideGnFin(ctypes.Structure):
@@ -45,7 +47,7 @@ class SlideGnFin(ctypes.Structure):
 
 class SlideOp(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("i", ctypes.c_int32 * 11), ("f", ctypes.c_float * 4),
-                ("p", ctypes.c_void_p * 12)]
+                ("p", ctypes.c_void_p * 14)]
 
 
 def ru(x, m=32):
@@ -112,6 +114,7 @@ class DenoiserEngine:
     NP = 16  # latent points per sample
     # chunk-major storage (see _buf): off unless __init__ enables it (bare plan builders in tests / tools stay row-major)
     use_cm = False
+    use_gx = False
     _cm = frozenset()
     _cm_copy = {}
 
@@ -146,6 +149,8 @@ class DenoiserEngine:
         # chunk-major activations / weights for the 128- and 256-row ring kernels (SLIDE_CM=0: row-major everywhere, A/B)
         self.use_cm = (self.prec == 1 and self.use_glds and self.glds_nst != 1 and _os.environ.get("SLIDE_CM", "1") != "0"
                        and not _os.environ.get("SLIDE_XS", ""))
+        # pair decomposition of the blocks' first layers + generated-X GEMMs (csrc/gemm_gx.hip; SLIDE_GX=0: the round-2 plan)
+        self.use_gx = self.use_cm and _os.environ.get("SLIDE_GX", "1") != "0"
         self._cm = set()
         self._cm_copy = {}  # per-point table (data_ptr) -> its chunk-major copy, written by the table's producer as well
         self.ops = []
@@ -207,14 +212,18 @@ class DenoiserEngine:
         return off
 
     def _gemm(self, X, npx_log2, segs, in_cols=None, in_affine=None, k_logical=None, gather=None, gn_fin=None,
-              pre_gather=None):
+              pre_gather=None, gx=None, pair_tabs=None):
         """X: input buffer [rows][ld].  segs: list of dicts describing consecutive output segments:
              w (O,I) bias (O) | out (tensor) out_coff | mode flags | gn=(gamma,beta) for NORM | layout (gn_layout) |
              addvec=(tensor, off, bs) | residual tensor | bcast | stats=(sum,sq tensors, coff, scale)
            in_cols: physical column index of every logical input channel (None = identity)."""
-        rows, ld = X.shape
-        x_ld = self._ldp(X)
-        assert not self._is_cm(X) or (npx_log2 >= 7 and gather is None)
+        if gx is not None:  # generated-X GEMM of the pair decomposition (SLIDE_OP_GEMM_GX): X is never stored
+            rows, ld, x_ld = gx["rows"], gx["k_pad"], 32
+            assert X is None and gather is None and gn_fin is None and npx_log2 in (7, 8) and self.use_cm
+        else:
+            rows, ld = X.shape
+            x_ld = self._ldp(X)
+            assert not self._is_cm(X) or (npx_log2 >= 7 and gather is None)
         if gather is not None:  # (feature table, neighbour table, K, chunks read from the table): X holds the remaining columns
             ld = gather[3] * 32 + ld
         npx = 1 << npx_log2
@@ -246,7 +255,7 @@ class DenoiserEngine:
         n_cob = W.shape[0] // 32
         # chunk-major weights [k / 32][n][32] for the ring kernels of the 128- / 256-row samples (the 16-row launches run the
         # split-K small-launch kernel, which reads row-major weights)
-        w_cm = bool(self.use_cm and npx_log2 >= 7)
+        w_cm = bool(self.use_cm and npx_log2 >= 7) or gx is not None
         Wst = np.ascontiguousarray(W.reshape(W.shape[0], ld // 32, 32).transpose(1, 0, 2)) if w_cm else W
         Wd = self.A.put(Wst, torch.float16 if self.prec == 1 else torch.float32)
         epis = (SlideEpi * n_cob)()
@@ -282,6 +291,23 @@ class DenoiserEngine:
                     if idx is not None:
                         e.addvec_idx = idx.data_ptr()
                         e.addvec_idx_stride = idx_stride
+                if sg.get("res_pair") is not None:
+                    # PAIR residual: residual(p, j) = ta[q] + tb[p] (+ d2 vd + w vw): (ta, tb fp16 tables, column offset,
+                    # vd | vw fp32 [2][Opad] for the 8-neighbour samples or None)
+                    rta, rtb, rcoff, rvv = sg["res_pair"]
+                    assert rta.dtype == torch.float16 and rta.shape == rtb.shape and rta.shape[0] == self.B * 16
+                    assert (rcoff + 32 * j) % 8 == 0 and rta.shape[1] >= rcoff + Opad
+                    e.residual = rta.data_ptr() + 2 * (rcoff + 32 * j)
+                    e.res_b = rtb.data_ptr() + 2 * (rcoff + 32 * j)
+                    e.res_ld = rta.shape[1]
+                    if rvv is None:
+                        assert npx_log2 == 8
+                        e.flags |= F_RES_PAIR
+                    else:
+                        assert npx_log2 == 7 and pair_tabs is not None
+                        e.flags |= F_RES_PAIR_NBR
+                        e.res_vd = rvv.data_ptr() + 4 * (32 * j)
+                        e.res_vw = rvv.data_ptr() + 4 * (Opad + 32 * j)
                 if sg.get("residual") is not None:
                     r = sg["residual"]
                     assert r.shape[0] == rows and r.shape[1] >= Opad and r.dtype == self.adt
@@ -309,6 +335,8 @@ class DenoiserEngine:
         in_bs = aff_off = 0
         if in_affine is not None:
             sc, sh, aff_off, in_bs = in_affine
+        if gx is not None:
+            return self._emit_gx(gx, npx_log2, rows, ld, n_cob, Wd, ed, segs, W, vec_list, in_affine, pair_tabs)
         assert X.dtype == self.adt
         # wide (128-channel) tiles only when the grid still covers the 256 CUs at least twice
         ntr = (rows + 255) // 256
@@ -361,8 +389,46 @@ class DenoiserEngine:
                                    None if gather is None else gtab.data_ptr(),
                                    (None if pre_gather is None else pre_gather.data_ptr()) if gather is None
                                    else gather[1].data_ptr(),
-                                   None if wfrag is None else wfrag.data_ptr())))
+                                   None if wfrag is None else wfrag.data_ptr(), None,
+                                   None if pair_tabs is None else pair_tabs[1].data_ptr(),
+                                   None if pair_tabs is None else pair_tabs[2].data_ptr())))
+        if pair_tabs is not None:  # PAIR_NBR residual: p[9] = neighbour table, p[12] / p[13] = squared distances / weights
+            assert gather is None and pre_gather is None
+            self.ops[-1].p[9] = pair_tabs[0].data_ptr()
         self.flops += 2 * rows * sum(int(s["w"].size) for s in segs)
+
+    def _emit_gx(self, gx, npx_log2, rows, ld, n_cob, Wd, ed, segs, W, vec_list, in_affine, pair_tabs):
+        """SLIDE_OP_GEMM_GX (include/slide_engine.h): gx = dict(ta, tb (fp16 tables [B*16][t_ld]), coff (first table column),
+        k_pad, rows, mode, add=(tensor, offset, per-sample stride, idx tensor or None, idx stride) or None, vv = per-sample
+        (vd | vw) fp32 [B][2][t_ld] of the 8-neighbour samples or None); pair_tabs = (neighbour, d2, w tables) for those"""
+        ta, tb, coff = gx["ta"], gx["tb"], gx["coff"]
+        assert ta.dtype == torch.float16 and ta.shape == tb.shape and coff % 8 == 0 and ta.shape[1] >= coff + ld
+        fl = 2 * rows * sum(int(s_["w"].size) for s_ in segs)
+        self.gemm_flops[len(self.ops)] = fl
+        rd = 2 * (rows >> npx_log2) * 16 * ld * 2 + W.size * 2
+        wr = sum(rows * v[2] * v[1]["out"].element_size() for v in vec_list)
+        self.gemm_bytes[len(self.ops)] = (rd, wr)
+        sc = sh = None
+        in_bs = aff_off = 0
+        if in_affine is not None:
+            sc, sh, aff_off, in_bs = in_affine
+        add = gx.get("add")
+        vv = gx.get("vv")
+        assert (npx_log2 == 7) == (pair_tabs is not None)
+        self._emit(make_op(OP_GEMM_GX,
+                           i=(rows, ta.shape[1], ld, n_cob, npx_log2, in_bs, gx["mode"], 0 if add is None else add[2],
+                              0 if add is None else add[4], 0 if vv is None else 2 * vv.shape[2]),
+                           p=(ta.data_ptr() + 2 * coff, Wd.data_ptr(), ed.data_ptr(),
+                              None if sc is None else sc.data_ptr() + 4 * aff_off,
+                              None if sh is None else sh.data_ptr() + 4 * aff_off,
+                              tb.data_ptr() + 2 * coff,
+                              None if add is None else add[0].data_ptr() + 4 * add[1],
+                              None if add is None or add[3] is None else add[3].data_ptr(),
+                              None if pair_tabs is None else pair_tabs[0].data_ptr(),
+                              None if pair_tabs is None else pair_tabs[1].data_ptr(),
+                              None if pair_tabs is None else pair_tabs[2].data_ptr(),
+                              None if vv is None else vv.data_ptr() + 4 * coff)))
+        self.flops += fl
 
     # ------------------------------------------------------------------ blocks
     def _mlp_segments(self, pfx, tvec, cvec, out1, res_out):
@@ -379,10 +445,27 @@ class DenoiserEngine:
         res = dict(w=self._w(pfx + ".res_connect.weight"), bias=sd[pfx + ".res_connect.bias"], mode=EPI_RAW, out=res_out)
         return first, res
 
-    def _mlp_tail(self, pfx, npx_log2, h1, cvec, r, final_out, final_coff=0):
-        """second_mlp (+fc_condition) [+ rest_mlp] + residual, writing the module output"""
+    def _mlp_tail(self, pfx, npx_log2, h1, cvec, r, final_out, final_coff=0, pair=None):
+        """second_mlp (+fc_condition) [+ rest_mlp] + residual, writing the module output.
+        pair (the block's pair decomposition, _pair_first): h1 and r are not buffers -- the first GEMM generates its input
+        from the pair tables (SLIDE_OP_GEMM_GX mode 0) and the residual enters as a PAIR residual"""
         sd = self.sd
-        rows = h1.shape[0]
+        rows = h1.shape[0] if pair is None else pair["rows"]
+
+        def first_gemm(seg_):
+            if pair is None:
+                return self._gemm(h1, npx_log2, [seg_])
+            lay1 = pair["lay1"]
+            self._gemm(None, npx_log2, [seg_], in_cols=lay1[0],
+                       gx=dict(ta=pair["ta"], tb=pair["tb"], coff=pair["off1"], k_pad=ru(lay1[1]), rows=rows, mode=0,
+                               add=pair["add1"], vv=pair["vv"]), pair_tabs=pair["tabs"])
+
+        def with_res(seg_):
+            if pair is None:
+                seg_["residual"] = r
+            else:
+                seg_["res_pair"] = (pair["ta"], pair["tb"], pair["offr"], pair["rvv"])
+            return seg_
         has_rest = (pfx + ".rest_mlp.0.weight") in sd
         c2 = sd[pfx + ".second_mlp.0.weight"].shape[0]
         seg = dict(w=self._w(pfx + ".second_mlp.0.weight"), bias=sd[pfx + ".second_mlp.0.bias"], mode=EPI_NORM,
@@ -393,17 +476,18 @@ class DenoiserEngine:
         if has_rest:
             h2 = self._buf(rows, c2, cm=npx_log2 >= 7)
             seg["out"] = h2
-            self._gemm(h1, npx_log2, [seg])
+            first_gemm(seg)
             c3 = sd[pfx + ".rest_mlp.0.weight"].shape[0]
-            seg3 = dict(w=self._w(pfx + ".rest_mlp.0.weight"), bias=sd[pfx + ".rest_mlp.0.bias"], mode=EPI_NORM,
-                        flags=F_POST_RELU, layout=gn_layout(c3), residual=r, out=final_out, out_coff=final_coff,
-                        gn=(sd[pfx + ".rest_mlp.1.group_norm.weight"], sd[pfx + ".rest_mlp.1.group_norm.bias"]))
-            self._gemm(h2, npx_log2, [seg3])
+            assert np.array_equal(gn_layout(c2)[0], np.arange(c2)), "second_mlp width with padded GroupNorm groups"
+            seg3 = with_res(dict(w=self._w(pfx + ".rest_mlp.0.weight"), bias=sd[pfx + ".rest_mlp.0.bias"], mode=EPI_NORM,
+                                 flags=F_POST_RELU, layout=gn_layout(c3), out=final_out, out_coff=final_coff,
+                                 gn=(sd[pfx + ".rest_mlp.1.group_norm.weight"], sd[pfx + ".rest_mlp.1.group_norm.bias"])))
+            self._gemm(h2, npx_log2, [seg3], pair_tabs=None if pair is None else pair["tabs"])
         else:
-            seg["residual"] = r
+            with_res(seg)
             seg["out"] = final_out
             seg["out_coff"] = final_coff
-            self._gemm(h1, npx_log2, [seg])
+            first_gemm(seg)
 
     def _attention_query(self, apfx, K):
         """buffers + GEMM segment of an attention block's per-point query branch (feat_conv): it depends on the block's input
@@ -419,8 +503,96 @@ class DenoiserEngine:
                     flags=F_PRE_RELU, out=Tq, stats=(ssum, ssq, 0, float(K)))
         return dict(Tq=Tq, ssum=ssum, ssq=ssq, qseg=qseg)
 
+    def _pair_first(self, npx_log2, K, feat_in, C, segs, coords):
+        """PAIR DECOMPOSITION of a block's shared first layer (csrc/gemm_gx.hip): the 1x1 convolutions over the grouped input
+        [neighbour features (C) | coordinate channels] are linear, so their output for row (point p, slot j) is a[q] + b[p]
+        (+ d2 vd + w vw), q the slot's neighbour.  Emits the 16-row GEMM y = Wf . feat + bias (1/K of the MACs) and
+        SLIDE_OP_PAIR_NORM (tables a, b in fp16 with the GroupNorm of NORM segments folded in, sums of STATS segments);
+        the K-expanded outputs are never stored.  segs: the segment dicts of the old shared GEMM (w over all grouped
+        channels); coords: dict(rel, abs, ctr = first column of each 3-channel coordinate group, d2 / w = column or None).
+        Returns the context the consumers (generated-X GEMMs, PAIR residuals) take."""
+        B = self.B
+        offs, ysegs, off = [], [], 0
+        for sg in segs:
+            lay = sg.get("layout")
+            Op = ru(sg["w"].shape[0] if lay is None else lay[1])
+            offs.append(off)
+            off += Op
+        ldy = off
+        Y = self.A.zeros(B * 16, ldy)  # fp32
+        wa, wb, vv_in = np.zeros((ldy, 4), np.float32), np.zeros((ldy, 4), np.float32), np.zeros((2, ldy), np.float32)
+        psegs = []
+        for sg, o_ in zip(segs, offs):
+            lay = sg.get("layout")
+            w = sg["w"]
+            oidx = (np.arange(w.shape[0]) if lay is None else lay[0]) + o_
+            ysegs.append(dict(w=w[:, :C], bias=sg.get("bias"), mode=EPI_RAW, out=Y, out_coff=o_,
+                              layout=None if lay is None else (lay[0], lay[1], 0, 1, 1)))
+            rel, ab, ctr = (w[:, coords[k_]:coords[k_] + 3] for k_ in ("rel", "abs", "ctr"))
+            wa[oidx, :3] = rel + ab
+            wb[oidx, :3] = ctr - rel
+            if coords.get("d2") is not None:
+                vv_in[0, oidx] = w[:, coords["d2"]]
+                vv_in[1, oidx] = w[:, coords["w"]]
+            ps = dict(sg)
+            ps["w"] = w[:, :0]  # descriptors only: mode / flags / GroupNorm parameters / statistics
+            ps["out"] = None
+            psegs.append(ps)
+        assert sum(3 for _ in ("rel", "abs", "ctr")) + (2 if coords.get("d2") is not None else 0) + C == segs[0]["w"].shape[1]
+        self._gemm(feat_in, 4, ysegs)
+        ta = self.A.zeros(B * 16, ldy, dtype=torch.float16)
+        tb = self.A.zeros(B * 16, ldy, dtype=torch.float16)
+        ed = self._epi_only(psegs, 1 << npx_log2)
+        fp = K == 8
+        d = [self.A.put(wa), self.A.put(wb)]
+        vv = rvv_all = None
+        if fp:
+            d.append(self.A.put(vv_in))
+            vv = self.A.zeros(B, 2, ldy)
+        # loop-invariant when the coordinates are a fixed condition?  No: y changes every step.
+        self._emit(make_op(OP_PAIR_NORM, i=(B, ldy, K),
+                           p=(Y.data_ptr(), self.xyz.data_ptr(), d[0].data_ptr(), d[1].data_ptr(), ed.data_ptr(),
+                              ta.data_ptr(), tb.data_ptr(), self.kidx.data_ptr() if fp else None,
+                              self.kd2.data_ptr() if fp else None, self.kw.data_ptr() if fp else None,
+                              d[2].data_ptr() if fp else None, vv.data_ptr() if fp else None)))
+        return dict(ta=ta, tb=tb, vv=vv, offs=offs, ldy=ldy, rows=B * 16 * K, vv_in=vv_in,
+                    tabs=(self.kidx, self.kd2, self.kw) if fp else None)
+
+    def _epi_only(self, segs, npx):
+        """device array of SlideEpi descriptors (one per 32 physical channels) carrying only what SLIDE_OP_PAIR_NORM reads:
+        mode, flags, GroupNorm layout / parameters, statistics pointers"""
+        blocks = []
+        for sg in segs:
+            lay = sg.get("layout")
+            O = sg["w"].shape[0]
+            oidx, Op, n_norm_p, gs_p, gs_l = (np.arange(O), O, 0, 1, 1) if lay is None else lay
+            Opad = ru(Op)
+            vec = np.zeros((2, Opad), np.float32)
+            if sg.get("gn") is not None:
+                gam, bet = sg["gn"]
+                vec[0, oidx[:gam.shape[0]]] = gam
+                vec[1, oidx[:gam.shape[0]]] = bet
+            vd = self.A.put(vec)
+            for j in range(Opad // 32):
+                e = SlideEpi()
+                e.mode = sg.get("mode", EPI_RAW)
+                e.flags = sg.get("flags", 0)
+                e.gs = gs_p
+                e.n_norm = int(min(32, max(0, n_norm_p - 32 * j)))
+                e.inv_count = 1.0 / (gs_l * npx)
+                e.gamma = vd.data_ptr() + 4 * (32 * j)
+                e.beta = vd.data_ptr() + 4 * (Opad + 32 * j)
+                if sg.get("stats") is not None:
+                    ssum, ssq, scoff, scale = sg["stats"]
+                    e.stats_sum = ssum.data_ptr() + 4 * (scoff + 32 * j)
+                    e.stats_sq = ssq.data_ptr() + 4 * (scoff + 32 * j)
+                    e.stats_bs = ssum.shape[1]
+                    e.stats_scale = scale
+                blocks.append(bytes(e))
+        return self.A.put(np.frombuffer(b"".join(blocks), dtype=np.uint8).copy())
+
     def _attention(self, apfx, npx_log2, K, g, q_in, mo, mlp_first, mlp_res, out, out_ld_buf, gather=None, qctx=None,
-                   extra_q=()):
+                   extra_q=(), pair=None):
         """AttentionModule (attention.py:35-96).  g: grouped input [B*npx][ldg]; q_in: query features [B*16][ld];
         mo: the Mlp output buffer (values input), produced by the caller AFTER the shared first GEMM.
 
@@ -430,7 +602,7 @@ class DenoiserEngine:
         per-neighbour GEMM as a pre-activation add -- 1/K of the reference's MACs for that half.
         Returns a closure continuing after the caller has produced `mo`."""
         sd, B = self.sd, self.B
-        rows = g.shape[0]
+        rows = B * 16 * K
         npx = 1 << npx_log2
         kshift = {8: 3, 16: 4}[K]
         C1 = sd[apfx + ".feat_conv.weight"].shape[0]
@@ -443,7 +615,7 @@ class DenoiserEngine:
         if qctx is None:
             qctx = self._attention_query(apfx, K)
         Tq, ssum, ssq = qctx["Tq"], qctx["ssum"], qctx["ssq"]
-        Tk = self._buf(rows, C2p, cm=True)
+        Tk = None if pair is not None else self._buf(rows, C2p, cm=True)
         kseg = dict(w=self._w(apfx + ".grouped_feat_conv.weight"), bias=sd[apfx + ".grouped_feat_conv.bias"],
                     mode=EPI_STATS, flags=F_PRE_RELU, out=Tk, stats=(ssum, ssq, C1p, 1.0))
         # lane 1 (query / score branch) forks here: it only needs the module inputs
@@ -453,7 +625,17 @@ class DenoiserEngine:
             self._gemm(q_in, 4, [qctx["qseg"]] + [e["qseg"] for e in extra_q])
             self._lane = 0
         # shared-input GEMM: [first_mlp | res_connect | grouped_feat_conv]
-        if gather is not None and gather[3] * 32 >= int(os.environ.get("SLIDE_SPLIT_FIRST", "1000000")):
+        if pair is not None:
+            feat_tab, Cf, coords = pair
+            ctx = self._pair_first(npx_log2, K, feat_tab, Cf, [mlp_first, mlp_res, kseg], coords)
+            ctx.update(off1=ctx["offs"][0], offr=ctx["offs"][1], offk=ctx["offs"][2], lay1=mlp_first["layout"],
+                       add1=mlp_first.get("addvec"))
+            rres = ru(mlp_res["w"].shape[0])
+            ctx["rvv"] = None
+            if K == 8:  # coefficient vectors of the two per-slot scalars for the res_connect channels (RAW segment: unscaled)
+                ctx["rvv"] = self.A.put(np.ascontiguousarray(ctx["vv_in"][:, ctx["offr"]:ctx["offr"] + rres]))
+            self.pair_ctx = ctx
+        elif gather is not None and gather[3] * 32 >= int(os.environ.get("SLIDE_SPLIT_FIRST", "1000000")):
             # (opt-in, SLIDE_SPLIT_FIRST=<min feature channels>: measured neutral to -1.5 % on the feature plan -- the
             # 256-row launch is bound by its epilogue, not by its K loop, and the per-point GEMM is one more launch)
             # The layer is linear in its input and the leading Cf input channels of row (point, neighbour) are the
@@ -526,11 +708,16 @@ class DenoiserEngine:
                        in_affine=(scale, shift, 0, ldT), gn_fin=gn_fin)
             # neighbour half: u = GN4(relu(W2[:, C1:] . GN(relu(k)) + bias + P[point]))
             u = self._buf(rows, ru(lay[1]), cm=True)
-            self._gemm(Tk, npx_log2, [dict(w=w2[:, C1:], bias=sd[apfx + ".weight_conv.2.bias"], mode=EPI_NORM,
-                                           flags=F_PRE_RELU, layout=lay, out=u, pre_add=(P, kshift),
-                                           gn=(sd[apfx + ".weight_conv.4.group_norm.weight"],
-                                               sd[apfx + ".weight_conv.4.group_norm.bias"]))],
-                       in_affine=(scale, shift, C1p, ldT))
+            useg = dict(w=w2[:, C1:], bias=sd[apfx + ".weight_conv.2.bias"], mode=EPI_NORM,
+                        flags=F_PRE_RELU, layout=lay, out=u, pre_add=(P, kshift),
+                        gn=(sd[apfx + ".weight_conv.4.group_norm.weight"], sd[apfx + ".weight_conv.4.group_norm.bias"]))
+            if pair is not None:  # the keys max(a[q] + b[p], 0) * scale + shift are generated from the pair tables
+                ctx = self.pair_ctx
+                self._gemm(None, npx_log2, [useg], in_affine=(scale, shift, C1p, ldT),
+                           gx=dict(ta=ctx["ta"], tb=ctx["tb"], coff=ctx["offk"], k_pad=C2p, rows=rows, mode=1, vv=ctx["vv"]),
+                           pair_tabs=ctx["tabs"])
+            else:
+                self._gemm(Tk, npx_log2, [useg], in_affine=(scale, shift, C1p, ldT))
             vlay = gn_layout(cout)
             if (self.prec == 1 and self.use_glds and os.environ.get("SLIDE_ATTN_TAIL", "1") != "0" and
                     np.array_equal(vlay[0], np.arange(cout))):
@@ -614,12 +801,22 @@ class DenoiserEngine:
         rows = B * 16 * K
         Cg = C + 9
         assert sd[mp + ".first_mlp.0.weight"].shape[1] == Cg
-        g, gather, _ = self._grouped_input(OP_ASSEMBLE_SA, feat_in, C, Cg, K)
         c1 = sd[mp + ".first_mlp.0.weight"].shape[0]
         c_last = sd[mp + ".res_connect.weight"].shape[0]
-        h1, r, mo = self._buf(rows, c1, cm=True), self._buf(rows, c_last, cm=True), self._buf(rows, c_last, cm=True)
-        first, res = self._mlp_segments(mp, self.tvec, self.cvec, h1, r)
+        mo = self._buf(rows, c_last, cm=True)
         out = self._buf(B * 16, c_last)
+        if self.use_gx:
+            # pair decomposition (csrc/gemm_gx.hip): no grouped input, no h1 / r / key buffers; rows in natural neighbour order
+            first, res = self._mlp_segments(mp, self.tvec, self.cvec, None, None)
+            pair = (feat_in, C, dict(rel=C, abs=C + 3, ctr=C + 6))
+            (scores, finish), cout = self._attention(ap, 8, K, None, feat_in, mo, first, res, out, None, extra_q=extra_q, pair=pair)
+            S = scores()
+            self._mlp_tail(mp, 8, None, self.cvec, None, mo, pair=self.pair_ctx)
+            finish(S)
+            return out, cout
+        g, gather, _ = self._grouped_input(OP_ASSEMBLE_SA, feat_in, C, Cg, K)
+        h1, r = self._buf(rows, c1, cm=True), self._buf(rows, c_last, cm=True)
+        first, res = self._mlp_segments(mp, self.tvec, self.cvec, h1, r)
         (scores, finish), cout = self._attention(ap, 8, K, g, feat_in, mo, first, res, out, None, gather=gather, extra_q=extra_q)
         S = scores()                                  # lane 1: finalize, P, weight_conv.2, weight_conv.5
         self._mlp_tail(mp, 8, h1, self.cvec, r, mo)   # lane 0: second / rest mlp
@@ -635,17 +832,23 @@ class DenoiserEngine:
         rows = B * 16 * K
         Cg = C2 + 11
         assert sd[m1 + ".first_mlp.0.weight"].shape[1] == Cg
-        g, gather, _ = self._grouped_input(OP_ASSEMBLE_FP, Kf, C2, Cg, K)
         c1 = sd[m1 + ".first_mlp.0.weight"].shape[0]
         c_last = sd[m1 + ".res_connect.weight"].shape[0]
-        h1, r, mo = self._buf(rows, c1, cm=True), self._buf(rows, c_last, cm=True), self._buf(rows, c_last, cm=True)
+        mo = self._buf(rows, c_last, cm=True)
+        pair = h1 = r = g = gather = None
+        if self.use_gx:  # pair decomposition: group_knn's channels are [feats | d2 | w | abs | rel | centre]
+            pair = (Kf, C2, dict(d2=C2, w=C2 + 1, abs=C2 + 2, rel=C2 + 5, ctr=C2 + 8))
+        else:
+            g, gather, _ = self._grouped_input(OP_ASSEMBLE_FP, Kf, C2, Cg, K)
+            h1, r = self._buf(rows, c1, cm=True), self._buf(rows, c_last, cm=True)
         first, res = self._mlp_segments(m1, self.tvec, self.cvec, h1, r)
         # mlp2 input: [interpolated (c_last) | unknown feats (CU) | xyz (3)]  (pointnet2_modules.py:842-855)
         zin = c_last + CU + 3
         assert sd[m2 + ".first_mlp.0.weight"].shape[1] == zin
         Z = self._buf(B * 16, zin)
-        (scores, finish), cout = self._attention(ap, 7, K, g, U, mo, first, res, Z, None, gather=gather, qctx=qctx)
+        (scores, finish), cout = self._attention(ap, 7, K, g, U, mo, first, res, Z, None, gather=gather, qctx=qctx, pair=pair)
         S = scores()
+        pctx = self.pair_ctx if pair is not None else None
         # skip features and coordinates: columns of Z the attention output does not touch -- on the score lane, beside
         # the value branch (joined by finish)
         es = Z.element_size()
@@ -668,7 +871,7 @@ class DenoiserEngine:
             self._emit(make_op(OP_COPY_COLS, i=(B * 16, 3, 3, Z.shape[1], 0, int(self.prec == 1)),
                                     p=(self.xyz.data_ptr(), Z.data_ptr() + es * (c_last + CU))))
         self._lane = 0
-        self._mlp_tail(m1, 7, h1, self.cvec, r, mo)
+        self._mlp_tail(m1, 7, h1, self.cvec, r, mo, pair=pctx)
         finish(S)
         n1 = sd[m2 + ".first_mlp.0.weight"].shape[0]
         n2 = sd[m2 + ".res_connect.weight"].shape[0]
@@ -698,6 +901,7 @@ class DenoiserEngine:
         self.feat0 = self._buf(B * 16, C0)  # activation storage type
         self.kidx = A.zeros(B * 16, 16, dtype=torch.int32)
         self.kd2 = A.zeros(B * 16, 16)
+        self.kw = A.zeros(B * 16, 16)  # group_knn's interpolation weights of the 8 nearest (pair decomposition)
         # t / condition vectors: widths are only known after the walk, so allocate generously and fix up below
         n_fc = sum(v.shape[0] for k, v in sd.items() if k.endswith(".fc.weight"))
         n_fcc = sum(v.shape[0] for k, v in sd.items() if k.endswith(".fc_condition.weight"))
@@ -721,7 +925,8 @@ class DenoiserEngine:
         self._prep_idx = len(self.ops)
         self._emit(make_op(OP_PREP_POINTS, i=(B, self.cx, self.feat0.shape[1], self.prec),
                                 p=(self.x.data_ptr(), self.xyz.data_ptr(), self.feat0.data_ptr(), self.kidx.data_ptr(),
-                                   self.kd2.data_ptr(), None if feat0_cm is None else feat0_cm.data_ptr())))
+                                   self.kd2.data_ptr(), None if feat0_cm is None else feat0_cm.data_ptr(), None,
+                                   self.kw.data_ptr())))
         feats, chans = [self.feat0], [C0]
         nsa, nfp = len(arch["npoint"]), len(arch["decoder_feature_dim"]) - 1
         # FP block j takes feats[nsa + j - nfp] as its skip / query input -- the table SA block nsa + j - nfp reads as well:
