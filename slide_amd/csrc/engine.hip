@@ -18,6 +18,7 @@ int slide_launch_gemm_xs(const GemmArgs &a, int npxl, int cbw, bool aff, bool ga
 // gemm_gx.hip: generated-X GEMM and the per-point table normalisation of the pair decomposition
 int slide_launch_gemm_gx(const SlideOp &o, hipStream_t s);
 int slide_launch_pair_norm(const SlideOp &o, hipStream_t s);
+int slide_launch_sa_chain(const SlideOp &o, hipStream_t s);
 
 namespace {
 
@@ -1670,6 +1671,8 @@ int run_op(const SlideOp &o, hipStream_t s) {
       return slide_launch_gemm_gx(o, s);
     case SLIDE_OP_PAIR_NORM:
       return slide_launch_pair_norm(o, s);
+    case SLIDE_OP_SA_CHAIN:
+      return slide_launch_sa_chain(o, s);
     case SLIDE_OP_TRANSPOSE:
       if (o.i[7])  // fp16 destination (module-level throughput mode)
         hipLaunchKernelGGL(transpose_kernel<_Float16>, dim3((o.i[2] + 31) / 32, (o.i[1] + 31) / 32, o.i[0]), dim3(256), 0, s,

@@ -28,15 +28,22 @@ constexpr int SLIDE_MAX_DEVICES = 64;
 // Tile: 256 rows (one 16x16 sample, or two 16x8 samples) x 128 channels; four waves, wave w owns rows 64 w .. 64 w + 63 and
 // all 128 channels (acc[4][2] = 128 registers).  W: chunk-major [k / 32][n_cob * 32][32]; a ring stage is two 32-deep
 // chunk images ([128 rows][64 B], source-side XOR swizzle as in the ring kernels of engine.hip) = 16 KB; NST stages.
-template <int NPXL, int NST>
+// Tables in LDS: [16-byte piece of the row][table row][8 halves] -- the 16 rows a ds_read_b128 lane group touches for one
+// piece are 256 consecutive bytes (conflict-free for any neighbour permutation), filled by LDS-DMA (per-lane source rows).
+// The K loop is software-pipelined by hand over its 16-deep steps: the LDS reads of step s + 1 (weight fragments, table
+// rows, vectors) are issued before the B fragments of step s are generated and its 8 MFMAs issued, so the reads' latency and
+// the packed-fp16 generation of the next fragments run under the matrix pipe's 256 busy cycles; the ring's wait + barrier of
+// the next stage sits one step early for the same reason.
+template <int NPXL, int NST, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_gx_kernel(GemmArgs a) {
   using T = _Float16;
   constexpr int CBW = 4;
   constexpr int NPX = 1 << NPXL;
   constexpr bool FP = NPXL == 7;
   constexpr int NSAMP = TM >> NPXL;            // 1 or 2
+  constexpr int NR = 16 * NSAMP;               // table rows in LDS
   constexpr int CH_B = 128 * 64, STAGE_B = 2 * CH_B;
-  constexpr int NVEC = FP ? 4 : 2;             // fp16 vectors per sample in LDS: [v0 | v1 | vd | vw][k_pad]
+  constexpr int NVEC = (MODE ? 2 : 1) + (FP ? 2 : 0);  // fp16 vectors per sample in LDS: [add | scale, shift][vd, vw][k_pad]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int ntc = (a.n_cob + CBW - 1) / CBW;
   const int ntr = (a.rows + TM - 1) / TM;
@@ -47,16 +54,85 @@ __global__ __launch_bounds__(256, 2) void gemm_gx_kernel(GemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, col = lane & 31;
   const int nk32 = a.k_pad >> 5, nks = (nk32 + 1) >> 1;
-  const int pitch = a.k_pad * 2 + 16;          // bytes between table rows in LDS: an ODD number of 16-byte pieces, so the 16
-                                               // rows a ds_read_b128 lane group touches fall on 16 different bank slots
   unsigned char *const ring = smem_raw;
   SLIDE_STAMP(a, 0);
   uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + (size_t)NST * STAGE_B);
   float *const vec_lds = reinterpret_cast<float *>(epi_lds + CBW * EPI_DW + (CBW * EPI_DW) % 4);
   unsigned char *const ta_l = reinterpret_cast<unsigned char *>(vec_lds + CBW * 96);
-  unsigned char *const tb_l = ta_l + (size_t)NSAMP * 16 * pitch;
-  T *const vv_l = reinterpret_cast<T *>(tb_l + (size_t)NSAMP * 16 * pitch);
+  const int tab_b = (a.k_pad >> 3) * NR * 16;  // bytes of one table image
+  unsigned char *const tb_l = ta_l + tab_b;
+  T *const vv_l = reinterpret_cast<T *>(tb_l + tab_b);
+  const int nsm = a.rows >> NPXL, smp0 = row0 >> NPXL;
 
+  // ---- per-sample vectors first (plain loads, converted to fp16): their latency runs under everything issued below
+  {
+    const float *addp = a.in_add;
+    if (MODE == 0 && addp && a.gx_add_idx) addp += (size_t)a.gx_add_idx[0] * a.gx_add_idx_stride;  // row t of a per-timestep table
+    for (int i = tid * 4; i < NSAMP * a.k_pad; i += 1024) {
+      const int sl = i / a.k_pad, k = i - sl * a.k_pad;
+      int smp = smp0 + sl;
+      smp = smp < nsm ? smp : nsm - 1;
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, vd = v0, vw = v0;
+      if (MODE == 0) {
+        if (addp) v0 = *reinterpret_cast<const float4 *>(addp + (size_t)smp * a.add_bs + k);
+      } else {
+        v0 = *reinterpret_cast<const float4 *>(a.in_scale + (size_t)smp * a.in_bs + k);
+        v1 = *reinterpret_cast<const float4 *>(a.in_shift + (size_t)smp * a.in_bs + k);
+      }
+      if (FP && a.gx_vv) {
+        vd = *reinterpret_cast<const float4 *>(a.gx_vv + (size_t)smp * a.gx_vbs + k);
+        vw = *reinterpret_cast<const float4 *>(a.gx_vv + (size_t)smp * a.gx_vbs + (a.gx_vbs >> 1) + k);
+      }
+      T *dst = vv_l + (size_t)sl * NVEC * a.k_pad + k;
+      store4<T>(dst, v0);
+      if (MODE) store4<T>(dst + a.k_pad, v1);
+      if (FP) {
+        store4<T>(dst + (MODE ? 2 : 1) * a.k_pad, vd);
+        store4<T>(dst + (MODE ? 3 : 2) * a.k_pad, vw);
+      }
+    }
+  }
+  // this lane's two row blocks: table rows of the neighbour (a) and of the centre point (b), per-slot scalars
+  int aoff[2], boff[2];
+  f16x2 d2s[2], ws[2];
+  const int sl_w = FP ? (wave >> 1) : 0;
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    int row = row0 + wave * 64 + rb * 32 + col;
+    row = row < a.rows ? row : a.rows - 1;
+    const int smp = row >> NPXL, pxl = row & (NPX - 1);
+    int p, q;
+    float d2 = 0.f, w = 0.f;
+    if (!FP) { p = pxl >> 4; q = pxl & 15; }
+    else {
+      p = pxl >> 3;
+      const int slot = (smp * 16 + p) * 16 + (pxl & 7);
+      q = a.gidx[slot];
+      d2 = a.gx_d2[slot]; w = a.gx_w[slot];
+    }
+    aoff[rb] = (half * NR + sl_w * 16 + q) * 16;
+    boff[rb] = (half * NR + sl_w * 16 + p) * 16;
+    d2s[rb] = f16x2{(T)d2, (T)d2};
+    ws[rb] = f16x2{(T)w, (T)w};
+  }
+  stage_epilogue_tables<CBW, 256>(a, cob0, tid, epi_lds, vec_lds);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every plain load above has landed: from here the VM counter counts DMA only
+
+  // ---- tables by LDS-DMA: instruction i carries 64 / NR pieces x NR rows (1 KB); lane -> (piece, row)
+  {
+    constexpr int PPI = 64 / NR;                 // pieces per instruction (4 or 2)
+    const int r = lane & (NR - 1), pl = lane / NR;
+    int smp = smp0 + (r >> 4);
+    smp = smp < nsm ? smp : nsm - 1;
+    const size_t grow = ((size_t)smp * 16 + (r & 15)) * a.gx_ld;
+    const int nins = (a.k_pad >> 3) / PPI;       // per table (k_pad is a multiple of 32)
+    for (int i = wave; i < 2 * nins; i += 4) {
+      const int t = i >= nins, ii = t ? i - nins : i;
+      const T *src = reinterpret_cast<const T *>(t ? a.gx_tb : a.gx_ta) + grow + (ii * PPI + pl) * 8;
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)src,
+                                       (__attribute__((address_space(3))) void *)((t ? tb_l : ta_l) + ii * 1024), 16, 0, 0);
+    }
+  }
   // ---- weight ring: this lane's source piece of the wave's two DMA instructions per 32-deep chunk
   const T *wsrc[2];
 #pragma unroll
@@ -84,74 +160,10 @@ __global__ __launch_bounds__(256, 2) void gemm_gx_kernel(GemmArgs a) {
 #pragma unroll
   for (int s0 = 0; s0 < NST - 1; ++s0)
     if (s0 < nks) issue(s0);
-
-  // ---- tables, vectors, epilogue descriptors (plain loads; the ring's first stages are in flight meanwhile)
-  stage_epilogue_tables<CBW, 256>(a, cob0, tid, epi_lds, vec_lds);
-  const int nsm = a.rows >> NPXL, smp0 = row0 >> NPXL;
-  {
-    const int ppr = a.k_pad >> 3;               // 16-byte pieces per table row
-    const int cnt = NSAMP * 16 * ppr;
-    for (int i = tid; i < cnt; i += 256) {
-      const int r = i / ppr, pc = i - r * ppr;  // r = sample slot * 16 + point
-      int smp = smp0 + (r >> 4);
-      smp = smp < nsm ? smp : nsm - 1;
-      const size_t g = ((size_t)smp * 16 + (r & 15)) * a.gx_ld + pc * 8;
-      const u32x4 va = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const T *>(a.gx_ta) + g);
-      const u32x4 vb = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const T *>(a.gx_tb) + g);
-      *reinterpret_cast<u32x4 *>(ta_l + (size_t)r * pitch + pc * 16) = va;
-      *reinterpret_cast<u32x4 *>(tb_l + (size_t)r * pitch + pc * 16) = vb;
-    }
-    const float *addp = a.in_add;
-    if (addp && a.gx_add_idx) addp += (size_t)a.gx_add_idx[0] * a.gx_add_idx_stride;  // row t of a per-timestep table
-    for (int i = tid; i < NSAMP * a.k_pad; i += 256) {
-      const int sl = i / a.k_pad, k = i - sl * a.k_pad;
-      int smp = smp0 + sl;
-      smp = smp < nsm ? smp : nsm - 1;
-      float v0 = 0.f, v1 = 0.f;
-      if (a.gx_mode == 0) {
-        if (addp) v0 = addp[(size_t)smp * a.add_bs + k];
-      } else {
-        v0 = a.in_scale[(size_t)smp * a.in_bs + k];
-        v1 = a.in_shift[(size_t)smp * a.in_bs + k];
-      }
-      vv_l[(sl * NVEC + 0) * a.k_pad + k] = (T)v0;
-      vv_l[(sl * NVEC + 1) * a.k_pad + k] = (T)v1;
-      if (FP) {
-        float d = 0.f, w = 0.f;
-        if (a.gx_vv) { d = a.gx_vv[(size_t)smp * a.gx_vbs + k]; w = a.gx_vv[(size_t)smp * a.gx_vbs + (a.gx_vbs >> 1) + k]; }
-        vv_l[(sl * NVEC + 2) * a.k_pad + k] = (T)d;
-        vv_l[(sl * NVEC + 3) * a.k_pad + k] = (T)w;
-      }
-    }
-  }
   SLIDE_STAMP(a, 7);
-  // this lane's two row blocks: table rows of the neighbour (a) and of the centre point (b), per-slot scalars
-  int aoff[2], boff[2];
-  f16x8 d2v[2], wv[2];
-  const int sl_w = FP ? (wave >> 1) : 0;
-#pragma unroll
-  for (int rb = 0; rb < 2; ++rb) {
-    int row = row0 + wave * 64 + rb * 32 + col;
-    row = row < a.rows ? row : a.rows - 1;
-    const int smp = row >> NPXL, pxl = row & (NPX - 1);
-    int p, q;
-    float d2 = 0.f, w = 0.f;
-    if (!FP) { p = pxl >> 4; q = pxl & 15; }
-    else {
-      p = pxl >> 3;
-      const int slot = (smp * 16 + p) * 16 + (pxl & 7);
-      q = a.gidx[slot];
-      d2 = a.gx_d2[slot]; w = a.gx_w[slot];
-    }
-    aoff[rb] = (sl_w * 16 + q) * pitch + half * 16;
-    boff[rb] = (sl_w * 16 + p) * pitch + half * 16;
-    const T dh = (T)d2, wh = (T)w;
-    d2v[rb] = f16x8{dh, dh, dh, dh, dh, dh, dh, dh};
-    wv[rb] = f16x8{wh, wh, wh, wh, wh, wh, wh, wh};
-  }
+
   const unsigned char *const vbase = reinterpret_cast<const unsigned char *>(vv_l + (size_t)sl_w * NVEC * a.k_pad) + half * 16;
   const int vstr = a.k_pad * 2;  // bytes between the vectors of a sample
-  const bool mode1 = a.gx_mode != 0;
 
   f32x16 acc[CBW][2];
 #pragma unroll
@@ -167,55 +179,84 @@ __global__ __launch_bounds__(256, 2) void gemm_gx_kernel(GemmArgs a) {
     wrow[cb] = trow * 64; wkey[cb] = (trow >> 2) & 3;
   }
 
-  SLIDE_STAMP(a, 1);
-  for (int st = 0; st < nks; ++st) {
-    // stage st must have landed; the next one (4 instructions per wave) may stay in flight
-    if (st + 1 < nks && NST > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // (first pass: also publishes the tables staged above)
-    if (st + NST - 1 < nks) issue(st + NST - 1);  // overwrites the stage consumed at st - 1
-    const unsigned char *sb = ring + (size_t)(st % NST) * STAGE_B;
+  // operands of one 16-deep step: weight fragments + the table rows its B fragments are generated from (the per-channel
+  // vectors are uniform reads, fetched where they are used: keeping them out of the double buffer is what fits 256 registers)
+  struct Step { f16x8 af[CBW], av[FP ? 2 : 1], bv[2]; int kb; };
+  auto load_step = [&](Step &o, const unsigned char *sb, int c2, int st2, int kc) __attribute__((always_inline)) {
+    const int piece = st2 * 2 + half;
 #pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2) {
-      const int kc = st * 2 + c2;
-      if (kc >= nk32) break;
+    for (int cb = 0; cb < CBW; ++cb)
+      o.af[cb] = *reinterpret_cast<const f16x8 *>(sb + c2 * CH_B + wrow[cb] + ((piece ^ wkey[cb]) << 4));
+    const int pb = (kc * 4 + st2 * 2) * NR * 16;  // byte offset of this step's first piece inside a table image
+    o.kb = (kc * 32 + st2 * 16) * 2;              // ... and inside a vector
+    o.av[0] = *reinterpret_cast<const f16x8 *>(ta_l + pb + aoff[0]);
+    if (FP) o.av[FP ? 1 : 0] = *reinterpret_cast<const f16x8 *>(ta_l + pb + aoff[1]);  // (natural order: q is the same in both blocks)
+    o.bv[0] = *reinterpret_cast<const f16x8 *>(tb_l + pb + boff[0]);
+    o.bv[1] = *reinterpret_cast<const f16x8 *>(tb_l + pb + boff[1]);
+  };
+  auto compute_step = [&](const Step &o) __attribute__((always_inline)) {
+    const f16x2 zero2 = {0, 0};
+    const f16x8 v0 = *reinterpret_cast<const f16x8 *>(vbase + o.kb);
+    f16x8 v1, vd, vw;
+    if (MODE) v1 = *reinterpret_cast<const f16x8 *>(vbase + vstr + o.kb);
+    if (FP) {
+      vd = *reinterpret_cast<const f16x8 *>(vbase + (MODE ? 2 : 1) * vstr + o.kb);
+      vw = *reinterpret_cast<const f16x8 *>(vbase + (MODE ? 3 : 2) * vstr + o.kb);
+    }
+    f16x8 bf[2];
 #pragma unroll
-      for (int st2 = 0; st2 < 2; ++st2) {
-        f16x8 af[CBW], bf[2];
-        const int piece = st2 * 2 + half;
+    for (int rb = 0; rb < 2; ++rb) {
+      const f16x8 av = o.av[FP ? rb : 0], bv = o.bv[rb];
 #pragma unroll
-        for (int cb = 0; cb < CBW; ++cb)
-          af[cb] = *reinterpret_cast<const f16x8 *>(sb + c2 * CH_B + wrow[cb] + ((piece ^ wkey[cb]) << 4));
-        const int kb = (kc * 32 + st2 * 16) * 2;  // byte offset of this K step inside a table row / vector
-        const f16x8 v0 = *reinterpret_cast<const f16x8 *>(vbase + kb);
-        f16x8 v1, vd, vw;
-        if (mode1) v1 = *reinterpret_cast<const f16x8 *>(vbase + vstr + kb);
+      for (int i = 0; i < 4; ++i) {  // packed fp16 math on register pieces; the per-slot scalars are ONE register each
+        f16x2 y = f16x2{av[2 * i], av[2 * i + 1]} + f16x2{bv[2 * i], bv[2 * i + 1]};
         if (FP) {
-          vd = *reinterpret_cast<const f16x8 *>(vbase + 2 * vstr + kb);
-          vw = *reinterpret_cast<const f16x8 *>(vbase + 3 * vstr + kb);
+          y = __builtin_elementwise_fma(d2s[rb], f16x2{vd[2 * i], vd[2 * i + 1]}, y);
+          y = __builtin_elementwise_fma(ws[rb], f16x2{vw[2 * i], vw[2 * i + 1]}, y);
         }
-        const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-        f16x8 a0 = *reinterpret_cast<const f16x8 *>(ta_l + aoff[0] + kb);
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-          f16x8 av = a0;
-          if (FP && rb) av = *reinterpret_cast<const f16x8 *>(ta_l + aoff[1] + kb);  // (natural order: q is the same in both blocks)
-          const f16x8 bv = *reinterpret_cast<const f16x8 *>(tb_l + boff[rb] + kb);
-          f16x8 y = av + bv;
-          if (FP) {
-            y = __builtin_elementwise_fma(d2v[rb], vd, y);
-            y = __builtin_elementwise_fma(wv[rb], vw, y);
-          }
-          y = __builtin_elementwise_max(y, zero);
-          bf[rb] = mode1 ? __builtin_elementwise_fma(y, v0, v1) : y + v0;
-        }
-#pragma unroll
-        for (int cb = 0; cb < CBW; ++cb)
-#pragma unroll
-          for (int rb = 0; rb < 2; ++rb)
-            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb], bf[rb], acc[cb][rb], 0, 0, 0);
+        y = __builtin_elementwise_max(y, zero2);
+        if (MODE) y = __builtin_elementwise_fma(y, f16x2{v0[2 * i], v0[2 * i + 1]}, f16x2{v1[2 * i], v1[2 * i + 1]});
+        else y = y + f16x2{v0[2 * i], v0[2 * i + 1]};
+        bf[rb][2 * i] = y[0]; bf[rb][2 * i + 1] = y[1];
       }
     }
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+        acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.af[cb], bf[rb], acc[cb][rb], 0, 0, 0);
+  };
+  // stage st must have landed before anyone reads it; the next one (4 instructions per wave) may stay in flight
+  auto stage_ready = [&](int st) __attribute__((always_inline)) {
+    if (st + 1 < nks && NST > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // (first pass: also publishes the tables and vectors staged above)
+    if (st + NST - 1 < nks) issue(st + NST - 1);  // overwrites the stage consumed at st - 1
+  };
+
+  SLIDE_STAMP(a, 1);
+  Step cur, nxt;
+  stage_ready(0);
+  load_step(cur, ring, 0, 0, 0);
+  for (int st = 0; st < nks; ++st) {
+    const unsigned char *sb = ring + (size_t)(st % NST) * STAGE_B;
+    const bool two = st * 2 + 1 < nk32;  // the stage's second 32-deep chunk exists
+    // step 0 of chunk 0
+    load_step(nxt, sb, 0, 1, st * 2);
+    compute_step(cur);
+    // step 1 of chunk 0
+    if (two) {
+      load_step(cur, sb, 1, 0, st * 2 + 1);
+      compute_step(nxt);
+      load_step(nxt, sb, 1, 1, st * 2 + 1);
+      compute_step(cur);
+    }
+    // last step of the stage: the next stage's barrier and first reads go ahead of its MFMAs
+    if (st + 1 < nks) {
+      stage_ready(st + 1);
+      load_step(cur, ring + (size_t)((st + 1) % NST) * STAGE_B, 0, 0, st * 2 + 2);
+    }
+    compute_step(nxt);
   }
   __syncthreads();  // every wave is done with the ring before `red` reuses it
   SLIDE_STAMP(a, 2);
@@ -318,11 +359,11 @@ __global__ __launch_bounds__(256) void pair_norm_kernel(int ld, const float *__r
   }
 }
 
-template <int NPXL, int NST>
+template <int NPXL, int NST, int MODE>
 int launch_gx(const GemmArgs &a, hipStream_t s) {
-  constexpr int NSAMP = TM >> NPXL, NVEC = NPXL == 7 ? 4 : 2;
+  constexpr int NSAMP = TM >> NPXL, NVEC = (MODE ? 2 : 1) + (NPXL == 7 ? 2 : 0);
   const size_t shm = (size_t)NST * 16384 + (4 * EPI_DW + (4 * EPI_DW) % 4 + 4 * 96) * 4 +
-                     (size_t)2 * NSAMP * 16 * (a.k_pad * 2 + 16) + (size_t)NSAMP * NVEC * a.k_pad * 2 + 16;
+                     (size_t)2 * NSAMP * 16 * a.k_pad * 2 + (size_t)NSAMP * NVEC * a.k_pad * 2 + 16;
   if (shm > 160 * 1024) return -8;
   const int ntc = (a.n_cob + 3) / 4, ntr = (a.rows + TM - 1) / TM;
   const int grid = ((ntr + 7) / 8) * 8 * ntc;
@@ -331,13 +372,13 @@ int launch_gx(const GemmArgs &a, hipStream_t s) {
   (void)hipGetDevice(&d);
   bool &attr_set = attr_done[d >= 0 && d < SLIDE_MAX_DEVICES ? d : 0];
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_gx_kernel<NPXL, NST>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_gx_kernel<NPXL, NST, MODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   GemmArgs b = a;
   b.shm_bytes = (int)shm;
-  hipLaunchKernelGGL((gemm_gx_kernel<NPXL, NST>), dim3(grid), dim3(256), shm, s, b);
+  hipLaunchKernelGGL((gemm_gx_kernel<NPXL, NST, MODE>), dim3(grid), dim3(256), shm, s, b);
   return (int)hipGetLastError();
 }
 
@@ -357,11 +398,16 @@ int slide_launch_gemm_gx(const SlideOp &o, hipStream_t s) {
   const int npxl = o.i[4];
   if (a.k_pad % 32 || a.k_pad <= 0 || a.gx_ld % 8 || a.rows <= 0 || a.n_cob <= 0 || !a.gx_ta || !a.gx_tb) return -3;
   if (a.gx_mode != 0 && (!a.in_scale || !a.in_shift)) return -3;
-  if (npxl == 8) return launch_gx<8, 3>(a, s);
+  if (a.in_add && ((uintptr_t)a.in_add % 16 || a.add_bs % 4 || a.gx_add_idx_stride % 4)) return -3;  // 16-byte vector loads
+  if (a.gx_mode != 0 && ((uintptr_t)a.in_scale % 16 || (uintptr_t)a.in_shift % 16 || a.in_bs % 4)) return -3;
+  if (a.gx_vv && ((uintptr_t)a.gx_vv % 16 || a.gx_vbs % 8)) return -3;
+  const bool m1 = a.gx_mode != 0;
+  if (npxl == 8) return m1 ? launch_gx<8, 3, 1>(a, s) : launch_gx<8, 3, 0>(a, s);
   if (npxl == 7) {
     if (!a.gidx || !a.gx_d2 || !a.gx_w) return -3;
-    const int st = launch_gx<7, 3>(a, s);
-    return st == -8 ? launch_gx<7, 2>(a, s) : st;
+    int st = m1 ? launch_gx<7, 3, 1>(a, s) : launch_gx<7, 3, 0>(a, s);
+    if (st == -8) st = m1 ? launch_gx<7, 2, 1>(a, s) : launch_gx<7, 2, 0>(a, s);
+    return st;
   }
   return -4;
 }
@@ -382,5 +428,403 @@ int slide_launch_pair_norm(const SlideOp &o, hipStream_t s) {
                        (_Float16 *)o.p[6], (const int *)o.p[7], (const float *)o.p[8], (const float *)o.p[9],
                        (const float *)o.p[10], (float *)o.p[11]);
   } else return -5;
+  return (int)hipGetLastError();
+}
+
+namespace {
+
+// ================================================================================================ fused SA Mlp chain
+// second_mlp -> rest_mlp of an SA block's Mlp_plus_t_emb (pointnet2_modules.py:119-176) in ONE launch, one workgroup per
+// sample (16 x 16 rows, natural neighbour order), eight waves x 32 rows:
+//   stage 1: h2 = relu(GN(W1 . h1 + b1)) + class-embedding vector, h1 GENERATED from the pair tables (mode 0 above);
+//            every wave owns ALL n1 channels of its 32 rows, so after the GroupNorm (statistics across the waves through
+//            LDS) its accumulators, converted to fp16 and re-paired with v_permlane32_swap, ARE the MFMA B fragments of
+//   stage 2: mo = relu(GN(W2 . h2 + b2)) + pair residual, in slabs of 256 channels, stored chunk-major for the attention tail.
+// h2 never exists in memory; one weight ring (16 KB chunk images of 256 channels x 32 K) streams W1 then the slabs of W2 and
+// keeps running ahead across the epilogues.  GroupNorm group sizes 4 / 8 / 16 (widths 128 / 256 / 512).
+struct F1Args {
+  const void *ta, *tb, *ra, *rb;  // fp16 pair tables [B*16][t_ld]: first_mlp columns (pre-normalised), res_connect columns
+  const void *W1, *W2;            // chunk-major [k1/32][n1][32], [n1/32][n2][32]
+  const float *vec1, *vec2;       // [bias | gamma | beta][n]
+  const float *add0;              // h1 add vector (t-embedding): add0[idx * add0_stride + b * add0_bs + k] or NULL
+  const int *add0_idx;
+  const float *add1;              // h2 add vector (class embedding): add1[b * add1_bs + c] or NULL
+  void *out;                      // mo, chunk-major [n2/32][B*256][32] fp16
+  unsigned long long *dbg;
+  int B, t_ld, k1, n1, n2, gs1, gs2, add0_stride, add0_bs, add1_bs;
+  float inv1, inv2;
+};
+
+// sum over the 32 lanes of a half wave; the total is valid in the half's UPPER 16 lanes (col >= 16).  Pure DPP: four steps
+// inside the 16-lane rows, then row_bcast15 carries row 0 / 2's total into row 1 / 3 (no LDS swizzle round trip).
+__device__ __forceinline__ float half_wave_sum_hi(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // xor 1
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // xor 2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false)); // row_bcast15 -> rows 1, 3
+  return v;
+}
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the VM counter, i.e. wait for the weight
+// ring's DMA in flight (and for the epilogue's own stores)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int NB1>  // 32-channel blocks of h2 (4 or 8)
+__global__ __launch_bounds__(512, 2) void sa_chain_kernel(F1Args a) {
+  using T = _Float16;
+  constexpr int NB2 = 8;                       // blocks per stage-2 slab
+  constexpr int CH_B = 256 * 64, STAGE_B = 2 * CH_B, NST = 2;
+  constexpr int NR = 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, col = lane & 31;
+  const int nk1 = a.k1 >> 5, nk2 = (NB1 * 32) >> 5, nslab = a.n2 >> 8;
+  const int nchunks = nk1 + nslab * nk2, nks = nchunks >> 1;  // (nk1, nk2 even)
+  unsigned char *const ring = smem_raw;
+  float *const vec1_l = reinterpret_cast<float *>(smem_raw + (size_t)NST * STAGE_B);  // [3][n1]
+  float *const vec2_l = vec1_l + 3 * a.n1;                                            // [3][n2]
+  float *const add1_l = vec2_l + 3 * a.n2;                                            // [n1]
+  float *const red = add1_l + a.n1;                                                   // [8 waves][8 cb][2 halves][4][2]
+  float *const gsh = red + 8 * 8 * 2 * 4 * 2;                                         // [8 cb][2][32]
+  T *const add0_l = reinterpret_cast<T *>(gsh + 8 * 2 * 32);                          // [k1] fp16
+  unsigned char *const ta_l = reinterpret_cast<unsigned char *>(add0_l + a.k1);
+  const int tab_b = (a.k1 >> 3) * NR * 16;
+  unsigned char *const tb_l = ta_l + tab_b;
+  unsigned char *const ra_l = tb_l + tab_b;                 // res_connect tables, same image: [piece][16 rows][16 B]
+  unsigned char *const rb_l = ra_l + (a.n2 >> 3) * NR * 16;
+#ifdef SLIDE_TIMELINE
+  if (a.dbg && tid == 0) a.dbg[(size_t)b * 16 + 0] = wall_clock64();
+#define F1_STAMP(k) do { if (a.dbg && tid == 0) a.dbg[(size_t)b * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define F1_STAMP(k) do { } while (0)
+#endif
+
+  // ---- vectors (plain loads)
+  for (int i = tid; i < 3 * a.n1; i += 512) vec1_l[i] = a.vec1[i];
+  for (int i = tid; i < 3 * a.n2; i += 512) vec2_l[i] = a.vec2[i];
+  for (int i = tid; i < a.n1; i += 512) add1_l[i] = a.add1 ? a.add1[(size_t)b * a.add1_bs + i] : 0.f;
+  {
+    const float *addp = a.add0;
+    if (addp && a.add0_idx) addp += (size_t)a.add0_idx[0] * a.add0_stride;
+    for (int i = tid; i < a.k1; i += 512) add0_l[i] = (T)(addp ? addp[(size_t)b * a.add0_bs + i] : 0.f);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- pair tables by LDS-DMA: [piece][16 rows][16 B]; one instruction = 4 pieces x 16 rows
+  {
+    const int r = lane & 15, pl = lane >> 4;
+    const size_t grow = ((size_t)b * 16 + r) * a.t_ld;
+    const int nins = (a.k1 >> 3) / 4;
+    for (int i = wave; i < 2 * nins; i += 8) {
+      const int t = i >= nins, ii = t ? i - nins : i;
+      const T *src = reinterpret_cast<const T *>(t ? a.tb : a.ta) + grow + (ii * 4 + pl) * 8;
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)src,
+                                       (__attribute__((address_space(3))) void *)((t ? tb_l : ta_l) + ii * 1024), 16, 0, 0);
+    }
+    const int rins = (a.n2 >> 3) / 4;
+    for (int i = wave; i < 2 * rins; i += 8) {
+      const int t = i >= rins, ii = t ? i - rins : i;
+      const T *src = reinterpret_cast<const T *>(t ? a.rb : a.ra) + grow + (ii * 4 + pl) * 8;
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)src,
+                                       (__attribute__((address_space(3))) void *)((t ? rb_l : ra_l) + ii * 1024), 16, 0, 0);
+    }
+  }
+  // ---- weight ring: chunk g = W1 chunk g (g < nk1) or chunk (g - nk1) % nk2 of slab (g - nk1) / nk2 of W2; image [256][64 B]
+  // 16 DMA instructions per chunk, 2 per wave: instruction j * 8 + wave carries image rows 16 (j * 8 + wave) ..
+  int wtrow[2], wpiece[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    wtrow[j] = 16 * (j * 8 + wave) + (lane >> 2);
+    wpiece[j] = (lane & 3) ^ ((wtrow[j] >> 2) & 3);
+  }
+  auto issue = [&](int st) __attribute__((always_inline)) {
+    unsigned char *dst = ring + (size_t)(st % NST) * STAGE_B;
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+      const int g = st * 2 + c2;
+      const T *base;
+      int nrow, kc, r0;
+      if (g < nk1) { base = reinterpret_cast<const T *>(a.W1); nrow = a.n1; kc = g; r0 = 0; }
+      else {
+        const int h = g - nk1, sl = h / nk2;
+        base = reinterpret_cast<const T *>(a.W2); nrow = a.n2; kc = h - sl * nk2; r0 = sl * 256;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int row = r0 + wtrow[j];
+        row = row < nrow ? row : nrow - 1;  // (stage 1 with n1 = 128: the image's upper half is never read)
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(base + ((size_t)kc * nrow + row) * 32 + wpiece[j] * 8),
+                                         (__attribute__((address_space(3))) void *)(dst + c2 * CH_B + (j * 8 + wave) * 1024),
+                                         16, 0, 0);
+      }
+    }
+  };
+  issue(0);
+  F1_STAMP(14);
+  // stage st must have landed before anyone reads it (NST = 2: nothing else is in flight)
+  auto stage_ready = [&](int st) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (st + 1 < nks) issue(st + 1);  // overwrites the stage consumed at st - 1
+  };
+
+  // this wave's 32 rows: points 2 wave, 2 wave + 1; neighbour q = col & 15
+  const int aoff = (half * NR + (col & 15)) * 16, boff = (half * NR + 2 * wave + (col >> 4)) * 16;
+  int wrow[NB2], wkey[NB2];
+#pragma unroll
+  for (int cb = 0; cb < NB2; ++cb) {
+    const int trow = cb * 32 + col;
+    wrow[cb] = trow * 64; wkey[cb] = (trow >> 2) & 3;
+  }
+
+  // ================================================================================================ stage 1
+  // accumulators start from the bias: the LDS reads land in the accumulator registers, the epilogue has no bias pass
+  auto init_acc = [&](auto nb_tag, f32x16 *v, const float *bias_l) __attribute__((always_inline)) {
+    constexpr int NB = decltype(nb_tag)::value;
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 bia = *reinterpret_cast<const float4 *>(bias_l + cb * 32 + 8 * q + 4 * half);
+        v[cb][4 * q] = bia.x; v[cb][4 * q + 1] = bia.y; v[cb][4 * q + 2] = bia.z; v[cb][4 * q + 3] = bia.w;
+      }
+  };
+  f32x16 acc1[NB1];
+  struct Step1 { f16x8 af[NB1], av, bv; int kb; };
+  auto load1 = [&](Step1 &o, const unsigned char *sb, int c2, int st2, int kc) __attribute__((always_inline)) {
+    const int piece = st2 * 2 + half;
+#pragma unroll
+    for (int cb = 0; cb < NB1; ++cb)
+      o.af[cb] = *reinterpret_cast<const f16x8 *>(sb + c2 * CH_B + wrow[cb] + ((piece ^ wkey[cb]) << 4));
+    const int pb = (kc * 4 + st2 * 2) * NR * 16;
+    o.kb = (kc * 32 + st2 * 16 + half * 8) * 2;
+    o.av = *reinterpret_cast<const f16x8 *>(ta_l + pb + aoff);
+    o.bv = *reinterpret_cast<const f16x8 *>(tb_l + pb + boff);
+  };
+  auto compute1 = [&](const Step1 &o) __attribute__((always_inline)) {
+    const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    const f16x8 v0 = *reinterpret_cast<const f16x8 *>(reinterpret_cast<const unsigned char *>(add0_l) + o.kb);
+    const f16x8 bf = __builtin_elementwise_max(o.av + o.bv, zero) + v0;
+#pragma unroll
+    for (int cb = 0; cb < NB1; ++cb) acc1[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.af[cb], bf, acc1[cb], 0, 0, 0);
+  };
+  const int nks1 = nk1 >> 1;
+  {
+    Step1 cur, nxt;
+    stage_ready(0);  // (its barrier publishes the vectors staged above)
+    init_acc(std::integral_constant<int, NB1>(), acc1, vec1_l);
+    load1(cur, ring, 0, 0, 0);
+    for (int st = 0; st < nks1; ++st) {
+      const unsigned char *sb = ring + (size_t)(st % NST) * STAGE_B;
+      load1(nxt, sb, 0, 1, st * 2);
+      compute1(cur);
+      load1(cur, sb, 1, 0, st * 2 + 1);
+      compute1(nxt);
+      load1(nxt, sb, 1, 1, st * 2 + 1);
+      compute1(cur);
+      if (st + 1 < nks1) {
+        stage_ready(st + 1);
+        load1(cur, ring + (size_t)((st + 1) % NST) * STAGE_B, 0, 0, st * 2 + 2);
+      }
+      compute1(nxt);
+    }
+  }
+  F1_STAMP(1);
+  // (the ring runs one stage ahead: stage_ready(s) issued stage s + 1, so the first chunks of W2 land under the epilogue below)
+
+  // GroupNorm of a stage: acc blocks v[NB] (D layout: reg r -> channel (r & 3) + 8 (r >> 2) + 4 half of the block, lane col ->
+  // row; bias included since the accumulator init); statistics over the sample's 256 rows x gs channels.  Leaves per-channel
+  // scale / shift in gsh.  Written on register PAIRS (packed fp32 VALU ops): these epilogues are VALU-issue bound.
+  auto group_stats = [&](auto nb_tag, f32x16 *v, const float *vec_l, int cb_base, int n, int gs, float inv_count) __attribute__((always_inline)) {
+    constexpr int NB = decltype(nb_tag)::value;
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      float s[4], ss[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x2 lo = {v[cb][4 * q], v[cb][4 * q + 1]}, hi = {v[cb][4 * q + 2], v[cb][4 * q + 3]};
+        const f32x2 t = lo + hi;
+        const f32x2 tt = __builtin_elementwise_fma(hi, hi, lo * lo);
+        s[q] = t[0] + t[1];
+        ss[q] = tt[0] + tt[1];
+      }
+      if (gs == 16) { s[0] += s[1]; ss[0] += ss[1]; s[2] += s[3]; ss[2] += ss[3]; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (gs == 16 && (q & 1)) continue;
+        s[q] = half_wave_sum_hi(s[q]);
+        ss[q] = half_wave_sum_hi(ss[q]);
+      }
+      if (col == 31) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x2 *>(red + ((((wave * 8 + cb) * 2 + half) * 4 + q) * 2)) = f32x2{s[q], ss[q]};
+      }
+    }
+    lds_barrier();
+    // one wave per channel block: channel c = lane (lower half), sums its group's partials over the 8 waves
+    if (wave < NB && half == 0) {
+      const int cb = wave, c = col, q = c >> 3, hh = (c >> 2) & 1;
+      f32x2 t = {0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        const float *pw = red + (((w * 8 + cb) * 2) * 4) * 2;
+        if (gs == 4) t += *reinterpret_cast<const f32x2 *>(pw + ((hh * 4 + q) * 2));
+        else if (gs == 8) t += *reinterpret_cast<const f32x2 *>(pw + (q * 2)) + *reinterpret_cast<const f32x2 *>(pw + ((4 + q) * 2));
+        else t += *reinterpret_cast<const f32x2 *>(pw + ((q & 2) * 2)) + *reinterpret_cast<const f32x2 *>(pw + ((4 + (q & 2)) * 2));
+      }
+      const float mean = t[0] * inv_count;
+      const float var = fmaxf(t[1] * inv_count - mean * mean, 0.f);
+      const float g = vec_l[n + (cb_base + cb) * 32 + c] * __builtin_amdgcn_rsqf(var + GN_EPS);
+      gsh[(cb * 2 + 0) * 32 + c] = g;
+      gsh[(cb * 2 + 1) * 32 + c] = vec_l[2 * n + (cb_base + cb) * 32 + c] - mean * g;
+    }
+    lds_barrier();
+  };
+  // normalise block cb (fp32, packed), convert to fp16, ReLU on the packed halves, [+ addp: 16 fp32 per lane in the D layout's
+  // channel order], and re-pair between the lane halves: o[p] = the 8 consecutive channels 16 p + 8 half of the lane's row
+  auto norm_pack = [&](const f32x16 &v, int cb, const float *addp, f16x8 (&o)[2]) __attribute__((always_inline)) {
+    uint32_t u[8];
+    const f16x2 zero2 = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 g = *reinterpret_cast<const float4 *>(gsh + (cb * 2 + 0) * 32 + 8 * q + 4 * half);
+      const float4 sh = *reinterpret_cast<const float4 *>(gsh + (cb * 2 + 1) * 32 + 8 * q + 4 * half);
+      f32x2 lo = __builtin_elementwise_fma(f32x2{v[4 * q], v[4 * q + 1]}, f32x2{g.x, g.y}, f32x2{sh.x, sh.y});
+      f32x2 hi = __builtin_elementwise_fma(f32x2{v[4 * q + 2], v[4 * q + 3]}, f32x2{g.z, g.w}, f32x2{sh.z, sh.w});
+      f16x2 l2 = __builtin_elementwise_max(__builtin_convertvector(lo, f16x2), zero2);
+      f16x2 h2 = __builtin_elementwise_max(__builtin_convertvector(hi, f16x2), zero2);
+      if (addp) {
+        const float4 ad = *reinterpret_cast<const float4 *>(addp + 8 * q + 4 * half);
+        l2 += __builtin_convertvector(f32x2{ad.x, ad.y}, f16x2);
+        h2 += __builtin_convertvector(f32x2{ad.z, ad.w}, f16x2);
+      }
+      u[2 * q] = __builtin_bit_cast(uint32_t, l2);
+      u[2 * q + 1] = __builtin_bit_cast(uint32_t, h2);
+    }
+    // quads 2p (u[4p], u[4p+1]) <-> 2p + 1 (u[4p+2], u[4p+3]) across the lane halves: four swaps behind one hazard pad
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"
+                 "v_permlane32_swap_b32 %4, %6\n\tv_permlane32_swap_b32 %5, %7\n\ts_nop 1"
+                 : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]));
+    o[0] = __builtin_bit_cast(f16x8, u32x4{u[0], u[1], u[2], u[3]});
+    o[1] = __builtin_bit_cast(f16x8, u32x4{u[4], u[5], u[6], u[7]});
+  };
+
+  group_stats(std::integral_constant<int, NB1>(), acc1, vec1_l, 0, a.n1, a.gs1, a.inv1);
+  f16x8 h2b[2 * NB1];  // B fragments of stage 2: K block kb of 16 channels, this lane's row
+#pragma unroll
+  for (int cb = 0; cb < NB1; ++cb) {
+    f16x8 o[2];
+    norm_pack(acc1[cb], cb, add1_l + cb * 32, o);
+    h2b[2 * cb] = o[0]; h2b[2 * cb + 1] = o[1];
+  }
+  F1_STAMP(2);
+
+  // ================================================================================================ stage 2
+  const size_t R = (size_t)a.B * 256;
+  const int row = b * 256 + wave * 32 + col;
+  const int raoff = (col & 15) * 16, rboff = (2 * wave + (col >> 4)) * 16;  // this lane's rows inside a piece of the residual tables
+  for (int sl = 0; sl < nslab; ++sl) {
+    f32x16 acc2[NB2];
+    init_acc(std::integral_constant<int, NB2>(), acc2, vec2_l + sl * 256);
+    const int st0 = nks1 + sl * (nk2 >> 1);  // first ring stage of this slab
+    f16x8 afc[NB2], afn[NB2];
+    auto loadw = [&](f16x8 (&o)[NB2], const unsigned char *sb, int c2, int st2) __attribute__((always_inline)) {
+      const int piece = st2 * 2 + half;
+#pragma unroll
+      for (int cb = 0; cb < NB2; ++cb)
+        o[cb] = *reinterpret_cast<const f16x8 *>(sb + c2 * CH_B + wrow[cb] + ((piece ^ wkey[cb]) << 4));
+    };
+    stage_ready(st0);
+    loadw(afc, ring + (size_t)(st0 % NST) * STAGE_B, 0, 0);
+#pragma unroll
+    for (int s2 = 0; s2 < NB1 / 2; ++s2) {  // ring stages of the slab: 4 K steps of 16 each (K blocks 4 s2 .. 4 s2 + 3)
+      const unsigned char *sb = ring + (size_t)((st0 + s2) % NST) * STAGE_B;
+      loadw(afn, sb, 0, 1);
+#pragma unroll
+      for (int cb = 0; cb < NB2; ++cb) acc2[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afc[cb], h2b[4 * s2], acc2[cb], 0, 0, 0);
+      loadw(afc, sb, 1, 0);
+#pragma unroll
+      for (int cb = 0; cb < NB2; ++cb) acc2[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afn[cb], h2b[4 * s2 + 1], acc2[cb], 0, 0, 0);
+      loadw(afn, sb, 1, 1);
+#pragma unroll
+      for (int cb = 0; cb < NB2; ++cb) acc2[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afc[cb], h2b[4 * s2 + 2], acc2[cb], 0, 0, 0);
+      if (s2 + 1 < NB1 / 2) {
+        stage_ready(st0 + s2 + 1);
+        loadw(afc, ring + (size_t)((st0 + s2 + 1) % NST) * STAGE_B, 0, 0);
+      }
+#pragma unroll
+      for (int cb = 0; cb < NB2; ++cb) acc2[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afn[cb], h2b[4 * s2 + 3], acc2[cb], 0, 0, 0);
+    }
+    F1_STAMP(3 + 3 * sl);
+    group_stats(std::integral_constant<int, NB2>(), acc2, vec2_l, sl * NB2, a.n2, a.gs2, a.inv2);
+    F1_STAMP(4 + 3 * sl);
+#pragma unroll
+    for (int cb = 0; cb < NB2; ++cb) {
+      const int cg = sl * 256 + cb * 32;
+      f16x8 ra4[2], rb4[2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int pc = ((cg + 16 * p) >> 3) + half;  // 16-byte piece of channels cg + 16 p + 8 half ..
+        ra4[p] = *reinterpret_cast<const f16x8 *>(ra_l + pc * NR * 16 + raoff);
+        rb4[p] = *reinterpret_cast<const f16x8 *>(rb_l + pc * NR * 16 + rboff);
+      }
+      f16x8 o[2];
+      norm_pack(acc2[cb], cb, nullptr, o);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const f16x8 y = o[p] + (ra4[p] + rb4[p]);
+        *reinterpret_cast<u32x4 *>(reinterpret_cast<T *>(a.out) + ((size_t)((cg >> 5)) * R + row) * 32 + 16 * p + 8 * half) =
+            __builtin_bit_cast(u32x4, y);
+      }
+    }
+    F1_STAMP(5 + 3 * sl);
+  }
+#ifdef SLIDE_TIMELINE
+  if (a.dbg) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    F1_STAMP(15);
+  }
+#endif
+}
+
+}  // namespace
+
+// SLIDE_OP_SA_CHAIN (include/slide_engine.h)
+int slide_launch_sa_chain(const SlideOp &o, hipStream_t s) {
+  F1Args a = {};
+  a.ta = o.p[0]; a.tb = o.p[1]; a.ra = o.p[2]; a.rb = o.p[3]; a.W1 = o.p[4]; a.W2 = o.p[5];
+  a.vec1 = (const float *)o.p[6]; a.vec2 = (const float *)o.p[7];
+  a.add0 = (const float *)o.p[8]; a.add0_idx = (const int *)o.p[9]; a.add1 = (const float *)o.p[10]; a.out = o.p[11];
+  a.dbg = (unsigned long long *)o.p[12];
+  a.B = o.i[0]; a.t_ld = o.i[1]; a.k1 = o.i[2]; a.n1 = o.i[3]; a.n2 = o.i[4]; a.gs1 = o.i[5]; a.gs2 = o.i[6];
+  a.add0_stride = o.i[7]; a.add0_bs = o.i[8]; a.add1_bs = o.i[9];
+  a.inv1 = o.f[0]; a.inv2 = o.f[1];
+  if (a.B <= 0 || a.k1 % 64 || a.k1 <= 0 || (a.n1 != 128 && a.n1 != 256) || a.n2 % 256 || a.n2 <= 0 || a.t_ld % 8) return -3;
+  auto okgs = [](int g) { return g == 4 || g == 8 || g == 16; };
+  if (!okgs(a.gs1) || !okgs(a.gs2)) return -3;
+  const size_t shm = (size_t)2 * 32768 + (size_t)(3 * a.n1 + 3 * a.n2 + a.n1 + 8 * 8 * 2 * 4 * 2 + 8 * 2 * 32) * 4 +
+                     (size_t)a.k1 * 2 + (size_t)2 * (a.k1 >> 3) * 16 * 16 + (size_t)2 * (a.n2 >> 3) * 16 * 16 + 64;
+  if (shm > 160 * 1024) return -8;
+  static bool attr_done[2][64] = {};
+  int d = 0;
+  (void)hipGetDevice(&d);
+  d = d >= 0 && d < 64 ? d : 0;
+  if (a.n1 == 128) {
+    if (!attr_done[0][d]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_chain_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_done[0][d] = true;
+    }
+    hipLaunchKernelGGL((sa_chain_kernel<4>), dim3(a.B), dim3(512), shm, s, a);
+  } else {
+    if (!attr_done[1][d]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_chain_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_done[1][d] = true;
+    }
+    hipLaunchKernelGGL((sa_chain_kernel<8>), dim3(a.B), dim3(512), shm, s, a);
+  }
   return (int)hipGetLastError();
 }

@@ -24,7 +24,7 @@ PREC = {"fp32": 0, "fp16": 1}
  OP_COND, OP_UPDATE_POS, OP_UPDATE_FEAT, OP_ADVANCE_T) = range(1, 13)
 OP_SYNC = 14
 OP_ATTN_TAIL = 16
-OP_GEMM_GX, OP_PAIR_NORM = 17, 18
+OP_GEMM_GX, OP_PAIR_NORM, OP_SA_CHAIN = 17, 18, 19
 
 
 class SlideEpi(ctypes.Structure):
@@ -473,6 +473,8 @@ class DenoiserEngine:
                    gn=(sd[pfx + ".second_mlp.1.group_norm.weight"], sd[pfx + ".second_mlp.1.group_norm.bias"]))
         if (pfx + ".fc_condition.weight") in sd:
             seg["addvec"] = (cvec, self._cvec_off(pfx + ".fc_condition", c2), self._c_bs, None, 0)
+        if has_rest and pair is not None and self._sa_chain(pfx, npx_log2, pair, cvec, seg, final_out, final_coff):
+            return
         if has_rest:
             h2 = self._buf(rows, c2, cm=npx_log2 >= 7)
             seg["out"] = h2
@@ -488,6 +490,46 @@ class DenoiserEngine:
             seg["out"] = final_out
             seg["out_coff"] = final_coff
             first_gemm(seg)
+
+    def _sa_chain(self, pfx, npx_log2, pair, cvec, seg, final_out, final_coff):
+        """second_mlp -> rest_mlp of an SA block as ONE launch (SLIDE_OP_SA_CHAIN, csrc/gemm_gx.hip: h2 stays in registers).
+        Returns False when the shapes are outside what the kernel covers (the two-launch path then runs)."""
+        sd, B = self.sd, self.B
+        if npx_log2 != 8 or os.environ.get("SLIDE_SA_CHAIN", "1") == "0" or pair["vv"] is not None:
+            return False
+        w1, w2 = self._w(pfx + ".second_mlp.0.weight"), self._w(pfx + ".rest_mlp.0.weight")
+        c2, c1 = w1.shape
+        c3 = w2.shape[0]
+        lay1, l2, l3 = pair["lay1"], gn_layout(c2), gn_layout(c3)
+        ident = lambda l, c: np.array_equal(l[0], np.arange(c)) and l[1] == c and l[2] == c
+        if not (c2 in (128, 256) and c3 % 256 == 0 and c1 % 64 == 0 and ident(lay1, c1) and ident(l2, c2) and ident(l3, c3)
+                and l2[3] in (4, 8, 16) and l3[3] in (4, 8, 16) and self._is_cm(final_out) and final_coff == 0
+                and final_out.shape[1] == c3):
+            return False
+        cm = lambda w: np.ascontiguousarray(w.reshape(w.shape[0], -1, 32).transpose(1, 0, 2))
+        vec = lambda b_, g_, bt_: np.stack([b_, g_, bt_]).astype(np.float32)
+        d = [self.A.put(cm(w1), torch.float16), self.A.put(cm(w2), torch.float16),
+             self.A.put(vec(sd[pfx + ".second_mlp.0.bias"], *seg["gn"])),
+             self.A.put(vec(sd[pfx + ".rest_mlp.0.bias"], sd[pfx + ".rest_mlp.1.group_norm.weight"],
+                            sd[pfx + ".rest_mlp.1.group_norm.bias"]))]
+        add0, add1 = pair["add1"], seg.get("addvec")
+        ta, tb = pair["ta"], pair["tb"]
+        rows = B * 256
+        fl = 2 * rows * (w1.size + w2.size)
+        self.gemm_flops[len(self.ops)] = fl
+        self.gemm_bytes[len(self.ops)] = (2 * B * 16 * (c1 + c3) * 2 + (w1.size + w2.size) * 2, rows * c3 * 2)
+        self.flops += fl
+        self._emit(make_op(OP_SA_CHAIN,
+                           i=(B, ta.shape[1], c1, c2, c3, l2[3], l3[3], 0 if add0 is None else add0[4], 0 if add0 is None else add0[2],
+                              0 if add1 is None else add1[2]),
+                           f=(1.0 / (l2[4] * 256), 1.0 / (l3[4] * 256)),
+                           p=(ta.data_ptr() + 2 * pair["off1"], tb.data_ptr() + 2 * pair["off1"],
+                              ta.data_ptr() + 2 * pair["offr"], tb.data_ptr() + 2 * pair["offr"],
+                              d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
+                              None if add0 is None else add0[0].data_ptr() + 4 * add0[1],
+                              None if add0 is None or add0[3] is None else add0[3].data_ptr(),
+                              None if add1 is None else add1[0].data_ptr() + 4 * add1[1], final_out.data_ptr())))
+        return True
 
     def _attention_query(self, apfx, K):
         """buffers + GEMM segment of an attention block's per-point query branch (feat_conv): it depends on the block's input

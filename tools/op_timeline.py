@@ -48,7 +48,7 @@ with torch.cuda.stream(s.stream):
         op = SlideOp.from_buffer_copy(bytes(s.step_ops[idx]))
         nwg = 16384
         dbg = torch.zeros(nwg * 16, dtype=torch.int64, device=dev)
-        slot = {1: 5, 17: 12}.get(op.kind)
+        slot = {1: 5, 17: 12, 19: 12}.get(op.kind)
         if slot is None:
             print("op %d: kind %d carries no stamps" % (idx, op.kind)); continue
         op.p[slot] = dbg.data_ptr()
@@ -62,7 +62,12 @@ with torch.cuda.stream(s.stream):
         t = (t - t0) / 100.0
         seq = [0, 7, 1, 2, 3, 4, 5, 6] if op.kind == 17 else [0, 1, 2, 3, 4, 5, 6]
         names = {0: "start", 7: "tables", 1: "primed", 2: "kloop", 3: "stats", 4: "barrier", 5: "stored", 6: "retired"}
+        if op.kind == 19:  # fused SA chain: 14 prologue | 1 stage-1 K loop | 2 h2 in registers | 3 / 6 slab K loop | 4 / 7 statistics | 5 / 8 stored | 15 retired
+            seq = [0, 14, 1, 2, 3, 4, 5] + ([6, 7, 8] if op.i[4] > 256 else []) + [15]
+            names = {14: "prologue", 1: "kloop1", 2: "epi1", 3: "kloop2a", 4: "stats2a", 5: "store2a", 6: "kloop2b", 7: "stats2b", 8: "store2b", 15: "retired"}
+            t[:, 6] = t[:, 15] if op.i[4] <= 256 else t[:, 6]
+        last = seq[-1]
         print("op %d kind %d rows %d k %d n %d: %d workgroups, span %.1f us, mean start %.1f" % (
-            idx, op.kind, op.i[0], op.i[2], op.i[3] * 32, len(t), t[:, 6].max(), t[:, 0].mean()))
+            idx, op.kind, op.i[0], op.i[2], op.i[3] * 32, len(t), t[:, last].max(), t[:, 0].mean()))
         print("   " + "  ".join("%s %.2f" % (names[b_], (t[:, b_] - t[:, a_]).mean()) for a_, b_ in zip(seq[:-1], seq[1:])) +
-              "  | total %.2f" % (t[:, 6] - t[:, 0]).mean())
+              "  | total %.2f" % (t[:, last] - t[:, 0]).mean())
