@@ -106,7 +106,9 @@ enum {
                              *   RAW  : ta = a, tb = b, vv = (vd | vw)
                              * p: [0] y fp32 [B*16][ld], [1] xyz fp32 [B*16][3], [2] wa fp32 [ld][4], [3] wb fp32 [ld][4], [4] epi [ld/32],
                              *    [5] ta, [6] tb (fp16 [B*16][ld]), [7] nbr table or NULL (natural order, K = 16), [8] d2, [9] w, [10] vd | vw
-                             *    fp32 [2][ld] (K = 8), [11] vv fp32 [B][2][ld] out (K = 8)      i: B, ld, K */
+                             *    fp32 [2][ld] (K = 8), [11] vv fp32 [B][2][ld] out (K = 8), [12] SlideGnFin* or NULL (version 2: the joint GroupNorm over the
+                             *    attention's [query | key] concatenation is finalised here: scale / shift rows written, the STATS sums stay on chip)
+                             * i: B, ld, K, version (2: one 1024-thread workgroup per sample, ld <= 2048; else one per 256 channels) */
   SLIDE_OP_SA_CHAIN = 19,   /* second_mlp -> rest_mlp of an SA block's Mlp_plus_t_emb in one launch, one workgroup per 16 x 16-row sample:
                              * h2 = relu(GN(W1 . h1 + b1)) + add1 with h1 = max(ta[q] + tb[p], 0) + add0 generated from the pair tables, kept in
                              * registers as the B fragments of mo = relu(GN(W2 . h2 + b2)) + ra[q] + rb[p] (pair residual), stored chunk-major.
@@ -115,6 +117,10 @@ enum {
                              *    [10] add1 fp32 [b*add1_bs + c] or NULL, [11] out [n2/32][B*256][32] fp16
                              * i: B, t_ld, k1, n1 (128 | 256), n2 (multiple of 256), gs1, gs2 (GroupNorm group sizes 4 | 8 | 16), add0_stride,
                              *    add0_bs, add1_bs      f: 1 / (gs1 * 256), 1 / (gs2 * 256) */
+  SLIDE_OP_BLOCK_BODY = 20, /* the whole K-expanded body of an SA / FP block whose widths are <= 256 channels in one launch (csrc/block_body.hip):
+                             * Mlp tail -> mo, generated keys -> u, attention tail; one workgroup per sample, mo / u as MFMA operand fragments in
+                             * registers, weights through one LDS-DMA ring.  p[0]: HOST pointer to the BodyArgs block (csrc/block_body.hip;
+                             * its members are device pointers), kept alive by the plan.  i: npx_log2 (7 | 8), has_rest_mlp */
   SLIDE_OP_TRANSPOSE = 15,  /* p: in, out (fp32)   i: B, R, C, in_ld, out_ld, in_batch_stride, out_batch_stride, out_is_fp16: out[b][c][r] = in[b][r][c] (module-level path: NCHW <-> row-major) */
   /* Row-major module-level path (rows_ops.hip): an activation is [B * S][ld] (S rows per sample, ld = channels rounded up
    * to 32, pad columns zero), fp32 or -- i[9] = 1 -- fp16.  Replaces the reference's NCHW tensor program of

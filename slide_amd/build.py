@@ -18,6 +18,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = [("point_ops.hip", ["-ffp-contract=off"]), ("engine.hip", ["-mllvm", "-pragma-unroll-threshold=100000"]),
            ("gemm_xs.hip", ["-mllvm", "-pragma-unroll-threshold=100000"]),
            ("gemm_gx.hip", ["-mllvm", "-pragma-unroll-threshold=100000"]),
+           ("block_body.hip", ["-mllvm", "-pragma-unroll-threshold=100000"]),
            ("resident.hip", ["-mllvm", "-pragma-unroll-threshold=100000"]), ("rows_ops.hip", [])]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
           "-Wno-unused-function"]

@@ -12,6 +12,8 @@
 // class-embedding add and the residual are all applied in the epilogue.
 #include "gemm_common.h"
 
+#include <cstdlib>
+
 // gemm_xs.hip: X-stationary kernel (-8: the X tile does not fit the LDS, -4: no such instantiation)
 int slide_launch_rows_op(const SlideOp &o, hipStream_t s);  // rows_ops.hip
 int slide_launch_gemm_xs(const GemmArgs &a, int npxl, int cbw, bool aff, bool gat, int want_occ, hipStream_t s);
@@ -19,6 +21,7 @@ int slide_launch_gemm_xs(const GemmArgs &a, int npxl, int cbw, bool aff, bool ga
 int slide_launch_gemm_gx(const SlideOp &o, hipStream_t s);
 int slide_launch_pair_norm(const SlideOp &o, hipStream_t s);
 int slide_launch_sa_chain(const SlideOp &o, hipStream_t s);
+int slide_launch_block_body(const SlideOp &o, hipStream_t s);  // block_body.hip
 
 namespace {
 
@@ -684,6 +687,8 @@ struct AttnTailArgs {
   void *out2;                     // optional copy of the first out2_n channels into another per-point buffer [..][out2_ld]
   int out2_ld, out2_n;
   int rows, x1_ld, k1, x2_ld, k2, n_cob, gs, n_norm, out_ld;
+  unsigned long long *dbg;        // optional per-workgroup timeline (instrumented builds)
+  int abl;                        // timing ablations of attn_tail8_kernel (tools only): 1 no DMA, 2 no fragment reads, 3 no MFMA
   int w_cm;                       // both weight matrices are chunk-major [k / 32][n_cob * 32][32] (u / mo are when their ld is 32)
   float inv_count;
 };
@@ -875,6 +880,231 @@ __global__ __launch_bounds__(256, 2) void attn_tail_kernel(AttnTailArgs a) {
         }
       }
   }
+}
+
+// Eight-wave form of the fused attention tail (round 3): tile 256 rows x 128 channels -- wave (wr, wc) owns rows 64 wr .. and the
+// channel half wc, so an X chunk is fetched once per 128 channels (24 KB of L2 -> LDS per 2 MFLOP instead of 20 KB per 1) --,
+// ring stages 64 deep (two chunk images: one barrier per 16 MFMAs of a wave), ONE continuous ring over the chunks of both
+// GEMMs (no drain between the score and the value contraction), fragment reads of the next 16-deep step issued before the
+// current step's MFMAs.  Same arithmetic, same epilogue as attn_tail_kernel; used when the layer has at least eight blocks.
+template <int NPXL>
+__global__ __launch_bounds__(512, 2) void attn_tail8_kernel(AttnTailArgs a) {
+  using T = _Float16;
+  constexpr int CBW = 2, NST = 3, RT = TM + 128, CH_B = RT * 64, STAGE_B = 2 * CH_B, LPW = RT / 16 / 8;  // 3 DMA / wave / chunk
+  constexpr int KLOG = NPXL - 4, KN = 1 << KLOG, GPB = 32 / KN;
+  constexpr int WPS = (1 << NPXL) / 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int ntc = (a.n_cob + 3) / 4;
+  const int xcd = blockIdx.x & 7, q0 = blockIdx.x >> 3;
+  const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;
+  if (tr * TM >= a.rows) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), wave = wv & 3, wc = wv >> 2;
+  const int half = lane >> 5, col = lane & 31;
+  const int row0 = tr * TM, cobt = tc * 4, cob0 = cobt + wc * CBW;
+  SLIDE_STAMP(a, 0);
+  float *const vec_lds = reinterpret_cast<float *>(smem_raw + (size_t)NST * STAGE_B);  // [4 vectors][4 * 32]
+  for (int i = tid; i < 4 * 128; i += 512) {
+    const int which = i >> 7, c = i & 127, gc = cobt * 32 + c;
+    vec_lds[i] = gc < a.n_cob * 32 ? a.vec[(size_t)which * a.n_cob * 32 + gc] : 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int wrow[CBW], wkey[CBW], xrow[2], xkey[2];
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb) {
+    const int trow = TM + (wc * CBW + cb) * 32 + col;
+    wrow[cb] = trow * 64; wkey[cb] = (trow >> 2) & 3;
+  }
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const int trow = wave * 64 + rb * 32 + col;
+    xrow[rb] = trow * 64; xkey[rb] = (trow >> 2) & 3;
+  }
+  const int nk1 = a.k1 >> 5, nk2 = a.k2 >> 5, nkt = nk1 + nk2, nks = (nkt + 1) >> 1;
+  // this lane's source piece of the wave's three DMA instructions per chunk, for both GEMMs
+  const T *gp[2][LPW];
+  size_t cs[2][LPW];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const void *Xp = g ? a.X2 : a.X1, *Wp = g ? a.W2 : a.W1;
+    const int x_ld = g ? a.x2_ld : a.x1_ld, k_pad = g ? a.k2 : a.k1;
+    const size_t x_cs = x_ld == 32 ? (size_t)a.rows * 32 : 32;
+    const size_t w_cs = a.w_cm ? (size_t)a.n_cob * 32 * 32 : 32;
+    const int w_ld = a.w_cm ? 32 : k_pad;
+#pragma unroll
+    for (int j = 0; j < LPW; ++j) {
+      const int trow = 16 * (j * 8 + wv) + (lane >> 2);
+      const int piece = (lane & 3) ^ ((trow >> 2) & 3);
+      if (trow < TM) {
+        int grow = row0 + trow;
+        grow = grow < a.rows ? grow : a.rows - 1;
+        gp[g][j] = reinterpret_cast<const T *>(Xp) + (size_t)grow * x_ld + piece * 8;
+        cs[g][j] = x_cs;
+      } else {
+        int gco = cobt * 32 + (trow - TM);
+        gco = gco < a.n_cob * 32 ? gco : a.n_cob * 32 - 1;
+        gp[g][j] = reinterpret_cast<const T *>(Wp) + (size_t)gco * w_ld + piece * 8;
+        cs[g][j] = w_cs;
+      }
+    }
+  }
+  auto issue = [&](int st) __attribute__((always_inline)) {
+    unsigned char *dst = smem_raw + (size_t)(st % NST) * STAGE_B;
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+      int h = st * 2 + c2;
+      h = h < nkt ? h : nkt - 1;  // odd total: the last image is a dummy (never read)
+      const int g = h >= nk1, kc = g ? h - nk1 : h;
+#pragma unroll
+      for (int j = 0; j < LPW; ++j)
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)((g ? gp[1][j] : gp[0][j]) + (size_t)kc * (g ? cs[1][j] : cs[0][j])),
+                                         (__attribute__((address_space(3))) void *)(dst + c2 * CH_B + (j * 8 + wv) * 1024), 16, 0, 0);
+    }
+  };
+  // stage st must have landed; the next one (2 * LPW instructions per wave) stays in flight: with ONE workgroup per CU the
+  // bytes in flight are what the L2 -> LDS rate hangs on (two-stage ring: 1.26 us per 48 KB stage, DMA-latency bound)
+  auto stage_ready = [&](int st) __attribute__((always_inline)) {
+    if (st + 1 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (st + 2 < nks && a.abl != 1) issue(st + 2);  // overwrites the stage consumed at st - 1
+  };
+  f32x16 sacc[CBW][2], vacc[CBW][2];
+#pragma unroll
+  for (int i = 0; i < CBW; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[i][j][r] = 0.f; vacc[i][j][r] = 0.f; }
+  struct Frag { f16x8 wf[CBW], xf[2]; };
+  auto loadf = [&](Frag &o, const unsigned char *sb, int st2) __attribute__((always_inline)) {
+    if (a.abl == 2 && sb != smem_raw) return;
+    const int piece = st2 * 2 + half;
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb) o.wf[cb] = *reinterpret_cast<const f16x8 *>(sb + wrow[cb] + ((piece ^ wkey[cb]) << 4));
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) o.xf[rb] = *reinterpret_cast<const f16x8 *>(sb + xrow[rb] + ((piece ^ xkey[rb]) << 4));
+  };
+  auto mma = [&](const Frag &o, f32x16 (&acc)[CBW][2]) __attribute__((always_inline)) {
+    if (a.abl == 3) { asm volatile("" :: "v"(o.xf[0]), "v"(o.xf[1]), "v"(o.wf[0]), "v"(o.wf[1])); return; }
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+        acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.xf[rb], o.wf[cb], acc[cb][rb], 0, 0, 0);  // rows x channels
+  };
+  issue(0);
+  if (nks > 1) issue(1);
+  SLIDE_STAMP(a, 1);
+  stage_ready(0);
+  SLIDE_STAMP(a, 2);
+  Frag cur, nxt;
+  loadf(cur, smem_raw, 0);
+  // (nk1, nk2 even: a ring stage never straddles the two GEMMs, each accumulator set has its own loop)
+  auto run = [&](int st_lo, int st_hi, f32x16 (&acc)[CBW][2]) __attribute__((always_inline)) {
+    for (int st = st_lo; st < st_hi; ++st) {
+      const unsigned char *sb = smem_raw + (size_t)(st % NST) * STAGE_B;
+      loadf(nxt, sb, 1);
+      mma(cur, acc);
+      loadf(cur, sb + CH_B, 0);
+      mma(nxt, acc);
+      loadf(nxt, sb + CH_B, 1);
+      mma(cur, acc);
+      if (st + 1 < nks) {
+        stage_ready(st + 1);
+        loadf(cur, smem_raw + (size_t)((st + 1) % NST) * STAGE_B, 0);
+      }
+      mma(nxt, acc);
+    }
+  };
+  run(0, nk1 >> 1, sacc);
+  SLIDE_STAMP(a, 3);
+  run(nk1 >> 1, nks, vacc);
+  SLIDE_STAMP(a, 4);
+  __syncthreads();  // ring drained and free
+
+  // ---- values: bias, GroupNorm over the sample (rows of WPS waves x the gs adjacent channel lanes), ReLU
+  float *const red = reinterpret_cast<float *>(smem_raw);  // [wave 0..7][cb][32 channels][sum, sumsq]
+  const float *b_s = vec_lds + wc * 64, *b_v = vec_lds + 128 + wc * 64, *gam = vec_lds + 256 + wc * 64, *bet = vec_lds + 384 + wc * 64;
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb) {
+    const float bv = b_v[cb * 32 + col];
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float x = vacc[cb][rb][r] + bv;
+        vacc[cb][rb][r] = x;
+        s += x;
+        ss = fmaf(x, x, ss);
+      }
+    s += other_half(s);
+    ss += other_half(ss);
+    if (half == 0) *reinterpret_cast<f32x2 *>(red + ((wv * CBW + cb) * 32 + col) * 2) = f32x2{s, ss};
+  }
+  __syncthreads();
+  SLIDE_STAMP(a, 5);
+  const int w0 = wc * 4 + (wave / WPS) * WPS;
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb) {
+    f32x2 t = {0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < WPS; ++w) t += *reinterpret_cast<const f32x2 *>(red + (((w0 + w) * CBW + cb) * 32 + col) * 2);
+    float s = t[0], ss = t[1];
+    if (a.gs >= 2) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1, 0xF, 0xF, true));
+                     ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0xB1, 0xF, 0xF, true)); }
+    if (a.gs >= 4) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E, 0xF, 0xF, true));
+                     ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x4E, 0xF, 0xF, true)); }
+    if (a.gs >= 8) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x141, 0xF, 0xF, true));
+                     ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x141, 0xF, 0xF, true)); }
+    if (a.gs >= 16) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x140, 0xF, 0xF, true));
+                      ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x140, 0xF, 0xF, true)); }
+    if (a.gs >= 32) { s += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s), 0x401F));
+                      ss += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(ss), 0x401F)); }
+    const float mean = s * a.inv_count;
+    const float var = fmaxf(ss * a.inv_count - mean * mean, 0.f);
+    float g = gam[cb * 32 + col] * __builtin_amdgcn_rsqf(var + GN_EPS);
+    float bt = bet[cb * 32 + col] - mean * g;
+    if ((cob0 + cb) * 32 + col >= a.n_norm) { g = 1.f; bt = 0.f; }
+    const float bs = b_s[cb * 32 + col];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int pg = 0; pg < GPB; ++pg) {
+        constexpr int RPG = 16 / GPB;
+        float sc[RPG], vv[RPG];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < RPG; ++j) {
+          sc[j] = sacc[cb][rb][pg * RPG + j] + bs;
+          vv[j] = fmaxf(fmaf(vacc[cb][rb][pg * RPG + j], g, bt), 0.f);
+          m = fmaxf(m, sc[j]);
+        }
+        m = fmaxf(m, other_half(m));
+        float den = 0.f, num = 0.f;
+#pragma unroll
+        for (int j = 0; j < RPG; ++j) {
+          const float e = __expf(sc[j] - m);
+          den += e;
+          num = fmaf(e, vv[j], num);
+        }
+        den += other_half(den);
+        num += other_half(num);
+        const int rbase = row0 + wave * 64 + rb * 32 + pg * KN;
+        if (half == 0 && rbase < a.rows && cob0 + cb < a.n_cob) {
+          const T v = (T)(num / den);
+          reinterpret_cast<T *>(a.out)[(size_t)(rbase >> KLOG) * a.out_ld + (cob0 + cb) * 32 + col] = v;
+          if (a.out_cm)
+            reinterpret_cast<T *>(a.out_cm)[((size_t)(cob0 + cb) * (a.rows >> KLOG) + (rbase >> KLOG)) * 32 + col] = v;
+          if (a.out2 && (cob0 + cb) * 32 + col < a.out2_n)
+            reinterpret_cast<T *>(a.out2)[(size_t)(rbase >> KLOG) * a.out2_ld + (cob0 + cb) * 32 + col] = v;
+        }
+      }
+  }
+  SLIDE_STAMP(a, 6);
+#ifdef SLIDE_TIMELINE
+  if (a.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SLIDE_STAMP(a, 7); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ points
@@ -1548,13 +1778,32 @@ int run_attn_tail(const SlideOp &o, hipStream_t s) {
   AttnTailArgs a;
   a.X1 = o.p[0]; a.W1 = o.p[1]; a.X2 = o.p[2]; a.W2 = o.p[3]; a.out = o.p[4]; a.vec = (const float *)o.p[5];
   a.out_cm = o.p[6];
+  a.dbg = (unsigned long long *)o.p[8];
   a.out2 = o.p[7]; a.out2_ld = (int)o.f[2]; a.out2_n = (int)o.f[3];
   a.rows = o.i[0]; a.x1_ld = o.i[1]; a.k1 = o.i[2]; a.x2_ld = o.i[3]; a.k2 = o.i[4]; a.n_cob = o.i[5];
   a.gs = o.i[7]; a.n_norm = o.i[8]; a.out_ld = o.i[9];
   a.inv_count = o.f[0];
   a.w_cm = o.f[1] != 0.f;
+  static const int tail_abl = [] { const char *e = getenv("SLIDE_TAIL_ABL"); return e ? atoi(e) : 0; }();
+  a.abl = tail_abl;
   const int npxl = o.i[6];
   if (a.k1 % 32 || a.k2 % 32 || a.rows <= 0 || a.n_cob <= 0) return -3;
+  const int ntr8 = (a.rows + TM - 1) / TM;
+  static const bool tail8_on = [] { const char *e = getenv("SLIDE_TAIL8"); return !(e && e[0] == '0'); }();
+  if (tail8_on && a.n_cob >= 8 && (npxl == 7 || npxl == 8) && a.k1 % 64 == 0 && a.k2 % 64 == 0) {  // eight-wave 256 x 128 tiles (see attn_tail8_kernel)
+    const size_t shm8 = (size_t)3 * 2 * (TM + 128) * 64 + 4 * 128 * 4 + 64;
+    const int grid8 = ((ntr8 + 7) / 8) * 8 * ((a.n_cob + 3) / 4);
+    static bool attr8_done[SLIDE_MAX_DEVICES] = {};
+    bool &attr8 = attr8_done[current_device_slot()];
+    if (!attr8) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_tail8_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_tail8_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr8 = true;
+    }
+    if (npxl == 8) hipLaunchKernelGGL(attn_tail8_kernel<8>, dim3(grid8), dim3(512), shm8, s, a);
+    else hipLaunchKernelGGL(attn_tail8_kernel<7>, dim3(grid8), dim3(512), shm8, s, a);
+    return (int)hipGetLastError();
+  }
   const size_t shm = (size_t)SLIDE_ATTN_NST * (TM + 64) * 64 + 4 * 2 * 32 * 4 + 64;
   const int ntc = (a.n_cob + 1) / 2, ntr = (a.rows + TM - 1) / TM;
   const int grid = ((ntr + 7) / 8) * 8 * ntc;
@@ -1673,6 +1922,8 @@ int run_op(const SlideOp &o, hipStream_t s) {
       return slide_launch_pair_norm(o, s);
     case SLIDE_OP_SA_CHAIN:
       return slide_launch_sa_chain(o, s);
+    case SLIDE_OP_BLOCK_BODY:
+      return slide_launch_block_body(o, s);
     case SLIDE_OP_TRANSPOSE:
       if (o.i[7])  // fp16 destination (module-level throughput mode)
         hipLaunchKernelGGL(transpose_kernel<_Float16>, dim3((o.i[2] + 31) / 32, (o.i[1] + 31) / 32, o.i[0]), dim3(256), 0, s,

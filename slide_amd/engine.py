@@ -24,7 +24,7 @@ PREC = {"fp32": 0, "fp16": 1}
  OP_COND, OP_UPDATE_POS, OP_UPDATE_FEAT, OP_ADVANCE_T) = range(1, 13)
 OP_SYNC = 14
 OP_ATTN_TAIL = 16
-OP_GEMM_GX, OP_PAIR_NORM, OP_SA_CHAIN = 17, 18, 19
+OP_GEMM_GX, OP_PAIR_NORM, OP_SA_CHAIN, OP_BLOCK_BODY = 17, 18, 19, 20
 
 
 class SlideEpi(ctypes.Structure):
@@ -43,6 +43,31 @@ class SlideEpi(ctypes.Structure):
 class SlideGnFin(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("sum", "sq", "gid", "gstart", "gend", "gamma", "beta", "scale", "shift")] + [
         ("inv_count", ctypes.c_float), ("C", ctypes.c_int32), ("bs", ctypes.c_int32), ("G", ctypes.c_int32)]
+
+
+class BodySlot(ctypes.Structure):  # csrc/block_body.hip
+    _fields_ = [("src", ctypes.c_void_p), ("chunk_stride", ctypes.c_int32), ("nrows", ctypes.c_int32),
+                ("kind", ctypes.c_int32), ("nvalid", ctypes.c_int32)]
+
+
+class BodyArgs(ctypes.Structure):  # csrc/block_body.hip (same field order: natural alignment on both sides)
+    _fields_ = [("slots", ctypes.c_void_p), ("n_slots", ctypes.c_int32),
+                ("ta", ctypes.c_void_p), ("tb", ctypes.c_void_p),
+                ("t_ld", ctypes.c_int32), ("off1", ctypes.c_int32), ("k1", ctypes.c_int32), ("offr", ctypes.c_int32),
+                ("offk", ctypes.c_int32), ("kk", ctypes.c_int32),
+                ("vv", ctypes.c_void_p), ("vbs", ctypes.c_int32), ("rv", ctypes.c_void_p),
+                ("nbr", ctypes.c_void_p), ("d2", ctypes.c_void_p), ("w", ctypes.c_void_p),
+                ("add0", ctypes.c_void_p), ("add0_idx", ctypes.c_void_p), ("add0_stride", ctypes.c_int32), ("add0_bs", ctypes.c_int32),
+                ("sc", ctypes.c_void_p), ("sh", ctypes.c_void_p), ("aff_bs", ctypes.c_int32),
+                ("P", ctypes.c_void_p), ("p_ld", ctypes.c_int32),
+                ("vec1", ctypes.c_void_p), ("n1", ctypes.c_int32), ("gs1", ctypes.c_int32), ("inv1", ctypes.c_float),
+                ("add1", ctypes.c_void_p), ("add1_bs", ctypes.c_int32),
+                ("vecm", ctypes.c_void_p), ("n_mo", ctypes.c_int32), ("gsm", ctypes.c_int32), ("invm", ctypes.c_float),
+                ("addm", ctypes.c_void_p), ("addm_bs", ctypes.c_int32),
+                ("vecu", ctypes.c_void_p), ("n_u", ctypes.c_int32), ("gsu", ctypes.c_int32), ("nnu", ctypes.c_int32), ("invu", ctypes.c_float),
+                ("vect", ctypes.c_void_p), ("n_out", ctypes.c_int32), ("gsv", ctypes.c_int32), ("nnv", ctypes.c_int32), ("invv", ctypes.c_float),
+                ("out", ctypes.c_void_p), ("out_ld", ctypes.c_int32), ("out2", ctypes.c_void_p), ("out2_ld", ctypes.c_int32), ("out2_n", ctypes.c_int32),
+                ("B", ctypes.c_int32), ("dbg", ctypes.c_void_p)]
 
 
 class SlideOp(ctypes.Structure):
@@ -545,7 +570,7 @@ class DenoiserEngine:
                     flags=F_PRE_RELU, out=Tq, stats=(ssum, ssq, 0, float(K)))
         return dict(Tq=Tq, ssum=ssum, ssq=ssq, qseg=qseg)
 
-    def _pair_first(self, npx_log2, K, feat_in, C, segs, coords):
+    def _pair_first(self, npx_log2, K, feat_in, C, segs, coords, fin=None, lead_segs=()):
         """PAIR DECOMPOSITION of a block's shared first layer (csrc/gemm_gx.hip): the 1x1 convolutions over the grouped input
         [neighbour features (C) | coordinate channels] are linear, so their output for row (point p, slot j) is a[q] + b[p]
         (+ d2 vd + w vw), q the slot's neighbour.  Emits the 16-row GEMM y = Wf . feat + bias (1/K of the MACs) and
@@ -581,7 +606,8 @@ class DenoiserEngine:
             ps["out"] = None
             psegs.append(ps)
         assert sum(3 for _ in ("rel", "abs", "ctr")) + (2 if coords.get("d2") is not None else 0) + C == segs[0]["w"].shape[1]
-        self._gemm(feat_in, 4, ysegs)
+        # (lead_segs: other per-point GEMM segments over the same table -- the attention queries -- ride on this launch)
+        self._gemm(feat_in, 4, list(lead_segs) + ysegs)
         ta = self.A.zeros(B * 16, ldy, dtype=torch.float16)
         tb = self.A.zeros(B * 16, ldy, dtype=torch.float16)
         ed = self._epi_only(psegs, 1 << npx_log2)
@@ -592,11 +618,14 @@ class DenoiserEngine:
             d.append(self.A.put(vv_in))
             vv = self.A.zeros(B, 2, ldy)
         # loop-invariant when the coordinates are a fixed condition?  No: y changes every step.
-        self._emit(make_op(OP_PAIR_NORM, i=(B, ldy, K),
+        v2 = ldy <= 2048 and os.environ.get("SLIDE_PAIR_NORM_V2", "1") != "0"
+        assert fin is None or v2
+        self._emit(make_op(OP_PAIR_NORM, i=(B, ldy, K, 2 if v2 else 1),
                            p=(Y.data_ptr(), self.xyz.data_ptr(), d[0].data_ptr(), d[1].data_ptr(), ed.data_ptr(),
                               ta.data_ptr(), tb.data_ptr(), self.kidx.data_ptr() if fp else None,
                               self.kd2.data_ptr() if fp else None, self.kw.data_ptr() if fp else None,
-                              d[2].data_ptr() if fp else None, vv.data_ptr() if fp else None)))
+                              d[2].data_ptr() if fp else None, vv.data_ptr() if fp else None,
+                              None if fin is None else fin.data_ptr())))
         return dict(ta=ta, tb=tb, vv=vv, offs=offs, ldy=ldy, rows=B * 16 * K, vv_in=vv_in,
                     tabs=(self.kidx, self.kd2, self.kw) if fp else None)
 
@@ -633,8 +662,163 @@ class DenoiserEngine:
                 blocks.append(bytes(e))
         return self.A.put(np.frombuffer(b"".join(blocks), dtype=np.uint8).copy())
 
+    def _body_shape(self, mpfx, apfx, npx_log2):
+        """(rest, nb1, nbm, nbu) if SLIDE_OP_BLOCK_BODY has an instantiation for this block's widths, else None"""
+        sd = self.sd
+        if not self.use_gx or os.environ.get("SLIDE_BODY", "1") == "0":
+            return None
+        rest = (mpfx + ".rest_mlp.0.weight") in sd
+        c1 = sd[mpfx + ".first_mlp.0.weight"].shape[0]
+        c2 = sd[mpfx + ".second_mlp.0.weight"].shape[0]
+        n_mo = sd[mpfx + ".rest_mlp.0.weight"].shape[0] if rest else c2
+        inter = sd[apfx + ".weight_conv.2.weight"].shape[0]
+        cout = sd[apfx + ".weight_conv.5.weight"].shape[0]
+        lay_u = gn_layout(inter)
+        n_u = ru(lay_u[1])
+        ident = lambda c: (lambda l: np.array_equal(l[0], np.arange(c)) and l[1] == c and l[2] == c)(gn_layout(c))
+        okgs = lambda c: gn_layout(c)[3] in (4, 8, 16)
+        if not (ident(c1) and ident(c2) and ident(n_mo) and ident(cout) and okgs(c2) and okgs(n_mo) and lay_u[3] in (4, 8, 16)
+                and c1 % 32 == 0 and n_mo % 32 == 0 and cout % 64 == 0 and gn_layout(cout)[3] <= 32):
+            return None
+        shape = (npx_log2, rest, (c2 // 32) if rest else 0, n_mo // 32, n_u // 32)
+        # ((7, False, 0, 8, 8) -- FP1 -- was built and measured slower than its three separate launches: one wave per SIMD)
+        if shape not in ((7, False, 0, 4, 4), (8, True, 4, 8, 5)):
+            return None
+        return shape
+
+    def _emit_block_body(self, body, mpfx, npx_log2, K, out, cvec):
+        """SLIDE_OP_BLOCK_BODY (csrc/block_body.hip): Mlp tail -> mo, keys -> u, attention tail, one workgroup per sample,
+        mo / u in registers.  body: state left by _attention's score closure (P, joint GroupNorm rows, ...); ctx: pair tables"""
+        sd, B = self.sd, self.B
+        ctx = self.pair_ctx
+        apfx = body["apfx"]
+        npx = 1 << npx_log2
+        rest = (mpfx + ".rest_mlp.0.weight") in sd
+        cm = lambda w: np.ascontiguousarray(w.reshape(w.shape[0], -1, 32).transpose(1, 0, 2))
+        vec3 = lambda n, lay, b_, g_, bt_: (lambda v: (v.__setitem__((0, lay[0]), b_), v.__setitem__((1, lay[0][:g_.shape[0]]), g_),
+                                                    v.__setitem__((2, lay[0][:bt_.shape[0]]), bt_), v)[-1])(np.zeros((3, n), np.float32))
+        a = BodyArgs()
+        keep = []
+        slots = []
+        put16 = lambda w: (lambda t: (keep.append(t), t)[1])(self.A.put(cm(w), torch.float16))
+        putf = lambda v: (lambda t: (keep.append(t), t)[1])(self.A.put(np.ascontiguousarray(v, np.float32)))
+
+        # slot geometry (csrc/block_body.hip): eight-wave form (16 x 16-row samples) 128-row slabs / 64-channel column blocks,
+        # four-wave form everything at once: 256-row images, one 32-deep chunk per slot
+        srows, trows = (128, 64) if npx_log2 == 8 else (256, 128)
+
+        def slab_slots(Wt, n, k):  # D[channel][row] stage
+            cps = 256 // srows
+            for r0 in range(0, n, srows):
+                for kc in range(0, k // 32, cps):
+                    slots.append((Wt.data_ptr() + 2 * ((kc * n + r0) * 32), n * 32, min(srows, n - r0), 0, min(cps, k // 32 - kc)))
+
+        c1 = sd[mpfx + ".first_mlp.0.weight"].shape[0]
+        w_sec = self._w(mpfx + ".second_mlp.0.weight")
+        c2 = w_sec.shape[0]
+        lay2 = gn_layout(c2)
+        fl = 0
+        if rest:
+            W1 = put16(w_sec)
+            slab_slots(W1, c2, c1)
+            a.vec1 = putf(vec3(c2, lay2, sd[mpfx + ".second_mlp.0.bias"], sd[mpfx + ".second_mlp.1.group_norm.weight"],
+                               sd[mpfx + ".second_mlp.1.group_norm.bias"])).data_ptr()
+            a.n1, a.gs1, a.inv1 = c2, lay2[3], 1.0 / (lay2[4] * npx)
+            if (mpfx + ".fc_condition.weight") in sd:
+                a.add1 = cvec.data_ptr() + 4 * self._cvec_off(mpfx + ".fc_condition", c2)
+                a.add1_bs = self._c_bs
+            w_m = self._w(mpfx + ".rest_mlp.0.weight")
+            n_mo = w_m.shape[0]
+            laym = gn_layout(n_mo)
+            Wm = put16(w_m)
+            slab_slots(Wm, n_mo, c2)
+            a.vecm = putf(vec3(n_mo, laym, sd[mpfx + ".rest_mlp.0.bias"], sd[mpfx + ".rest_mlp.1.group_norm.weight"],
+                               sd[mpfx + ".rest_mlp.1.group_norm.bias"])).data_ptr()
+            fl += w_sec.size + w_m.size
+        else:
+            n_mo, laym = c2, lay2
+            Wm = put16(w_sec)
+            slab_slots(Wm, n_mo, c1)
+            a.vecm = putf(vec3(n_mo, laym, sd[mpfx + ".second_mlp.0.bias"], sd[mpfx + ".second_mlp.1.group_norm.weight"],
+                               sd[mpfx + ".second_mlp.1.group_norm.bias"])).data_ptr()
+            if (mpfx + ".fc_condition.weight") in sd:
+                a.addm = cvec.data_ptr() + 4 * self._cvec_off(mpfx + ".fc_condition", c2)
+                a.addm_bs = self._c_bs
+            fl += w_sec.size
+        a.n_mo, a.gsm, a.invm = n_mo, laym[3], 1.0 / (laym[4] * npx)
+        # keys -> u
+        lay_u = body["lay_u"]
+        n_u = ru(lay_u[1])
+        C1, C2p = body["C1"], body["C2p"]
+        w2k = body["w2"][:, C1:]
+        wk = np.zeros((n_u, C2p), np.float32)
+        wk[lay_u[0], :w2k.shape[1]] = w2k
+        Wu = put16(wk)
+        slab_slots(Wu, n_u, C2p)
+        gu = sd[apfx + ".weight_conv.4.group_norm.weight"]
+        a.vecu = putf(vec3(n_u, lay_u, sd[apfx + ".weight_conv.2.bias"], gu, sd[apfx + ".weight_conv.4.group_norm.bias"])).data_ptr()
+        a.n_u, a.gsu, a.nnu, a.invu = n_u, lay_u[3], lay_u[2], 1.0 / (lay_u[4] * npx)
+        fl += w2k.size
+        # tail
+        cout = body["cout"]
+        vlay = gn_layout(cout)
+        w5 = np.zeros((cout, n_u), np.float32)
+        w5[:, lay_u[0]] = self._w(apfx + ".weight_conv.5.weight")
+        wv = self._w(apfx + ".feat_out_conv.0.weight")
+        W5, Wv = put16(w5), put16(wv)
+        assert cout % trows == 0 or npx_log2 == 8
+        for cbk in range((cout + trows - 1) // trows):
+            for Wt, k in ((W5, n_u), (Wv, n_mo)):
+                cps = 256 // trows
+                for kc in range(0, k // 32, cps):
+                    slots.append((Wt.data_ptr() + 2 * ((kc * cout + cbk * trows) * 32), cout * 32, min(trows, cout - cbk * trows), 1,
+                                  min(cps, k // 32 - kc)))
+        vect = np.zeros((4, cout), np.float32)
+        vect[0] = sd[apfx + ".weight_conv.5.bias"]
+        vect[1] = sd[apfx + ".feat_out_conv.0.bias"]
+        gam = sd[apfx + ".feat_out_conv.1.group_norm.weight"]
+        vect[2, :gam.shape[0]] = gam
+        vect[3, :gam.shape[0]] = sd[apfx + ".feat_out_conv.1.group_norm.bias"]
+        a.vect = putf(vect).data_ptr()
+        a.n_out, a.gsv, a.nnv, a.invv = cout, vlay[3], vlay[2], 1.0 / (vlay[4] * npx)
+        fl += self._w(apfx + ".weight_conv.5.weight").size + wv.size
+        # tables and vectors
+        ta, tb = ctx["ta"], ctx["tb"]
+        a.ta, a.tb, a.t_ld = ta.data_ptr(), tb.data_ptr(), ta.shape[1]
+        a.off1, a.k1, a.offr, a.offk, a.kk = ctx["off1"], c1, ctx["offr"], ctx["offk"], C2p
+        if K == 8:
+            a.vv, a.vbs = ctx["vv"].data_ptr(), 2 * ctx["vv"].shape[2]
+            a.rv = ctx["rvv"].data_ptr()
+            a.nbr, a.d2, a.w = self.kidx.data_ptr(), self.kd2.data_ptr(), self.kw.data_ptr()
+            assert ctx["rvv"].shape[1] == n_mo
+        add0 = ctx["add1"]
+        if add0 is not None:
+            a.add0 = add0[0].data_ptr() + 4 * add0[1]
+            a.add0_bs, a.add0_stride = add0[2], add0[4]
+            a.add0_idx = None if add0[3] is None else add0[3].data_ptr()
+        a.sc = body["scale"].data_ptr() + 4 * body["C1p"]
+        a.sh = body["shift"].data_ptr() + 4 * body["C1p"]
+        a.aff_bs = body["ldT"]
+        a.P, a.p_ld = body["P"].data_ptr(), body["P"].shape[1]
+        assert body["P"].shape[1] >= n_u and out.dtype == torch.float16 and not self._is_cm(out)
+        a.out, a.out_ld = out.data_ptr(), out.shape[1]
+        a.B = B
+        sl = (BodySlot * len(slots))()
+        for i, (src, cs, nr, kind, nv) in enumerate(slots):
+            sl[i].src, sl[i].chunk_stride, sl[i].nrows, sl[i].kind, sl[i].nvalid = src, cs, nr, kind, nv
+        sd_ = self.A.put(np.frombuffer(bytes(sl), dtype=np.uint8).copy())
+        a.slots, a.n_slots = sd_.data_ptr(), len(slots)
+        self.A.keep.append((a, keep))  # the op carries a HOST pointer to the argument block
+        rows = B * 16 * K
+        self.gemm_flops[len(self.ops)] = 2 * rows * fl
+        self.gemm_bytes[len(self.ops)] = (2 * B * 16 * ta.shape[1] * 2, B * 16 * cout * 2)
+        self.flops += 2 * rows * fl
+        self._tail_of[out.data_ptr()] = len(self.ops)
+        self._body_args[len(self.ops)] = a
+        self._emit(make_op(OP_BLOCK_BODY, i=(npx_log2, int(rest)), p=(ctypes.addressof(a),)))
+
     def _attention(self, apfx, npx_log2, K, g, q_in, mo, mlp_first, mlp_res, out, out_ld_buf, gather=None, qctx=None,
-                   extra_q=(), pair=None):
+                   extra_q=(), pair=None, body=None):
         """AttentionModule (attention.py:35-96).  g: grouped input [B*npx][ldg]; q_in: query features [B*16][ld];
         mo: the Mlp output buffer (values input), produced by the caller AFTER the shared first GEMM.
 
@@ -660,16 +844,46 @@ class DenoiserEngine:
         Tk = None if pair is not None else self._buf(rows, C2p, cm=True)
         kseg = dict(w=self._w(apfx + ".grouped_feat_conv.weight"), bias=sd[apfx + ".grouped_feat_conv.bias"],
                     mode=EPI_STATS, flags=F_PRE_RELU, out=Tk, stats=(ssum, ssq, C1p, 1.0))
+        # GroupNorm over the concatenation [q | k] (weight_conv.1): groups may straddle the two producers
+        Ct = C1 + C2
+        G = min(32, Ct)
+        n_norm = Ct - Ct % G
+        gs = n_norm // G
+        phys = np.array([c if c < C1 else C1p + (c - C1) for c in range(Ct)], np.int64)
+        gid = np.full(ldT, -1, np.int32)
+        gam, bet = np.zeros(ldT, np.float32), np.zeros(ldT, np.float32)
+        gid[phys[:n_norm]] = np.arange(n_norm) // gs
+        gam[phys[:n_norm]] = sd[apfx + ".weight_conv.1.group_norm.weight"]
+        bet[phys[:n_norm]] = sd[apfx + ".weight_conv.1.group_norm.bias"]
+        gstart = np.array([phys[gq * gs] for gq in range(G)], np.int32)
+        gend = np.array([phys[(gq + 1) * gs - 1] + 1 for gq in range(G)], np.int32)
+        scale, shift = self.A.zeros(B, ldT), self.A.zeros(B, ldT)
+        fin_d = [self.A.put(a) for a in (gid, gstart, gend, gam, bet)]
+
+        def fin_struct():
+            fin = SlideGnFin()
+            for n_, t_ in zip(("sum", "sq", "gid", "gstart", "gend", "gamma", "beta", "scale", "shift"),
+                              (ssum, ssq, fin_d[0], fin_d[1], fin_d[2], fin_d[3], fin_d[4], scale, shift)):
+                setattr(fin, n_, t_.data_ptr())
+            fin.inv_count, fin.C, fin.bs, fin.G = 1.0 / (gs * npx), ldT, ldT, G
+            return self.A.put(np.frombuffer(bytes(fin), dtype=np.uint8).copy())
+
         # lane 1 (query / score branch) forks here: it only needs the module inputs
         self._sync(0, 1)
-        if not issued:
+        q_rides = pair is not None and not issued and q_in is pair[0] and not self.two_lanes
+        if not issued and not q_rides:
             self._lane = 1
             self._gemm(q_in, 4, [qctx["qseg"]] + [e["qseg"] for e in extra_q])
             self._lane = 0
+        pair_fin = False
         # shared-input GEMM: [first_mlp | res_connect | grouped_feat_conv]
         if pair is not None:
             feat_tab, Cf, coords = pair
-            ctx = self._pair_first(npx_log2, K, feat_tab, Cf, [mlp_first, mlp_res, kseg], coords)
+            # the per-sample table pass also finalises the joint GroupNorm (SLIDE_OP_PAIR_NORM version 2)
+            pair_fin = ldT <= 2048 and os.environ.get("SLIDE_PAIR_NORM_V2", "1") != "0"
+            ctx = self._pair_first(npx_log2, K, feat_tab, Cf, [mlp_first, mlp_res, kseg], coords,
+                                   fin=fin_struct() if pair_fin else None,
+                                   lead_segs=([qctx["qseg"]] + [e["qseg"] for e in extra_q]) if q_rides else ())
             ctx.update(off1=ctx["offs"][0], offr=ctx["offs"][1], offk=ctx["offs"][2], lay1=mlp_first["layout"],
                        add1=mlp_first.get("addvec"))
             rres = ru(mlp_res["w"].shape[0])
@@ -710,34 +924,19 @@ class DenoiserEngine:
         self._sync(0, 1)  # the key statistics are ready
 
         def finish_scores():
-            # lane 1.  GroupNorm over the concatenation [q | k] (weight_conv.1): groups may straddle the two producers
+            # lane 1.  Joint GroupNorm of [q | k]: finalised by the pair-table pass, inside the per-point query GEMM below
+            # (its small-launch kernel), or by its own launch
             self._lane = 1
-            Ct = C1 + C2
-            G = min(32, Ct)
-            n_norm = Ct - Ct % G
-            gs = n_norm // G
-            phys = np.array([c if c < C1 else C1p + (c - C1) for c in range(Ct)], np.int64)
-            gid = np.full(ldT, -1, np.int32)
-            gam, bet = np.zeros(ldT, np.float32), np.zeros(ldT, np.float32)
-            gid[phys[:n_norm]] = np.arange(n_norm) // gs
-            gam[phys[:n_norm]] = sd[apfx + ".weight_conv.1.group_norm.weight"]
-            bet[phys[:n_norm]] = sd[apfx + ".weight_conv.1.group_norm.bias"]
-            gstart = np.array([phys[gq * gs] for gq in range(G)], np.int32)
-            gend = np.array([phys[(gq + 1) * gs - 1] + 1 for gq in range(G)], np.int32)
-            scale, shift = self.A.zeros(B, ldT), self.A.zeros(B, ldT)
-            d = [self.A.put(a) for a in (gid, gstart, gend, gam, bet)]
+            d = fin_d
             # (only the small-launch kernel finalises: same grid bound as run_gemm's dispatch)
             n_cob_p = ru(gn_layout(inter)[1]) // 32
             fuse_fin = (self.prec == 1 and self.use_glds and os.environ.get("SLIDE_FUSE_FIN", "1") != "0" and
                         ((B * 16 + 63) // 64) * ((n_cob_p + 1) // 2) <= 1024)
             gn_fin = None
-            if fuse_fin:  # finalised inside the per-point query GEMM below (its small-launch kernel), one launch less
-                fin = SlideGnFin()
-                for n_, t_ in zip(("sum", "sq", "gid", "gstart", "gend", "gamma", "beta", "scale", "shift"),
-                                  (ssum, ssq, d[0], d[1], d[2], d[3], d[4], scale, shift)):
-                    setattr(fin, n_, t_.data_ptr())
-                fin.inv_count, fin.C, fin.bs, fin.G = 1.0 / (gs * npx), ldT, ldT, G
-                gn_fin = self.A.put(np.frombuffer(bytes(fin), dtype=np.uint8).copy())
+            if pair_fin:
+                pass
+            elif fuse_fin:  # finalised inside the per-point query GEMM below (its small-launch kernel), one launch less
+                gn_fin = fin_struct()
             else:
                 self._emit(make_op(OP_FINALIZE_GN, i=(B, ldT, ldT), f=(1.0 / (gs * npx),),
                                         p=(ssum.data_ptr(), ssq.data_ptr(), d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(),
@@ -748,6 +947,11 @@ class DenoiserEngine:
             P = self.A.zeros(B * 16, ru(lay[1]), dtype=self.adt)
             self._gemm(Tq, 4, [dict(w=w2[:, :C1], mode=EPI_RAW, layout=(lay[0], lay[1], 0, 1, 1), out=P)],
                        in_affine=(scale, shift, 0, ldT), gn_fin=gn_fin)
+            if body is not None:  # the block body kernel (SLIDE_OP_BLOCK_BODY) takes it from here
+                self._lane = 0
+                body.update(P=P, lay_u=lay, scale=scale, shift=shift, C1=C1, C1p=C1p, C2p=C2p, ldT=ldT, w2=w2, apfx=apfx,
+                            cout=cout, inter=inter)
+                return ("body",)
             # neighbour half: u = GN4(relu(W2[:, C1:] . GN(relu(k)) + bias + P[point]))
             u = self._buf(rows, ru(lay[1]), cm=True)
             useg = dict(w=w2[:, C1:], bias=sd[apfx + ".weight_conv.2.bias"], mode=EPI_NORM,
@@ -851,8 +1055,13 @@ class DenoiserEngine:
             # pair decomposition (csrc/gemm_gx.hip): no grouped input, no h1 / r / key buffers; rows in natural neighbour order
             first, res = self._mlp_segments(mp, self.tvec, self.cvec, None, None)
             pair = (feat_in, C, dict(rel=C, abs=C + 3, ctr=C + 6))
-            (scores, finish), cout = self._attention(ap, 8, K, None, feat_in, mo, first, res, out, None, extra_q=extra_q, pair=pair)
+            body = {} if self._body_shape(mp, ap, 8) is not None else None
+            (scores, finish), cout = self._attention(ap, 8, K, None, feat_in, mo, first, res, out, None, extra_q=extra_q, pair=pair,
+                                                     body=body)
             S = scores()
+            if body is not None:
+                self._emit_block_body(body, mp, 8, K, out, self.cvec)
+                return out, cout
             self._mlp_tail(mp, 8, None, self.cvec, None, mo, pair=self.pair_ctx)
             finish(S)
             return out, cout
@@ -888,7 +1097,9 @@ class DenoiserEngine:
         zin = c_last + CU + 3
         assert sd[m2 + ".first_mlp.0.weight"].shape[1] == zin
         Z = self._buf(B * 16, zin)
-        (scores, finish), cout = self._attention(ap, 7, K, g, U, mo, first, res, Z, None, gather=gather, qctx=qctx, pair=pair)
+        body = {} if pair is not None and self._body_shape(m1, ap, 7) is not None else None
+        (scores, finish), cout = self._attention(ap, 7, K, g, U, mo, first, res, Z, None, gather=gather, qctx=qctx, pair=pair,
+                                                 body=body)
         S = scores()
         pctx = self.pair_ctx if pair is not None else None
         # skip features and coordinates: columns of Z the attention output does not touch -- on the score lane, beside
@@ -900,6 +1111,9 @@ class DenoiserEngine:
         tail_idx = self._tail_of.get(U.data_ptr())
         if self.fold_copies and U is self.feat0:
             self._prep_copies.append((Z.data_ptr() + es * c_last, Z.shape[1], 0, CU))
+        elif self.fold_copies and tail_idx is not None and tail_idx in self._body_args:
+            ba = self._body_args[tail_idx]
+            ba.out2, ba.out2_ld, ba.out2_n = Z.data_ptr() + es * c_last, Z.shape[1], CU
         elif self.fold_copies and tail_idx is not None:
             t_op = self.ops[tail_idx]
             t_op.p[7], t_op.f[2], t_op.f[3] = Z.data_ptr() + es * c_last, float(Z.shape[1]), float(CU)
@@ -913,8 +1127,11 @@ class DenoiserEngine:
             self._emit(make_op(OP_COPY_COLS, i=(B * 16, 3, 3, Z.shape[1], 0, int(self.prec == 1)),
                                     p=(self.xyz.data_ptr(), Z.data_ptr() + es * (c_last + CU))))
         self._lane = 0
-        self._mlp_tail(m1, 7, h1, self.cvec, r, mo, pair=pctx)
-        finish(S)
+        if body is not None:
+            self._emit_block_body(body, m1, 7, K, Z, self.cvec)
+        else:
+            self._mlp_tail(m1, 7, h1, self.cvec, r, mo, pair=pctx)
+            finish(S)
         n1 = sd[m2 + ".first_mlp.0.weight"].shape[0]
         n2 = sd[m2 + ".res_connect.weight"].shape[0]
         hz, rz = self._buf(B * 16, n1), self._buf(B * 16, n2)
@@ -964,6 +1181,7 @@ class DenoiserEngine:
         # COPY launches folded into the producers of their sources (SLIDE_FOLD_COPIES=0: separate launches)
         self.fold_copies = os.environ.get("SLIDE_FOLD_COPIES", "1") != "0"
         self._prep_copies, self._tail_of = [], {}
+        self._body_args = {}
         self._prep_idx = len(self.ops)
         self._emit(make_op(OP_PREP_POINTS, i=(B, self.cx, self.feat0.shape[1], self.prec),
                                 p=(self.x.data_ptr(), self.xyz.data_ptr(), self.feat0.data_ptr(), self.kidx.data_ptr(),
