@@ -321,7 +321,7 @@ def main():
                 return None
             rows, n_cob, npxl, cbw = o.i[0], o.i[3], o.i[4], o.i[7]
             grid = ((rows + 63) // 64) * ((n_cob + 1) // 2)
-            if a.prec == "fp16" and npxl == 4 and grid <= 1024:
+            if a.prec == "fp16" and npxl == 4 and grid <= (1024 if o.p[6] else 8192):
                 return "gemm_small_kernel<2, %s>" % b(o.p[3])
             if a.prec == "fp32" or not o.i[8]:
                 return "gemm_kernel<%d, %d, %d>" % (0 if a.prec == "fp32" else 1, npxl, cbw)
@@ -332,7 +332,7 @@ def main():
         # dominant kernel = the MFMA kernel with the largest share of the feature denoiser's step time, measured here
         by_k = {}
         for i in range(n):
-            k = kernel_of(f.step_ops[i])
+            k = f.kernel_names.get(i) or kernel_of(f.step_ops[i])  # (round-3 ops name their kernel at plan time)
             if k is not None and i in flops:
                 e = by_k.setdefault(k, [0.0, 0.0, 0])
                 e[0] += tot[i]; e[1] += flops[i]; e[2] += 1

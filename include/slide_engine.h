@@ -71,7 +71,7 @@ typedef struct SlideEpi {
 } SlideEpi;
 
 enum {
-  SLIDE_OP_GEMM = 1,        /* ([12] / [13]: squared-distance / interpolation-weight tables fp32 [B*16][16] of a SLIDE_F_RES_PAIR_NBR residual, with [9] the neighbour table)  p: X, W, epi, in_scale, in_shift, [5] timeline buffer (instrumented builds only, else NULL), [6] SlideGnFin* (16-row launches with input affine: finalise the statistics in this launch), [7] 9 zeroed ints for the optional persistent tile scheduler (NULL = one tile per workgroup), [8] point-feature table + [9] neighbour table of the GATHER mode (first GEMM of an SA / FP block: the first f[1] 32-column chunks of X row (b, p, k) are read from row b*16 + idx[(b*16+p)*16+k] of the table with row length f[2], neighbours per point 2^f[3]; p[0] / x_ld then describe only the remaining columns; with p[8] NULL, p[9] is the neighbour table of gathered pre_add terms, SlideEpi.pre_add_shift < 0); [11] + f[1..3] with p[3] / p[4] set and no gather: DEFERRED NORMALISATION of the module-level path -- x' = relu?(x * scale + shift) + add applied to the X fragments, p[11] = add vectors [sample][f[2]] (or NULL), f[1] = 256-row tiles per sample, f[3] = 2 * (channels of add) + (ReLU ? 1 : 0); [10] non-NULL selects the X-stationary kernel for sample-wide fp16 layers whose 256-row X tile fits the LDS (one workgroup per row tile keeps X resident and computes every column tile, the weights stream through a small LDS-DMA ring; i[9] == 5 keeps the ring kernels); f[0]: start stagger in us for the persistent mode; i[9]: 0 = default ring, 1 = 64-deep chunks, 2 = eight-wave 256x256 tiles   i: rows, x_ld, k_pad, n_cob, npx_log2, in_bs, prec, cbw(2|4), lds_dma (bit 0: fp16 LDS-DMA ring kernels; bit 1: W is CHUNK-MAJOR [k_pad/32][n_cob*32][32] -- ring kernels of the 128- / 256-row samples only).  CHUNK-MAJOR X: with x_ld == 32 and k_pad > 32 the ring kernels read X as [k/32][rows][32] (chunk kc of row r at X + (kc*rows + r)*32); outputs / residuals use the same layout through SlideEpi's per-block pointer with out_ld / res_ld == 32 */
+  SLIDE_OP_GEMM = 1,        /* ([12] / [13]: squared-distance / interpolation-weight tables fp32 [B*16][16] of a SLIDE_F_RES_PAIR_NBR residual, with [9] the neighbour table)  p: X, W, epi, in_scale, in_shift, [5] timeline buffer (instrumented builds only, else NULL), [6] SlideGnFin* (16-row launches with input affine: finalise the statistics in this launch), [7] 9 zeroed ints for the optional persistent tile scheduler (NULL = one tile per workgroup), [8] point-feature table + [9] neighbour table of the GATHER mode (first GEMM of an SA / FP block: the first f[1] 32-column chunks of X row (b, p, k) are read from row b*16 + idx[(b*16+p)*16+k] of the table with row length f[2], neighbours per point 2^f[3]; p[0] / x_ld then describe only the remaining columns; with p[8] NULL, p[9] is the neighbour table of gathered pre_add terms, SlideEpi.pre_add_shift < 0); [11] + f[1..3] with p[3] / p[4] set and no gather: DEFERRED NORMALISATION of the module-level path -- x' = relu?(x * scale + shift) + add applied to the X fragments, p[11] = add vectors [sample][f[2]] (or NULL), f[1] = 256-row tiles per sample, f[3] = 2 * (channels of add) + (ReLU ? 1 : 0); [10] non-NULL selects the X-stationary kernel for sample-wide fp16 layers whose 256-row X tile fits the LDS (one workgroup per row tile keeps X resident and computes every column tile, the weights stream through a small LDS-DMA ring; i[9] == 5 keeps the ring kernels); f[0]: start stagger in us for the persistent mode; i[9]: 0 = default ring, 1 = 64-deep chunks, 2 = eight-wave 256x256 tiles   i: rows, x_ld, k_pad, n_cob, npx_log2, in_bs, prec, cbw(2|4), lds_dma (bit 0: fp16 LDS-DMA ring kernels; bit 1: W is CHUNK-MAJOR [k_pad/32][n_cob*32][32] -- ring kernels of the 128- / 256-row samples only; bit 2: a block carries a PAIR residual).  CHUNK-MAJOR X: with x_ld == 32 and k_pad > 32 the ring kernels read X as [k/32][rows][32] (chunk kc of row r at X + (kc*rows + r)*32); outputs / residuals use the same layout through SlideEpi's per-block pointer with out_ld / res_ld == 32 */
   SLIDE_OP_PREP_POINTS = 2, /* p: x, xyz, feat0, knn_idx, knn_d2, [5] optional second copy of feat0, chunk-major [c/32][B*16][32], [6] SlidePrepCopy[i[4]] (device), [7] optional knn_w [B*16][16]: group_knn's interpolation weights of the 8 nearest (pointnet2_utils.py:510-513), 0 beyond   i: B, cx, ldf, prec, n_copies     (16 points / sample) */
   SLIDE_OP_ASSEMBLE_SA = 3, /* p: xyz, feat, knn_idx, g            i: B, C, ldf, ldg, K, prec, c_begin (0 = all columns; else only columns >= c_begin), ld_out */
   SLIDE_OP_ASSEMBLE_FP = 4, /* p: xyz, feat, knn_idx, knn_d2, g    i: B, C, ldf, ldg, K, prec, c_begin, ld_out */
@@ -117,7 +117,7 @@ enum {
                              *    [10] add1 fp32 [b*add1_bs + c] or NULL, [11] out [n2/32][B*256][32] fp16
                              * i: B, t_ld, k1, n1 (128 | 256), n2 (multiple of 256), gs1, gs2 (GroupNorm group sizes 4 | 8 | 16), add0_stride,
                              *    add0_bs, add1_bs      f: 1 / (gs1 * 256), 1 / (gs2 * 256) */
-  SLIDE_OP_BLOCK_BODY = 20, /* the whole K-expanded body of an SA / FP block whose widths are <= 256 channels in one launch (csrc/block_body.hip):
+  SLIDE_OP_BLOCK_BODY = 30, /* the whole K-expanded body of an SA / FP block whose widths are <= 256 channels in one launch (csrc/block_body.hip):
                              * Mlp tail -> mo, generated keys -> u, attention tail; one workgroup per sample, mo / u as MFMA operand fragments in
                              * registers, weights through one LDS-DMA ring.  p[0]: HOST pointer to the BodyArgs block (csrc/block_body.hip;
                              * its members are device pointers), kept alive by the plan.  i: npx_log2 (7 | 8), has_rest_mlp */

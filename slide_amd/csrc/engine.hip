@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
 // WC = 1: four waves, tile 256 rows x 32*CBW channels.  WC = 2: eight waves, tile 256 rows x 64*CBW channels -- wave
 // (wr, wc) owns rows 64*wr.. and channel half wc, so the X chunk is fetched once per 64*CBW channels (less L2 -> LDS
 // traffic per MAC, half as many prologues); each channel half runs the 4-wave epilogue on its own LDS tables.
-template <int NPXL, int CBW, int NST, int BKT, bool AFF, int WC = 1, bool GAT = false>
+template <int NPXL, int CBW, int NST, int BKT, bool AFF, int WC = 1, bool GAT = false, bool PAIRRES = false>
 __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem_raw, const int tr, const int tc) {
   using T = _Float16;
   constexpr int NW = 4 * WC, NT = 256 * WC;  // waves, threads
@@ -359,7 +359,7 @@ __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem
   __syncthreads();  // every wave is done with the tiles before `red` reuses them
   SLIDE_STAMP(a, 2);
 
-  gemm_epilogue<SLIDE_PREC_F16, NPXL, CBW>(a, acc, row0, cob0 + wc * CBW, wave, half, col, epi_lds + wc * CBW * EPI_DW,
+  gemm_epilogue<SLIDE_PREC_F16, NPXL, CBW, 2, PAIRRES>(a, acc, row0, cob0 + wc * CBW, wave, half, col, epi_lds + wc * CBW * EPI_DW,
                                            vec_lds + wc * CBW * 96,
                                            reinterpret_cast<float *>(smem_raw) + wc * (256 + 128) * CBW);
   SLIDE_STAMP(a, 5);
@@ -376,7 +376,7 @@ __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem
 // phase instead of all bursting their loads, then all bursting their stores, and there is no last partial round.
 // The workgroup in the odd wave slot of a CU starts `stagger` later so that the pair begins half a tile apart.
 // sched[0..7] = next tile per XCD, sched[8] = finished workgroups; the last one to finish re-arms the counters.
-template <int NPXL, int CBW, int NST, int BKT, bool AFF, bool GAT = false>
+template <int NPXL, int CBW, int NST, int BKT, bool AFF, bool GAT = false, bool PAIRRES = false>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int ntc = (a.n_cob + CBW - 1) / CBW;
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
     const int q0 = blockIdx.x >> 3;
     const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;
     if (tr >= ntr) return;
-    glds_tile<NPXL, CBW, NST, BKT, AFF, 1, GAT>(a, smem_raw, tr, tc);
+    glds_tile<NPXL, CBW, NST, BKT, AFF, 1, GAT, PAIRRES>(a, smem_raw, tr, tc);
     return;
   }
   const int my_tiles = ((ntr - xcd + 7) / 8) * ntc;  // row tiles tr = xcd, xcd + 8, ...
@@ -415,9 +415,9 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
 #ifdef SLIDE_TIMELINE
     GemmArgs a2 = a;  // stamps indexed by tile instead of by workgroup
     if (a.dbg) a2.dbg = a.dbg + ((long long)(xcd + 8 * t) - (long long)blockIdx.x) * 16;
-    glds_tile<NPXL, CBW, NST, BKT, AFF, 1, GAT>(a2, smem_raw, (t / ntc) * 8 + xcd, t % ntc);
+    glds_tile<NPXL, CBW, NST, BKT, AFF, 1, GAT, PAIRRES>(a2, smem_raw, (t / ntc) * 8 + xcd, t % ntc);
 #else
-    glds_tile<NPXL, CBW, NST, BKT, AFF, 1, GAT>(a, smem_raw, (t / ntc) * 8 + xcd, t % ntc);
+    glds_tile<NPXL, CBW, NST, BKT, AFF, 1, GAT, PAIRRES>(a, smem_raw, (t / ntc) * 8 + xcd, t % ntc);
 #endif
     __syncthreads();  // the epilogue's LDS reads are done before the next tile's tables / DMAs / s_tile land
   }
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs a) {
 
 // Three workgroups per CU: 64-channel tiles on a two-stage ring (41 KB of LDS) under a 168-VGPR budget -- one more
 // resident workgroup to fill the epilogue / prologue bubbles of the other two (opt-in: GemmArgs.stagger == 3).
-template <int NPXL, bool AFF, bool GAT>
+template <int NPXL, bool AFF, bool GAT, bool PAIRRES = false>
 __global__ __launch_bounds__(256, 3) void gemm_glds_occ3_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int ntc = (a.n_cob + 1) / 2;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256, 3) void gemm_glds_occ3_kernel(GemmArgs a) {
   const int xcd = blockIdx.x & 7, q0 = blockIdx.x >> 3;
   const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;
   if (tr >= ntr) return;
-  glds_tile<NPXL, 2, 2, 32, AFF, 1, GAT>(a, smem_raw, tr, tc);
+  glds_tile<NPXL, 2, 2, 32, AFF, 1, GAT, PAIRRES>(a, smem_raw, tr, tc);
 }
 
 // eight-wave variant (one tile per workgroup, one workgroup per CU: its deeper ring needs the LDS of two)
@@ -1556,7 +1556,7 @@ int launch_gemm(const GemmArgs &a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-template <int NPXL, int CBW, int NST, int BKT, bool AFF, bool GAT = false>
+template <int NPXL, int CBW, int NST, int BKT, bool AFF, bool GAT = false, bool PAIRRES = false>
 int launch_gemm_glds(const GemmArgs &a, hipStream_t s) {
   constexpr int NSAMP = (1 << NPXL) >= TM ? 1 : TM >> NPXL;
   const size_t shm = (size_t)NST * (TM + (CBW < 2 ? 64 : 32 * CBW)) * BKT * 2 + CBW * (sizeof(SlideEpi) + 96 * 4) + 32 +
@@ -1572,15 +1572,15 @@ int launch_gemm_glds(const GemmArgs &a, hipStream_t s) {
   static bool attr_done[SLIDE_MAX_DEVICES] = {};
   bool &attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_glds_kernel<NPXL, CBW, NST, BKT, AFF, GAT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_glds_kernel<NPXL, CBW, NST, BKT, AFF, GAT, PAIRRES>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (NST > 3 || BKT > 32) ? 160 * 1024 : 84 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<NPXL, CBW, NST, BKT, AFF, GAT>), dim3(grid), dim3(256), (size_t)b.shm_bytes, s, b);
+  hipLaunchKernelGGL((gemm_glds_kernel<NPXL, CBW, NST, BKT, AFF, GAT, PAIRRES>), dim3(grid), dim3(256), (size_t)b.shm_bytes, s, b);
   return (int)hipGetLastError();
 }
 
-template <int NPXL, bool AFF, bool GAT>
+template <int NPXL, bool AFF, bool GAT, bool PAIRRES = false>
 int launch_gemm_occ3(const GemmArgs &a, hipStream_t s) {
   constexpr int NSAMP = (1 << NPXL) >= TM ? 1 : TM >> NPXL;
   const size_t shm = (size_t)2 * (TM + 64) * 32 * 2 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32 + (AFF ? (size_t)NSAMP * 3 * a.k_pad * 2 : 0);
@@ -1593,11 +1593,11 @@ int launch_gemm_occ3(const GemmArgs &a, hipStream_t s) {
   static bool attr_done[SLIDE_MAX_DEVICES] = {};
   bool &attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_glds_occ3_kernel<NPXL, AFF, GAT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_glds_occ3_kernel<NPXL, AFF, GAT, PAIRRES>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 53 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_glds_occ3_kernel<NPXL, AFF, GAT>), dim3(grid), dim3(256), (size_t)b.shm_bytes, s, b);
+  hipLaunchKernelGGL((gemm_glds_occ3_kernel<NPXL, AFF, GAT, PAIRRES>), dim3(grid), dim3(256), (size_t)b.shm_bytes, s, b);
   return (int)hipGetLastError();
 }
 
@@ -1672,11 +1672,21 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
   a.rows = o.i[0]; a.x_ld = o.i[1]; a.k_pad = o.i[2]; a.n_cob = o.i[3]; a.in_bs = o.i[5];
   const int npxl = o.i[4], prec = o.i[6], cbw = o.i[7], glds = o.i[8] & 1;
   a.w_cm = (o.i[8] >> 1) & 1;  // chunk-major weights (ring kernels of the 128 / 256-row samples only)
+  if ((o.i[8] >> 2) & 1) {     // a block of this GEMM carries a PAIR residual: the instantiations compiled for it
+    if (!glds || prec != SLIDE_PREC_F16 || a.in_scale || o.p[8] || o.p[10]) return -12;
+    // (two workgroups per CU, 256 registers: the three-workgroup form spills with the pair address arithmetic)
+    if (npxl == 8) return launch_gemm_glds<8, 2, 3, 32, false, false, true>(a, s);
+    if (npxl == 7) return launch_gemm_glds<7, 2, 3, 32, false, false, true>(a, s);
+    return -12;
+  }
   if (a.w_cm && (!glds || (npxl != 7 && npxl != 8) || o.p[10] || o.i[9] == 1)) return -11;
   if (a.k_pad % BK || a.x_ld % 8 || a.rows <= 0 || a.n_cob <= 0) return -3;
   // fp16 16-row launches: split-K small-launch kernel, with or without the input affine (i[9] == 3 keeps the 256-row
   // kernels, for A/B timing)
-  if (prec == SLIDE_PREC_F16 && npxl == 4 && o.i[9] != 3 && ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2) <= 1024)
+  // (up to 1024 tiles with the statistics finalisation, 8192 without: the wide per-point GEMMs of the pair decomposition --
+  //  N = 1056 .. 1568 -- stay on this spill-free kernel instead of the 256-row ring tiles, which spill at 16 rows per sample)
+  if (prec == SLIDE_PREC_F16 && npxl == 4 && o.i[9] != 3 &&
+      ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2) <= (a.gn_fin ? 1024 : 8192))
     return launch_gemm_small(a, s);
   if (a.gn_fin) return -10;  // only the small-launch kernel finalises statistics
   // X-stationary kernel (SlideOp.p[10] = the weights as MFMA A fragments): one workgroup per row tile computes every
@@ -1789,7 +1799,9 @@ int run_attn_tail(const SlideOp &o, hipStream_t s) {
   const int npxl = o.i[6];
   if (a.k1 % 32 || a.k2 % 32 || a.rows <= 0 || a.n_cob <= 0) return -3;
   const int ntr8 = (a.rows + TM - 1) / TM;
-  static const bool tail8_on = [] { const char *e = getenv("SLIDE_TAIL8"); return !(e && e[0] == '0'); }();
+  // (opt-in, SLIDE_TAIL8=1: measured equal to the four-wave form for one chain and 2 % slower with four chains in flight --
+  //  both forms are bound by the per-CU L2 -> LDS fill rate of the non-resident u / mo tiles)
+  static const bool tail8_on = [] { const char *e = getenv("SLIDE_TAIL8"); return e && e[0] == '1'; }();
   if (tail8_on && a.n_cob >= 8 && (npxl == 7 || npxl == 8) && a.k1 % 64 == 0 && a.k2 % 64 == 0) {  // eight-wave 256 x 128 tiles (see attn_tail8_kernel)
     const size_t shm8 = (size_t)3 * 2 * (TM + 128) * 64 + 4 * 128 * 4 + 64;
     const int grid8 = ((ntr8 + 7) / 8) * 8 * ((a.n_cob + 3) / 4);

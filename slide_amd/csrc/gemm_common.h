@@ -154,7 +154,9 @@ __device__ __forceinline__ void stage_epilogue_tables(const GemmArgs &a, int cob
 // Shared epilogue of the GEMM kernels: acc[cb][rb] holds D[co][row] in the 32x32 MFMA C layout (lane: row = lane & 31,
 // reg r: co = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  `red` = 4*CBW*2*16*2 floats of LDS scratch (the dead tiles).
 // RB = 32-row blocks per wave (2; 1 for the split-K small-launch kernel, whose waves own one block each).
-template <int PREC, int NPXL, int CBW, int RB = 2>
+// PAIRRES: the instantiation also serves the PAIR residual (SLIDE_F_RES_PAIR / _NBR: two table rows instead of one stored row) --
+// a template parameter because its address arithmetic costs every instantiation registers, also where no plan uses it
+template <int PREC, int NPXL, int CBW, int RB = 2, bool PAIRRES = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[CBW][RB], int row0, int cob0, int wave,
                                               int half, int col, const uint32_t *epi_lds, const float *vec_lds,
                                               float *red) {
@@ -184,7 +186,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     // global reads of the store phase, issued first so that their latency overlaps the statistics / normalisation work
     constexpr bool kHalf = std::is_same<T, _Float16>::value;
     const bool wide16 = kHalf && !(flags & SLIDE_F_OUT_F32);
-    const bool pair = (flags & (SLIDE_F_RES_PAIR | SLIDE_F_RES_PAIR_NBR)) != 0;  // (fp16 rows, 128- / 256-row samples only)
+    const bool pair = PAIRRES && (flags & (SLIDE_F_RES_PAIR | SLIDE_F_RES_PAIR_NBR)) != 0;  // (fp16 rows, 128- / 256-row samples only)
     const GLOBAL_AS float *addv = e_addvec;
     static_assert(RB == 2 || NPXL < 6, "one row block per wave only for samples of at most 32 rows");
     constexpr int NA = NPXL >= 6 ? 1 : RB;  // a wave's 64 rows belong to one sample when NPX >= 64
@@ -206,7 +208,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
         // pair residual: the row's value is the sum of two per-point table rows (+ the two per-slot terms of group_knn)
         size_t ra_row = (size_t)row, rb_row = 0;
         _Float16 sd2 = (_Float16)0.f, sw = (_Float16)0.f;
-        if constexpr (kHalf && NPXL >= 7) {
+        if constexpr (kHalf && NPXL >= 7 && PAIRRES) {
           if (pair && ok) {
             const int smp = row >> NPXL, pxl = row & (NPX - 1);
             if (flags & SLIDE_F_RES_PAIR) {
@@ -224,7 +226,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
           if constexpr (kHalf)
             if (wide16 && resid && ok) {
               rpre[rb][p] = *(const GLOBAL_AS u32x4 *)(resid + ra_row * e_res_ld + 16 * p + 8 * half);
-              if constexpr (NPXL >= 7) {
+              if constexpr (NPXL >= 7 && PAIRRES) {
                 if (pair) {
                   const u32x4 tb = *(const GLOBAL_AS u32x4 *)(gptr<const T>(rdp(34)) + rb_row * e_res_ld + 16 * p + 8 * half);
                   f16x8 r8 = __builtin_bit_cast(f16x8, rpre[rb][p]) + __builtin_bit_cast(f16x8, tb);

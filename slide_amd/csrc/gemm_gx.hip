@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void gemm_gx_kernel(GemmArgs a) {
   }
   __syncthreads();  // every wave is done with the ring before `red` reuses it
   SLIDE_STAMP(a, 2);
-  gemm_epilogue<SLIDE_PREC_F16, NPXL, CBW>(a, acc, row0, cob0, wave, half, col, epi_lds, vec_lds,
+  gemm_epilogue<SLIDE_PREC_F16, NPXL, CBW, 2, MODE == 0>(a, acc, row0, cob0, wave, half, col, epi_lds, vec_lds,  // (mode 0 = the Mlp layers: PAIR residual)
                                            reinterpret_cast<float *>(smem_raw));
   SLIDE_STAMP(a, 5);
 #ifdef SLIDE_TIMELINE

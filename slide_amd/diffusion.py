@@ -83,6 +83,7 @@ class _GraphedSampler:
         # per-launch accounting of the engine, re-keyed by position in the step plan
         self.gemm_flops = {j: e.gemm_flops[i] for j, i in enumerate(kept) if i in e.gemm_flops}
         self.gemm_bytes = {j: e.gemm_bytes[i] for j, i in enumerate(kept) if i in e.gemm_bytes}
+        self.kernel_names = {j: e.kernel_names[i] for j, i in enumerate(kept) if i in getattr(e, "kernel_names", {})}
         ops += [update_op]  # the update kernel's last block also advances the device-side timestep (t -= 1, step += 1)
         self.step_ops = (SlideOp * len(ops))(*ops)
         self.n_launches = len(ops)

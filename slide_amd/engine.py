@@ -24,7 +24,7 @@ PREC = {"fp32": 0, "fp16": 1}
  OP_COND, OP_UPDATE_POS, OP_UPDATE_FEAT, OP_ADVANCE_T) = range(1, 13)
 OP_SYNC = 14
 OP_ATTN_TAIL = 16
-OP_GEMM_GX, OP_PAIR_NORM, OP_SA_CHAIN, OP_BLOCK_BODY = 17, 18, 19, 20
+OP_GEMM_GX, OP_PAIR_NORM, OP_SA_CHAIN, OP_BLOCK_BODY = 17, 18, 19, 30
 
 
 class SlideEpi(ctypes.Structure):
@@ -404,7 +404,8 @@ class DenoiserEngine:
         assert wfrag is None or not (w_cm or self._is_cm(X))
         if wfrag is not None and os.environ.get("SLIDE_XS_OCC"):
             knob = 10 + int(os.environ["SLIDE_XS_OCC"])  # cap the workgroups per CU of the X-stationary kernel (A/B timing)
-        self._emit(make_op(OP_GEMM, i=(rows, x_ld, ld, n_cob, npx_log2, in_bs, self.prec, cbw, glds | (2 if w_cm else 0), knob),
+        has_pair = any(v[1].get("res_pair") is not None for v in vec_list)  # -> the kernels compiled with the PAIR residual
+        self._emit(make_op(OP_GEMM, i=(rows, x_ld, ld, n_cob, npx_log2, in_bs, self.prec, cbw, glds | (2 if w_cm else 0) | (4 if has_pair else 0), knob),
                            f=(-1.0 if self.persistent == 2 else float(os.environ.get('SLIDE_STAGGER_US', '0')),) + gf,
                                 p=(X.data_ptr(), Wd.data_ptr(), ed.data_ptr(),
                                    None if sc is None else sc.data_ptr() + 4 * aff_off,
@@ -440,6 +441,7 @@ class DenoiserEngine:
         add = gx.get("add")
         vv = gx.get("vv")
         assert (npx_log2 == 7) == (pair_tabs is not None)
+        self.kernel_names[len(self.ops)] = "gemm_gx_kernel<%d, 3, %d>" % (npx_log2, gx["mode"])
         self._emit(make_op(OP_GEMM_GX,
                            i=(rows, ta.shape[1], ld, n_cob, npx_log2, in_bs, gx["mode"], 0 if add is None else add[2],
                               0 if add is None else add[4], 0 if vv is None else 2 * vv.shape[2]),
@@ -544,6 +546,7 @@ class DenoiserEngine:
         self.gemm_flops[len(self.ops)] = fl
         self.gemm_bytes[len(self.ops)] = (2 * B * 16 * (c1 + c3) * 2 + (w1.size + w2.size) * 2, rows * c3 * 2)
         self.flops += fl
+        self.kernel_names[len(self.ops)] = "sa_chain_kernel<%d>" % (c2 // 32)
         self._emit(make_op(OP_SA_CHAIN,
                            i=(B, ta.shape[1], c1, c2, c3, l2[3], l3[3], 0 if add0 is None else add0[4], 0 if add0 is None else add0[2],
                               0 if add1 is None else add1[2]),
@@ -618,7 +621,7 @@ class DenoiserEngine:
             d.append(self.A.put(vv_in))
             vv = self.A.zeros(B, 2, ldy)
         # loop-invariant when the coordinates are a fixed condition?  No: y changes every step.
-        v2 = ldy <= 2048 and os.environ.get("SLIDE_PAIR_NORM_V2", "1") != "0"
+        v2 = ldy <= 2048 and os.environ.get("SLIDE_PAIR_NORM_V2", "0") != "0"
         assert fin is None or v2
         self._emit(make_op(OP_PAIR_NORM, i=(B, ldy, K, 2 if v2 else 1),
                            p=(Y.data_ptr(), self.xyz.data_ptr(), d[0].data_ptr(), d[1].data_ptr(), ed.data_ptr(),
@@ -682,7 +685,8 @@ class DenoiserEngine:
             return None
         shape = (npx_log2, rest, (c2 // 32) if rest else 0, n_mo // 32, n_u // 32)
         # ((7, False, 0, 8, 8) -- FP1 -- was built and measured slower than its three separate launches: one wave per SIMD)
-        if shape not in ((7, False, 0, 4, 4), (8, True, 4, 8, 5)):
+        # ((8, True, 4, 8, 5) -- SA0 -- spills under its 256-register budget: opt-in with SLIDE_BODY=2)
+        if shape not in (((7, False, 0, 4, 4), (8, True, 4, 8, 5)) if os.environ.get("SLIDE_BODY", "1") == "2" else ((7, False, 0, 4, 4),)):
             return None
         return shape
 
@@ -815,6 +819,8 @@ class DenoiserEngine:
         self.flops += 2 * rows * fl
         self._tail_of[out.data_ptr()] = len(self.ops)
         self._body_args[len(self.ops)] = a
+        self.kernel_names[len(self.ops)] = "block_body_kernel<%d, %s, %d, %d, %d>" % (
+            npx_log2, "true" if rest else "false", (c2 // 32) if rest else 0, n_mo // 32, n_u // 32)
         self._emit(make_op(OP_BLOCK_BODY, i=(npx_log2, int(rest)), p=(ctypes.addressof(a),)))
 
     def _attention(self, apfx, npx_log2, K, g, q_in, mo, mlp_first, mlp_res, out, out_ld_buf, gather=None, qctx=None,
@@ -880,7 +886,9 @@ class DenoiserEngine:
         if pair is not None:
             feat_tab, Cf, coords = pair
             # the per-sample table pass also finalises the joint GroupNorm (SLIDE_OP_PAIR_NORM version 2)
-            pair_fin = ldT <= 2048 and os.environ.get("SLIDE_PAIR_NORM_V2", "1") != "0"
+            # (SLIDE_PAIR_NORM_V2=1, opt-in: one 1024-thread workgroup per sample that also finalises the joint GroupNorm -- 3 %
+            #  faster for a single chain, 5 % slower with four chains in flight: sixteen waves must find room on ONE CU)
+            pair_fin = ldT <= 2048 and os.environ.get("SLIDE_PAIR_NORM_V2", "0") != "0"
             ctx = self._pair_first(npx_log2, K, feat_tab, Cf, [mlp_first, mlp_res, kseg], coords,
                                    fin=fin_struct() if pair_fin else None,
                                    lead_segs=([qctx["qseg"]] + [e["qseg"] for e in extra_q]) if q_rides else ())
@@ -1148,6 +1156,7 @@ class DenoiserEngine:
         self.flops = 0
         self.gemm_flops = {}
         self.gemm_bytes = {}
+        self.kernel_names = {}  # rocprofv3 kernel name of the round-3 ops (bench.py's roofline attribution), by op index
         self.xyz_copy_idx = []
         self.persistent = int(os.environ.get('SLIDE_PERSISTENT', '0'))  # 1: tile counter per XCD, 2: static tile lists
         # persistent I/O + per-step state

@@ -128,19 +128,26 @@ class CategoryChains:
     weights(category) -> (position state dict, feature state dict)."""
 
     def __init__(self, total, rank, world_size, pos_cfg, feat_cfg, weights, device, prec="fp16", seed=0, categories=FIVE_CATEGORIES):
-        from .diffusion import FeatureSampler, PositionSampler
         self.total, self.rank, self.world, self.device, self.categories = int(total), rank, world_size, device, categories
         self.segments = category_segments(total, rank, world_size, categories)
+        # width of a latent row: known on EVERY rank, also on one whose shard is empty -- all ranks must enter the same
+        # collectives in generate() (ADVICE r2: a rank without chains used to take the object all-gather alone)
+        self.cx = 3 + int(feat_cfg["pointnet_config"]["in_fea_dim"])
         self.chains = []
         for k, (c, lo, hi) in enumerate(self.segments):
             sd_p, sd_f = weights(c)
             # the in-kernel noise is keyed on (seed, chain nonce, step, element): the global offset `lo` keeps the streams of
             # different segments / ranks apart
-            ps = PositionSampler(pos_cfg["pointnet_config"], sd_p, hi - lo, device, pos_cfg["diffusion_config"], prec=prec,
-                                 seed=(seed << 24) ^ (2 * lo + 1), use_graph=False)
-            fs = FeatureSampler(feat_cfg["pointnet_config"], sd_f, hi - lo, device, feat_cfg["standard_diffusion_config"], prec=prec,
-                                seed=(seed << 24) ^ (2 * lo + 2), use_graph=False)
+            ps, fs = self._make_chain(pos_cfg, feat_cfg, sd_p, sd_f, hi - lo, prec, (seed << 24) ^ (2 * lo + 1), (seed << 24) ^ (2 * lo + 2))
             self.chains.append((c, lo, hi, ps, fs))
+
+    def _make_chain(self, pos_cfg, feat_cfg, sd_p, sd_f, n, prec, seed_p, seed_f):
+        from .diffusion import FeatureSampler, PositionSampler
+        ps = PositionSampler(pos_cfg["pointnet_config"], sd_p, n, self.device, pos_cfg["diffusion_config"], prec=prec,
+                             seed=seed_p, use_graph=False)
+        fs = FeatureSampler(feat_cfg["pointnet_config"], sd_f, n, self.device, feat_cfg["standard_diffusion_config"], prec=prec,
+                            seed=seed_f, use_graph=False)
+        return ps, fs
 
     def run(self, gen=None, steps=None):
         """position chain then feature chain of every segment (all `steps` reverse steps, default the full schedule); the
@@ -161,15 +168,14 @@ class CategoryChains:
             pending = fs
         if pending is not None:
             outs.append(pending.state())
-        return torch.cat(outs, dim=0) if outs else torch.empty(0, 16, 0, device=self.device)
+        return torch.cat(outs, dim=0) if outs else torch.empty(0, 16, self.cx, device=self.device)
 
     def generate(self, gen=None, steps=None):
         """-> (latents [total, 16, 3 + F] on every rank, labels [total]); one all-gather (RCCL over xGMI; gloo in the tests)"""
         local = self.run(gen, steps)
         base = self.segments[0][1] if self.segments else 0
-        cx = self.chains[0][4].engine.cx if self.chains else None
         return generate_categories(self.total, lambda c, lo, hi: local[lo - base:hi - base], self.rank, self.world, self.categories,
-                                   gather_device=self.device, row_shape=None if cx is None else (16, cx))
+                                   gather_device=self.device, row_shape=(16, self.cx))
 
 
 def save_generated(save_dir, points, labels, timing, num_points, keypoint=None, keypoint_feature=None, ckpt_info=""):

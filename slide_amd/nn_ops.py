@@ -55,7 +55,7 @@ class _GemmPlan:
             e.out = self.y.data_ptr() + 4 * 32 * j
         self.epi = torch.from_numpy(np.frombuffer(bytes(epis), dtype=np.uint8).copy()).to(device)
         ntr = (rows + 255) // 256
-        cbw = 4 if (self.half and n_cob >= 4 and ntr * ((n_cob + 3) // 4) >= 256) else 2
+        cbw = 4 if (self.half and n_cob >= 4 and ntr * ((n_cob + 3) // 4) >= 256 and os.environ.get("SLIDE_MODULE_CBW4", "0") != "0") else 2
         self.op = make_op(OP_GEMM, i=(rows, self.kp, self.kp, n_cob, 8, 0, int(self.half), cbw, int(self.half), 0),
                           p=(self.x.data_ptr(), self.W.data_ptr(), self.epi.data_ptr(), None, None))
 

@@ -185,7 +185,7 @@ class _ConvPlan:
             st = (torch.empty(rows // 256, self.op_, device=out.device), torch.empty(rows // 256, self.op_, device=out.device))
         n_cob = self.op_ // 32
         ntr = (rows + 255) // 256
-        cbw = 4 if (self.half and n_cob >= 4 and ntr * ((n_cob + 3) // 4) >= 256) else 2
+        cbw = 4 if (self.half and n_cob >= 4 and ntr * ((n_cob + 3) // 4) >= 256 and os.environ.get("SLIDE_MODULE_CBW4", "0") != "0") else 2
         sc = sh = add = None
         f = (0.0, 0.0, 0.0, 0.0)
         in_bs = 0

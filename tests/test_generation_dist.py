@@ -105,3 +105,53 @@ def _worker_cat(rank, world, port, total):
 @pytest.mark.parametrize("total,world", [(23, 2), (7, 3)])
 def test_five_category_generation_gloo(total, world):
     mp.spawn(_worker_cat, args=(world, _free_port(), total), nprocs=world, join=True)
+
+
+class _StubSampler:
+    """stands in for a HIP sampler on CPU: state = a tensor that encodes the chain's seed and batch row"""
+
+    def __init__(self, n, width, seed):
+        self.n, self.width, self.seed, self.T = n, width, seed, 1
+        self.engine = type("E", (), {"cx": width})()
+
+    def begin(self, lab, *xs):
+        self.lab = lab
+
+    def advance(self, steps):
+        pass
+
+    def state(self):
+        base = torch.arange(self.n, dtype=torch.float32)[:, None, None] + float(self.seed % 1000) * 1000
+        return (base + self.lab.float()[:, None, None]).expand(self.n, 16, self.width).clone()
+
+
+def _worker_chains(rank, world, port, total):
+    """CategoryChains.generate with MORE RANKS THAN SHARDS: a rank without chains must enter the same collectives
+    as the ranks with chains (it used to take an object all-gather alone: gloo aborted, RCCL would hang)"""
+    from slide_amd.generation import CategoryChains
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Chains(CategoryChains):
+        def _make_chain(self, pos_cfg, feat_cfg, sd_p, sd_f, n, prec, seed_p, seed_f):
+            return _StubSampler(n, 3, seed_p), _StubSampler(n, self.cx, seed_f)
+
+    feat_cfg = {"pointnet_config": {"in_fea_dim": 48}}
+    ch = Chains(total, rank, world, None, feat_cfg, lambda c: (None, None), torch.device("cpu"))
+    assert (len(ch.chains) == 0) == (shard_range(total, rank, world)[0] >= shard_range(total, rank, world)[1])
+    full, labels = ch.generate()
+    assert full.shape == (total, 16, 51) and labels.shape == (total,)
+    # every row carries its category label in the fractional encoding and is identical on every rank
+    gathered = [torch.empty_like(full) for _ in range(world)]
+    dist.all_gather(gathered, full)
+    assert all(torch.equal(g, full) for g in gathered)
+    assert torch.equal(full[:, 0, 0] % 1000 - torch.as_tensor(labels, dtype=torch.float32),
+                       torch.cat([torch.arange(hi - lo, dtype=torch.float32) for r in range(world)
+                                  for _, lo, hi in category_segments(total, r, world)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total,world", [(2, 3), (1, 2), (9, 2)])
+def test_category_chains_more_ranks_than_shards_gloo(total, world):
+    mp.spawn(_worker_chains, args=(world, _free_port(), total), nprocs=world, join=True)

@@ -392,6 +392,7 @@ def test_x_stationary_kernel_bit_identical(gpu_device, monkeypatch):
     column tiles from it -- the same MFMA / epilogue arithmetic in the same order as the ring kernels, so the denoiser output
     must be bit-identical in every mode (default policy, every eligible layer, 128-channel tiles, capped occupancy)"""
     from slide_amd.engine import DenoiserEngine
+    monkeypatch.setenv("SLIDE_GX", "0")  # the round-2 plan (the X-stationary kernel reads stored K-expanded inputs)
     for name in ("pos", "feat"):
         g, hp, sd = _load(name)
         x, ts, lab = g["x_mixed"], g["ts_mixed"], g["label_mixed"]
@@ -414,6 +415,7 @@ def test_chunk_major_layout_bit_identical(gpu_device, monkeypatch):
     pure re-layout of the K-expanded buffers between GEMM epilogues and ring-kernel loaders: the denoiser output must be
     bit-identical to the row-major plan, with the gather-on-load first layers, the fused attention tail, and without either."""
     from slide_amd.engine import DenoiserEngine
+    monkeypatch.setenv("SLIDE_GX", "0")  # the round-2 plan on both sides (the pair decomposition needs chunk-major weights)
     for name in ("pos", "feat"):
         g, hp, sd = _load(name)
         x, ts, lab = g["x_mixed"], g["ts_mixed"], g["label_mixed"]
@@ -438,6 +440,40 @@ def test_chunk_major_layout_bit_identical(gpu_device, monkeypatch):
             assert np.array_equal(got, ref), (name, knobs, float(np.abs(got - ref).max()))
             for k_ in knobs:
                 monkeypatch.delenv(k_)
+
+
+def test_pair_decomposition_plan_variants(gpu_device, monkeypatch):
+    """Round 3: the pair decomposition (csrc/gemm_gx.hip, block_body.hip) re-associates the blocks' first layers (a[q] + b[p]
+    from 16-row GEMMs instead of 256- / 128-row ones) and runs the SA blocks in natural neighbour order, so it is NOT
+    bit-identical to the round-2 plan; both are fp16 renderings of the same network.  Every combination of the round-3
+    kernels (fused SA chain, block body, pair-table pass v1 / v2, eight-wave tail) must agree with the reference golden
+    within the fp16 forward bound (5e-3 of the output's L2 norm, as test_denoiser_forward_fp16_mfma) AND with each other
+    within 4e-3 (measured <= 2e-3: different summation orders of fp16-rounded terms)."""
+    from slide_amd.engine import DenoiserEngine
+    for name in ("pos", "feat"):
+        g, hp, sd = _load(name)
+        x, ts, lab = g["x_mixed"], g["ts_mixed"], g["label_mixed"]
+        ref = g["eps_mixed"]
+        outs = {}
+        for tag, knobs in (("round2", {"SLIDE_GX": "0"}), ("default", {}), ("no_body", {"SLIDE_BODY": "0"}),
+                           ("no_body_no_chain", {"SLIDE_BODY": "0", "SLIDE_SA_CHAIN": "0"}),
+                           ("pair_norm_v2", {"SLIDE_PAIR_NORM_V2": "1"}), ("tail8", {"SLIDE_TAIL8": "1", "SLIDE_BODY": "0"})):
+            for k_, v_ in knobs.items():
+                monkeypatch.setenv(k_, v_)
+            e = DenoiserEngine(hp, sd, x.shape[0], gpu_device, prec="fp16")
+            kinds = {o.kind for o in e.ops}
+            if tag == "round2":
+                assert not kinds & {17, 18, 19, 30}
+            else:
+                assert 18 in kinds  # SLIDE_OP_PAIR_NORM
+            outs[tag] = e.forward(x, ts, lab).cpu().numpy().astype(np.float64)
+            for k_ in knobs:
+                monkeypatch.delenv(k_)
+            err = np.linalg.norm(outs[tag] - ref) / np.linalg.norm(ref)
+            assert np.isfinite(outs[tag]).all() and err <= 5e-3, (name, tag, err)
+        for tag, o in outs.items():
+            d = np.linalg.norm(o - outs["default"]) / np.linalg.norm(outs["default"])
+            assert d <= 4e-3, (name, tag, d)
 
 
 def test_fp16_full_chains_follow_the_fp32_chains(gpu_device):

@@ -48,7 +48,7 @@ with torch.cuda.stream(s.stream):
         op = SlideOp.from_buffer_copy(bytes(s.step_ops[idx]))
         nwg = 16384
         dbg = torch.zeros(nwg * 16, dtype=torch.int64, device=dev)
-        slot = {1: 5, 17: 12, 19: 12, 16: 8, 20: 1}.get(op.kind)
+        slot = {1: 5, 17: 12, 19: 12, 16: 8, 30: 1}.get(op.kind)
         if slot is None:
             print("op %d: kind %d carries no stamps" % (idx, op.kind)); continue
         op.p[slot] = dbg.data_ptr()
@@ -67,7 +67,7 @@ with torch.cuda.stream(s.stream):
         if op.kind == 16:  # eight-wave attention tail: 1 first DMA issued | 2 landed | 3 scores K loop | 4 values K loop | 5 statistics | 6 softmax + stores | 7 retired
             seq = [0, 1, 2, 3, 4, 5, 6, 7]
             names = {1: "prologue", 2: "first_stage", 3: "kloop_s", 4: "kloop_v", 5: "stats", 6: "softmax", 7: "retired"}
-        if op.kind == 20:  # block body: 1 prologue | 2 h2 | 3 mo | 4 u | 5 tail | 6 retired
+        if op.kind == 30:  # block body: 1 prologue | 2 h2 | 3 mo | 4 u | 5 tail | 6 retired
             seq = [0, 1, 2, 3, 4, 5, 6]
             names = {1: "prologue", 2: "h2", 3: "mo", 4: "u", 5: "tail", 6: "retired"}
         if op.kind == 19:  # fused SA chain: 14 prologue | 1 stage-1 K loop | 2 h2 in registers | 3 / 6 slab K loop | 4 / 7 statistics | 5 / 8 stored | 15 retired
