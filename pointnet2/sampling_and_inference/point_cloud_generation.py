@@ -25,8 +25,13 @@ def main():
     ap.add_argument("--data_clamp_range", type=float, default=1)
     ap.add_argument("--model_var_type", type=str, default="fixedsmall")
     ap.add_argument("--random_init", action="store_true")
-    ap.add_argument("--prec", default="fp32", choices=["fp32", "fp16"])
+    ap.add_argument("--prec", default="fp16", choices=["fp32", "fp16"],
+                    help="MFMA operand type (fp32 accumulate); fp32 = the exact parity mode")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--chains", type=int, default=3,
+                    help="batches kept in flight: the position chain is launch-latency bound, so independent batches run as "
+                         "concurrent chains replayed round-robin (the arrangement bench.py times)")
+    ap.add_argument("--serial_chains", action="store_true", help="run the same chains one after the other (bit-identical; tests)")
     a = ap.parse_args()
 
     import torch
@@ -34,7 +39,7 @@ def main():
     from slide_amd.checkpoint import load_denoiser_state
     from slide_amd.configs import CATEGORY_IDS
     from slide_amd.diffusion import PositionSampler
-    from slide_amd.generation import generate_latents, save_generated
+    from slide_amd.generation import save_generated
     from slide_amd.json_reader import read_json_file
 
     cfg = read_json_file(a.config)
@@ -50,17 +55,46 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL, bound to this rank's GPU
     sd = load_denoiser_state(hp, None if a.random_init else a.ckpt, a.ema_idx)
     B = a.batch_size
-    smp = PositionSampler(hp, sd, B, dev, cfg["diffusion_config"], prec=a.prec, seed=a.seed + rank)
+    from slide_amd.diffusion import EagerChainsSampler
+    from slide_amd.generation import batches, shard_range
+    import time
     cats = cfg["shapenet_psr_dataset_config"]["categories"]
     labels = np.array([CATEGORY_IDS.index(cats[i % len(cats)]) for i in range(a.num_samples)], np.int64)
-    rs = np.random.RandomState(a.seed + 7919 * rank)
-
-    def run_batch(lab, lo, hi):
-        n = hi - lo
-        lab = np.concatenate([lab, np.zeros(B - n, np.int64)])  # the plan is built for a fixed batch; pad the last one
-        return smp.sample(lab, rs.standard_normal((B, 16, 3)).astype(np.float32))[:n]
-
-    pts, timing = generate_latents(a.num_samples, B, labels, run_batch, rank, world, gather_device=dev, row_shape=(16, 3))
+    s0, e0 = shard_range(a.num_samples, rank, world)
+    my = list(batches(s0, e0, B))
+    C = max(1, min(a.chains, len(my)))
+    # chain c serves batches c, c + C, ...; its in-kernel noise is keyed on (seed of the chain, chain nonce, step, element)
+    smps = [PositionSampler(hp, sd, B, dev, cfg["diffusion_config"], prec=a.prec, seed=a.seed + 97 * rank + c, use_graph=False)
+            for c in range(C)]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(a.seed + 7919 * rank)
+    outs, timing = {}, []
+    torch.cuda.synchronize(dev)
+    t_all = time.time()
+    for g0 in range(0, len(my), C):
+        grp = my[g0:g0 + C]
+        t0 = time.time()
+        for c, (lo, hi) in enumerate(grp):
+            lab = np.concatenate([labels[lo:hi], np.zeros(B - (hi - lo), np.int64)])  # the plan is built for a fixed batch
+            smps[c].begin(lab, torch.randn(B, 16, 3, device=dev, generator=gen))
+        if a.serial_chains:
+            for c in range(len(grp)):
+                smps[c].advance(smps[c].T)
+        else:
+            EagerChainsSampler(smps[:len(grp)]).advance(smps[0].T)
+        for c, (lo, hi) in enumerate(grp):
+            outs[lo] = smps[c].state()[:hi - lo]
+        dt = time.time() - t0
+        timing += [dt / sum(hi - lo for lo, hi in grp)] * sum(hi - lo for lo, hi in grp)
+    torch.cuda.synchronize(dev)
+    dt_all = time.time() - t_all
+    local = torch.cat([outs[lo] for lo, _ in my]) if my else torch.empty(0, 16, 3, device=dev)
+    from slide_amd.generation import all_gather_rows
+    pts = all_gather_rows(local, a.num_samples, world, device=dev)
+    timing = np.asarray(timing)
+    if rank == 0 and my:
+        print("position DDPM: %d shapes on this rank in %.2f s = %.1f shapes/s (%d chain(s) of %d, %s)" % (
+            e0 - s0, dt_all, (e0 - s0) / dt_all, C, B, a.prec))
     if rank == 0:
         f = save_generated(a.save_dir, pts.cpu().numpy(), labels, np.resize(timing, a.num_samples), 16)
         print("Generated samples have been saved to", f)

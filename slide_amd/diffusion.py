@@ -140,9 +140,14 @@ class _GraphedSampler:
             e.t_dev[:3].copy_(t0)
             e.t_dev[3:].add_(1)  # chain nonce (starts at 1)
 
-    def _order_after_current(self):
-        """inputs handed to begin() may have been produced on the caller's current stream"""
+    def _order_after_current(self, *inputs):
+        """inputs handed to begin() may have been produced on the caller's current stream: the sampler stream waits for it, and
+        every CUDA input is recorded on the sampler stream so that the caching allocator does not hand its block to a later
+        allocation of the caller's stream before the copies below have run"""
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        for t in inputs:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(self.stream)
 
     def advance(self, n_steps):
         """replay n reverse steps from the current device-side state (no host sync)"""
@@ -189,7 +194,7 @@ class PositionSampler(_GraphedSampler):
         return self.state()
 
     def begin(self, label, x_T, t_start=None):
-        self._order_after_current()
+        self._order_after_current(label, x_T)
         with torch.cuda.stream(self.stream):
             self.engine.set_label(label)
             self._set_state(x_T, self.T - 1 if t_start is None else t_start)
@@ -235,7 +240,7 @@ class FeatureSampler(_GraphedSampler):
     def begin(self, label, keypoint, x_T, t_start=None, complete_x0=None, keypoint_mask=None):
         """complete_x0 (B,16,3+F) / keypoint_mask (B,16) in {0,1}: local re-sampling (diffusion.py:76-79,352-359) --
         only the points with mask 1 are re-generated, the predicted x0 of the others is pinned to complete_x0."""
-        self._order_after_current()
+        self._order_after_current(label, keypoint, x_T, complete_x0, keypoint_mask)
         if (complete_x0 is None) != (keypoint_mask is None):
             raise ValueError("local resampling needs both complete_x0 and keypoint_mask")
         if complete_x0 is not None and self.resample is None:

@@ -178,6 +178,94 @@ class CategoryChains:
                                    gather_device=self.device, row_shape=(16, self.cx))
 
 
+def sub_batch_sizes(B, P):
+    """P sub-batches of a batch of B (multiples of 8 samples where possible: the row tiles of a launch then spread evenly over
+    the 8 XCDs) -- the split bench.py times"""
+    P = max(1, min(int(P), int(B)))
+    if B % 8 == 0 and B // 8 >= P:
+        return [8 * ((B // 8) // P + (1 if i < (B // 8) % P else 0)) for i in range(P)]
+    return [B // P + (1 if i < B % P else 0) for i in range(P)]
+
+
+class PipelinedGenerator:
+    """The arrangement bench.py times, as a generator of latents: per batch of B shapes the feature chain
+    runs as P independent sub-batch chains and the position chain as one chain over the batch, all replayed round-robin by one
+    library call per advance (EagerChainsSampler); with both DDPMs, the position chain of batch i + 1 runs beside the feature
+    chains of batch i.  Sub-batches are objects of the same partition the multi-GPU path uses (independent samples): every
+    chain is bit-identical to running it alone (`serial=True` does exactly that, for the tests).
+    pos = (pointnet_config, state dict, diffusion_config) or None (key points supplied); feat likewise (standard_diffusion_config)
+    or None (positions only)."""
+
+    def __init__(self, B, device, pos=None, feat=None, prec="fp16", seed=0, n_sub=3, serial=False, local_resampling=False):
+        from .diffusion import EagerChainsSampler, FeatureSampler, PositionSampler
+        assert pos is not None or feat is not None
+        self.B, self.device, self.serial = int(B), device, serial
+        self.pos = self.feats = None
+        if pos is not None:
+            self.pos = PositionSampler(pos[0], pos[1], self.B, device, pos[2], prec=prec, seed=seed + 1000, use_graph=False)
+        self.sizes = []
+        if feat is not None:
+            self.sizes = sub_batch_sizes(self.B, n_sub)
+            self.feats = [FeatureSampler(feat[0], feat[1], b, device, feat[2], prec=prec, seed=seed + i, use_graph=False,
+                                         local_resampling=local_resampling) for i, b in enumerate(self.sizes)]
+            self.cx = self.feats[0].engine.cx
+        self._Eager = EagerChainsSampler
+        self.T = (self.pos or self.feats[0]).T
+
+    def _advance(self, samplers):
+        if not samplers:
+            return
+        if self.serial:
+            for s_ in samplers:
+                s_.advance(s_.T)
+        else:
+            order = samplers[:1] + [s_ for s_ in samplers[1:]]
+            self._Eager(order).advance(self.T)
+
+    def _begin_feats(self, lab, kp, x_T, extra):
+        lo = 0
+        for f_, b in zip(self.feats, self.sizes):
+            kw = {k_: v_[lo:lo + b] for k_, v_ in extra.items()}
+            f_.begin(lab[lo:lo + b], kp[lo:lo + b], x_T[lo:lo + b], **kw)
+            lo += b
+
+    def run(self, n, labels, x_T_pos=None, keypoints=None, x_T_feat=None, extra=None):
+        """n shapes (any count: the last batch is padded).  labels [n]; x_T_pos(lo, hi) -> (B, 16, 3) start noise of a position
+        batch, x_T_feat(lo, hi) -> (B, 16, cx); keypoints [n, 16, 3] when there is no position DDPM; extra: per-shape arrays
+        handed to FeatureSampler.begin (local re-sampling).  Returns [n, 16, 3] / [n, 16, cx] on the device."""
+        B, dev = self.B, self.device
+        labels = torch.as_tensor(np.asarray(labels), dtype=torch.int64, device=dev)
+        pad = lambda t, m: torch.cat([t, torch.zeros((B - m,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)]) if m < B else t
+        ranges = list(batches(0, n, B))
+        outs, pending = [], None  # pending: (lo, hi) of the batch whose feature chains are in flight
+        kp_next = None
+        for i in range(len(ranges) + 1):
+            group = []
+            if i < len(ranges) and self.pos is not None:  # position chain of batch i
+                lo, hi = ranges[i]
+                self.pos.begin(pad(labels[lo:hi], hi - lo), torch.as_tensor(x_T_pos(lo, hi), device=dev))
+                group.append(self.pos)
+            if pending is not None:
+                group = self.feats[:1] + group + self.feats[1:]  # (the order bench.py launches them in)
+            self._advance(group)
+            for s_ in group:
+                s_.stream.synchronize()
+            if pending is not None:
+                plo, phi = pending
+                outs.append(torch.cat([f_.state() for f_ in self.feats])[:phi - plo])
+                pending = None
+            if i < len(ranges):
+                lo, hi = ranges[i]
+                kp = self.pos.state() if self.pos is not None else pad(torch.as_tensor(keypoints[lo:hi], dtype=torch.float32, device=dev), hi - lo)
+                if self.feats is None:
+                    outs.append(kp[:hi - lo].clone())
+                else:
+                    ex = {k_: pad(torch.as_tensor(v_[lo:hi], dtype=torch.float32, device=dev), hi - lo) for k_, v_ in (extra or {}).items()}
+                    self._begin_feats(pad(labels[lo:hi], hi - lo), kp, torch.as_tensor(x_T_feat(lo, hi), device=dev), ex)
+                    pending = (lo, hi)
+        return torch.cat(outs) if outs else torch.empty(0, 16, self.cx if self.feats else 3, device=dev)
+
+
 def save_generated(save_dir, points, labels, timing, num_points, keypoint=None, keypoint_feature=None, ckpt_info=""):
     """npz schema of mesh_evaluation.py:135-150: points,label,category,category_name,timing[,keypoint,keypoint_feature]"""
     os.makedirs(save_dir, exist_ok=True)

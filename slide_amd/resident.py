@@ -504,6 +504,9 @@ class ResidentPositionSampler:
         e = self.engine
         t_start = self.T - 1 if t_start is None else int(t_start)
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        for t_ in (label, x_T):  # (the allocator must not recycle a caller-stream input before the copies below have run)
+            if torch.is_tensor(t_) and t_.is_cuda:
+                t_.record_stream(self.stream)
         with torch.cuda.stream(self.stream):
             e.set_label(label)
             e.x.copy_(torch.as_tensor(x_T).to(self.device, torch.float32).reshape(e.x.shape))

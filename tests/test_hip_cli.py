@@ -152,14 +152,16 @@ def test_released_checkpoint_layout_through_the_clis(gpu_device, tmp_path):
     cli = os.path.join(REPO, "pointnet2", "sampling_and_inference")
     out1 = tmp_path / "gen"
     r = subprocess.run([sys.executable, os.path.join(cli, "point_cloud_generation.py"), "-c", str(cdir / "pos.json"), "--ckpt", str(ck),
-                        "--ema_idx", "1", "--num_samples", "4", "--batch_size", "4", "--save_dir", str(out1), "--seed", "5"],
-                       env=env, capture_output=True, text=True)
+                        "--ema_idx", "1", "--num_samples", "4", "--batch_size", "4", "--save_dir", str(out1), "--seed", "5",
+                        "--prec", "fp32"], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     got = np.load(out1 / "shapenet_psr_generated_data_16_pts.npz")["points"]
     want_sd = dict(raw)
     want_sd.update({k: v for k, v in ema1.items() if k != skip})
     smp = PositionSampler(hp, want_sd, 4, gpu_device, pc["diffusion_config"], prec="fp32", seed=5)
-    xT = np.random.RandomState(5).standard_normal((4, 16, 3)).astype(np.float32)
+    gen = torch.Generator(device=gpu_device)  # the CLI draws x_T on the device: generator seeded seed + 7919 * rank
+    gen.manual_seed(5)
+    xT = torch.randn(4, 16, 3, device=gpu_device, generator=gen).cpu().numpy()
     want = smp.sample(np.zeros(4, np.int64), xT).cpu().numpy()
     assert np.array_equal(got, want)
     other = PositionSampler(hp, raw, 4, gpu_device, pc["diffusion_config"], prec="fp32", seed=5).sample(np.zeros(4, np.int64), xT).cpu().numpy()
@@ -192,13 +194,66 @@ def test_released_checkpoint_layout_through_the_clis(gpu_device, tmp_path):
     out2 = tmp_path / "gen2"
     r = subprocess.run([sys.executable, os.path.join(cli, "latent_ddpm_keypoint_conditional_generation.py"), "-c", str(cdir / "feat.json"),
                         "--ckpt", str(fck), "--ema_idx", "0", "--keypoint_file", str(out1 / "shapenet_psr_generated_data_16_pts.npz"),
-                        "--batch_size", "4", "--save_dir", str(out2), "--decode", "--save_keypoint_feature", "--seed", "3"],
-                       env=env, capture_output=True, text=True)
+                        "--batch_size", "4", "--save_dir", str(out2), "--decode", "--save_keypoint_feature", "--seed", "3",
+                        "--prec", "fp32", "--chains", "1"], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     d2 = np.load(out2 / "shapenet_psr_generated_data_2048_pts.npz")
     assert d2["points"].shape == (4, 2048, 3) and np.isfinite(d2["points"]).all() and np.allclose(d2["keypoint"], got)
     from slide_amd.diffusion import FeatureSampler
     fs = FeatureSampler(fc["pointnet_config"], fema, 4, gpu_device, fc["standard_diffusion_config"], prec="fp32", seed=3)
-    xf = np.random.RandomState(3).standard_normal((4, 16, 51)).astype(np.float32)
+    gen.manual_seed(3)
+    xf = torch.randn(4, 16, 51, device=gpu_device, generator=gen).cpu().numpy()
     lat = fs.sample(np.zeros(4, np.int64), got, xf).cpu().numpy()
     assert np.array_equal(d2["keypoint_feature"], lat[:, :, 3:])
+
+
+def test_clis_drive_the_benched_arrangement(gpu_device, tmp_path):
+    """both generation CLIs run the arrangement bench.py times -- independent chains replayed round-robin by
+    one library call (feature sub-batch chains of a batch; position batches in flight; on the fly: the position chain of batch
+    i + 1 beside the feature chains of batch i), fp16 operands by default -- and their output is BIT-IDENTICAL to running the
+    same chains one after the other (--serial_chains): the chains are independent objects of the sample partition."""
+    cdir = tmp_path / "configs" / "a" / "b"
+    os.makedirs(cdir)
+    pc = configs.position_ddpm_config()
+    pc["shapenet_psr_dataset_config"] = {"dataset": "shapenet_psr_dataset", "categories": ["02691156", "03001627"], "num_keypoints": 16}
+    pc["train_config"] = {"task": "keypoint_generation", "dataset": "shapenet_psr_dataset"}
+    (cdir / "pos.json").write_text(json.dumps(_stringify(pc)))
+    fc = configs.feature_ddpm_config()
+    (cdir / "feat.json").write_text(json.dumps(_stringify(fc)))
+    env = dict(os.environ, PYTHONPATH=REPO)
+    cli = os.path.join(REPO, "pointnet2", "sampling_and_inference")
+    outs = {}
+    for tag, extra in (("par", []), ("ser", ["--serial_chains"])):
+        o1 = tmp_path / ("pos_" + tag)
+        r = subprocess.run([sys.executable, os.path.join(cli, "point_cloud_generation.py"), "-c", str(cdir / "pos.json"), "--random_init",
+                            "--num_samples", "40", "--batch_size", "8", "--chains", "3", "--save_dir", str(o1)] + extra,
+                           env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "shapes/s" in r.stdout and "fp16" in r.stdout  # end-to-end rate of the run, fp16 operands by default
+        outs["pos_" + tag] = np.load(o1 / "shapenet_psr_generated_data_16_pts.npz")
+        o2 = tmp_path / ("feat_" + tag)
+        r = subprocess.run([sys.executable, os.path.join(cli, "latent_ddpm_keypoint_conditional_generation.py"), "-c", str(cdir / "feat.json"),
+                            "--random_init", "--keypoint_file", str(o1 / "shapenet_psr_generated_data_16_pts.npz"), "--batch_size", "24",
+                            "--chains", "3", "--save_dir", str(o2)] + extra, env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "8/8/8 feature chain(s)" in r.stdout
+        outs["feat_" + tag] = np.load(o2 / "shapenet_psr_generated_data_16_pts_latents.npz")
+        o3 = tmp_path / ("fly_" + tag)
+        r = subprocess.run([sys.executable, os.path.join(cli, "latent_ddpm_keypoint_conditional_generation.py"), "-c", str(cdir / "feat.json"),
+                            "--random_init", "--position_config", str(cdir / "pos.json"), "--num_samples", "40", "--batch_size", "16",
+                            "--chains", "2", "--save_dir", str(o3)] + extra, env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "position + feature DDPM" in r.stdout
+        outs["fly_" + tag] = np.load(o3 / "shapenet_psr_generated_data_16_pts_latents.npz")
+    assert outs["pos_par"]["points"].shape == (40, 16, 3) and np.isfinite(outs["pos_par"]["points"]).all()
+    assert (outs["pos_par"]["label"] == np.array([0, 4] * 20)).all()
+    assert np.array_equal(outs["pos_par"]["points"], outs["pos_ser"]["points"])
+    for k in ("feat", "fly"):
+        a_, b_ = outs[k + "_par"], outs[k + "_ser"]
+        assert a_["keypoint_feature"].shape == (40, 16, 48) and np.isfinite(a_["keypoint_feature"]).all()
+        assert np.array_equal(a_["keypoint_feature"], b_["keypoint_feature"]) and np.array_equal(a_["points"], b_["points"])
+    # the feature chains were conditioned on the key points of the file / of the on-the-fly position chains
+    assert np.array_equal(outs["feat_par"]["points"], outs["pos_par"]["points"])
+    # batches of one position sampler draw independent noise (chain nonce): no two shapes coincide
+    p_ = outs["pos_par"]["points"].reshape(40, -1)
+    assert len({p_[i].tobytes() for i in range(40)}) == 40
