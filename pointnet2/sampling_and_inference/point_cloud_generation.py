@@ -48,11 +48,8 @@ def main():
         raise SystemExit("this CLI drives the `diffusion_config` (util.sampling) path of the shipped position configs")
     if a.ckpt is None and not a.random_init:
         raise SystemExit("--ckpt is required (or pass --random_init for synthetic weights)")
-    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL, bound to this rank's GPU
+    from slide_amd.generation import init_distributed, start_noise
+    rank, world, dev, gdev = init_distributed()  # one process per GPU over RCCL (SLIDE_SHARE_GPU=1: gloo on one GPU, tests)
     sd = load_denoiser_state(hp, None if a.random_init else a.ckpt, a.ema_idx)
     B = a.batch_size
     from slide_amd.diffusion import EagerChainsSampler
@@ -63,11 +60,9 @@ def main():
     s0, e0 = shard_range(a.num_samples, rank, world)
     my = list(batches(s0, e0, B))
     C = max(1, min(a.chains, len(my)))
-    # chain c serves batches c, c + C, ...; its in-kernel noise is keyed on (seed of the chain, chain nonce, step, element)
-    smps = [PositionSampler(hp, sd, B, dev, cfg["diffusion_config"], prec=a.prec, seed=a.seed + 97 * rank + c, use_graph=False)
-            for c in range(C)]
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(a.seed + 7919 * rank)
+    # chain c serves batches c, c + C, ...  Start noise and in-kernel noise of a shape are functions of (seed, its GLOBAL index)
+    # only: the output does not depend on the number of ranks, the batch size or the chains in flight
+    smps = [PositionSampler(hp, sd, B, dev, cfg["diffusion_config"], prec=a.prec, seed=a.seed, use_graph=False) for c in range(C)]
     outs, timing = {}, []
     torch.cuda.synchronize(dev)
     t_all = time.time()
@@ -76,7 +71,7 @@ def main():
         t0 = time.time()
         for c, (lo, hi) in enumerate(grp):
             lab = np.concatenate([labels[lo:hi], np.zeros(B - (hi - lo), np.int64)])  # the plan is built for a fixed batch
-            smps[c].begin(lab, torch.randn(B, 16, 3, device=dev, generator=gen))
+            smps[c].begin(lab, start_noise(a.seed, 1, lo, lo + B, (16, 3), dev), nonce=1, sample_offset=lo)
         if a.serial_chains:
             for c in range(len(grp)):
                 smps[c].advance(smps[c].T)
@@ -90,7 +85,7 @@ def main():
     dt_all = time.time() - t_all
     local = torch.cat([outs[lo] for lo, _ in my]) if my else torch.empty(0, 16, 3, device=dev)
     from slide_amd.generation import all_gather_rows
-    pts = all_gather_rows(local, a.num_samples, world, device=dev)
+    pts = all_gather_rows(local, a.num_samples, world, device=gdev)
     timing = np.asarray(timing)
     if rank == 0 and my:
         print("position DDPM: %d shapes on this rank in %.2f s = %.1f shapes/s (%d chain(s) of %d, %s)" % (

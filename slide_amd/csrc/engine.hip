@@ -1450,7 +1450,7 @@ __device__ __forceinline__ void advance_t_last_block(int *t_dev, int t, int step
 __device__ __forceinline__ void update_feat_element(int e, int npts, int C, int kdim, int eps_ld, float clamp,
                                                     uint32_t seed_lo, uint32_t seed_hi, float *__restrict__ x,
                                                     const float *__restrict__ eps, const float *__restrict__ noise, int t,
-                                                    int step, uint32_t nonce, const float *__restrict__ complete_x0,
+                                                    int step, uint32_t nonce, uint32_t eoff, const float *__restrict__ complete_x0,
                                                     const float *__restrict__ kmask, const float *__restrict__ keypoint,
                                                     const float *__restrict__ rc, const float *__restrict__ rm1,
                                                     const float *__restrict__ c1, const float *__restrict__ c2,
@@ -1472,7 +1472,7 @@ __device__ __forceinline__ void update_feat_element(int e, int npts, int C, int 
   float v = c1[t] * x0 + c2[t] * xv;
   if (t > 0) {
     const float z = noise ? noise[(size_t)step * npts * C + e]
-                          : philox_normal(seed_lo, seed_hi, (uint32_t)step, (uint32_t)e, nonce);
+                          : philox_normal(seed_lo, seed_hi, (uint32_t)step, (uint32_t)e + eoff, nonce);
     v = v + stdv[t] * z;
   }
   x[e] = v;
@@ -1492,7 +1492,7 @@ __global__ __launch_bounds__(256) void update_pos_kernel(int n, int eps_ld, uint
     float v = (x[e] - c_eps[t] * eps[ep]) / sqrt_alpha[t];
     if (t > 0) {
       const float z = noise ? noise[(size_t)step * n + e]
-                            : philox_normal(seed_lo, seed_hi, (uint32_t)step, (uint32_t)e, (uint32_t)t_dev[3]);
+                            : philox_normal(seed_lo, seed_hi, (uint32_t)step, (uint32_t)e + (uint32_t)t_dev[4] * 48u, (uint32_t)t_dev[3]);
       v = v + sigma[t] * z;
     }
     x[e] = v;
@@ -1514,11 +1514,14 @@ __global__ __launch_bounds__(256) void update_feat_kernel(int npts, int C, int k
 #pragma clang fp contract(off)
   const int t = t_dev[0], step = t_dev[1];
   const uint32_t nonce = (uint32_t)t_dev[3];
+  // the noise element index is GLOBAL: t_dev[4] = global index of the chain's first sample, so that a shape's noise does not
+  // depend on how the run was split into ranks, batches and sub-batch chains
+  const uint32_t eoff = (uint32_t)t_dev[4] * (uint32_t)(16 * C);
   // four elements per thread: a quarter of the blocks queue on the completion counter
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     update_feat_element(blockIdx.x * 1024 + j * 256 + threadIdx.x, npts, C, kdim, eps_ld, clamp, seed_lo, seed_hi, x, eps, noise,
-                        t, step, nonce, complete_x0, kmask, keypoint, rc, rm1, c1, c2, stdv);
+                        t, step, nonce, eoff, complete_x0, kmask, keypoint, rc, rm1, c1, c2, stdv);
   advance_t_last_block(t_dev, t, step);
 }
 

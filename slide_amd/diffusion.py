@@ -125,7 +125,7 @@ class _GraphedSampler:
             for _ in range(n_steps):
                 check(L.slide_graph_launch(self.graph, s), "graph_launch")
 
-    def _set_state(self, x, t_start):
+    def _set_state(self, x, t_start, nonce=None, sample_offset=0):
         """starts a chain: state, timestep, step counter 0 and a fresh NONCE in t_dev[3] -- the in-kernel noise is keyed on
         (seed, nonce, step, element), so consecutive chains of one sampler (the batches of a generation run) draw
         independent noise like the reference's per-batch torch.randn (pointnet2/util.py:252, diffusion.py:88)."""
@@ -138,7 +138,14 @@ class _GraphedSampler:
             if t0 is None:  # device-resident [t, step, blocks-done]: restarting a chain needs no host upload
                 t0 = self._t_init[int(t_start)] = torch.tensor([t_start, 0, 0], dtype=torch.int32).to(self.device)
             e.t_dev[:3].copy_(t0)
-            e.t_dev[3:].add_(1)  # chain nonce (starts at 1)
+            # chain nonce: bumped per chain (consecutive batches of one sampler draw independent noise), or SET by the caller
+            # together with sample_offset = the GLOBAL index of the chain's first sample: the noise of a shape is then a function
+            # of (seed, nonce, step, global element) only -- independent of ranks, batches and sub-batch chains
+            if nonce is None:
+                e.t_dev[3:4].add_(1)
+            else:
+                e.t_dev[3:4].fill_(int(nonce))
+            e.t_dev[4:5].fill_(int(sample_offset))
 
     def _order_after_current(self, *inputs):
         """inputs handed to begin() may have been produced on the caller's current stream: the sampler stream waits for it, and
@@ -193,11 +200,11 @@ class PositionSampler(_GraphedSampler):
         self.advance(n_steps)
         return self.state()
 
-    def begin(self, label, x_T, t_start=None):
+    def begin(self, label, x_T, t_start=None, nonce=None, sample_offset=0):
         self._order_after_current(label, x_T)
         with torch.cuda.stream(self.stream):
             self.engine.set_label(label)
-            self._set_state(x_T, self.T - 1 if t_start is None else t_start)
+            self._set_state(x_T, self.T - 1 if t_start is None else t_start, nonce, sample_offset)
 
 
 class FeatureSampler(_GraphedSampler):
@@ -237,7 +244,7 @@ class FeatureSampler(_GraphedSampler):
         self.advance(n_steps)
         return self.state()  # the key-point channels are re-clamped to the condition by every update (:395-397)
 
-    def begin(self, label, keypoint, x_T, t_start=None, complete_x0=None, keypoint_mask=None):
+    def begin(self, label, keypoint, x_T, t_start=None, complete_x0=None, keypoint_mask=None, nonce=None, sample_offset=0):
         """complete_x0 (B,16,3+F) / keypoint_mask (B,16) in {0,1}: local re-sampling (diffusion.py:76-79,352-359) --
         only the points with mask 1 are re-generated, the predicted x0 of the others is pinned to complete_x0."""
         self._order_after_current(label, keypoint, x_T, complete_x0, keypoint_mask)
@@ -258,7 +265,7 @@ class FeatureSampler(_GraphedSampler):
             x[:, :, :self.kdim] = kp  # diffusion.py:383-385
             self.keypoint.copy_(kp.reshape(self.B * 16, self.kdim))
             self.engine.set_label(label)
-            self._set_state(x, self.T - 1 if t_start is None else t_start)
+            self._set_state(x, self.T - 1 if t_start is None else t_start, nonce, sample_offset)
             if self.begin_ops is not None:  # coordinate columns of the key points: constant over the chain
                 self.engine.run(self.begin_ops)
 

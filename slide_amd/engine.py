@@ -1163,7 +1163,7 @@ class DenoiserEngine:
         self.x = A.zeros(B, 16, self.cx)
         self.ts = A.zeros(B)
         self.label = A.zeros(B, dtype=torch.int64)
-        self.t_dev = A.zeros(4, dtype=torch.int32)  # [t, step counter, blocks-done counter of the update kernel, -]
+        self.t_dev = A.zeros(8, dtype=torch.int32)  # [t, step counter, blocks-done counter of the update kernel, chain nonce, global index of the chain's first sample, -, -, -]
         self.xyz = A.zeros(B * 16, 3)
         C0 = self.cx  # in_fea_dim + 3 (position attached as feature)
         self.feat0 = self._buf(B * 16, C0)  # activation storage type

@@ -17,6 +17,37 @@ import torch.distributed as dist
 from .configs import CATEGORY_IDS, CATEGORY_NAMES
 
 
+def init_distributed():
+    """(rank, world, device, gather_device) of this process.  One process per GPU over RCCL (backend "nccl", bound to the rank's
+    GPU); SLIDE_SHARE_GPU=1 (test knob for 1-GPU boxes): every rank uses device 0 and the collectives run on gloo / CPU tensors."""
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
+    share = os.environ.get("SLIDE_SHARE_GPU", "0") != "0"
+    if share:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    return rank, world, dev, (torch.device("cpu") if share else dev)
+
+
+def start_noise(seed, tag, lo, hi, tail, device):
+    """x_T rows [lo, hi) of a run: N(0, 1) of shape (hi - lo,) + tail, a function of (seed, tag, GLOBAL shape index) only -- drawn
+    in fixed blocks of 1024 shapes, each from its own generator -- so that a shape's start noise does not depend on how the run
+    is split into ranks and batches"""
+    out = []
+    g = torch.Generator(device=device)
+    for k in range(lo // 1024, (max(hi, lo + 1) - 1) // 1024 + 1):
+        g.manual_seed((int(seed) * 1000003 + int(tag) * 7919 + k) & 0x7FFFFFFFFFFF)
+        blk = torch.randn((1024,) + tuple(tail), device=device, generator=g)
+        out.append(blk[max(lo - 1024 * k, 0):min(hi - 1024 * k, 1024)])
+    return torch.cat(out) if out else torch.empty((0,) + tuple(tail), device=device)
+
+
 def shard_range(num_samples, rank, world_size):
     """contiguous slice [start, end) of rank `rank` (ceil division; trailing ranks may be short or empty)"""
     if world_size <= 1:
@@ -136,10 +167,11 @@ class CategoryChains:
         self.chains = []
         for k, (c, lo, hi) in enumerate(self.segments):
             sd_p, sd_f = weights(c)
-            # the in-kernel noise is keyed on (seed, chain nonce, step, element): the global offset `lo` keeps the streams of
-            # different segments / ranks apart
-            ps, fs = self._make_chain(pos_cfg, feat_cfg, sd_p, sd_f, hi - lo, prec, (seed << 24) ^ (2 * lo + 1), (seed << 24) ^ (2 * lo + 2))
+            # the in-kernel noise is keyed on (seed, chain nonce, step, GLOBAL element): every chain has the same seed and a fixed
+            # nonce, its sample_offset `lo` tells the shapes apart -- a shape's noise does not depend on the world size
+            ps, fs = self._make_chain(pos_cfg, feat_cfg, sd_p, sd_f, hi - lo, prec, seed, seed)
             self.chains.append((c, lo, hi, ps, fs))
+        self.seed = int(seed)
 
     def _make_chain(self, pos_cfg, feat_cfg, sd_p, sd_f, n, prec, seed_p, seed_f):
         from .diffusion import FeatureSampler, PositionSampler
@@ -157,13 +189,13 @@ class CategoryChains:
         for c, lo, hi, ps, fs in self.chains:
             n = hi - lo
             lab = torch.full((n,), c, dtype=torch.int64, device=self.device)
-            ps.begin(lab, torch.randn(n, 16, 3, device=self.device, generator=gen))
+            ps.begin(lab, start_noise(self.seed, 1, lo, hi, (16, 3), self.device), nonce=1, sample_offset=lo)
             ps.advance(ps.T if steps is None else steps)
             if pending is not None:
                 outs.append(pending.state())
             kp = ps.state()
             cx = fs.engine.cx
-            fs.begin(lab, kp, torch.randn(n, 16, cx, device=self.device, generator=gen))
+            fs.begin(lab, kp, start_noise(self.seed, 2, lo, hi, (16, cx), self.device), nonce=2, sample_offset=lo)
             fs.advance(fs.T if steps is None else steps)
             pending = fs
         if pending is not None:
@@ -196,17 +228,21 @@ class PipelinedGenerator:
     pos = (pointnet_config, state dict, diffusion_config) or None (key points supplied); feat likewise (standard_diffusion_config)
     or None (positions only)."""
 
-    def __init__(self, B, device, pos=None, feat=None, prec="fp16", seed=0, n_sub=3, serial=False, local_resampling=False):
+    def __init__(self, B, device, pos=None, feat=None, prec="fp16", seed=0, n_sub=3, serial=False, local_resampling=False,
+                 global_offset=0):
         from .diffusion import EagerChainsSampler, FeatureSampler, PositionSampler
         assert pos is not None or feat is not None
         self.B, self.device, self.serial = int(B), device, serial
+        # Every chain has the SAME seed and nonce; what tells shapes apart is their GLOBAL index (sample_offset of the chain +
+        # row): start noise and in-kernel noise of a shape do not depend on ranks, batches or the sub-batch split
+        self.seed, self.g0 = int(seed), int(global_offset)
         self.pos = self.feats = None
         if pos is not None:
-            self.pos = PositionSampler(pos[0], pos[1], self.B, device, pos[2], prec=prec, seed=seed + 1000, use_graph=False)
+            self.pos = PositionSampler(pos[0], pos[1], self.B, device, pos[2], prec=prec, seed=seed, use_graph=False)
         self.sizes = []
         if feat is not None:
             self.sizes = sub_batch_sizes(self.B, n_sub)
-            self.feats = [FeatureSampler(feat[0], feat[1], b, device, feat[2], prec=prec, seed=seed + i, use_graph=False,
+            self.feats = [FeatureSampler(feat[0], feat[1], b, device, feat[2], prec=prec, seed=seed, use_graph=False,
                                          local_resampling=local_resampling) for i, b in enumerate(self.sizes)]
             self.cx = self.feats[0].engine.cx
         self._Eager = EagerChainsSampler
@@ -222,18 +258,20 @@ class PipelinedGenerator:
             order = samplers[:1] + [s_ for s_ in samplers[1:]]
             self._Eager(order).advance(self.T)
 
-    def _begin_feats(self, lab, kp, x_T, extra):
+    def _begin_feats(self, lab, kp, x_T, extra, g_lo):
         lo = 0
         for f_, b in zip(self.feats, self.sizes):
             kw = {k_: v_[lo:lo + b] for k_, v_ in extra.items()}
-            f_.begin(lab[lo:lo + b], kp[lo:lo + b], x_T[lo:lo + b], **kw)
+            f_.begin(lab[lo:lo + b], kp[lo:lo + b], x_T[lo:lo + b], nonce=2, sample_offset=g_lo + lo, **kw)
             lo += b
 
-    def run(self, n, labels, x_T_pos=None, keypoints=None, x_T_feat=None, extra=None):
-        """n shapes (any count: the last batch is padded).  labels [n]; x_T_pos(lo, hi) -> (B, 16, 3) start noise of a position
-        batch, x_T_feat(lo, hi) -> (B, 16, cx); keypoints [n, 16, 3] when there is no position DDPM; extra: per-shape arrays
-        handed to FeatureSampler.begin (local re-sampling).  Returns [n, 16, 3] / [n, 16, cx] on the device."""
+    def run(self, n, labels, keypoints=None, extra=None):
+        """n shapes (any count: the last batch is padded): global indices global_offset .. global_offset + n.  labels [n];
+        keypoints [n, 16, 3] when there is no position DDPM; extra: per-shape arrays handed to FeatureSampler.begin (local
+        re-sampling).  Returns [n, 16, 3] / [n, 16, cx] on the device."""
         B, dev = self.B, self.device
+        x_T_pos = lambda lo, hi: start_noise(self.seed, 1, self.g0 + lo, self.g0 + lo + B, (16, 3), dev)
+        x_T_feat = lambda lo, hi: start_noise(self.seed, 2, self.g0 + lo, self.g0 + lo + B, (16, self.cx), dev)
         labels = torch.as_tensor(np.asarray(labels), dtype=torch.int64, device=dev)
         pad = lambda t, m: torch.cat([t, torch.zeros((B - m,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)]) if m < B else t
         ranges = list(batches(0, n, B))
@@ -243,7 +281,7 @@ class PipelinedGenerator:
             group = []
             if i < len(ranges) and self.pos is not None:  # position chain of batch i
                 lo, hi = ranges[i]
-                self.pos.begin(pad(labels[lo:hi], hi - lo), torch.as_tensor(x_T_pos(lo, hi), device=dev))
+                self.pos.begin(pad(labels[lo:hi], hi - lo), x_T_pos(lo, hi), nonce=1, sample_offset=self.g0 + lo)
                 group.append(self.pos)
             if pending is not None:
                 group = self.feats[:1] + group + self.feats[1:]  # (the order bench.py launches them in)
@@ -261,7 +299,7 @@ class PipelinedGenerator:
                     outs.append(kp[:hi - lo].clone())
                 else:
                     ex = {k_: pad(torch.as_tensor(v_[lo:hi], dtype=torch.float32, device=dev), hi - lo) for k_, v_ in (extra or {}).items()}
-                    self._begin_feats(pad(labels[lo:hi], hi - lo), kp, torch.as_tensor(x_T_feat(lo, hi), device=dev), ex)
+                    self._begin_feats(pad(labels[lo:hi], hi - lo), kp, x_T_feat(lo, hi), ex, self.g0 + lo)
                     pending = (lo, hi)
         return torch.cat(outs) if outs else torch.empty(0, 16, self.cx if self.feats else 3, device=dev)
 

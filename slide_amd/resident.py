@@ -514,7 +514,7 @@ class ResidentPositionSampler:
             if t0 is None:
                 t0 = self._t_init[t_start] = torch.tensor([t_start, 0, 0], dtype=torch.int32).to(self.device)
             e.t_dev[:3].copy_(t0)
-            e.t_dev[3:].add_(1)  # chain nonce
+            e.t_dev[3:4].add_(1)  # chain nonce
 
     def advance(self, n_steps):
         if n_steps <= 0:

@@ -114,7 +114,7 @@ class _StubSampler:
         self.n, self.width, self.seed, self.T = n, width, seed, 1
         self.engine = type("E", (), {"cx": width})()
 
-    def begin(self, lab, *xs):
+    def begin(self, lab, *xs, **kw):
         self.lab = lab
 
     def advance(self, steps):
@@ -155,3 +155,38 @@ def _worker_chains(rank, world, port, total):
 @pytest.mark.parametrize("total,world", [(2, 3), (1, 2), (9, 2)])
 def test_category_chains_more_ranks_than_shards_gloo(total, world):
     mp.spawn(_worker_chains, args=(world, _free_port(), total), nprocs=world, join=True)
+
+
+def _worker_real_chains(rank, world, port, total, steps):
+    """CategoryChains with the REAL HIP samplers at world = 2 (both ranks on the one GPU of this box, gloo)
+    must equal the world = 1 result bit for bit: a shape's start noise and in-kernel noise depend on (seed, global index) only"""
+    from slide_amd import configs, model_spec
+    from slide_amd.generation import CategoryChains
+    from slide_amd.synth import synth_state_dict
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    pc, fc = configs.position_ddpm_config(), configs.feature_ddpm_config()
+    spec_p, spec_f = model_spec.denoiser_param_spec(pc["pointnet_config"]), model_spec.denoiser_param_spec(fc["pointnet_config"])
+    weights = lambda c: (synth_state_dict(spec_p, seed=100 + c), synth_state_dict(spec_f, seed=200 + c))
+
+    class Chains(CategoryChains):
+        def generate(self, gen=None, steps=None):  # gather through the CPU (gloo)
+            from slide_amd.generation import generate_categories
+            local = self.run(gen, steps).cpu()
+            base = self.segments[0][1] if self.segments else 0
+            return generate_categories(self.total, lambda c, lo, hi: local[lo - base:hi - base], self.rank, self.world, self.categories,
+                                       gather_device=torch.device("cpu"), row_shape=(16, self.cx))
+
+    full, labels = Chains(total, rank, world, pc, fc, weights, dev, prec="fp16", seed=3).generate(steps=steps)
+    if rank == 0:
+        ref, labels1 = CategoryChains(total, 0, 1, pc, fc, weights, dev, prec="fp16", seed=3).generate(steps=steps)
+        assert np.array_equal(labels, labels1)
+        assert torch.isfinite(full).all() and torch.equal(full, ref.cpu()), float((full - ref.cpu()).abs().max())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_category_chains_world2_equals_world1_on_the_gpu():
+    mp.spawn(_worker_real_chains, args=(2, _free_port(), 13, 8), nprocs=2, join=True)

@@ -159,12 +159,16 @@ def test_released_checkpoint_layout_through_the_clis(gpu_device, tmp_path):
     want_sd = dict(raw)
     want_sd.update({k: v for k, v in ema1.items() if k != skip})
     smp = PositionSampler(hp, want_sd, 4, gpu_device, pc["diffusion_config"], prec="fp32", seed=5)
-    gen = torch.Generator(device=gpu_device)  # the CLI draws x_T on the device: generator seeded seed + 7919 * rank
-    gen.manual_seed(5)
-    xT = torch.randn(4, 16, 3, device=gpu_device, generator=gen).cpu().numpy()
-    want = smp.sample(np.zeros(4, np.int64), xT).cpu().numpy()
+    from slide_amd.generation import start_noise
+    # the CLI's conventions: start noise of shape i = start_noise(seed, 1 (position) | 2 (feature), i ...), chain nonce 1 | 2,
+    # in-kernel noise keyed on the shape's global index
+    def run_pos(s_, w_):
+        s_.begin(np.zeros(4, np.int64), start_noise(5, 1, 0, 4, (16, 3), gpu_device), nonce=1, sample_offset=0)
+        s_.advance(s_.T)
+        return s_.state().cpu().numpy()
+    want = run_pos(smp, want_sd)
     assert np.array_equal(got, want)
-    other = PositionSampler(hp, raw, 4, gpu_device, pc["diffusion_config"], prec="fp32", seed=5).sample(np.zeros(4, np.int64), xT).cpu().numpy()
+    other = run_pos(PositionSampler(hp, raw, 4, gpu_device, pc["diffusion_config"], prec="fp32", seed=5), raw)
     assert not np.allclose(got, other)
     # feature CLI: denoiser --ckpt (EMA 0) + autoencoder --ae_ckpt (model_state_dict of the whole autoencoder), --decode
     fc = configs.feature_ddpm_config()
@@ -201,9 +205,9 @@ def test_released_checkpoint_layout_through_the_clis(gpu_device, tmp_path):
     assert d2["points"].shape == (4, 2048, 3) and np.isfinite(d2["points"]).all() and np.allclose(d2["keypoint"], got)
     from slide_amd.diffusion import FeatureSampler
     fs = FeatureSampler(fc["pointnet_config"], fema, 4, gpu_device, fc["standard_diffusion_config"], prec="fp32", seed=3)
-    gen.manual_seed(3)
-    xf = torch.randn(4, 16, 51, device=gpu_device, generator=gen).cpu().numpy()
-    lat = fs.sample(np.zeros(4, np.int64), got, xf).cpu().numpy()
+    fs.begin(np.zeros(4, np.int64), got, start_noise(3, 2, 0, 4, (16, 51), gpu_device), nonce=2, sample_offset=0)
+    fs.advance(fs.T)
+    lat = fs.state().cpu().numpy()
     assert np.array_equal(d2["keypoint_feature"], lat[:, :, 3:])
 
 
@@ -254,6 +258,24 @@ def test_clis_drive_the_benched_arrangement(gpu_device, tmp_path):
         assert np.array_equal(a_["keypoint_feature"], b_["keypoint_feature"]) and np.array_equal(a_["points"], b_["points"])
     # the feature chains were conditioned on the key points of the file / of the on-the-fly position chains
     assert np.array_equal(outs["feat_par"]["points"], outs["pos_par"]["points"])
-    # batches of one position sampler draw independent noise (chain nonce): no two shapes coincide
+    # no two shapes coincide (noise keyed on the global shape index)
     p_ = outs["pos_par"]["points"].reshape(40, -1)
     assert len({p_[i].tobytes() for i in range(40)}) == 40
+    # the same commands under torch.distributed.run with TWO ranks (sharing the one GPU of this box over gloo,
+    # SLIDE_SHARE_GPU=1; RCCL over xGMI on a multi-GPU node) and with a different batch size / chain count give the SAME files:
+    # a shape's start noise and in-kernel noise depend on (seed, global index) only
+    env2 = dict(env, SLIDE_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    o1 = tmp_path / "pos_2rank"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29611", os.path.join(cli, "point_cloud_generation.py"), "-c", str(cdir / "pos.json"), "--random_init",
+                        "--num_samples", "40", "--batch_size", "4", "--chains", "2", "--save_dir", str(o1)], env=env2, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.load(o1 / "shapenet_psr_generated_data_16_pts.npz")["points"], outs["pos_par"]["points"])
+    o3 = tmp_path / "fly_2rank"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29612", os.path.join(cli, "latent_ddpm_keypoint_conditional_generation.py"), "-c", str(cdir / "feat.json"),
+                        "--random_init", "--position_config", str(cdir / "pos.json"), "--num_samples", "40", "--batch_size", "8",
+                        "--chains", "3", "--save_dir", str(o3)], env=env2, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d_ = np.load(o3 / "shapenet_psr_generated_data_16_pts_latents.npz")
+    assert np.array_equal(d_["points"], outs["fly_par"]["points"]) and np.array_equal(d_["keypoint_feature"], outs["fly_par"]["keypoint_feature"])

@@ -133,8 +133,9 @@ def test_position_sampler_tail_fp16(gpu_device):
     """the bench's precision (fp16 operands / activation storage, fp32 accumulate) over the golden 20-step tail with the
     reference's injected noise.  One fp16 forward of eps is 1e-3 .. 4e-3 off, but the update scales eps by
     (1 - alpha_t) / sqrt(1 - alpha_bar_t): over the last 20 steps the STATE stays within BASELINE's 1e-3 of the reference
-    (measured 1.7e-4) -- asserted.  Over a full 1000-step chain an fp16 chain is NOT trajectory-equal to fp32:
-    nearest-neighbour ties of the 16 noisy points flip under such a perturbation (two fp16 implementations differ O(1))."""
+    (measured 1.7e-4) -- asserted.  Complete 1000-step chains: test_position_sampler_full_chain_fp16_matches_reference and
+    test_feature_sampler_full_chain_matches_reference (both <= 1e-3 vs the reference's goldens; the reverse process contracts
+    the per-step error, and no near-tie of a per-step kNN flipped on the golden chains)."""
     from slide_amd.diffusion import PositionSampler, calc_diffusion_hyperparams
     g = load_golden("golden_sampler_pos.npz")
     _, hp, sd = _load("pos")
@@ -212,6 +213,28 @@ def test_feature_sampler_matches_reference(gpu_device):
     smp = FeatureSampler(hp, sd, size[0], gpu_device, cfg, prec="fp32", noise=noise, use_graph=True)
     x = smp.sample(g["label"], g["keypoint"], g["tail_x_in"], t_start=cs - 1).cpu().numpy()
     assert _rel(x, g["tail_x0"]) <= 1e-3, _rel(x, g["tail_x0"])
+
+
+def test_feature_sampler_full_chain_matches_reference(gpu_device):
+    """The reference's COMPLETE 1000-step denoise_and_reconstruct chain (tests/golden/golden_sampler_feat_full.npz, generated by
+    tools/gen_golden.py --only featfull from the imported reference with the noise stream injected): exact-fp32 mode AND the
+    fp16 throughput mode within north_star's 1e-3"""
+    from slide_amd.diffusion import FeatureSampler
+    g = load_golden("golden_sampler_feat_full.npz")
+    _, hp, sd = _load("feat")
+    cfg = json.loads(str(g["config_json"]))
+    size = g["full_x0"].shape
+    ns = NoiseStream(g["full_seed"])
+    xT = ns(size)
+    noise = np.stack([ns(size) for _ in range(1000)])
+    assert int(g["full_ndraws"]) == 1001
+    for prec in ("fp32", "fp16"):
+        smp = FeatureSampler(hp, sd, size[0], gpu_device, cfg, prec=prec, noise=noise, use_graph=(prec == "fp32"))
+        x = smp.sample(g["label"], g["keypoint"], xT).cpu().numpy()
+        r = _rel(x, g["full_x0"])
+        print("1000-step feature chain, %s: relative max error vs reference %.3e" % (prec, r))
+        assert np.isfinite(x).all() and r <= 1e-3, (prec, r)
+        assert np.array_equal(x[:, :, :3], g["keypoint"])  # the key points are re-clamped every step (diffusion.py:383-385)
 
 
 def test_feature_sampler_local_resampling_matches_reference(gpu_device):
@@ -510,7 +533,10 @@ def test_fp16_full_chains_follow_the_fp32_chains(gpu_device):
         ratio = a2.std(axis=0) / sd_b
         print("%s: per-shape relative max distance: median %.2e, 95 %% %.2e, max %.2e; |mean diff| / std <= %.1e, std ratio %.4f .. %.4f"
               % (name, np.median(per_shape), np.quantile(per_shape, 0.95), per_shape.max(), dm.max(), ratio.min(), ratio.max()))
-        assert per_shape.max() <= 3e-3 and np.quantile(per_shape, 0.95) <= 1e-3, (per_shape.max(), np.quantile(per_shape, 0.95))
+        # measured (round 3 plan): position max 1.1e-3 / median 1.5e-4, feature max 4e-4.  A position chain re-runs its kNN on
+        # noisy points every step: a near-tie may flip for an individual shape, after which that shape is a different sample
+        # of the same distribution -- hence 2e-3 for every shape, 1e-3 for 95 % of them (the golden chains above: <= 1e-3)
+        assert per_shape.max() <= 2e-3 and np.quantile(per_shape, 0.95) <= 1e-3, (per_shape.max(), np.quantile(per_shape, 0.95))
         assert dm.max() <= 0.01 and 0.99 <= ratio.min() and ratio.max() <= 1.01
 
 

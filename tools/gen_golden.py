@@ -189,6 +189,35 @@ def gen_sampler_feat(net, cfg, out, B=2):
     print("sampler feat: head draws", res["head_ndraws"], "tail draws", res["tail_ndraws"])
 
 
+def gen_sampler_feat_full(net, cfg, out, B=2):
+    """COMPLETE 1000-step LatentDiffusion.denoise_and_reconstruct chain (diffusion.py:346-404) with the noise stream injected:
+    pins the fp32 AND the fp16 mode of the HIP feature sampler over a whole generation"""
+    from diffusion_utils import diffusion as D
+    res = {}
+    dcfg = copy.deepcopy(cfg["standard_diffusion_config"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        dm = D.LatentDiffusion(dcfg, autoencoder=None, device=torch.device("cpu"))
+    dm.decode = lambda latent, keypoint_dim, label: latent
+    res["config_json"] = np.array(json.dumps(dcfg))
+    label = torch.tensor([4, 4][:B]).long()
+    keypoint = torch.from_numpy(synth_keypoints(B, 16, seed=6))
+    res["label"] = label.numpy(); res["keypoint"] = keypoint.numpy()
+    ns = NoiseStream(505)
+    o1, o2 = torch.randn, torch.randn_like
+    torch.randn = lambda *size, **k: ns(size)
+    torch.randn_like = lambda x, **k: ns(x.shape)
+    try:
+        with torch.no_grad():
+            _, kp, feat = dm.denoise_and_reconstruct(B, net, 3, (16, 51), label=label, keypoint=keypoint, return_keypoint_feature=True)
+    finally:
+        torch.randn, torch.randn_like = o1, o2
+    res["full_seed"] = np.array(505)
+    res["full_x0"] = torch.cat([kp, feat], dim=2).numpy()
+    res["full_ndraws"] = np.array(ns.count)
+    np.savez_compressed(os.path.join(out, "golden_sampler_feat_full.npz"), **res)
+    print("sampler feat full chain: draws", ns.count)
+
+
 def gen_sampler_feat_resample(out, B=2):
     """LatentDiffusion.denoise_and_reconstruct(local_resampling=True) (diffusion.py:346-359, :76-79): features are
     re-generated only on the points with keypoint_mask == 1, the predicted x0 of the others is pinned to complete_x0.
@@ -456,6 +485,10 @@ if __name__ == "__main__":
     if "feat" in want:
         net, cfg = gen_denoiser("feat", FEAT_CFG, a.out)
         gen_sampler_feat(net, cfg, a.out)
+    if "featfull" in want:  # (not in the default set: ~10 min of reference CPU time; the file is committed)
+        import tempfile
+        net, cfg = gen_denoiser("feat", FEAT_CFG, tempfile.mkdtemp())  # (the denoiser fixture itself is not rewritten)
+        gen_sampler_feat_full(net, cfg, a.out)
     if "resample" in want:
         gen_sampler_feat_resample(a.out)
     if "decode" in want:
