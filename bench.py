@@ -81,6 +81,45 @@ def relaunch_argv(gpus, argv, port=None):
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
+def decode_leg(dev, B):
+    """BASELINE configs[4] on the driver's record: PointAutoencoder.decode of B synthetic latents to
+    (B, 2048, 6) on the HIP module path (fp16 MFMA operands), shapes/s over three timed passes after two warm-up passes; not part
+    of `value`.  Chamfer parity vs the reference: tests/test_hip_modules.py / golden_decode.npz."""
+    import torch
+    from slide_amd.synth import synth_keypoints, synth_state_dict
+    sys.path.insert(0, os.path.join(REPO, "pointnet2"))
+    prev = os.environ.get("SLIDE_MODULE_PREC")
+    os.environ["SLIDE_MODULE_PREC"] = "fp16"
+    try:
+        from models.autoencoder import PointAutoencoder
+        g = np.load(os.path.join(REPO, "tests", "golden", "golden_decode.npz"))
+        decs = json.loads(str(g["decoder_configs_json"]))
+        spec = [(str(n), tuple(int(x) for x in str(s_).split(","))) for n, s_ in zip(g["spec_names"], g["spec_shapes"])]
+        vals = synth_state_dict([("ae." + n, s_) for n, s_ in spec])
+        ae = PointAutoencoder(None, decs, True)
+        ae.load_state_dict({n: torch.from_numpy(vals["ae." + n]) for n, _ in spec})
+        ae = ae.to(dev).eval()
+        kp = torch.from_numpy(synth_keypoints(B)).to(dev)
+        feat = 0.5 * torch.randn(B, 16, 48, device=dev)
+        lab = torch.zeros(B, dtype=torch.long, device=dev)
+        for _ in range(2):
+            o = ae.decode(kp, feat, label=lab)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            o = ae.decode(kp, feat, label=lab)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / 3
+        return {"workload": "BASELINE configs[4]: autoencoder decode of %d latents (16 x 51) to %d x 2048 x 6, HIP module path, fp16 MFMA "
+                            "operands / fp32 accumulate" % (B, B), "shapes_per_s": round(B / dt, 1), "ms_per_batch": round(dt * 1e3, 2),
+                "gflop_per_shape": 16.6, "tflops": round(16.6e9 * B / dt / 1e12, 1), "finite": bool(torch.isfinite(o).all())}
+    finally:
+        if prev is None:
+            os.environ.pop("SLIDE_MODULE_PREC", None)
+        else:
+            os.environ["SLIDE_MODULE_PREC"] = prev
+
+
 def main():
     # multi-process GPU work on this pool needs dmabuf IPC (RCCL / hipIpc* fail with the legacy mode)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -100,6 +139,7 @@ def main():
                          "256 shapes of every GPU are its contiguous shard of a five-category run (labels 0, 2, 3, 4, 6, one weight "
                          "set per category: a chain pair per category segment), latents all-gathered")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the autoencoder-decode leg (BASELINE configs[4]) of the JSON line")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the live fp16-vs-fp32 forward error and the fp32-mode timing")
     ap.add_argument("--fp32-steps", type=int, default=10, help="reverse steps of the exact-fp32 mode timed for parity.fp32_mode_shapes_per_s")
@@ -392,6 +432,8 @@ def main():
                 j32.synchronize()
                 d32 = time.perf_counter() - t1
             out["parity"]["fp32_mode_shapes_per_s"] = round(B / (1000.0 * d32 / a.fp32_steps), 2)
+    if rank == 0 and not a.no_decode and a.workload == "default":
+        out["decode"] = decode_leg(dev, B)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -21,7 +21,7 @@ def short(n):
 
 rows = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
 with open(os.path.join(dst, tag + "_kernel_stats.md"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats (%s): `python bench.py --steps 100 --warmup 5 --no-cpu-baseline`\n\n" % tag)
+    f.write("# rocprofv3 --kernel-trace --stats (%s): `python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-parity --no-decode --replay graph` (graph replay: not host-bound under the profiler)\n\n" % tag)
     bl = os.path.join(src, "bench.log")
     if os.path.exists(bl):
         for line in open(bl):
@@ -54,7 +54,7 @@ if os.path.exists(fp) and os.path.exists(wp):
                 "Units: KiB per dispatch as reported by rocprofv3.  On gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x\n"
                 "(MI355X_MICROARCH.md, HBM section): the `fetch x2` column applies that correction.\n\n"
                 "| kernel | dispatches | FETCH KiB/disp | fetch x2 KiB | WRITE KiB/disp | avg us |\n|---|---|---|---|---|---|\n")
-        keys = [k for k in fa if any(t in k for t in ("gemm", "assemble", "attn", "copy", "prep", "update", "finalize"))]
+        keys = [k for k in fa if any(t in k for t in ("gemm", "assemble", "attn", "copy", "prep", "update", "finalize", "sa_chain", "block_body", "pair_norm"))]
         for k in sorted(keys, key=lambda k: -fa[k][0]):
             w = wa.get(k, [0, 1, 0])
             f.write("| %s | %d | %.0f | %.0f | %.0f | %.1f |\n" % (k, fa[k][1], fa[k][0] / fa[k][1], 2 * fa[k][0] / fa[k][1],
@@ -62,7 +62,7 @@ if os.path.exists(fp) and os.path.exists(wp):
     import json
     kern = {}
     for k in fa:
-        if "gemm" in k or "attn_tail" in k:
+        if any(t in k for t in ("gemm", "attn_tail", "sa_chain", "block_body")):
             w = wa.get(k, [0, 1, 0])
             kern[k] = {"hbm_bytes_per_launch": int(1024 * (2 * fa[k][0] / fa[k][1] + w[0] / max(w[1], 1))),
                        "fetch_kib_x2": 2 * fa[k][0] / fa[k][1], "write_kib": w[0] / max(w[1], 1), "dispatches": fa[k][1]}
@@ -80,7 +80,7 @@ if os.path.exists(mp):
                 "MI355X_MICROARCH.md: the counter advances 32 per 32x32x16 MFMA, summed over all SIMDs).  "
                 "wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES: share of wave-cycles parked in s_waitcnt / barriers.\n\n"
                 "| kernel | dispatches | avg us | MFMA utilisation | VALU per MFMA | wait share |\n|---|---|---|---|---|---|\n")
-        ks = [k for k in acc["SQ_BUSY_CYCLES"] if any(t in k for t in ("gemm", "attn"))]
+        ks = [k for k in acc["SQ_BUSY_CYCLES"] if any(t in k for t in ("gemm", "attn", "sa_chain", "block_body", "pair_norm"))]
         for k in sorted(ks, key=lambda k: -acc["SQ_BUSY_CYCLES"][k][2]):
             g_ = lambda n: acc[n].get(k, [0.0, 1, 0.0])[0]
             d = acc["SQ_BUSY_CYCLES"][k]
