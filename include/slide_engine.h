@@ -117,6 +117,14 @@ enum {
                              *    [10] add1 fp32 [b*add1_bs + c] or NULL, [11] out [n2/32][B*256][32] fp16
                              * i: B, t_ld, k1, n1 (128 | 256), n2 (multiple of 256), gs1, gs2 (GroupNorm group sizes 4 | 8 | 16), add0_stride,
                              *    add0_bs, add1_bs      f: 1 / (gs1 * 256), 1 / (gs2 * 256) */
+  SLIDE_OP_PAIR_FIRST = 31, /* the per-point GEMM of a block's pair decomposition AND its pair-table pass (SLIDE_OP_PAIR_NORM version 1) in one
+                             * launch: y = W . feat + bias never goes through memory.  The channel blocks [0, pair_cob0) are ordinary segments
+                             * (the attention queries riding on the launch: common epilogue, SlideEpi as for SLIDE_OP_GEMM); the blocks from
+                             * pair_cob0 on are the pair channels: their SlideEpi carries bias + what SLIDE_OP_PAIR_NORM reads.
+                             * p: [0] X fp16 [rows][x_ld], [1] W fp16 [n_cob*32][k_pad], [2] epi [n_cob], [3] xyz, [4] wa, [5] wb (fp32 [ld][4]),
+                             *    [6] ta, [7] tb (fp16 [rows][ld]), [8] nbr, [9] d2, [10] w, [11] vd | vw fp32 [2][ld], [12] vv out fp32 [B][2][ld]
+                             *    (8 .. 12: K = 8 only)
+                             * i: rows (= B*16), x_ld, k_pad, n_cob, pair_cob0, ld (= (n_cob - pair_cob0) * 32), K (16 | 8) */
   SLIDE_OP_BLOCK_BODY = 30, /* the whole K-expanded body of an SA / FP block whose widths are <= 256 channels in one launch (csrc/block_body.hip):
                              * Mlp tail -> mo, generated keys -> u, attention tail; one workgroup per sample, mo / u as MFMA operand fragments in
                              * registers, weights through one LDS-DMA ring.  p[0]: HOST pointer to the BodyArgs block (csrc/block_body.hip;

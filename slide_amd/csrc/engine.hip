@@ -458,8 +458,10 @@ __global__ __launch_bounds__(512, 2) void gemm_glds8_kernel(GemmArgs a) {
 // accumulators meet in LDS and every wave finishes ONE 32x32 output block (channel block w & 1, row block w >> 1)
 // through the common epilogue: the K loop and the epilogue are each ~4x shorter per wave and the grid is 4x larger.
 // (168-VGPR budget: a wave of this kernel then shares a SIMD with two waves of the 64-channel GEMM tiles of the other chains)
-template <int NST, bool AFF>
-__global__ __launch_bounds__(256, 3) void gemm_small_kernel(GemmArgs a) {
+// PAIR (pair_first_kernel below): 0 = none, 1 / 2 = the channel blocks from pa.pair_cob0 on are the per-point products of an
+// SA / FP block's pair decomposition and leave through the pair-table epilogue instead of the common one
+template <int NST, bool AFF, int PAIR>
+__device__ __forceinline__ void small_body(const GemmArgs &a, const PairArgs &pa) {
   using T = _Float16;
   constexpr int NPXL = 4;
   constexpr int STAGE_B = 128 * 64;  // 64 X rows + 64 W rows, 64 bytes each
@@ -516,6 +518,24 @@ __global__ __launch_bounds__(256, 3) void gemm_small_kernel(GemmArgs a) {
     if (s0 < mine) issue(wave + 4 * s0, s0);
   // tables (and the affine vectors) are staged behind the primed rings: their latency overlaps the first chunks'
   stage_epilogue_tables<2>(a, cob0, tid, epi_lds, vec_lds);
+  // PAIR: the four samples' coordinates [4][48] and (FP) neighbour / squared-distance / weight slots [4][16 x 8] each
+  float *const pair_lds = vec_lds + 2 * 96;
+  if constexpr (PAIR != 0) {
+    const int nb = a.rows >> NPXL, b0 = row0 >> NPXL;
+    if (tid < 192) {
+      const int bb = b0 + tid / 48 < nb ? b0 + tid / 48 : nb - 1;
+      pair_lds[tid] = pa.xyz[(size_t)bb * 48 + tid % 48];
+    }
+    if (PAIR == 2) {
+      for (int i = tid; i < 512; i += 256) {
+        const int bb = b0 + (i >> 7) < nb ? b0 + (i >> 7) : nb - 1, t = i & 127;
+        const int slot = (bb * 16 + (t >> 3)) * 16 + (t & 7);
+        reinterpret_cast<int *>(pair_lds + 192)[i] = pa.nbr[slot];
+        pair_lds[192 + 512 + i] = pa.d2t[slot];
+        pair_lds[192 + 1024 + i] = pa.wt[slot];
+      }
+    }
+  }
   // AFF: consumer-side GroupNorm affine of the four samples of this tile, fp16 [sample][scale | shift][k_pad]
   _Float16 *const aff_lds = reinterpret_cast<_Float16 *>(vec_lds + 2 * 96);
   if (AFF) {
@@ -660,8 +680,104 @@ __global__ __launch_bounds__(256, 3) void gemm_small_kernel(GemmArgs a) {
   SLIDE_STAMP(a, 3);
   SLIDE_STAMP(a, 4);
   const int cb = wave >> 1, rb = wave & 1;  // block index wave = cb*2 + rb
-  gemm_epilogue<SLIDE_PREC_F16, NPXL, 1, 1>(a, one, row0 + rb * 32, cob0 + cb, 0, half, col, epi_lds + cb * EPI_DW,
-                                            vec_lds + cb * 96, nullptr);
+  if (PAIR == 0 || cob0 + cb < pa.pair_cob0)
+    gemm_epilogue<SLIDE_PREC_F16, NPXL, 1, 1>(a, one, row0 + rb * 32, cob0 + cb, 0, half, col, epi_lds + cb * EPI_DW,
+                                              vec_lds + cb * 96, nullptr);
+  if constexpr (PAIR != 0) {
+    // ---- pair-table epilogue (the arithmetic of pair_norm_kernel, gemm_gx.hip, on the accumulators instead of a stored y).
+    // The wave's block D[channel][row] is transposed through LDS so that a lane owns ONE channel of ONE of the block's two
+    // samples and its registers run over the sample's 16 points.
+    __syncthreads();  // every wave has summed its block: the partial-sum area is free
+    const int cobi = cob0 + cb;
+    if (cobi >= pa.pair_cob0 && cobi < a.n_cob) {
+      float *const tr = reinterpret_cast<float *>(smem_raw) + wave * 4096;  // [32 channels][33] transposed block, then [16][65] columns
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + col] = one[0][0][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int smp = half, cl = col;                    // lane = (sample of the block, channel)
+      const int sl4 = rb * 2 + smp;                      // sample slot of the tile (0..3)
+      const int nb = a.rows >> NPXL;
+      const int b = (row0 >> NPXL) + sl4;
+      const int c = (cobi - pa.pair_cob0) * 32 + cl;     // pair channel
+      const int ld = pa.ld;
+      const uint32_t *ed = epi_lds + cb * EPI_DW;
+      const int e_mode = (int)ed[0], e_flags = (int)ed[1], e_gs = (int)ed[2], e_n_norm = (int)ed[3];
+      const float e_inv_count = __uint_as_float(ed[4]), e_stats_scale = __uint_as_float(ed[5]);
+      const int e_stats_bs = (int)ed[9];
+      float *const e_sum = reinterpret_cast<float *>((uint64_t)ed[30] | ((uint64_t)ed[31] << 32));
+      float *const e_sq = reinterpret_cast<float *>((uint64_t)ed[32] | ((uint64_t)ed[33] << 32));
+      const float *sxs = pair_lds + sl4 * 48;
+      const float bias = vec_lds[cb * 96 + cl];
+      const float4 ca = *reinterpret_cast<const float4 *>(pa.wa + (size_t)c * 4), cbv = *reinterpret_cast<const float4 *>(pa.wb + (size_t)c * 4);
+      float av[16], bv[16];
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        const float x0 = sxs[p * 3], x1 = sxs[p * 3 + 1], x2 = sxs[p * 3 + 2];
+        av[p] = (tr[cl * 33 + smp * 16 + p] + bias) + (ca.x * x0 + ca.y * x1 + ca.z * x2);
+        bv[p] = cbv.x * x0 + cbv.y * x1 + cbv.z * x2;
+      }
+      float vd = 0.f, vw = 0.f;
+      if (PAIR == 2) { vd = pa.vv_in[c]; vw = pa.vv_in[ld + c]; }
+      float g = 1.f, sh = 0.f;
+      if (e_mode != SLIDE_EPI_RAW) {
+        const bool pre_relu = (e_flags & SLIDE_F_PRE_RELU) != 0;
+        float s = 0.f, ss = 0.f;
+        if (PAIR == 1) {
+#pragma unroll
+          for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              float v = av[q] + bv[p];
+              if (pre_relu) v = fmaxf(v, 0.f);
+              s += v; ss = fmaf(v, v, ss);
+            }
+        } else {
+          const int *sqs = reinterpret_cast<const int *>(pair_lds + 192) + sl4 * 128;
+          const float *sds = pair_lds + 192 + 512 + sl4 * 128, *sws = pair_lds + 192 + 1024 + sl4 * 128;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the transposed block has been read: its area takes the columns
+          float *const sa = tr;  // [16][65]
+#pragma unroll
+          for (int p = 0; p < 16; ++p) sa[p * 65 + lane] = av[p];  // (a lane reads back only its own column)
+#pragma unroll
+          for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int sl = p * 8 + j;
+              float v = sa[sqs[sl] * 65 + lane] + bv[p] + sds[sl] * vd + sws[sl] * vw;
+              if (pre_relu) v = fmaxf(v, 0.f);
+              s += v; ss = fmaf(v, v, ss);
+            }
+        }
+        if (e_mode == SLIDE_EPI_STATS) {
+          if (b < nb) {
+            e_sum[(size_t)b * e_stats_bs + cl] = s * e_stats_scale;
+            e_sq[(size_t)b * e_stats_bs + cl] = ss * e_stats_scale;
+          }
+        } else {  // NORM: groups of e_gs physical channels (a power of two <= 32: lanes of one half)
+          for (int m = 1; m < e_gs; m <<= 1) {
+            s += __shfl_xor(s, m, 64);
+            ss += __shfl_xor(ss, m, 64);
+          }
+          const float mean = s * e_inv_count;
+          const float var = fmaxf(ss * e_inv_count - mean * mean, 0.f);
+          g = vec_lds[cb * 96 + 32 + cl] * __builtin_amdgcn_rsqf(var + GN_EPS);
+          sh = vec_lds[cb * 96 + 64 + cl] - mean * g;
+          if (cl >= e_n_norm) { g = 1.f; sh = 0.f; }  // MyGroupNorm leaves the last C % G channels as they are
+        }
+      }
+      if (b < nb) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+          pa.ta[((size_t)b * 16 + p) * ld + c] = (_Float16)(av[p] * g + sh);
+          pa.tb[((size_t)b * 16 + p) * ld + c] = (_Float16)(bv[p] * g);
+        }
+        if (PAIR == 2) {
+          pa.vv_out[(size_t)b * 2 * ld + c] = vd * g;
+          pa.vv_out[(size_t)b * 2 * ld + ld + c] = vw * g;
+        }
+      }
+    }
+  }
   SLIDE_STAMP(a, 5);
 #ifdef SLIDE_TIMELINE
   if (a.dbg) {
@@ -669,6 +785,18 @@ __global__ __launch_bounds__(256, 3) void gemm_small_kernel(GemmArgs a) {
     SLIDE_STAMP(a, 6);
   }
 #endif
+}
+
+template <int NST, bool AFF>
+__global__ __launch_bounds__(256, 3) void gemm_small_kernel(GemmArgs a) {
+  small_body<NST, AFF, 0>(a, PairArgs());
+}
+
+// The per-point GEMM of a block's pair decomposition and the pair-table pass (SLIDE_OP_PAIR_NORM version 1) as ONE launch
+// (SLIDE_OP_PAIR_FIRST): the products never go through memory.  FP: the 8-neighbour samples of the FP blocks.
+template <bool FP>
+__global__ __launch_bounds__(256, 3) void pair_first_kernel(GemmArgs a, PairArgs pa) {
+  small_body<2, false, FP ? 2 : 1>(a, pa);
 }
 
 // ------------------------------------------------------------------------------------------------ attention tail
@@ -1641,6 +1769,44 @@ int launch_gemm_small_t(const GemmArgs &a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+template <bool FP>
+int launch_pair_first_t(const GemmArgs &a, const PairArgs &pa, hipStream_t s) {
+  const int grid = ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2);
+  const size_t shm = (size_t)4 * 2 * 8192 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32 + (192 + 3 * 512) * 4;
+  static bool attr_done[SLIDE_MAX_DEVICES] = {};
+  bool &attr_set = attr_done[current_device_slot()];
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_first_kernel<FP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((pair_first_kernel<FP>), dim3(grid), dim3(256), shm, s, a, pa);
+  return (int)hipGetLastError();
+}
+
+// SLIDE_OP_PAIR_FIRST (include/slide_engine.h)
+int run_pair_first(const SlideOp &o, hipStream_t s) {
+  GemmArgs a = GemmArgs();
+  a.X = o.p[0]; a.W = o.p[1]; a.epi = (const SlideEpi *)o.p[2];
+  a.aff_tps = 1;
+  a.rows = o.i[0]; a.x_ld = o.i[1]; a.k_pad = o.i[2]; a.n_cob = o.i[3];
+  a.dbg = (unsigned long long *)o.p[13];
+  PairArgs pa;
+  pa.pair_cob0 = o.i[4]; pa.ld = o.i[5];
+  pa.xyz = (const float *)o.p[3]; pa.wa = (const float *)o.p[4]; pa.wb = (const float *)o.p[5];
+  pa.ta = (_Float16 *)o.p[6]; pa.tb = (_Float16 *)o.p[7];
+  pa.nbr = (const int *)o.p[8]; pa.d2t = (const float *)o.p[9]; pa.wt = (const float *)o.p[10];
+  pa.vv_in = (const float *)o.p[11]; pa.vv_out = (float *)o.p[12];
+  if (a.k_pad % BK || a.x_ld % 8 || a.rows <= 0 || a.n_cob <= 0 || a.rows % 16 || pa.pair_cob0 < 0 || pa.pair_cob0 > a.n_cob ||
+      pa.ld != (a.n_cob - pa.pair_cob0) * 32)
+    return -3;
+  if (o.i[6] == 8) {
+    if (!pa.nbr || !pa.d2t || !pa.wt || !pa.vv_in || !pa.vv_out) return -3;
+    return launch_pair_first_t<true>(a, pa, s);
+  }
+  return launch_pair_first_t<false>(a, pa, s);
+}
+
 int launch_gemm_small(const GemmArgs &a, hipStream_t s) {
   const int grid = ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2);
   // two stages per wave (64 KB of LDS: the size of the partial-sum exchange) rather than three (96 KB): the workgroup
@@ -1935,6 +2101,8 @@ int run_op(const SlideOp &o, hipStream_t s) {
       return slide_launch_gemm_gx(o, s);
     case SLIDE_OP_PAIR_NORM:
       return slide_launch_pair_norm(o, s);
+    case SLIDE_OP_PAIR_FIRST:
+      return run_pair_first(o, s);
     case SLIDE_OP_SA_CHAIN:
       return slide_launch_sa_chain(o, s);
     case SLIDE_OP_BLOCK_BODY:

@@ -48,6 +48,18 @@ struct GemmArgs {
   int gx_ld, gx_mode, gx_add_idx_stride, gx_vbs;
 };
 
+// SLIDE_OP_PAIR_FIRST (pair_first_kernel, engine.hip): what the pair-table epilogue reads beside the GEMM arguments
+struct PairArgs {
+  const float *xyz;          // coordinates [B*16][3]
+  const float *wa, *wb;      // coordinate coefficients of the a / b tables, [ld][4] per pair channel
+  _Float16 *ta, *tb;         // the tables [B*16][ld]
+  const int *nbr;            // FP blocks: neighbour / squared-distance / weight slots [B*16][16] (first 8 of a row)
+  const float *d2t, *wt;
+  const float *vv_in;        // FP blocks: coefficient vectors of the two per-slot scalars [2][ld]
+  float *vv_out;             //            and their per-sample scaled copies [B][2][ld]
+  int pair_cob0, ld;         // first 32-channel block of the pair segments; table row length
+};
+
 namespace {
 
 constexpr int TM = 256;  // rows per workgroup (whole samples: 1 x 256, 2 x 128 or 16 x 16 rows)

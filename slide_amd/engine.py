@@ -24,7 +24,7 @@ PREC = {"fp32": 0, "fp16": 1}
  OP_COND, OP_UPDATE_POS, OP_UPDATE_FEAT, OP_ADVANCE_T) = range(1, 13)
 OP_SYNC = 14
 OP_ATTN_TAIL = 16
-OP_GEMM_GX, OP_PAIR_NORM, OP_SA_CHAIN, OP_BLOCK_BODY = 17, 18, 19, 30
+OP_GEMM_GX, OP_PAIR_NORM, OP_SA_CHAIN, OP_BLOCK_BODY, OP_PAIR_FIRST = 17, 18, 19, 30, 31
 
 
 class SlideEpi(ctypes.Structure):
@@ -237,7 +237,7 @@ class DenoiserEngine:
         return off
 
     def _gemm(self, X, npx_log2, segs, in_cols=None, in_affine=None, k_logical=None, gather=None, gn_fin=None,
-              pre_gather=None, gx=None, pair_tabs=None):
+              pre_gather=None, gx=None, pair_tabs=None, pair_fused=None):
         """X: input buffer [rows][ld].  segs: list of dicts describing consecutive output segments:
              w (O,I) bias (O) | out (tensor) out_coff | mode flags | gn=(gamma,beta) for NORM | layout (gn_layout) |
              addvec=(tensor, off, bs) | residual tensor | bcast | stats=(sum,sq tensors, coff, scale)
@@ -302,7 +302,7 @@ class DenoiserEngine:
                 e.flags = flags
                 e.gs = gs_p
                 e.n_norm = int(min(32, max(0, n_norm_p - 32 * j)))
-                e.inv_count = 1.0 / (gs_l * npx)
+                e.inv_count = 1.0 / (gs_l * sg.get("npx", npx))  # (npx: a pair segment's GroupNorm runs over the K-expanded rows)
                 e.out_ld = self._ldp(out)
                 e.bias = vd.data_ptr() + 4 * (32 * j)
                 e.gamma = vd.data_ptr() + 4 * (Opad + 32 * j)
@@ -362,6 +362,20 @@ class DenoiserEngine:
             sc, sh, aff_off, in_bs = in_affine
         if gx is not None:
             return self._emit_gx(gx, npx_log2, rows, ld, n_cob, Wd, ed, segs, W, vec_list, in_affine, pair_tabs)
+        if pair_fused is not None:  # SLIDE_OP_PAIR_FIRST: per-point GEMM + pair-table pass in one launch (_pair_first)
+            pf = pair_fused
+            assert npx_log2 == 4 and self.prec == 1 and in_affine is None and gather is None and gn_fin is None and not w_cm
+            assert X.dtype == self.adt and not self._is_cm(X)
+            self.gemm_flops[len(self.ops)] = 2 * rows * sum(int(s_["w"].size) for s_ in segs)
+            self.gemm_bytes[len(self.ops)] = (rows * ld * 2 + W.size * 2, 2 * rows * pf["ld"] * 2 + rows * 32 * pf["cob0"] * 2)
+            self.flops += 2 * rows * sum(int(s_["w"].size) for s_ in segs)
+            self.kernel_names[len(self.ops)] = "pair_first_kernel<%s>" % ("true" if pf["K"] == 8 else "false")
+            ptr = lambda t: None if t is None else t.data_ptr()
+            self._emit(make_op(OP_PAIR_FIRST, i=(rows, x_ld, ld, n_cob, pf["cob0"], pf["ld"], pf["K"]),
+                               p=(X.data_ptr(), Wd.data_ptr(), ed.data_ptr(), self.xyz.data_ptr(), pf["wa"].data_ptr(),
+                                  pf["wb"].data_ptr(), pf["ta"].data_ptr(), pf["tb"].data_ptr(), ptr(pf.get("nbr")), ptr(pf.get("d2")),
+                                  ptr(pf.get("w")), ptr(pf.get("vv_in")), ptr(pf.get("vv")))))
+            return
         assert X.dtype == self.adt
         # wide (128-channel) tiles only when the grid still covers the 256 CUs at least twice
         ntr = (rows + 255) // 256
@@ -589,7 +603,10 @@ class DenoiserEngine:
             offs.append(off)
             off += Op
         ldy = off
-        Y = self.A.zeros(B * 16, ldy)  # fp32
+        # SLIDE_PAIR_FUSED (default on): the per-point GEMM and the pair-table pass as ONE launch (SLIDE_OP_PAIR_FIRST,
+        # csrc/engine.hip pair_first_kernel) -- y never goes through memory; bit-identical to the two-launch form
+        fused = fin is None and self.prec == 1 and self.use_glds and os.environ.get("SLIDE_PAIR_FUSED", "1") != "0"
+        Y = None if fused else self.A.zeros(B * 16, ldy)  # fp32
         wa, wb, vv_in = np.zeros((ldy, 4), np.float32), np.zeros((ldy, 4), np.float32), np.zeros((2, ldy), np.float32)
         psegs = []
         for sg, o_ in zip(segs, offs):
@@ -609,17 +626,33 @@ class DenoiserEngine:
             ps["out"] = None
             psegs.append(ps)
         assert sum(3 for _ in ("rel", "abs", "ctr")) + (2 if coords.get("d2") is not None else 0) + C == segs[0]["w"].shape[1]
-        # (lead_segs: other per-point GEMM segments over the same table -- the attention queries -- ride on this launch)
-        self._gemm(feat_in, 4, list(lead_segs) + ysegs)
         ta = self.A.zeros(B * 16, ldy, dtype=torch.float16)
         tb = self.A.zeros(B * 16, ldy, dtype=torch.float16)
-        ed = self._epi_only(psegs, 1 << npx_log2)
         fp = K == 8
         d = [self.A.put(wa), self.A.put(wb)]
         vv = rvv_all = None
         if fp:
             d.append(self.A.put(vv_in))
             vv = self.A.zeros(B, 2, ldy)
+        if fused:
+            fsegs = []
+            for sg, o_ in zip(segs, offs):
+                fs = dict(sg)
+                fs.update(w=sg["w"][:, :C], out=ta, out_coff=o_, npx=1 << npx_log2)
+                for k_ in ("addvec", "residual", "res_pair", "pre_add"):
+                    assert fs.get(k_) is None or k_ == "addvec"
+                fs.pop("addvec", None)  # (first_mlp's t-embedding rows are added by the consumers, after the ReLU)
+                fsegs.append(fs)
+            lead_cobs = sum(ru(sg["w"].shape[0] if sg.get("layout") is None else sg["layout"][1]) for sg in lead_segs) // 32
+            self._gemm(feat_in, 4, list(lead_segs) + fsegs,
+                       pair_fused=dict(cob0=lead_cobs, ld=ldy, K=K, wa=d[0], wb=d[1], ta=ta, tb=tb,
+                                       nbr=self.kidx if fp else None, d2=self.kd2 if fp else None, w=self.kw if fp else None,
+                                       vv_in=d[2] if fp else None, vv=vv))
+            return dict(ta=ta, tb=tb, vv=vv, offs=offs, ldy=ldy, rows=B * 16 * K, vv_in=vv_in,
+                        tabs=(self.kidx, self.kd2, self.kw) if fp else None)
+        # (lead_segs: other per-point GEMM segments over the same table -- the attention queries -- ride on this launch)
+        self._gemm(feat_in, 4, list(lead_segs) + ysegs)
+        ed = self._epi_only(psegs, 1 << npx_log2)
         # loop-invariant when the coordinates are a fixed condition?  No: y changes every step.
         v2 = ldy <= 2048 and os.environ.get("SLIDE_PAIR_NORM_V2", "0") != "0"
         assert fin is None or v2

@@ -469,7 +469,7 @@ def test_pair_decomposition_plan_variants(gpu_device, monkeypatch):
     """Round 3: the pair decomposition (csrc/gemm_gx.hip, block_body.hip) re-associates the blocks' first layers (a[q] + b[p]
     from 16-row GEMMs instead of 256- / 128-row ones) and runs the SA blocks in natural neighbour order, so it is NOT
     bit-identical to the round-2 plan; both are fp16 renderings of the same network.  Every combination of the round-3
-    kernels (fused SA chain, block body, pair-table pass v1 / v2, eight-wave tail) must agree with the reference golden
+    kernels (fused SA chain, block body, pair-table pass fused / v1 / v2, eight-wave tail) must agree with the reference golden
     within the fp16 forward bound (5e-3 of the output's L2 norm, as test_denoiser_forward_fp16_mfma) AND with each other
     within 4e-3 (measured <= 2e-3: different summation orders of fp16-rounded terms)."""
     from slide_amd.engine import DenoiserEngine
@@ -480,15 +480,18 @@ def test_pair_decomposition_plan_variants(gpu_device, monkeypatch):
         outs = {}
         for tag, knobs in (("round2", {"SLIDE_GX": "0"}), ("default", {}), ("no_body", {"SLIDE_BODY": "0"}),
                            ("no_body_no_chain", {"SLIDE_BODY": "0", "SLIDE_SA_CHAIN": "0"}),
-                           ("pair_norm_v2", {"SLIDE_PAIR_NORM_V2": "1"}), ("tail8", {"SLIDE_TAIL8": "1", "SLIDE_BODY": "0"})):
+                           ("pair_norm_v2", {"SLIDE_PAIR_NORM_V2": "1"}), ("tail8", {"SLIDE_TAIL8": "1", "SLIDE_BODY": "0"}),
+                           ("two_launch_tables", {"SLIDE_PAIR_FUSED": "0"})):
             for k_, v_ in knobs.items():
                 monkeypatch.setenv(k_, v_)
             e = DenoiserEngine(hp, sd, x.shape[0], gpu_device, prec="fp16")
             kinds = {o.kind for o in e.ops}
             if tag == "round2":
                 assert not kinds & {17, 18, 19, 30}
+            elif tag in ("pair_norm_v2", "two_launch_tables"):
+                assert 18 in kinds and 31 not in kinds  # SLIDE_OP_PAIR_NORM after a 16-row GEMM
             else:
-                assert 18 in kinds  # SLIDE_OP_PAIR_NORM
+                assert 31 in kinds and 18 not in kinds  # SLIDE_OP_PAIR_FIRST: GEMM + table pass in one launch
             outs[tag] = e.forward(x, ts, lab).cpu().numpy().astype(np.float64)
             for k_ in knobs:
                 monkeypatch.delenv(k_)
@@ -497,6 +500,8 @@ def test_pair_decomposition_plan_variants(gpu_device, monkeypatch):
         for tag, o in outs.items():
             d = np.linalg.norm(o - outs["default"]) / np.linalg.norm(outs["default"])
             assert d <= 4e-3, (name, tag, d)
+        # the fused launch evaluates the table pass's arithmetic on the accumulators instead of a stored fp32 y: same bits
+        assert np.array_equal(outs["two_launch_tables"], outs["default"]), name
 
 
 def test_fp16_full_chains_follow_the_fp32_chains(gpu_device):

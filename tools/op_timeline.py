@@ -48,7 +48,7 @@ with torch.cuda.stream(s.stream):
         op = SlideOp.from_buffer_copy(bytes(s.step_ops[idx]))
         nwg = 16384
         dbg = torch.zeros(nwg * 16, dtype=torch.int64, device=dev)
-        slot = {1: 5, 17: 12, 19: 12, 16: 8, 30: 1}.get(op.kind)
+        slot = {1: 5, 17: 12, 19: 12, 16: 8, 30: 1, 31: 13}.get(op.kind)
         if slot is None:
             print("op %d: kind %d carries no stamps" % (idx, op.kind)); continue
         op.p[slot] = dbg.data_ptr()
