@@ -125,6 +125,10 @@ enum {
                              *    [6] ta, [7] tb (fp16 [rows][ld]), [8] nbr, [9] d2, [10] w, [11] vd | vw fp32 [2][ld], [12] vv out fp32 [B][2][ld]
                              *    (8 .. 12: K = 8 only)
                              * i: rows (= B*16), x_ld, k_pad, n_cob, pair_cob0, ld (= (n_cob - pair_cob0) * 32), K (16 | 8) */
+  SLIDE_OP_GEMM_CHAIN = 32, /* consecutive 16-rows-per-sample SLIDE_OP_GEMM launches (fp16, no input affine / gather / statistics finalisation)
+                             * as ONE launch (csrc/gemm_chain.hip): a workgroup owns 64 rows and walks the layers, each through the common
+                             * epilogue of its SlideEpi descriptors.  p[0]: HOST pointer to SlideChainLayer[n] (device pointers inside), kept
+                             * alive by the plan.  i: rows, n (<= 6) */
   SLIDE_OP_BLOCK_BODY = 30, /* the whole K-expanded body of an SA / FP block whose widths are <= 256 channels in one launch (csrc/block_body.hip):
                              * Mlp tail -> mo, generated keys -> u, attention tail; one workgroup per sample, mo / u as MFMA operand fragments in
                              * registers, weights through one LDS-DMA ring.  p[0]: HOST pointer to the BodyArgs block (csrc/block_body.hip;
@@ -163,6 +167,12 @@ typedef struct SlidePrepCopy {
   void *dst;
   int32_t ld, kind, n, pad;
 } SlidePrepCopy;
+
+/* one layer of SLIDE_OP_GEMM_CHAIN: X fp16 [rows][x_ld] (k_pad columns read), W fp16 row-major [n_cob*32][k_pad], epi SlideEpi[n_cob] */
+typedef struct SlideChainLayer {
+  const void *X, *W, *epi;
+  int32_t x_ld, k_pad, n_cob, pad;
+} SlideChainLayer;
 
 typedef struct SlideOp {
   int32_t kind;

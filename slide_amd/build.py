@@ -19,6 +19,7 @@ SOURCES = [("point_ops.hip", ["-ffp-contract=off"]), ("engine.hip", ["-mllvm", "
            ("gemm_xs.hip", ["-mllvm", "-pragma-unroll-threshold=100000"]),
            ("gemm_gx.hip", ["-mllvm", "-pragma-unroll-threshold=100000"]),
            ("block_body.hip", ["-mllvm", "-pragma-unroll-threshold=100000"]),
+           ("gemm_chain.hip", ["-mllvm", "-pragma-unroll-threshold=100000"]),
            ("resident.hip", ["-mllvm", "-pragma-unroll-threshold=100000"]), ("rows_ops.hip", [])]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
           "-Wno-unused-function"]

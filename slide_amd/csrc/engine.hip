@@ -22,6 +22,7 @@ int slide_launch_gemm_gx(const SlideOp &o, hipStream_t s);
 int slide_launch_pair_norm(const SlideOp &o, hipStream_t s);
 int slide_launch_sa_chain(const SlideOp &o, hipStream_t s);
 int slide_launch_block_body(const SlideOp &o, hipStream_t s);  // block_body.hip
+int slide_launch_gemm_chain(const SlideOp &o, hipStream_t s);  // gemm_chain.hip
 
 namespace {
 
@@ -2103,6 +2104,8 @@ int run_op(const SlideOp &o, hipStream_t s) {
       return slide_launch_pair_norm(o, s);
     case SLIDE_OP_PAIR_FIRST:
       return run_pair_first(o, s);
+    case SLIDE_OP_GEMM_CHAIN:
+      return slide_launch_gemm_chain(o, s);
     case SLIDE_OP_SA_CHAIN:
       return slide_launch_sa_chain(o, s);
     case SLIDE_OP_BLOCK_BODY:

@@ -24,7 +24,7 @@ PREC = {"fp32": 0, "fp16": 1}
  OP_COND, OP_UPDATE_POS, OP_UPDATE_FEAT, OP_ADVANCE_T) = range(1, 13)
 OP_SYNC = 14
 OP_ATTN_TAIL = 16
-OP_GEMM_GX, OP_PAIR_NORM, OP_SA_CHAIN, OP_BLOCK_BODY, OP_PAIR_FIRST = 17, 18, 19, 30, 31
+OP_GEMM_GX, OP_PAIR_NORM, OP_SA_CHAIN, OP_BLOCK_BODY, OP_PAIR_FIRST, OP_GEMM_CHAIN = 17, 18, 19, 30, 31, 32
 
 
 class SlideEpi(ctypes.Structure):
@@ -68,6 +68,11 @@ class BodyArgs(ctypes.Structure):  # csrc/block_body.hip (same field order: natu
                 ("vect", ctypes.c_void_p), ("n_out", ctypes.c_int32), ("gsv", ctypes.c_int32), ("nnv", ctypes.c_int32), ("invv", ctypes.c_float),
                 ("out", ctypes.c_void_p), ("out_ld", ctypes.c_int32), ("out2", ctypes.c_void_p), ("out2_ld", ctypes.c_int32), ("out2_n", ctypes.c_int32),
                 ("B", ctypes.c_int32), ("dbg", ctypes.c_void_p)]
+
+
+class SlideChainLayer(ctypes.Structure):  # include/slide_engine.h
+    _fields_ = [("X", ctypes.c_void_p), ("W", ctypes.c_void_p), ("epi", ctypes.c_void_p),
+                ("x_ld", ctypes.c_int32), ("k_pad", ctypes.c_int32), ("n_cob", ctypes.c_int32), ("pad", ctypes.c_int32)]
 
 
 class SlideOp(ctypes.Structure):
@@ -1305,8 +1310,65 @@ class DenoiserEngine:
             self._prep_tab = A.put(np.frombuffer(bytes(tab), dtype=np.uint8).copy())
             prep = self.ops[self._prep_idx]
             prep.p[6], prep.i[4] = self._prep_tab.data_ptr(), len(self._prep_copies)
+        self._merge_chains()
         self.step_ops = (SlideOp * len(self.ops))(*self.ops)
         self.cond_ops = (SlideOp * 1)(self.cond_op)
+
+    def _merge_chains(self):
+        """runs of consecutive per-point GEMM launches (16 rows per sample, fp16, plain input) become ONE SLIDE_OP_GEMM_CHAIN
+        launch each (csrc/gemm_chain.hip): the FP blocks' second Mlp_plus_t_emb, the output head.  SLIDE_GEMM_CHAIN=0 keeps the
+        launches apart.  Every op-index table of the plan is re-keyed."""
+        # SLIDE_GEMM_CHAIN = largest chain in KB of weights (default 0: none).  OPT-IN -- measured in bench.py's arrangement (three
+        # feature sub-batches + the position chain): 92 launches per step instead of 108, but 366 shapes/s with every chain
+        # merged and 371 with the chains of <= 256 KB of weights against 374 without: a chain's 20-odd workgroups each stream
+        # ALL its weights (660 KB for the feature net's FP1.mlp2) and pay every layer's descriptor -> operands -> epilogue ->
+        # store round trips in sequence, where the wide-grid launches of the other chains fill the same CUs meanwhile
+        max_kb = int(os.environ.get("SLIDE_GEMM_CHAIN", "0"))
+        if self.prec != 1 or not self.use_glds or max_kb <= 0:
+            return
+        def eligible(o):
+            return (o is not None and o.kind == OP_GEMM and o.i[4] == 4 and o.i[6] == 1 and o.i[8] == 1 and o.i[9] != 3
+                    and not any(o.p[k] for k in (3, 4, 6, 7, 8, 9, 10, 11, 12, 13)) and o.i[2] <= 1024)
+        new_ops, remap, i = [], {}, 0
+        self._chain_keep = []
+        flops, nbytes, names = {}, {}, {}
+        while i < len(self.ops):
+            j = i
+            while (j < len(self.ops) and eligible(self.ops[j]) and self.ops[j].i[0] == self.ops[i].i[0]
+                   and self.ops[j].i[10] == self.ops[i].i[10] and j - i < 6):
+                j += 1
+            k = len(new_ops)
+            while j - i >= 2 and sum(o.i[2] * o.i[3] * 64 for o in self.ops[i:j]) > max_kb * 1024:
+                j -= 1  # (drop layers from the end until the chain's weights fit)
+            if j - i >= 2:
+                tab = (SlideChainLayer * (j - i))()
+                for q, o in enumerate(self.ops[i:j]):
+                    tab[q].X, tab[q].W, tab[q].epi = o.p[0], o.p[1], o.p[2]
+                    tab[q].x_ld, tab[q].k_pad, tab[q].n_cob = o.i[1], o.i[2], o.i[3]
+                self._chain_keep.append(tab)
+                op = make_op(OP_GEMM_CHAIN, i=(self.ops[i].i[0], j - i), p=(ctypes.addressof(tab),))
+                op.i[10] = self.ops[i].i[10]
+                new_ops.append(op)
+                for q in range(i, j):
+                    remap[q] = k
+                flops[k] = sum(self.gemm_flops.get(q, 0) for q in range(i, j))
+                nbytes[k] = tuple(sum(self.gemm_bytes.get(q, (0, 0))[z] for q in range(i, j)) for z in (0, 1))
+                names[k] = "gemm_chain_kernel"
+                i = j
+                continue
+            new_ops.append(self.ops[i])
+            remap[i] = k
+            for src, dst in ((self.gemm_flops, flops), (self.gemm_bytes, nbytes), (self.kernel_names, names)):
+                if i in src:
+                    dst[k] = src[i]
+            i += 1
+        self.ops = new_ops
+        self.gemm_flops, self.gemm_bytes, self.kernel_names = flops, nbytes, names
+        self.xyz_copy_idx = [remap[q] for q in self.xyz_copy_idx]
+        self.eps_copy_idx = remap[self.eps_copy_idx]
+        self._prep_idx = remap[self._prep_idx]
+        self._body_args = {remap[q]: v for q, v in self._body_args.items()}
+        self._tail_of = {k_: remap[v] for k_, v in self._tail_of.items()}
 
     # ------------------------------------------------------------------ execution
     def _stream(self):

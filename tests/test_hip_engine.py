@@ -439,6 +439,7 @@ def test_chunk_major_layout_bit_identical(gpu_device, monkeypatch):
     bit-identical to the row-major plan, with the gather-on-load first layers, the fused attention tail, and without either."""
     from slide_amd.engine import DenoiserEngine
     monkeypatch.setenv("SLIDE_GX", "0")  # the round-2 plan on both sides (the pair decomposition needs chunk-major weights)
+    monkeypatch.setenv("SLIDE_GEMM_CHAIN", "0")  # (COPY launches between the per-point GEMMs change which of them form a chain)
     for name in ("pos", "feat"):
         g, hp, sd = _load(name)
         x, ts, lab = g["x_mixed"], g["ts_mixed"], g["label_mixed"]
@@ -469,7 +470,7 @@ def test_pair_decomposition_plan_variants(gpu_device, monkeypatch):
     """Round 3: the pair decomposition (csrc/gemm_gx.hip, block_body.hip) re-associates the blocks' first layers (a[q] + b[p]
     from 16-row GEMMs instead of 256- / 128-row ones) and runs the SA blocks in natural neighbour order, so it is NOT
     bit-identical to the round-2 plan; both are fp16 renderings of the same network.  Every combination of the round-3
-    kernels (fused SA chain, block body, pair-table pass fused / v1 / v2, eight-wave tail) must agree with the reference golden
+    kernels (fused SA chain, block body, pair-table pass fused / v1 / v2, eight-wave tail, per-point layer chains) must agree with the reference golden
     within the fp16 forward bound (5e-3 of the output's L2 norm, as test_denoiser_forward_fp16_mfma) AND with each other
     within 4e-3 (measured <= 2e-3: different summation orders of fp16-rounded terms)."""
     from slide_amd.engine import DenoiserEngine
@@ -481,7 +482,8 @@ def test_pair_decomposition_plan_variants(gpu_device, monkeypatch):
         for tag, knobs in (("round2", {"SLIDE_GX": "0"}), ("default", {}), ("no_body", {"SLIDE_BODY": "0"}),
                            ("no_body_no_chain", {"SLIDE_BODY": "0", "SLIDE_SA_CHAIN": "0"}),
                            ("pair_norm_v2", {"SLIDE_PAIR_NORM_V2": "1"}), ("tail8", {"SLIDE_TAIL8": "1", "SLIDE_BODY": "0"}),
-                           ("two_launch_tables", {"SLIDE_PAIR_FUSED": "0"})):
+                           ("two_launch_tables", {"SLIDE_PAIR_FUSED": "0"}), ("gemm_chains", {"SLIDE_GEMM_CHAIN": "256"}),
+                           ("long_gemm_chains", {"SLIDE_GEMM_CHAIN": "100000"})):
             for k_, v_ in knobs.items():
                 monkeypatch.setenv(k_, v_)
             e = DenoiserEngine(hp, sd, x.shape[0], gpu_device, prec="fp16")
@@ -492,6 +494,7 @@ def test_pair_decomposition_plan_variants(gpu_device, monkeypatch):
                 assert 18 in kinds and 31 not in kinds  # SLIDE_OP_PAIR_NORM after a 16-row GEMM
             else:
                 assert 31 in kinds and 18 not in kinds  # SLIDE_OP_PAIR_FIRST: GEMM + table pass in one launch
+            assert (32 in kinds) == ("gemm_chain" in tag)  # SLIDE_OP_GEMM_CHAIN (opt-in): per-point layer chains, one launch each
             outs[tag] = e.forward(x, ts, lab).cpu().numpy().astype(np.float64)
             for k_ in knobs:
                 monkeypatch.delenv(k_)
