@@ -831,10 +831,10 @@ __device__ __forceinline__ float other_half(float x) {  // value of lane ^ 32
 #ifndef SLIDE_ATTN_NST
 #define SLIDE_ATTN_NST 3  // ring stages of the fused attention tail
 #endif
-template <int NPXL>
-__global__ __launch_bounds__(256, 2) void attn_tail_kernel(AttnTailArgs a) {
+template <int NPXL, int NST>
+__device__ __forceinline__ void attn_tail_body(const AttnTailArgs &a) {
   using T = _Float16;
-  constexpr int CBW = 2, NST = SLIDE_ATTN_NST, RT = TM + 64, STAGE_B = RT * 64, LPW = RT / 16 / 4;
+  constexpr int CBW = 2, RT = TM + 64, STAGE_B = RT * 64, LPW = RT / 16 / 4;
   constexpr int KLOG = NPXL - 4, KN = 1 << KLOG, GPB = 32 / KN;  // neighbours per point, points per 32-row block
   constexpr int WPS = (1 << NPXL) / 64;                            // waves per sample
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1009,6 +1009,17 @@ __global__ __launch_bounds__(256, 2) void attn_tail_kernel(AttnTailArgs a) {
         }
       }
   }
+}
+
+template <int NPXL>
+__global__ __launch_bounds__(256, 2) void attn_tail_kernel(AttnTailArgs a) {
+  attn_tail_body<NPXL, SLIDE_ATTN_NST>(a);
+}
+
+// the same tile on a TWO-stage ring (41 KB) inside the 168-register budget: three workgroups per CU instead of two
+template <int NPXL>
+__global__ __launch_bounds__(256, 3) void attn_tail_occ3_kernel(AttnTailArgs a) {
+  attn_tail_body<NPXL, 2>(a);
 }
 
 // Eight-wave form of the fused attention tail (round 3): tile 256 rows x 128 channels -- wave (wr, wc) owns rows 64 wr .. and the
@@ -1986,9 +1997,16 @@ int run_attn_tail(const SlideOp &o, hipStream_t s) {
     else hipLaunchKernelGGL(attn_tail8_kernel<7>, dim3(grid8), dim3(512), shm8, s, a);
     return (int)hipGetLastError();
   }
-  const size_t shm = (size_t)SLIDE_ATTN_NST * (TM + 64) * 64 + 4 * 2 * 32 * 4 + 64;
   const int ntc = (a.n_cob + 1) / 2, ntr = (a.rows + TM - 1) / TM;
   const int grid = ((ntr + 7) / 8) * 8 * ntc;
+  static const int tail_occ3 = [] { const char *e = getenv("SLIDE_TAIL_OCC3"); return e ? atoi(e) : 0; }();
+  if (tail_occ3 && (npxl == 7 || npxl == 8)) {
+    const size_t shm3 = (size_t)2 * (TM + 64) * 64 + 4 * 2 * 32 * 4 + 64;
+    if (npxl == 8) hipLaunchKernelGGL(attn_tail_occ3_kernel<8>, dim3(grid), dim3(256), shm3, s, a);
+    else hipLaunchKernelGGL(attn_tail_occ3_kernel<7>, dim3(grid), dim3(256), shm3, s, a);
+    return (int)hipGetLastError();
+  }
+  const size_t shm = (size_t)SLIDE_ATTN_NST * (TM + 64) * 64 + 4 * 2 * 32 * 4 + 64;
   static bool attr_done[SLIDE_MAX_DEVICES] = {};
   bool &attr_set = attr_done[current_device_slot()];
   if (!attr_set) {

@@ -295,22 +295,22 @@ __global__ __launch_bounds__(256) void group_points_v4_kernel(int c, int n, int 
   }
 }
 
-// Row-in-LDS gather (group_points, and gather_points = the ns == 1 case): a block owns QPT*1024 consecutive output slots
+// Row-in-LDS gather (group_points, and gather_points = the ns == 1 case): a block owns QPT*NT*4 consecutive output slots
 // of one batch element -- their indices stay in registers -- and walks a chunk of channels.  Per channel the n-float point
 // row is staged in LDS with coalesced 16-byte loads (read from L2 once per block instead of 4 bytes per gathered element),
 // gathered with ds_read_b32, and written with 16-byte non-temporal stores: the op then moves little more than its
 // output through HBM.  QPT = index quads per thread.
-template <int QPT>
-__global__ __launch_bounds__(256) void group_points_lds_kernel(int c, int n, int slots, int cchunk,
+template <int QPT, int NT = 256>
+__global__ __launch_bounds__(NT) void group_points_lds_kernel(int c, int n, int slots, int cchunk,
                                                                const float *__restrict__ points,
                                                                const int *__restrict__ idx, float *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float row[];
   const int b = blockIdx.z;
-  const int s0 = blockIdx.x * (QPT * 1024);
+  const int s0 = blockIdx.x * (QPT * NT * 4);
   pi4 ii[QPT];
 #pragma unroll
   for (int q = 0; q < QPT; ++q) {
-    const int s = s0 + (q * 256 + threadIdx.x) * 4;
+    const int s = s0 + (q * NT + threadIdx.x) * 4;
     ii[q] = s < slots ? *reinterpret_cast<const pi4 *>(idx + (size_t)b * slots + s) : pi4{0, 0, 0, 0};
   }
   const int l0 = blockIdx.y * cchunk, l1 = min(c, l0 + cchunk);
@@ -320,14 +320,14 @@ __global__ __launch_bounds__(256) void group_points_lds_kernel(int c, int n, int
     __syncthreads();  // the previous channel's gathers are done
     const float *pl = p + (size_t)l * n;
     if ((n & 3) == 0) {
-      for (int i = threadIdx.x * 4; i < n; i += 1024) *reinterpret_cast<pf4 *>(row + i) = *reinterpret_cast<const pf4 *>(pl + i);
+      for (int i = threadIdx.x * 4; i < n; i += NT * 4) *reinterpret_cast<pf4 *>(row + i) = *reinterpret_cast<const pf4 *>(pl + i);
     } else {
-      for (int i = threadIdx.x; i < n; i += 256) row[i] = pl[i];
+      for (int i = threadIdx.x; i < n; i += NT) row[i] = pl[i];
     }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < QPT; ++q) {
-      const int s = s0 + (q * 256 + threadIdx.x) * 4;
+      const int s = s0 + (q * NT + threadIdx.x) * 4;
       if (s < slots) {
         const pf4 v = {row[ii[q][0]], row[ii[q][1]], row[ii[q][2]], row[ii[q][3]]};
         __builtin_nontemporal_store(v, reinterpret_cast<pf4 *>(o + (size_t)l * slots + s));
@@ -673,8 +673,14 @@ int slide_hip_device_ok(void) {
 static inline int pick_cchunk(int c, int blocks_other);
 static int launch_group_lds(int b, int c, int n, int slots, const float *points, const int *idx, float *out,
                             hipStream_t stream) {
-  const int qpt = slots >= 4096 ? 4 : (slots >= 2048 ? 2 : 1);
-  const int gx = (slots + qpt * 1024 - 1) / (qpt * 1024);
+  // index quads per thread: a block's tile of QPT*1024 slots shares one staged n-float row, so long rows want large tiles
+  // (the staging traffic is n / tile of the output: 2x the output at n = 8192 with QPT = 4); past 16 quads the index
+  // registers cost occupancy, so the longest rows run 512-thread blocks instead (tile = 32768 slots)
+  int qpt = slots >= 4096 ? 4 : (slots >= 2048 ? 2 : 1);
+  while (qpt < 16 && qpt * 1024 < 4 * n && slots >= qpt * 2048) qpt *= 2;
+  const bool wide = qpt == 16 && n >= 8192 && slots >= 65536;
+  const int tile = qpt * (wide ? 2048 : 1024);
+  const int gx = (slots + tile - 1) / tile;
   int chunks = (1024 + gx * b - 1) / (gx * b);  // >= 4 blocks per CU overall; long channel walks amortise the index reads
   chunks = chunks < 1 ? 1 : (chunks > c ? c : chunks);
   const int cchunk = (c + chunks - 1) / chunks;
@@ -682,7 +688,9 @@ static int launch_group_lds(int b, int c, int n, int slots, const float *points,
   const size_t shm = (size_t)((n + 3) & ~3) * 4;
 #define GL(Q)                                                                                                        \
   hipLaunchKernelGGL((group_points_lds_kernel<Q>), grid, dim3(256), shm, stream, c, n, slots, cchunk, points, idx, out)
-  if (qpt == 4) GL(4); else if (qpt == 2) GL(2); else GL(1);
+  if (wide)
+    hipLaunchKernelGGL((group_points_lds_kernel<16, 512>), grid, dim3(512), shm, stream, c, n, slots, cchunk, points, idx, out);
+  else if (qpt == 16) GL(16); else if (qpt == 8) GL(8); else if (qpt == 4) GL(4); else if (qpt == 2) GL(2); else GL(1);
 #undef GL
   return LAUNCH_STATUS();
 }
@@ -802,6 +810,51 @@ int group_points_grad_kernel_wrapper(int b, int c, int n, int npoints, int nsamp
   return LAUNCH_STATUS();
 }
 
+// three_interpolate for n = 256 / 512 / 1024 outputs per row: the block's 256 threads cover R = 1024 / n channel rows at a
+// time (one output quad per thread), each row's m known features staged in LDS -- the scattered 4-byte reads then hit
+// LDS instead of the vector cache (12 gathers per 16 bytes stored).  Indices / weights of the thread's quad stay in registers
+// over the block's channel chunk.
+__global__ __launch_bounds__(256) void three_interpolate_rows_kernel(int c, int m, int n, int cchunk, int mp,
+                                                                     const float *__restrict__ points,
+                                                                     const int *__restrict__ idx,
+                                                                     const float *__restrict__ weight,
+                                                                     float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float row[];
+  const int b = blockIdx.z;
+  const int qn = n >> 2, R = 256 / qn;            // quads per row, rows per pass
+  const int r = threadIdx.x / qn, j = (threadIdx.x - r * qn) * 4;
+  const pi4 *id = reinterpret_cast<const pi4 *>(idx + ((size_t)b * n + j) * 3);
+  const pf4 *w = reinterpret_cast<const pf4 *>(weight + ((size_t)b * n + j) * 3);
+  const pi4 ia = id[0], ib = id[1], ic = id[2];
+  const pf4 wa = w[0], wb = w[1], wc = w[2];
+  const int l0 = blockIdx.y * cchunk, l1 = min(c, l0 + cchunk);
+  const float *p = points + (size_t)b * c * m;
+  float *o = out + (size_t)b * c * n;
+  const float *rw = row + r * mp;
+  for (int l = l0; l < l1; l += R) {
+    __syncthreads();
+    const int nr = min(R, l1 - l);               // rows l .. l + nr - 1 are consecutive in memory: one flat copy
+    const float *pl = p + (size_t)l * m;
+    if ((m & 3) == 0) {
+      for (int i = threadIdx.x * 4; i < nr * m; i += 1024) {
+        const int rr = i / m, k = i - rr * m;
+        *reinterpret_cast<pf4 *>(row + rr * mp + k) = *reinterpret_cast<const pf4 *>(pl + i);
+      }
+    } else {
+      for (int i = threadIdx.x; i < nr * m; i += 256) row[(i / m) * mp + i % m] = pl[i];
+    }
+    __syncthreads();
+    if (r < nr) {
+      pf4 v;
+      v[0] = fmaf(rw[ia[2]], wa[2], fmaf(rw[ia[1]], wa[1], rw[ia[0]] * wa[0]));
+      v[1] = fmaf(rw[ib[1]], wb[1], fmaf(rw[ib[0]], wb[0], rw[ia[3]] * wa[3]));
+      v[2] = fmaf(rw[ic[0]], wc[0], fmaf(rw[ib[3]], wb[3], rw[ib[2]] * wb[2]));
+      v[3] = fmaf(rw[ic[3]], wc[3], fmaf(rw[ic[2]], wc[2], rw[ic[1]] * wc[1]));
+      __builtin_nontemporal_store(v, reinterpret_cast<pf4 *>(o + (size_t)(l + r) * n + j));
+    }
+  }
+}
+
 int three_nn_kernel_wrapper(int b, int n, int m, const float *unknown, const float *known, float *dist2,
                             int *idx, slide_stream_t stream) {
   if (b <= 0 || n <= 0) return 0;
@@ -821,6 +874,18 @@ int three_interpolate_kernel_wrapper(int b, int c, int m, int n, const float *po
     const int cchunk = (c + chunks - 1) / chunks;
     hipLaunchKernelGGL(three_interpolate_lds_kernel, dim3(gx, (c + cchunk - 1) / cchunk, b), dim3(256),
                        (size_t)((m + 3) & ~3) * 4, (hipStream_t)stream, c, m, n, cchunk, points, idx, weight, out);
+    return LAUNCH_STATUS();
+  }
+  if ((n == 256 || n == 512 || n == 1024) && (((uintptr_t)idx | (uintptr_t)weight | (uintptr_t)out | (uintptr_t)points) & 15) == 0 &&
+      m <= 8192) {
+    const int R = 1024 / n;
+    int chunks = (1024 + b - 1) / b;  // >= 4 blocks per CU overall
+    chunks = chunks < 1 ? 1 : (chunks > (c + R - 1) / R ? (c + R - 1) / R : chunks);
+    int cchunk = (c + chunks - 1) / chunks;
+    cchunk = (cchunk + R - 1) / R * R;   // whole passes
+    const int mp = ((m + 3) & ~3) + 4;   // row pitch (floats)
+    hipLaunchKernelGGL(three_interpolate_rows_kernel, dim3(1, (c + cchunk - 1) / cchunk, b), dim3(256), (size_t)R * mp * 4,
+                       (hipStream_t)stream, c, m, n, cchunk, mp, points, idx, weight, out);
     return LAUNCH_STATUS();
   }
   if (n % 4 == 0 && (((uintptr_t)idx | (uintptr_t)weight | (uintptr_t)out) & 15) == 0) {

@@ -72,15 +72,18 @@ def test_gather_group_interpolate(gpu_device):
         G = rs.standard_normal((B, C, m)).astype(np.float32)
         assert np.allclose(N(_ext.gather_points_grad(T(G, gpu_device), T(idx, gpu_device), n)),
                            O.gather_points_grad(G, idx, n), atol=1e-4)
+    # (the last two: long rows -> 8 / 16 index quads per thread in the row-in-LDS kernel)
     for (B, C, n, npnt, ns) in [(4, 51, 16, 16, 16), (2, 256, 16, 16, 16), (2, 64, 256, 128, 32), (1, 128, 1024, 256, 32),
-                                (2, 3, 7, 5, 3)]:
+                                (2, 3, 7, 5, 3), (1, 5, 4096, 256, 32), (2, 3, 8192, 512, 32)]:
         pts = rs.standard_normal((B, C, n)).astype(np.float32)
         idx = rs.randint(0, n, (B, npnt, ns)).astype(np.int32)
         assert np.array_equal(N(_ext.group_points(T(pts, gpu_device), T(idx, gpu_device))), O.group_points(pts, idx))
         G = rs.standard_normal((B, C, npnt, ns)).astype(np.float32)
         assert np.allclose(N(_ext.group_points_grad(T(G, gpu_device), T(idx, gpu_device), n)),
                            O.group_points_grad(G, idx, n), atol=1e-3)
-    for (B, C, m, n) in [(2, 64, 100, 300), (1, 7, 3, 5), (2, 128, 256, 1024)]:
+    # (n = 256 / 512 / 1024: the rows-in-LDS kernel, 4 / 2 / 1 channel rows per pass, ragged channel counts and row lengths)
+    for (B, C, m, n) in [(2, 64, 100, 300), (1, 7, 3, 5), (2, 128, 256, 1024), (3, 37, 128, 256), (2, 10, 101, 512),
+                         (2, 3, 64, 1024)]:
         pts = rs.standard_normal((B, C, m)).astype(np.float32)
         idx = rs.randint(0, m, (B, n, 3)).astype(np.int32)
         w = rs.uniform(0, 1, (B, n, 3)).astype(np.float32)
