@@ -340,7 +340,11 @@ __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem
       if (AFF) {
         const f16x8 sc = *reinterpret_cast<const f16x8 *>(aff_w + kc * BKT + piece * 8);
         const f16x8 sh = *reinterpret_cast<const f16x8 *>(aff_w + a.k_pad + kc * BKT + piece * 8);
-        // packed fp16 fma (v_pk_fma_f16, one rounding like the fp32-then-convert form it replaces, 1/6 of the VALU ops)
+        // packed fp16 fma (v_pk_fma_f16, one rounding like the fp32-then-convert form it replaces, 1/6 of the VALU ops).
+        // scale / shift / add are fp16 copies of the fp32 vectors (2^-11 relative each): against normalising in fp32 and
+        // storing the fp16 result (SLIDE_MODULE_DEFER=0) the GEMM output moves by <= 3e-3 of its L2 norm at |shift| ~ 6 and
+        // |add| ~ 50 (tests/test_hip_modules.py::test_deferred_normalisation_matches_the_materialised_path); values beyond
+        // fp16's range (65504) do not occur: scale = gamma * rstd <= gamma / sqrt(eps), shift and add are O(activations)
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) bf[rb] = __builtin_elementwise_fma(bf[rb], sc, sh);
         if (aff_relu) {  // deferred GroupNorm + ReLU + embedding add of the producing layer (module-level path)

@@ -65,6 +65,11 @@ class _GemmPlan:
         return self.y[:, : self.O]
 
 
+def _bias_key(bias):
+    """plan-cache key part: a packed plan snapshots the bias too (an in-place bias update alone must re-pack)"""
+    return None if bias is None else (bias._version, bias.data_ptr())
+
+
 class HipConv1x1(nn.Module):
     """nn.Conv2d / nn.Conv1d with kernel size 1 (same parameter names and shapes), forward on the HIP GEMM."""
 
@@ -82,7 +87,7 @@ class HipConv1x1(nn.Module):
         B, C = x.shape[:2]
         sp = x.shape[2:]
         rows = B * int(np.prod(sp)) if len(sp) else B
-        key = (rows, self.weight._version, self.weight.data_ptr())
+        key = (rows, self.weight._version, self.weight.data_ptr(), _bias_key(self.bias), x.device.index)
         if key not in self._plans:
             self._plans = {key: _GemmPlan(self.weight, self.bias, rows, x.device)}
         plan = self._plans[key]
@@ -114,7 +119,7 @@ class HipLinear(nn.Module):
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("CPU not supported")
-        key = (x.shape[0], self.weight._version, self.weight.data_ptr())
+        key = (x.shape[0], self.weight._version, self.weight.data_ptr(), _bias_key(self.bias), x.device.index)
         if key not in self._plans:
             self._plans = {key: _GemmPlan(self.weight, self.bias, x.shape[0], x.device)}
         return self._plans[key](x).clone()

@@ -148,7 +148,7 @@ class _ConvPlan:
         self.epis = {}  # output pointer -> device epilogue table (the caching allocator recycles a handful of addresses)
 
     def epi(self, out, stats=None, pre_relu=False):
-        key = (out.data_ptr(), None if stats is None else (stats[0].data_ptr(), stats[1].data_ptr()), pre_relu)
+        key = (out.device.index, out.data_ptr(), None if stats is None else (stats[0].data_ptr(), stats[1].data_ptr()), pre_relu)
         e = self.epis.get(key)
         if e is None:
             if len(self.epis) >= 16:
@@ -225,8 +225,11 @@ def conv(x, module, stats=None):
     A deferred normalisation of x is applied by the GEMM itself when its tiles do not straddle samples."""
     if x.pending is not None and not (x.half and x.S % 256 == 0):
         materialise(x)
-    w = module.weight
-    key = (w._version, w.data_ptr(), x.half)
+    w, bias = module.weight, module.bias
+    dev = x.data.device
+    # (the packed weights, bias vector and epilogue tables live on ONE device and snapshot BOTH parameters: the key carries the
+    #  bias' version / storage and the device as well -- ADVICE r2)
+    key = (w._version, w.data_ptr(), None if bias is None else (bias._version, bias.data_ptr()), x.half, dev.type, dev.index)
     plan = module.__dict__.get("_rows_plan")
     if plan is None or plan[0] != key:
         plan = (key, _ConvPlan(w, module.bias, x.half, x.data.device))

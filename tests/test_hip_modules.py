@@ -342,3 +342,70 @@ def test_empty_batch_flows_through_the_modules(gpu_device):
                                            attention_setting=att), d)
     out = fp(torch.zeros(0, 20, 3, device=d), nx, torch.zeros(0, 5, 20, device=d), nf)
     assert out.shape == (0, 16, 20)
+
+
+def test_rows_conv_plan_follows_bias_updates(gpu_device):
+    """The row-major path packs a convolution's weight AND bias once per parameter version (rows.conv's plan cache): an
+    in-place update of the bias alone (an optimiser step, an EMA copy_) must re-pack -- the key carries the bias' version
+    and storage and the device."""
+    from pointnet2_ops import pointnet2_modules as PM
+    from slide_amd import rows as R
+    d = gpu_device
+    conv = PM.HipConv1x1(40, 24, bias=True).to(d)
+    x = torch.randn(2, 40, 64, 1, device=d)
+    want = lambda: torch.nn.functional.conv2d(x, conv.weight, conv.bias)
+    y0 = R.to_ncx(R.conv(R.from_ncx(x, half=False), conv), spatial=(64, 1))
+    assert torch.allclose(y0, want(), atol=1e-4, rtol=1e-4)
+    with torch.no_grad():
+        conv.bias.add_(3.0)
+    y1 = R.to_ncx(R.conv(R.from_ncx(x, half=False), conv), spatial=(64, 1))
+    assert torch.allclose(y1, want(), atol=1e-4, rtol=1e-4) and float((y1 - y0).mean()) > 2.9
+    with torch.no_grad():
+        conv.weight.mul_(0.5)
+    y2 = R.to_ncx(R.conv(R.from_ncx(x, half=False), conv), spatial=(64, 1))
+    assert torch.allclose(y2, want(), atol=1e-4, rtol=1e-4)
+    # the NCHW tensor-program path (HipConv1x1.forward / HipLinear.forward) caches a packed plan the same way
+    with torch.no_grad():
+        conv.bias.sub_(1.5)
+    assert torch.allclose(conv(x), want(), atol=1e-4, rtol=1e-4)
+    lin = PM.HipLinear(12, 20).to(d)
+    z = torch.randn(5, 12, device=d)
+    a0 = lin(z).clone()
+    with torch.no_grad():
+        lin.bias.add_(2.0)
+    assert torch.allclose(lin(z), torch.nn.functional.linear(z, lin.weight, lin.bias), atol=1e-4, rtol=1e-4)
+    assert float((lin(z) - a0).mean()) > 1.9
+
+
+def test_deferred_normalisation_matches_the_materialised_path(gpu_device, monkeypatch):
+    """fp16 module path: a GroupNorm whose consumer is a GEMM is DEFERRED -- the producer's raw output stays in memory and the
+    consumer's loader applies relu(x * scale + shift) + add from per-sample fp16 vectors in LDS (csrc/engine.hip, AFF
+    loaders) -- where SLIDE_MODULE_DEFER=0 normalises in fp32 arithmetic first and stores the fp16 result.  The two differ by
+    the fp16 rounding of scale / shift / add (2^-11 relative each) and of the affine's result: bounded here on activations
+    with a large mean (|shift| = mean * rstd ~ 6) and large embedding rows (|add| up to 50), where that rounding is at its
+    worst: <= 3e-3 of the output's L2 norm, and both within 6e-3 of the fp32 arithmetic."""
+    from pointnet2_ops import pointnet2_modules as PM
+    from slide_amd import rows as R
+    monkeypatch.setenv("SLIDE_MODULE_PREC", "fp16")
+    d = gpu_device
+    gen = torch.Generator().manual_seed(3)
+    B, S, C, O_ = 3, 512, 64, 96
+    x = (torch.randn(B, C, S, 1, generator=gen) * 5 + 30).to(d)
+    add = (torch.rand(B, C, generator=gen) * 100 - 50).to(d)
+    gn = PM.HipGroupNorm(8, C).to(d)
+    conv = PM.HipConv1x1(C, O_, bias=True).to(d)
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 2.0, generator=None); gn.bias.uniform_(-1, 1)
+    outs = {}
+    for defer in ("1", "0"):
+        monkeypatch.setenv("SLIDE_MODULE_DEFER", defer)
+        r = R.from_ncx(x)
+        assert r.half
+        r = R.norm_act(r, gn=gn, relu=True, addvec=add, defer=True)
+        assert (r.pending is not None) == (defer == "1")
+        outs[defer] = R.to_ncx(R.conv(r, conv), spatial=(S, 1)).double()
+    h = torch.nn.functional.group_norm(x.double(), 8, gn.weight.double(), gn.bias.double(), 1e-5).relu() + add.double()[:, :, None, None]
+    ref = torch.nn.functional.conv2d(h, conv.weight.double(), conv.bias.double())
+    rel = lambda a, b: float(((a - b).norm() / b.norm()).detach())
+    assert rel(outs["1"], outs["0"]) <= 3e-3, rel(outs["1"], outs["0"])
+    assert rel(outs["1"], ref) <= 6e-3 and rel(outs["0"], ref) <= 6e-3, (rel(outs["1"], ref), rel(outs["0"], ref))
