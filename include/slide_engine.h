@@ -85,7 +85,7 @@ enum {
   SLIDE_OP_ADVANCE_T = 12,  /* p: t_dev  (t_dev[0] -= 1; t_dev[1] += 1); t_dev = [t, step, blocks-done counter, chain nonce, global index of the first sample, 3 spare] (8 ints) */
   SLIDE_OP_SYNC = 14,       /* i: from_lane, to_lane -- lane `to` waits for everything issued so far on lane `from` */
   SLIDE_OP_GROUPNORM_NCHW = 13,/* p: x, gamma, beta, y (NCHW fp32)   i: B, C, HW, G, n_norm, relu  (module-level path) */
-  SLIDE_OP_ATTN_TAIL = 16,  /* fp16: scores GEMM + values GEMM (GroupNorm, ReLU) + softmax-weighted sum over the neighbours in one launch.  p: u, W5, mo, Wv, out, vec [bias_s | bias_v | gamma | beta][n_cob*32], [6] optional chunk-major copy of out [c/32][points][32] (a gather table of the next block: SLIDE_OP_GEMM f[2] == 32 reads p[8] that way), [7] optional copy of the first f[3] channels into another per-point buffer with leading dimension f[2]   i: rows, u_ld, k1, mo_ld, k2, n_cob, npx_log2, gs, n_norm, out_ld   f: 1 / (gs * rows per sample), [1] != 0: both weight matrices chunk-major [k/32][n_cob*32][32]; u / mo are chunk-major [k/32][rows][32] when their ld is 32 */
+  SLIDE_OP_ATTN_TAIL = 16,  /* fp16: scores GEMM + values GEMM (GroupNorm, ReLU) + softmax-weighted sum over the neighbours in one launch.  p: u, W5, mo, Wv, out, vec [bias_s | bias_v | gamma | beta][n_cob*32], [6] optional chunk-major copy of out [c/32][points][32] (a gather table of the next block: SLIDE_OP_GEMM f[2] == 32 reads p[8] that way), [7] optional copy of the first f[3] channels into another per-point buffer with leading dimension f[2]   i: rows, u_ld, k1, mo_ld, k2, n_cob, npx_log2, gs, n_norm, out_ld   f: 1 / (gs * rows per sample), [1] bit 0: both weight matrices chunk-major [k/32][n_cob*32][32] (u / mo are chunk-major [k/32][rows][32] when their ld is 32), bit 1: the two-stage-ring form at three workgroups per CU */
   SLIDE_OP_GEMM_GX = 17,    /* fp16 "generated-X" GEMM of the pair decomposition (gemm_gx.hip): the first layer of an SA / FP
                              * block is linear in [neighbour features | coordinates], so its output for row (point p, slot j) is ta[q] + tb[p]
                              * (q = the slot's neighbour) -- the 256- / 128-row activation this GEMM consumes is never stored: a workgroup keeps
@@ -97,7 +97,8 @@ enum {
                              * p: [0] ta, [1] W chunk-major [k_pad/32][n_cob*32][32], [2] epi, [3] scale, [4] shift (fp32 [b*in_bs + k], mode 1),
                              *    [5] tb, [6] add vectors fp32 [idx*add_idx_stride + b*add_bs + k] or NULL (mode 0), [7] idx (device int) or NULL,
                              *    [8] nbr table, [9] d2, [10] w (fp32 [B*16][16]; npx_log2 7), [11] vd | vw fp32 [b*vbs + {0, vbs/2} + k] (SLIDE_OP_PAIR_NORM's vv, column offset applied) or NULL
-                             * i: rows, t_ld (elements between table rows), k_pad, n_cob, npx_log2, in_bs, mode, add_bs, add_idx_stride, vbs */
+                             * i: rows, t_ld (elements between table rows), k_pad, n_cob, npx_log2, in_bs, mode, add_bs, add_idx_stride, vbs
+                             * f: [0] != 0 (mode 1): 256 x 64 tiles at three workgroups per CU when their LDS fits, else 256 x 128 tiles */
   SLIDE_OP_PAIR_NORM = 18,  /* per-point tables of the pair decomposition: a[q][c] = y[q][c] + wa[c] . xyz[q], b[p][c] = wb[c] . xyz[p]; for each
                              * 32-channel block by its SlideEpi (mode, gs, n_norm, inv_count, gamma, beta, stats_*; bias already in y):
                              *   NORM : GroupNorm statistics over the sample's (p, slot) pairs of a[q] + b[p] (+ d2 vd + w vw), folded into the

@@ -1978,7 +1978,7 @@ int run_attn_tail(const SlideOp &o, hipStream_t s) {
   a.rows = o.i[0]; a.x1_ld = o.i[1]; a.k1 = o.i[2]; a.x2_ld = o.i[3]; a.k2 = o.i[4]; a.n_cob = o.i[5];
   a.gs = o.i[7]; a.n_norm = o.i[8]; a.out_ld = o.i[9];
   a.inv_count = o.f[0];
-  a.w_cm = o.f[1] != 0.f;
+  a.w_cm = ((int)o.f[1] & 1) != 0;
   static const int tail_abl = [] { const char *e = getenv("SLIDE_TAIL_ABL"); return e ? atoi(e) : 0; }();
   a.abl = tail_abl;
   const int npxl = o.i[6];
@@ -2003,7 +2003,7 @@ int run_attn_tail(const SlideOp &o, hipStream_t s) {
   }
   const int ntc = (a.n_cob + 1) / 2, ntr = (a.rows + TM - 1) / TM;
   const int grid = ((ntr + 7) / 8) * 8 * ntc;
-  static const int tail_occ3 = [] { const char *e = getenv("SLIDE_TAIL_OCC3"); return e ? atoi(e) : 0; }();
+  const bool tail_occ3 = ((int)o.f[1] & 2) != 0;  // (plan knob SLIDE_TAIL_OCC3: two-stage ring, three workgroups per CU)
   if (tail_occ3 && (npxl == 7 || npxl == 8)) {
     const size_t shm3 = (size_t)2 * (TM + 64) * 64 + 4 * 2 * 32 * 4 + 64;
     if (npxl == 8) hipLaunchKernelGGL(attn_tail_occ3_kernel<8>, dim3(grid), dim3(256), shm3, s, a);

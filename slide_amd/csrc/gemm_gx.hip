@@ -34,15 +34,15 @@ constexpr int SLIDE_MAX_DEVICES = 64;
 // rows, vectors) are issued before the B fragments of step s are generated and its 8 MFMAs issued, so the reads' latency and
 // the packed-fp16 generation of the next fragments run under the matrix pipe's 256 busy cycles; the ring's wait + barrier of
 // the next stage sits one step early for the same reason.
-template <int NPXL, int NST, int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_gx_kernel(GemmArgs a) {
+template <int NPXL, int NST, int MODE, int CBW>
+__device__ __forceinline__ void gemm_gx_body(const GemmArgs &a) {
   using T = _Float16;
-  constexpr int CBW = 4;
   constexpr int NPX = 1 << NPXL;
   constexpr bool FP = NPXL == 7;
   constexpr int NSAMP = TM >> NPXL;            // 1 or 2
   constexpr int NR = 16 * NSAMP;               // table rows in LDS
-  constexpr int CH_B = 128 * 64, STAGE_B = 2 * CH_B;
+  constexpr int CH_B = 32 * CBW * 64, STAGE_B = 2 * CH_B;  // a chunk image: [32 CBW weight rows][64 B]
+  constexpr int NJ = CBW / 2;                              // DMA instructions per wave and chunk image (16 rows each)
   constexpr int NVEC = (MODE ? 2 : 1) + (FP ? 2 : 0);  // fp16 vectors per sample in LDS: [add | scale, shift][vd, vw][k_pad]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int ntc = (a.n_cob + CBW - 1) / CBW;
@@ -134,9 +134,9 @@ __global__ __launch_bounds__(256, 2) void gemm_gx_kernel(GemmArgs a) {
     }
   }
   // ---- weight ring: this lane's source piece of the wave's two DMA instructions per 32-deep chunk
-  const T *wsrc[2];
+  const T *wsrc[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int trow = 16 * (j * 4 + wave) + (lane >> 2);
     const int piece = (lane & 3) ^ ((trow >> 2) & 3);
     int gco = cob0 * 32 + trow;
@@ -144,14 +144,14 @@ __global__ __launch_bounds__(256, 2) void gemm_gx_kernel(GemmArgs a) {
     wsrc[j] = reinterpret_cast<const T *>(a.W) + (size_t)gco * 32 + piece * 8;
   }
   const size_t w_cs = (size_t)a.n_cob * 32 * 32;  // elements between consecutive chunks
-  auto issue = [&](int st) __attribute__((always_inline)) {  // stage st -> slot st % NST (4 DMA instructions per wave)
+  auto issue = [&](int st) __attribute__((always_inline)) {  // stage st -> slot st % NST (2 NJ DMA instructions per wave)
     unsigned char *dst = ring + (size_t)(st % NST) * STAGE_B;
 #pragma unroll
     for (int c2 = 0; c2 < 2; ++c2) {
       int kc = st * 2 + c2;
       kc = kc < nk32 ? kc : nk32 - 1;  // odd chunk count: the last stage's second image is a dummy (never read)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
         __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(wsrc[j] + (size_t)kc * w_cs),
                                          (__attribute__((address_space(3))) void *)(dst + c2 * CH_B + (j * 4 + wave) * 1024),
                                          16, 0, 0);
@@ -226,9 +226,9 @@ __global__ __launch_bounds__(256, 2) void gemm_gx_kernel(GemmArgs a) {
       for (int rb = 0; rb < 2; ++rb)
         acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.af[cb], bf[rb], acc[cb][rb], 0, 0, 0);
   };
-  // stage st must have landed before anyone reads it; the next one (4 instructions per wave) may stay in flight
+  // stage st must have landed before anyone reads it; the next one (2 NJ instructions per wave) may stay in flight
   auto stage_ready = [&](int st) __attribute__((always_inline)) {
-    if (st + 1 < nks && NST > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (st + 1 < nks && NST > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJ) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // (first pass: also publishes the tables and vectors staged above)
     if (st + NST - 1 < nks) issue(st + NST - 1);  // overwrites the stage consumed at st - 1
@@ -269,6 +269,19 @@ __global__ __launch_bounds__(256, 2) void gemm_gx_kernel(GemmArgs a) {
     SLIDE_STAMP(a, 6);
   }
 #endif
+}
+
+template <int NPXL, int NST, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_gx_kernel(GemmArgs a) {
+  gemm_gx_body<NPXL, NST, MODE, 4>(a);
+}
+
+// 256 x 64 tiles inside the 168-register budget (64 accumulator registers, 8 KB ring stages): THREE workgroups per CU and
+// twice the workgroups per launch -- the K loops of these layers are short (K = 64 .. 544) and each workgroup spends most of
+// its life in the table prologue and the epilogue, which a third resident workgroup overlaps
+template <int NPXL, int NST, int MODE>
+__global__ __launch_bounds__(256, 3) void gemm_gx_n64_kernel(GemmArgs a) {
+  gemm_gx_body<NPXL, NST, MODE, 2>(a);
 }
 
 // ------------------------------------------------------------------------------------------------ pair-table normalisation
@@ -495,26 +508,36 @@ __global__ __launch_bounds__(1024) void pair_norm2_kernel(int ld, const float *_
   }
 }
 
-template <int NPXL, int NST, int MODE>
+template <int NPXL, int NST, int MODE, int CBW = 4>
 int launch_gx(const GemmArgs &a, hipStream_t s) {
   constexpr int NSAMP = TM >> NPXL, NVEC = (MODE ? 2 : 1) + (NPXL == 7 ? 2 : 0);
-  const size_t shm = (size_t)NST * 16384 + (4 * EPI_DW + (4 * EPI_DW) % 4 + 4 * 96) * 4 +
+  const size_t shm = (size_t)NST * 4096 * CBW + (CBW * EPI_DW + (CBW * EPI_DW) % 4 + CBW * 96) * 4 +
                      (size_t)2 * NSAMP * 16 * a.k_pad * 2 + (size_t)NSAMP * NVEC * a.k_pad * 2 + 16;
-  if (shm > 160 * 1024) return -8;
-  const int ntc = (a.n_cob + 3) / 4, ntr = (a.rows + TM - 1) / TM;
+  if (shm > (CBW == 2 ? 53 : 160) * 1024) return -8;  // (the 64-channel form is only worth it with three workgroups per CU)
+  const int ntc = (a.n_cob + CBW - 1) / CBW, ntr = (a.rows + TM - 1) / TM;
   const int grid = ((ntr + 7) / 8) * 8 * ntc;
   static bool attr_done[SLIDE_MAX_DEVICES] = {};
   int d = 0;
   (void)hipGetDevice(&d);
   bool &attr_set = attr_done[d >= 0 && d < SLIDE_MAX_DEVICES ? d : 0];
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_gx_kernel<NPXL, NST, MODE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
   GemmArgs b = a;
   b.shm_bytes = (int)shm;
-  hipLaunchKernelGGL((gemm_gx_kernel<NPXL, NST, MODE>), dim3(grid), dim3(256), shm, s, b);
+  if constexpr (CBW == 2) {
+    // (red / gsh of the common epilogue live in the dead ring: 256 CBW + 128 CBW floats = 3 KB < the ring)
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_gx_n64_kernel<NPXL, NST, MODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_gx_n64_kernel<NPXL, NST, MODE>), dim3(grid), dim3(256), shm, s, b);
+  } else {
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_gx_kernel<NPXL, NST, MODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_gx_kernel<NPXL, NST, MODE>), dim3(grid), dim3(256), shm, s, b);
+  }
   return (int)hipGetLastError();
 }
 
@@ -538,9 +561,19 @@ int slide_launch_gemm_gx(const SlideOp &o, hipStream_t s) {
   if (a.gx_mode != 0 && ((uintptr_t)a.in_scale % 16 || (uintptr_t)a.in_shift % 16 || a.in_bs % 4)) return -3;
   if (a.gx_vv && ((uintptr_t)a.gx_vv % 16 || a.gx_vbs % 8)) return -3;
   const bool m1 = a.gx_mode != 0;
+  // f[0] != 0 (the plan's default, SLIDE_GX_N64): 256 x 64 tiles, three workgroups per CU (128-channel tiles when the LDS does
+  // not fit): measured 385 vs 374 shapes/s in bench.py's arrangement
+  const bool n64 = o.f[0] != 0.f;
+  if (npxl == 7 && (!a.gidx || !a.gx_d2 || !a.gx_w)) return -3;
+  // (mode 1 only -- the keys -> u layers: with mode 0's PAIR residual the epilogue does not fit 168 registers)
+  if (n64 && m1) {
+    int st = -8;
+    if (npxl == 8) st = launch_gx<8, 3, 1, 2>(a, s);
+    else if (npxl == 7) st = launch_gx<7, 3, 1, 2>(a, s);
+    if (st != -8) return st;
+  }
   if (npxl == 8) return m1 ? launch_gx<8, 3, 1>(a, s) : launch_gx<8, 3, 0>(a, s);
   if (npxl == 7) {
-    if (!a.gidx || !a.gx_d2 || !a.gx_w) return -3;
     int st = m1 ? launch_gx<7, 3, 1>(a, s) : launch_gx<7, 3, 0>(a, s);
     if (st == -8) st = m1 ? launch_gx<7, 2, 1>(a, s) : launch_gx<7, 2, 0>(a, s);
     return st;

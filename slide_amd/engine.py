@@ -460,10 +460,15 @@ class DenoiserEngine:
         add = gx.get("add")
         vv = gx.get("vv")
         assert (npx_log2 == 7) == (pair_tabs is not None)
-        self.kernel_names[len(self.ops)] = "gemm_gx_kernel<%d, 3, %d>" % (npx_log2, gx["mode"])
+        # (the launcher's choice, csrc/gemm_gx.hip: mode-1 layers run 256 x 64 tiles when three workgroups fit a CU's LDS)
+        nsamp, nvec = 256 >> npx_log2, (2 if gx["mode"] else 1) + (2 if npx_log2 == 7 else 0)
+        shm64 = 3 * 8192 + (2 * 40 + 2 * 96) * 4 + 2 * nsamp * 16 * ld * 2 + nsamp * nvec * ld * 2 + 16
+        n64 = gx["mode"] == 1 and os.environ.get("SLIDE_GX_N64", "1") != "0" and shm64 <= 53 * 1024
+        self.kernel_names[len(self.ops)] = "gemm_gx_%skernel<%d, 3, %d>" % ("n64_" if n64 else "", npx_log2, gx["mode"])
         self._emit(make_op(OP_GEMM_GX,
                            i=(rows, ta.shape[1], ld, n_cob, npx_log2, in_bs, gx["mode"], 0 if add is None else add[2],
                               0 if add is None else add[4], 0 if vv is None else 2 * vv.shape[2]),
+                           f=(1.0 if n64 else 0.0,),
                            p=(ta.data_ptr() + 2 * coff, Wd.data_ptr(), ed.data_ptr(),
                               None if sc is None else sc.data_ptr() + 4 * aff_off,
                               None if sh is None else sh.data_ptr() + 4 * aff_off,
@@ -1049,7 +1054,10 @@ class DenoiserEngine:
                 self._tail_of[out.data_ptr()] = len(self.ops)
                 self._emit(make_op(OP_ATTN_TAIL, i=(rows, self._ldp(u), u.shape[1], self._ldp(mo), mo.shape[1], Cp // 32, npx_log2,
                                                     vlay[3], vlay[2], out.shape[1]),
-                                        f=(1.0 / (vlay[4] * npx), 1.0 if self.use_cm else 0.0),
+                                        # f[1]: 1 = chunk-major operands, + 2 = two-stage ring at three workgroups per CU (opt-in,
+                                        # SLIDE_TAIL_OCC3=1: measured neutral, 373.0 vs 372.3 shapes/s)
+                                        f=(1.0 / (vlay[4] * npx), (1.0 if self.use_cm else 0.0) +
+                                           (2.0 if os.environ.get("SLIDE_TAIL_OCC3", "0") != "0" else 0.0)),
                                         p=(u.data_ptr(), d[0].data_ptr(), mo.data_ptr(), d[1].data_ptr(), out.data_ptr(),
                                            d[2].data_ptr(), None if out_cm is None else out_cm.data_ptr())))
                 return
