@@ -98,7 +98,8 @@ enum {
                              *    [5] tb, [6] add vectors fp32 [idx*add_idx_stride + b*add_bs + k] or NULL (mode 0), [7] idx (device int) or NULL,
                              *    [8] nbr table, [9] d2, [10] w (fp32 [B*16][16]; npx_log2 7), [11] vd | vw fp32 [b*vbs + {0, vbs/2} + k] (SLIDE_OP_PAIR_NORM's vv, column offset applied) or NULL
                              * i: rows, t_ld (elements between table rows), k_pad, n_cob, npx_log2, in_bs, mode, add_bs, add_idx_stride, vbs
-                             * f: [0] != 0 (mode 1): 256 x 64 tiles at three workgroups per CU when their LDS fits, else 256 x 128 tiles */
+                             * f: [0] = 1 (mode 1): 256 x 64 tiles at three workgroups per CU when their LDS fits; 2: 256 x 64 tiles at two per CU
+                             *    (launches whose 128-channel grid leaves CUs empty); else 256 x 128 tiles */
   SLIDE_OP_PAIR_NORM = 18,  /* per-point tables of the pair decomposition: a[q][c] = y[q][c] + wa[c] . xyz[q], b[p][c] = wb[c] . xyz[p]; for each
                              * 32-channel block by its SlideEpi (mode, gs, n_norm, inv_count, gamma, beta, stats_*; bias already in y):
                              *   NORM : GroupNorm statistics over the sample's (p, slot) pairs of a[q] + b[p] (+ d2 vd + w vw), folded into the

@@ -284,6 +284,14 @@ __global__ __launch_bounds__(256, 3) void gemm_gx_n64_kernel(GemmArgs a) {
   gemm_gx_body<NPXL, NST, MODE, 2>(a);
 }
 
+// the same 64-channel tile at two workgroups per CU (256 registers: also mode 0 with its PAIR residual): for launches whose
+// 128-channel grid does not cover the chip -- the FP blocks at 88 samples: 96 workgroups -- half-size tiles double the
+// workgroups in flight and halve each one's K loop and epilogue
+template <int NPXL, int NST, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_gx_n64w_kernel(GemmArgs a) {
+  gemm_gx_body<NPXL, NST, MODE, 2>(a);
+}
+
 // ------------------------------------------------------------------------------------------------ pair-table normalisation
 // One workgroup per (sample, 256-channel chunk), one channel per thread: the thread builds its channel's a[0..15] and
 // b[0..15] in registers / LDS, walks the sample's pairs for the statistics of its 32-channel block's mode, and writes the
@@ -508,12 +516,12 @@ __global__ __launch_bounds__(1024) void pair_norm2_kernel(int ld, const float *_
   }
 }
 
-template <int NPXL, int NST, int MODE, int CBW = 4>
+template <int NPXL, int NST, int MODE, int CBW = 4, bool OCC3 = true>
 int launch_gx(const GemmArgs &a, hipStream_t s) {
   constexpr int NSAMP = TM >> NPXL, NVEC = (MODE ? 2 : 1) + (NPXL == 7 ? 2 : 0);
   const size_t shm = (size_t)NST * 4096 * CBW + (CBW * EPI_DW + (CBW * EPI_DW) % 4 + CBW * 96) * 4 +
                      (size_t)2 * NSAMP * 16 * a.k_pad * 2 + (size_t)NSAMP * NVEC * a.k_pad * 2 + 16;
-  if (shm > (CBW == 2 ? 53 : 160) * 1024) return -8;  // (the 64-channel form is only worth it with three workgroups per CU)
+  if (shm > (CBW == 2 && OCC3 ? 53 : 160) * 1024) return -8;  // (three workgroups per CU must fit for the OCC3 form)
   const int ntc = (a.n_cob + CBW - 1) / CBW, ntr = (a.rows + TM - 1) / TM;
   const int grid = ((ntr + 7) / 8) * 8 * ntc;
   static bool attr_done[SLIDE_MAX_DEVICES] = {};
@@ -522,7 +530,14 @@ int launch_gx(const GemmArgs &a, hipStream_t s) {
   bool &attr_set = attr_done[d >= 0 && d < SLIDE_MAX_DEVICES ? d : 0];
   GemmArgs b = a;
   b.shm_bytes = (int)shm;
-  if constexpr (CBW == 2) {
+  if constexpr (CBW == 2 && !OCC3) {
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_gx_n64w_kernel<NPXL, NST, MODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_gx_n64w_kernel<NPXL, NST, MODE>), dim3(grid), dim3(256), shm, s, b);
+  } else if constexpr (CBW == 2) {
     // (red / gsh of the common epilogue live in the dead ring: 256 CBW + 128 CBW floats = 3 KB < the ring)
     if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_gx_n64_kernel<NPXL, NST, MODE>),
@@ -563,13 +578,21 @@ int slide_launch_gemm_gx(const SlideOp &o, hipStream_t s) {
   const bool m1 = a.gx_mode != 0;
   // f[0] != 0 (the plan's default, SLIDE_GX_N64): 256 x 64 tiles, three workgroups per CU (128-channel tiles when the LDS does
   // not fit): measured 385 vs 374 shapes/s in bench.py's arrangement
-  const bool n64 = o.f[0] != 0.f;
+  // f[0] == 2: the 64-channel tile at two workgroups per CU (both modes; the plan asks for it when the 128-channel grid would
+  // leave CUs empty)
+  const int n64 = (int)o.f[0];
   if (npxl == 7 && (!a.gidx || !a.gx_d2 || !a.gx_w)) return -3;
   // (mode 1 only -- the keys -> u layers: with mode 0's PAIR residual the epilogue does not fit 168 registers)
-  if (n64 && m1) {
+  if (n64 == 1 && m1) {
     int st = -8;
     if (npxl == 8) st = launch_gx<8, 3, 1, 2>(a, s);
     else if (npxl == 7) st = launch_gx<7, 3, 1, 2>(a, s);
+    if (st != -8) return st;
+  }
+  if (n64 == 2) {
+    int st = -8;
+    if (npxl == 8) st = m1 ? launch_gx<8, 3, 1, 2, false>(a, s) : launch_gx<8, 3, 0, 2, false>(a, s);
+    else if (npxl == 7) st = m1 ? launch_gx<7, 3, 1, 2, false>(a, s) : launch_gx<7, 3, 0, 2, false>(a, s);
     if (st != -8) return st;
   }
   if (npxl == 8) return m1 ? launch_gx<8, 3, 1>(a, s) : launch_gx<8, 3, 0>(a, s);
