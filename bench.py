@@ -301,13 +301,25 @@ def main():
     state["left"] = 1000
     sync_all()
     state["enq"] = 0.0
+    chain_ev = None
+    if os.environ.get("SLIDE_BENCH_CHAIN_ENDS"):  # diagnostic: when each chain retires its last step (stderr)
+        streams = [p_.stream for p_, _ in pos_chains] + [f_.stream for f_, _, _ in feat_chains]
+        chain_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), st_) for st_ in streams]
+        for e0, _, st_ in chain_ev:
+            e0.record(st_)
     t0 = time.perf_counter()
     run(a.steps)
     host_enq = state["enq"]
+    if chain_ev:
+        for _, e1, st_ in chain_ev:
+            e1.record(st_)
     if use_dist:
         gather_latents()
     sync_all()
     dt = time.perf_counter() - t0
+    if chain_ev:
+        print("chain ends (ms after its start event; position chain(s) first): %s; wall %.3f ms" %
+              (", ".join("%.3f" % e0.elapsed_time(e1) for e0, e1, _ in chain_ev), dt * 1e3), file=sys.stderr)
     if use_dist:
         tt = torch.tensor([dt], device=gdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
