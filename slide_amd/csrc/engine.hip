@@ -1015,6 +1015,202 @@ __device__ __forceinline__ void attn_tail_body(const AttnTailArgs &a) {
   }
 }
 
+// WIDE form (round 3): 256 rows x 128 channels on the same four waves.  Per MFMA the tile moves 1.1 KB through the LDS instead
+// of 1.6 KB (X fragments feed four channel blocks, an X chunk is written once per 128 channels) -- the 64-channel tile's K
+// loop is LDS-bandwidth-bound at ~60 % of the matrix pipe -- and a sample's u / mo tiles are read from L2
+// by half as many workgroups.  128 accumulator registers hold ONE contraction at a time: VALUES first (GroupNorm statistics,
+// normalise, ReLU, packed to fp16: 64 registers), then the SCORES into the same accumulators, then the soft-max weighted sum.
+template <int NPXL, int NST>
+__device__ __forceinline__ void attn_tail_wide_body(const AttnTailArgs &a) {
+  using T = _Float16;
+  constexpr int CBW = 4, RT = TM + 32 * CBW, STAGE_B = RT * 64, LPW = RT / 16 / 4;
+  constexpr int KLOG = NPXL - 4, KN = 1 << KLOG, GPB = 32 / KN;  // neighbours per point, points per 32-row block
+  constexpr int WPS = (1 << NPXL) / 64;                            // waves per sample
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int ntc = (a.n_cob + CBW - 1) / CBW;
+  const int xcd = blockIdx.x & 7, q0 = blockIdx.x >> 3;
+  const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;
+  if (tr * TM >= a.rows) return;
+  const int row0 = tr * TM, cob0 = tc * CBW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+  float *const vec_lds = reinterpret_cast<float *>(smem_raw + (size_t)NST * STAGE_B);  // [4 vectors][CBW*32]
+  for (int i = tid; i < 4 * CBW * 32; i += 256) {
+    const int which = i / (CBW * 32), c = i - which * (CBW * 32), gc = cob0 * 32 + c;
+    vec_lds[i] = gc < a.n_cob * 32 ? a.vec[(size_t)which * a.n_cob * 32 + gc] : 0.f;
+  }
+  int wrow[CBW], wkey[CBW], xrow[2], xkey[2];
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb) {
+    const int trow = TM + cb * 32 + col;
+    wrow[cb] = trow * 64; wkey[cb] = (trow >> 2) & 3;
+  }
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const int trow = wave * 64 + rb * 32 + col;
+    xrow[rb] = trow * 64; xkey[rb] = (trow >> 2) & 3;
+  }
+  // one LDS-DMA ring GEMM: acc[cb][rb] = D[row][channel] (lane: channel col of block cb; reg r: row (r&3)+8(r>>2)+4 half)
+  auto run = [&](const void *Xp, const void *Wp, int x_ld, int k_pad, f32x16 (&acc)[CBW][2]) __attribute__((always_inline)) {
+    // chunk-major operands as in glds_tile: X when x_ld == 32, the weights when a.w_cm
+    const size_t x_cs = x_ld == 32 ? (size_t)a.rows * 32 : 32;
+    const size_t w_cs = a.w_cm ? (size_t)a.n_cob * 32 * 32 : 32;
+    const int w_ld = a.w_cm ? 32 : k_pad;
+    const T *gp[LPW];
+#pragma unroll
+    for (int j = 0; j < LPW; ++j) {
+      const int trow = 16 * (j * 4 + wave) + (lane >> 2);
+      const int piece = (lane & 3) ^ ((trow >> 2) & 3);
+      if (trow < TM) {
+        int grow = row0 + trow;
+        grow = grow < a.rows ? grow : a.rows - 1;
+        gp[j] = reinterpret_cast<const T *>(Xp) + (size_t)grow * x_ld + piece * 8;
+      } else {
+        int gco = cob0 * 32 + (trow - TM);
+        gco = gco < a.n_cob * 32 ? gco : a.n_cob * 32 - 1;
+        gp[j] = reinterpret_cast<const T *>(Wp) + (size_t)gco * w_ld + piece * 8;
+      }
+    }
+    auto issue = [&](int kc, int st) {
+#pragma unroll
+      for (int j = 0; j < LPW; ++j)
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(gp[j] + (size_t)kc * (j < TM / 64 ? x_cs : w_cs)),
+                                         (__attribute__((address_space(3))) void *)(smem_raw + (size_t)st * STAGE_B +
+                                                                                    (j * 4 + wave) * 1024),
+                                         16, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < CBW; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nk = k_pad / 32;
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0)
+      if (s0 < nk) issue(s0, s0);
+    for (int kc = 0; kc < nk; ++kc) {
+      if (kc + NST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kc + NST - 1 < nk) issue(kc + NST - 1, (kc + NST - 1) % NST);
+      const unsigned char *sb = smem_raw + (size_t)(kc % NST) * STAGE_B;
+#pragma unroll
+      for (int st2 = 0; st2 < 2; ++st2) {
+        f16x8 wf[CBW], xf[2];
+        const int piece = st2 * 2 + half;
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb) wf[cb] = *reinterpret_cast<const f16x8 *>(sb + wrow[cb] + ((piece ^ wkey[cb]) << 4));
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) xf[rb] = *reinterpret_cast<const f16x8 *>(sb + xrow[rb] + ((piece ^ xkey[rb]) << 4));
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb)
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[rb], wf[cb], acc[cb][rb], 0, 0, 0);  // rows x channels
+      }
+    }
+    __syncthreads();  // ring drained and free (also orders the staged vectors before their first use)
+  };
+  f32x16 acc[CBW][2];
+  run(a.X2, a.W2, a.x2_ld, a.k2, acc);  // values first
+
+  // ---- values: bias, GroupNorm over the sample (rows of WPS waves x the gs adjacent channel lanes), ReLU, packed to fp16
+  float *const red = reinterpret_cast<float *>(smem_raw);  // [wave][cb][32 channels][sum, sumsq]
+  const float *b_s = vec_lds, *b_v = vec_lds + CBW * 32, *gam = vec_lds + 2 * CBW * 32, *bet = vec_lds + 3 * CBW * 32;
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb) {
+    const float bv = b_v[cb * 32 + col];
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float x = acc[cb][rb][r] + bv;
+        acc[cb][rb][r] = x;
+        s += x;
+        ss = fmaf(x, x, ss);
+      }
+    s += other_half(s);
+    ss += other_half(ss);
+    if (half == 0) *reinterpret_cast<f32x2 *>(red + ((wave * CBW + cb) * 32 + col) * 2) = f32x2{s, ss};
+  }
+  __syncthreads();
+  const int w0 = (wave / WPS) * WPS;
+  f16x2 vp[CBW][2][8];  // relu(GN(values)) of this lane's channel, rows (2 j, 2 j + 1) of the block
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb) {
+    f32x2 t = {0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < WPS; ++w) t += *reinterpret_cast<const f32x2 *>(red + (((w0 + w) * CBW + cb) * 32 + col) * 2);
+    float s = t[0], ss = t[1];
+    if (a.gs >= 2) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1, 0xF, 0xF, true));
+                     ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0xB1, 0xF, 0xF, true)); }
+    if (a.gs >= 4) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E, 0xF, 0xF, true));
+                     ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x4E, 0xF, 0xF, true)); }
+    if (a.gs >= 8) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x141, 0xF, 0xF, true));
+                     ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x141, 0xF, 0xF, true)); }
+    if (a.gs >= 16) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x140, 0xF, 0xF, true));
+                      ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x140, 0xF, 0xF, true)); }
+    if (a.gs >= 32) { s += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s), 0x401F));
+                      ss += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(ss), 0x401F)); }
+    const float mean = s * a.inv_count;
+    const float var = fmaxf(ss * a.inv_count - mean * mean, 0.f);
+    float g = gam[cb * 32 + col] * __builtin_amdgcn_rsqf(var + GN_EPS);
+    float bt = bet[cb * 32 + col] - mean * g;
+    if ((cob0 + cb) * 32 + col >= a.n_norm) { g = 1.f; bt = 0.f; }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        vp[cb][rb][j] = f16x2{(T)fmaxf(fmaf(acc[cb][rb][2 * j], g, bt), 0.f), (T)fmaxf(fmaf(acc[cb][rb][2 * j + 1], g, bt), 0.f)};
+  }
+  __syncthreads();  // every wave has read the statistics: the ring area is free for the score contraction
+  run(a.X1, a.W1, a.x1_ld, a.k1, acc);  // scores into the same accumulators
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb) {
+    const float bs = b_s[cb * 32 + col];
+    // ---- softmax over the K neighbour rows of every point, weighted sum of the values, one row out per point
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int pg = 0; pg < GPB; ++pg) {
+        constexpr int RPG = 16 / GPB;
+        float sc[RPG], vv[RPG];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < RPG; ++j) {
+          sc[j] = acc[cb][rb][pg * RPG + j] + bs;
+          vv[j] = (float)vp[cb][rb][(pg * RPG + j) >> 1][(pg * RPG + j) & 1];
+          m = fmaxf(m, sc[j]);
+        }
+        m = fmaxf(m, other_half(m));
+        float den = 0.f, num = 0.f;
+#pragma unroll
+        for (int j = 0; j < RPG; ++j) {
+          const float e = __expf(sc[j] - m);
+          den += e;
+          num = fmaf(e, vv[j], num);
+        }
+        den += other_half(den);
+        num += other_half(num);
+        const int rbase = row0 + wave * 64 + rb * 32 + pg * KN;
+        if (half == 0 && rbase < a.rows && cob0 + cb < a.n_cob) {
+          const T v = (T)(num / den);
+          reinterpret_cast<T *>(a.out)[(size_t)(rbase >> KLOG) * a.out_ld + (cob0 + cb) * 32 + col] = v;
+          if (a.out_cm)
+            reinterpret_cast<T *>(a.out_cm)[((size_t)(cob0 + cb) * (a.rows >> KLOG) + (rbase >> KLOG)) * 32 + col] = v;
+          if (a.out2 && (cob0 + cb) * 32 + col < a.out2_n)
+            reinterpret_cast<T *>(a.out2)[(size_t)(rbase >> KLOG) * a.out2_ld + (cob0 + cb) * 32 + col] = v;
+        }
+      }
+  }
+}
+
+template <int NPXL>
+__global__ __launch_bounds__(256, 1) void attn_tail_wide_kernel(AttnTailArgs a) {
+  attn_tail_wide_body<NPXL, 3>(a);
+}
+
 template <int NPXL>
 __global__ __launch_bounds__(256, 2) void attn_tail_kernel(AttnTailArgs a) {
   attn_tail_body<NPXL, SLIDE_ATTN_NST>(a);
@@ -2003,6 +2199,19 @@ int run_attn_tail(const SlideOp &o, hipStream_t s) {
   }
   const int ntc = (a.n_cob + 1) / 2, ntr = (a.rows + TM - 1) / TM;
   const int grid = ((ntr + 7) / 8) * 8 * ntc;
+  if (((int)o.f[1] & 4) && npxl == 8 && a.n_cob % 4 == 0) {  // plan knob SLIDE_TAIL_WIDE: 256 x 128 tiles (attn_tail_wide_kernel)
+    const int ntc4 = a.n_cob / 4;
+    const int grid4 = ((ntr8 + 7) / 8) * 8 * ntc4;
+    const size_t shm4 = (size_t)3 * (TM + 128) * 64 + 4 * 4 * 32 * 4 + 64;
+    static bool attrw_done[SLIDE_MAX_DEVICES] = {};
+    bool &attrw = attrw_done[current_device_slot()];
+    if (!attrw) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_tail_wide_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      attrw = true;
+    }
+    hipLaunchKernelGGL(attn_tail_wide_kernel<8>, dim3(grid4), dim3(256), shm4, s, a);
+    return (int)hipGetLastError();
+  }
   const bool tail_occ3 = ((int)o.f[1] & 2) != 0;  // (plan knob SLIDE_TAIL_OCC3: two-stage ring, three workgroups per CU)
   if (tail_occ3 && (npxl == 7 || npxl == 8)) {
     const size_t shm3 = (size_t)2 * (TM + 64) * 64 + 4 * 2 * 32 * 4 + 64;

@@ -1065,7 +1065,8 @@ class DenoiserEngine:
                                         # f[1]: 1 = chunk-major operands, + 2 = two-stage ring at three workgroups per CU (opt-in,
                                         # SLIDE_TAIL_OCC3=1: measured neutral, 373.0 vs 372.3 shapes/s)
                                         f=(1.0 / (vlay[4] * npx), (1.0 if self.use_cm else 0.0) +
-                                           (2.0 if os.environ.get("SLIDE_TAIL_OCC3", "0") != "0" else 0.0)),
+                                           (2.0 if os.environ.get("SLIDE_TAIL_OCC3", "0") != "0" else 0.0) +
+                                           (4.0 if (Cp // 32) % 4 == 0 and Cp // 32 >= int(os.environ.get("SLIDE_TAIL_WIDE", "1000")) else 0.0)),
                                         p=(u.data_ptr(), d[0].data_ptr(), mo.data_ptr(), d[1].data_ptr(), out.data_ptr(),
                                            d[2].data_ptr(), None if out_cm is None else out_cm.data_ptr())))
                 return
