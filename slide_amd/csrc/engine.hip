@@ -458,10 +458,11 @@ __global__ __launch_bounds__(512, 2) void gemm_glds8_kernel(GemmArgs a) {
 }
 
 // Small launches (the 16-row per-point GEMMs: rows = 16 x batch, so a 256-row tiling yields a handful of workgroups
-// whose cost is their own serial latency).  Tile 64 rows x 64 channels; the four waves SPLIT K -- wave w takes the
-// 32-deep chunks w, w+4, ... through a private LDS-DMA ring (no workgroup barrier in the loop) -- then the partial
-// accumulators meet in LDS and every wave finishes ONE 32x32 output block (channel block w & 1, row block w >> 1)
-// through the common epilogue: the K loop and the epilogue are each ~4x shorter per wave and the grid is 4x larger.
+// whose cost is their own serial latency).  Tile 64 rows x 64 channels; the four waves are (K half, channel block): wave
+// (kh, cbw) takes the 32-deep chunks kh, kh+2, ... of channel block cbw through a private LDS-DMA ring (no workgroup barrier
+// in the loop) -- then the two K halves of a block meet through LDS and every wave finishes ONE 32x32 output block (channel
+// block cbw, row block kh) through the common epilogue: the K loop and the epilogue are each ~4x shorter per wave than
+// on a 256-row tile and the grid is 4x larger.  48 KB of rings: three workgroups per CU.
 // (168-VGPR budget: a wave of this kernel then shares a SIMD with two waves of the 64-channel GEMM tiles of the other chains)
 // PAIR (pair_first_kernel below): 0 = none, 1 / 2 = the channel blocks from pa.pair_cob0 on are the per-point products of an
 // SA / FP block's pair decomposition and leave through the pair-table epilogue instead of the common one
@@ -469,7 +470,10 @@ template <int NST, bool AFF, int PAIR>
 __device__ __forceinline__ void small_body(const GemmArgs &a, const PairArgs &pa) {
   using T = _Float16;
   constexpr int NPXL = 4;
-  constexpr int STAGE_B = 128 * 64;  // 64 X rows + 64 W rows, 64 bytes each
+  // (round 3: waves = (K half kh, channel block cbw) instead of four K quarters over both blocks: a stage is 64 X rows + the
+  //  wave's 32 W rows = 6 KB, the rings 48 KB instead of 64 and the exchange 16 KB -- THREE workgroups fit a CU's LDS)
+  constexpr int STAGE_B = 96 * 64;  // 64 X rows + 32 W rows, 64 bytes each
+  constexpr int NJ = 6;             // LDS-DMA instructions per stage (16 rows each)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   SLIDE_STAMP(a, 0);
   const int ntc = (a.n_cob + 1) / 2;
@@ -477,12 +481,13 @@ __device__ __forceinline__ void small_body(const GemmArgs &a, const PairArgs &pa
   const int row0 = tr * 64, cob0 = tc * 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
+  const int kh = wave >> 1, cbw = wave & 1;
   unsigned char *const ring = smem_raw + (size_t)wave * NST * STAGE_B;
   uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + (size_t)4 * NST * STAGE_B);
   float *const vec_lds = reinterpret_cast<float *>(epi_lds + 2 * EPI_DW + (2 * EPI_DW) % 4);
-  const T *gp[8];
+  const T *gp[NJ];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int trow = 16 * j + (lane >> 2);
     const int piece = (lane & 3) ^ ((trow >> 2) & 3);
     if (trow < 64) {
@@ -490,37 +495,35 @@ __device__ __forceinline__ void small_body(const GemmArgs &a, const PairArgs &pa
       grow = grow < a.rows ? grow : a.rows - 1;
       gp[j] = reinterpret_cast<const T *>(a.X) + (size_t)grow * a.x_ld + piece * 8;
     } else {
-      int gco = cob0 * 32 + (trow - 64);
+      int gco = (cob0 + cbw) * 32 + (trow - 64);
       gco = gco < a.n_cob * 32 ? gco : a.n_cob * 32 - 1;
       gp[j] = reinterpret_cast<const T *>(a.W) + (size_t)gco * a.k_pad + piece * 8;
     }
   }
   auto issue = [&](int kc, int st) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < NJ; ++j)
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(gp[j] + kc * 32),
                                        (__attribute__((address_space(3))) void *)(ring + (size_t)st * STAGE_B + j * 1024),
                                        16, 0, 0);
   };
-  f32x16 acc[2][2];
+  f32x16 acc[2];  // row blocks 0 / 1 of channel block cbw, this wave's K half
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  int wrow[2], wkey[2], xrow[2], xkey[2];
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  int xrow[2], xkey[2];
+  const int wrow = (64 + col) * 64, wkey = ((64 + col) >> 2) & 3;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int tw = 64 + i * 32 + col, tx = i * 32 + col;
-    wrow[i] = tw * 64; wkey[i] = (tw >> 2) & 3;
+    const int tx = i * 32 + col;
     xrow[i] = tx * 64; xkey[i] = (tx >> 2) & 3;
   }
   const int nk = a.k_pad / 32;
-  const int mine = nk > wave ? (nk - wave + 3) / 4 : 0;  // chunks wave, wave + 4, ...
+  const int mine = nk > kh ? (nk - kh + 1) / 2 : 0;  // chunks kh, kh + 2, ...
 #pragma unroll
   for (int s0 = 0; s0 < NST - 1; ++s0)
-    if (s0 < mine) issue(wave + 4 * s0, s0);
+    if (s0 < mine) issue(kh + 2 * s0, s0);
   // tables (and the affine vectors) are staged behind the primed rings: their latency overlaps the first chunks'
   stage_epilogue_tables<2>(a, cob0, tid, epi_lds, vec_lds);
   // PAIR: the four samples' coordinates [4][48] and (FP) neighbour / squared-distance / weight slots [4][16 x 8] each
@@ -632,19 +635,18 @@ __device__ __forceinline__ void small_body(const GemmArgs &a, const PairArgs &pa
   SLIDE_STAMP(a, 1);
   for (int i = 0; i < mine; ++i) {
     // this wave's own DMA: a counted wait orders it for this wave's reads, no barrier involved
-    if (i + NST - 2 < mine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * 8) : "memory");
+    if (i + NST - 2 < mine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NJ) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned char *sb = ring + (size_t)(i % NST) * STAGE_B;
-    f16x8 af[2][2], bf[2][2];
+    f16x8 af[2], bf[2][2];
 #pragma unroll
     for (int st2 = 0; st2 < 2; ++st2) {
       const int piece = st2 * 2 + half;
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) af[st2][cb] = *reinterpret_cast<const f16x8 *>(sb + wrow[cb] + ((piece ^ wkey[cb]) << 4));
+      af[st2] = *reinterpret_cast<const f16x8 *>(sb + wrow + ((piece ^ wkey) << 4));
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) bf[st2][rb] = *reinterpret_cast<const f16x8 *>(sb + xrow[rb] + ((piece ^ xkey[rb]) << 4));
       if (AFF) {
-        const int kc = wave + 4 * i;
+        const int kc = kh + 2 * i;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
           const _Float16 *ap = aff_lds + (size_t)((rb * 2 + (col >> 4)) * 2) * a.k_pad + kc * 32 + piece * 8;
@@ -654,37 +656,33 @@ __device__ __forceinline__ void small_body(const GemmArgs &a, const PairArgs &pa
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is free again before it is re-armed below
-    if (i + NST - 1 < mine) issue(wave + 4 * (i + NST - 1), (i + NST - 1) % NST);
+    if (i + NST - 1 < mine) issue(kh + 2 * (i + NST - 1), (i + NST - 1) % NST);
 #pragma unroll
     for (int st2 = 0; st2 < 2; ++st2)
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-          acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[st2][cb], bf[st2][rb], acc[cb][rb], 0, 0, 0);
+      for (int rb = 0; rb < 2; ++rb)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[st2], bf[st2][rb], acc[rb], 0, 0, 0);
   }
   __syncthreads();  // rings are dead, tables are visible
   SLIDE_STAMP(a, 2);
-  // partial accumulators -> LDS [wave][block = cb*2+rb][reg][lane]; wave w sums block w
+  // wave (kh, cbw) finishes the block (channel block cbw, row block kh): it keeps its own partial of that block in registers
+  // and takes the other K half's from its partner (1 - kh, cbw) through LDS [wave][reg][lane]
   float *const part = reinterpret_cast<float *>(smem_raw);
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) part[(((wave * 4 + cb * 2 + rb) * 16 + r) << 6) + lane] = acc[cb][rb][r];
+  for (int r = 0; r < 16; ++r) part[((wave * 16 + r) << 6) + lane] = kh ? acc[0][r] : acc[1][r];  // the block it does NOT own
   __syncthreads();
   f32x16 one[1][1];
+  {
+    const int pw = ((1 - kh) << 1) | cbw;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) t += part[(((w * 4 + wave) * 16 + r) << 6) + lane];
-    one[0][0][r] = t;
+    for (int r = 0; r < 16; ++r) {
+      const float own = kh ? acc[1][r] : acc[0][r], oth = part[((pw * 16 + r) << 6) + lane];
+      one[0][0][r] = kh ? oth + own : own + oth;  // K half 0 first, whichever wave adds
+    }
   }
   SLIDE_STAMP(a, 3);
   SLIDE_STAMP(a, 4);
-  const int cb = wave >> 1, rb = wave & 1;  // block index wave = cb*2 + rb
+  const int cb = cbw, rb = kh;
   if (PAIR == 0 || cob0 + cb < pa.pair_cob0)
     gemm_epilogue<SLIDE_PREC_F16, NPXL, 1, 1>(a, one, row0 + rb * 32, cob0 + cb, 0, half, col, epi_lds + cb * EPI_DW,
                                               vec_lds + cb * 96, nullptr);
@@ -695,7 +693,7 @@ __device__ __forceinline__ void small_body(const GemmArgs &a, const PairArgs &pa
     __syncthreads();  // every wave has summed its block: the partial-sum area is free
     const int cobi = cob0 + cb;
     if (cobi >= pa.pair_cob0 && cobi < a.n_cob) {
-      float *const tr = reinterpret_cast<float *>(smem_raw) + wave * 4096;  // [32 channels][33] transposed block, then [16][65] columns
+      float *const tr = reinterpret_cast<float *>(smem_raw) + wave * 1152;  // [32 channels][33] transposed block, then [16][65] columns
 #pragma unroll
       for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + col] = one[0][0][r];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1968,7 +1966,7 @@ int launch_gemm_glds8(const GemmArgs &a, hipStream_t s) {
 
 template <int NST, bool AFF>
 int launch_gemm_small_t(const GemmArgs &a, hipStream_t s) {
-  const size_t shm = (size_t)4 * NST * 8192 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32 + (AFF ? (size_t)4 * 2 * a.k_pad * 2 + 1024 : 0);
+  const size_t shm = (size_t)4 * NST * 6144 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32 + (AFF ? (size_t)4 * 2 * a.k_pad * 2 + 1024 : 0);
   const int grid = ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2);
   static bool attr_done[SLIDE_MAX_DEVICES] = {};
   bool &attr_set = attr_done[current_device_slot()];
@@ -1984,7 +1982,7 @@ int launch_gemm_small_t(const GemmArgs &a, hipStream_t s) {
 template <bool FP>
 int launch_pair_first_t(const GemmArgs &a, const PairArgs &pa, hipStream_t s) {
   const int grid = ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2);
-  const size_t shm = (size_t)4 * 2 * 8192 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32 + (192 + 3 * 512) * 4;
+  const size_t shm = (size_t)4 * 2 * 6144 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32 + (192 + 3 * 512) * 4;
   static bool attr_done[SLIDE_MAX_DEVICES] = {};
   bool &attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
