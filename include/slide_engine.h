@@ -81,7 +81,7 @@ enum {
   SLIDE_OP_TEMB = 8,        /* p: ts(or NULL), t_dev, w1,b1,w2,b2, wfc, bfc, out, freq   i: nsamp, t_dim, n_out  (weights [in][out]) */
   SLIDE_OP_COND = 9,        /* p: label(int64), class_emb, wfc, bfc, out           i: B, dim, n_out */
   SLIDE_OP_UPDATE_POS = 10, /* p: x, eps, noise(or NULL), t_dev, c_eps, sqrt_alpha, sigma  i: n_elem, eps_ld (0 = compact rows of 3), seed_lo, seed_hi */
-  SLIDE_OP_UPDATE_FEAT = 11,/* p: x, eps, noise(or NULL), t_dev, keypoint, c_recip, c_recipm1, c1, c2, c_std, [10] complete_x0 (n_pts*C) + [11] keypoint_mask (n_pts) of the local re-sampling mode (both NULL = off)  i: n_pts, C, kdim, seed_lo, seed_hi, eps_ld (0 = C)  f: clamp.  In-kernel noise is keyed on (seed, t_dev[3] = chain nonce, t_dev[1] = step, GLOBAL element = element + t_dev[4] * elements per sample; t_dev[4] = global index of the chain's first sample) */
+  SLIDE_OP_UPDATE_FEAT = 11,/* p: x, eps, noise(or NULL), t_dev, keypoint, c_recip, c_recipm1, c1, c2, c_std, [10] complete_x0 (n_pts*C) + [11] keypoint_mask (n_pts) of the local re-sampling mode (both NULL = off), [12] per-point table feat0 [n_pts][i[6]] (fp16 if i[7]) or NULL + [13] SlidePrepCopy[i[8]]: with fixed key points the update also writes the feature columns SLIDE_OP_PREP_POINTS would derive from the new state (the preparation then runs once per chain, not per step)  i: n_pts, C, kdim, seed_lo, seed_hi, eps_ld (0 = C), ldf, feat0 is fp16, n_copies  f: clamp.  In-kernel noise is keyed on (seed, t_dev[3] = chain nonce, t_dev[1] = step, GLOBAL element = element + t_dev[4] * elements per sample; t_dev[4] = global index of the chain's first sample) */
   SLIDE_OP_ADVANCE_T = 12,  /* p: t_dev  (t_dev[0] -= 1; t_dev[1] += 1); t_dev = [t, step, blocks-done counter, chain nonce, global index of the first sample, 3 spare] (8 ints) */
   SLIDE_OP_SYNC = 14,       /* i: from_lane, to_lane -- lane `to` waits for everything issued so far on lane `from` */
   SLIDE_OP_GROUPNORM_NCHW = 13,/* p: x, gamma, beta, y (NCHW fp32)   i: B, C, HW, G, n_norm, relu  (module-level path) */

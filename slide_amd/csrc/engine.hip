@@ -1792,7 +1792,9 @@ __device__ __forceinline__ void update_feat_element(int e, int npts, int C, int 
                                                     const float *__restrict__ kmask, const float *__restrict__ keypoint,
                                                     const float *__restrict__ rc, const float *__restrict__ rm1,
                                                     const float *__restrict__ c1, const float *__restrict__ c2,
-                                                    const float *__restrict__ stdv) {
+                                                    const float *__restrict__ stdv, void *__restrict__ feat0 = nullptr,
+                                                    int ldf = 0, int half_out = 0,
+                                                    const SlidePrepCopy *__restrict__ copies = nullptr, int n_copies = 0) {
 #pragma clang fp contract(off)
   if (e >= npts * C) return;
   const int p = e / C, c = e - p * C;
@@ -1814,6 +1816,21 @@ __device__ __forceinline__ void update_feat_element(int e, int npts, int C, int 
     v = v + stdv[t] * z;
   }
   x[e] = v;
+  // fixed key points (kdim == 3): what the NEXT step's point preparation would derive from this element -- the feature
+  // column of the per-point table and of the concatenation buffers that carry the input features -- is written here, and
+  // SLIDE_OP_PREP_POINTS (coordinates, neighbour tables: constant over the chain) leaves the step plan
+  if (feat0) {
+    const int cf = c - kdim;
+    if (half_out) reinterpret_cast<_Float16 *>(feat0)[(size_t)p * ldf + cf] = (_Float16)v;
+    else reinterpret_cast<float *>(feat0)[(size_t)p * ldf + cf] = v;
+    for (int q = 0; q < n_copies; ++q) {
+      const SlidePrepCopy cp = copies[q];
+      if (cp.kind == 0 && cf < cp.n) {
+        if (half_out) reinterpret_cast<_Float16 *>(cp.dst)[(size_t)p * cp.ld + cf] = (_Float16)v;
+        else reinterpret_cast<float *>(cp.dst)[(size_t)p * cp.ld + cf] = v;
+      }
+    }
+  }
 }
 
 // sampling() update (pointnet2/util.py:247-253): x = (x - c_eps[t]*eps)/sqrt_alpha[t]; t>0: x += sigma[t]*z
@@ -1848,7 +1865,8 @@ __global__ __launch_bounds__(256) void update_feat_kernel(int npts, int C, int k
                                                           const float *__restrict__ c1, const float *__restrict__ c2,
                                                           const float *__restrict__ stdv,
                                                           const float *__restrict__ complete_x0,
-                                                          const float *__restrict__ kmask) {
+                                                          const float *__restrict__ kmask, void *__restrict__ feat0, int ldf,
+                                                          int half_out, const SlidePrepCopy *__restrict__ copies, int n_copies) {
 #pragma clang fp contract(off)
   const int t = t_dev[0], step = t_dev[1];
   const uint32_t nonce = (uint32_t)t_dev[3];
@@ -1859,7 +1877,8 @@ __global__ __launch_bounds__(256) void update_feat_kernel(int npts, int C, int k
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     update_feat_element(blockIdx.x * 1024 + j * 256 + threadIdx.x, npts, C, kdim, eps_ld, clamp, seed_lo, seed_hi, x, eps, noise,
-                        t, step, nonce, eoff, complete_x0, kmask, keypoint, rc, rm1, c1, c2, stdv);
+                        t, step, nonce, eoff, complete_x0, kmask, keypoint, rc, rm1, c1, c2, stdv, feat0, ldf, half_out, copies,
+                        n_copies);
   advance_t_last_block(t_dev, t, step);
 }
 
@@ -2323,7 +2342,8 @@ int run_op(const SlideOp &o, hipStream_t s) {
                          o.i[2], o.i[5], o.f[0], (uint32_t)o.i[3], (uint32_t)o.i[4], (float *)o.p[0], (const float *)o.p[1],
                          (const float *)o.p[2], (int *)o.p[3], (const float *)o.p[4], (const float *)o.p[5],
                          (const float *)o.p[6], (const float *)o.p[7], (const float *)o.p[8], (const float *)o.p[9],
-                         (const float *)o.p[10], (const float *)o.p[11]);
+                         (const float *)o.p[10], (const float *)o.p[11], o.p[12], o.i[6], o.i[7],
+                         (const SlidePrepCopy *)o.p[13], o.i[8]);
       break;
     case SLIDE_OP_ATTN_TAIL:
       return run_attn_tail(o, s);

@@ -11,6 +11,7 @@ Noise is either an explicit tensor (parity tests inject the reference's stream) 
 (Philox4x32-10 + Box-Muller keyed on (seed, step, element)).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -78,6 +79,20 @@ class _GraphedSampler:
         e = self.engine
         hoisted = set(e.xyz_copy_idx) if fixed_xyz else set()
         drop = hoisted | {e.eps_copy_idx}
+        # fixed key points: the update kernel writes the feature columns the next step's point preparation would derive from
+        # the new state (per-point table, concatenation columns), so SLIDE_OP_PREP_POINTS -- coordinates and neighbour tables,
+        # constant over the chain -- runs once per chain in begin() instead of once per step (SLIDE_FUSE_PREP=0: per step)
+        from .engine import OP_PREP_POINTS
+        self.fuse_prep = False
+        if (fixed_xyz and update_op.kind == OP_UPDATE_FEAT and os.environ.get("SLIDE_FUSE_PREP", "1") != "0"
+                and e.ops[e._prep_idx].p[5] is None):  # (no chunk-major second copy of the table)
+            prep = e.ops[e._prep_idx]
+            assert prep.kind == OP_PREP_POINTS
+            update_op.p[12] = e.feat0.data_ptr()
+            update_op.i[6], update_op.i[7] = e.feat0.shape[1], int(e.feat0.dtype == torch.float16)
+            update_op.p[13], update_op.i[8] = prep.p[6], prep.i[4]
+            drop = drop | {e._prep_idx}
+            self.fuse_prep = True
         kept = [i for i in range(len(e.ops)) if i not in drop]
         ops = [e.ops[i] for i in kept]
         # per-launch accounting of the engine, re-keyed by position in the step plan
@@ -89,8 +104,7 @@ class _GraphedSampler:
         self.n_launches = len(ops)
         # once per batch: everything up to the last hoisted copy that the copies depend on (the point preparation)
         self.begin_ops = None
-        if hoisted:
-            from .engine import OP_PREP_POINTS
+        if hoisted or self.fuse_prep:
             b_ops = [SlideOp.from_buffer_copy(bytes(o)) for i, o in enumerate(e.ops) if o.kind == OP_PREP_POINTS or i in hoisted]
             for o in b_ops:
                 o.i[10] = 0  # one lane: the plan's fork / join launches are not part of this list
@@ -115,6 +129,8 @@ class _GraphedSampler:
                 check(L.slide_run_ops2(self.step_ops, len(self.step_ops), s, s2), "slide_run_ops")
                 self.stream.synchronize(); self.stream2.synchronize()
                 e.x.copy_(x0); e.t_dev.copy_(t0)
+                if getattr(self, "fuse_prep", False):  # the warm-up's update also rewrote the tables derived from the state
+                    e.run(self.begin_ops)
                 self.stream.synchronize()
                 check(L.slide_graph_begin(s), "graph_begin")
                 st = L.slide_run_ops2(self.step_ops, len(self.step_ops), s, s2)
@@ -311,6 +327,9 @@ class JointSampler:
             self.stream.synchronize(); self.stream2.synchronize()
             for e, (x0, t0) in zip(engines, keep):
                 e.x.copy_(x0); e.t_dev.copy_(t0)
+            for smp in (self.pos, self.feat):  # (the warm-up's update also rewrote the tables derived from the state)
+                if smp is not None and getattr(smp, "fuse_prep", False):
+                    smp.engine.run(smp.begin_ops)
             self.stream.synchronize()
             check(L.slide_graph_begin(s), "graph_begin")
             st = L.slide_run_ops2(self.step_ops, len(self.step_ops), s, s2)

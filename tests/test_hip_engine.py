@@ -179,6 +179,32 @@ def test_feature_sampler_fp16(gpu_device):
     assert rh <= 1e-3 and rt <= 1e-3, (rh, rt)
 
 
+@pytest.mark.parametrize("prec", ["fp16", "fp32"])
+def test_point_preparation_folded_into_the_update(gpu_device, monkeypatch, prec):
+    """Feature DDPM (fixed key points): the update kernel writes the feature columns of the per-point table and of the
+    concatenation buffers itself, SLIDE_OP_PREP_POINTS runs once per chain instead of once per step -- one launch less per
+    step, and the SAME bits as the per-step preparation (same values, same conversions), over a chain with in-kernel noise
+    and over a restarted chain (begin() must re-prime the tables)."""
+    from slide_amd.diffusion import FeatureSampler
+    g = load_golden("golden_sampler_feat.npz")
+    _, hp, sd = _load("feat")
+    cfg = json.loads(str(g["config_json"]))
+    size = g["head_x"].shape
+    rs = np.random.RandomState(2)
+    xa, xb = rs.standard_normal(size).astype(np.float32), rs.standard_normal(size).astype(np.float32)
+    kp2 = (g["keypoint"] + rs.standard_normal(g["keypoint"].shape).astype(np.float32) * 0.1).astype(np.float32)
+    out = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("SLIDE_FUSE_PREP", fuse)
+        smp = FeatureSampler(hp, sd, size[0], gpu_device, cfg, prec=prec, seed=77, use_graph=False)
+        assert smp.fuse_prep == (fuse == "1")
+        assert sum(1 for o in smp.step_ops if o.kind == 2) == (0 if fuse == "1" else 1)  # SLIDE_OP_PREP_POINTS
+        a_ = smp.sample(g["label"], g["keypoint"], xa, t_start=40, n_steps=12).cpu().numpy()
+        b_ = smp.sample(g["label"], kp2, xb, t_start=999, n_steps=7).cpu().numpy()  # a second chain, other key points
+        out[fuse] = (a_, b_)
+    assert np.isfinite(out["1"][0]).all() and np.array_equal(out["1"][0], out["0"][0]) and np.array_equal(out["1"][1], out["0"][1])
+
+
 def test_position_sampler_full_chain_matches_reference(gpu_device):
     from slide_amd.diffusion import PositionSampler
     g = load_golden("golden_sampler_pos.npz")
