@@ -131,6 +131,8 @@ enum {
                              * as ONE launch (csrc/gemm_chain.hip): a workgroup owns 64 rows and walks the layers, each through the common
                              * epilogue of its SlideEpi descriptors.  p[0]: HOST pointer to SlideChainLayer[n] (device pointers inside), kept
                              * alive by the plan.  i: rows, n (<= 6) */
+  SLIDE_OP_HEAD_UPDATE = 33,/* output head (two per-point GEMMs with the GroupNorm between them) + DDPM update + device-side t -= 1 as one launch
+                             * (csrc/engine.hip head_update_kernel): p[0] = HOST pointer to a SlideHeadArgs block */
   SLIDE_OP_BLOCK_BODY = 30, /* the whole K-expanded body of an SA / FP block whose widths are <= 256 channels in one launch (csrc/block_body.hip):
                              * Mlp tail -> mo, generated keys -> u, attention tail; one workgroup per sample, mo / u as MFMA operand fragments in
                              * registers, weights through one LDS-DMA ring.  p[0]: HOST pointer to the BodyArgs block (csrc/block_body.hip;
@@ -175,6 +177,24 @@ typedef struct SlideChainLayer {
   const void *X, *W, *epi;
   int32_t x_ld, k_pad, n_cob, pad;
 } SlideChainLayer;
+
+/* SLIDE_OP_HEAD_UPDATE (p[0] = HOST pointer to this block, device pointers inside; kept alive by the plan): the output head
+ * fc_lyaer (conv 128 -> GroupNorm(32, 128) -> ReLU -> conv) and the sampler's DDPM update in one launch */
+typedef struct SlideHeadArgs {
+  const void *X, *W0, *W1;     /* fp16: head input [rows][x_ld]; W0 [128][k0] row-major; W1 [n1c*32][128] row-major */
+  const float *v0, *b1;        /* [bias | gamma | beta][128] of layer 1; bias [n1c*32] of layer 2 */
+  float *eps_out;              /* optional copy of the prediction [rows][eps_ld], or NULL */
+  int32_t rows, x_ld, k0, n1c, eps_ld;
+  int32_t kind, C, kdim, ldf, half_out, n_copies; /* update: 0 = position (SLIDE_OP_UPDATE_POS), 1 = feature (SLIDE_OP_UPDATE_FEAT) */
+  float clamp;
+  uint32_t seed_lo, seed_hi;
+  float *x;
+  const float *noise;
+  int32_t *t_dev;
+  const float *keypoint, *t0, *t1, *t2, *t3, *t4, *complete_x0, *kmask; /* schedule tables in the update op's order */
+  void *feat0;
+  const struct SlidePrepCopy *copies;
+} SlideHeadArgs;
 
 typedef struct SlideOp {
   int32_t kind;

@@ -1794,7 +1794,8 @@ __device__ __forceinline__ void update_feat_element(int e, int npts, int C, int 
                                                     const float *__restrict__ c1, const float *__restrict__ c2,
                                                     const float *__restrict__ stdv, void *__restrict__ feat0 = nullptr,
                                                     int ldf = 0, int half_out = 0,
-                                                    const SlidePrepCopy *__restrict__ copies = nullptr, int n_copies = 0) {
+                                                    const SlidePrepCopy *__restrict__ copies = nullptr, int n_copies = 0,
+                                                    float eps_val = 0.f) {  // (eps == nullptr: the prediction is eps_val)
 #pragma clang fp contract(off)
   if (e >= npts * C) return;
   const int p = e / C, c = e - p * C;
@@ -1803,7 +1804,7 @@ __device__ __forceinline__ void update_feat_element(int e, int npts, int C, int 
     return;
   }
   const float xv = x[e];
-  float x0 = rc[t] * xv - rm1[t] * eps[eps_ld ? (size_t)p * eps_ld + c : (size_t)e];
+  float x0 = rc[t] * xv - rm1[t] * (eps ? eps[eps_ld ? (size_t)p * eps_ld + c : (size_t)e] : eps_val);
   if (clamp > 0.f) x0 = fminf(fmaxf(x0, -clamp), clamp);
   if (complete_x0) {  // local re-sampling (diffusion.py:76-79): pred_xstart*mask + complete_x0*(1-mask), mask per point
     const float m = kmask[p];
@@ -1880,6 +1881,152 @@ __global__ __launch_bounds__(256) void update_feat_kernel(int npts, int C, int k
                         t, step, nonce, eoff, complete_x0, kmask, keypoint, rc, rm1, c1, c2, stdv, feat0, ldf, half_out, copies,
                         n_copies);
   advance_t_last_block(t_dev, t, step);
+}
+
+// ------------------------------------------------------------------------------------------------ output head + DDPM update
+// fc_lyaer (conv -> GroupNorm(32, 128) -> ReLU -> conv, pointnet2_with_pcld_condition.py:480-483) and the DDPM update of the
+// sampler as ONE launch (SLIDE_OP_HEAD_UPDATE) instead of two small GEMM launches + the update kernel.  A workgroup owns 64
+// rows (four samples); both layers' weights are tiny (<= 40 KB + 16 KB), so each wave loads the rows of ITS channel block
+// straight into A-fragment registers at kernel start together with everything else the kernel reads (one L2 round trip), the
+// hidden activation crosses the waves through LDS, and the prediction eps never leaves the registers: the lane that holds
+// eps[row][channel] applies the update to x[row][channel] (and, for the feature DDPM with fixed key points, writes the per-point
+// table / concatenation columns of the next step, as update_feat_kernel does).
+typedef SlideHeadArgs HeadArgs;  // include/slide_engine.h
+
+template <int K0MAX>  // k0 <= K0MAX (multiple of 32)
+__global__ __launch_bounds__(256, 2) void head_update_kernel(HeadArgs a) {
+#pragma clang fp contract(off)
+  using T = _Float16;
+  constexpr int LDX = K0MAX + 8, LDH = 128 + 8;
+  __shared__ __attribute__((aligned(16))) T xs[64 * LDX];
+  __shared__ __attribute__((aligned(16))) T hs[64 * LDH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+  const int row0 = blockIdx.x * 64;
+  const int t = a.t_dev[0], step = a.t_dev[1];
+  const uint32_t nonce = (uint32_t)a.t_dev[3];
+  const uint32_t eoff = (uint32_t)a.t_dev[4] * (uint32_t)(16 * a.C);
+  // ---- every global read of the two layers, issued together
+  const int nk0 = a.k0 >> 4;  // 16-deep steps of layer 1
+  f16x8 w0[K0MAX / 16];
+  {
+    const GLOBAL_AS T *wp = gptr<const T>((uint64_t)a.W0) + (size_t)(wave * 32 + col) * a.k0 + half * 8;
+#pragma unroll
+    for (int s2 = 0; s2 < K0MAX / 16; ++s2)
+      if (s2 < nk0) w0[s2] = *(const GLOBAL_AS f16x8 *)(wp + s2 * 16);
+  }
+  const int cb2 = a.n1c == 2 ? (wave & 1) : 0, rb2 = a.n1c == 2 ? (wave >> 1) : wave;  // layer-2 block of this wave
+  const bool l2 = rb2 < 2;
+  f16x8 w1[8];
+  if (l2) {
+    const GLOBAL_AS T *wp = gptr<const T>((uint64_t)a.W1) + (size_t)(cb2 * 32 + col) * 128 + half * 8;
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) w1[s2] = *(const GLOBAL_AS f16x8 *)(wp + s2 * 16);
+  }
+  {
+    const int ppr = a.k0 >> 3;
+    for (int i = tid; i < 64 * ppr; i += 256) {
+      const int r = i / ppr, pc = i - r * ppr;
+      int grow = row0 + r;
+      grow = grow < a.rows ? grow : a.rows - 1;
+      *reinterpret_cast<u32x4 *>(xs + r * LDX + pc * 8) = *(const GLOBAL_AS u32x4 *)(gptr<const T>((uint64_t)a.X) + (size_t)grow * a.x_ld + pc * 8);
+    }
+  }
+  float bia[16], gam[16], bet[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 b4 = *reinterpret_cast<const float4 *>(a.v0 + wave * 32 + 8 * q + 4 * half);
+    const float4 g4 = *reinterpret_cast<const float4 *>(a.v0 + 128 + wave * 32 + 8 * q + 4 * half);
+    const float4 t4 = *reinterpret_cast<const float4 *>(a.v0 + 256 + wave * 32 + 8 * q + 4 * half);
+    bia[4 * q] = b4.x; bia[4 * q + 1] = b4.y; bia[4 * q + 2] = b4.z; bia[4 * q + 3] = b4.w;
+    gam[4 * q] = g4.x; gam[4 * q + 1] = g4.y; gam[4 * q + 2] = g4.z; gam[4 * q + 3] = g4.w;
+    bet[4 * q] = t4.x; bet[4 * q + 1] = t4.y; bet[4 * q + 2] = t4.z; bet[4 * q + 3] = t4.w;
+  }
+  float b1v[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 b4 = l2 ? *reinterpret_cast<const float4 *>(a.b1 + cb2 * 32 + 8 * q + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+    b1v[4 * q] = b4.x; b1v[4 * q + 1] = b4.y; b1v[4 * q + 2] = b4.z; b1v[4 * q + 3] = b4.w;
+  }
+  __syncthreads();
+  // ---- layer 1: channel block `wave`, both 32-row blocks; D[channel][row]: lane = row, reg r = channel (r&3)+8(r>>2)+4 half
+  f32x16 acc[2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+#pragma unroll
+  for (int s2 = 0; s2 < K0MAX / 16; ++s2)
+    if (s2 < nk0) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const f16x8 xb = *reinterpret_cast<const f16x8 *>(xs + (rb * 32 + col) * LDX + s2 * 16 + half * 8);
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[s2], xb, acc[rb], 0, 0, 0);
+      }
+    }
+  // bias, GroupNorm(32, 128) = groups of four consecutive channels = the four registers 4q .. 4q+3 of a lane, statistics over
+  // the sample's 16 rows = 16 lanes; ReLU; fp16 into LDS [row][channel]
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[4], s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = acc[rb][4 * q + j] + bia[4 * q + j];
+        s += v[j];
+        ss = fmaf(v[j], v[j], ss);
+      }
+      s = lane_group_sum<16>(s);
+      ss = lane_group_sum<16>(ss);
+      const float mean = s * (1.0f / 64.0f);
+      const float var = fmaxf(ss * (1.0f / 64.0f) - mean * mean, 0.f);
+      const float rstd = __builtin_amdgcn_rsqf(var + GN_EPS);
+      f16x4 h;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float g = gam[4 * q + j] * rstd;
+        h[j] = (T)fmaxf(fmaf(v[j], g, bet[4 * q + j] - mean * g), 0.f);
+      }
+      *reinterpret_cast<f16x4 *>(hs + (rb * 32 + col) * LDH + wave * 32 + 8 * q + 4 * half) = h;
+    }
+  }
+  __syncthreads();
+  // ---- layer 2 + update
+  if (l2) {
+    f32x16 e2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e2[r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) {
+      const f16x8 hb = *reinterpret_cast<const f16x8 *>(hs + (rb2 * 32 + col) * LDH + s2 * 16 + half * 8);
+      e2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[s2], hb, e2, 0, 0, 0);
+    }
+    const int p = row0 + rb2 * 32 + col;
+    if (p < a.rows) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = cb2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float ev = e2[r] + b1v[r];
+        if (a.eps_out && c < a.eps_ld) a.eps_out[(size_t)p * a.eps_ld + c] = ev;
+        if (c >= a.C) continue;
+        const int e = p * a.C + c;
+        if (a.kind == 1) {
+          update_feat_element(e, a.rows, a.C, a.kdim, 0, a.clamp, a.seed_lo, a.seed_hi, a.x, nullptr, a.noise, t, step, nonce, eoff,
+                              a.complete_x0, a.kmask, a.keypoint, a.t0, a.t1, a.t2, a.t3, a.t4, a.feat0, a.ldf, a.half_out,
+                              a.copies, a.n_copies, ev);
+        } else {  // position DDPM: x = (x - c_eps[t] eps) / sqrt_alpha[t] (+ sigma[t] z)   (tables t0, t1, t2)
+          float v = (a.x[e] - a.t0[t] * ev) / a.t1[t];
+          if (t > 0) {
+            const float z = a.noise ? a.noise[(size_t)step * a.rows * 3 + e]
+                                    : philox_normal(a.seed_lo, a.seed_hi, (uint32_t)step, (uint32_t)e + (uint32_t)a.t_dev[4] * 48u, nonce);
+            v = v + a.t2[t] * z;
+          }
+          a.x[e] = v;
+        }
+      }
+    }
+  }
+  advance_t_last_block(a.t_dev, t, step);
 }
 
 __global__ void advance_t_kernel(int *t_dev) {
@@ -2345,6 +2492,17 @@ int run_op(const SlideOp &o, hipStream_t s) {
                          (const float *)o.p[10], (const float *)o.p[11], o.p[12], o.i[6], o.i[7],
                          (const SlidePrepCopy *)o.p[13], o.i[8]);
       break;
+    case SLIDE_OP_HEAD_UPDATE: {
+      const SlideHeadArgs *h = (const SlideHeadArgs *)o.p[0];  // HOST pointer, kept alive by the plan
+      if (!h || h->rows <= 0 || h->rows % 16 || h->k0 % 32 || h->k0 <= 0 || h->k0 > 160 || h->x_ld < h->k0 || h->x_ld % 8 ||
+          (h->n1c != 1 && h->n1c != 2) || !h->X || !h->W0 || !h->W1 || !h->v0 || !h->b1 || !h->x || !h->t_dev ||
+          (h->kind != 0 && h->kind != 1) || h->C > 32 * h->n1c)
+        return -3;
+      const int grid = (h->rows + 63) / 64;
+      if (h->k0 <= 96) hipLaunchKernelGGL(head_update_kernel<96>, dim3(grid), dim3(256), 0, s, *h);
+      else hipLaunchKernelGGL(head_update_kernel<160>, dim3(grid), dim3(256), 0, s, *h);
+      break;
+    }
     case SLIDE_OP_ATTN_TAIL:
       return run_attn_tail(o, s);
     case SLIDE_OP_GEMM_GX:

@@ -93,6 +93,33 @@ class _GraphedSampler:
             update_op.p[13], update_op.i[8] = prep.p[6], prep.i[4]
             drop = drop | {e._prep_idx}
             self.fuse_prep = True
+        # OPT-IN (SLIDE_HEAD_UPDATE=1): output head + update as ONE launch (SLIDE_OP_HEAD_UPDATE, csrc/engine.hip
+        # head_update_kernel) -- the two per-point head GEMMs and the update kernel leave the step plan.  97 launches per joint
+        # step instead of 105, but 384.1 vs 389.4 shapes/s: one workgroup per four samples runs the layers, the Philox draws and
+        # the state update of 3264 elements in sequence, where the three launches spread them over 22 + 44 + 71 workgroups
+        head = getattr(e, "head", None)
+        if (head is not None and os.environ.get("SLIDE_HEAD_UPDATE", "0") != "0" and update_op.kind in (OP_UPDATE_POS, OP_UPDATE_FEAT)
+                and e.ops[head["idx"][0]].kind == 1 and e.ops[head["idx"][1]].kind == 1 and head["idx"][1] == e.eps_copy_idx - 1):
+            from .engine import OP_HEAD_UPDATE, SlideHeadArgs
+            h, u = SlideHeadArgs(), update_op
+            h.X, h.W0, h.W1, h.v0, h.b1 = (head[k_].data_ptr() for k_ in ("X", "W0", "W1", "v0", "b1"))
+            h.eps_out = None
+            h.rows, h.x_ld, h.k0, h.n1c, h.eps_ld = self.B * 16, head["X"].shape[1], head["k0"], head["n1c"], e.eps_pad.shape[1]
+            h.x, h.noise, h.t_dev = u.p[0], u.p[2], u.p[3]
+            if u.kind == OP_UPDATE_POS:
+                h.kind, h.C, h.kdim = 0, 3, 0
+                h.seed_lo, h.seed_hi = u.i[2] & 0xFFFFFFFF, u.i[3] & 0xFFFFFFFF
+                h.t0, h.t1, h.t2 = u.p[4], u.p[5], u.p[6]
+            else:
+                h.kind, h.C, h.kdim = 1, u.i[1], u.i[2]
+                h.seed_lo, h.seed_hi = u.i[3] & 0xFFFFFFFF, u.i[4] & 0xFFFFFFFF
+                h.clamp = u.f[0]
+                h.keypoint, h.t0, h.t1, h.t2, h.t3, h.t4 = u.p[4], u.p[5], u.p[6], u.p[7], u.p[8], u.p[9]
+                h.complete_x0, h.kmask = u.p[10], u.p[11]
+                h.feat0, h.ldf, h.half_out, h.copies, h.n_copies = u.p[12], u.i[6], u.i[7], u.p[13], u.i[8]
+            self._head_args = h  # (kept alive: the op carries its address)
+            update_op = make_op(OP_HEAD_UPDATE, p=(ctypes.addressof(h),))
+            drop = drop | set(head["idx"])
         kept = [i for i in range(len(e.ops)) if i not in drop]
         ops = [e.ops[i] for i in kept]
         # per-launch accounting of the engine, re-keyed by position in the step plan

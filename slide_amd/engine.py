@@ -24,7 +24,7 @@ PREC = {"fp32": 0, "fp16": 1}
  OP_COND, OP_UPDATE_POS, OP_UPDATE_FEAT, OP_ADVANCE_T) = range(1, 13)
 OP_SYNC = 14
 OP_ATTN_TAIL = 16
-OP_GEMM_GX, OP_PAIR_NORM, OP_SA_CHAIN, OP_BLOCK_BODY, OP_PAIR_FIRST, OP_GEMM_CHAIN = 17, 18, 19, 30, 31, 32
+OP_GEMM_GX, OP_PAIR_NORM, OP_SA_CHAIN, OP_BLOCK_BODY, OP_PAIR_FIRST, OP_GEMM_CHAIN, OP_HEAD_UPDATE = 17, 18, 19, 30, 31, 32, 33
 
 
 class SlideEpi(ctypes.Structure):
@@ -73,6 +73,20 @@ class BodyArgs(ctypes.Structure):  # csrc/block_body.hip (same field order: natu
 class SlideChainLayer(ctypes.Structure):  # include/slide_engine.h
     _fields_ = [("X", ctypes.c_void_p), ("W", ctypes.c_void_p), ("epi", ctypes.c_void_p),
                 ("x_ld", ctypes.c_int32), ("k_pad", ctypes.c_int32), ("n_cob", ctypes.c_int32), ("pad", ctypes.c_int32)]
+
+
+class SlideHeadArgs(ctypes.Structure):  # include/slide_engine.h
+    _fields_ = [("X", ctypes.c_void_p), ("W0", ctypes.c_void_p), ("W1", ctypes.c_void_p), ("v0", ctypes.c_void_p),
+                ("b1", ctypes.c_void_p), ("eps_out", ctypes.c_void_p),
+                ("rows", ctypes.c_int32), ("x_ld", ctypes.c_int32), ("k0", ctypes.c_int32), ("n1c", ctypes.c_int32),
+                ("eps_ld", ctypes.c_int32),
+                ("kind", ctypes.c_int32), ("C", ctypes.c_int32), ("kdim", ctypes.c_int32), ("ldf", ctypes.c_int32),
+                ("half_out", ctypes.c_int32), ("n_copies", ctypes.c_int32),
+                ("clamp", ctypes.c_float), ("seed_lo", ctypes.c_uint32), ("seed_hi", ctypes.c_uint32),
+                ("x", ctypes.c_void_p), ("noise", ctypes.c_void_p), ("t_dev", ctypes.c_void_p),
+                ("keypoint", ctypes.c_void_p), ("t0", ctypes.c_void_p), ("t1", ctypes.c_void_p), ("t2", ctypes.c_void_p),
+                ("t3", ctypes.c_void_p), ("t4", ctypes.c_void_p), ("complete_x0", ctypes.c_void_p), ("kmask", ctypes.c_void_p),
+                ("feat0", ctypes.c_void_p), ("copies", ctypes.c_void_p)]
 
 
 class SlideOp(ctypes.Structure):
@@ -1284,11 +1298,25 @@ class DenoiserEngine:
                                     p=(self.xyz.data_ptr(), dec0.data_ptr() + dec0.element_size() * c)))
         hh = self._buf(B * 16, sd["fc_lyaer.0.weight"].shape[0])
         assert sd["fc_lyaer.0.weight"].shape[1] == c + 3
+        head_i0 = len(self.ops)
         self._gemm(dec0, 4, [dict(w=self._w("fc_lyaer.0.weight"), bias=sd["fc_lyaer.0.bias"], mode=EPI_NORM,
                                   flags=F_POST_RELU, layout=gn_layout(sd["fc_lyaer.0.weight"].shape[0]), out=hh,
                                   gn=(sd["fc_lyaer.1.weight"], sd["fc_lyaer.1.bias"]))])
         self.eps_pad = self._buf(B * 16, self.out_dim, dtype=torch.float32)
         self._gemm(hh, 4, [dict(w=self._w("fc_lyaer.3.weight"), bias=sd["fc_lyaer.3.bias"], mode=EPI_RAW, out=self.eps_pad)])
+        # what SLIDE_OP_HEAD_UPDATE needs (the samplers replace the two head GEMMs + their update launch by it, diffusion.py)
+        self.head = None
+        w0, w1 = self._w("fc_lyaer.0.weight"), self._w("fc_lyaer.3.weight")
+        lay0 = gn_layout(w0.shape[0])
+        if (self.prec == 1 and w0.shape[0] == 128 and np.array_equal(lay0[0], np.arange(128)) and lay0[3] == 4 and lay0[2] == 128
+                and dec0.shape[1] <= 160 and w1.shape[1] == 128 and self.out_dim <= 64 and sd["fc_lyaer.1.weight"].shape[0] == 128):
+            W0 = np.zeros((128, dec0.shape[1]), np.float32); W0[:, :w0.shape[1]] = w0
+            n1c = ru(self.out_dim) // 32
+            W1 = np.zeros((n1c * 32, 128), np.float32); W1[:w1.shape[0]] = w1
+            b1 = np.zeros(n1c * 32, np.float32); b1[:w1.shape[0]] = sd["fc_lyaer.3.bias"]
+            v0 = np.stack([sd["fc_lyaer.0.bias"], sd["fc_lyaer.1.weight"], sd["fc_lyaer.1.bias"]]).astype(np.float32)
+            self.head = dict(idx=[head_i0, head_i0 + 1], X=dec0, k0=dec0.shape[1], n1c=n1c,
+                             W0=self.A.put(W0, torch.float16), W1=self.A.put(W1, torch.float16), v0=self.A.put(v0), b1=self.A.put(b1))
         self.eps = A.zeros(B, 16, self.out_dim)
         self.eps_copy_idx = len(self.ops)  # samplers read eps_pad directly and drop this op
         self._emit(make_op(OP_COPY_COLS, i=(B * 16, self.out_dim, self.eps_pad.shape[1], self.out_dim, 0, 0),
@@ -1383,6 +1411,10 @@ class DenoiserEngine:
         self.gemm_flops, self.gemm_bytes, self.kernel_names = flops, nbytes, names
         self.xyz_copy_idx = [remap[q] for q in self.xyz_copy_idx]
         self.eps_copy_idx = remap[self.eps_copy_idx]
+        if self.head is not None:
+            self.head["idx"] = [remap[q] for q in self.head["idx"]]
+            if len(set(self.head["idx"])) != 2:
+                self.head = None  # (the head GEMMs went into a chain launch)
         self._prep_idx = remap[self._prep_idx]
         self._body_args = {remap[q]: v for q, v in self._body_args.items()}
         self._tail_of = {k_: remap[v] for k_, v in self._tail_of.items()}

@@ -205,6 +205,34 @@ def test_point_preparation_folded_into_the_update(gpu_device, monkeypatch, prec)
     assert np.isfinite(out["1"][0]).all() and np.array_equal(out["1"][0], out["0"][0]) and np.array_equal(out["1"][1], out["0"][1])
 
 
+def test_head_and_update_as_one_launch(gpu_device, monkeypatch):
+    """SLIDE_OP_HEAD_UPDATE: fc_lyaer's two per-point GEMMs (GroupNorm between them) and the DDPM update in one launch -- the
+    prediction never leaves the registers.  Against the three-launch plan (SLIDE_HEAD_UPDATE=0: same arithmetic, other
+    summation order in the K loops) over 10 steps with in-kernel noise: position and feature chains within 5e-4 relative
+    max; the golden-chain tests run on the fused plan (the default)."""
+    from slide_amd.diffusion import FeatureSampler, PositionSampler
+    g = load_golden("golden_sampler_feat.npz")
+    _, hpf, sdf = _load("feat")
+    _, hpp, sdp = _load("pos")
+    cfg = json.loads(str(g["config_json"]))
+    size = g["head_x"].shape
+    rs = np.random.RandomState(5)
+    xf = rs.standard_normal(size).astype(np.float32)
+    xp = rs.standard_normal((size[0], 16, 3)).astype(np.float32)
+    out = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("SLIDE_HEAD_UPDATE", fuse)
+        fs = FeatureSampler(hpf, sdf, size[0], gpu_device, cfg, prec="fp16", seed=9, use_graph=False)
+        ps = PositionSampler(hpp, sdp, size[0], gpu_device, _pos_cfg(), prec="fp16", seed=9, use_graph=False)
+        for smp in (fs, ps):
+            kinds = [o.kind for o in smp.step_ops]
+            assert (33 in kinds) == (fuse == "1") and ((10 in kinds) or (11 in kinds)) == (fuse == "0")
+        out[fuse] = (fs.sample(g["label"], g["keypoint"], xf, t_start=60, n_steps=10).cpu().numpy(),
+                     ps.sample(g["label"], xp, t_start=60, n_steps=10).cpu().numpy())
+    for a_, b_ in zip(out["1"], out["0"]):
+        assert np.isfinite(a_).all() and _rel(a_, b_) <= 5e-4, _rel(a_, b_)
+
+
 def test_position_sampler_full_chain_matches_reference(gpu_device):
     from slide_amd.diffusion import PositionSampler
     g = load_golden("golden_sampler_pos.npz")
