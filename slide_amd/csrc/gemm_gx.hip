@@ -41,8 +41,15 @@ __device__ __forceinline__ void gemm_gx_body(const GemmArgs &a) {
   constexpr bool FP = NPXL == 7;
   constexpr int NSAMP = TM >> NPXL;            // 1 or 2
   constexpr int NR = 16 * NSAMP;               // table rows in LDS
-  constexpr int CH_B = 32 * CBW * 64, STAGE_B = 2 * CH_B;  // a chunk image: [32 CBW weight rows][64 B]
-  constexpr int NJ = CBW / 2;                              // DMA instructions per wave and chunk image (16 rows each)
+  constexpr int CH_B = 32 * CBW * 64;                      // a weight chunk image: [32 CBW weight rows][64 B]
+  constexpr int NJ = CBW / 2;                              // weight DMA instructions per wave and chunk image (16 rows each)
+  // the sample's pair tables STREAM with the weights (round 3): a stage also carries, per 32-deep chunk and table, the image
+  // [4 sixteen-byte pieces][NR rows][8 halves] = 64 NR bytes -- instead of both tables staged whole before the K loop
+  // (2 x 16 x k_pad x 2 B per sample: 69 KB on the FP1 layer, which pinned that launch to one workgroup per CU, and a 2 - 3 us
+  // prologue on every workgroup)
+  constexpr int TBL_B = 64 * NR;                           // one (chunk, table) image
+  constexpr int STAGE_B = 2 * CH_B + 4 * TBL_B;
+  constexpr int NTI = NSAMP;                               // table DMA instructions per wave and stage (1 KB each)
   constexpr int NVEC = (MODE ? 2 : 1) + (FP ? 2 : 0);  // fp16 vectors per sample in LDS: [add | scale, shift][vd, vw][k_pad]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int ntc = (a.n_cob + CBW - 1) / CBW;
@@ -58,10 +65,7 @@ __device__ __forceinline__ void gemm_gx_body(const GemmArgs &a) {
   SLIDE_STAMP(a, 0);
   uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + (size_t)NST * STAGE_B);
   float *const vec_lds = reinterpret_cast<float *>(epi_lds + CBW * EPI_DW + (CBW * EPI_DW) % 4);
-  unsigned char *const ta_l = reinterpret_cast<unsigned char *>(vec_lds + CBW * 96);
-  const int tab_b = (a.k_pad >> 3) * NR * 16;  // bytes of one table image
-  unsigned char *const tb_l = ta_l + tab_b;
-  T *const vv_l = reinterpret_cast<T *>(tb_l + tab_b);
+  T *const vv_l = reinterpret_cast<T *>(vec_lds + CBW * 96);
   const int nsm = a.rows >> NPXL, smp0 = row0 >> NPXL;
 
   // ---- per-sample vectors first (plain loads, converted to fp16): their latency runs under everything issued below
@@ -118,20 +122,18 @@ __device__ __forceinline__ void gemm_gx_body(const GemmArgs &a) {
   stage_epilogue_tables<CBW, 256>(a, cob0, tid, epi_lds, vec_lds);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every plain load above has landed: from here the VM counter counts DMA only
 
-  // ---- tables by LDS-DMA: instruction i carries 64 / NR pieces x NR rows (1 KB); lane -> (piece, row)
-  {
-    constexpr int PPI = 64 / NR;                 // pieces per instruction (4 or 2)
-    const int r = lane & (NR - 1), pl = lane / NR;
+  // ---- table stream: this wave's NTI instructions per stage; instruction id = wave + 4 n -> (chunk of the stage, table, piece half)
+  const T *tsrc[NTI];
+  int tdst[NTI];
+#pragma unroll
+  for (int n = 0; n < NTI; ++n) {
+    const int id = wave + 4 * n;                       // SA: 0..3 = (c2, t); FP: 0..7 = (c2, t, h)
+    const int c2 = FP ? (id >> 2) & 1 : (id >> 1) & 1, t = FP ? (id >> 1) & 1 : id & 1, h = FP ? id & 1 : 0;
+    const int piece = FP ? 2 * h + (lane >> 5) : lane >> 4, r = lane & (NR - 1);
     int smp = smp0 + (r >> 4);
     smp = smp < nsm ? smp : nsm - 1;
-    const size_t grow = ((size_t)smp * 16 + (r & 15)) * a.gx_ld;
-    const int nins = (a.k_pad >> 3) / PPI;       // per table (k_pad is a multiple of 32)
-    for (int i = wave; i < 2 * nins; i += 4) {
-      const int t = i >= nins, ii = t ? i - nins : i;
-      const T *src = reinterpret_cast<const T *>(t ? a.gx_tb : a.gx_ta) + grow + (ii * PPI + pl) * 8;
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)src,
-                                       (__attribute__((address_space(3))) void *)((t ? tb_l : ta_l) + ii * 1024), 16, 0, 0);
-    }
+    tsrc[n] = reinterpret_cast<const T *>(t ? a.gx_tb : a.gx_ta) + ((size_t)smp * 16 + (r & 15)) * a.gx_ld + piece * 8;
+    tdst[n] = 2 * CH_B + (c2 * 2 + t) * TBL_B + (FP ? 2 * h * NR * 16 : 0);
   }
   // ---- weight ring: this lane's source piece of the wave's two DMA instructions per 32-deep chunk
   const T *wsrc[NJ];
@@ -155,6 +157,13 @@ __device__ __forceinline__ void gemm_gx_body(const GemmArgs &a) {
         __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(wsrc[j] + (size_t)kc * w_cs),
                                          (__attribute__((address_space(3))) void *)(dst + c2 * CH_B + (j * 4 + wave) * 1024),
                                          16, 0, 0);
+    }
+#pragma unroll
+    for (int n = 0; n < NTI; ++n) {
+      int kc = st * 2 + (FP ? n : (wave >> 1));  // the chunk of the stage this instruction serves (id = wave + 4 n)
+      kc = kc < nk32 ? kc : nk32 - 1;
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(tsrc[n] + kc * 32),
+                                       (__attribute__((address_space(3))) void *)(dst + tdst[n]), 16, 0, 0);
     }
   };
 #pragma unroll
@@ -187,12 +196,13 @@ __device__ __forceinline__ void gemm_gx_body(const GemmArgs &a) {
 #pragma unroll
     for (int cb = 0; cb < CBW; ++cb)
       o.af[cb] = *reinterpret_cast<const f16x8 *>(sb + c2 * CH_B + wrow[cb] + ((piece ^ wkey[cb]) << 4));
-    const int pb = (kc * 4 + st2 * 2) * NR * 16;  // byte offset of this step's first piece inside a table image
-    o.kb = (kc * 32 + st2 * 16) * 2;              // ... and inside a vector
-    o.av[0] = *reinterpret_cast<const f16x8 *>(ta_l + pb + aoff[0]);
-    if (FP) o.av[FP ? 1 : 0] = *reinterpret_cast<const f16x8 *>(ta_l + pb + aoff[1]);  // (natural order: q is the same in both blocks)
-    o.bv[0] = *reinterpret_cast<const f16x8 *>(tb_l + pb + boff[0]);
-    o.bv[1] = *reinterpret_cast<const f16x8 *>(tb_l + pb + boff[1]);
+    const unsigned char *ta_s = sb + 2 * CH_B + (c2 * 2) * TBL_B + st2 * 2 * NR * 16;  // this step's pieces of the a image
+    const unsigned char *tb_s = ta_s + TBL_B;
+    o.kb = (kc * 32 + st2 * 16) * 2;              // byte offset of this step inside a vector
+    o.av[0] = *reinterpret_cast<const f16x8 *>(ta_s + aoff[0]);
+    if (FP) o.av[FP ? 1 : 0] = *reinterpret_cast<const f16x8 *>(ta_s + aoff[1]);  // (natural order: q is the same in both blocks)
+    o.bv[0] = *reinterpret_cast<const f16x8 *>(tb_s + boff[0]);
+    o.bv[1] = *reinterpret_cast<const f16x8 *>(tb_s + boff[1]);
   };
   auto compute_step = [&](const Step &o) __attribute__((always_inline)) {
     const f16x2 zero2 = {0, 0};
@@ -228,7 +238,7 @@ __device__ __forceinline__ void gemm_gx_body(const GemmArgs &a) {
   };
   // stage st must have landed before anyone reads it; the next one (2 NJ instructions per wave) may stay in flight
   auto stage_ready = [&](int st) __attribute__((always_inline)) {
-    if (st + 1 < nks && NST > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJ) : "memory");
+    if (st + 1 < nks && NST > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJ + NTI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // (first pass: also publishes the tables and vectors staged above)
     if (st + NST - 1 < nks) issue(st + NST - 1);  // overwrites the stage consumed at st - 1
@@ -519,9 +529,11 @@ __global__ __launch_bounds__(1024) void pair_norm2_kernel(int ld, const float *_
 template <int NPXL, int NST, int MODE, int CBW = 4, bool OCC3 = true>
 int launch_gx(const GemmArgs &a, hipStream_t s) {
   constexpr int NSAMP = TM >> NPXL, NVEC = (MODE ? 2 : 1) + (NPXL == 7 ? 2 : 0);
-  const size_t shm = (size_t)NST * 4096 * CBW + (CBW * EPI_DW + (CBW * EPI_DW) % 4 + CBW * 96) * 4 +
-                     (size_t)2 * NSAMP * 16 * a.k_pad * 2 + (size_t)NSAMP * NVEC * a.k_pad * 2 + 16;
-  if (shm > (CBW == 2 && OCC3 ? 53 : 160) * 1024) return -8;  // (three workgroups per CU must fit for the OCC3 form)
+  const size_t shm = (size_t)NST * (4096 * CBW + 4 * 64 * 16 * NSAMP) + (CBW * EPI_DW + (CBW * EPI_DW) % 4 + CBW * 96) * 4 +
+                     (size_t)NSAMP * NVEC * a.k_pad * 2 + 16;
+  // the OCC3 form needs three workgroups per CU, the others two (the tables stream through the ring, so only the per-sample
+  // vectors grow with K)
+  if (shm > (CBW == 2 && OCC3 ? 53 : 80) * 1024) return -8;
   const int ntc = (a.n_cob + CBW - 1) / CBW, ntr = (a.rows + TM - 1) / TM;
   const int grid = ((ntr + 7) / 8) * 8 * ntc;
   static bool attr_done[SLIDE_MAX_DEVICES] = {};
@@ -583,21 +595,25 @@ int slide_launch_gemm_gx(const SlideOp &o, hipStream_t s) {
   const int n64 = (int)o.f[0];
   if (npxl == 7 && (!a.gidx || !a.gx_d2 || !a.gx_w)) return -3;
   // (mode 1 only -- the keys -> u layers: with mode 0's PAIR residual the epilogue does not fit 168 registers)
-  if (n64 == 1 && m1) {
-    int st = -8;
+  int st = -8;
+  if (n64 == 1 && m1) {  // 64-channel tiles at three workgroups per CU (a two-stage ring of this form spills at 168 registers)
     if (npxl == 8) st = launch_gx<8, 3, 1, 2>(a, s);
     else if (npxl == 7) st = launch_gx<7, 3, 1, 2>(a, s);
     if (st != -8) return st;
   }
   if (n64 == 2) {
-    int st = -8;
     if (npxl == 8) st = m1 ? launch_gx<8, 3, 1, 2, false>(a, s) : launch_gx<8, 3, 0, 2, false>(a, s);
     else if (npxl == 7) st = m1 ? launch_gx<7, 3, 1, 2, false>(a, s) : launch_gx<7, 3, 0, 2, false>(a, s);
     if (st != -8) return st;
   }
-  if (npxl == 8) return m1 ? launch_gx<8, 3, 1>(a, s) : launch_gx<8, 3, 0>(a, s);
+  // 128-channel tiles at two workgroups per CU: three ring stages, else two
+  if (npxl == 8) {
+    st = m1 ? launch_gx<8, 3, 1>(a, s) : launch_gx<8, 3, 0>(a, s);
+    if (st == -8) st = m1 ? launch_gx<8, 2, 1>(a, s) : launch_gx<8, 2, 0>(a, s);
+    return st;
+  }
   if (npxl == 7) {
-    int st = m1 ? launch_gx<7, 3, 1>(a, s) : launch_gx<7, 3, 0>(a, s);
+    st = m1 ? launch_gx<7, 3, 1>(a, s) : launch_gx<7, 3, 0>(a, s);
     if (st == -8) st = m1 ? launch_gx<7, 2, 1>(a, s) : launch_gx<7, 2, 0>(a, s);
     return st;
   }

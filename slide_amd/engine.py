@@ -476,17 +476,22 @@ class DenoiserEngine:
         assert (npx_log2 == 7) == (pair_tabs is not None)
         # (the launcher's choice, csrc/gemm_gx.hip: mode-1 layers run 256 x 64 tiles when three workgroups fit a CU's LDS)
         nsamp, nvec = 256 >> npx_log2, (2 if gx["mode"] else 1) + (2 if npx_log2 == 7 else 0)
-        shm64 = 3 * 8192 + (2 * 40 + 2 * 96) * 4 + 2 * nsamp * 16 * ld * 2 + nsamp * nvec * ld * 2 + 16
+        # (LDS of the 64-channel form: ring stages of 8 KB of weights + 4 KB of streamed table images per sample, epilogue
+        #  descriptors, per-sample vectors; three stages, else two)
+        shm64 = lambda nst: nst * (8192 + 4096 * nsamp) + (2 * 40 + 2 * 96) * 4 + nsamp * nvec * ld * 2 + 16
         knob = os.environ.get("SLIDE_GX_N64", "1")
-        n64 = 0
-        if knob != "0" and gx["mode"] == 1 and shm64 <= 53 * 1024:
+        n64, nst = 0, 3
+        if knob != "0" and gx["mode"] == 1 and shm64(3) <= 53 * 1024:
             n64 = 1
         elif knob != "0" and os.environ.get("SLIDE_GX_N64W", "0") != "0" and n_cob > 2 and ((rows + 255) // 256) * ((n_cob + 3) // 4) <= 256:
             # (opt-in: where the 128-channel grid would leave CUs empty -- the FP blocks at 88 samples, 96 workgroups -- 64-channel
             #  tiles at two workgroups per CU, either mode.  Measured 385.4 vs 386.6 shapes/s without: with four chains in flight the
             #  other chains' workgroups already fill those CUs)
             n64 = 2
-        self.kernel_names[len(self.ops)] = "gemm_gx_%skernel<%d, 3, %d>" % (("", "n64_", "n64w_")[n64], npx_log2, gx["mode"])
+        if n64 == 0:  # 128-channel tiles: two workgroups per CU (80 KB each)
+            shm128 = lambda k_: k_ * (16384 + 4096 * nsamp) + (4 * 40 + 4 * 96) * 4 + nsamp * nvec * ld * 2 + 16
+            nst = 3 if shm128(3) <= 80 * 1024 else 2
+        self.kernel_names[len(self.ops)] = "gemm_gx_%skernel<%d, %d, %d>" % (("", "n64_", "n64w_")[n64], npx_log2, nst, gx["mode"])
         self._emit(make_op(OP_GEMM_GX,
                            i=(rows, ta.shape[1], ld, n_cob, npx_log2, in_bs, gx["mode"], 0 if add is None else add[2],
                               0 if add is None else add[4], 0 if vv is None else 2 * vv.shape[2]),
