@@ -483,10 +483,10 @@ class DenoiserEngine:
         n64, nst = 0, 3
         if knob != "0" and gx["mode"] == 1 and shm64(3) <= 53 * 1024:
             n64 = 1
-        elif knob != "0" and os.environ.get("SLIDE_GX_N64W", "0") != "0" and n_cob > 2 and ((rows + 255) // 256) * ((n_cob + 3) // 4) <= 256:
-            # (opt-in: where the 128-channel grid would leave CUs empty -- the FP blocks at 88 samples, 96 workgroups -- 64-channel
-            #  tiles at two workgroups per CU, either mode.  Measured 385.4 vs 386.6 shapes/s without: with four chains in flight the
-            #  other chains' workgroups already fill those CUs)
+        elif knob != "0" and os.environ.get("SLIDE_GX_N64W", "1") != "0" and n_cob > 2 and ((rows + 255) // 256) * ((n_cob + 3) // 4) <= 256:
+            # where the 128-channel grid would leave CUs empty -- the FP blocks at 88 samples: 96 workgroups -- 64-channel tiles at
+            # two workgroups per CU, either mode (SLIDE_GX_N64W=0: 128-channel tiles).  Neutral while the staged tables pinned
+            # these launches to one workgroup per CU (385.4 vs 386.6); with the tables streamed through the ring 394.3 vs 390.2
             n64 = 2
         if n64 == 0:  # 128-channel tiles: two workgroups per CU (80 KB each)
             shm128 = lambda k_: k_ * (16384 + 4096 * nsamp) + (4 * 40 + 4 * 96) * 4 + nsamp * nvec * ld * 2 + 16
