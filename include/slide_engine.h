@@ -131,6 +131,9 @@ enum {
                              * as ONE launch (csrc/gemm_chain.hip): a workgroup owns 64 rows and walks the layers, each through the common
                              * epilogue of its SlideEpi descriptors.  p[0]: HOST pointer to SlideChainLayer[n] (device pointers inside), kept
                              * alive by the plan.  i: rows, n (<= 6) */
+  SLIDE_OP_GEMM_GX_DUAL = 34,/* two independent SLIDE_OP_GEMM_GX of one block -- the mode-1 keys -> u layer and the mode-0 first Mlp layer of an FP
+                             * block -- as ONE launch on 64-channel tiles: p[0] = HOST pointer to the two SlideOp (mode 1 first), kept alive
+                             * by the plan; falls back to two launches when the LDS of the dual form does not fit */
   SLIDE_OP_HEAD_UPDATE = 33,/* output head (two per-point GEMMs with the GroupNorm between them) + DDPM update + device-side t -= 1 as one launch
                              * (csrc/engine.hip head_update_kernel): p[0] = HOST pointer to a SlideHeadArgs block */
   SLIDE_OP_BLOCK_BODY = 30, /* the whole K-expanded body of an SA / FP block whose widths are <= 256 channels in one launch (csrc/block_body.hip):

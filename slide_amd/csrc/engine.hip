@@ -23,6 +23,7 @@ int slide_launch_pair_norm(const SlideOp &o, hipStream_t s);
 int slide_launch_sa_chain(const SlideOp &o, hipStream_t s);
 int slide_launch_block_body(const SlideOp &o, hipStream_t s);  // block_body.hip
 int slide_launch_gemm_chain(const SlideOp &o, hipStream_t s);  // gemm_chain.hip
+int slide_launch_gemm_gx_dual(const SlideOp &o, hipStream_t s);  // gemm_gx.hip
 
 namespace {
 
@@ -2507,6 +2508,8 @@ int run_op(const SlideOp &o, hipStream_t s) {
       return run_attn_tail(o, s);
     case SLIDE_OP_GEMM_GX:
       return slide_launch_gemm_gx(o, s);
+    case SLIDE_OP_GEMM_GX_DUAL:
+      return slide_launch_gemm_gx_dual(o, s);
     case SLIDE_OP_PAIR_NORM:
       return slide_launch_pair_norm(o, s);
     case SLIDE_OP_PAIR_FIRST:

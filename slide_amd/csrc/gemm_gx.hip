@@ -35,7 +35,7 @@ constexpr int SLIDE_MAX_DEVICES = 64;
 // the packed-fp16 generation of the next fragments run under the matrix pipe's 256 busy cycles; the ring's wait + barrier of
 // the next stage sits one step early for the same reason.
 template <int NPXL, int NST, int MODE, int CBW>
-__device__ __forceinline__ void gemm_gx_body(const GemmArgs &a) {
+__device__ __forceinline__ void gemm_gx_body(const GemmArgs &a, const int bid) {
   using T = _Float16;
   constexpr int NPX = 1 << NPXL;
   constexpr bool FP = NPXL == 7;
@@ -54,7 +54,7 @@ __device__ __forceinline__ void gemm_gx_body(const GemmArgs &a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int ntc = (a.n_cob + CBW - 1) / CBW;
   const int ntr = (a.rows + TM - 1) / TM;
-  const int xcd = blockIdx.x & 7, q0 = blockIdx.x >> 3;
+  const int xcd = bid & 7, q0 = bid >> 3;
   const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;  // the column tiles of a row tile share one XCD's L2 (weights + tables)
   if (tr >= ntr) return;
   const int row0 = tr * TM, cob0 = tc * CBW;
@@ -283,7 +283,7 @@ __device__ __forceinline__ void gemm_gx_body(const GemmArgs &a) {
 
 template <int NPXL, int NST, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_gx_kernel(GemmArgs a) {
-  gemm_gx_body<NPXL, NST, MODE, 4>(a);
+  gemm_gx_body<NPXL, NST, MODE, 4>(a, blockIdx.x);
 }
 
 // 256 x 64 tiles inside the 168-register budget (64 accumulator registers, 8 KB ring stages): THREE workgroups per CU and
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void gemm_gx_kernel(GemmArgs a) {
 // its life in the table prologue and the epilogue, which a third resident workgroup overlaps
 template <int NPXL, int NST, int MODE>
 __global__ __launch_bounds__(256, 3) void gemm_gx_n64_kernel(GemmArgs a) {
-  gemm_gx_body<NPXL, NST, MODE, 2>(a);
+  gemm_gx_body<NPXL, NST, MODE, 2>(a, blockIdx.x);
 }
 
 // the same 64-channel tile at two workgroups per CU (256 registers: also mode 0 with its PAIR residual): for launches whose
@@ -299,7 +299,16 @@ __global__ __launch_bounds__(256, 3) void gemm_gx_n64_kernel(GemmArgs a) {
 // workgroups in flight and halve each one's K loop and epilogue
 template <int NPXL, int NST, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_gx_n64w_kernel(GemmArgs a) {
-  gemm_gx_body<NPXL, NST, MODE, 2>(a);
+  gemm_gx_body<NPXL, NST, MODE, 2>(a, blockIdx.x);
+}
+
+// TWO independent generated-X GEMMs of one block in ONE launch (SLIDE_OP_GEMM_GX_DUAL): the keys -> u layer (mode 1) and the
+// first Mlp layer (mode 0) of an FP block read the same pair tables and nothing of each other; as one grid they cost one
+// launch gap instead of two and their workgroups fill the chip together (64-channel tiles, two workgroups per CU)
+template <int NPXL>
+__global__ __launch_bounds__(256, 2) void gemm_gx_dual_kernel(GemmArgs a1, GemmArgs a0, int grid1) {
+  if ((int)blockIdx.x < grid1) gemm_gx_body<NPXL, 3, 1, 2>(a1, blockIdx.x);
+  else gemm_gx_body<NPXL, 3, 0, 2>(a0, blockIdx.x - grid1);
 }
 
 // ------------------------------------------------------------------------------------------------ pair-table normalisation
@@ -570,8 +579,10 @@ int launch_gx(const GemmArgs &a, hipStream_t s) {
 
 }  // namespace
 
-int slide_launch_gemm_gx(const SlideOp &o, hipStream_t s) {
-  GemmArgs a = {};
+int slide_launch_gemm_gx(const SlideOp &o, hipStream_t s);
+
+static int gx_args_from_op(const SlideOp &o, GemmArgs &a) {
+  a = GemmArgs();
   a.gx_ta = o.p[0]; a.W = o.p[1]; a.epi = (const SlideEpi *)o.p[2];
   a.in_scale = (const float *)o.p[3]; a.in_shift = (const float *)o.p[4];
   a.gx_tb = o.p[5]; a.in_add = (const float *)o.p[6]; a.gx_add_idx = (const int *)o.p[7];
@@ -587,13 +598,66 @@ int slide_launch_gemm_gx(const SlideOp &o, hipStream_t s) {
   if (a.in_add && ((uintptr_t)a.in_add % 16 || a.add_bs % 4 || a.gx_add_idx_stride % 4)) return -3;  // 16-byte vector loads
   if (a.gx_mode != 0 && ((uintptr_t)a.in_scale % 16 || (uintptr_t)a.in_shift % 16 || a.in_bs % 4)) return -3;
   if (a.gx_vv && ((uintptr_t)a.gx_vv % 16 || a.gx_vbs % 8)) return -3;
+  if (npxl == 7 && (!a.gidx || !a.gx_d2 || !a.gx_w)) return -3;
+  return 0;
+}
+
+template <int NPXL>
+static int launch_gx_dual(const GemmArgs &a1, const GemmArgs &a0, hipStream_t s) {
+  constexpr int NSAMP = TM >> NPXL;
+  auto lds = [&](const GemmArgs &a, int nvec) {
+    return (size_t)3 * (8192 + 4 * 64 * 16 * NSAMP) + (2 * EPI_DW + (2 * EPI_DW) % 4 + 2 * 96) * 4 + (size_t)NSAMP * nvec * a.k_pad * 2 + 16;
+  };
+  const size_t s1 = lds(a1, 2 + (NPXL == 7 ? 2 : 0)), s0 = lds(a0, 1 + (NPXL == 7 ? 2 : 0));
+  const size_t shm = s1 > s0 ? s1 : s0;
+  if (shm > 80 * 1024) return -8;
+  const int ntr = (a1.rows + TM - 1) / TM;
+  const int g1 = ((ntr + 7) / 8) * 8 * ((a1.n_cob + 1) / 2), g0 = ((ntr + 7) / 8) * 8 * ((a0.n_cob + 1) / 2);
+  static bool attr_done[SLIDE_MAX_DEVICES] = {};
+  int d = 0;
+  (void)hipGetDevice(&d);
+  bool &attr_set = attr_done[d >= 0 && d < SLIDE_MAX_DEVICES ? d : 0];
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_gx_dual_kernel<NPXL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  GemmArgs b1 = a1, b0 = a0;
+  b1.shm_bytes = b0.shm_bytes = (int)shm;
+  hipLaunchKernelGGL((gemm_gx_dual_kernel<NPXL>), dim3(g1 + g0), dim3(256), shm, s, b1, b0, g1);
+  return (int)hipGetLastError();
+}
+
+// SLIDE_OP_GEMM_GX_DUAL: p[0] = HOST pointer to two SlideOp (SLIDE_OP_GEMM_GX: mode 1, then mode 0) of the same block
+int slide_launch_gemm_gx_dual(const SlideOp &o, hipStream_t s) {
+  const SlideOp *pr = (const SlideOp *)o.p[0];
+  if (!pr || pr[0].kind != SLIDE_OP_GEMM_GX || pr[1].kind != SLIDE_OP_GEMM_GX) return -3;
+  GemmArgs a1, a0;
+  int st = gx_args_from_op(pr[0], a1);
+  if (st == 0) st = gx_args_from_op(pr[1], a0);
+  if (st != 0) return st;
+  if (a1.gx_mode == 0 || a0.gx_mode != 0 || a1.rows != a0.rows || pr[0].i[4] != pr[1].i[4]) return -3;
+  if (pr[0].i[4] == 8) st = launch_gx_dual<8>(a1, a0, s);
+  else if (pr[0].i[4] == 7) st = launch_gx_dual<7>(a1, a0, s);
+  else return -4;
+  if (st == -8) {  // (LDS of the dual form does not fit: two launches)
+    st = slide_launch_gemm_gx(pr[0], s);
+    if (st == 0) st = slide_launch_gemm_gx(pr[1], s);
+  }
+  return st;
+}
+
+int slide_launch_gemm_gx(const SlideOp &o, hipStream_t s) {
+  GemmArgs a;
+  const int ast = gx_args_from_op(o, a);
+  if (ast != 0) return ast;
+  const int npxl = o.i[4];
   const bool m1 = a.gx_mode != 0;
   // f[0] != 0 (the plan's default, SLIDE_GX_N64): 256 x 64 tiles, three workgroups per CU (128-channel tiles when the LDS does
   // not fit): measured 385 vs 374 shapes/s in bench.py's arrangement
   // f[0] == 2: the 64-channel tile at two workgroups per CU (both modes; the plan asks for it when the 128-channel grid would
   // leave CUs empty)
   const int n64 = (int)o.f[0];
-  if (npxl == 7 && (!a.gidx || !a.gx_d2 || !a.gx_w)) return -3;
   // (mode 1 only -- the keys -> u layers: with mode 0's PAIR residual the epilogue does not fit 168 registers)
   int st = -8;
   if (n64 == 1 && m1) {  // 64-channel tiles at three workgroups per CU (a two-stage ring of this form spills at 168 registers)

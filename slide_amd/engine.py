@@ -24,7 +24,7 @@ PREC = {"fp32": 0, "fp16": 1}
  OP_COND, OP_UPDATE_POS, OP_UPDATE_FEAT, OP_ADVANCE_T) = range(1, 13)
 OP_SYNC = 14
 OP_ATTN_TAIL = 16
-OP_GEMM_GX, OP_PAIR_NORM, OP_SA_CHAIN, OP_BLOCK_BODY, OP_PAIR_FIRST, OP_GEMM_CHAIN, OP_HEAD_UPDATE = 17, 18, 19, 30, 31, 32, 33
+OP_GEMM_GX, OP_PAIR_NORM, OP_SA_CHAIN, OP_BLOCK_BODY, OP_PAIR_FIRST, OP_GEMM_CHAIN, OP_HEAD_UPDATE, OP_GEMM_GX_DUAL = 17, 18, 19, 30, 31, 32, 33, 34
 
 
 class SlideEpi(ctypes.Structure):
@@ -1361,8 +1361,50 @@ class DenoiserEngine:
             prep = self.ops[self._prep_idx]
             prep.p[6], prep.i[4] = self._prep_tab.data_ptr(), len(self._prep_copies)
         self._merge_chains()
+        self._merge_gx_pairs()
         self.step_ops = (SlideOp * len(self.ops))(*self.ops)
         self.cond_ops = (SlideOp * 1)(self.cond_op)
+
+    def _merge_gx_pairs(self):
+        """the mode-1 (keys -> u) and mode-0 (first Mlp layer) generated-X GEMMs of an FP block are independent and adjacent in
+        the plan: where both run 64-channel tiles at two workgroups per CU they become ONE SLIDE_OP_GEMM_GX_DUAL launch
+        (SLIDE_GX_DUAL=0: two launches).  Op-index tables are re-keyed."""
+        if os.environ.get("SLIDE_GX_DUAL", "1") == "0":
+            return
+        new_ops, remap, i = [], {}, 0
+        self._dual_keep = []
+        flops, nbytes, names = {}, {}, {}
+        while i < len(self.ops):
+            a_, b_ = self.ops[i], self.ops[i + 1] if i + 1 < len(self.ops) else None
+            k = len(new_ops)
+            if (a_ is not None and b_ is not None and a_.kind == OP_GEMM_GX and b_.kind == OP_GEMM_GX and a_.i[6] == 1 and b_.i[6] == 0
+                    and a_.f[0] == 2.0 and b_.f[0] == 2.0 and a_.i[0] == b_.i[0] and a_.i[4] == b_.i[4] and a_.i[10] == b_.i[10]):
+                pair = (SlideOp * 2)(SlideOp.from_buffer_copy(bytes(a_)), SlideOp.from_buffer_copy(bytes(b_)))
+                self._dual_keep.append(pair)
+                op = make_op(OP_GEMM_GX_DUAL, i=(a_.i[0],), p=(ctypes.addressof(pair),))
+                op.i[10] = a_.i[10]
+                new_ops.append(op)
+                remap[i] = remap[i + 1] = k
+                flops[k] = self.gemm_flops.get(i, 0) + self.gemm_flops.get(i + 1, 0)
+                nbytes[k] = tuple(self.gemm_bytes.get(i, (0, 0))[z] + self.gemm_bytes.get(i + 1, (0, 0))[z] for z in (0, 1))
+                names[k] = "gemm_gx_dual_kernel<%d>" % a_.i[4]
+                i += 2
+                continue
+            new_ops.append(a_)
+            remap[i] = k
+            for src, dst in ((self.gemm_flops, flops), (self.gemm_bytes, nbytes), (self.kernel_names, names)):
+                if i in src:
+                    dst[k] = src[i]
+            i += 1
+        self.ops = new_ops
+        self.gemm_flops, self.gemm_bytes, self.kernel_names = flops, nbytes, names
+        self.xyz_copy_idx = [remap[q] for q in self.xyz_copy_idx]
+        self.eps_copy_idx = remap[self.eps_copy_idx]
+        self._prep_idx = remap[self._prep_idx]
+        if self.head is not None:
+            self.head["idx"] = [remap[q] for q in self.head["idx"]]
+        self._body_args = {remap[q]: v for q, v in self._body_args.items()}
+        self._tail_of = {k_: remap[v] for k_, v in self._tail_of.items()}
 
     def _merge_chains(self):
         """runs of consecutive per-point GEMM launches (16 rows per sample, fp16, plain input) become ONE SLIDE_OP_GEMM_CHAIN
