@@ -134,6 +134,9 @@ enum {
   SLIDE_OP_GEMM_GX_DUAL = 34,/* two independent SLIDE_OP_GEMM_GX of one block -- the mode-1 keys -> u layer and the mode-0 first Mlp layer of an FP
                              * block -- as ONE launch on 64-channel tiles: p[0] = HOST pointer to the two SlideOp (mode 1 first), kept alive
                              * by the plan; falls back to two launches when the LDS of the dual form does not fit */
+  SLIDE_OP_SA_CHAIN_P = 35, /* an SA block's fused Mlp chain (SLIDE_OP_SA_CHAIN) and the per-point query GEMM of its attention (SLIDE_OP_GEMM, 16 rows per
+                             * sample, input affine + statistics finalisation) in ONE launch -- both depend on the block's pair tables only:
+                             * p[0] = HOST pointer to the two SlideOp (chain first), kept alive by the plan */
   SLIDE_OP_HEAD_UPDATE = 33,/* output head (two per-point GEMMs with the GroupNorm between them) + DDPM update + device-side t -= 1 as one launch
                              * (csrc/engine.hip head_update_kernel): p[0] = HOST pointer to a SlideHeadArgs block */
   SLIDE_OP_BLOCK_BODY = 30, /* the whole K-expanded body of an SA / FP block whose widths are <= 256 channels in one launch (csrc/block_body.hip):

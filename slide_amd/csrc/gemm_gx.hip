@@ -19,6 +19,7 @@
 // softmax-weighted sum over the neighbours) is invariant to the neighbour ORDER, so rows run in natural order (q = j): no
 // index table, and the a-fragment is shared by all row blocks of a wave.
 #include "gemm_common.h"
+#include "gemm_small.h"
 
 namespace {
 
@@ -774,13 +775,13 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 template <int NB1>  // 32-channel blocks of h2 (4 or 8)
-__global__ __launch_bounds__(512, 2) void sa_chain_kernel(F1Args a) {
+__device__ __forceinline__ void sa_chain_body(const F1Args &a, const int bid) {
   using T = _Float16;
   constexpr int NB2 = 8;                       // blocks per stage-2 slab
   constexpr int CH_B = 256 * 64, STAGE_B = 2 * CH_B, NST = 2;
   constexpr int NR = 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int b = blockIdx.x;
+  const int b = bid;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, col = lane & 31;
   const int nk1 = a.k1 >> 5, nk2 = (NB1 * 32) >> 5, nslab = a.n2 >> 8;
@@ -1092,11 +1093,30 @@ __global__ __launch_bounds__(512, 2) void sa_chain_kernel(F1Args a) {
 #endif
 }
 
+template <int NB1>
+__global__ __launch_bounds__(512, 2) void sa_chain_kernel(F1Args a) {
+  sa_chain_body<NB1>(a, blockIdx.x);
+}
+
+// The fused Mlp chain of an SA block AND the per-point query GEMM of its attention (weight_conv.2's query half with the joint
+// GroupNorm finalisation: gemm_small.h, AFF form) in ONE launch (SLIDE_OP_SA_CHAIN_P): both depend on the block's pair tables
+// only and nothing on each other.  Blocks [0, grid_sa) run the chain (eight waves); the others run one 64 x 64 tile of the
+// query GEMM on their first four waves (the other four exit).  The query GEMM's ~10 us launch + gap disappear under the chain.
+template <int NB1>
+__global__ __launch_bounds__(512, 2) void sa_chain_p_kernel(F1Args a, GemmArgs g, int grid_sa) {
+  if ((int)blockIdx.x < grid_sa) {
+    sa_chain_body<NB1>(a, blockIdx.x);
+    return;
+  }
+  if (threadIdx.x >= 256) return;
+  small_body<2, true, 0>(g, PairArgs(), (int)blockIdx.x - grid_sa);
+}
+
 }  // namespace
 
 // SLIDE_OP_SA_CHAIN (include/slide_engine.h)
-int slide_launch_sa_chain(const SlideOp &o, hipStream_t s) {
-  F1Args a = {};
+static int sa_args_from_op(const SlideOp &o, F1Args &a, size_t &shm) {
+  a = F1Args();
   a.ta = o.p[0]; a.tb = o.p[1]; a.ra = o.p[2]; a.rb = o.p[3]; a.W1 = o.p[4]; a.W2 = o.p[5];
   a.vec1 = (const float *)o.p[6]; a.vec2 = (const float *)o.p[7];
   a.add0 = (const float *)o.p[8]; a.add0_idx = (const int *)o.p[9]; a.add1 = (const float *)o.p[10]; a.out = o.p[11];
@@ -1107,9 +1127,59 @@ int slide_launch_sa_chain(const SlideOp &o, hipStream_t s) {
   if (a.B <= 0 || a.k1 % 64 || a.k1 <= 0 || (a.n1 != 128 && a.n1 != 256) || a.n2 % 256 || a.n2 <= 0 || a.t_ld % 8) return -3;
   auto okgs = [](int g) { return g == 4 || g == 8 || g == 16; };
   if (!okgs(a.gs1) || !okgs(a.gs2)) return -3;
-  const size_t shm = (size_t)2 * 32768 + (size_t)(3 * a.n1 + 3 * a.n2 + a.n1 + 8 * 8 * 2 * 4 * 2 + 8 * 2 * 32) * 4 +
-                     (size_t)a.k1 * 2 + (size_t)2 * (a.k1 >> 3) * 16 * 16 + (size_t)2 * (a.n2 >> 3) * 16 * 16 + 64;
+  shm = (size_t)2 * 32768 + (size_t)(3 * a.n1 + 3 * a.n2 + a.n1 + 8 * 8 * 2 * 4 * 2 + 8 * 2 * 32) * 4 +
+        (size_t)a.k1 * 2 + (size_t)2 * (a.k1 >> 3) * 16 * 16 + (size_t)2 * (a.n2 >> 3) * 16 * 16 + 64;
   if (shm > 160 * 1024) return -8;
+  return 0;
+}
+
+// SLIDE_OP_SA_CHAIN_P: p[0] = HOST pointer to two SlideOp: the SLIDE_OP_SA_CHAIN and the SLIDE_OP_GEMM of the per-point query
+// layer (16 rows per sample, fp16, input affine + statistics finalisation: the small-launch kernel's AFF form)
+int slide_launch_sa_chain_p(const SlideOp &o, hipStream_t s) {
+  const SlideOp *pr = (const SlideOp *)o.p[0];
+  if (!pr || pr[0].kind != SLIDE_OP_SA_CHAIN || pr[1].kind != SLIDE_OP_GEMM) return -3;
+  F1Args a;
+  size_t shm_sa = 0;
+  const int st = sa_args_from_op(pr[0], a, shm_sa);
+  if (st != 0) return st;
+  const SlideOp &q = pr[1];
+  GemmArgs g = GemmArgs();
+  g.X = q.p[0]; g.W = q.p[1]; g.epi = (const SlideEpi *)q.p[2];
+  g.in_scale = (const float *)q.p[3]; g.in_shift = (const float *)q.p[4];
+  g.gn_fin = (const SlideGnFin *)q.p[6];
+  g.aff_tps = 1;
+  g.rows = q.i[0]; g.x_ld = q.i[1]; g.k_pad = q.i[2]; g.n_cob = q.i[3]; g.in_bs = q.i[5];
+  if (q.i[4] != 4 || q.i[6] != SLIDE_PREC_F16 || (q.i[8] & 6) || !g.in_scale || !g.in_shift || q.p[8] || q.p[9] ||
+      q.p[10] || q.p[11] || g.k_pad % 32 || g.x_ld % 8 || g.rows != a.B * 16 || g.n_cob <= 0)
+    return -3;
+  const int grid_p = ((g.rows + 63) / 64) * ((g.n_cob + 1) / 2);
+  const size_t shm_p = (size_t)4 * 2 * 6144 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32 + (size_t)4 * 2 * g.k_pad * 2 + 1024;
+  const size_t shm = shm_sa > shm_p ? shm_sa : shm_p;
+  static bool attr_done[2][64] = {};
+  int d = 0;
+  (void)hipGetDevice(&d);
+  d = d >= 0 && d < 64 ? d : 0;
+  if (a.n1 == 128) {
+    if (!attr_done[0][d]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_chain_p_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_done[0][d] = true;
+    }
+    hipLaunchKernelGGL((sa_chain_p_kernel<4>), dim3(a.B + grid_p), dim3(512), shm, s, a, g, a.B);
+  } else {
+    if (!attr_done[1][d]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_chain_p_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_done[1][d] = true;
+    }
+    hipLaunchKernelGGL((sa_chain_p_kernel<8>), dim3(a.B + grid_p), dim3(512), shm, s, a, g, a.B);
+  }
+  return (int)hipGetLastError();
+}
+
+int slide_launch_sa_chain(const SlideOp &o, hipStream_t s) {
+  F1Args a;
+  size_t shm = 0;
+  const int ast = sa_args_from_op(o, a, shm);
+  if (ast != 0) return ast;
   static bool attr_done[2][64] = {};
   int d = 0;
   (void)hipGetDevice(&d);

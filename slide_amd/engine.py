@@ -24,7 +24,7 @@ PREC = {"fp32": 0, "fp16": 1}
  OP_COND, OP_UPDATE_POS, OP_UPDATE_FEAT, OP_ADVANCE_T) = range(1, 13)
 OP_SYNC = 14
 OP_ATTN_TAIL = 16
-OP_GEMM_GX, OP_PAIR_NORM, OP_SA_CHAIN, OP_BLOCK_BODY, OP_PAIR_FIRST, OP_GEMM_CHAIN, OP_HEAD_UPDATE, OP_GEMM_GX_DUAL = 17, 18, 19, 30, 31, 32, 33, 34
+OP_GEMM_GX, OP_PAIR_NORM, OP_SA_CHAIN, OP_BLOCK_BODY, OP_PAIR_FIRST, OP_GEMM_CHAIN, OP_HEAD_UPDATE, OP_GEMM_GX_DUAL, OP_SA_CHAIN_P = 17, 18, 19, 30, 31, 32, 33, 34, 35
 
 
 class SlideEpi(ctypes.Structure):
@@ -1362,8 +1362,56 @@ class DenoiserEngine:
             prep.p[6], prep.i[4] = self._prep_tab.data_ptr(), len(self._prep_copies)
         self._merge_chains()
         self._merge_gx_pairs()
+        self._merge_chain_query()
         self.step_ops = (SlideOp * len(self.ops))(*self.ops)
         self.cond_ops = (SlideOp * 1)(self.cond_op)
+
+    def _merge_chain_query(self):
+        """SA blocks: [per-point query GEMM P | keys -> u GEMM (needs P) | fused Mlp chain (needs neither)] becomes
+        [chain + query GEMM in ONE launch (SLIDE_OP_SA_CHAIN_P) | keys -> u GEMM]: the query GEMM's launch and gap disappear under
+        the chain (SLIDE_CHAIN_P=0: three launches).  Op-index tables are re-keyed (the triple keeps its position)."""
+        if os.environ.get("SLIDE_CHAIN_P", "1") == "0":
+            return
+        is_p = lambda o: (o is not None and o.kind == OP_GEMM and o.i[4] == 4 and o.i[6] == 1 and not (o.i[8] & 6) and o.i[9] != 3 and o.p[3] and o.p[6]
+                          and not any(o.p[k] for k in (8, 9, 10, 11, 12, 13)))
+        new_ops, remap, i = [], {}, 0
+        self._chain_p_keep = []
+        flops, nbytes, names = {}, {}, {}
+        take = lambda src, dst, a_, b_: dst.__setitem__(b_, src[a_]) if a_ in src else None
+        while i < len(self.ops):
+            o0 = self.ops[i]
+            o1 = self.ops[i + 1] if i + 1 < len(self.ops) else None
+            o2 = self.ops[i + 2] if i + 2 < len(self.ops) else None
+            k = len(new_ops)
+            if (is_p(o0) and o1 is not None and o2 is not None and o1.kind == OP_GEMM_GX and o1.i[6] == 1 and o2.kind == OP_SA_CHAIN
+                    and o0.i[0] == o2.i[0] * 16 and o0.i[10] == o1.i[10] == o2.i[10]):
+                pair = (SlideOp * 2)(SlideOp.from_buffer_copy(bytes(o2)), SlideOp.from_buffer_copy(bytes(o0)))
+                self._chain_p_keep.append(pair)
+                op = make_op(OP_SA_CHAIN_P, i=(o2.i[0],), p=(ctypes.addressof(pair),))
+                op.i[10] = o0.i[10]
+                new_ops += [op, o1]
+                remap[i], remap[i + 2], remap[i + 1] = k, k, k + 1
+                flops[k] = self.gemm_flops.get(i, 0) + self.gemm_flops.get(i + 2, 0)
+                nbytes[k] = tuple(self.gemm_bytes.get(i, (0, 0))[z] + self.gemm_bytes.get(i + 2, (0, 0))[z] for z in (0, 1))
+                names[k] = "sa_chain_p_kernel<%d>" % (o2.i[3] // 32)
+                for src, dst in ((self.gemm_flops, flops), (self.gemm_bytes, nbytes), (self.kernel_names, names)):
+                    take(src, dst, i + 1, k + 1)
+                i += 3
+                continue
+            new_ops.append(o0)
+            remap[i] = k
+            for src, dst in ((self.gemm_flops, flops), (self.gemm_bytes, nbytes), (self.kernel_names, names)):
+                take(src, dst, i, k)
+            i += 1
+        self.ops = new_ops
+        self.gemm_flops, self.gemm_bytes, self.kernel_names = flops, nbytes, names
+        self.xyz_copy_idx = [remap[q] for q in self.xyz_copy_idx]
+        self.eps_copy_idx = remap[self.eps_copy_idx]
+        self._prep_idx = remap[self._prep_idx]
+        if self.head is not None:
+            self.head["idx"] = [remap[q] for q in self.head["idx"]]
+        self._body_args = {remap[q]: v for q, v in self._body_args.items()}
+        self._tail_of = {k_: remap[v] for k_, v in self._tail_of.items()}
 
     def _merge_gx_pairs(self):
         """the mode-1 (keys -> u) and mode-0 (first Mlp layer) generated-X GEMMs of an FP block are independent and adjacent in

@@ -556,7 +556,7 @@ def test_pair_decomposition_plan_variants(gpu_device, monkeypatch):
                            ("no_body_no_chain", {"SLIDE_BODY": "0", "SLIDE_SA_CHAIN": "0"}),
                            ("pair_norm_v2", {"SLIDE_PAIR_NORM_V2": "1"}), ("tail8", {"SLIDE_TAIL8": "1", "SLIDE_BODY": "0"}),
                            ("two_launch_tables", {"SLIDE_PAIR_FUSED": "0"}), ("gemm_chains", {"SLIDE_GEMM_CHAIN": "256"}),
-                           ("wide_key_tiles", {"SLIDE_GX_N64": "0"}), ("no_half_tiles_on_small_grids", {"SLIDE_GX_N64W": "0"}), ("no_dual_launch", {"SLIDE_GX_DUAL": "0"}), ("tail_occ3", {"SLIDE_TAIL_OCC3": "1"}), ("wide_tail", {"SLIDE_TAIL_WIDE": "8"}),
+                           ("wide_key_tiles", {"SLIDE_GX_N64": "0"}), ("no_half_tiles_on_small_grids", {"SLIDE_GX_N64W": "0"}), ("no_dual_launch", {"SLIDE_GX_DUAL": "0"}), ("query_gemm_apart", {"SLIDE_CHAIN_P": "0"}), ("tail_occ3", {"SLIDE_TAIL_OCC3": "1"}), ("wide_tail", {"SLIDE_TAIL_WIDE": "8"}),
                            ("long_gemm_chains", {"SLIDE_GEMM_CHAIN": "100000"})):
             for k_, v_ in knobs.items():
                 monkeypatch.setenv(k_, v_)
@@ -577,6 +577,8 @@ def test_pair_decomposition_plan_variants(gpu_device, monkeypatch):
         for tag, o in outs.items():
             d = np.linalg.norm(o - outs["default"]) / np.linalg.norm(outs["default"])
             assert d <= 4e-3, (name, tag, d)
+        # the query GEMM riding on the Mlp chain's launch runs the same body on the same tiles: same bits
+        assert np.array_equal(outs["query_gemm_apart"], outs["default"]), name
         # one launch for the two independent generated-X GEMMs of an FP block: the same two kernels' bodies, same bits
         assert np.array_equal(outs["no_dual_launch"], outs["default"]), name
         # the fused launch evaluates the table pass's arithmetic on the accumulators instead of a stored fp32 y: same bits
