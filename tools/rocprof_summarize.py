@@ -62,7 +62,7 @@ if os.path.exists(fp) and os.path.exists(wp):
     import json
     kern = {}
     for k in fa:
-        if any(t in k for t in ("gemm", "attn_tail", "sa_chain", "block_body", "pair_first")):
+        if any(t in k for t in ("gemm", "attn_tail", "sa_chain", "block_body", "pair_first", "head_update")):
             w = wa.get(k, [0, 1, 0])
             kern[k] = {"hbm_bytes_per_launch": int(1024 * (2 * fa[k][0] / fa[k][1] + w[0] / max(w[1], 1))),
                        "fetch_kib_x2": 2 * fa[k][0] / fa[k][1], "write_kib": w[0] / max(w[1], 1), "dispatches": fa[k][1]}
