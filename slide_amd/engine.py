@@ -483,7 +483,9 @@ class DenoiserEngine:
         n64, nst = 0, 3
         if knob != "0" and gx["mode"] == 1 and shm64(3) <= 53 * 1024:
             n64 = 1
-        elif knob != "0" and os.environ.get("SLIDE_GX_N64W", "1") != "0" and n_cob > 2 and ((rows + 255) // 256) * ((n_cob + 3) // 4) <= 256:
+        elif knob != "0" and os.environ.get("SLIDE_GX_N64W", "1") != "0" and (
+                n_cob <= 2 or ((rows + 255) // 256) * ((n_cob + 3) // 4) <= 256):
+            # (n_cob <= 2 -- the position net's 32- / 64-channel layers: a 128-channel tile would be half empty)
             # where the 128-channel grid would leave CUs empty -- the FP blocks at 88 samples: 96 workgroups -- 64-channel tiles at
             # two workgroups per CU, either mode (SLIDE_GX_N64W=0: 128-channel tiles).  Neutral while the staged tables pinned
             # these launches to one workgroup per CU (385.4 vs 386.6); with the tables streamed through the ring 394.3 vs 390.2
@@ -1426,7 +1428,7 @@ class DenoiserEngine:
             a_, b_ = self.ops[i], self.ops[i + 1] if i + 1 < len(self.ops) else None
             k = len(new_ops)
             if (a_ is not None and b_ is not None and a_.kind == OP_GEMM_GX and b_.kind == OP_GEMM_GX and a_.i[6] == 1 and b_.i[6] == 0
-                    and a_.f[0] == 2.0 and b_.f[0] == 2.0 and a_.i[0] == b_.i[0] and a_.i[4] == b_.i[4] and a_.i[10] == b_.i[10]):
+                    and a_.f[0] in (1.0, 2.0) and b_.f[0] == 2.0 and a_.i[0] == b_.i[0] and a_.i[4] == b_.i[4] and a_.i[10] == b_.i[10]):
                 pair = (SlideOp * 2)(SlideOp.from_buffer_copy(bytes(a_)), SlideOp.from_buffer_copy(bytes(b_)))
                 self._dual_keep.append(pair)
                 op = make_op(OP_GEMM_GX_DUAL, i=(a_.i[0],), p=(ctypes.addressof(pair),))
