@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="latent shapes per GPU (BASELINE configs[1]/[2]: 256)")
     ap.add_argument("--prec", default="fp16", choices=["fp16", "fp32"], help="MFMA operand type (fp32 accumulate)")
+    ap.add_argument("--pos-prec", default=None, choices=["fp16", "fp32"], help="operand type of the POSITION plan (default: --prec)")
     ap.add_argument("--sub-batches", type=int, default=3,
                     help="independent sub-batches of the per-GPU batch replayed concurrently (scheduling only)")
     ap.add_argument("--replay", default=os.environ.get("SLIDE_REPLAY", "eager"), choices=["eager", "threads", "graph"],
@@ -202,7 +203,7 @@ def main():
         a.replay = "graph"
     eager = a.replay != "graph"
     if a.workload == "default":
-        pos = PositionSampler(pc["pointnet_config"], sd_p, B, dev, pc["diffusion_config"], prec=a.prec, seed=1000 + rank * 16,
+        pos = PositionSampler(pc["pointnet_config"], sd_p, B, dev, pc["diffusion_config"], prec=a.pos_prec or a.prec, seed=1000 + rank * 16,
                               use_graph=not eager)
         # position plan: its own step graph on its own stream ("own", default: 1-1.5 % faster) or a parallel branch of the
         # first feature sub-batch's graph ("branch")

@@ -1,5 +1,5 @@
 /*
- * slide_resident.h -- C-ABI of the LDS-resident denoiser kernel in libslide_hip.so.
+ * slide_resident.h -- C-ABI of the LDS-resident denoiser kernel in libslide_hip_exp.so (the EXPERIMENTS build; not in the product library).
  *
  * What it replaces: the same thing include/slide_engine.h's plan replaces -- one reverse-diffusion step of the
  * reference = PointNet2CloudCondition.forward (pointnet2/models/pointnet2_with_pcld_condition.py:286-489) + the DDPM
@@ -30,7 +30,7 @@
 
 #include <stdint.h>
 
-#include "slide_hip.h"
+#include "../slide_hip.h"
 
 #ifdef __cplusplus
 extern "C" {

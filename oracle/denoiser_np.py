@@ -453,9 +453,19 @@ def position_sampling(net, dh, label, x, draw, t_start=None, t_end=0):
 
 def latent_diffusion_params(cfg):
     """Diffusion.init_diffusion_parameters (P2/diffusion_utils/diffusion.py:158-208), float64
-    numpy, 'linear' schedule + 'fixedsmall' / 'fixedlarge' variance."""
-    assert cfg["beta_schedule"] == "linear"
-    betas = np.linspace(cfg["beta_start"], cfg["beta_end"], cfg["num_diffusion_timesteps"], dtype=np.float64)
+    numpy, the schedules of get_beta_schedule (:12-28; the two 'warmup' names call a helper the reference does not define and
+    are not restated) + 'fixedsmall' / 'fixedlarge' variance."""
+    sched, T = cfg["beta_schedule"], cfg["num_diffusion_timesteps"]
+    if sched == "linear":
+        betas = np.linspace(cfg["beta_start"], cfg["beta_end"], T, dtype=np.float64)
+    elif sched == "quad":
+        betas = np.linspace(cfg["beta_start"] ** 0.5, cfg["beta_end"] ** 0.5, T, dtype=np.float64) ** 2
+    elif sched == "const":
+        betas = cfg["beta_end"] * np.ones(T, dtype=np.float64)
+    elif sched == "jsd":
+        betas = 1. / np.linspace(T, 1, T, dtype=np.float64)
+    else:
+        raise NotImplementedError(sched)
     alphas = 1.0 - betas
     ac = np.cumprod(alphas, axis=0)
     acp = np.append(1.0, ac[:-1])

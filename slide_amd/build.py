@@ -11,35 +11,27 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libslide_hip.so")
+# EXPERIMENTS build (-DSLIDE_EXPERIMENTS): the product sources + every opt-in variant that lost its A/B (X-stationary GEMM,
+# per-point layer chains, LDS-resident position denoiser, head + update launch, wide / eight-wave attention tails, 128- / 32-
+# channel and 64-deep ring tiles, the round-2 plan's kernels, the register-staged fp16 GEMM, the SA0 block body, the two-launch
+# pair-table pass).  Loaded instead of the product library with SLIDE_EXPERIMENTS=1 or `slide_amd._lib.experiments()`;
+# the plan-variant tests use it.  Its kernels may spill; the PRODUCT library may not.
+LIB_EXP = os.path.join(HERE, "libslide_hip_exp.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # (source, extra flags).  point_ops needs contraction OFF (bit-exact index parity with the oracle).
 # engine: the GEMM epilogue's per-channel-block loop must unroll fully (the accumulators are indexed by it; left rolled
 # they are demoted to scratch), which needs more than LLVM's default 16k-instruction cap for `#pragma unroll`.
-SOURCES = [("point_ops.hip", ["-ffp-contract=off"]), ("engine.hip", ["-mllvm", "-pragma-unroll-threshold=100000"]),
-           ("gemm_xs.hip", ["-mllvm", "-pragma-unroll-threshold=100000"]),
-           ("gemm_gx.hip", ["-mllvm", "-pragma-unroll-threshold=100000"]),
-           ("block_body.hip", ["-mllvm", "-pragma-unroll-threshold=100000"]),
-           ("gemm_chain.hip", ["-mllvm", "-pragma-unroll-threshold=100000"]),
-           ("resident.hip", ["-mllvm", "-pragma-unroll-threshold=100000"]), ("rows_ops.hip", [])]
+UNROLL = ["-mllvm", "-pragma-unroll-threshold=100000"]
+SOURCES = [("point_ops.hip", ["-ffp-contract=off"]), ("engine.hip", UNROLL), ("gemm_gx.hip", UNROLL), ("block_body.hip", UNROLL),
+           ("rows_ops.hip", [])]
+SOURCES_EXP = SOURCES + [("experiments/gemm_xs.hip", UNROLL), ("experiments/gemm_chain.hip", UNROLL),
+                         ("experiments/resident.hip", UNROLL)]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
-          "-Wno-unused-function"]
+          "-Wno-unused-function", "-I", CSRC]
 
-
-# Kernels that are allowed to spill: nothing a DEFAULT path dispatches.  Every entry is an opt-in /
-# fallback instantiation (the knob that selects it in brackets); any other kernel with a spilled VGPR or a private segment
-# fails the build.  Patterns are regular expressions over the demangled kernel name.
-SPILL_OPT_IN = [
-    r"gemm_glds_kernel<\d, 4, ",            # 128-channel ring tiles [SLIDE_CBW4_TILES]
-    r"gemm_glds_kernel<\d, \d, 3, 64, ",    # 64-deep chunks [SLIDE_GLDS_WIDE=1]
-    r"gemm_glds_kernel<7, 2, 3, 32, true",  # round-2 FP key GEMM [SLIDE_GX=0]
-    r"gemm_glds_occ3_kernel<7, ",           # round-2 FP blocks [SLIDE_GX=0]
-    r"gemm_glds_kernel<4, 2, ",             # 256-row ring tiles over 16-row samples [SlideOp.i[9] == 3, > 8192 small tiles]
-    r"gemm_kernel<1, ",                     # register-staged fp16 GEMM [SLIDE_GLDS=0]
-    r"gemm_xs_kernel<",                     # X-stationary GEMM [SLIDE_XS]
-    r"resident_kernel",                     # LDS-resident position denoiser [ResidentPositionSampler]
-    r"pair_norm2_kernel",                   # one-workgroup-per-sample table pass [SLIDE_PAIR_NORM_V2=1]
-    r"block_body_kernel<8, ",               # SA0 block body [SLIDE_BODY=2]
-]
+# PRODUCT build: NO kernel may spill a register or use scratch (the build fails otherwise; SLIDE_ALLOW_SPILLS=1 downgrades that
+# to a warning for other ROCm / LLVM versions).  The experiments build is not linted.
+SPILL_OPT_IN = []
 
 
 def parse_resource_remarks(stderr):
@@ -62,8 +54,18 @@ def parse_resource_remarks(stderr):
 
 
 def demangle(names):
-    out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
-    return [o.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "") for o in out[:len(names)]]
+    """c++filt, else ROCm's llvm-cxxfilt; with neither the MANGLED names are returned (SPILL_OPT_IN patterns then match on
+    the kernel's base name only: template arguments are encoded, so argument-specific patterns do not apply)"""
+    import shutil
+    for tool in ("c++filt", "/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "llvm-cxxfilt"):
+        exe = shutil.which(tool) or (tool if os.path.isabs(tool) and os.path.exists(tool) else None)
+        if exe is None:
+            continue
+        r = subprocess.run([exe], input="\n".join(names), capture_output=True, text=True)
+        out = r.stdout.split("\n")
+        if r.returncode == 0 and len(out) >= len(names):
+            return [o.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "") for o in out[:len(names)]]
+    return list(names)
 
 
 def check_spills(src, stderr):
@@ -74,8 +76,12 @@ def check_spills(src, stderr):
     rows = [(n,) + r[1:] for n, r in zip(names, rows)]
     bad = [r for r in rows if (r[3] or r[4]) and not any(re.search(p, r[0]) for p in SPILL_OPT_IN)]
     if bad:
-        raise RuntimeError("%s: kernels on a default path spill registers:\n%s" % (
-            src, "\n".join("  %s: %d VGPRs spilled, %d B scratch" % (r[0], r[3], r[4]) for r in bad)))
+        msg = "%s: kernels on a default path spill registers:\n%s" % (
+            src, "\n".join("  %s: %d VGPRs spilled, %d B scratch" % (r[0], r[3], r[4]) for r in bad))
+        if os.environ.get("SLIDE_ALLOW_SPILLS", "0") != "0":  # escape hatch for other ROCm / LLVM versions
+            sys.stderr.write("WARNING (SLIDE_ALLOW_SPILLS=1): " + msg + "\n")
+        else:
+            raise RuntimeError(msg + "\n(set SLIDE_ALLOW_SPILLS=1 to build anyway)")
     return rows
 
 
@@ -83,41 +89,68 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force=False, verbose=False):
-    objs = []
+def _compile(src, extra, obj, defines, lint, verbose):
+    cmd = [HIPCC] + COMMON + extra + defines + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stderr)
+        raise subprocess.CalledProcessError(r.returncode, cmd)
+    # compiler diagnostics that are not resource remarks (-Wall warnings) are passed on, also on success
+    diag = [ln for ln in r.stderr.split("\n") if ln.strip() and "remark:" not in ln and "[-Rpass-analysis" not in ln]
+    if diag:
+        sys.stderr.write("\n".join(diag) + "\n")
+    rows = parse_resource_remarks(r.stderr)
+    names = demangle([q[0] for q in rows])
+    rows = [(n,) + q[1:] for n, q in zip(names, rows)]
+    if lint:
+        try:
+            check_spills(os.path.basename(src), r.stderr)
+        except RuntimeError:
+            os.remove(obj)  # (the next build re-checks instead of linking the stale object)
+            raise
+    with open(obj + ".resources", "w") as f:  # tools/kernel_resources.py collects these into profiles/
+        for row in rows:
+            f.write("\t".join(str(v) for v in row) + "\n")
+
+
+def _build_one(lib, sources, objdir, defines, lint, force, verbose):
+    from concurrent.futures import ThreadPoolExecutor
     deps = [os.path.join(HERE, "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "include"))]
     deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
-    relink = force
-    for src, extra in SOURCES:
+    deps.append(os.path.abspath(__file__))
+    os.makedirs(objdir, exist_ok=True)
+    objs, jobs = [], []
+    for src, extra in sources:
         s = os.path.join(CSRC, src)
         if not os.path.exists(s):
             continue
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
         if force or _newer(s, o) or any(_newer(d, o) for d in deps):
-            cmd = [HIPCC] + COMMON + extra + ["-Rpass-analysis=kernel-resource-usage", "-c", s, "-o", o]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            r = subprocess.run(cmd, capture_output=True, text=True)
-            if r.returncode != 0:
-                sys.stderr.write(r.stderr)
-                raise subprocess.CalledProcessError(r.returncode, cmd)
-            try:
-                rows = check_spills(src, r.stderr)
-            except RuntimeError:
-                os.remove(o)  # (the next build re-checks instead of linking the stale object)
-                raise
-            with open(o + ".resources", "w") as f:  # tools/kernel_resources.py collects these into profiles/
-                for row in rows:
-                    f.write("\t".join(str(v) for v in row) + "\n")
-            relink = True
+            jobs.append((s, extra, o))
         objs.append(o)
-    if relink or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if jobs:  # the translation units compile concurrently (hipcc is single-threaded per file; engine.hip is the long pole)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            for f in [ex.submit(_compile, s, extra, o, defines, lint, verbose) for s, extra, o in jobs]:
+                f.result()
+    if jobs or not os.path.exists(lib):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    return lib
+
+
+def build(force=False, verbose=False, experiments=False):
+    """the product library; experiments=True: also (only with experiments="only") the experiments library"""
+    if experiments != "only":
+        _build_one(LIB, SOURCES, CSRC, [], True, force, verbose)
+    if experiments:
+        _build_one(LIB_EXP, SOURCES_EXP, os.path.join(CSRC, "exp"), ["-DSLIDE_EXPERIMENTS"], False, force, verbose)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True,
+                experiments=("only" if "--experiments-only" in sys.argv else "--experiments" in sys.argv)))

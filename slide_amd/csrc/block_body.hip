@@ -628,7 +628,11 @@ int slide_launch_block_body(const SlideOp &o, hipStream_t s) {
   const int nb1 = a.n1 >> 5, nbm = a.n_mo >> 5, nbu = a.n_u >> 5;
 #define BODY(L, R, N1, NM, NU) if (npxl == L && (rest != 0) == R && (!R || nb1 == N1) && nbm == NM && nbu == NU) return launch_body<L, R, N1, NM, NU>(a, shm, s)
   BODY(7, false, 0, 4, 4);   // FP0
-  BODY(8, true, 4, 8, 5);    // SA0
+#ifdef SLIDE_EXPERIMENTS
+  BODY(8, true, 4, 8, 5);    // SA0 (spills 96 registers; SLIDE_BODY=2)
+#else
+  if (npxl == 8) return -20;  // experiments build only
+#endif
 #undef BODY
   return -4;
 }

@@ -17,13 +17,22 @@
 
 // gemm_xs.hip: X-stationary kernel (-8: the X tile does not fit the LDS, -4: no such instantiation)
 int slide_launch_rows_op(const SlideOp &o, hipStream_t s);  // rows_ops.hip
-int slide_launch_gemm_xs(const GemmArgs &a, int npxl, int cbw, bool aff, bool gat, int want_occ, hipStream_t s);
+#ifdef SLIDE_EXPERIMENTS
+int slide_launch_gemm_xs(const GemmArgs &a, int npxl, int cbw, bool aff, bool gat, int want_occ, hipStream_t s);  // gemm_xs.hip
+#endif
 // gemm_gx.hip: generated-X GEMM and the per-point table normalisation of the pair decomposition
 int slide_launch_gemm_gx(const SlideOp &o, hipStream_t s);
 int slide_launch_pair_norm(const SlideOp &o, hipStream_t s);
 int slide_launch_sa_chain(const SlideOp &o, hipStream_t s);
 int slide_launch_block_body(const SlideOp &o, hipStream_t s);  // block_body.hip
+#ifdef SLIDE_EXPERIMENTS
 int slide_launch_gemm_chain(const SlideOp &o, hipStream_t s);  // gemm_chain.hip
+#endif
+// Status of an op whose kernel only exists in the EXPERIMENTS build (slide_amd/build.py: libslide_hip_exp.so, -DSLIDE_EXPERIMENTS):
+// the opt-in variants that lost their A/Bs (X-stationary tiles, per-point layer chains, head + update launch, wide / eight-wave
+// attention tails, 128- / 32-channel and 64-deep ring tiles, the round-2 plan's gathered first layers, the register-staged fp16
+// GEMM).  The product library carries only what a default plan dispatches.
+#define SLIDE_ST_EXPERIMENT (-20)
 int slide_launch_gemm_gx_dual(const SlideOp &o, hipStream_t s);  // gemm_gx.hip
 int slide_launch_sa_chain_p(const SlideOp &o, hipStream_t s);    // gemm_gx.hip
 
@@ -38,7 +47,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
   constexpr int RPP = 256 / TPR;          // rows per pass
   constexpr int TN = 32 * CBW;
   constexpr int XP = TM / RPP, WP = TN / RPP;
-  constexpr int NPX = 1 << NPXL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T *const sbase = reinterpret_cast<T *>(smem_raw);
   constexpr int STAGE = (TM + TN) * LDK;
@@ -1858,9 +1866,12 @@ int launch_gemm_small(const GemmArgs &a, hipStream_t s) {
   // two stages per wave (64 KB of LDS: the size of the partial-sum exchange) rather than three (96 KB): the workgroup
   // then fits a CU beside two 41 KB GEMM workgroups of the other chains (0.913 vs 0.927 ms/step); a.stagger == 5 keeps
   // three stages on single-round grids, for A/B timing
+#ifdef SLIDE_EXPERIMENTS
   const bool three = grid <= 256 && a.stagger == 5;
-  if (a.in_scale) return three ? launch_gemm_small_t<3, true>(a, s) : launch_gemm_small_t<2, true>(a, s);
-  return three ? launch_gemm_small_t<3, false>(a, s) : launch_gemm_small_t<2, false>(a, s);
+  if (three) return a.in_scale ? launch_gemm_small_t<3, true>(a, s) : launch_gemm_small_t<3, false>(a, s);
+#endif
+  (void)grid;
+  return a.in_scale ? launch_gemm_small_t<2, true>(a, s) : launch_gemm_small_t<2, false>(a, s);
 }
 
 int run_gemm(const SlideOp &o, hipStream_t s) {
@@ -1900,20 +1911,41 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
   // kernels, for A/B timing)
   // (up to 1024 tiles with the statistics finalisation, 8192 without: the wide per-point GEMMs of the pair decomposition --
   //  N = 1056 .. 1568 -- stay on this spill-free kernel instead of the 256-row ring tiles, which spill at 16 rows per sample)
+  // (round 4: no tile limit without the finalisation -- a chain of 2048 samples used to fall back to the 256-row ring tiles,
+  //  which spill at 16 rows per sample; those are experiments-build kernels now)
   if (prec == SLIDE_PREC_F16 && npxl == 4 && o.i[9] != 3 &&
-      ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2) <= (a.gn_fin ? 1024 : 8192))
+      (!a.gn_fin || ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2) <= 1024))
     return launch_gemm_small(a, s);
   if (a.gn_fin) return -10;  // only the small-launch kernel finalises statistics
   // X-stationary kernel (SlideOp.p[10] = the weights as MFMA A fragments): one workgroup per row tile computes every
   // column tile from an LDS-resident X.  i[9] == 5 keeps the ring kernels, for A/B timing.
+#ifndef SLIDE_EXPERIMENTS
+  if (o.p[10]) return SLIDE_ST_EXPERIMENT;
+#else
   if (o.p[10] && glds && prec == SLIDE_PREC_F16 && o.i[9] != 5 && (npxl == 8 || npxl == 7) && !(a.gfeat && a.in_scale)) {
     int st = -8;
     const bool aff = a.in_scale != nullptr, gat = a.gfeat != nullptr;
     st = slide_launch_gemm_xs(a, npxl, cbw, aff, gat, o.i[9] >= 11 && o.i[9] <= 13 ? o.i[9] - 10 : 0, s);
     if (st != -8) return st;  // -8: the X tile does not fit the LDS -> ring kernels
   }
+#endif
   if (glds) {
     if (prec != SLIDE_PREC_F16) return -7;
+#ifndef SLIDE_EXPERIMENTS
+    // PRODUCT build: 256 x 64 tiles at three workgroups per CU (plain or with the input affine), the two-workgroup form of the
+    // affine tile where its vectors do not fit beside three -- what the default DDPM plans and the module path (decode, encode)
+    // dispatch.  Every other ring variant is an experiments-build kernel.
+    if (o.i[9] != 0 || cbw != 2 || a.gfeat || a.stagger == 7 || (npxl != 7 && npxl != 8)) return SLIDE_ST_EXPERIMENT;
+    {
+      int st3 = -8;
+      if (npxl == 8) st3 = a.in_scale ? launch_gemm_occ3<8, true, false>(a, s) : launch_gemm_occ3<8, false, false>(a, s);
+      else if (!a.in_scale) return SLIDE_ST_EXPERIMENT;  // (128-row samples on stored inputs: the round-2 plan's FP blocks)
+      else return launch_gemm_glds<7, 2, 3, 32, true>(a, s);
+      if (st3 != -8) return st3;
+      if (a.in_scale) return launch_gemm_glds<8, 2, 3, 32, true>(a, s);
+      return -4;
+    }
+#else
     // i[9]: 0 = BK 32, three stages (two workgroups / CU); 1 = BK 64 (full 128-B lines), three stages (one / CU)
     const int wide = o.i[9] == 1 && (a.k_pad % 64 == 0) && !a.in_scale;
 #define GCASE(L, C)                                                                                        \
@@ -1966,11 +1998,16 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
 #undef ACASE
 #undef GCASE
     return -4;
+#endif
   }
 #define CASE(P, L, C) if (prec == P && npxl == L && cbw == C) return launch_gemm<P, L, C>(a, s)
   CASE(SLIDE_PREC_F32, 4, 2); CASE(SLIDE_PREC_F32, 7, 2); CASE(SLIDE_PREC_F32, 8, 2);
+#ifdef SLIDE_EXPERIMENTS
   CASE(SLIDE_PREC_F16, 4, 2); CASE(SLIDE_PREC_F16, 7, 2); CASE(SLIDE_PREC_F16, 8, 2);
   CASE(SLIDE_PREC_F16, 4, 4); CASE(SLIDE_PREC_F16, 7, 4); CASE(SLIDE_PREC_F16, 8, 4);
+#else
+  if (prec == SLIDE_PREC_F16) return SLIDE_ST_EXPERIMENT;  // register-staged fp16 GEMM [SLIDE_GLDS=0]
+#endif
 #undef CASE
   return -4;
 }
@@ -2017,6 +2054,12 @@ int run_attn_tail(const SlideOp &o, hipStream_t s) {
   // (opt-in, SLIDE_TAIL8=1: measured equal to the four-wave form for one chain and 2 % slower with four chains in flight --
   //  both forms are bound by the per-CU L2 -> LDS fill rate of the non-resident u / mo tiles)
   static const bool tail8_on = [] { const char *e = getenv("SLIDE_TAIL8"); return e && e[0] == '1'; }();
+  const int ntc = (a.n_cob + 1) / 2, ntr = (a.rows + TM - 1) / TM;
+  const int grid = ((ntr + 7) / 8) * 8 * ntc;
+#ifndef SLIDE_EXPERIMENTS
+  (void)ntr8;
+  if (tail8_on || ((int)o.f[1] & 6)) return SLIDE_ST_EXPERIMENT;  // eight-wave / wide / three-workgroup tails
+#else
   if (tail8_on && a.n_cob >= 8 && (npxl == 7 || npxl == 8) && a.k1 % 64 == 0 && a.k2 % 64 == 0) {  // eight-wave 256 x 128 tiles (see attn_tail8_kernel)
     const size_t shm8 = (size_t)3 * 2 * (TM + 128) * 64 + 4 * 128 * 4 + 64;
     const int grid8 = ((ntr8 + 7) / 8) * 8 * ((a.n_cob + 3) / 4);
@@ -2031,8 +2074,6 @@ int run_attn_tail(const SlideOp &o, hipStream_t s) {
     else hipLaunchKernelGGL(attn_tail8_kernel<7>, dim3(grid8), dim3(512), shm8, s, a);
     return (int)hipGetLastError();
   }
-  const int ntc = (a.n_cob + 1) / 2, ntr = (a.rows + TM - 1) / TM;
-  const int grid = ((ntr + 7) / 8) * 8 * ntc;
   if (((int)o.f[1] & 4) && npxl == 8 && a.n_cob % 4 == 0) {  // plan knob SLIDE_TAIL_WIDE: 256 x 128 tiles (attn_tail_wide_kernel)
     const int ntc4 = a.n_cob / 4;
     const int grid4 = ((ntr8 + 7) / 8) * 8 * ntc4;
@@ -2053,6 +2094,7 @@ int run_attn_tail(const SlideOp &o, hipStream_t s) {
     else hipLaunchKernelGGL(attn_tail_occ3_kernel<7>, dim3(grid), dim3(256), shm3, s, a);
     return (int)hipGetLastError();
   }
+#endif
   const size_t shm = (size_t)SLIDE_ATTN_NST * (TM + 64) * 64 + 4 * 2 * 32 * 4 + 64;
   static bool attr_done[SLIDE_MAX_DEVICES] = {};
   bool &attr_set = attr_done[current_device_slot()];
@@ -2162,6 +2204,13 @@ int run_op(const SlideOp &o, hipStream_t s) {
                          (const float *)o.p[10], (const float *)o.p[11], o.p[12], o.i[6], o.i[7],
                          (const SlidePrepCopy *)o.p[13], o.i[8]);
       break;
+#ifndef SLIDE_EXPERIMENTS
+    case SLIDE_OP_HEAD_UPDATE:
+    case SLIDE_OP_GEMM_CHAIN:
+      return SLIDE_ST_EXPERIMENT;
+#else
+    case SLIDE_OP_GEMM_CHAIN:
+      return slide_launch_gemm_chain(o, s);
     case SLIDE_OP_HEAD_UPDATE: {
       const SlideHeadArgs *h = (const SlideHeadArgs *)o.p[0];  // HOST pointer, kept alive by the plan
       if (!h || h->rows <= 0 || h->rows % 16 || h->k0 % 32 || h->k0 <= 0 || h->k0 > 160 || h->x_ld < h->k0 || h->x_ld % 8 ||
@@ -2173,6 +2222,7 @@ int run_op(const SlideOp &o, hipStream_t s) {
       else hipLaunchKernelGGL(head_update_kernel<160>, dim3(grid), dim3(256), 0, s, *h);
       break;
     }
+#endif
     case SLIDE_OP_ATTN_TAIL:
       return run_attn_tail(o, s);
     case SLIDE_OP_GEMM_GX:
@@ -2183,8 +2233,6 @@ int run_op(const SlideOp &o, hipStream_t s) {
       return slide_launch_pair_norm(o, s);
     case SLIDE_OP_PAIR_FIRST:
       return run_pair_first(o, s);
-    case SLIDE_OP_GEMM_CHAIN:
-      return slide_launch_gemm_chain(o, s);
     case SLIDE_OP_SA_CHAIN:
       return slide_launch_sa_chain(o, s);
     case SLIDE_OP_SA_CHAIN_P:

@@ -1,4 +1,4 @@
-// resident.hip -- LDS-resident denoiser for gfx950 (C-ABI: include/slide_resident.h).
+// resident.hip -- LDS-resident denoiser for gfx950 (C-ABI: include/experiments/slide_resident.h).
 //
 // One workgroup (4 waves, one per SIMD, the whole 512-register file each) owns ONE latent-point set and runs the whole
 // PointNet2CloudCondition.forward (pointnet2/models/pointnet2_with_pcld_condition.py:286-489) for it, timestep after
@@ -17,7 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../include/slide_resident.h"
+#include "../../../include/experiments/slide_resident.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

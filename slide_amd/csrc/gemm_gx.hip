@@ -685,6 +685,11 @@ int slide_launch_gemm_gx(const SlideOp &o, hipStream_t s) {
   return -4;
 }
 
+// SLIDE_OP_PAIR_NORM: the two-launch form of the pair-table pass (SLIDE_PAIR_FUSED=0) and its one-workgroup-per-sample version
+// (SLIDE_PAIR_NORM_V2=1) -- experiments build only; the default plans run SLIDE_OP_PAIR_FIRST (engine.hip)
+#ifndef SLIDE_EXPERIMENTS
+int slide_launch_pair_norm(const SlideOp &, hipStream_t) { return -20; }
+#else
 int slide_launch_pair_norm(const SlideOp &o, hipStream_t s) {
   const int B = o.i[0], ld = o.i[1], K = o.i[2];
   if (B <= 0 || ld <= 0 || ld % 32) return -3;
@@ -732,6 +737,7 @@ int slide_launch_pair_norm(const SlideOp &o, hipStream_t s) {
   } else return -5;
   return (int)hipGetLastError();
 }
+#endif
 
 namespace {
 

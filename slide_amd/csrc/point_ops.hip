@@ -876,8 +876,10 @@ int three_interpolate_kernel_wrapper(int b, int c, int m, int n, const float *po
                        (size_t)((m + 3) & ~3) * 4, (hipStream_t)stream, c, m, n, cchunk, points, idx, weight, out);
     return LAUNCH_STATUS();
   }
+  // (R staged rows of mp floats: the launch stays inside the 64 KB of dynamic LDS every device grants without an attribute --
+  //  n = 256 with m > 4092 or n = 512 with m > 8188 fall through to the generic kernels below)
   if ((n == 256 || n == 512 || n == 1024) && (((uintptr_t)idx | (uintptr_t)weight | (uintptr_t)out | (uintptr_t)points) & 15) == 0 &&
-      m <= 8192) {
+      m <= 8192 && (size_t)(1024 / n) * (size_t)(((m + 3) & ~3) + 4) * 4 <= 64 * 1024) {
     const int R = 1024 / n;
     int chunks = (1024 + b - 1) / b;  // >= 4 blocks per CU overall
     chunks = chunks < 1 ? 1 : (chunks > (c + R - 1) / R ? (c + R - 1) / R : chunks);

@@ -37,12 +37,34 @@ def calc_diffusion_hyperparams(T, beta_0, beta_T):
     return {"T": T, "Beta": Beta, "Alpha": Alpha, "Alpha_bar": Alpha_bar, "Sigma": np.sqrt(Beta_tilde).astype(F32)}
 
 
+def get_beta_schedule(beta_schedule, beta_start, beta_end, num_diffusion_timesteps):
+    """get_beta_schedule (pointnet2/diffusion_utils/diffusion.py:12-28): float64 beta tables of the six schedule names the
+    reference accepts.  'warmup10' / 'warmup50' call a helper (`_warmup_beta`) the reference never defines -- there they end in
+    a NameError; here they follow the DDPM convention the name comes from (beta_end everywhere, a linear ramp from beta_start over
+    the first 10 % / 50 % of the steps)."""
+    T = int(num_diffusion_timesteps)
+    if beta_schedule == "quad":
+        betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, T, dtype=np.float64) ** 2
+    elif beta_schedule == "linear":
+        betas = np.linspace(beta_start, beta_end, T, dtype=np.float64)
+    elif beta_schedule in ("warmup10", "warmup50"):
+        betas = beta_end * np.ones(T, dtype=np.float64)
+        n = int(T * (0.1 if beta_schedule == "warmup10" else 0.5))
+        betas[:n] = np.linspace(beta_start, beta_end, n, dtype=np.float64)
+    elif beta_schedule == "const":
+        betas = beta_end * np.ones(T, dtype=np.float64)
+    elif beta_schedule == "jsd":  # 1/T, 1/(T-1), ..., 1
+        betas = 1.0 / np.linspace(T, 1, T, dtype=np.float64)
+    else:
+        raise NotImplementedError(beta_schedule)
+    assert betas.shape == (T,)
+    return betas
+
+
 def latent_diffusion_params(cfg):
     """Diffusion.init_diffusion_parameters (pointnet2/diffusion_utils/diffusion.py:158-208): float64 numpy tables,
-    cast to float32 where the sampler reads them (extract(), :31-39)."""
-    if cfg["beta_schedule"] != "linear":
-        raise NotImplementedError(cfg["beta_schedule"])
-    betas = np.linspace(cfg["beta_start"], cfg["beta_end"], cfg["num_diffusion_timesteps"], dtype=np.float64)
+    cast to float32 where the sampler reads them (extract(), :31-39).  Every schedule name of get_beta_schedule (:12-28)."""
+    betas = get_beta_schedule(cfg["beta_schedule"], cfg["beta_start"], cfg["beta_end"], cfg["num_diffusion_timesteps"])
     alphas = 1.0 - betas
     ac = np.cumprod(alphas, axis=0)
     acp = np.append(1.0, ac[:-1])

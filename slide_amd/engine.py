@@ -1285,6 +1285,8 @@ class DenoiserEngine:
                 extra = (fp_q[j],)
             o, c = self._sa_module(i, feats[i], chans[i], extra_q=extra)
             feats.append(o); chans.append(c)
+        # per-level per-point outputs [B*16][ld] (diagnostics: tools/prec_probe.py compares them between precisions)
+        self.levels = {"sa%d" % i: (feats[i + 1], chans[i + 1]) for i in range(nsa)}
         dec0 = None
         for i in range(-1, -(nfp + 1), -1):
             j = nfp + i
@@ -1295,6 +1297,7 @@ class DenoiserEngine:
                 out_buf = dec0
             o, c = self._fp_module(j, feats[i - 1], chans[i - 1], feats[i], chans[i], out_buf, qctx=fp_q.get(j))
             feats[i - 1], chans[i - 1] = o, c
+            self.levels["fp%d" % j] = (o, c)
         # output head fc_lyaer (pointnet2_with_pcld_condition.py:480-483): conv -> GN(32,128) -> ReLU -> conv
         c = chans[0]
         if self.fold_copies:

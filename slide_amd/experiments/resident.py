@@ -1,4 +1,4 @@
-"""Host side of the LDS-resident denoiser kernel (include/slide_resident.h, csrc/resident.hip).
+"""Host side of the LDS-resident denoiser kernel (include/experiments/slide_resident.h, csrc/experiments/resident.hip).
 
 `ResidentPlan` turns a reference `pointnet_config` + reference-named state dict into the kernel's inputs for the network
 family whose per-sample working set fits one compute unit's LDS (the shipped position-DDPM configs: 16 points, 'nn'
@@ -18,8 +18,14 @@ import ctypes
 import numpy as np
 import torch
 
-from ._lib import SlideHipError, check, lib
-from .engine import DenoiserEngine
+from .._lib import LIB_EXP_PATH, SlideHipError, _load, check
+
+
+def lib():
+    """the resident kernel only exists in the EXPERIMENTS build of the library"""
+    return _load(LIB_EXP_PATH)
+
+from ..engine import DenoiserEngine
 
 R_PREP, R_ASSEMBLE, R_GEMM, R_FINALIZE, R_AFFINE, R_TAIL, R_ZFILL = range(1, 8)
 RS_RAW, RS_NORM, RS_STATS = 0, 1, 2

@@ -184,7 +184,10 @@ class CategoryChains:
     def run(self, gen=None, steps=None):
         """position chain then feature chain of every segment (all `steps` reverse steps, default the full schedule); the
         position chain of segment k + 1 runs beside the feature chain of segment k (independent streams).
-        Returns the rank's latents (n_local, 16, 3 + F) on the device."""
+        Returns the rank's latents (n_local, 16, 3 + F) on the device.  `gen` is no longer used -- the start noise of shape g is
+        start_noise(seed, ..., g), independent of ranks and batches -- and passing one is an error rather than silently ignored."""
+        if gen is not None:
+            raise TypeError("CategoryChains.run: `gen` is not supported any more (start noise is keyed on (seed, global shape index))")
         outs, pending = [], None
         for c, lo, hi, ps, fs in self.chains:
             n = hi - lo
@@ -247,11 +250,14 @@ class PipelinedGenerator:
             self.cx = self.feats[0].engine.cx
         self._Eager = EagerChainsSampler
         self.T = (self.pos or self.feats[0]).T
+        # one slide_run_chains call replays every chain of a group for the SAME number of steps: configurations whose
+        # position and feature schedules differ in length advance chain by chain instead
+        self._same_T = all(s_.T == self.T for s_ in ([self.pos] if self.pos is not None else []) + (self.feats or []))
 
     def _advance(self, samplers):
         if not samplers:
             return
-        if self.serial:
+        if self.serial or not self._same_T:
             for s_ in samplers:
                 s_.advance(s_.T)
         else:

@@ -42,3 +42,15 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def exp_lib():
+    """the EXPERIMENTS build of the HIP library (slide_amd/build.py --experiments) for the duration of a test: the opt-in plan
+    variants (round-2 plan, X-stationary tiles, per-point layer chains, wide tails, head + update launch, resident kernel ...) are
+    not in the product library"""
+    from slide_amd import _lib
+    if not _lib.have_experiments():
+        pytest.skip("libslide_hip_exp.so is not built (python slide_amd/build.py --experiments)")
+    with _lib.experiments():
+        yield

@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE: a numpy interpreter of the LDS-resident kernel's op program (include/slide_resident.h).
+"""TEST INFRASTRUCTURE: a numpy interpreter of the LDS-resident kernel's op program (include/experiments/slide_resident.h).
 
 It executes the `ROp` / `RStrip` records and the packed weight / vector pools that `slide_amd.resident.ResidentPlan` hands
 to `resident_kernel` with the kernel's own data layout (a byte arena standing for one workgroup's LDS, fp16 activations,
@@ -8,7 +8,7 @@ program never wrote shows up as a NaN in the output.
 """
 import numpy as np
 
-from slide_amd import resident as R
+from slide_amd.experiments import resident as R
 
 F32 = np.float32
 

@@ -8,9 +8,9 @@ import pytest
 from conftest import REPO
 
 
-def _declared_symbols():
+def _declared_symbols(sub=""):
     names = []
-    inc = os.path.join(REPO, "include")
+    inc = os.path.join(REPO, "include", sub)
     for f in sorted(os.listdir(inc)):
         if not f.endswith(".h"):
             continue
@@ -34,6 +34,20 @@ def test_library_builds_and_exports_header_symbols():
     assert not missing, missing
     lib.slide_hip_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.slide_hip_version()
+
+
+def test_experiments_library_exports_product_and_experiment_symbols():
+    """libslide_hip_exp.so (-DSLIDE_EXPERIMENTS: product kernels + the opt-in variants) exports everything the product headers
+    declare plus include/experiments/*.h; the PRODUCT library does not carry the experiments' entry points"""
+    from slide_amd import build
+    build.build(experiments="only")
+    lib = ctypes.CDLL(build.LIB_EXP)
+    syms = _declared_symbols() + _declared_symbols("experiments")
+    assert "slide_resident_run" in syms
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+    prod = ctypes.CDLL(build.build())
+    assert not hasattr(prod, "slide_resident_run")
 
 
 def test_ops_fail_loudly_without_gpu():

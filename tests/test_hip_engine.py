@@ -224,7 +224,7 @@ def test_point_preparation_folded_into_the_update(gpu_device, monkeypatch, prec)
     assert np.isfinite(out["1"][0]).all() and np.array_equal(out["1"][0], out["0"][0]) and np.array_equal(out["1"][1], out["0"][1])
 
 
-def test_head_and_update_as_one_launch(gpu_device, monkeypatch):
+def test_head_and_update_as_one_launch(gpu_device, exp_lib, monkeypatch):
     """SLIDE_OP_HEAD_UPDATE: fc_lyaer's two per-point GEMMs (GroupNorm between them) and the DDPM update in one launch -- the
     prediction never leaves the registers.  Against the three-launch plan (SLIDE_HEAD_UPDATE=0: same arithmetic, other
     summation order in the K loops) over 10 steps with in-kernel noise: position and feature chains within 5e-4 relative
@@ -483,7 +483,7 @@ def test_threaded_eager_sampler_equals_separate_chains(gpu_device):
         assert np.array_equal(f.state().cpu().numpy(), w)
 
 
-def test_x_stationary_kernel_bit_identical(gpu_device, monkeypatch):
+def test_x_stationary_kernel_bit_identical(gpu_device, exp_lib, monkeypatch):
     """csrc/gemm_xs.hip: input resident in LDS (gathered first layers: only the point table), a workgroup computes several
     column tiles from it -- the same MFMA / epilogue arithmetic in the same order as the ring kernels, so the denoiser output
     must be bit-identical in every mode (default policy, every eligible layer, 128-channel tiles, capped occupancy)"""
@@ -506,7 +506,7 @@ def test_x_stationary_kernel_bit_identical(gpu_device, monkeypatch):
             assert np.array_equal(got, ref), (name, mode, cbw, occ, float(np.abs(got - ref).max()))
 
 
-def test_chunk_major_layout_bit_identical(gpu_device, monkeypatch):
+def test_chunk_major_layout_bit_identical(gpu_device, exp_lib, monkeypatch):
     """Chunk-major activations / weights ([k / 32][rows][32]: one LDS-DMA instruction reads 1 KB of consecutive memory) are a
     pure re-layout of the K-expanded buffers between GEMM epilogues and ring-kernel loaders: the denoiser output must be
     bit-identical to the row-major plan, with the gather-on-load first layers, the fused attention tail, and without either."""
@@ -539,7 +539,7 @@ def test_chunk_major_layout_bit_identical(gpu_device, monkeypatch):
                 monkeypatch.delenv(k_)
 
 
-def test_pair_decomposition_plan_variants(gpu_device, monkeypatch):
+def test_pair_decomposition_plan_variants(gpu_device, exp_lib, monkeypatch):
     """Round 3: the pair decomposition (csrc/gemm_gx.hip, block_body.hip) re-associates the blocks' first layers (a[q] + b[p]
     from 16-row GEMMs instead of 256- / 128-row ones) and runs the SA blocks in natural neighbour order, so it is NOT
     bit-identical to the round-2 plan; both are fp16 renderings of the same network.  Every combination of the round-3

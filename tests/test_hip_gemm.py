@@ -116,7 +116,14 @@ def test_gemm_op_matches_numpy(gpu_device, npxl, B, K, N, mode, extras, cm):
         seg["addvec"] = (m.A.put(ap), 0, Np, None, 0)
     m._gemm(X, npxl, [seg], in_cols=None)
     ops = (E.SlideOp * 1)(*m.ops)
-    check(lib().slide_run_ops(ops, 1, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "run")
+    # the product library carries the 256 x 64 ring tile for 256-row samples (module path) and the small-launch kernel; the
+    # 128-row form on stored inputs is a round-2-plan kernel of the experiments build (same tile body and epilogue)
+    import contextlib
+    from slide_amd import _lib
+    if npxl == 7 and not _lib.have_experiments():
+        pytest.skip("libslide_hip_exp.so is not built")
+    with (_lib.experiments() if npxl == 7 else contextlib.nullcontext()):
+        check(lib().slide_run_ops(ops, 1, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "run")
     torch.cuda.synchronize()
     got = out.float().cpu().numpy()
     got = (_from_cm(got) if cm else got)[:, oidx]

@@ -83,7 +83,9 @@ def test_gather_group_interpolate(gpu_device):
                            O.group_points_grad(G, idx, n), atol=1e-3)
     # (n = 256 / 512 / 1024: the rows-in-LDS kernel, 4 / 2 / 1 channel rows per pass, ragged channel counts and row lengths)
     for (B, C, m, n) in [(2, 64, 100, 300), (1, 7, 3, 5), (2, 128, 256, 1024), (3, 37, 128, 256), (2, 10, 101, 512),
-                         (2, 3, 64, 1024)]:
+                         (2, 3, 64, 1024),
+                         # staged rows beyond 64 KB of LDS (n = 256: m > 4092; n = 512: m > 8188) take the generic kernels
+                         (1, 6, 4096, 256), (1, 5, 8192, 256), (1, 3, 4092, 256), (1, 3, 8192, 512), (1, 3, 8188, 512)]:
         pts = rs.standard_normal((B, C, m)).astype(np.float32)
         idx = rs.randint(0, m, (B, n, 3)).astype(np.int32)
         w = rs.uniform(0, 1, (B, n, 3)).astype(np.float32)

@@ -1,4 +1,5 @@
-"""GPU: the LDS-resident position denoiser / sampler (slide_amd/resident.py, csrc/resident.hip) against the
+"""GPU, EXPERIMENTS build: the LDS-resident position denoiser / sampler (slide_amd/experiments/resident.py,
+csrc/experiments/resident.hip -- opt-in, not in the product library) against the
 reference-generated goldens, the engine plan and itself (one launch of n steps == n launches of one step)."""
 import json
 
@@ -10,6 +11,13 @@ from conftest import NoiseStream, golden_spec, load_golden
 from slide_amd.synth import synth_state_dict
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _needs_experiments_build():
+    from slide_amd import _lib
+    if not _lib.have_experiments():
+        pytest.skip("libslide_hip_exp.so is not built (python slide_amd/build.py --experiments)")
 
 
 def _load():
@@ -28,7 +36,7 @@ def _rel(a, b):
 def test_resident_denoiser_forward_matches_reference(gpu_device):
     """PointNet2CloudCondition.forward in ONE launch, fp16 activations in LDS: <= 1e-2 of max|ref| asserted (measured
     1e-3 .. 4.4e-3, the same as the numpy emulation of the op program with fp16 storage)"""
-    from slide_amd.resident import ResidentDenoiser
+    from slide_amd.experiments.resident import ResidentDenoiser
     g, hp, sd = _load()
     den = ResidentDenoiser(hp, sd, 3, gpu_device)
     for k in ["t0", "t1", "t500", "t999", "mixed"]:
@@ -39,7 +47,7 @@ def test_resident_denoiser_forward_matches_reference(gpu_device):
 
 def test_resident_sampler_tail_matches_reference(gpu_device):
     """last 20 reverse steps of sampling() (pointnet2/util.py:235-253) with the reference's injected noise stream"""
-    from slide_amd.resident import ResidentPositionSampler
+    from slide_amd.experiments.resident import ResidentPositionSampler
     _, hp, sd = _load()
     g = load_golden("golden_sampler_pos.npz")
     dh_sigma = None
@@ -61,7 +69,7 @@ def test_resident_sampler_one_launch_equals_many(gpu_device):
     """n reverse steps inside one launch == n launches of one step (bit-identical), and the in-kernel Philox stream is the
     engine sampler's: (seed, chain nonce, step, element)"""
     from slide_amd.diffusion import PositionSampler
-    from slide_amd.resident import ResidentPositionSampler
+    from slide_amd.experiments.resident import ResidentPositionSampler
     _, hp, sd = _load()
     B, n = 7, 12
     rs = np.random.RandomState(3)

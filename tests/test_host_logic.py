@@ -3,6 +3,7 @@ parameter spec, schedules, plan structure / FLOP accounting, checkpoint layout."
 import json
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import golden_spec, load_golden
@@ -37,6 +38,32 @@ def test_schedules_match_reference_tables():
     dp = latent_diffusion_params(json.loads(str(g["config_json"])))
     for k in ("logvar", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1", "posterior_mean_coef2"):
         assert np.array_equal(dp[k], g["sched_" + k])
+
+
+def test_every_beta_schedule_matches_the_reference_tables():
+    """golden_schedules.npz: Diffusion.init_diffusion_parameters of the reference (diffusion.py:158-208) for every schedule
+    name its get_beta_schedule (:12-28) can produce x both variance types x T in {1000, 50}; product and oracle restatements"""
+    import warnings
+    from oracle import denoiser_np as D
+    from slide_amd.diffusion import get_beta_schedule, latent_diffusion_params
+    g = load_golden("golden_schedules.npz")
+    cfgs = json.loads(str(g["configs_json"]))
+    assert {c["beta_schedule"] for c in cfgs} == {"linear", "quad", "const", "jsd"}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # ('jsd' ends at beta = 1: alpha_bar = 0 -> inf / nan entries, as in the reference)
+        for k, c in enumerate(cfgs):
+            for name, dp in (("product", latent_diffusion_params(c)), ("oracle", D.latent_diffusion_params(c))):
+                assert dp["T"] == c["num_diffusion_timesteps"]
+                for nm in ("logvar", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
+                           "posterior_mean_coef2"):
+                    assert np.array_equal(dp[nm], g["c%d_%s" % (k, nm)], equal_nan=True), (name, c["beta_schedule"], nm)
+    # the two names whose helper the reference never defines: DDPM's warm-up ramp
+    for nm, frac in (("warmup10", 0.1), ("warmup50", 0.5)):
+        b = get_beta_schedule(nm, 1e-4, 0.02, 1000)
+        n = int(1000 * frac)
+        assert b.shape == (1000,) and b[0] == 1e-4 and np.all(b[n - 1:] == 0.02) and np.all(np.diff(b[:n]) > 0)
+    with pytest.raises(NotImplementedError):
+        get_beta_schedule("cosine", 1e-4, 0.02, 10)
 
 
 def test_plan_structure_and_flops():

@@ -10,7 +10,7 @@ from conftest import golden_spec, load_golden
 from oracle import denoiser_np as D
 from resident_emu import Emu
 from slide_amd.engine import DenoiserEngine
-from slide_amd.resident import LDS_LIMIT, R_GEMM, R_TAIL, ResidentPlan
+from slide_amd.experiments.resident import LDS_LIMIT, R_GEMM, R_TAIL, ResidentPlan
 from slide_amd.synth import synth_state_dict
 
 

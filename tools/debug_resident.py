@@ -12,7 +12,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 from conftest import golden_spec, load_golden  # noqa: E402
 from resident_emu import Emu  # noqa: E402
-from slide_amd import resident as R  # noqa: E402
+from slide_amd.experiments import resident as R  # noqa: E402
 from slide_amd.synth import synth_state_dict  # noqa: E402
 
 g = load_golden("golden_denoiser_pos.npz")

@@ -218,6 +218,36 @@ def gen_sampler_feat_full(net, cfg, out, B=2):
     print("sampler feat full chain: draws", ns.count)
 
 
+def gen_schedules(out):
+    """the schedule tables of Diffusion.init_diffusion_parameters (diffusion.py:158-208) for every beta schedule the
+    reference's get_beta_schedule can produce ('warmup10' / 'warmup50' raise NameError there: `_warmup_beta` is never
+    defined) and both variance types, T = 1000 and a short T = 50"""
+    from diffusion_utils import diffusion as D
+    res, cfgs = {}, []
+    base = copy.deepcopy(load_cfg(FEAT_CFG)["standard_diffusion_config"])
+    for sched in ("linear", "quad", "const", "jsd"):
+        for vt in ("fixedsmall", "fixedlarge"):
+            for T in (1000, 50):
+                c = copy.deepcopy(base)
+                c.update(beta_schedule=sched, model_var_type=vt, num_diffusion_timesteps=T)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    dm = D.LatentDiffusion(c, autoencoder=None, device=torch.device("cpu"))
+                k = len(cfgs)
+                cfgs.append(c)
+                for nm in ["logvar", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
+                           "posterior_mean_coef2"]:
+                    res["c%d_%s" % (k, nm)] = np.asarray(getattr(dm, nm), np.float64)
+    for sched in ("warmup10", "warmup50"):
+        try:
+            D.get_beta_schedule(sched, beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=10)
+            raise SystemExit("the reference now defines _warmup_beta: record its tables too")
+        except NameError:
+            pass
+    res["configs_json"] = np.array(json.dumps(cfgs))
+    np.savez_compressed(os.path.join(out, "golden_schedules.npz"), **res)
+    print("schedules:", len(cfgs), "configs")
+
+
 def gen_sampler_feat_resample(out, B=2):
     """LatentDiffusion.denoise_and_reconstruct(local_resampling=True) (diffusion.py:346-359, :76-79): features are
     re-generated only on the points with keypoint_mask == 1, the predicted x0 of the others is pinned to complete_x0.
@@ -474,7 +504,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.manual_seed(0)
-    want = set(a.only.split(",")) if a.only else {"ops", "blocks", "pos", "feat", "resample", "decode", "encode"}
+    want = set(a.only.split(",")) if a.only else {"ops", "blocks", "pos", "feat", "resample", "sched", "decode", "encode"}
     if "ops" in want:
         gen_ops(a.out)
     if "blocks" in want:
@@ -491,6 +521,8 @@ if __name__ == "__main__":
         gen_sampler_feat_full(net, cfg, a.out)
     if "resample" in want:
         gen_sampler_feat_resample(a.out)
+    if "sched" in want:
+        gen_schedules(a.out)
     if "decode" in want:
         gen_decode(a.out)
     if "encode" in want:

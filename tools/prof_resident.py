@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from slide_amd import configs, model_spec
-from slide_amd.resident import ResidentPositionSampler
+from slide_amd.experiments.resident import ResidentPositionSampler
 from slide_amd.synth import synth_state_dict
 dev = torch.device("cuda:0")
 B = 256

@@ -4,7 +4,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slide_amd import configs, model_spec
 from slide_amd.diffusion import PositionSampler
-from slide_amd.resident import ResidentPositionSampler
+from slide_amd.experiments.resident import ResidentPositionSampler
 from slide_amd.synth import synth_state_dict
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
@@ -40,7 +40,7 @@ tl = torch.zeros(len(r.plan.ops) + 2, dtype=torch.int64, device=dev)
 r.begin(lab, xT)
 with torch.cuda.stream(r.stream):
     a = r.plan.args(3, r.engine.x, t_dev=r.engine.t_dev, tabs=r.tabs, seed=5, timeline=tl)
-    from slide_amd.resident import _run
+    from slide_amd.experiments.resident import _run
     _run(a, r.stream)
 r.stream.synchronize()
 t = tl.cpu().numpy()
