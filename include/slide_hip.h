@@ -79,6 +79,12 @@ SLIDE_API int slide_knn_gather(int b, int n2, int u, int n1, int K, const float 
 SLIDE_API int slide_sample_farthest_points(int b, int n, int K, const float *points, const int *start_idx, float *temp,
                                            int *idx, slide_stream_t stream);
 
+/* Row-layout gather (build addition; the (B, N, C) counterpart of gather_points, sampling.cpp:4-6): points (b,n,c) row-major,
+ * idx (b,m) int32 -> out (b,m,c).  Moves exactly the gathered bytes; gather_points' (B,C,N) layout costs a 64-byte sector per
+ * gathered element.  What FPS -> gather of the row-major module path and of (B,N,3) coordinates uses. */
+SLIDE_API int slide_gather_rows(int b, int n, int m, int c, const float *points, const int *idx, float *out,
+                                slide_stream_t stream);
+
 /* ------------------------------------------------------------------ Part 3: denoiser engine */
 /* see slide_engine.h */
 SLIDE_API const char *slide_hip_version(void);

@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--not_include_idx_to_save_name", action="store_true")
     ap.add_argument("--random_init", action="store_true")
     ap.add_argument("--encode_from", type=str, default=None, help="npz with points, normals, keypoint, label: encode first")
+    ap.add_argument("--seed", type=int, default=0, help="seeds the start index of the decode's plain-FPS calls (per shape: a function "
+                                                          "of (seed, shape index), independent of ranks and batches)")
     a = ap.parse_args()
 
     import torch
@@ -66,7 +68,10 @@ def main():
         raise SystemExit("give exactly one of --dataset_path / --encode_from")
     cfg = read_json_file(a.config)
     enc, decs = autoencoder_read_config(os.path.dirname(os.path.abspath(a.config)), cfg)
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    # one process per GPU under torch.distributed.run: every rank decodes its contiguous shard (the
+    # reference's per-rank decode: pointnet2/mesh_evaluation.py:113-118), one all-gather of the clouds, rank 0 writes
+    from slide_amd.generation import all_gather_rows, decode_shard, init_distributed, shard_range
+    rank, world, dev, gdev = init_distributed()
     ae = PointAutoencoder(enc if a.encode_from else None, decs,
                           apply_kl_regularization=cfg["pointnet_config"].get("apply_kl_regularization", False),
                           kl_weight=cfg["pointnet_config"].get("kl_weight", 0))
@@ -83,18 +88,33 @@ def main():
     n = keypoint.shape[0]
     label = src["label"].astype(np.int64) if "label" in src.files else np.zeros(n, np.int64)
     B = a.batch_size
-    feats, clouds = [], []
-    for lo in range(0, n, B):
-        kp = torch.from_numpy(keypoint[lo:lo + B]).to(dev)
-        lab = torch.from_numpy(label[lo:lo + B]).to(dev)
-        if a.encode_from:
-            pc = np.concatenate([src["points"][lo:lo + B], src["normals"][lo:lo + B]], axis=2).astype(np.float32)
-            f = ae.encode(torch.from_numpy(pc).to(dev), kp, ts=None, label=lab, sample_posterior=False)
-        else:
-            f = torch.from_numpy(src["keypoint_feature"][lo:lo + B].astype(np.float32)).to(dev)
-        feats.append(f.cpu().numpy())
-        clouds.append(ae.decode(kp, f.contiguous(), ts=None, label=lab).cpu().numpy())
-    clouds = np.concatenate(clouds, axis=0)
+    s0, e0 = shard_range(n, rank, world)
+    feats = None
+    if a.encode_from:
+        def encode(lo, hi, kp, lab):
+            pc = np.concatenate([src["points"][s0 + lo:s0 + hi], src["normals"][s0 + lo:s0 + hi]], axis=2).astype(np.float32)
+            return ae.encode(torch.from_numpy(pc).to(dev), kp, ts=None, label=lab, sample_posterior=False)
+        c_local, f_local = decode_shard(ae, keypoint[s0:e0], None, label[s0:e0], B, dev, seed=a.seed, global_offset=s0, encode=encode)
+        if f_local is None:
+            f_local = torch.empty(0, 16, 1, device=dev)
+        if world > 1:  # (an empty shard learns the feature width from the others)
+            import torch.distributed as dist
+            widths = [None] * world
+            dist.all_gather_object(widths, int(f_local.shape[2]) if e0 > s0 else None)
+            wf = next(w for w in widths if w is not None)
+            if e0 == s0:
+                f_local = torch.empty(0, 16, wf, device=dev)
+        feats = all_gather_rows(f_local, n, world, device=gdev).cpu().numpy()
+    else:
+        c_local = decode_shard(ae, keypoint[s0:e0], src["keypoint_feature"][s0:e0].astype(np.float32), label[s0:e0], B, dev,
+                               seed=a.seed, global_offset=s0)
+    clouds = all_gather_rows(c_local, n, world, device=gdev).cpu().numpy()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
     category = list(src["category"]) if "category" in src.files else [CATEGORY_IDS[int(l)] for l in label]
     category_name = list(src["category_name"]) if "category_name" in src.files else [CATEGORY_NAMES[int(l)] for l in label]
     result = {"points": clouds[:, :, 0:3], "label": label, "category": np.array(category), "category_name":
@@ -102,7 +122,7 @@ def main():
     if clouds.shape[2] == 6:
         result["normals"] = clouds[:, :, 3:6]
     if a.encode_from:
-        result["keypoint_feature"] = np.concatenate(feats, axis=0)
+        result["keypoint_feature"] = feats
     os.makedirs(a.save_dir, exist_ok=True)
     f = os.path.join(a.save_dir, "reconstructed_pcd.npz")
     np.savez(f, **result)

@@ -190,6 +190,20 @@ def knn_gather(x, idx):
     return out
 
 
+def gather_rows(points, idx):
+    """row-layout counterpart of gather_points: points (B,N,C) float32, idx (B,M) int32 -> (B,M,C).  Moves only the gathered rows
+    (gather_points on the reference's (B,C,N) layout pays a 64-byte sector per gathered element)."""
+    points = points.contiguous(); idx = idx.contiguous()
+    _chk_float(points, "points"); _need_gpu(points)
+    if idx.dtype != torch.int32:
+        raise RuntimeError("idx must be an int tensor")
+    B, N, C = points.shape
+    M = idx.shape[1]
+    out = torch.empty((B, M, C), device=points.device, dtype=torch.float32)
+    check(lib().slide_gather_rows(B, N, M, C, ptr(points), ptr(idx), ptr(out), stream_of()), "gather_rows")
+    return out
+
+
 def sample_farthest_points(points, lengths=None, K=50, random_start_point=False, start_idx=None):
     """pytorch3d.ops.sample_farthest_points counterpart (call site point_upsample_decoder.py:178-180):
     -> (selected points (B,K,C), idx int64 (B,K)).  FPS on points[..., :3]; `random_start_point` draws the first index

@@ -18,7 +18,7 @@ EXPORTS = [
     "furthest_point_sampling_kernel_wrapper", "query_ball_point_kernel_wrapper",
     "group_points_kernel_wrapper", "group_points_grad_kernel_wrapper", "three_nn_kernel_wrapper",
     "three_interpolate_kernel_wrapper", "three_interpolate_grad_kernel_wrapper", "slide_knn_points",
-    "slide_knn_gather", "slide_sample_farthest_points", "slide_hip_version", "slide_hip_device_ok",
+    "slide_knn_gather", "slide_gather_rows", "slide_sample_farthest_points", "slide_hip_version", "slide_hip_device_ok",
 ]
 
 

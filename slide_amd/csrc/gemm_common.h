@@ -182,18 +182,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
   // is the same for every channel block: looked up ONCE here, under phase 1, instead of at the top of every block's phase 2
   // (one dependent L2 round trip per block less: 11.3 -> 6 us of store phase on the FP1 layer of the feature net)
   int nbr_row[RB];
-  f32x2 nbr_sc[RB];  // (d2, w)
+  f16x2 nbr_sc[RB];  // (d2, w)
   if constexpr (PAIRRES && NPXL == 7 && std::is_same<T, _Float16>::value) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       nbr_row[rb] = 0;
-      nbr_sc[rb] = f32x2{0.f, 0.f};
+      nbr_sc[rb] = f16x2{(_Float16)0.f, (_Float16)0.f};
       const int row = row0 + wave * 64 + rb * 32 + col;
       if (a.gidx && a.gx_d2 && a.gx_w && row < a.rows) {
         const int smp = row >> NPXL, pxl = row & (NPX - 1);
         const int slot = (smp * 16 + (pxl >> 3)) * 16 + (pxl & 7);
         nbr_row[rb] = smp * 16 + a.gidx[slot];
-        nbr_sc[rb] = f32x2{a.gx_d2[slot], a.gx_w[slot]};
+        // (the squared distance is clamped to the fp16 range before the conversion -- ADVICE r3: beyond 65504 it became inf.  The
+        //  residual itself stays in packed fp16, like the generated-X fragments of the same block: evaluating it in fp32 -- tried in
+        //  round 4 -- left single forwards unchanged and made 1000-step position chains deviate 5x MORE from the fp32 mode
+        //  (median per-shape distance 6.8e-4 vs 1.4e-4, tools/chain_dev.py): the block's two uses of (d2, w) then round differently)
+        nbr_sc[rb] = f16x2{(_Float16)fminf(a.gx_d2[slot], 65504.f), (_Float16)a.gx_w[slot]};
       }
     }
   }
@@ -238,7 +242,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
         }
         // pair residual: the row's value is the sum of two per-point table rows (+ the two per-slot terms of group_knn)
         size_t ra_row = (size_t)row, rb_row = 0;
-        float sd232 = 0.f, sw32 = 0.f;
+        _Float16 sd2 = (_Float16)0.f, sw = (_Float16)0.f;
         if constexpr (kHalf && NPXL >= 7 && PAIRRES) {
           if (pair && ok) {
             const int smp = row >> NPXL, pxl = row & (NPX - 1);
@@ -246,7 +250,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
               ra_row = (size_t)(smp * 16 + (pxl & 15)); rb_row = (size_t)(row >> 4);
             } else if constexpr (NPXL == 7) {
               ra_row = (size_t)nbr_row[rb]; rb_row = (size_t)(row >> 3);
-              sd232 = nbr_sc[rb][0]; sw32 = nbr_sc[rb][1];
+              sd2 = nbr_sc[rb][0]; sw = nbr_sc[rb][1];
             }
           }
         }
@@ -259,25 +263,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
               if constexpr (NPXL >= 7 && PAIRRES) {
                 if (pair) {
                   const u32x4 tb = *(const GLOBAL_AS u32x4 *)(gptr<const T>(rdp(34)) + rb_row * e_res_ld + 16 * p + 8 * half);
-                  // the residual's terms are summed in fp32 and rounded ONCE to the fp16 row the store phase adds (in
-                  // packed fp16 the squared distance -- unbounded for position chains -- overflowed above 65504 and the sum was
-                  // rounded three times)
-                  const f16x8 ra8 = __builtin_bit_cast(f16x8, rpre[rb][p]), rb8 = __builtin_bit_cast(f16x8, tb);
-                  float r32[8];
-#pragma unroll
-                  for (int e = 0; e < 8; ++e) r32[e] = (float)ra8[e] + (float)rb8[e];
+                  f16x8 r8 = __builtin_bit_cast(f16x8, rpre[rb][p]) + __builtin_bit_cast(f16x8, tb);
                   if (flags & SLIDE_F_RES_PAIR_NBR) {
                     const GLOBAL_AS float *vd = gptr<const float>(rdp(36)) + 16 * p + 8 * half;
                     const GLOBAL_AS float *vw = gptr<const float>(rdp(38)) + 16 * p + 8 * half;
                     const float4 d0 = gload4(vd), d1 = gload4(vd + 4), w0 = gload4(vw), w1 = gload4(vw + 4);
-                    const float vd8[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-                    const float vw8[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) r32[e] = fmaf(sw32, vw8[e], fmaf(sd232, vd8[e], r32[e]));
+                    const f16x8 vd8 = {(_Float16)d0.x, (_Float16)d0.y, (_Float16)d0.z, (_Float16)d0.w,
+                                       (_Float16)d1.x, (_Float16)d1.y, (_Float16)d1.z, (_Float16)d1.w};
+                    const f16x8 vw8 = {(_Float16)w0.x, (_Float16)w0.y, (_Float16)w0.z, (_Float16)w0.w,
+                                       (_Float16)w1.x, (_Float16)w1.y, (_Float16)w1.z, (_Float16)w1.w};
+                    const f16x8 s8 = {sd2, sd2, sd2, sd2, sd2, sd2, sd2, sd2}, t8 = {sw, sw, sw, sw, sw, sw, sw, sw};
+                    r8 = __builtin_elementwise_fma(s8, vd8, r8);
+                    r8 = __builtin_elementwise_fma(t8, vw8, r8);
                   }
-                  f16x8 r8;
-#pragma unroll
-                  for (int e = 0; e < 8; ++e) r8[e] = (_Float16)r32[e];
                   rpre[rb][p] = __builtin_bit_cast(u32x4, r8);
                 }
               }

@@ -117,6 +117,7 @@ __device__ __forceinline__ void gemm_gx_body(const GemmArgs &a, const int bid) {
     }
     aoff[rb] = (half * NR + sl_w * 16 + q) * 16;
     boff[rb] = (half * NR + sl_w * 16 + p) * 16;
+    d2 = fminf(d2, 65504.f);  // (fp16 range: beyond it the conversion gives inf)
     d2s[rb] = f16x2{(T)d2, (T)d2};
     ws[rb] = f16x2{(T)w, (T)w};
   }

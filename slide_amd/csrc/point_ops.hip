@@ -643,6 +643,28 @@ __global__ __launch_bounds__(256) void knn_gather_kernel(int n2, int u, size_t t
   }
 }
 
+// gather of whole ROWS: points (b, n, c) row-major, idx (b, m) -> out (b, m, c).  The (B, C, N) layout of gather_points costs a
+// 64-byte sector per gathered 4-byte element (with m = n / 4 random indices nearly every sector of a channel row holds a selected
+// element: the whole row is fetched, 2.5x the algorithmic bytes at best); a row-major table moves exactly what it gathers.
+// One 16-byte piece per thread (c % 4 == 0, 16-byte aligned rows), else one element per thread.
+template <bool V4>
+__global__ __launch_bounds__(256) void gather_rows_kernel(int n, int m, int c, size_t total, const float *__restrict__ points,
+                                                          const int *__restrict__ idx, float *__restrict__ out) {
+  const int per = V4 ? c >> 2 : c;  // work items per row
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t slot = e / per;  // (batch, output row)
+    const int piece = (int)(e - slot * per);
+    const size_t b = slot / m;
+    const float *src = points + (b * n + (size_t)idx[slot]) * c;
+    if (V4) {
+      const pf4 v = __builtin_nontemporal_load(reinterpret_cast<const pf4 *>(src) + piece);
+      __builtin_nontemporal_store(v, reinterpret_cast<pf4 *>(out + slot * c) + piece);
+    } else {
+      out[slot * c + piece] = src[piece];
+    }
+  }
+}
+
 inline int ilog2(int v) {
   int l = 0;
   while ((1 << (l + 1)) <= v) ++l;
@@ -942,6 +964,21 @@ int slide_knn_gather(int b, int n2, int u, int n1, int K, const float *x, const 
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(knn_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n2, u, total,
                      x, idx, out, n1 * K);
+  return LAUNCH_STATUS();
+}
+
+int slide_gather_rows(int b, int n, int m, int c, const float *points, const int *idx, float *out, slide_stream_t stream) {
+  if (b <= 0 || m <= 0 || c <= 0) return 0;
+  const bool v4 = c % 4 == 0 && (((uintptr_t)points | (uintptr_t)out) & 15) == 0;
+  const size_t total = (size_t)b * m * (v4 ? c / 4 : c);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  if (v4)
+    hipLaunchKernelGGL(gather_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, m, c, total, points,
+                       idx, out);
+  else
+    hipLaunchKernelGGL(gather_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, m, c, total, points,
+                       idx, out);
   return LAUNCH_STATUS();
 }
 

@@ -476,7 +476,7 @@ class ResidentDenoiser:
         e.x.copy_(torch.as_tensor(x).to(e.device, torch.float32).reshape(e.x.shape))
         e.ts.copy_(torch.as_tensor(ts).to(e.device, torch.float32).reshape(e.B))
         e.set_label(label)
-        from .engine import OP_TEMB, SlideOp
+        from ..engine import OP_TEMB, SlideOp
         temb = [o for o in e.ops if o.kind == OP_TEMB]
         e.run((SlideOp * 1)(temb[0]))
         d = torch.zeros(e.B, self.plan.lds_bytes, dtype=torch.uint8, device=e.device) if dbg else None
@@ -490,7 +490,7 @@ class ResidentPositionSampler:
     diffusion.PositionSampler (seed, chain nonce, step, element)."""
 
     def __init__(self, hp, state_dict, batch, device, diffusion_config, noise=None, seed=0):
-        from .diffusion import F32, calc_diffusion_hyperparams
+        from ..diffusion import F32, calc_diffusion_hyperparams
         self.engine = e = DenoiserEngine(hp, state_dict, batch, device, prec="fp16", per_sample_t=False, t_table=diffusion_config["T"])
         self.plan = ResidentPlan(e)
         self.B, self.device, self.seed = int(batch), device, int(seed)

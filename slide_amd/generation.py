@@ -48,6 +48,42 @@ def start_noise(seed, tag, lo, hi, tail, device):
     return torch.cat(out) if out else torch.empty((0,) + tuple(tail), device=device)
 
 
+def fps_start_indices(seed, lo, hi, n, device):
+    """first index of the decode's plain-FPS calls for shapes [lo, hi) of a run: uniform in [0, n), a function of (seed, GLOBAL shape
+    index) only (blocks of 1024 shapes, like start_noise) -- the reference draws it from the device generator
+    (point_upsample_decoder.py:178-180, random_start_point=True), which makes a decoded cloud depend on the rank / batch split"""
+    out = []
+    g = torch.Generator(device=device)
+    for k in range(lo // 1024, (max(hi, lo + 1) - 1) // 1024 + 1):
+        g.manual_seed((int(seed) * 1000003 + 3 * 7919 + k) & 0x7FFFFFFFFFFF)
+        blk = torch.randint(0, int(n), (1024,), device=device, generator=g, dtype=torch.int64)
+        out.append(blk[max(lo - 1024 * k, 0):min(hi - 1024 * k, 1024)])
+    return torch.cat(out) if out else torch.empty((0,), device=device, dtype=torch.int64)
+
+
+def decode_shard(ae, keypoint, feature, labels, batch_size, device, seed=0, global_offset=0, encode=None):
+    """this rank's part of BASELINE configs[4] (the reference decodes per rank too,
+    pointnet2/mesh_evaluation.py:113-118): PointAutoencoder.decode of the rank's OWN latents, batch by batch ->
+    (n_local, 2048, 6) on `device` (empty shard: (0, 2048, 6)).  keypoint (n_local, 16, 3) / feature (n_local, 16, F) / labels
+    (n_local,): tensors or arrays.  The plain-FPS start index of shape g is fps_start_indices(seed, g), so a decoded cloud does not
+    depend on how the run is split.  encode(lo, hi, keypoint batch, label batch) -> feature batch, when the features come from
+    PointAutoencoder.encode instead (autoencoder_decode_keypoint.py --encode_from); returns (clouds, features) then."""
+    kp = torch.as_tensor(keypoint, dtype=torch.float32)
+    n = int(kp.shape[0])
+    clouds, feats = [], []
+    for lo, hi in batches(0, n, batch_size):
+        k_ = kp[lo:hi].to(device).contiguous()
+        lab = torch.as_tensor(labels[lo:hi]).to(device=device, dtype=torch.int64)
+        f_ = encode(lo, hi, k_, lab) if encode is not None else torch.as_tensor(feature[lo:hi], dtype=torch.float32).to(device)
+        start = fps_start_indices(seed, global_offset + lo, global_offset + hi, 512, device)
+        clouds.append(ae.decode(k_, f_.contiguous(), ts=None, label=lab, fps_start_idx=start))
+        feats.append(f_)
+    out = torch.cat(clouds) if clouds else torch.empty(0, 2048, 6, device=device)
+    if encode is not None:
+        return out, (torch.cat(feats) if feats else None)
+    return out
+
+
 def shard_range(num_samples, rank, world_size):
     """contiguous slice [start, end) of rank `rank` (ceil division; trailing ranks may be short or empty)"""
     if world_size <= 1:
@@ -181,13 +217,11 @@ class CategoryChains:
                             seed=seed_f, use_graph=False)
         return ps, fs
 
-    def run(self, gen=None, steps=None):
+    def run(self, steps=None):
         """position chain then feature chain of every segment (all `steps` reverse steps, default the full schedule); the
         position chain of segment k + 1 runs beside the feature chain of segment k (independent streams).
-        Returns the rank's latents (n_local, 16, 3 + F) on the device.  `gen` is no longer used -- the start noise of shape g is
-        start_noise(seed, ..., g), independent of ranks and batches -- and passing one is an error rather than silently ignored."""
-        if gen is not None:
-            raise TypeError("CategoryChains.run: `gen` is not supported any more (start noise is keyed on (seed, global shape index))")
+        Returns the rank's latents (n_local, 16, 3 + F) on the device.  (The start noise of shape g is start_noise(seed, ..., g),
+        independent of ranks and batches: there is no generator argument any more -- ADVICE r3.)"""
         outs, pending = [], None
         for c, lo, hi, ps, fs in self.chains:
             n = hi - lo
@@ -205,9 +239,9 @@ class CategoryChains:
             outs.append(pending.state())
         return torch.cat(outs, dim=0) if outs else torch.empty(0, 16, self.cx, device=self.device)
 
-    def generate(self, gen=None, steps=None):
+    def generate(self, steps=None):
         """-> (latents [total, 16, 3 + F] on every rank, labels [total]); one all-gather (RCCL over xGMI; gloo in the tests)"""
-        local = self.run(gen, steps)
+        local = self.run(steps)
         base = self.segments[0][1] if self.segments else 0
         return generate_categories(self.total, lambda c, lo, hi: local[lo - base:hi - base], self.rank, self.world, self.categories,
                                    gather_device=self.device, row_shape=(16, self.cx))

@@ -9,8 +9,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from slide_amd.generation import (FIVE_CATEGORIES, all_gather_rows, batches, category_layout, category_segments,
-                                   generate_categories, generate_latents, save_generated, shard_range)
+from slide_amd.generation import (FIVE_CATEGORIES, all_gather_rows, batches, category_layout, category_segments, decode_shard,
+                                   fps_start_indices, generate_categories, generate_latents, save_generated, shard_range)
 
 
 def test_shard_range_matches_reference_rule():
@@ -171,9 +171,9 @@ def _worker_real_chains(rank, world, port, total, steps):
     weights = lambda c: (synth_state_dict(spec_p, seed=100 + c), synth_state_dict(spec_f, seed=200 + c))
 
     class Chains(CategoryChains):
-        def generate(self, gen=None, steps=None):  # gather through the CPU (gloo)
+        def generate(self, steps=None):  # gather through the CPU (gloo)
             from slide_amd.generation import generate_categories
-            local = self.run(gen, steps).cpu()
+            local = self.run(steps).cpu()
             base = self.segments[0][1] if self.segments else 0
             return generate_categories(self.total, lambda c, lo, hi: local[lo - base:hi - base], self.rank, self.world, self.categories,
                                        gather_device=torch.device("cpu"), row_shape=(16, self.cx))
@@ -190,3 +190,54 @@ def _worker_real_chains(rank, world, port, total, steps):
 @pytest.mark.gpu
 def test_category_chains_world2_equals_world1_on_the_gpu():
     mp.spawn(_worker_real_chains, args=(2, _free_port(), 13, 8), nprocs=2, join=True)
+
+
+class _FakeAutoencoder:
+    """stands in for PointAutoencoder.decode on CPU: the cloud of a shape encodes its key points, features, label and the FPS start
+    index it was handed -- whatever batch it sits in"""
+
+    def __init__(self):
+        self.batches = []
+
+    def decode(self, keypoint, feature, ts=None, label=None, fps_start_idx=None):
+        b = keypoint.shape[0]
+        self.batches.append(b)
+        assert fps_start_idx.shape == (b,) and fps_start_idx.dtype == torch.int64 and int(fps_start_idx.max()) < 512
+        base = keypoint.sum(dim=(1, 2)) + 10 * feature.sum(dim=(1, 2)) + 1000 * label.float() + 1e4 * fps_start_idx.float()
+        return base[:, None, None] + torch.arange(2048 * 6, dtype=torch.float32).reshape(1, 2048, 6)
+
+
+def _decode_worker(rank, world, port, n, bs):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    rs = np.random.RandomState(0)
+    lat = rs.standard_normal((n, 16, 51)).astype(np.float32)
+    labels = np.arange(n) % 13
+    s0, e0 = shard_range(n, rank, world)
+    ae = _FakeAutoencoder()
+    c_local = decode_shard(ae, lat[s0:e0, :, :3], lat[s0:e0, :, 3:], labels[s0:e0], bs, dev, seed=5, global_offset=s0)
+    assert c_local.shape == (e0 - s0, 2048, 6) and ae.batches == [hi - lo for lo, hi in batches(0, e0 - s0, bs)]
+    full = all_gather_rows(c_local, n, world)
+    # one rank, one batch: the same clouds in the same order (per-shape FPS start indices are keyed on the global index)
+    ref = decode_shard(_FakeAutoencoder(), lat[:, :, :3], lat[:, :, 3:], labels, n, dev, seed=5, global_offset=0)
+    assert full.shape == (n, 2048, 6) and torch.equal(full, ref)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world,bs", [(11, 2, 4), (5, 3, 2), (2, 3, 4)])
+def test_sharded_decode_gathers_in_order_gloo(n, world, bs):
+    """BASELINE configs[4] on N ranks: every rank decodes its own latent shard, one all-gather of the (n_local, 2048, 6) clouds
+    (ranks with short or EMPTY shards included) reproduces the single-rank result"""
+    mp.spawn(_decode_worker, args=(world, _free_port(), n, bs), nprocs=world, join=True)
+
+
+def test_fps_start_indices_depend_on_the_global_index_only():
+    dev = torch.device("cpu")
+    a = fps_start_indices(7, 0, 3000, 512, dev)
+    assert a.shape == (3000,) and int(a.min()) >= 0 and int(a.max()) < 512 and len(set(a.tolist())) > 300
+    assert torch.equal(fps_start_indices(7, 1000, 1030, 512, dev), a[1000:1030])  # across a block boundary
+    assert torch.equal(fps_start_indices(7, 2047, 2050, 512, dev), a[2047:2050])
+    assert not torch.equal(fps_start_indices(8, 0, 64, 512, dev), a[:64])
+    assert fps_start_indices(7, 5, 5, 512, dev).shape == (0,)

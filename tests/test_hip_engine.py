@@ -47,7 +47,61 @@ def test_denoiser_forward_fp16_mfma(gpu_device, name):
         ref = g["eps_" + k]
         worst = max(worst, float(np.linalg.norm(y - ref) / np.linalg.norm(ref)))
     print("fp16-MFMA relative L2 error vs reference (%s): %.3e" % (name, worst))
-    assert worst <= 5e-3, worst
+    # north_star / BASELINE.md section 4: 1e-3 relative on single forwards.  The FEATURE net meets it in the throughput mode
+    # (measured 8.5e-4).  The POSITION net does not (3.2e-3 on these inputs): every one of its layers' operand roundings
+    # contributes -- tools/prec_emul.py: weights-only 9.5e-4, activations-only 8.5e-4, no subset of modules in wide operands gets
+    # under 7.5e-4, a two-term fp16 split of both operands 1e-6 -- and the error grows as the coordinates shrink (DESIGN.md
+    # section 5).  Its 1e-3 mode is `prec="fp32"` (bench.py --pos-prec fp32; the CLIs' --prec fp32), asserted above at 2e-4.
+    assert worst <= (1e-3 if name == "feat" else 4e-3), worst
+
+
+@pytest.mark.parametrize("B", [88, 256])
+def test_feature_denoiser_at_the_benched_launch_sizes_matches_oracle(gpu_device, B):
+    """the goldens hold 2-3 samples; the benched launches hold 88 / 80 samples per feature sub-batch (and 256 in
+    the single-chain arrangement) -- other tile maps, XCD groups, grid-size dependent kernel choices.  The exact-fp32 engine
+    against the numpy oracle at those sizes (<= 2e-4 of the output's max, as at golden size), and the fp16 throughput plan
+    against the same oracle output (<= 1e-3 relative L2, the single-forward criterion)."""
+    from oracle import denoiser_np as D
+    from slide_amd.engine import DenoiserEngine
+    from slide_amd.synth import synth_keypoints
+    g, hp, sd = _load("feat")
+    rs = np.random.RandomState(B)
+    x = rs.standard_normal((B, 16, 51)).astype(np.float32)
+    x[:, :, :3] = synth_keypoints(B, seed=B)
+    ts = rs.randint(0, 1000, B).astype(np.float32)
+    label = rs.randint(0, 13, B).astype(np.int64)
+    ref = np.concatenate([D.denoiser_forward(hp, sd, x[i:i + 32], ts[i:i + 32], label[i:i + 32]) for i in range(0, B, 32)])
+    y32 = DenoiserEngine(hp, sd, B, gpu_device, prec="fp32").forward(x, ts, label).cpu().numpy()
+    assert np.isfinite(y32).all() and _rel(y32, ref) <= 2e-4, _rel(y32, ref)
+    y16 = DenoiserEngine(hp, sd, B, gpu_device, prec="fp16").forward(x, ts, label).cpu().numpy()
+    r16 = float(np.linalg.norm(y16 - ref) / np.linalg.norm(ref))
+    per = np.linalg.norm((y16 - ref).reshape(B, -1), axis=1) / np.linalg.norm(ref.reshape(B, -1), axis=1)
+    print("feature net, B = %d: fp32 engine vs oracle %.2e (max-norm); fp16 plan vs oracle %.2e relative L2 (per sample: median %.2e, max %.2e)"
+          % (B, _rel(y32, ref), r16, np.median(per), per.max()))
+    assert np.isfinite(y16).all() and r16 <= 1e-3, r16
+
+
+def test_position_denoiser_at_the_benched_launch_size_matches_oracle(gpu_device):
+    """the position chain's launch size (256 samples): exact-fp32 engine vs the numpy oracle, <= 2e-4; the fp16 plan is reported
+    against the same output for two input families (chain start: N(0, 1); chain end: key-point-like coordinates)"""
+    from oracle import denoiser_np as D
+    from slide_amd.engine import DenoiserEngine
+    from slide_amd.synth import synth_keypoints
+    g, hp, sd = _load("pos")
+    B = 256
+    rs = np.random.RandomState(17)
+    ts = rs.randint(0, 1000, B).astype(np.float32)
+    label = rs.randint(0, 13, B).astype(np.int64)
+    e32 = DenoiserEngine(hp, sd, B, gpu_device, prec="fp32")
+    e16 = DenoiserEngine(hp, sd, B, gpu_device, prec="fp16")
+    for fam, x in (("normal", rs.standard_normal((B, 16, 3)).astype(np.float32)), ("keypoints", synth_keypoints(B, seed=3).astype(np.float32))):
+        ref = D.denoiser_forward(hp, sd, x, ts, label)
+        y32 = e32.forward(x, ts, label).cpu().numpy()
+        assert np.isfinite(y32).all() and _rel(y32, ref) <= 2e-4, (fam, _rel(y32, ref))
+        y16 = e16.forward(x, ts, label).cpu().numpy()
+        r16 = float(np.linalg.norm(y16 - ref) / np.linalg.norm(ref))
+        print("position net, B = 256, %s inputs: fp32 engine vs oracle %.2e; fp16 plan vs oracle %.2e relative L2" % (fam, _rel(y32, ref), r16))
+        assert np.isfinite(y16).all() and r16 <= (1.2e-3 if fam == "normal" else 4e-3), (fam, r16)
 
 
 def test_denoiser_larger_batch_matches_oracle(gpu_device):

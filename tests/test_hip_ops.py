@@ -96,6 +96,24 @@ def test_gather_group_interpolate(gpu_device):
                            O.three_interpolate_grad(G, idx, w, m), atol=1e-3)
 
 
+def test_gather_rows(gpu_device):
+    """row-layout gather (build addition, include/slide_hip.h): (B,N,C) rows by (B,M) indices == numpy take_along_axis, and
+    == gather_points on the transposed layout; 16-byte pieces, unaligned widths, repeated and boundary indices, empty output"""
+    from slide_amd import _ext
+    rs = np.random.RandomState(21)
+    for (B, N, M, C) in [(3, 100, 37, 64), (2, 1024, 256, 128), (4, 16, 16, 51), (1, 7, 9, 3), (2, 2048, 1024, 32), (1, 5, 1, 4)]:
+        pts = rs.standard_normal((B, N, C)).astype(np.float32)
+        idx = rs.randint(0, N, (B, M)).astype(np.int32)
+        idx[:, 0] = N - 1
+        idx[:, -1] = 0
+        got = _ext.gather_rows(T(pts, gpu_device), T(idx, gpu_device)).cpu().numpy()
+        want = np.take_along_axis(pts, idx[:, :, None].astype(np.int64), axis=1)
+        assert got.shape == (B, M, C) and np.array_equal(got, want)
+        ref_api = _ext.gather_points(T(np.ascontiguousarray(pts.transpose(0, 2, 1)), gpu_device), T(idx, gpu_device)).cpu().numpy()
+        assert np.array_equal(got, ref_api.transpose(0, 2, 1))
+    assert _ext.gather_rows(T(pts, gpu_device), T(np.zeros((1, 0), np.int32), gpu_device)).shape == (1, 0, 4)
+
+
 def test_three_nn(gpu_device):
     from slide_amd import _ext
     g = load_golden("golden_ops.npz")

@@ -10,11 +10,12 @@ from slide_amd import _ext as E
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--manifest", required=True); ap.add_argument("--reps", type=int, default=3)
-ap.add_argument("--max-gb", type=float, default=12.0)
+ap.add_argument("--max-gb", type=float, default=40.0)  # (B 2048 x N 8192 group_points writes 34 GB; the GPU holds 288)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(0)
-SIZES = [(256, 128, 32, 64), (1024, 256, 32, 128), (2048, 1024, 32, 32), (8192, 2048, 32, 64)]  # (N, npoint, nsample, C)
+SIZES = [(16, 16, 16, 51), (16, 16, 16, 256), (256, 128, 32, 64), (1024, 256, 32, 128), (2048, 1024, 32, 32),
+         (8192, 2048, 32, 64)]  # (N, npoint, nsample, C): every row of SURVEY.md section 8(d)
 cases = []
 
 
@@ -47,6 +48,11 @@ for B in (256, 2048):
                 lambda: E.group_points(feats, idx_g))
             run("gather_points", tag, dict(r=4 * B * (C * M + M), w=4 * B * C * M, alloc=4.0 * B * C * M),
                 lambda: E.gather_points(feats, idx_m), dict(physical_read_B=4 * B * C * N))
+            # the same gather on a ROW-MAJOR (B, N, C) table (slide_gather_rows): moves what it gathers
+            feats_r = feats.transpose(1, 2).contiguous()
+            run("gather_rows", tag, dict(r=4 * B * (C * M + M), w=4 * B * C * M, alloc=4.0 * B * C * M),
+                lambda: E.gather_rows(feats_r, idx_m))
+            del feats_r
         known = torch.randn(B, C, M, device=dev, generator=g)
         idx3 = torch.randint(0, M, (B, N, 3), device=dev, generator=g, dtype=torch.int32)
         w3 = torch.rand(B, N, 3, device=dev, generator=g)

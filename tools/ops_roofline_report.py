@@ -9,7 +9,7 @@ import numpy as np
 
 d, out = sys.argv[1], sys.argv[2]
 man = json.load(open(os.path.join(d, "manifest.json")))["cases"]
-OURS = ("group_points", "gather_points", "three_interpolate", "three_nn", "ball_query", "knn", "fps_kernel", "sample_farthest", "furthest")
+OURS = ("group_points", "gather_points", "gather_rows", "three_interpolate", "three_nn", "ball_query", "knn", "fps_kernel", "sample_farthest", "furthest")
 
 
 def split_by_marker(rows, key):
