@@ -90,7 +90,7 @@ def _decode_profile_note():
         return None
     for line in open(fs[-1]):
         m = re.match(r"\| ([^|]+) \| (\d+) \| ([0-9.]+) \| ([0-9.]+) \| ([0-9.]+) \|", line)
-        if m and "kernel" not in m.group(1):
+        if m and m.group(1).strip() != "kernel":
             return {"source": os.path.relpath(fs[-1], REPO), "dominant_kernel": m.group(1).strip(), "share_pct": float(m.group(5)),
                     "avg_us": float(m.group(4)), "calls": int(m.group(2))}
     return {"source": os.path.relpath(fs[-1], REPO)}
@@ -304,7 +304,12 @@ def main():
         if a.replay == "threads":
             joint = ThreadedEagerSampler([pos] + [s_[0] for s_ in subs])
         elif a.replay == "eager":
-            joint = EagerChainsSampler([s_[0] for s_ in subs[:1]] + [pos] + [s_[0] for s_ in subs[1:]])
+            order = [s_[0] for s_ in subs[:1]] + [pos] + [s_[0] for s_ in subs[1:]]
+            if os.environ.get("SLIDE_BENCH_ONLY"):  # diagnostic: time a subset of the chains ("pos", "feat", "feat1" = one sub-batch)
+                only = os.environ["SLIDE_BENCH_ONLY"]
+                order = {"pos": [pos], "feat": [s_[0] for s_ in subs], "feat1": [subs[0][0]], "feat2": [s_[0] for s_ in subs[:2]],
+                         "pos+feat1": [subs[0][0], pos]}[only]
+            joint = EagerChainsSampler(order)
     cat_desc = None
     if a.workload == "five-cat":
         # per-category weight sets (synthetic, keyed on the category id); every segment of this rank's shard is a chain pair

@@ -86,7 +86,12 @@ class _GraphedSampler:
         self.engine = DenoiserEngine(hp, state_dict, batch, device, prec=prec, per_sample_t=False, t_table=T)
         self.B, self.device = int(batch), device
         self.use_graph = use_graph
-        self.stream = torch.cuda.Stream(device=device)
+        # (experiment knob SLIDE_STREAM_PRIO="<position>,<feature>": HIP stream priorities of the chains, -1 = high, 0 = default)
+        prio = 0
+        if os.environ.get("SLIDE_STREAM_PRIO"):
+            pp = [int(v) for v in os.environ["SLIDE_STREAM_PRIO"].split(",")]
+            prio = pp[0] if hp.get("in_fea_dim", 0) == 0 else pp[-1]
+        self.stream = torch.cuda.Stream(device=device, priority=prio) if prio else torch.cuda.Stream(device=device)
         # second lane of the plan (independent branches overlap); single-lane plans (the default) do not take a second
         # stream: HIP spreads streams over a few hardware queues, and an idle stream still occupies a slot
         self.stream2 = torch.cuda.Stream(device=device) if self.engine.two_lanes else self.stream
