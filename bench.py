@@ -33,7 +33,8 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}  # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+# MI355X dense MFMA peaks (MI355X_MICROARCH.md); "split" = three fp16 MFMAs per logical product
+PEAK_TFLOPS = {"fp16": 2500.0, "fp32": 157.3, "split": 2500.0 / 3}
 
 
 def cpu_baseline(batch=16, budget_s=25.0):
@@ -148,7 +149,7 @@ def parity_leg(dev, B, a, pc, fc, sd_p, sd_f, gen):
       position net grows as the coordinates shrink.
     chain: complete 1000-step chains of 64 shapes in fp16 against the fp32 mode with equal in-kernel noise: per-shape relative
       max distance (median / max) -- north_star's criterion on generated latents.
-    fp32_mode_shapes_per_s: throughput of the exact-fp32 mode; pos_fp32: see --pos-prec."""
+    fp32_mode_shapes_per_s / split_mode_shapes_per_s: throughput of the two fp32-grade modes (--prec fp32 / split)."""
     import torch
     from slide_amd.diffusion import FeatureSampler, JointSampler, PositionSampler
     from slide_amd.engine import DenoiserEngine
@@ -187,19 +188,23 @@ def parity_leg(dev, B, a, pc, fc, sd_p, sd_f, gen):
             per = np.abs(x16 - x32).max(axis=1) / np.abs(x32).max()
             par["chain_1000_steps_fp16_vs_fp32_mode"][nm] = {"shapes": nc, "per_shape_rel_max_median": round(float(np.median(per)), 6),
                                                              "per_shape_rel_max_max": round(float(per.max()), 6)}
-        p32 = PositionSampler(pc["pointnet_config"], sd_p, B, dev, pc["diffusion_config"], prec="fp32", seed=7, use_graph=True)
-        f32 = FeatureSampler(fc["pointnet_config"], sd_f, B, dev, fc["standard_diffusion_config"], prec="fp32", seed=8, use_graph=True)
-        j32 = JointSampler(p32, f32)
-        for k_ in (2, a.fp32_steps):
-            p32.begin(torch.zeros(B, dtype=torch.int64, device=dev), torch.randn(B, 16, 3, device=dev, generator=gen))
-            f32.begin(torch.full((B,), 4, dtype=torch.int64, device=dev), torch.as_tensor(synth_keypoints(B, seed=5), device=dev),
-                      torch.randn(B, 16, 51, device=dev, generator=gen))
-            j32.synchronize(); torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            j32.advance(k_)
-            j32.synchronize()
-            d32 = time.perf_counter() - t1
-        par["fp32_mode_shapes_per_s"] = round(B / (1000.0 * d32 / a.fp32_steps), 2)
+        # throughput of the two fp32-grade modes: "fp32" (fp32 MFMA) and "split" (the same plan, contractions as two-term fp16
+        # operand splits on the fp16 matrix pipe; <= 4e-6 of the fp32 mode on a forward)
+        for mode in ("fp32", "split"):
+            p32 = PositionSampler(pc["pointnet_config"], sd_p, B, dev, pc["diffusion_config"], prec=mode, seed=7, use_graph=True)
+            f32 = FeatureSampler(fc["pointnet_config"], sd_f, B, dev, fc["standard_diffusion_config"], prec=mode, seed=8, use_graph=True)
+            j32 = JointSampler(p32, f32)
+            for k_ in (2, a.fp32_steps):
+                p32.begin(torch.zeros(B, dtype=torch.int64, device=dev), torch.randn(B, 16, 3, device=dev, generator=gen))
+                f32.begin(torch.full((B,), 4, dtype=torch.int64, device=dev), torch.as_tensor(synth_keypoints(B, seed=5), device=dev),
+                          torch.randn(B, 16, 51, device=dev, generator=gen))
+                j32.synchronize(); torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                j32.advance(k_)
+                j32.synchronize()
+                d32 = time.perf_counter() - t1
+            par["%s_mode_shapes_per_s" % mode] = round(B / (1000.0 * d32 / a.fp32_steps), 2)
+            del p32, f32, j32
     return par
 
 
@@ -211,8 +216,10 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="latent shapes per GPU (BASELINE configs[1]/[2]: 256)")
-    ap.add_argument("--prec", default="fp16", choices=["fp16", "fp32"], help="MFMA operand type (fp32 accumulate)")
-    ap.add_argument("--pos-prec", default=None, choices=["fp16", "fp32"], help="operand type of the POSITION plan (default: --prec)")
+    ap.add_argument("--prec", default="fp16", choices=["fp16", "fp32", "split"],
+                    help="MFMA operand type (fp32 accumulate): fp16 = throughput mode; fp32 = exact parity mode (fp32 MFMA); split = fp32 "
+                         "storage with the contractions as two-term fp16 operand splits on the fp16 matrix pipe (fp32-grade results)")
+    ap.add_argument("--pos-prec", default=None, choices=["fp16", "fp32", "split"], help="operand type of the POSITION plan (default: --prec)")
     ap.add_argument("--sub-batches", type=int, default=3,
                     help="independent sub-batches of the per-GPU batch replayed concurrently (scheduling only)")
     ap.add_argument("--replay", default=os.environ.get("SLIDE_REPLAY", "eager"), choices=["eager", "threads", "graph"],
@@ -421,7 +428,9 @@ def main():
     out = {"metric": "latent shapes/sec (pos+feat DDPM, 1000 steps, 16 pts)", "value": round(value, 3),
            "unit": "shapes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f16 (MFMA operands + activation storage; f32 accumulate, norm statistics, softmax)" if a.prec == "fp16" else "f32", "data": "synthetic",
+           "dtype": {"fp16": "f16 (MFMA operands + activation storage; f32 accumulate, norm statistics, softmax)", "fp32": "f32",
+                     "split": "f32 storage, contractions as two-term f16 operand splits (3 x f16 MFMA per product, f32 accumulate)"}[a.prec],
+           "data": "synthetic",
            "config": {"workload": "BASELINE configs[1]+[2]: airplane position DDPM (16x3) + chair feature DDPM (16x51), "
                                   "batch %d per GPU; 1 step = one reverse step of each; shape = 1000+1000 steps" % B,
                       "batch_per_gpu": B, "sub_batches": sizes, "prec": a.prec, "replay": a.replay,
@@ -464,8 +473,8 @@ def main():
             grid = ((rows + 63) // 64) * ((n_cob + 1) // 2)
             if a.prec == "fp16" and npxl == 4 and grid <= (1024 if o.p[6] else 8192):
                 return "gemm_small_kernel<2, %s>" % b(o.p[3])
-            if a.prec == "fp32" or not o.i[8]:
-                return "gemm_kernel<%d, %d, %d>" % (0 if a.prec == "fp32" else 1, npxl, cbw)
+            if a.prec in ("fp32", "split") or not o.i[8]:
+                return "gemm_kernel<%d, %d, %d>" % ({"fp32": 0, "fp16": 1, "split": 2}[a.prec], npxl, cbw)
             if cbw == 2 and not (o.p[3] and o.p[8]):
                 return "gemm_glds_occ3_kernel<%d, %s, %s>" % (npxl, b(o.p[3]), b(o.p[8]))  # three workgroups per CU
             return "gemm_glds_kernel<%d, %d, 3, 32, %s, %s>" % (npxl, cbw, b(o.p[3]), b(o.p[8]))

@@ -36,7 +36,11 @@ enum { SLIDE_F_PRE_RELU = 1, SLIDE_F_POST_RELU = 2, SLIDE_F_OUT_F32 = 4,
        SLIDE_F_RES_PAIR = 8, SLIDE_F_RES_PAIR_NBR = 16 };
 /* MFMA precision of a GEMM: exact fp32 (v_mfma_f32_32x32x2_f32) or fp16 inputs / fp32 accumulate
  * (v_mfma_f32_32x32x16_f16) */
-enum { SLIDE_PREC_F32 = 0, SLIDE_PREC_F16 = 1 };
+/* SLIDE_PREC_SPLIT (round 4): fp32 STORAGE (the fp32 plan: same ops, buffers and epilogues as SLIDE_PREC_F32), the contractions
+ * on the fp16 matrix pipe with BOTH operands as two-term fp16 splits x = hi + 2^-11 lo (hi = fp16(x), lo = fp16(2^11 (x - hi))),
+ * three products hi*hi + 2^-11 (hi*lo + lo*hi) accumulated in fp32: ~2^-22 relative per product (fp32-grade; tools/prec_emul.py:
+ * 1e-6 on a forward where fp16 operands give 1.4e-3) at 3/16 of the fp32 MFMA's matrix-pipe time. */
+enum { SLIDE_PREC_F32 = 0, SLIDE_PREC_F16 = 1, SLIDE_PREC_SPLIT = 2 };
 
 /* One per 32 output channels of a GEMM; an array of these lives in DEVICE memory.
  *   y = acc + bias + pre_add[row >> pre_add_shift];  PRE_RELU;

@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--data_clamp_range", type=float, default=1)
     ap.add_argument("--model_var_type", type=str, default="fixedsmall")
     ap.add_argument("--random_init", action="store_true")
-    ap.add_argument("--prec", default="fp16", choices=["fp32", "fp16"],
+    ap.add_argument("--prec", default="fp16", choices=["fp32", "fp16", "split"],
                     help="MFMA operand type (fp32 accumulate); fp32 = the exact parity mode")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--chains", type=int, default=3,

@@ -38,8 +38,10 @@ int slide_launch_sa_chain_p(const SlideOp &o, hipStream_t s);    // gemm_gx.hip
 
 namespace {
 
+// (split mode: its two stages of four fp16 planes take 102 KB of LDS -- one workgroup per CU anyway, so it may use the whole
+//  register file: the second accumulator set of the cross products does not fit 256 registers next to the 16-row epilogue)
 template <int PREC, int NPXL, int CBW>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256, (PREC == SLIDE_PREC_SPLIT && NPXL == 4) ? 1 : 2) void gemm_kernel(GemmArgs a) {
   using T = typename TileT<PREC>::T;
   constexpr int LDK = TileT<PREC>::LDK;
   constexpr int EPL = TileT<PREC>::EPL;   // elements per 16-byte load
@@ -48,8 +50,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
   constexpr int TN = 32 * CBW;
   constexpr int XP = TM / RPP, WP = TN / RPP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T *const sbase = reinterpret_cast<T *>(smem_raw);
-  constexpr int STAGE = (TM + TN) * LDK;
+  constexpr bool SPLIT = PREC == SLIDE_PREC_SPLIT;
+  // LDS element type of a stage: T, or (split mode) _Float16 with two planes per operand tile: [X hi | W hi | X lo | W lo]
+  using TS = typename std::conditional<SPLIT, _Float16, T>::type;
+  TS *const sbase = reinterpret_cast<TS *>(smem_raw);
+  constexpr int STAGE = (SPLIT ? 2 : 1) * (TM + TN) * LDK;
+  // split mode keeps ONE stage in LDS (51 KB: two workgroups per CU; the next chunk waits in registers, as in the other modes,
+  // at the price of a second barrier per chunk)
+  constexpr int NSTG = SPLIT ? 1 : 2;
 
   const int ntc = (a.n_cob + CBW - 1) / CBW;
   const int ntr = (a.rows + TM - 1) / TM;
@@ -65,12 +73,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
   const T *W = reinterpret_cast<const T *>(a.W);
 
   f32x16 acc[CBW][2];
+  f32x16 acc2[SPLIT ? CBW : 1][2];  // split mode: the two cross products hi*lo + lo*hi (scaled by 2^11), folded in at the end
 #pragma unroll
   for (int i = 0; i < CBW; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        acc[i][j][r] = 0.f;
+        if (SPLIT) acc2[SPLIT ? i : 0][j][r] = 0.f;
+      }
 
   float4 xr[XP], wr[WP];  // raw 16-byte pieces in flight
   const int l_row = tid / TPR, l_c = (tid % TPR) * EPL;
@@ -84,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
         v = *reinterpret_cast<const float4 *>(X + (size_t)grow * a.x_ld + kc * BK + l_c);
         if (a.in_scale) {  // consumer-side GroupNorm affine (only the attention weight_conv.2 GEMMs)
           const size_t o = (size_t)(grow >> NPXL) * a.in_bs + kc * BK + l_c;
-          if (PREC == SLIDE_PREC_F32) {
+          if (PREC != SLIDE_PREC_F16) {
             const float4 sc = *reinterpret_cast<const float4 *>(a.in_scale + o);
             const float4 sh = *reinterpret_cast<const float4 *>(a.in_shift + o);
             v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
@@ -105,18 +117,67 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
+  // split mode: x = hi + 2^-11 lo, hi = fp16(x), lo = fp16(2^11 (x - hi)) -- the scaling keeps lo a NORMAL fp16 number
+  // whatever the magnitude of x (unscaled, the low parts of values below ~0.1 would fall into fp16's denormal range)
+  auto split4 = [](const float4 v, f16x4 &hi, f16x4 &lo) {
+    hi = f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    lo = f16x4{(_Float16)((v.x - (float)hi[0]) * 2048.f), (_Float16)((v.y - (float)hi[1]) * 2048.f),
+               (_Float16)((v.z - (float)hi[2]) * 2048.f), (_Float16)((v.w - (float)hi[3]) * 2048.f)};
+  };
   auto store_chunk = [&](int s) {
-    T *Xs = sbase + s * STAGE;
-    T *Ws = Xs + TM * LDK;
+    TS *Xs = sbase + s * STAGE;
+    TS *Ws = Xs + TM * LDK;
+    if constexpr (SPLIT) {
+      _Float16 *Xl = Xs + (TM + TN) * LDK, *Wl = Xl + TM * LDK;
 #pragma unroll
-    for (int p = 0; p < XP; ++p) *reinterpret_cast<float4 *>(Xs + (p * RPP + l_row) * LDK + l_c) = xr[p];
+      for (int p = 0; p < XP; ++p) {
+        f16x4 hi, lo;
+        split4(xr[p], hi, lo);
+        *reinterpret_cast<f16x4 *>(Xs + (p * RPP + l_row) * LDK + l_c) = hi;
+        *reinterpret_cast<f16x4 *>(Xl + (p * RPP + l_row) * LDK + l_c) = lo;
+      }
 #pragma unroll
-    for (int p = 0; p < WP; ++p) *reinterpret_cast<float4 *>(Ws + (p * RPP + l_row) * LDK + l_c) = wr[p];
+      for (int p = 0; p < WP; ++p) {
+        f16x4 hi, lo;
+        split4(wr[p], hi, lo);
+        *reinterpret_cast<f16x4 *>(Ws + (p * RPP + l_row) * LDK + l_c) = hi;
+        *reinterpret_cast<f16x4 *>(Wl + (p * RPP + l_row) * LDK + l_c) = lo;
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < XP; ++p) *reinterpret_cast<float4 *>(Xs + (p * RPP + l_row) * LDK + l_c) = xr[p];
+#pragma unroll
+      for (int p = 0; p < WP; ++p) *reinterpret_cast<float4 *>(Ws + (p * RPP + l_row) * LDK + l_c) = wr[p];
+    }
   };
   auto compute = [&](int s) {
-    const T *Xs = sbase + s * STAGE;
-    const T *Ws = Xs + TM * LDK;
-    if (PREC == SLIDE_PREC_F32) {
+    const TS *Xs = sbase + s * STAGE;
+    const TS *Ws = Xs + TM * LDK;
+    if constexpr (SPLIT) {
+      const _Float16 *Xl = Xs + (TM + TN) * LDK, *Wl = Xl + TM * LDK;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        f16x8 ah[CBW], al[CBW], bh[2], bl[2];
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb) {
+          ah[cb] = *reinterpret_cast<const f16x8 *>(Ws + (cb * 32 + col) * LDK + st * 16 + half * 8);
+          al[cb] = *reinterpret_cast<const f16x8 *>(Wl + (cb * 32 + col) * LDK + st * 16 + half * 8);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          bh[rb] = *reinterpret_cast<const f16x8 *>(Xs + (wave * 64 + rb * 32 + col) * LDK + st * 16 + half * 8);
+          bl[rb] = *reinterpret_cast<const f16x8 *>(Xl + (wave * 64 + rb * 32 + col) * LDK + st * 16 + half * 8);
+        }
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) {
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb], bh[rb], acc[cb][rb], 0, 0, 0);
+            acc2[SPLIT ? cb : 0][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb], bl[rb], acc2[SPLIT ? cb : 0][rb], 0, 0, 0);
+            acc2[SPLIT ? cb : 0][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb], bh[rb], acc2[SPLIT ? cb : 0][rb], 0, 0, 0);
+          }
+      }
+    } else if (PREC == SLIDE_PREC_F32) {
       const float *Xf = reinterpret_cast<const float *>(Xs);
       const float *Wf = reinterpret_cast<const float *>(Ws);
 #pragma unroll
@@ -159,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
     }
   };
 
-  uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + 2 * (size_t)STAGE * sizeof(T));
+  uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + NSTG * (size_t)STAGE * sizeof(TS));
   float *const vec_lds = reinterpret_cast<float *>(epi_lds + CBW * EPI_DW + (CBW * EPI_DW) % 4);
   stage_epilogue_tables<CBW>(a, cob0, tid, epi_lds, vec_lds);
 
@@ -175,13 +236,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
   __syncthreads();
   for (int kc = 0; kc < nk; ++kc) {
     if (kc + 1 < nk) load_chunk(KIDX(kc + 1));
-    compute(kc & 1);
-    if (kc + 1 < nk) store_chunk((kc + 1) & 1);
+    compute(kc & (NSTG - 1));
+    if (NSTG == 1) __syncthreads();  // every wave is done reading the stage before it is overwritten
+    if (kc + 1 < nk) store_chunk((kc + 1) & (NSTG - 1));
     __syncthreads();
   }
 #undef KIDX
-
-  gemm_epilogue<PREC, NPXL, CBW>(a, acc, row0, cob0, wave, half, col, epi_lds, vec_lds, reinterpret_cast<float *>(smem_raw));
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int i = 0; i < CBW; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaf(acc2[i][j][r], 1.f / 2048.f, acc[i][j][r]);
+  }
+  // (split mode stores float activations: the fp32 epilogue)
+  gemm_epilogue<SPLIT ? SLIDE_PREC_F32 : PREC, NPXL, CBW>(a, acc, row0, cob0, wave, half, col, epi_lds, vec_lds,
+                                                          reinterpret_cast<float *>(smem_raw));
 }
 
 // ------------------------------------------------------------------------------------------------ LDS-DMA GEMM
@@ -1727,7 +1798,9 @@ inline int current_device_slot() {
 template <int PREC, int NPXL, int CBW>
 int launch_gemm(const GemmArgs &a, hipStream_t s) {
   constexpr int LDK = TileT<PREC>::LDK;
-  const size_t shm = 2 * (size_t)(TM + 32 * CBW) * LDK * sizeof(typename TileT<PREC>::T) + CBW * (sizeof(SlideEpi) + 96 * 4) + 16;
+  // (split mode: two fp16 planes per operand tile)
+  const size_t shm = (PREC == SLIDE_PREC_SPLIT ? (size_t)(TM + 32 * CBW) * LDK * 4 : 2 * (size_t)(TM + 32 * CBW) * LDK * sizeof(typename TileT<PREC>::T)) +
+                     CBW * (sizeof(SlideEpi) + 96 * 4) + 16;
   const int ntc = (a.n_cob + CBW - 1) / CBW, ntr = (a.rows + TM - 1) / TM;
   const int grid = ((ntr + 7) / 8) * 8 * ntc;
   static bool attr_done[SLIDE_MAX_DEVICES] = {};
@@ -2002,6 +2075,7 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
   }
 #define CASE(P, L, C) if (prec == P && npxl == L && cbw == C) return launch_gemm<P, L, C>(a, s)
   CASE(SLIDE_PREC_F32, 4, 2); CASE(SLIDE_PREC_F32, 7, 2); CASE(SLIDE_PREC_F32, 8, 2);
+  CASE(SLIDE_PREC_SPLIT, 4, 2); CASE(SLIDE_PREC_SPLIT, 7, 2); CASE(SLIDE_PREC_SPLIT, 8, 2);
 #ifdef SLIDE_EXPERIMENTS
   CASE(SLIDE_PREC_F16, 4, 2); CASE(SLIDE_PREC_F16, 7, 2); CASE(SLIDE_PREC_F16, 8, 2);
   CASE(SLIDE_PREC_F16, 4, 4); CASE(SLIDE_PREC_F16, 7, 4); CASE(SLIDE_PREC_F16, 8, 4);

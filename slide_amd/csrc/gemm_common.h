@@ -72,6 +72,8 @@ constexpr float GN_EPS = 1e-5f;
 template <int PREC> struct TileT;
 template <> struct TileT<SLIDE_PREC_F32> { using T = float; static constexpr int LDK = 36; static constexpr int EPL = 4; };
 template <> struct TileT<SLIDE_PREC_F16> { using T = _Float16; static constexpr int LDK = 40; static constexpr int EPL = 8; };
+// split mode: float activations in HBM (T), two fp16 planes (hi, scaled lo) per operand tile in LDS (rows of LDK = 40 halves)
+template <> struct TileT<SLIDE_PREC_SPLIT> { using T = float; static constexpr int LDK = 40; static constexpr int EPL = 4; };
 
 #ifdef SLIDE_TIMELINE  // instrumented build only (tools/gemm_timeline.py); the product library carries no stamps
 #define SLIDE_STAMP(a, k)                                                                     \

@@ -19,7 +19,9 @@ from ._lib import SlideHipError, check, lib
 
 EPI_RAW, EPI_NORM, EPI_STATS = 0, 1, 2
 F_PRE_RELU, F_POST_RELU, F_OUT_F32, F_RES_PAIR, F_RES_PAIR_NBR = 1, 2, 4, 8, 16
-PREC = {"fp32": 0, "fp16": 1}
+# "split": the fp32 plan (float storage, same ops) with its contractions on the fp16 matrix pipe as two-term operand splits --
+# fp32-grade results (include/slide_engine.h: SLIDE_PREC_SPLIT)
+PREC = {"fp32": 0, "fp16": 1, "split": 2}
 (OP_GEMM, OP_PREP_POINTS, OP_ASSEMBLE_SA, OP_ASSEMBLE_FP, OP_FINALIZE_GN, OP_ATTN_COMBINE, OP_COPY_COLS, OP_TEMB,
  OP_COND, OP_UPDATE_POS, OP_UPDATE_FEAT, OP_ADVANCE_T) = range(1, 13)
 OP_SYNC = 14

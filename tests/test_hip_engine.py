@@ -22,12 +22,15 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
 
 
+@pytest.mark.parametrize("prec", ["fp32", "split"])
 @pytest.mark.parametrize("name", ["pos", "feat"])
-def test_denoiser_forward_fp32_matches_reference(gpu_device, name):
+def test_denoiser_forward_fp32_matches_reference(gpu_device, name, prec):
+    """the two fp32-grade modes against the reference goldens: "fp32" = fp32 MFMA; "split" (round 4) = the same plan with its
+    contractions as two-term fp16 operand splits on the fp16 matrix pipe (include/slide_engine.h: SLIDE_PREC_SPLIT)"""
     from slide_amd.engine import DenoiserEngine
     g, hp, sd = _load(name)
     B = g["x_t0"].shape[0]
-    eng = DenoiserEngine(hp, sd, B, gpu_device, prec="fp32")
+    eng = DenoiserEngine(hp, sd, B, gpu_device, prec=prec)
     for k in ["t0", "t1", "t500", "t999", "mixed"]:
         y = eng.forward(g["x_" + k], g["ts_" + k], g["label_" + k]).cpu().numpy()
         assert np.isfinite(y).all(), k
@@ -306,7 +309,8 @@ def test_head_and_update_as_one_launch(gpu_device, exp_lib, monkeypatch):
         assert np.isfinite(a_).all() and _rel(a_, b_) <= 5e-4, _rel(a_, b_)
 
 
-def test_position_sampler_full_chain_matches_reference(gpu_device):
+@pytest.mark.parametrize("prec", ["fp32", "split"])
+def test_position_sampler_full_chain_matches_reference(gpu_device, prec):
     from slide_amd.diffusion import PositionSampler
     g = load_golden("golden_sampler_pos.npz")
     _, hp, sd = _load("pos")
@@ -314,7 +318,7 @@ def test_position_sampler_full_chain_matches_reference(gpu_device):
     size = g["full_x0"].shape
     xT = ns(size)
     noise = np.stack([ns(size) for _ in range(999)])
-    smp = PositionSampler(hp, sd, size[0], gpu_device, _pos_cfg(), prec="fp32", noise=noise, use_graph=True)
+    smp = PositionSampler(hp, sd, size[0], gpu_device, _pos_cfg(), prec=prec, noise=noise, use_graph=True)
     x0 = smp.sample(g["label"], xT).cpu().numpy()
     r = _rel(x0, g["full_x0"])
     print("1000-step position chain, relative max error vs reference: %.3e" % r)
