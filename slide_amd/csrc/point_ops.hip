@@ -759,6 +759,10 @@ static int fps_launch(int b, int n, int m, int bs, int skip_origin, const int *s
   else if (n <= 256) FPS_LAUNCH(1, 256);
   else if (n <= 512) FPS_LAUNCH(2, 256);
   else if (n <= 1024) FPS_LAUNCH(4, 256);
+  // (round 4, measured and NOT kept -- tools/time_fps.py: 512- / 1024-thread workgroups for long clouds, i.e. fewer points per
+  //  thread, are SLOWER: n = 4096 at 256 clouds 1.54 vs 1.13 us per selection, 8.4 vs 3.6 at 2048 clouds -- the cross-wave step
+  //  (one barrier + one key per wave) grows with the wave count faster than the per-thread update shrinks, and fewer clouds fit a
+  //  CU; only n = 8192 at <= 256 clouds gains, 1.81 vs 2.09)
   else if (n <= 2048) FPS_LAUNCH(8, 256);
   else if (n <= 4096) FPS_LAUNCH(16, 256);
   else if (n <= 8192) FPS_LAUNCH(32, 256);
