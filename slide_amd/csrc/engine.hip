@@ -1899,7 +1899,9 @@ int launch_gemm_small_t(const GemmArgs &a, hipStream_t s) {
 template <bool FP>
 int launch_pair_first_t(const GemmArgs &a, const PairArgs &pa, hipStream_t s) {
   const int grid = ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2);
-  const size_t shm = (size_t)4 * 2 * 6144 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32 + (192 + 3 * 512) * 4;
+  // (SA blocks stage only the four samples' coordinates: 51 KB -> THREE workgroups per CU; FP blocks also the neighbour / distance /
+  //  weight slots: 57 KB, two per CU)
+  const size_t shm = (size_t)4 * 2 * 6144 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32 + (192 + (FP ? 3 * 512 : 0)) * 4;
   static bool attr_done[SLIDE_MAX_DEVICES] = {};
   bool &attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
