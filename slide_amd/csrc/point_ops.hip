@@ -536,7 +536,7 @@ constexpr int KNN_TILE = 512;
 constexpr int KNN_CH = 8;   // candidates per distance chunk
 // queue slots per lane (a flush is due once a lane holds more than KNN_Q - KNN_CH): deeper queues amortise the long
 // insertion passes of big K better, shallow ones leave LDS for more resident waves
-constexpr int knn_queue_slots(int KT) { return KT >= 32 ? 24 : 16; }
+constexpr int knn_queue_slots(int KT) { return KT >= 32 ? 32 : 16; }  // (round 4: 32 = the sort width of the batch merge)
 
 __device__ __forceinline__ double knn_key(float d, int i) {
   return __longlong_as_double(((long long)__float_as_int(d) << 32) | (unsigned int)i);
@@ -547,6 +547,40 @@ __device__ __forceinline__ void knn_minmax(double &l, double &c) {
   asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(l), "v"(c));
   asm("v_min_f64 %0, %0, %1" : "+v"(l) : "v"(c));  // in place: the list stays in its registers across the loop
   c = hi;
+}
+
+// Round 4: BATCH MERGE instead of per-candidate insertion for K >= 16.  Inserting one candidate costs a full pass over the KT
+// list slots (2 KT f64 ops) in every lane of the wave for as many passes as the FULLEST lane's queue holds -- ~3/4 of the kernel's
+// time at K = 32.  A flush now (i) sorts the lane's queued keys with a bitonic network (QS = 16 or 32 slots, unused ones +inf),
+// (ii) takes the element-wise minimum of the ascending list and the REVERSED sorted queue -- the half-cleaner of a bitonic merge:
+// exactly the KT smallest of the union, as a bitonic sequence -- and (iii) sorts that sequence with log2(KT) merge stages: for
+// KT = 32, QS = 32: 480 + 32 + 160 f64 ops per flush whatever the fill, against 64 per queued candidate of the fullest lane
+// (up to 1536).  Keys are unique (index in the low word), so the K smallest of the union are the same set in the same order as
+// sequential insertion gives: bit-identical results.
+template <int N>
+__device__ __forceinline__ void knn_bitonic_sort(double (&a)[N]) {
+#pragma unroll
+  for (int k = 2; k <= N; k <<= 1)
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          if ((i & k) == 0) knn_minmax(a[i], a[l]);  // ascending block: min to the lower slot
+          else knn_minmax(a[l], a[i]);               // descending block
+        }
+      }
+}
+template <int N>
+__device__ __forceinline__ void knn_bitonic_merge(double (&a)[N]) {  // a bitonic (up, then down) -> ascending
+#pragma unroll
+  for (int j = N >> 1; j > 0; j >>= 1)
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int l = i ^ j;
+      if (l > i) knn_minmax(a[i], a[l]);
+    }
 }
 
 template <int NT, int KT>
@@ -603,10 +637,22 @@ __global__ __launch_bounds__(NT) void knn_key_kernel(int n1, int n2, int K, cons
       }
       const bool last = k0 + KNN_CH >= tn && t0 + tn >= len2;
       if (__any(qn > KNN_Q - KNN_CH) || last) {
-        for (int j = 0; __any(j < qn); ++j) {
-          double c = j < qn ? queue[j * NT + tid] : pad;
+        if constexpr (KT >= 16) {
+          constexpr int QS = KNN_Q > 16 ? 32 : 16;   // sort slots (queue depth rounded up to a power of two)
+          constexpr int QN = QS < KT ? QS : KT;      // queue entries that can still enter the list
+          double Qr[QS];
 #pragma unroll
-          for (int p = 0; p < KT; ++p) knn_minmax(L[p], c);
+          for (int j = 0; j < QS; ++j) Qr[j] = (j < KNN_Q && j < qn) ? queue[j * NT + tid] : pad;
+          knn_bitonic_sort<QS>(Qr);
+#pragma unroll
+          for (int p = KT - QN; p < KT; ++p) asm("v_min_f64 %0, %0, %1" : "+v"(L[p]) : "v"(Qr[KT - 1 - p]));
+          knn_bitonic_merge<KT>(L);
+        } else {
+          for (int j = 0; __any(j < qn); ++j) {
+            double c = j < qn ? queue[j * NT + tid] : pad;
+#pragma unroll
+            for (int p = 0; p < KT; ++p) knn_minmax(L[p], c);
+          }
         }
         qn = 0;
         double w = L[KT - 1];  // K-th entry by a uniform select chain (K is a runtime value <= KT)
