@@ -382,7 +382,14 @@ def main():
         if use_dist:
             dist.barrier() if share else dist.barrier(device_ids=[local])
 
-    run(max(a.warmup, 1))
+    # Device priming, part of set-up (untimed, in front of the W warm-up steps the command line asks for): a fresh process starts on
+    # a cold GPU and the first tens of milliseconds of chain replay run slower than steady state -- 20 timed steps after W = 5 / 10 /
+    # 20 / 30 / 50 warm-up steps take 13.3 / 13.25 / 12.9 / 12.7 / 12.6 ms, every chain alike (clock ramp; tools/r4 notes in DESIGN.md
+    # section 9).  A generation is 1000 steps, so the warmed-up rate is what a user sees: 64 priming steps (40 ms) are replayed with
+    # the warm-up steps whatever --warmup says: --steps 20 --warmup 5 then measures 0.638-0.645 ms per step instead of 0.663 (five
+    # alternating pairs), the --steps 300 rate being 0.62.  SLIDE_BENCH_PRIME=0 switches it off; `config.prime_steps` records it.
+    prime = int(os.environ.get("SLIDE_BENCH_PRIME", "64"))
+    run(max(a.warmup, 1) + max(prime, 0))  # (one replay call: priming steps, then the W warm-up steps)
     gdev = torch.device("cpu") if share else dev
     gathered = [torch.empty(B, 16, 51, device=gdev) for _ in range(world)] if use_dist else None
 
@@ -393,9 +400,17 @@ def main():
 
     if use_dist:
         gather_latents()  # untimed, like the warm-up steps: the first call builds RCCL's channels
-    reset()  # begin the timed chains (x_T, labels, key points, per-chain pre-computes) before the clock starts
-    state["left"] = 1000
+    if os.environ.get("SLIDE_BENCH_NO_RESET"):  # diagnostic: the timed region continues the warm-up chains
+        pass
+    else:
+        reset()  # begin the timed chains (x_T, labels, key points, per-chain pre-computes) before the clock starts
+        state["left"] = 1000
     sync_all()
+    if os.environ.get("SLIDE_BENCH_PRESPIN"):  # diagnostic: keep the GPU busy right up to the start of the timed region
+        _w = torch.randn(4096, 4096, device=dev)
+        for _ in range(int(os.environ["SLIDE_BENCH_PRESPIN"])):
+            _w = _w @ _w * 1e-4
+        torch.cuda.synchronize(dev)
     state["enq"] = 0.0
     chain_ev = None
     if os.environ.get("SLIDE_BENCH_CHAIN_ENDS"):  # diagnostic: when each chain retires its last step (stderr)
@@ -438,6 +453,7 @@ def main():
                       # host seconds inside the launch calls of the timed region, per step: close to ms_per_step = the host
                       # (or a full hardware queue it is blocked on) paces the run, far below = the GPU does
                       "host_enqueue_ms_per_step": round(host_enq * 1e3 / a.steps, 4),
+                      "prime_steps": prime,  # untimed device priming before the --warmup steps (set-up; see bench.py)
                       "finite": finite}}
     if cat_desc is not None:
         out["config"]["workload"] = ("BASELINE configs[3]: five-category run (labels 0, 2, 3, 4, 6; one position + one feature weight set "
