@@ -157,6 +157,13 @@ def knn_gather(x, idx):
     return out
 
 
+def gather_rows(points, idx):
+    """row-layout counterpart of gather_points (the build's slide_gather_rows): points (B,N,C), idx (B,M) -> (B,M,C);
+    by definition gather_points (sampling_gpu.cu:8-20) on the transposed table, transposed back"""
+    p = np.ascontiguousarray(points, dtype=np.float32)
+    return np.ascontiguousarray(gather_points(np.ascontiguousarray(p.transpose(0, 2, 1)), idx).transpose(0, 2, 1))
+
+
 def sample_farthest_points(points, K, start_idx=None):
     """-> (selected points (B,K,C), idx int64 (B,K)); FPS runs on the first three channels"""
     pts3, pp = _f(points[:, :, 0:3])

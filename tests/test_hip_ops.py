@@ -108,7 +108,7 @@ def test_gather_rows(gpu_device):
         idx[:, -1] = 0
         got = _ext.gather_rows(T(pts, gpu_device), T(idx, gpu_device)).cpu().numpy()
         want = np.take_along_axis(pts, idx[:, :, None].astype(np.int64), axis=1)
-        assert got.shape == (B, M, C) and np.array_equal(got, want)
+        assert got.shape == (B, M, C) and np.array_equal(got, want) and np.array_equal(O.gather_rows(pts, idx), want)
         ref_api = _ext.gather_points(T(np.ascontiguousarray(pts.transpose(0, 2, 1)), gpu_device), T(idx, gpu_device)).cpu().numpy()
         assert np.array_equal(got, ref_api.transpose(0, 2, 1))
     assert _ext.gather_rows(T(pts, gpu_device), T(np.zeros((1, 0), np.int32), gpu_device)).shape == (1, 0, 4)
