@@ -206,6 +206,15 @@ def test_released_checkpoint_layout_through_the_clis(gpu_device, tmp_path):
                         "--prec", "fp32"], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     got = np.load(out1 / "shapenet_psr_generated_data_16_pts.npz")["points"]
+    # --prec split (round 4: fp32 storage, contractions as two-term fp16 operand splits): the same run within 1e-3 of the fp32 one
+    # over the whole 1000-step chain (fp32-grade forwards; the chains still see different last-bit rounding at every step)
+    out1s = tmp_path / "gen_split"
+    r = subprocess.run([sys.executable, os.path.join(cli, "point_cloud_generation.py"), "-c", str(cdir / "pos.json"), "--ckpt", str(ck),
+                        "--ema_idx", "1", "--num_samples", "4", "--batch_size", "4", "--save_dir", str(out1s), "--seed", "5",
+                        "--prec", "split"], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got_s = np.load(out1s / "shapenet_psr_generated_data_16_pts.npz")["points"]
+    assert np.isfinite(got_s).all() and np.abs(got_s - got).max() <= 1e-3 * np.abs(got).max(), np.abs(got_s - got).max()
     want_sd = dict(raw)
     want_sd.update({k: v for k, v in ema1.items() if k != skip})
     smp = PositionSampler(hp, want_sd, 4, gpu_device, pc["diffusion_config"], prec="fp32", seed=5)
