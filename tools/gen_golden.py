@@ -218,6 +218,73 @@ def gen_sampler_feat_full(net, cfg, out, B=2):
     print("sampler feat full chain: draws", ns.count)
 
 
+def gen_train(out, B=2):
+    """TRAINING-STEP fixtures: the reference's own losses and autograd on CPU --
+    util.training_loss (pointnet2/util.py:262-300, position DDPM, nn.MSELoss) and LatentDiffusion.train_loss
+    (pointnet2/diffusion_utils/diffusion.py:319-341, feature DDPM on given latents: encode() is an identity here) -- with the
+    random timesteps and the noise INJECTED; recorded: inputs, loss, the L2 norm of every parameter's gradient and the full
+    gradients of a handful of parameters of every kind."""
+    import util as U
+    from diffusion_utils import diffusion as D
+    keep = ("class_emb.weight", "fc_t1.weight", "fc_t2.bias", "SA_modules.0.mlps.0.first_mlp.0.weight",
+            "SA_modules.0.mlps.0.first_mlp.1.group_norm.weight", "SA_modules.0.mlps.0.fc.weight", "SA_modules.1.mlps.0.res_connect.weight",
+            "SA_modules.1.attention_modules.0.weight_conv.2.weight", "SA_modules.1.attention_modules.0.weight_conv.4.group_norm.bias",
+            "SA_modules.0.attention_modules.0.feat_conv.weight", "FP_modules.1.mlp1.second_mlp.0.weight",
+            "FP_modules.0.attention_module.grouped_feat_conv.weight", "FP_modules.0.mlp2.fc_condition.bias",
+            "FP_modules.0.attention_module.feat_out_conv.1.group_norm.weight", "fc_lyaer.0.weight", "fc_lyaer.1.weight", "fc_lyaer.3.bias")
+    for name, cfg_path in (("pos", POS_CFG), ("feat", FEAT_CFG)):
+        cfg = load_cfg(cfg_path)
+        net, spec = build_net(cfg)
+        net.train()
+        hp = cfg["pointnet_config"]
+        C = 3 + hp["in_fea_dim"]
+        rs = np.random.RandomState(31 if name == "pos" else 32)
+        x0 = (0.6 * rs.standard_normal((B, 16, C))).astype(np.float32)
+        x0[:, :, :3] = synth_keypoints(B, 16, seed=9)
+        label = np.array([0, 4][:B], np.int64)
+        steps = np.array([37, 812][:B], np.int64)
+        z = rs.standard_normal((B, 16, C)).astype(np.float32)
+        res = {"x0": x0, "label": label, "steps": steps, "z": z, "config_json": np.array(json.dumps(cfg))}
+        names, shapes = spec_arrays(spec)
+        res["spec_names"], res["spec_shapes"] = names, shapes
+        o_randint, o_randn_like = torch.randint, torch.randn_like
+        try:
+            if name == "pos":
+                dh = U.calc_diffusion_hyperparams(**cfg["diffusion_config"])
+                torch.randint = lambda *a, **k: torch.from_numpy(steps).reshape(B, 1, 1)
+                o_std = U.std_normal
+                U.std_normal = lambda size: torch.from_numpy(z)
+                try:
+                    loss = U.training_loss(net, torch.nn.MSELoss(), torch.from_numpy(x0), dh, label=torch.from_numpy(label))
+                finally:
+                    U.std_normal = o_std
+            else:
+                dcfg = copy.deepcopy(cfg["standard_diffusion_config"])
+                with contextlib.redirect_stdout(io.StringIO()):
+                    dm = D.LatentDiffusion(dcfg, autoencoder=None, device=torch.device("cpu"))
+                dm.encode = lambda x, keypoint, label: x  # the latents are given: [key points | features]
+                torch.randint = lambda *a, **k: torch.from_numpy(steps)
+                torch.randn_like = lambda t, **k: torch.from_numpy(z)
+                res["diffusion_config_json"] = np.array(json.dumps(dcfg))
+                loss_b = dm.train_loss(net, torch.from_numpy(x0), torch.from_numpy(x0[:, :, :3].copy()), torch.from_numpy(label))
+                res["loss_per_sample"] = loss_b.detach().numpy()
+                loss = loss_b.mean()
+        finally:
+            torch.randint, torch.randn_like = o_randint, o_randn_like
+        loss.backward()
+        res["loss"] = np.array(loss.item(), np.float64)
+        grads = {k: p.grad.detach().numpy() for k, p in net.named_parameters()}
+        assert list(grads) == [n for n, _ in spec] and all(g is not None for g in grads.values())
+        res["grad_norms"] = np.array([np.linalg.norm(grads[n].astype(np.float64)) for n, _ in spec])
+        for k in keep:  # (big tensors: every stride-th entry of the flattened gradient, ~8k values)
+            g_ = grads[k].reshape(-1)
+            stride = max(1, g_.size // 8192)
+            res["grad__" + k] = g_[::stride].copy()
+            res["stride__" + k] = np.array(stride)
+        np.savez_compressed(os.path.join(out, "golden_train_%s.npz" % name), **res)
+        print("train", name, "loss", float(loss), "grad norm", float(np.sqrt((res["grad_norms"] ** 2).sum())))
+
+
 def gen_schedules(out):
     """the schedule tables of Diffusion.init_diffusion_parameters (diffusion.py:158-208) for every beta schedule the
     reference's get_beta_schedule can produce ('warmup10' / 'warmup50' raise NameError there: `_warmup_beta` is never
@@ -504,7 +571,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.manual_seed(0)
-    want = set(a.only.split(",")) if a.only else {"ops", "blocks", "pos", "feat", "resample", "sched", "decode", "encode"}
+    want = set(a.only.split(",")) if a.only else {"ops", "blocks", "pos", "feat", "resample", "sched", "train", "decode", "encode"}
     if "ops" in want:
         gen_ops(a.out)
     if "blocks" in want:
@@ -523,6 +590,8 @@ if __name__ == "__main__":
         gen_sampler_feat_resample(a.out)
     if "sched" in want:
         gen_schedules(a.out)
+    if "train" in want:
+        gen_train(a.out)
     if "decode" in want:
         gen_decode(a.out)
     if "encode" in want:

@@ -55,7 +55,11 @@ def install():
         return KNN(torch.from_numpy(d), torch.from_numpy(i), nn)
 
     def knn_gather(x, idx, lengths=None):
-        return torch.from_numpy(O.knn_gather(_n(x), _n(idx)))
+        # pytorch3d's own formulation (a torch gather: differentiable in x, which the gradient fixtures need; same values as
+        # oracle.ops.knn_gather)
+        B, N1, K = idx.shape
+        U = x.shape[2]
+        return x[:, :, None].expand(-1, -1, K, -1).gather(1, idx[:, :, :, None].expand(-1, -1, -1, U).long())
 
     def sample_farthest_points(points, lengths=None, K=50, random_start_point=False):
         # plain fp32 FPS from the oracle; start index 0 (the reference's random start makes its result
