@@ -25,7 +25,8 @@ def allreduce_gradients(module, bucket=None):
     if not dist.is_initialized() or dist.get_world_size() == 1 or not params:
         return bucket
     n = sum(p.numel() for p in params)
-    dev = params[0].device
+    # (gloo reduces host memory: the CPU tests, and the 2-ranks-on-one-GPU test; RCCL reduces in HBM over xGMI)
+    dev = torch.device("cpu") if dist.get_backend() == "gloo" else params[0].device
     if bucket is None or bucket.numel() != n or bucket.device != dev:
         bucket = torch.empty(n, device=dev, dtype=torch.float32)
     o = 0
