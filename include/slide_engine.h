@@ -155,7 +155,7 @@ enum {
   SLIDE_OP_ROWS_FROM_NCX = 20, /* p: in (B,C,P) fp32, out rows   i: B, C, P, ld */
   SLIDE_OP_ROWS_TO_NCX = 21,   /* p: in rows, out (B,C,P) fp32   i: B, C, P, ld */
   SLIDE_OP_ROWS_GROUP = 22,    /* p: xyz (B,N,3), new_xyz (B,np,3), feat rows [B*N][ldf] (or NULL), idx int64 (B,np,K), d2 (B,np,K) (FP layout), out [B*np*K][ldg]   i: B, N, np, K, C, ldf, ldg, flags (1: group_knn layout [feat|d2|w|abs|rel|centre]; else [feat|rel|abs if 2|centre if 4], 8: no coordinate channels, 16: idx is int32), [6] counts int32 (B,np) or NULL: a centre with count 0 stands in as its own neighbour with zero features */
-  SLIDE_OP_ROWS_GN = 23,       /* p: x, gamma, beta, addvec [B][addvec_ld] fp32 (or NULL), residual rows (or NULL), scratch (B*64*ld*2 + B*2*ld floats), y (may be x), [7] / [8] per-tile channel sums / sums of squares [B*i[8]][ld] from the producing GEMM's STATS epilogue (256-row tiles, i[8] tiles per sample) instead of a statistics pass   i: B, S, ld, G (0 = no normalisation), n_norm, flags (1 ReLU before, 2 ReLU after, 4 statistics + scale / shift only -> p[9] [B][2][ld] fp32, for a consumer GEMM with the deferred affine; 8 apply only with p[9]), addvec_ld, res_ld, tiles per sample */
+  SLIDE_OP_ROWS_GN = 23,       /* p: x, gamma, beta, addvec [B][addvec_ld] fp32 (or NULL), residual rows (or NULL), scratch (B*64*ld*2 + B*2*ld floats), y (may be x), [7] / [8] per-tile channel sums / sums of squares [B*i[8]][ld] from the producing GEMM's STATS epilogue (256-row tiles, i[8] tiles per sample) instead of a statistics pass, [10] optional OUT: the statistics [B][64][mean | rstd] fp32 (the training step's backward, slide_train.h)   i: B, S, ld, G (0 = no normalisation), n_norm, flags (1 ReLU before, 2 ReLU after, 4 statistics + scale / shift only -> p[9] [B][2][ld] fp32, for a consumer GEMM with the deferred affine; 8 apply only with p[9]), addvec_ld, res_ld, tiles per sample */
   SLIDE_OP_ROWS_CONCAT_QK = 24,/* p: q [rows/K][ldq], k [rows][ldk], out [rows][ldo] = relu([q | k])   i: rows, K, C1, ldq, C2, ldk, ldo */
   SLIDE_OP_ROWS_ATTN = 25,     /* p: scores [pts*K][lds], values [pts*K][ldv], out [pts][ldo], [3] counts int32 [pts] or NULL (softmax over the first max(1,count) slots), [4] deferred normalisation of the values: scale / shift [sample][2][ldv] fp32 or NULL   i: pts, K, C, lds, ldv, ldo, points per sample, ReLU after the affine */
   SLIDE_OP_ROWS_POOL = 26      /* p: x [pts*K][ldx], out [pts][ldo], counts int32 [pts] or NULL   i: pts, K, C, ldx, ldo, mode (0 max, 1 mean over the counted slots, 2 max for channels < C/2 and mean for the rest) */

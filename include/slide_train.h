@@ -25,12 +25,18 @@
 extern "C" {
 #endif
 
-/* y = post_relu?(GroupNorm_G(pre_relu?(x))) on [B*S][ld]: the first n_norm channels in G groups over (group x S rows of a
- * sample), the rest pass through (MyGroupNorm); flags: 1 = ReLU before, 2 = ReLU after.  G = 0: no normalisation (ReLUs only).
- * Writes dx [B*S][ld] and the PER-SAMPLE parameter gradients dgamma, dbeta [B][ld] (first n_norm channels; the caller sums
- * over B: a deterministic reduction). */
+/* y = post_relu?(GroupNorm_G(pre_relu?(x))) on [B*S][ld]: the first n_norm channels in G <= 64 groups over (group x S rows of a
+ * sample), the rest pass through (MyGroupNorm); flags: 1 = ReLU before, 2 = ReLU after.  G = 0: no normalisation (ReLUs only;
+ * gamma, beta, mean_rstd, dgamma, dbeta, scratch may be NULL).  mean_rstd [B][64][2]: the forward's statistics
+ * (SLIDE_OP_ROWS_GN p[10], slide_engine.h).  Writes dx [B*S][ld] and the PER-SAMPLE parameter gradients dgamma, dbeta [B][ld]
+ * (zero beyond n_norm; the caller sums over B: a deterministic reduction).  scratch: B * (64 * ld * 2 + 128) floats. */
 SLIDE_API int slide_gn_rows_bwd(int B, int S, int ld, int G, int n_norm, int flags, const float *x, const float *gamma,
-                                const float *beta, const float *dy, float *dx, float *dgamma, float *dbeta, slide_stream_t stream);
+                                const float *beta, const float *mean_rstd, const float *dy, float *dx, float *dgamma, float *dbeta,
+                                float *scratch, slide_stream_t stream);
+
+/* column sums of x [rows][ld] in nchunk row chunks: part [nchunk][ld] (the caller adds the partial rows) -- the bias gradient of a
+ * convolution (sum of dy over the rows). */
+SLIDE_API int slide_col_sums(long long rows, int ld, int nchunk, const float *x, float *part, slide_stream_t stream);
 
 /* grouped rows out[(b,p,k)][0..C) = feat[b][idx[b][p][k]][0..C): dfeat [B*N][ldf] += dout [B*np*K][ldg] (atomic; dfeat must be
  * zero-initialised); counts (B*np) int32 or NULL: centres with count 0 carried zero features and receive nothing. */

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void rows_gn_finalize_kernel(int S, int ld, in
                                                                const float *__restrict__ gamma,
                                                                const float *__restrict__ beta,
                                                                const float *__restrict__ tsum, const float *__restrict__ tsq,
-                                                               int tps, float *__restrict__ ss) {
+                                                               int tps, float *__restrict__ ss, float *__restrict__ mr) {
   __shared__ float lsum[1024], lsq[1024], lmean[64], lrstd[64];
   const int b = blockIdx.x;
   const float *pp = part + ((size_t)b * nchunk_stats * ld) * 2;
@@ -244,6 +244,10 @@ __global__ __launch_bounds__(256) void rows_gn_finalize_kernel(int S, int ld, in
     const float var = fmaxf(q1 * inv - mean * mean, 0.f);
     lmean[g] = mean;
     lrstd[g] = 1.0f / sqrtf(var + 1e-5f);
+    if (mr) {  // the training step's backward reads the statistics back (slide_gn_rows_bwd): [b][64][mean | rstd]
+      mr[((size_t)b * 64 + g) * 2 + 0] = mean;
+      mr[((size_t)b * 64 + g) * 2 + 1] = lrstd[g];
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < ld; c += 256) {
@@ -471,7 +475,7 @@ int launch_rows(const SlideOp &o, hipStream_t s) {
                          (const float *)o.p[4], (const int *)o.p[6], (T *)o.p[5], total);
       break;
     }
-    case SLIDE_OP_ROWS_GN: {  // i: B, S, ld, G, n_norm, flags, addvec_ld, res_ld   p: x, gamma, beta, addvec, residual, part, y
+    case SLIDE_OP_ROWS_GN: {  // i: B, S, ld, G, n_norm, flags, addvec_ld, res_ld   p: x, gamma, beta, addvec, residual, part, y, [10] optional mean / rstd out [B][64][2]
       const int B = o.i[0], S = o.i[1], ld = o.i[2], G = o.i[3], n_norm = o.i[4], flags = o.i[5];
       if (ld % 32 || ld > 1024 || G > 64 || (G > 0 && n_norm % G)) return -3;
       if (S <= 0) return 0;
@@ -490,7 +494,7 @@ int launch_rows(const SlideOp &o, hipStream_t s) {
       if (G > 0 && !(flags & 8))
         hipLaunchKernelGGL(rows_gn_finalize_kernel, dim3(B), dim3(256), 0, s, S, ld, nchunk, G, n_norm, (const float *)o.p[5],
                            (const float *)o.p[1], (const float *)o.p[2], (const float *)o.p[7], (const float *)o.p[8], o.i[8],
-                           ssp);
+                           ssp, (float *)o.p[10]);
       if (!(flags & 4))
         hipLaunchKernelGGL(rows_gn_apply_kernel<T>, dim3(nchunk, B), dim3(256), 0, s, S, ld, rpc, flags, (const T *)o.p[0], ssp,
                            (const float *)o.p[3], o.i[6], (const T *)o.p[4], o.i[7], (T *)o.p[6]);

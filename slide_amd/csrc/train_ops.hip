@@ -10,7 +10,7 @@
 //                                                  _ext-src/src/group_points_gpu.cu:30-60 -- an atomicAdd scatter, as here)
 // The GEMM's data gradient is the forward GEMM on the transposed weights (slide_amd/train/functions.py); its weight gradient is a
 // plain [O x rows] x [rows x I] library GEMM.  HBM-bound kernels: one thread per 4 consecutive channels of a row where rows are
-// independent, one workgroup per (sample, group) where GroupNorm couples them.
+// independent; GroupNorm's backward as column reductions + an elementwise pass on the forward's thread layout.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -32,95 +32,182 @@ __device__ __forceinline__ float block_sum(float v, float *red) {  // sum over t
 // ---------------------------------------------------------------------------------------------------- GroupNorm (+ ReLUs)
 // forward (rows_ops.hip): z = pre_relu ? relu(x) : x;  n = (z - mean_g) rstd_g over (gs channels x S rows) of sample b;
 //                         g = n gamma + beta;  y = post_relu ? relu(g) : g;   channels >= n_norm: y = relu?(relu?(x)).
-// backward, one workgroup per (sample, group): statistics recomputed from x (fp32, two passes over the 256-row x gs-channel
-// slab, which stays in the caches), then  dg = dy [g > 0];  dgamma += sum dg n;  dbeta += sum dg;  dn = dg gamma;
-//   dz = rstd (dn - mean(dn) - n mean(dn n));  dx = dz [x > 0 if pre_relu].
+// backward:  dg = dy [g > 0];  dgamma_c = sum_rows dg n;  dbeta_c = sum_rows dg;  dn = dg gamma;
+//            dz = rstd (dn - mean_g(dn) - n mean_g(dn n));  dx = dz [x > 0 if pre_relu],
+// and the group means follow from the per-channel sums: mean_g(dn) = sum_{c in g} gamma_c dbeta_c / n, mean_g(dn n) likewise from
+// dgamma_c.  So the backward is the forward's shape again -- a per-channel column reduction over the sample's rows, a tiny
+// per-sample finalisation, an elementwise pass -- on the forward's thread layout: a thread owns 4 consecutive channels, cn = ld / 4
+// threads cover a row, rt = 256 / cn rows are in flight per workgroup step; every access is a full coalesced row.  mean / rstd
+// come from the forward (SLIDE_OP_ROWS_GN p[10]).  HBM traffic: x and dy twice, dx once (5 passes; the first version's one
+// workgroup per (sample, group) read 16-byte slivers of every row and ran at 3 % of the HBM rate).
 // dgamma / dbeta: per-sample partials [B][ld] (summed over the batch by the caller: deterministic).
-__global__ __launch_bounds__(256) void gn_rows_bwd_kernel(int S, int ld, int G, int n_norm, int flags, const float *__restrict__ x,
-                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                          const float *__restrict__ dy, float *__restrict__ dx,
-                                                          float *__restrict__ dgamma, float *__restrict__ dbeta) {
-  __shared__ float red[4];
-  const bool pre_relu = flags & 1, post_relu = flags & 2;
-  const int b = blockIdx.y, g = blockIdx.x;
-  const int gs = G > 0 ? n_norm / G : 0;
-  const size_t base = (size_t)b * S * ld;
-  if (g == G) {  // pass-through channels [n_norm, ld): y = post_relu(pre_relu(x))
-    const int w = ld - n_norm;
-    for (int e = threadIdx.x; e < S * w; e += 256) {
-      const int r = e / w, c = n_norm + e - r * w;
-      const float xv = x[base + (size_t)r * ld + c];
-      float d = dy[base + (size_t)r * ld + c];
-      if ((pre_relu || post_relu) && !(xv > 0.f)) d = 0.f;
-      dx[base + (size_t)r * ld + c] = d;
-    }
-    return;
-  }
-  const int c0 = g * gs, n = S * gs;
-  const float inv = 1.0f / (float)n;
-  float s = 0.f;
-  for (int e = threadIdx.x; e < n; e += 256) {
-    const int r = e / gs, c = c0 + e - r * gs;
-    float z = x[base + (size_t)r * ld + c];
-    if (pre_relu) z = fmaxf(z, 0.f);
-    s += z;
-  }
-  const float mean = block_sum(s, red) * inv;
-  float q = 0.f;
-  for (int e = threadIdx.x; e < n; e += 256) {
-    const int r = e / gs, c = c0 + e - r * gs;
-    float z = x[base + (size_t)r * ld + c];
-    if (pre_relu) z = fmaxf(z, 0.f);
-    q += (z - mean) * (z - mean);
-  }
-  const float rstd = 1.0f / sqrtf(block_sum(q, red) * inv + GN_EPS);
-  // sums of dn and dn * n over the slab; per-channel dgamma / dbeta (a thread visits the channels c0 + (tid + 256 k) % gs: when
-  // gs divides 256 always the same one -- accumulated in registers, combined through LDS below)
-  float s1 = 0.f, s2 = 0.f;
-  for (int e = threadIdx.x; e < n; e += 256) {
-    const int r = e / gs, c = c0 + e - r * gs;
-    float z = x[base + (size_t)r * ld + c];
-    if (pre_relu) z = fmaxf(z, 0.f);
-    const float nv = (z - mean) * rstd, gm = gamma[c];
-    float dg = dy[base + (size_t)r * ld + c];
-    if (post_relu && !(nv * gm + beta[c] > 0.f)) dg = 0.f;
-    const float dn = dg * gm;
-    s1 += dn;
-    s2 += dn * nv;
-  }
-  const float m1 = block_sum(s1, red) * inv;
-  const float m2 = block_sum(s2, red) * inv;
-  for (int e = threadIdx.x; e < n; e += 256) {
-    const int r = e / gs, c = c0 + e - r * gs;
-    const float xv = x[base + (size_t)r * ld + c];
-    const float z = pre_relu ? fmaxf(xv, 0.f) : xv;
-    const float nv = (z - mean) * rstd, gm = gamma[c];
-    float dg = dy[base + (size_t)r * ld + c];
-    if (post_relu && !(nv * gm + beta[c] > 0.f)) dg = 0.f;
-    float d = rstd * (dg * gm - m1 - nv * m2);
-    if (pre_relu && !(xv > 0.f)) d = 0.f;
-    dx[base + (size_t)r * ld + c] = d;
-  }
-  // parameter gradients of this (sample, group): one channel at a time, the workgroup reduces over the sample's rows
-  for (int j = 0; j < gs; ++j) {
+struct GnCh {  // per-thread constants of its 4 channels
+  float gam[4], bet[4], mean[4], rstd[4];
+  bool norm[4];
+};
+
+__device__ __forceinline__ GnCh gn_channels(int b, int c0, int gs, int n_norm, const float *__restrict__ gamma,
+                                            const float *__restrict__ beta, const float *__restrict__ mr) {
+  GnCh k;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
     const int c = c0 + j;
-    const float gm = gamma[c], bt = beta[c];
-    float a = 0.f, bsum = 0.f;
-    for (int r = threadIdx.x; r < S; r += 256) {
-      float z = x[base + (size_t)r * ld + c];
-      if (pre_relu) z = fmaxf(z, 0.f);
-      const float nv = (z - mean) * rstd;
-      float dg = dy[base + (size_t)r * ld + c];
-      if (post_relu && !(nv * gm + bt > 0.f)) dg = 0.f;
-      a += dg * nv;
-      bsum += dg;
+    k.norm[j] = c < n_norm;
+    const int g = k.norm[j] ? c / gs : 0;
+    k.gam[j] = k.norm[j] ? gamma[c] : 1.f;
+    k.bet[j] = k.norm[j] ? beta[c] : 0.f;
+    k.mean[j] = k.norm[j] ? mr[((size_t)b * 64 + g) * 2 + 0] : 0.f;
+    k.rstd[j] = k.norm[j] ? mr[((size_t)b * 64 + g) * 2 + 1] : 1.f;
+  }
+  return k;
+}
+
+// pass 1: part[b][chunk][ld][2] = per-channel (sum dg, sum dg n) over the chunk's rows
+__global__ __launch_bounds__(256) void gn_bwd_sums_kernel(int S, int ld, int rpc, int gs, int n_norm, int flags, const float *__restrict__ x,
+                                                          const float *__restrict__ dy, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, const float *__restrict__ mr,
+                                                          float *__restrict__ part) {
+  __shared__ float red[256 * 4 * 2];
+  const bool pre_relu = flags & 1, post_relu = flags & 2;
+  const int cn = ld / 4, rt = 256 / cn;
+  const int pr = threadIdx.x / cn, pc = threadIdx.x - pr * cn;
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int r0 = chunk * rpc, r1 = min(S, r0 + rpc);
+  if (pr < rt) {
+    const GnCh k = gn_channels(b, pc * 4, gs, n_norm, gamma, beta, mr);
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const size_t base = ((size_t)b * S) * ld + pc * 4;
+    for (int r = r0 + pr; r < r1; r += rt) {
+      const float4 xv = *reinterpret_cast<const float4 *>(x + base + (size_t)r * ld);
+      const float4 dv = *reinterpret_cast<const float4 *>(dy + base + (size_t)r * ld);
+      const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, da[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float z = pre_relu ? fmaxf(xa[j], 0.f) : xa[j];
+        const float nv = (z - k.mean[j]) * k.rstd[j];
+        float d = da[j];
+        if (post_relu && !(nv * k.gam[j] + k.bet[j] > 0.f)) d = 0.f;
+        s1[j] += d;
+        s2[j] += d * nv;
+      }
     }
-    a = block_sum(a, red);
-    bsum = block_sum(bsum, red);
-    if (threadIdx.x == 0) {
-      dgamma[(size_t)b * ld + c] = a;
-      dbeta[(size_t)b * ld + c] = bsum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[(pr * ld + pc * 4 + j) * 2 + 0] = s1[j];
+      red[(pr * ld + pc * 4 + j) * 2 + 1] = s2[j];
     }
+  }
+  __syncthreads();
+  float *po = part + (((size_t)b * nchunk + chunk) * ld) * 2;
+  for (int c = threadIdx.x; c < ld; c += 256) {
+    float a = 0.f, q = 0.f;
+    for (int r = 0; r < rt; ++r) {
+      a += red[(r * ld + c) * 2 + 0];
+      q += red[(r * ld + c) * 2 + 1];
+    }
+    po[c * 2 + 0] = a;
+    po[c * 2 + 1] = q;
+  }
+}
+
+// between the passes, once per sample: dgamma / dbeta of the sample and the two group means -> coef[b][g][2]
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(int S, int ld, int nchunk, int G, int n_norm, const float *__restrict__ part,
+                                                              const float *__restrict__ gamma, float *__restrict__ dgamma,
+                                                              float *__restrict__ dbeta, float *__restrict__ coef) {
+  __shared__ float l1[1024], l2[1024];
+  const int b = blockIdx.x;
+  const float *pp = part + ((size_t)b * nchunk * ld) * 2;
+  for (int c = threadIdx.x; c < ld; c += 256) {
+    float a = 0.f, q = 0.f;
+    if (c < n_norm) {
+      for (int k = 0; k < nchunk; ++k) {
+        a += pp[((size_t)k * ld + c) * 2 + 0];
+        q += pp[((size_t)k * ld + c) * 2 + 1];
+      }
+      l1[c] = gamma[c] * a;
+      l2[c] = gamma[c] * q;
+    }
+    dbeta[(size_t)b * ld + c] = a;
+    dgamma[(size_t)b * ld + c] = q;
+  }
+  __syncthreads();
+  const int gs = n_norm / G;
+  const float inv = 1.0f / ((float)gs * (float)S);
+  for (int g = threadIdx.x; g < G; g += 256) {
+    float a = 0.f, q = 0.f;
+    for (int j = 0; j < gs; ++j) {
+      a += l1[g * gs + j];
+      q += l2[g * gs + j];
+    }
+    coef[((size_t)b * 64 + g) * 2 + 0] = a * inv;
+    coef[((size_t)b * 64 + g) * 2 + 1] = q * inv;
+  }
+}
+
+// pass 2: dx.  gs == 0: no normalisation anywhere (ReLUs only; mr / coef unused)
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(int S, int ld, int rpc, int gs, int n_norm, int flags, const float *__restrict__ x,
+                                                           const float *__restrict__ dy, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, const float *__restrict__ mr,
+                                                           const float *__restrict__ coef, float *__restrict__ dx) {
+  const bool pre_relu = flags & 1, post_relu = flags & 2;
+  const int cn = ld / 4, rt = 256 / cn;
+  const int pr = threadIdx.x / cn, pc = threadIdx.x - pr * cn;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  if (pr >= rt) return;
+  const GnCh k = gn_channels(b, pc * 4, gs, n_norm, gamma, beta, mr);
+  float m1[4], m2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int g = k.norm[j] ? (pc * 4 + j) / gs : 0;
+    m1[j] = k.norm[j] ? coef[((size_t)b * 64 + g) * 2 + 0] : 0.f;
+    m2[j] = k.norm[j] ? coef[((size_t)b * 64 + g) * 2 + 1] : 0.f;
+  }
+  const int r0 = chunk * rpc, r1 = min(S, r0 + rpc);
+  const size_t base = ((size_t)b * S) * ld + pc * 4;
+  for (int r = r0 + pr; r < r1; r += rt) {
+    const float4 xv = *reinterpret_cast<const float4 *>(x + base + (size_t)r * ld);
+    const float4 dv = *reinterpret_cast<const float4 *>(dy + base + (size_t)r * ld);
+    const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, da[4] = {dv.x, dv.y, dv.z, dv.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float d = da[j];
+      if (k.norm[j]) {
+        const float z = pre_relu ? fmaxf(xa[j], 0.f) : xa[j];
+        const float nv = (z - k.mean[j]) * k.rstd[j];
+        if (post_relu && !(nv * k.gam[j] + k.bet[j] > 0.f)) d = 0.f;
+        d = k.rstd[j] * (d * k.gam[j] - m1[j] - nv * m2[j]);
+        if (pre_relu && !(xa[j] > 0.f)) d = 0.f;
+      } else if ((pre_relu || post_relu) && !(xa[j] > 0.f)) {  // pass-through channel: y = relu?(relu?(x))
+        d = 0.f;
+      }
+      o[j] = d;
+    }
+    *reinterpret_cast<float4 *>(dx + base + (size_t)r * ld) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- column sums (bias gradient)
+// part[chunk][ld] = sum over the chunk's rows of x[row][:] (same thread layout); the caller adds the <= 1024 partial rows.
+__global__ __launch_bounds__(256) void col_sums_kernel(long long rows, int ld, int rpc, const float *__restrict__ x, float *__restrict__ part) {
+  __shared__ float red[256 * 4];
+  const int cn = ld / 4, rt = 256 / cn;
+  const int pr = threadIdx.x / cn, pc = threadIdx.x - pr * cn;
+  const long long r0 = (long long)blockIdx.x * rpc, r1 = min(rows, r0 + rpc);
+  if (pr < rt) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long long r = r0 + pr; r < r1; r += rt) {
+      const float4 v = *reinterpret_cast<const float4 *>(x + (size_t)r * ld + pc * 4);
+      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[pr * ld + pc * 4 + j] = s[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < ld; c += 256) {
+    float a = 0.f;
+    for (int r = 0; r < rt; ++r) a += red[r * ld + c];
+    part[(size_t)blockIdx.x * ld + c] = a;
   }
 }
 
@@ -215,12 +302,33 @@ __global__ __launch_bounds__(256) void attn_rows_bwd_kernel(int K, int C, int ld
 extern "C" {
 
 int slide_gn_rows_bwd(int B, int S, int ld, int G, int n_norm, int flags, const float *x, const float *gamma, const float *beta,
-                      const float *dy, float *dx, float *dgamma, float *dbeta, slide_stream_t stream) {
+                      const float *mean_rstd, const float *dy, float *dx, float *dgamma, float *dbeta, float *scratch,
+                      slide_stream_t stream) {
   if (B <= 0 || S <= 0) return 0;
-  if (ld % 4 || G < 0 || n_norm < 0 || n_norm > ld || (G > 0 && n_norm % G) || (G == 0 && n_norm != 0)) return -3;
-  const int extra = n_norm < ld ? 1 : 0;
-  hipLaunchKernelGGL(gn_rows_bwd_kernel, dim3(G + extra, B), dim3(256), 0, (hipStream_t)stream, S, ld, G, n_norm, flags, x, gamma, beta,
-                     dy, dx, dgamma, dbeta);
+  if (ld % 32 || ld > 1024 || G < 0 || G > 64 || n_norm < 0 || n_norm > ld || (G > 0 && n_norm % G) || (G == 0 && n_norm != 0)) return -3;
+  if (G > 0 && (!mean_rstd || !scratch || !gamma || !beta || !dgamma || !dbeta)) return -3;
+  const int rt = 256 / (ld / 4);
+  int nchunk = (S + rt * 4 - 1) / (rt * 4);
+  nchunk = nchunk < 1 ? 1 : nchunk > 64 ? 64 : nchunk;
+  const int rpc = (S + nchunk - 1) / nchunk;
+  nchunk = (S + rpc - 1) / rpc;
+  const int gs = G > 0 ? n_norm / G : 0;
+  float *coef = scratch ? scratch + (size_t)B * 64 * ld * 2 : nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  if (G > 0) {
+    hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3(nchunk, B), dim3(256), 0, st, S, ld, rpc, gs, n_norm, flags, x, dy, gamma, beta, mean_rstd,
+                       scratch);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, st, S, ld, nchunk, G, n_norm, scratch, gamma, dgamma, dbeta, coef);
+  }
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nchunk, B), dim3(256), 0, st, S, ld, rpc, gs, G > 0 ? n_norm : 0, flags, x, dy, gamma, beta,
+                     mean_rstd, coef, dx);
+  return LAUNCH_STATUS();
+}
+
+int slide_col_sums(long long rows, int ld, int nchunk, const float *x, float *part, slide_stream_t stream) {
+  if (ld % 32 || ld > 1024 || nchunk < 1 || rows < 0) return -3;
+  const int rpc = (int)((rows + nchunk - 1) / nchunk);
+  hipLaunchKernelGGL(col_sums_kernel, dim3(nchunk), dim3(256), 0, (hipStream_t)stream, rows, ld, rpc < 1 ? 1 : rpc, x, part);
   return LAUNCH_STATUS();
 }
 

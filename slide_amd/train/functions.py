@@ -38,6 +38,25 @@ def pad_cols(x, ld=None):
     return torch.nn.functional.pad(x, (0, ld - x.shape[1])).contiguous()
 
 
+_EPI_CACHE = {}   # (bias-vector address, blocks, out_ld) -> (device epilogue-table template, mask of its `out` words): a step's table is
+                  # template + mask * output address, one small device add -- an upload would be a blocking host -> device copy
+_PACK_CACHE = {}  # id(parameter) -> persistent packed buffers (refilled in place every call: the weights change every step)
+
+
+def _packs(weight, kp, op_):
+    # (the shape is part of the key: a new parameter can inherit the id of a collected one, and the buffers' pad regions must stay zero)
+    key = (id(weight), tuple(weight.shape), kp, op_, weight.device.index)
+    c = _PACK_CACHE.get(key)
+    if c is None:
+        if len(_PACK_CACHE) > 4096:
+            _PACK_CACHE.clear()
+        dev = weight.device
+        c = {"W": torch.zeros(op_, kp, device=dev), "Wt": torch.zeros(kp, op_, device=dev), "vec": torch.zeros(op_, device=dev),
+             "zero": torch.zeros(kp, device=dev)}
+        _PACK_CACHE[key] = c
+    return c
+
+
 def _gemm(x, w_packed, bias_vec, n_out_pad):
     """y [rows, n_out_pad] = x [rows, kp] @ w_packed[n_out_pad, kp]^T + bias_vec (split-precision MFMA GEMM, RAW epilogue)"""
     rows, kp = x.shape
@@ -45,17 +64,55 @@ def _gemm(x, w_packed, bias_vec, n_out_pad):
     if rows == 0:
         return out
     n_cob = n_out_pad // 32
-    tab = (SlideEpi * n_cob)()
-    for j in range(n_cob):
-        t = tab[j]
-        t.mode = EPI_RAW
-        t.out_ld = n_out_pad
-        t.bias = bias_vec.data_ptr() + 4 * 32 * j
-        t.out = out.data_ptr() + 4 * 32 * j
-    epi = torch.from_numpy(np.frombuffer(bytes(tab), dtype=np.uint8).copy()).to(x.device)
+    key = (bias_vec.data_ptr(), n_cob, n_out_pad, x.device.index)
+    c = _EPI_CACHE.get(key)
+    if c is None:
+        if len(_EPI_CACHE) > 8192:
+            _EPI_CACHE.clear()
+        tab = (SlideEpi * n_cob)()
+        for j in range(n_cob):
+            t = tab[j]
+            t.mode = EPI_RAW
+            t.out_ld = n_out_pad
+            t.bias = bias_vec.data_ptr() + 4 * 32 * j
+            t.out = 4 * 32 * j
+        words = ctypes.sizeof(SlideEpi) // 8
+        mask = np.zeros((n_cob, words), np.int64)
+        mask[:, SlideEpi.out.offset // 8] = 1
+        c = (torch.from_numpy(np.frombuffer(bytes(tab), dtype=np.int64).reshape(n_cob, words).copy()).to(x.device),
+             torch.from_numpy(mask).to(x.device))
+        _EPI_CACHE[key] = c
+    epi = torch.add(c[0], c[1], alpha=out.data_ptr())
     _run(make_op(OP_GEMM, i=(rows, kp, kp, n_cob, 8, 0, PREC_SPLIT, 2, 0, 0),
                  p=(x.data_ptr(), w_packed.data_ptr(), epi.data_ptr())))
     return out
+
+
+def col_sums(x):
+    """sum over the rows of x [rows, ld] -> [ld] (csrc/train_ops.hip col_sums_kernel: coalesced row chunks, then the same kernel over
+    the partial rows).  torch's dim-0 reduction of a 65536 x 128 matrix runs at 4 % of the HBM rate, and its multi-block reductions
+    (semaphore + staging buffer) returned garbage inside replayed HIP graphs (tools/debug_train_nan4.py)."""
+    rows, ld = x.shape
+    nchunk = max(1, min(256, rows // 256))
+    part = torch.empty(nchunk + 1, ld, device=x.device, dtype=torch.float32)
+    check(lib().slide_col_sums(ctypes.c_longlong(rows), ld, nchunk, _p(x), _p(part), _stream()), "slide_col_sums")
+    if nchunk == 1:
+        return part[0]
+    check(lib().slide_col_sums(ctypes.c_longlong(nchunk), ld, 1, _p(part), _c(part.data_ptr() + 4 * nchunk * ld), _stream()), "slide_col_sums")
+    return part[nchunk]
+
+
+def _weight_grad(dy, x):
+    """dW (padded) [op_, kp] = dy^T x over the rows: a library GEMM (hipBLASLt through torch) whose contraction is the LONG dimension
+    (up to 65536 rows against 32..512 outputs), so it is split into row slabs -- a batched GEMM that fills the chip -- and the
+    slab results are added."""
+    rows = dy.shape[0]
+    slabs = 1
+    while slabs < 64 and rows % (slabs * 2) == 0 and rows // (slabs * 2) >= 256:
+        slabs *= 2
+    if slabs == 1:
+        return dy.t() @ x
+    return torch.bmm(dy.view(slabs, rows // slabs, -1).transpose(1, 2), x.view(slabs, rows // slabs, -1)).sum(dim=0)
 
 
 class ConvRows(torch.autograd.Function):
@@ -67,14 +124,13 @@ class ConvRows(torch.autograd.Function):
         O, I = weight.shape[0], int(np.prod(weight.shape[1:]))
         kp, op_ = x.shape[1], ru(O)
         assert kp == ru(I), (kp, I)
-        W = torch.zeros(op_, kp, device=x.device, dtype=torch.float32)
-        W[:O, :I] = weight.detach().reshape(O, I)
-        vec = torch.zeros(op_, device=x.device, dtype=torch.float32)
+        c = _packs(weight, kp, op_)
+        c["W"][:O, :I].copy_(weight.detach().reshape(O, I))
         if bias is not None:
-            vec[:O] = bias.detach()
+            c["vec"][:O].copy_(bias.detach())
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return _gemm(x, W, vec, op_)
+        return _gemm(x, c["W"], c["vec"], op_)
 
     @staticmethod
     def backward(ctx, dy):
@@ -84,13 +140,13 @@ class ConvRows(torch.autograd.Function):
         kp, op_ = x.shape[1], dy.shape[1]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:  # dx = dy @ W: the forward GEMM on the transposed weights
-            Wt = torch.zeros(kp, op_, device=x.device, dtype=torch.float32)
-            Wt[:I, :O] = weight.detach().reshape(O, I).t()
-            dx = _gemm(dy, Wt, torch.zeros(kp, device=x.device), kp)
-        if ctx.needs_input_grad[1]:  # dW = dy^T x: a plain [O x rows] x [rows x I] library GEMM (hipBLASLt through torch)
-            dw = (dy[:, :O].t() @ x[:, :I]).reshape(weight.shape)
+            c = _packs(weight, kp, op_)
+            c["Wt"][:I, :O].copy_(weight.detach().reshape(O, I).t())
+            dx = _gemm(dy, c["Wt"], c["zero"], kp)
+        if ctx.needs_input_grad[1]:
+            dw = _weight_grad(dy, x)[:O, :I].reshape(weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy[:, :O].sum(dim=0)
+            db = col_sums(dy)[:O]
         return dx, dw, db
 
 
@@ -107,29 +163,34 @@ class GroupNormRows(torch.autograd.Function):
         G = G if n_norm else 0
         flags = (GN_PRE_RELU if pre_relu else 0) | (GN_POST_RELU if post_relu else 0)
         out = torch.empty_like(x)
-        gam = bet = part = None
+        gam = bet = part = mr = None
         if n_norm:
             gam, bet = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
             part = torch.empty(B * 64 * ld * 2 + B * 2 * ld, device=x.device, dtype=torch.float32)
+            mr = torch.empty(B, 64, 2, device=x.device, dtype=torch.float32)  # the statistics, for the backward
         if x.shape[0]:
-            _run(_rop(OP_ROWS_GN, False, (B, S, ld, G, n_norm, flags, 0, 0, 0), (x, gam, bet, None, None, part, out, None, None, None)))
-        ctx.save_for_backward(x, gam, bet)
+            _run(_rop(OP_ROWS_GN, False, (B, S, ld, G, n_norm, flags, 0, 0, 0), (x, gam, bet, None, None, part, out, None, None, None, mr)))
+        ctx.save_for_backward(x, gam, bet, mr)
         ctx.cfg = (B, S, G, n_norm, flags)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        x, gam, bet = ctx.saved_tensors
+        x, gam, bet, mr = ctx.saved_tensors
         B, S, G, n_norm, flags = ctx.cfg
         ld = x.shape[1]
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dg = torch.zeros(B, ld, device=x.device) if n_norm else None
-        db = torch.zeros(B, ld, device=x.device) if n_norm else None
+        dg = db = scratch = None
+        if n_norm:
+            dg, db = torch.empty(B, ld, device=x.device), torch.empty(B, ld, device=x.device)
+            scratch = torch.empty(B * (64 * ld * 2 + 128), device=x.device, dtype=torch.float32)
         if x.shape[0]:
-            check(lib().slide_gn_rows_bwd(B, S, ld, G, n_norm, flags, _p(x), _p(gam), _p(bet), _p(dy), _p(dx), _p(dg), _p(db), _stream()),
-                  "slide_gn_rows_bwd")
-        return (dx, None if dg is None else dg.sum(0)[:n_norm], None if db is None else db.sum(0)[:n_norm], None, None, None, None, None)
+            check(lib().slide_gn_rows_bwd(B, S, ld, G, n_norm, flags, _p(x), _p(gam), _p(bet), _p(mr), _p(dy), _p(dx), _p(dg), _p(db),
+                                          _p(scratch), _stream()), "slide_gn_rows_bwd")
+        elif n_norm:
+            dg.zero_(), db.zero_()
+        return (dx, None if dg is None else col_sums(dg)[:n_norm], None if db is None else col_sums(db)[:n_norm], None, None, None, None, None)
 
 
 class GroupRows(torch.autograd.Function):

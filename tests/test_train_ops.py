@@ -38,7 +38,8 @@ def test_conv_rows(gpu_device, rows, I, O, bias):
 
 
 @pytest.mark.parametrize("B,S,C,pre,post", [(3, 48, 70, False, True), (2, 256, 128, False, True), (4, 16, 64, True, False), (2, 128, 111, True, True),
-                                            (3, 16, 51, False, False), (2, 40, 20, False, True)])
+                                            (3, 16, 51, False, False), (2, 40, 20, False, True), (2, 256, 515, True, True), (3, 100, 1024, False, True),
+                                            (33, 128, 64, False, True)])
 def test_group_norm_rows(gpu_device, B, S, C, pre, post):
     """MyGroupNorm(min(32, C), C) (pointnet2_modules.py:24-42): the first C - C % G channels in G groups, the rest pass through"""
     from slide_amd.train import functions as F
@@ -69,6 +70,15 @@ def test_group_norm_rows(gpu_device, B, S, C, pre, post):
     assert _rel(y2[:, :C], r2) <= 1e-6
     d2 = torch.autograd.grad(y2, [xp], _pad(dy, ld))[0]
     assert _rel(d2[:, :C], torch.autograd.grad(r2, [xr], dy)[0]) <= 1e-6
+
+
+@pytest.mark.parametrize("rows,ld", [(5, 32), (4096, 128), (1000, 544), (70000, 64), (300, 1024)])
+def test_col_sums(gpu_device, rows, ld):
+    from slide_amd.train import functions as F
+    g = torch.Generator(device=gpu_device); g.manual_seed(rows)
+    x = torch.randn(rows, ld, device=gpu_device, generator=g)
+    ref = x.double().sum(0)
+    assert float((F.col_sums(x).double() - ref).abs().max()) <= 1e-5 * float(x.abs().sum(0).max())
 
 
 @pytest.mark.parametrize("fp", [False, True])
