@@ -34,9 +34,10 @@ SLIDE_API int slide_gn_rows_bwd(int B, int S, int ld, int G, int n_norm, int fla
                                 const float *beta, const float *mean_rstd, const float *dy, float *dx, float *dgamma, float *dbeta,
                                 float *scratch, slide_stream_t stream);
 
-/* column sums of x [rows][ld] in nchunk row chunks: part [nchunk][ld] (the caller adds the partial rows) -- the bias gradient of a
- * convolution (sum of dy over the rows). */
-SLIDE_API int slide_col_sums(long long rows, int ld, int nchunk, const float *x, float *part, slide_stream_t stream);
+/* out [ld] = column sums of x [rows][ld] (the bias gradient of a convolution: the sum of dy over the rows; GroupNorm's parameter
+ * gradients over the batch).  Two launches: row chunks, then 32-column stripes over the partial rows; deterministic.
+ * scratch: 1024 * ld floats (unused when rows < 128). */
+SLIDE_API int slide_col_sums(long long rows, int ld, const float *x, float *out, float *scratch, slide_stream_t stream);
 
 /* grouped rows out[(b,p,k)][0..C) = feat[b][idx[b][p][k]][0..C): dfeat [B*N][ldf] += dout [B*np*K][ldg] (atomic; dfeat must be
  * zero-initialised); counts (B*np) int32 or NULL: centres with count 0 carried zero features and receive nothing. */

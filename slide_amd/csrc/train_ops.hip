@@ -188,26 +188,30 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(int S, int ld, int rp
 }
 
 // ---------------------------------------------------------------------------------------------------- column sums (bias gradient)
-// part[chunk][ld] = sum over the chunk's rows of x[row][:] (same thread layout); the caller adds the <= 1024 partial rows.
-__global__ __launch_bounds__(256) void col_sums_kernel(long long rows, int ld, int rpc, const float *__restrict__ x, float *__restrict__ part) {
+// part[chunk][c] = sum over the chunk's rows of x[row][c] for the `width` columns of stripe blockIdx.y (same thread layout over the
+// stripe: width / 4 threads per row).  Two launches make a full column sum: full-width row chunks that fill the chip, then one
+// 32-column stripe per workgroup over the <= 1024 partial rows (deterministic; no atomics).
+__global__ __launch_bounds__(256) void col_sums_kernel(long long rows, int ld, int width, int rpc, const float *__restrict__ x,
+                                                       float *__restrict__ part) {
   __shared__ float red[256 * 4];
-  const int cn = ld / 4, rt = 256 / cn;
+  const int cn = width / 4, rt = 256 / cn;
   const int pr = threadIdx.x / cn, pc = threadIdx.x - pr * cn;
+  const int c0 = blockIdx.y * width;
   const long long r0 = (long long)blockIdx.x * rpc, r1 = min(rows, r0 + rpc);
   if (pr < rt) {
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     for (long long r = r0 + pr; r < r1; r += rt) {
-      const float4 v = *reinterpret_cast<const float4 *>(x + (size_t)r * ld + pc * 4);
+      const float4 v = *reinterpret_cast<const float4 *>(x + (size_t)r * ld + c0 + pc * 4);
       s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) red[pr * ld + pc * 4 + j] = s[j];
+    for (int j = 0; j < 4; ++j) red[pr * width + pc * 4 + j] = s[j];
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < ld; c += 256) {
+  for (int c = threadIdx.x; c < width; c += 256) {
     float a = 0.f;
-    for (int r = 0; r < rt; ++r) a += red[r * ld + c];
-    part[(size_t)blockIdx.x * ld + c] = a;
+    for (int r = 0; r < rt; ++r) a += red[r * width + c];
+    part[(size_t)blockIdx.x * ld + c0 + c] = a;
   }
 }
 
@@ -325,10 +329,18 @@ int slide_gn_rows_bwd(int B, int S, int ld, int G, int n_norm, int flags, const 
   return LAUNCH_STATUS();
 }
 
-int slide_col_sums(long long rows, int ld, int nchunk, const float *x, float *part, slide_stream_t stream) {
-  if (ld % 32 || ld > 1024 || nchunk < 1 || rows < 0) return -3;
+int slide_col_sums(long long rows, int ld, const float *x, float *out, float *scratch, slide_stream_t stream) {
+  if (ld % 32 || ld > 1024 || rows < 0) return -3;
+  long long nchunk = rows / 64;
+  nchunk = nchunk < 1 ? 1 : nchunk > 1024 ? 1024 : nchunk;
   const int rpc = (int)((rows + nchunk - 1) / nchunk);
-  hipLaunchKernelGGL(col_sums_kernel, dim3(nchunk), dim3(256), 0, (hipStream_t)stream, rows, ld, rpc < 1 ? 1 : rpc, x, part);
+  if (nchunk == 1) {
+    hipLaunchKernelGGL(col_sums_kernel, dim3(1, ld / 32), dim3(256), 0, (hipStream_t)stream, rows, ld, 32, rpc < 1 ? 1 : rpc, x, out);
+    return LAUNCH_STATUS();
+  }
+  if (!scratch) return -3;
+  hipLaunchKernelGGL(col_sums_kernel, dim3((unsigned)nchunk), dim3(256), 0, (hipStream_t)stream, rows, ld, ld, rpc, x, scratch);
+  hipLaunchKernelGGL(col_sums_kernel, dim3(1, ld / 32), dim3(256), 0, (hipStream_t)stream, nchunk, ld, 32, (int)nchunk, scratch, out);
   return LAUNCH_STATUS();
 }
 

@@ -93,13 +93,10 @@ def col_sums(x):
     the partial rows).  torch's dim-0 reduction of a 65536 x 128 matrix runs at 4 % of the HBM rate, and its multi-block reductions
     (semaphore + staging buffer) returned garbage inside replayed HIP graphs (tools/debug_train_nan4.py)."""
     rows, ld = x.shape
-    nchunk = max(1, min(256, rows // 256))
-    part = torch.empty(nchunk + 1, ld, device=x.device, dtype=torch.float32)
-    check(lib().slide_col_sums(ctypes.c_longlong(rows), ld, nchunk, _p(x), _p(part), _stream()), "slide_col_sums")
-    if nchunk == 1:
-        return part[0]
-    check(lib().slide_col_sums(ctypes.c_longlong(nchunk), ld, 1, _p(part), _c(part.data_ptr() + 4 * nchunk * ld), _stream()), "slide_col_sums")
-    return part[nchunk]
+    buf = torch.empty(1025 if rows >= 128 else 1, ld, device=x.device, dtype=torch.float32)
+    check(lib().slide_col_sums(ctypes.c_longlong(rows), ld, _p(x), _p(buf), _c(buf.data_ptr() + 4 * ld) if rows >= 128 else None, _stream()),
+          "slide_col_sums")
+    return buf[0]
 
 
 def _weight_grad(dy, x):
