@@ -293,7 +293,8 @@ def main():
         a.replay = "graph"
     eager = a.replay != "graph"
     if a.workload == "default":
-        pos = PositionSampler(pc["pointnet_config"], sd_p, B, dev, pc["diffusion_config"], prec=a.pos_prec or a.prec, seed=1000 + rank * 16,
+        pos_mult = int(os.environ.get("SLIDE_POS_MULT", "1"))  # experiment: position chain over pos_mult x B, one step per pos_mult rounds
+        pos = PositionSampler(pc["pointnet_config"], sd_p, B * pos_mult, dev, pc["diffusion_config"], prec=a.pos_prec or a.prec, seed=1000 + rank * 16,
                               use_graph=not eager)
         # position plan: its own step graph on its own stream ("own", default: 1-1.5 % faster) or a parallel branch of the
         # first feature sub-batch's graph ("branch")
@@ -316,7 +317,7 @@ def main():
                 only = os.environ["SLIDE_BENCH_ONLY"]
                 order = {"pos": [pos], "feat": [s_[0] for s_ in subs], "feat1": [subs[0][0]], "feat2": [s_[0] for s_ in subs[:2]],
                          "pos+feat1": [subs[0][0], pos]}[only]
-            joint = EagerChainsSampler(order)
+            joint = EagerChainsSampler(order, every=[pos_mult if s_ is pos else 1 for s_ in order])
     cat_desc = None
     if a.workload == "five-cat":
         # per-category weight sets (synthetic, keyed on the category id); every segment of this rank's shard is a chain pair
@@ -339,7 +340,7 @@ def main():
         sizes = [fs.B for fs, _, _ in feat_chains]
         P = len(sizes)
     else:
-        pos_chains = [(pos, torch.zeros(B, dtype=torch.int64, device=dev))]
+        pos_chains = [(pos, torch.zeros(pos.B, dtype=torch.int64, device=dev))]
         feat_chains = [(f_, torch.full((b,), 4, dtype=torch.int64, device=dev), torch.as_tensor(k_, device=dev))
                        for (f_, _, k_), b in zip(subs, sizes)]
     rs = np.random.RandomState(rank)

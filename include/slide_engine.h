@@ -222,6 +222,9 @@ SLIDE_API int slide_run_ops2(const SlideOp *ops, int n, slide_stream_t stream0, 
 /* `reps` back-to-back eager replays of one plan (one host thread per chain / stream; no SLIDE_OP_SYNC across threads) */
 /* `reps` steps of n_chains independent single-lane plans, issued round-robin from the calling thread (chain c on streams[c]) */
 SLIDE_API int slide_run_chains(const SlideOp *const *ops, const int *n, const slide_stream_t *streams, int n_chains, int reps);
+/* ... chain c issues a step only on rounds r with r % every[c] == 0 (every[c] >= 1) */
+SLIDE_API int slide_run_chains_every(const SlideOp *const *ops, const int *n, const slide_stream_t *streams, const int *every,
+                                     int n_chains, int reps);
 SLIDE_API int slide_run_ops_repeat(const SlideOp *ops, int n, slide_stream_t stream0, slide_stream_t stream1, int reps);
 
 /* same, eagerly, with a HIP event recorded on `stream` between consecutive launches; ms_out[i] (HOST, n floats)

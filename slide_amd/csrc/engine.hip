@@ -2398,6 +2398,19 @@ int slide_run_chains(const SlideOp *const *ops, const int *n, const slide_stream
   return 0;
 }
 
+// The same with chain c stepping only on every every[c]-th round (a chain over a multiple of the common batch advances once per
+// `every` rounds of the others: same shapes per unit time, fewer dependent launches on the critical path).
+int slide_run_chains_every(const SlideOp *const *ops, const int *n, const slide_stream_t *streams, const int *every, int n_chains,
+                           int reps) {
+  for (int r = 0; r < reps; ++r)
+    for (int c = 0; c < n_chains; ++c) {
+      if (every[c] > 1 && r % every[c] != 0) continue;
+      const int st = slide_run_ops2(ops[c], n[c], streams[c], streams[c]);
+      if (st != 0) return st;
+    }
+  return 0;
+}
+
 // Eager replay with a HIP event between consecutive launches (recorded on the launch stream): ms_out[i] = device
 // time of ops[i].  Used by bench.py for the per-kernel roofline figure; not used on the timed path.
 int slide_run_ops_timed(const SlideOp *ops, int n, slide_stream_t stream, float *ms_out) {

@@ -480,14 +480,20 @@ class EagerChainsSampler:
     """Independent chains replayed eagerly from ONE host thread, round-robin per step, in a single library call per
     advance() (slide_run_chains): no graph, no interpreter work between launches."""
 
-    def __init__(self, samplers):
+    def __init__(self, samplers, every=None):
         self.samplers = list(samplers)
         k = len(self.samplers)
+        # every[c] > 1: chain c (a sampler over every[c] x the common batch) steps once per every[c] rounds
+        self._every = None if every is None or all(e == 1 for e in every) else (ctypes.c_int * k)(*[int(e) for e in every])
         self._ops = (ctypes.c_void_p * k)(*[ctypes.cast(s_.step_ops, ctypes.c_void_p) for s_ in self.samplers])
         self._n = (ctypes.c_int * k)(*[len(s_.step_ops) for s_ in self.samplers])
         self._streams = (ctypes.c_void_p * k)(*[s_.stream.cuda_stream for s_ in self.samplers])
 
     def advance(self, n_steps):
+        if self._every is not None:
+            check(lib().slide_run_chains_every(self._ops, self._n, self._streams, self._every, len(self.samplers), int(n_steps)),
+                  "slide_run_chains_every")
+            return
         check(lib().slide_run_chains(self._ops, self._n, self._streams, len(self.samplers), int(n_steps)), "slide_run_chains")
 
     def synchronize(self):
