@@ -539,6 +539,13 @@ def test_threaded_eager_sampler_equals_separate_chains(gpu_device):
     assert np.array_equal(pe.state().cpu().numpy(), want_p)
     for f, w in zip(fe, want_f):
         assert np.array_equal(f.state().cpu().numpy(), w)
+    # a chain that steps once per TWO rounds (slide_run_chains_every: a position chain over a multiple of the batch beside chains
+    # over the batch): rounds 0, 2, ..., 2 n - 2 make the same n steps
+    begin(pe, fe)
+    rr = EagerChainsSampler([pe], every=[2])
+    rr.advance(2 * n - 1)
+    rr.synchronize()
+    assert np.array_equal(pe.state().cpu().numpy(), want_p)
 
 
 def test_x_stationary_kernel_bit_identical(gpu_device, exp_lib, monkeypatch):
