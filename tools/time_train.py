@@ -1,5 +1,5 @@
 """Training step (forward + loss + backward + Adam) of the two latent-DDPM denoisers on the HIP training path: ms per step and
-samples/s at the reference's training batch size (32, config_*_batchsize_32_*).  usage: python tools/time_train.py [batch=32]"""
+samples/s at the reference's training batch size (32, config_*_batchsize_32_*).  usage: python tools/time_train.py [batch=32] [--eager-only]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,8 @@ from slide_amd.train.dp import training_step
 from slide_amd.train.graph import GraphedTrainingStep
 from slide_amd.train.losses import latent_training_loss, position_training_loss
 dev = torch.device("cuda:0")
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 32
+EAGER_ONLY = "--eager-only" in sys.argv  # (for rocprofv3 --kernel-trace: per-kernel times of the eager step)
 for name in ("pos", "feat"):
     cfg = configs.position_ddpm_config() if name == "pos" else configs.feature_ddpm_config()
     hp = cfg["pointnet_config"]
@@ -41,6 +42,9 @@ for name in ("pos", "feat"):
             net(x0, torch.zeros(B, device=dev), lab)
         torch.cuda.synchronize()
         df = (time.perf_counter() - t0) / n
+    if EAGER_ONLY:
+        print("%s denoiser, batch %d: training step eager %.2f ms (%.0f samples/s), forward only %.2f ms" % (name, B, dt * 1e3, B / dt, df * 1e3), flush=True)
+        continue
     step = GraphedTrainingStep(net, opt, fn)
     step(); torch.cuda.synchronize()
     t0 = time.perf_counter()
