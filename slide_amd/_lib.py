@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SLIDE_HIP_LIB: developer knob for A/B timing of two builds of the same library (tools/ab_build.sh)
+# SLIDE_HIP_LIB: developer knob for A/B timing of two builds of the same library (tools/ab/ab_build.sh)
 LIB_PATH = os.environ.get("SLIDE_HIP_LIB") or os.path.join(_HERE, "libslide_hip.so")
 # the EXPERIMENTS build (slide_amd/build.py): the product kernels + every opt-in variant.  SLIDE_EXPERIMENTS=1 makes it the
 # library of the process; `with experiments():` switches to it for a block (the plan-variant tests)

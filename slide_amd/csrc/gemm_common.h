@@ -39,7 +39,7 @@ struct GemmArgs {
   int g_ldf, g_nsplit, g_klog2;
   int *sched;               // persistent-mode tile counters (9 ints, zero), or nullptr
   int stagger;              // start delay (10 ns units) of the workgroups in odd wave slots, 0 = none
-  unsigned long long *dbg;  // optional per-workgroup timeline (tools/gemm_timeline.py): 16 x 100 MHz stamps per workgroup
+  unsigned long long *dbg;  // optional per-workgroup timeline (tools/ab/gemm_timeline.py): 16 x 100 MHz stamps per workgroup
   // pair decomposition (gemm_gx.hip; SLIDE_OP_GEMM_GX in include/slide_engine.h): per-point tables the X operand is generated
   // from, the per-slot scalars of group_knn and their coefficient vectors; gx_d2 / gx_w also serve the PAIR_NBR residual
   const void *gx_ta, *gx_tb;
@@ -75,7 +75,7 @@ template <> struct TileT<SLIDE_PREC_F16> { using T = _Float16; static constexpr 
 // split mode: float activations in HBM (T), two fp16 planes (hi, scaled lo) per operand tile in LDS (rows of LDK = 40 halves)
 template <> struct TileT<SLIDE_PREC_SPLIT> { using T = float; static constexpr int LDK = 40; static constexpr int EPL = 4; };
 
-#ifdef SLIDE_TIMELINE  // instrumented build only (tools/gemm_timeline.py); the product library carries no stamps
+#ifdef SLIDE_TIMELINE  // instrumented build only (tools/ab/gemm_timeline.py); the product library carries no stamps
 #define SLIDE_STAMP(a, k)                                                                     \
   do {                                                                                        \
     if ((a).dbg && threadIdx.x == 0) (a).dbg[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); \
@@ -198,7 +198,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
         // (the squared distance is clamped to the fp16 range before the conversion -- ADVICE r3: beyond 65504 it became inf.  The
         //  residual itself stays in packed fp16, like the generated-X fragments of the same block: evaluating it in fp32 -- tried in
         //  round 4 -- left single forwards unchanged and made 1000-step position chains deviate 5x MORE from the fp32 mode
-        //  (median per-shape distance 6.8e-4 vs 1.4e-4, tools/chain_dev.py): the block's two uses of (d2, w) then round differently)
+        //  (median per-shape distance 6.8e-4 vs 1.4e-4, tools/ab/chain_dev.py): the block's two uses of (d2, w) then round differently)
         nbr_sc[rb] = f16x2{(_Float16)fminf(a.gx_d2[slot], 65504.f), (_Float16)a.gx_w[slot]};
       }
     }
@@ -523,7 +523,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     if (PH == 2 && cb == 0) SLIDE_STAMP(a, 9);
     // store.  A lane holds 4 consecutive channels per quad q (channels 8q + 4*half).  fp32 rows go out as they are
     // (16 B per lane).  For fp16 rows an 8-byte store per lane would touch only 16 B of every row per instruction,
-    // which the memory system writes at half the rate of wider row pieces (tools/store_pattern.hip: 3.1 vs 5.2 TB/s):
+    // which the memory system writes at half the rate of wider row pieces (tools/ab/store_pattern.hip: 3.1 vs 5.2 TB/s):
     // v_permlane32_swap trades quads 2p+1 / 2p between the lane halves so that lane (col, half) owns the 8 channels
     // 16p + 8*half .. +7 and issues 16-byte stores (32 B per row and instruction).  The residual is read the same way.
     // Pass 1 consumes every value that came from a global load (t-embedding rows, residual); pass 2 only converts and

@@ -1,6 +1,6 @@
 #!/bin/bash
 # builds build_tmp/libA.so from the engine.hip of a git revision (default HEAD) for A/B timing against the working tree:
-#   tools/ab_build.sh [rev];  then on the GPU box:  SLIDE_HIP_LIB=$PWD/build_tmp/libA.so python tools/time_chains.py
+#   tools/ab/ab_build.sh [rev];  then on the GPU box:  SLIDE_HIP_LIB=$PWD/build_tmp/libA.so python tools/ab/time_chains.py
 set -e
 REV=${1:-HEAD}
 cd "$(dirname "$0")/.."

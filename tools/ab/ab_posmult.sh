@@ -1,4 +1,4 @@
-# position chain over a multiple of the batch, stepping once per that many rounds: tools/ab_posmult.sh
+# position chain over a multiple of the batch, stepping once per that many rounds: tools/ab/ab_posmult.sh
 cd /root/repo
 Q="--steps 300 --warmup 20 --no-cpu-baseline --no-parity --no-roofline --no-decode"
 run() { python bench.py $Q $2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'], d['ms_per_step'])"; }

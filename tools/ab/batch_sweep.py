@@ -1,7 +1,7 @@
 """Odd batch sizes through the default fp16 plans (ragged row tiles, partial XCD groups): forward vs the fp32 engine of the same
 batch, and a few sampler steps of both DDPMs (finite, batch-size independent)."""
 import numpy as np, torch, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from slide_amd import configs, model_spec
 from slide_amd.diffusion import PositionSampler, FeatureSampler
 from slide_amd.engine import DenoiserEngine

@@ -1,7 +1,7 @@
 """fp16-mode position chains against the exact-fp32 mode (equal in-kernel noise): per-shape relative max distance after n steps"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from slide_amd import configs, model_spec
 from slide_amd.diffusion import PositionSampler

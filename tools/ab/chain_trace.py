@@ -1,11 +1,11 @@
 """One chain under rocprofv3 --kernel-trace: per-launch durations AND the gaps between consecutive kernels of a step.
 on the GPU box:
   cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/ct -o ct -- \
-      python $GRAFT_REPO_ROOT/tools/chain_trace.py run feat 256
-  python tools/chain_trace.py report gpurun_out/ct [n_ops]
+      python $GRAFT_REPO_ROOT/tools/ab/chain_trace.py run feat 256
+  python tools/ab/chain_trace.py report gpurun_out/ct [n_ops]
 """
 import csv, glob, os, re, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

@@ -1,6 +1,6 @@
 """GPU debugging aid for the LDS-resident kernel: runs the op program truncated after k ops for k = 1 .. n on the GPU (every
 workgroup dumps its LDS arena) and in the numpy emulator (tests/resident_emu.py), and reports the first op whose arena
-differs.  usage: python tools/debug_resident.py [first_k]"""
+differs.  usage: python tools/ab/debug_resident.py [first_k]"""
 import json
 import os
 import sys
@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 from conftest import golden_spec, load_golden  # noqa: E402
 from resident_emu import Emu  # noqa: E402

@@ -1,6 +1,6 @@
 """per-call device time and effective bandwidth of the row-major module kernels in one decode (authoring tool)"""
 import os, sys, collections
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "pointnet2"))
 import torch
 from slide_amd import rows as R

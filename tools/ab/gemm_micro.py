@@ -1,7 +1,7 @@
 """micro-benchmark of the engine GEMM op in isolation (one op, many reps, HIP events)"""
 import ctypes, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from slide_amd import engine as E
 from slide_amd._lib import check, lib

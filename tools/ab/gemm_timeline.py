@@ -1,10 +1,10 @@
 """Per-workgroup timeline of one GEMM launch (100 MHz stamps written by the kernel when SlideOp.p[5] is set).
-usage: python tools/gemm_timeline.py rows,npxl,K,N,mode[,extras]   (same case syntax as tools/gemm_micro.py)
+usage: python tools/ab/gemm_timeline.py rows,npxl,K,N,mode[,extras]   (same case syntax as tools/ab/gemm_micro.py)
 stamps: 0 start | 1 tables staged + ring primed | 2 K loop done | 3 partial statistics published | 4 barrier passed |
         5 stores issued | 6 stores retired"""
 import ctypes, os, subprocess, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 LIBT = os.path.join(ROOT, "build_tmp", "libT.so")
 if "--build" in sys.argv:  # instrumented copy of the library (-DSLIDE_TIMELINE); run this part where hipcc is

@@ -1,12 +1,12 @@
 """Per-workgroup timeline of single launches of the feature / position step plan (100 MHz stamps written by instrumented
 kernels: SlideOp.p[5] of SLIDE_OP_GEMM, p[12] of SLIDE_OP_GEMM_GX).
-  python tools/op_timeline.py --build                 (where hipcc is: build_tmp/libT.so, -DSLIDE_TIMELINE)
-  python tools/op_timeline.py feat 256 13 14 ...      (on the GPU box: op indices as tools/profile_ops.py prints them)
+  python tools/ab/op_timeline.py --build                 (where hipcc is: build_tmp/libT.so, -DSLIDE_TIMELINE)
+  python tools/ab/op_timeline.py feat 256 13 14 ...      (on the GPU box: op indices as tools/profile_ops.py prints them)
 stamps: 0 start | 7 tables staged (GX) | 1 ring primed / lane set-up done | 2 K loop done | 3 partial statistics published |
         4 barrier passed | 5 stores issued | 6 stores retired"""
 import ctypes, os, subprocess, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 LIBT = os.path.join(ROOT, "build_tmp", "libT.so")
 if "--build" in sys.argv:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box): tools/pmc_resident.sh  -- SQ counters of the LDS-resident kernel (20 steps, batch 256)
+# usage (on the GPU box): tools/ab/pmc_resident.sh  -- SQ counters of the LDS-resident kernel (20 steps, batch 256)
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_resident
 mkdir -p $OUT
@@ -10,7 +10,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ
            "SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_INST_LEVEL_SMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS"; do
   i=$((i+1))
   rm -rf $OUT/p$i
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -o p -- python tools/prof_resident.py > $OUT/p$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -o p -- python tools/ab/prof_resident.py > $OUT/p$i.log 2>&1
   python - <<PY
 import csv, glob
 agg = {}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box): tools/pmc_step.sh <tag>   -- SQ instruction counters of every kernel of one feature-denoiser step
+# usage (on the GPU box): tools/ab/pmc_step.sh <tag>   -- SQ instruction counters of every kernel of one feature-denoiser step
 TAG=$1
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmcstep_$TAG

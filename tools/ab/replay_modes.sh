@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box): tools/replay_modes.sh  -- ms/step of the replay modes (graphs / threaded eager) x feature sub-batches
+# usage (on the GPU box): tools/ab/replay_modes.sh  -- ms/step of the replay modes (graphs / threaded eager) x feature sub-batches
 cd $GRAFT_REPO_ROOT
 grep -m1 "model name" /proc/cpuinfo; nproc
 for rep in 1 2; do

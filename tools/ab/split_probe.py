@@ -1,7 +1,7 @@
 """split mode (fp32 storage, 3 x fp16 MFMA per product) against the exact-fp32 mode: forward error, per-op and chain timing"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from slide_amd import configs, model_spec
 from slide_amd.engine import DenoiserEngine

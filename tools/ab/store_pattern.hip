@@ -1,6 +1,6 @@
 // Store-pattern micro-benchmark (authoring tool, not part of the library):
 // every workgroup writes one 256-row x 128-channel fp16 tile of a [rows][ld] matrix, the way the GEMM epilogue does,
-// with different per-instruction footprints.  build: hipcc --offload-arch=gfx950 -O3 tools/store_pattern.hip -o /tmp/sp
+// with different per-instruction footprints.  build: hipcc --offload-arch=gfx950 -O3 tools/ab/store_pattern.hip -o /tmp/sp
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -2,7 +2,7 @@
 sub-batch counts (marginal cost of each chain)"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from slide_amd import configs, model_spec
 from slide_amd.diffusion import EagerChainsSampler, FeatureSampler, PositionSampler

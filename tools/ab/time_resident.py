@@ -1,7 +1,7 @@
 """ms per reverse step of the LDS-resident position sampler (one launch of n steps) vs the engine plan, batch 256"""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from slide_amd import configs, model_spec
 from slide_amd.diffusion import PositionSampler
 from slide_amd.experiments.resident import ResidentPositionSampler

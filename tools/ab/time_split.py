@@ -1,7 +1,7 @@
 """two half-batch joint samplers replayed concurrently (separate stream pairs) vs one full-batch joint sampler"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from slide_amd import configs, model_spec
 from slide_amd.diffusion import FeatureSampler, JointSampler, PositionSampler
