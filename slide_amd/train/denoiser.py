@@ -57,6 +57,28 @@ class TrainableDenoiser(nn.Module):
     def _has(self, name):
         return name in self._names
 
+    def reset_parameters(self, seed=0):
+        """PyTorch's default initialisation of the reference's layers (the reference trains from it, pointnet2/train.py:100-112):
+        Conv / Linear weights and biases U(-1/sqrt(fan_in), 1/sqrt(fan_in)), GroupNorm weight 1 / bias 0, Embedding N(0, 1)"""
+        g = torch.Generator().manual_seed(int(seed))
+        fan = {}
+        with torch.no_grad():
+            for name in self._names:
+                p = self._p(name)
+                if "group_norm" in name or name.startswith("fc_lyaer.1."):
+                    p.fill_(1.0 if name.endswith(".weight") else 0.0)
+                elif name == "class_emb.weight":
+                    p.copy_(torch.randn(p.shape, generator=g))
+                elif name.endswith(".weight"):
+                    fan[name[:-7]] = int(np.prod(p.shape[1:]))
+                    b = 1.0 / np.sqrt(fan[name[:-7]])
+                    p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * b)
+            for name in self._names:
+                if name.endswith(".bias") and name[:-5] in fan:
+                    p = self._p(name)
+                    p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) / np.sqrt(fan[name[:-5]]))
+        return self
+
     # ------------------------------------------------------------------ layers
     def _shared(self, x, prefix, B, S):
         """build_shared_mlp stage (pointnet2_modules.py:44-69): Conv(1x1, bias) -> MyGroupNorm -> ReLU"""

@@ -19,10 +19,10 @@ import torch.distributed as dist
 class GraphedTrainingStep:
     """step = GraphedTrainingStep(net, optimizer, loss_fn); loss = step()  (a device scalar, overwritten by the next replay).
     loss_fn() must read its batch from tensors that stay at the same address (copy_ each new batch into them) and must not
-    synchronise.  Drop every reference to the loss of an earlier EAGER step first (use .detach() / float()): a live autograd graph
+    synchronise.  post_step(): captured after the optimizer step (the EMA weight sets of trainer.py).  Drop every reference to the loss of an earlier EAGER step first (use .detach() / float()): a live autograd graph
     keeps its gradient-accumulation nodes, which stay bound to the stream they were created on and would pull it into the capture."""
 
-    def __init__(self, net, optimizer, loss_fn, warmup=3):
+    def __init__(self, net, optimizer, loss_fn, warmup=3, post_step=None):
         self.net, self.optimizer = net, optimizer
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         if not all(g.get("capturable", True) for g in optimizer.param_groups):
@@ -56,6 +56,8 @@ class GraphedTrainingStep:
                 loss_fn().backward()
                 self._reduce(side)
                 optimizer.step()
+                if post_step is not None:
+                    post_step()
         torch.cuda.current_stream().wait_stream(side)
         self.graph, self.graph_b = torch.cuda.CUDAGraph(), None
         if self.world == 1:
@@ -67,11 +69,15 @@ class GraphedTrainingStep:
             loss.backward()
             if self.world == 1:
                 optimizer.step()
+                if post_step is not None:
+                    post_step()
         if self.world > 1:
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b, pool=self.graph.pool(), stream=side):
                 self.bucket.div_(self.world)
                 optimizer.step()
+                if post_step is not None:
+                    post_step()
         self.loss = loss.detach()
 
     def _reduce(self, stream=None):

@@ -81,3 +81,36 @@ def test_single_process_is_a_no_op():
     g0 = net.a.grad.clone()
     broadcast_parameters(net)
     assert allreduce_gradients(net) is None and torch.equal(net.a.grad, g0)
+
+
+def test_trainer_host_pieces(tmp_path):
+    """EMA weight sets (pointnet2/data_utils/ema.py:20-26), newest-checkpoint search, the config's string-encoded EMA rates, the npz
+    epoch iterator's rank shares"""
+    import numpy as np
+    import torch
+    from slide_amd.train.trainer import EmaSet, find_max_ckpt, npz_batches, parse_ema_rate
+    assert parse_ema_rate("[0.999, 0.9999]") == [0.999, 0.9999] and parse_ema_rate(None) is None and parse_ema_rate([0.5]) == [0.5]
+    net = torch.nn.Linear(3, 2)
+    ema = EmaSet(net, [0.9, 0.5])
+    w0 = net.weight.detach().clone()
+    with torch.no_grad():
+        net.weight.add_(1.0)
+    ema.update()
+    sl = ema.state_list()
+    assert torch.allclose(sl[0]["weight"], 0.1 * (w0 + 1) + 0.9 * w0) and torch.allclose(sl[1]["weight"], 0.5 * (w0 + 1) + 0.5 * w0)
+    assert set(sl[0]) == {"weight", "bias"}
+    ema2 = EmaSet(net, [0.9, 0.5])
+    ema2.load_state_list(sl)
+    assert torch.equal(ema2.shadows[1][0], sl[1]["weight"])
+    assert find_max_ckpt(str(tmp_path)) == -1
+    for i in (3, 11, 7):
+        (tmp_path / ("pointnet_ckpt_%d.pkl" % i)).write_bytes(b"")
+    (tmp_path / "pointnet_ckpt_99.tmp").write_bytes(b"")
+    assert find_max_ckpt(str(tmp_path)) == 11
+    np.savez(tmp_path / "c.npz", points=np.arange(20 * 4 * 3, dtype=np.float32).reshape(20, 4, 3), label=np.arange(20))
+    seen = []
+    for rank in range(2):
+        ep = list(npz_batches(str(tmp_path / "c.npz"), 4, rank, 2, seed=5))
+        assert len(ep) == 2 and ep[0]["points"].shape == (4, 4, 3)
+        seen += [int(v) for b in ep for v in b["label"]]
+    assert len(set(seen)) == 16   # disjoint shares, full batches only
