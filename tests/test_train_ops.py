@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _rel(a, b):
-    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+    return float((a.detach() - b.detach()).abs().max() / b.detach().abs().max().clamp_min(1e-12))
 
 
 def _pad(x, ld):
