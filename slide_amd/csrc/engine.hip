@@ -255,6 +255,113 @@ __global__ __launch_bounds__(256, (PREC == SLIDE_PREC_SPLIT && NPXL == 4) ? 1 : 
                                                           reinterpret_cast<float *>(smem_raw));
 }
 
+// ------------------------------------------------------------------------------------------------ small split GEMM
+// Split-mode GEMM for SMALL launches (the 16-row per-point layers of the fp32-structured plan; the training step's layers at the
+// reference's batch 32): tile 64 rows x 64 channels, wave (rb, cb) owns ONE 32x32 block over the whole K.  The 256-row tile of
+// gemm_kernel leaves such a launch with a handful of workgroups (1408 rows x 512 channels: 48) whose cost is their own serial
+// latency -- here the grid is 4x larger and a workgroup's K loop moves a quarter of the X rows per chunk.  Stage = four fp16
+// planes [X hi | W hi | X lo | W lo] of 64 rows (20 KB), double-buffered; three workgroups per CU.  Same split arithmetic
+// (hi*hi into one accumulator, hi*lo + lo*hi scaled by 2^11 into a second) and the common epilogue at one block per wave.
+template <int NPXL>
+__global__ __launch_bounds__(256, 3) void gemm_split_small_kernel(GemmArgs a) {
+  constexpr int LDK = TileT<SLIDE_PREC_SPLIT>::LDK;
+  constexpr int TR = 64;                       // tile rows = tile channels
+  constexpr int PLANE = TR * LDK;              // halves per plane
+  constexpr int STAGE = 4 * PLANE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16 *const sbase = reinterpret_cast<_Float16 *>(smem_raw);
+  const int ntc = (a.n_cob + 1) / 2;
+  const int tc = blockIdx.x % ntc, tr = blockIdx.x / ntc;
+  const int row0 = tr * TR, cob0 = tc * 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int rb = wave >> 1, cb = wave & 1;
+  const float *X = reinterpret_cast<const float *>(a.X);
+  const float *W = reinterpret_cast<const float *>(a.W);
+  f32x16 acc, acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = acc2[r] = 0.f;
+  // loads: 8 threads per 32-float row, 32 rows per pass, two passes per operand tile
+  const int l_row = tid >> 3, l_c = (tid & 7) * 4;
+  constexpr int PD = 3;  // chunks in flight in registers: a lone workgroup's global-load latency hides behind three K steps
+  float4 xr[PD][2], wr[PD][2];
+  auto load_chunk = [&](int kc, float4 (&xr)[2], float4 (&wr)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int grow = row0 + p * 32 + l_row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (grow < a.rows) {
+        v = *reinterpret_cast<const float4 *>(X + (size_t)grow * a.x_ld + kc * BK + l_c);
+        if (a.in_scale) {  // consumer-side GroupNorm affine
+          const size_t o = (size_t)(grow >> NPXL) * a.in_bs + kc * BK + l_c;
+          const float4 sc = *reinterpret_cast<const float4 *>(a.in_scale + o);
+          const float4 sh = *reinterpret_cast<const float4 *>(a.in_shift + o);
+          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        }
+      }
+      xr[p] = v;
+      const int gco = cob0 * 32 + p * 32 + l_row;
+      wr[p] = gco < a.n_cob * 32 ? *reinterpret_cast<const float4 *>(W + (size_t)gco * a.k_pad + kc * BK + l_c)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto split4 = [](const float4 v, f16x4 &hi, f16x4 &lo) {
+    hi = f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    lo = f16x4{(_Float16)((v.x - (float)hi[0]) * 2048.f), (_Float16)((v.y - (float)hi[1]) * 2048.f),
+               (_Float16)((v.z - (float)hi[2]) * 2048.f), (_Float16)((v.w - (float)hi[3]) * 2048.f)};
+  };
+  auto store_chunk = [&](int s, const float4 (&xr)[2], const float4 (&wr)[2]) __attribute__((always_inline)) {
+    _Float16 *Xh = sbase + s * STAGE, *Wh = Xh + PLANE, *Xl = Wh + PLANE, *Wl = Xl + PLANE;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      f16x4 hi, lo;
+      split4(xr[p], hi, lo);
+      *reinterpret_cast<f16x4 *>(Xh + (p * 32 + l_row) * LDK + l_c) = hi;
+      *reinterpret_cast<f16x4 *>(Xl + (p * 32 + l_row) * LDK + l_c) = lo;
+      split4(wr[p], hi, lo);
+      *reinterpret_cast<f16x4 *>(Wh + (p * 32 + l_row) * LDK + l_c) = hi;
+      *reinterpret_cast<f16x4 *>(Wl + (p * 32 + l_row) * LDK + l_c) = lo;
+    }
+  };
+  uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + 2 * (size_t)STAGE * sizeof(_Float16));
+  float *const vec_lds = reinterpret_cast<float *>(epi_lds + 2 * EPI_DW + (2 * EPI_DW) % 4);
+  stage_epilogue_tables<2>(a, cob0, tid, epi_lds, vec_lds);
+  const int nk = a.k_pad / BK;
+  load_chunk(0, xr[0], wr[0]);
+  store_chunk(0, xr[0], wr[0]);
+#pragma unroll
+  for (int j = 0; j < PD; ++j)
+    if (j + 1 < nk) load_chunk(j + 1, xr[j], wr[j]);  // buffer j: chunks j + 1, j + 1 + PD, ...
+  __syncthreads();
+  for (int kc0 = 0; kc0 < nk; kc0 += PD) {
+#pragma unroll
+    for (int j = 0; j < PD; ++j) {
+      const int kc = kc0 + j;
+      if (kc >= nk) break;
+      const _Float16 *Xh = sbase + (kc & 1) * STAGE, *Wh = Xh + PLANE, *Xl = Wh + PLANE, *Wl = Xl + PLANE;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const f16x8 ah = *reinterpret_cast<const f16x8 *>(Wh + (cb * 32 + col) * LDK + st * 16 + half * 8);
+        const f16x8 al = *reinterpret_cast<const f16x8 *>(Wl + (cb * 32 + col) * LDK + st * 16 + half * 8);
+        const f16x8 bh = *reinterpret_cast<const f16x8 *>(Xh + (rb * 32 + col) * LDK + st * 16 + half * 8);
+        const f16x8 bl = *reinterpret_cast<const f16x8 *>(Xl + (rb * 32 + col) * LDK + st * 16 + half * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
+      }
+      // the other stage: its last readers passed the barrier of chunk kc - 1
+      if (kc + 1 < nk) store_chunk((kc + 1) & 1, xr[j], wr[j]);
+      __syncthreads();
+      if (kc + 1 + PD < nk) load_chunk(kc + 1 + PD, xr[j], wr[j]);
+    }
+  }
+  f32x16 one[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) one[0][0][r] = fmaf(acc2[r], 1.f / 2048.f, acc[r]);
+  gemm_epilogue<SLIDE_PREC_F32, NPXL, 1, 1>(a, one, row0 + rb * 32, cob0 + cb, 0, half, col, epi_lds + cb * EPI_DW, vec_lds + cb * 96,
+                                            nullptr);
+}
+
 // ------------------------------------------------------------------------------------------------ LDS-DMA GEMM
 // fp16 throughput variant of gemm_kernel (no consumer-side affine): the X / W chunks go HBM/L2 -> LDS directly with
 // `global_load_lds_dwordx4` (no VGPR staging), NST chunks deep, so many more bytes are in flight per CU than a
@@ -1814,6 +1921,14 @@ int launch_gemm(const GemmArgs &a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+int launch_gemm_split_small(const GemmArgs &a, hipStream_t s) {
+  constexpr int LDK = TileT<SLIDE_PREC_SPLIT>::LDK;
+  const size_t shm = (size_t)2 * 4 * 64 * LDK * 2 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32;
+  const int grid = ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2);
+  hipLaunchKernelGGL((gemm_split_small_kernel<4>), dim3(grid), dim3(256), shm, s, a);
+  return (int)hipGetLastError();
+}
+
 template <int NPXL, int CBW, int NST, int BKT, bool AFF, bool GAT = false, bool PAIRRES = false>
 int launch_gemm_glds(const GemmArgs &a, hipStream_t s) {
   constexpr int NSAMP = (1 << NPXL) >= TM ? 1 : TM >> NPXL;
@@ -2075,6 +2190,8 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
     return -4;
 #endif
   }
+  // split mode, 16-row samples (and RAW-epilogue launches that ask for them): 64-row tiles
+  if (prec == SLIDE_PREC_SPLIT && npxl == 4 && cbw == 2 && o.i[9] != 3) return launch_gemm_split_small(a, s);
 #define CASE(P, L, C) if (prec == P && npxl == L && cbw == C) return launch_gemm<P, L, C>(a, s)
   CASE(SLIDE_PREC_F32, 4, 2); CASE(SLIDE_PREC_F32, 7, 2); CASE(SLIDE_PREC_F32, 8, 2);
   CASE(SLIDE_PREC_SPLIT, 4, 2); CASE(SLIDE_PREC_SPLIT, 7, 2); CASE(SLIDE_PREC_SPLIT, 8, 2);
