@@ -85,7 +85,7 @@ def _gemm(x, w_packed, bias_vec, n_out_pad):
     epi = torch.add(c[0], c[1], alpha=out.data_ptr())
     # small launches (fewer than 256 of the 256-row tiles): the 64-row-tile kernel (the RAW epilogue does not look at samples, so the
     # "16 rows per sample" form that selects it is only a tile-shape request)
-    npx = 4 if ((rows + 255) // 256) * ((n_cob + 1) // 2) < 256 else 8
+    npx = 4 if ((rows + 255) // 256) * ((n_cob + 1) // 2) < 256 else 8  # (measured: 0 / 256 / 1024 / always -- 256 is best at batch 32 and 256)
     _run(make_op(OP_GEMM, i=(rows, kp, kp, n_cob, npx, 0, PREC_SPLIT, 2, 0, 0),
                  p=(x.data_ptr(), w_packed.data_ptr(), epi.data_ptr())))
     return out
