@@ -293,7 +293,11 @@ def main():
         a.replay = "graph"
     eager = a.replay != "graph"
     if a.workload == "default":
-        pos_mult = int(os.environ.get("SLIDE_POS_MULT", "1"))  # experiment: position chain over pos_mult x B, one step per pos_mult rounds
+        # position chain over pos_mult x B shapes, stepping once per pos_mult rounds of the feature chains (same shapes per unit time,
+        # fewer dependent launches): 1 for the fp16 plan (measured neutral), 2 when the position plan runs wide operands beside fp16
+        # feature chains (--pos-prec split: 272 -> 315 shapes/s)
+        wide_pos = a.pos_prec in ("split", "fp32") and a.prec == "fp16"
+        pos_mult = int(os.environ.get("SLIDE_POS_MULT", "2" if (wide_pos and eager and a.replay == "eager") else "1"))
         pos = PositionSampler(pc["pointnet_config"], sd_p, B * pos_mult, dev, pc["diffusion_config"], prec=a.pos_prec or a.prec, seed=1000 + rank * 16,
                               use_graph=not eager)
         # position plan: its own step graph on its own stream ("own", default: 1-1.5 % faster) or a parallel branch of the
@@ -450,6 +454,7 @@ def main():
            "config": {"workload": "BASELINE configs[1]+[2]: airplane position DDPM (16x3) + chair feature DDPM (16x51), "
                                   "batch %d per GPU; 1 step = one reverse step of each; shape = 1000+1000 steps" % B,
                       "batch_per_gpu": B, "sub_batches": sizes, "prec": a.prec, "replay": a.replay,
+                      "pos_batch_multiple": pos_mult if a.workload == "default" else 1,
                       "launches_per_step": sum(p_.n_launches for p_, _ in pos_chains) + sum(f_.n_launches for f_, _, _ in feat_chains),
                       # host seconds inside the launch calls of the timed region, per step: close to ms_per_step = the host
                       # (or a full hardware queue it is blocked on) paces the run, far below = the GPU does
