@@ -54,7 +54,7 @@ class GraphedTrainingStep:
             for _ in range(warmup):
                 zero()
                 loss_fn().backward()
-                self._reduce(side)
+                self._reduce(divide=True)
                 optimizer.step()
                 if post_step is not None:
                     post_step()
@@ -80,8 +80,9 @@ class GraphedTrainingStep:
                     post_step()
         self.loss = loss.detach()
 
-    def _reduce(self, stream=None):
-        """sum of the ranks' buckets (in place); the division by the world size is the first node of graph B"""
+    def _reduce(self, divide=False):
+        """sum of the ranks' buckets (in place).  divide: also divide by the world size (the eager warm-up steps; in the replayed
+        step the division is the first node of graph B)"""
         if self.world == 1:
             return
         if self.host_bucket is not None:
@@ -90,7 +91,7 @@ class GraphedTrainingStep:
             self.bucket.copy_(self.host_bucket)
         else:
             dist.all_reduce(self.bucket)
-        if stream is not None:  # eager warm-up steps: the division graph B would do
+        if divide:
             self.bucket.div_(self.world)
 
     def __call__(self):
