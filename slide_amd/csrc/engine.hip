@@ -58,6 +58,11 @@ __global__ __launch_bounds__(256, (PREC == SLIDE_PREC_SPLIT && NPXL == 4) ? 1 : 
   // split mode keeps ONE stage in LDS (51 KB: two workgroups per CU; the next chunk waits in registers, as in the other modes,
   // at the price of a second barrier per chunk)
   constexpr int NSTG = SPLIT ? 1 : 2;
+  // consumer-side affine of the fp32 / split modes on 128- / 256-row samples: the tile's one or two samples' scale / shift vectors
+  // are staged ONCE in LDS ([sample][scale | shift][k_pad] floats behind the epilogue tables) and applied when a chunk is written to
+  // its stage -- loading them per X row (two more global loads per 16 bytes of X) made these launches 2x slower than their plain twins
+  constexpr bool AFF_LDS = PREC != SLIDE_PREC_F16 && NPXL >= 7;
+  constexpr int AFF_NS = TM >> (NPXL >= 7 ? NPXL : 7);
 
   const int ntc = (a.n_cob + CBW - 1) / CBW;
   const int ntr = (a.rows + TM - 1) / TM;
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(256, (PREC == SLIDE_PREC_SPLIT && NPXL == 4) ? 1 : 
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (grow < a.rows) {
         v = *reinterpret_cast<const float4 *>(X + (size_t)grow * a.x_ld + kc * BK + l_c);
-        if (a.in_scale) {  // consumer-side GroupNorm affine (only the attention weight_conv.2 GEMMs)
+        if (a.in_scale && !AFF_LDS) {  // consumer-side GroupNorm affine (only the attention weight_conv.2 GEMMs)
           const size_t o = (size_t)(grow >> NPXL) * a.in_bs + kc * BK + l_c;
           if (PREC != SLIDE_PREC_F16) {
             const float4 sc = *reinterpret_cast<const float4 *>(a.in_scale + o);
@@ -124,9 +129,24 @@ __global__ __launch_bounds__(256, (PREC == SLIDE_PREC_SPLIT && NPXL == 4) ? 1 : 
     lo = f16x4{(_Float16)((v.x - (float)hi[0]) * 2048.f), (_Float16)((v.y - (float)hi[1]) * 2048.f),
                (_Float16)((v.z - (float)hi[2]) * 2048.f), (_Float16)((v.w - (float)hi[3]) * 2048.f)};
   };
-  auto store_chunk = [&](int s) {
+  const float *aff_lds = nullptr;  // set below (behind the epilogue tables)
+  auto store_chunk = [&](int s, int kc) {
     TS *Xs = sbase + s * STAGE;
     TS *Ws = Xs + TM * LDK;
+    if constexpr (AFF_LDS) {
+      if (a.in_scale) {
+#pragma unroll
+        for (int p = 0; p < XP; ++p) {
+          const int trow = p * RPP + l_row;
+          if (row0 + trow < a.rows) {
+            const float *ap = aff_lds + (size_t)((trow >> NPXL) * 2) * a.k_pad + kc * BK + l_c;
+            const float4 sc = *reinterpret_cast<const float4 *>(ap), sh = *reinterpret_cast<const float4 *>(ap + a.k_pad);
+            float4 &v = xr[p];
+            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+          }
+        }
+      }
+    }
     if constexpr (SPLIT) {
       _Float16 *Xl = Xs + (TM + TN) * LDK, *Wl = Xl + TM * LDK;
 #pragma unroll
@@ -223,6 +243,21 @@ __global__ __launch_bounds__(256, (PREC == SLIDE_PREC_SPLIT && NPXL == 4) ? 1 : 
   uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + NSTG * (size_t)STAGE * sizeof(TS));
   float *const vec_lds = reinterpret_cast<float *>(epi_lds + CBW * EPI_DW + (CBW * EPI_DW) % 4);
   stage_epilogue_tables<CBW>(a, cob0, tid, epi_lds, vec_lds);
+  if constexpr (AFF_LDS) {
+    if (a.in_scale) {
+      float *al = vec_lds + CBW * 96;
+      const int nb = a.rows >> NPXL;
+      for (int i = tid * 4; i < AFF_NS * a.k_pad; i += 1024) {
+        const int sm = i / a.k_pad, k = i - sm * a.k_pad;
+        int b = (row0 >> NPXL) + sm;
+        b = b < nb ? b : nb - 1;
+        *reinterpret_cast<float4 *>(al + (size_t)(sm * 2 + 0) * a.k_pad + k) = *reinterpret_cast<const float4 *>(a.in_scale + (size_t)b * a.in_bs + k);
+        *reinterpret_cast<float4 *>(al + (size_t)(sm * 2 + 1) * a.k_pad + k) = *reinterpret_cast<const float4 *>(a.in_shift + (size_t)b * a.in_bs + k);
+      }
+      aff_lds = al;
+      __syncthreads();
+    }
+  }
 
   const int nk = a.k_pad / BK;
 #ifdef SLIDE_STAGGER
@@ -232,13 +267,13 @@ __global__ __launch_bounds__(256, (PREC == SLIDE_PREC_SPLIT && NPXL == 4) ? 1 : 
 #define KIDX(k) (k)
 #endif
   load_chunk(KIDX(0));
-  store_chunk(0);
+  store_chunk(0, KIDX(0));
   __syncthreads();
   for (int kc = 0; kc < nk; ++kc) {
     if (kc + 1 < nk) load_chunk(KIDX(kc + 1));
     compute(kc & (NSTG - 1));
     if (NSTG == 1) __syncthreads();  // every wave is done reading the stage before it is overwritten
-    if (kc + 1 < nk) store_chunk((kc + 1) & (NSTG - 1));
+    if (kc + 1 < nk) store_chunk((kc + 1) & (NSTG - 1), KIDX(kc + 1));
     __syncthreads();
   }
 #undef KIDX
@@ -292,12 +327,6 @@ __global__ __launch_bounds__(256, 3) void gemm_split_small_kernel(GemmArgs a) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (grow < a.rows) {
         v = *reinterpret_cast<const float4 *>(X + (size_t)grow * a.x_ld + kc * BK + l_c);
-        if (a.in_scale) {  // consumer-side GroupNorm affine
-          const size_t o = (size_t)(grow >> NPXL) * a.in_bs + kc * BK + l_c;
-          const float4 sc = *reinterpret_cast<const float4 *>(a.in_scale + o);
-          const float4 sh = *reinterpret_cast<const float4 *>(a.in_shift + o);
-          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-        }
       }
       xr[p] = v;
       const int gco = cob0 * 32 + p * 32 + l_row;
@@ -310,12 +339,19 @@ __global__ __launch_bounds__(256, 3) void gemm_split_small_kernel(GemmArgs a) {
     lo = f16x4{(_Float16)((v.x - (float)hi[0]) * 2048.f), (_Float16)((v.y - (float)hi[1]) * 2048.f),
                (_Float16)((v.z - (float)hi[2]) * 2048.f), (_Float16)((v.w - (float)hi[3]) * 2048.f)};
   };
-  auto store_chunk = [&](int s, const float4 (&xr)[2], const float4 (&wr)[2]) __attribute__((always_inline)) {
+  const float *aff_lds = nullptr;  // consumer-side affine: the tile's samples' [scale | shift][k_pad], staged once (set below)
+  auto store_chunk = [&](int s, int kc, const float4 (&xr)[2], const float4 (&wr)[2]) __attribute__((always_inline)) {
     _Float16 *Xh = sbase + s * STAGE, *Wh = Xh + PLANE, *Xl = Wh + PLANE, *Wl = Xl + PLANE;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       f16x4 hi, lo;
-      split4(xr[p], hi, lo);
+      float4 v = xr[p];
+      if (aff_lds && row0 + p * 32 + l_row < a.rows) {
+        const float *ap = aff_lds + (size_t)(((p * 32 + l_row) >> NPXL) * 2) * a.k_pad + kc * BK + l_c;
+        const float4 sc = *reinterpret_cast<const float4 *>(ap), sh = *reinterpret_cast<const float4 *>(ap + a.k_pad);
+        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+      }
+      split4(v, hi, lo);
       *reinterpret_cast<f16x4 *>(Xh + (p * 32 + l_row) * LDK + l_c) = hi;
       *reinterpret_cast<f16x4 *>(Xl + (p * 32 + l_row) * LDK + l_c) = lo;
       split4(wr[p], hi, lo);
@@ -326,9 +362,22 @@ __global__ __launch_bounds__(256, 3) void gemm_split_small_kernel(GemmArgs a) {
   uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + 2 * (size_t)STAGE * sizeof(_Float16));
   float *const vec_lds = reinterpret_cast<float *>(epi_lds + 2 * EPI_DW + (2 * EPI_DW) % 4);
   stage_epilogue_tables<2>(a, cob0, tid, epi_lds, vec_lds);
+  if (a.in_scale) {
+    float *al = vec_lds + 2 * 96;
+    const int nb = a.rows >> NPXL;
+    for (int i = tid * 4; i < (TR >> NPXL) * a.k_pad; i += 1024) {
+      const int sm = i / a.k_pad, k = i - sm * a.k_pad;
+      int b = (row0 >> NPXL) + sm;
+      b = b < nb ? b : nb - 1;
+      *reinterpret_cast<float4 *>(al + (size_t)(sm * 2 + 0) * a.k_pad + k) = *reinterpret_cast<const float4 *>(a.in_scale + (size_t)b * a.in_bs + k);
+      *reinterpret_cast<float4 *>(al + (size_t)(sm * 2 + 1) * a.k_pad + k) = *reinterpret_cast<const float4 *>(a.in_shift + (size_t)b * a.in_bs + k);
+    }
+    aff_lds = al;
+    __syncthreads();
+  }
   const int nk = a.k_pad / BK;
   load_chunk(0, xr[0], wr[0]);
-  store_chunk(0, xr[0], wr[0]);
+  store_chunk(0, 0, xr[0], wr[0]);
 #pragma unroll
   for (int j = 0; j < PD; ++j)
     if (j + 1 < nk) load_chunk(j + 1, xr[j], wr[j]);  // buffer j: chunks j + 1, j + 1 + PD, ...
@@ -350,7 +399,7 @@ __global__ __launch_bounds__(256, 3) void gemm_split_small_kernel(GemmArgs a) {
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
       }
       // the other stage: its last readers passed the barrier of chunk kc - 1
-      if (kc + 1 < nk) store_chunk((kc + 1) & 1, xr[j], wr[j]);
+      if (kc + 1 < nk) store_chunk((kc + 1) & 1, kc + 1, xr[j], wr[j]);
       __syncthreads();
       if (kc + 1 + PD < nk) load_chunk(kc + 1 + PD, xr[j], wr[j]);
     }
@@ -1906,15 +1955,17 @@ template <int PREC, int NPXL, int CBW>
 int launch_gemm(const GemmArgs &a, hipStream_t s) {
   constexpr int LDK = TileT<PREC>::LDK;
   // (split mode: two fp16 planes per operand tile)
+  const size_t aff = (PREC != SLIDE_PREC_F16 && NPXL >= 7 && a.in_scale) ? (size_t)(TM >> NPXL) * 2 * a.k_pad * 4 : 0;
   const size_t shm = (PREC == SLIDE_PREC_SPLIT ? (size_t)(TM + 32 * CBW) * LDK * 4 : 2 * (size_t)(TM + 32 * CBW) * LDK * sizeof(typename TileT<PREC>::T)) +
-                     CBW * (sizeof(SlideEpi) + 96 * 4) + 16;
+                     CBW * (sizeof(SlideEpi) + 96 * 4) + 16 + aff;
+  if (shm > 160 * 1024) return -8;
   const int ntc = (a.n_cob + CBW - 1) / CBW, ntr = (a.rows + TM - 1) / TM;
   const int grid = ((ntr + 7) / 8) * 8 * ntc;
   static bool attr_done[SLIDE_MAX_DEVICES] = {};
   bool &attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<PREC, NPXL, CBW>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   hipLaunchKernelGGL((gemm_kernel<PREC, NPXL, CBW>), dim3(grid), dim3(256), shm, s, a);
@@ -1923,7 +1974,8 @@ int launch_gemm(const GemmArgs &a, hipStream_t s) {
 
 int launch_gemm_split_small(const GemmArgs &a, hipStream_t s) {
   constexpr int LDK = TileT<SLIDE_PREC_SPLIT>::LDK;
-  const size_t shm = (size_t)2 * 4 * 64 * LDK * 2 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32;
+  const size_t shm = (size_t)2 * 4 * 64 * LDK * 2 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32 + (a.in_scale ? (size_t)4 * 2 * a.k_pad * 4 : 0);
+  if (shm > 64 * 1024) return -8;
   const int grid = ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2);
   hipLaunchKernelGGL((gemm_split_small_kernel<4>), dim3(grid), dim3(256), shm, s, a);
   return (int)hipGetLastError();
