@@ -143,24 +143,27 @@ def decode_leg(dev, B):
 
 def parity_leg(dev, B, a, pc, fc, sd_p, sd_f, gen):
     """`parity` object of the JSON line: ONLY numbers measured in this run, on this GPU.
-    forward: relative L2 of one fp16-mode denoiser forward against the exact-fp32 mode of the same plan (which tests/ pin to the
-      reference goldens at <= 2e-4), batch 32, timesteps spread over the schedule, for two input families: x ~ N(0, 1) (the
-      start of a chain) and x = key-point-like coordinates (|x| rms 0.37: the end of a position chain).  The fp16 error of the
-      position net grows as the coordinates shrink.
-    chain: complete 1000-step chains of 64 shapes in fp16 against the fp32 mode with equal in-kernel noise: per-shape relative
-      max distance (median / max) -- north_star's criterion on generated latents.
-    fp32_mode_shapes_per_s / split_mode_shapes_per_s: throughput of the two fp32-grade modes (--prec fp32 / split)."""
+    forward_rel_l2_vs_fp32_mode: relative L2 of one denoiser forward IN THE BENCHED ARITHMETIC (position plan: --pos-prec,
+      feature plan: --prec) against the exact-fp32 mode of the same plan (which tests/ pin to the reference goldens at <= 2e-4),
+      batch 32, timesteps spread over the schedule, for two input families: x ~ N(0, 1) (the start of a chain) and x =
+      key-point-like coordinates (|x| rms 0.37: the end of a position chain).  north_star's bar is 1e-3.
+    forward_rel_l2_fp16_position_plan_vs_fp32_mode: the same for the fp16 POSITION plan when it is not the benched one -- why it is
+      not (its error grows as the coordinates shrink).
+    chain: complete 1000-step chains of 64 shapes in the benched arithmetic against the fp32 mode with equal in-kernel noise:
+      per-shape relative max distance (median / max) -- north_star's criterion on generated latents.
+    fp32_mode_shapes_per_s / split_mode_shapes_per_s: throughput of the two whole-path fp32-grade modes (--prec fp32 / split)."""
     import torch
     from slide_amd.diffusion import FeatureSampler, JointSampler, PositionSampler
     from slide_amd.engine import DenoiserEngine
     from slide_amd.synth import synth_keypoints
     rs = np.random.RandomState(123)
-    par = {"forward_rel_l2_fp16_vs_fp32_mode": {}, "chain_1000_steps_fp16_vs_fp32_mode": {}}
+    par = {"forward_rel_l2_vs_fp32_mode": {"pos_prec": a.pos_prec, "feat_prec": a.prec}, "chain_1000_steps_vs_fp32_mode": {}}
     nb = 32
-    for nm, cfg_, sd_ in (("pos", pc, sd_p), ("feat", fc, sd_f)):
+    for nm, cfg_, sd_, mode in (("pos", pc, sd_p, a.pos_prec), ("feat", fc, sd_f, a.prec)):
         hp_ = cfg_["pointnet_config"]
         e32 = DenoiserEngine(hp_, sd_, nb, dev, prec="fp32")
-        e16 = DenoiserEngine(hp_, sd_, nb, dev, prec="fp16")
+        eb = DenoiserEngine(hp_, sd_, nb, dev, prec=mode)
+        e16 = DenoiserEngine(hp_, sd_, nb, dev, prec="fp16") if (nm == "pos" and mode != "fp16") else None
         tsb, lb = np.linspace(0, 999, nb).astype(np.float32), np.full(nb, 4 if nm == "feat" else 0, np.int64)
         for fam in ("normal", "keypoints"):
             xb = rs.standard_normal((nb, 16, 3 + hp_["in_fea_dim"])).astype(np.float32)
@@ -169,24 +172,30 @@ def parity_leg(dev, B, a, pc, fc, sd_p, sd_f, gen):
             if nm == "feat" and fam == "keypoints":
                 continue  # (the feature net's coordinates are key points in both families)
             y32 = e32.forward(xb, tsb, lb).double()
-            y16 = e16.forward(xb, tsb, lb).double()
-            par["forward_rel_l2_fp16_vs_fp32_mode"]["%s_%s" % (nm, fam)] = round(float(((y16 - y32).norm() / y32.norm()).item()), 6)
-        del e32, e16
+            yb = eb.forward(xb, tsb, lb).double()
+            par["forward_rel_l2_vs_fp32_mode"]["%s_%s" % (nm, fam)] = round(float(((yb - y32).norm() / y32.norm()).item()), 7)
+            if e16 is not None:
+                y16 = e16.forward(xb, tsb, lb).double()
+                par.setdefault("forward_rel_l2_fp16_position_plan_vs_fp32_mode", {})["%s_%s" % (nm, fam)] = round(
+                    float(((y16 - y32).norm() / y32.norm()).item()), 6)
+        del e32, eb, e16
     nc = 64
     if a.prec == "fp16" and a.fp32_steps > 0:
         res = {}
-        for prec in ("fp16", "fp32"):
-            ps = PositionSampler(pc["pointnet_config"], sd_p, nc, dev, pc["diffusion_config"], prec=prec, seed=77, use_graph=True)
+        for prec in ("bench", "fp32"):
+            ps = PositionSampler(pc["pointnet_config"], sd_p, nc, dev, pc["diffusion_config"], prec=a.pos_prec if prec == "bench" else prec,
+                                 seed=77, use_graph=True)
             xT = np.random.RandomState(4).standard_normal((nc, 16, 3)).astype(np.float32)
             res["pos", prec] = ps.sample(np.zeros(nc, np.int64), xT).cpu().numpy()
-            fs = FeatureSampler(fc["pointnet_config"], sd_f, nc, dev, fc["standard_diffusion_config"], prec=prec, seed=78, use_graph=True)
+            fs = FeatureSampler(fc["pointnet_config"], sd_f, nc, dev, fc["standard_diffusion_config"], prec=a.prec if prec == "bench" else prec,
+                                seed=78, use_graph=True)
             xT = np.random.RandomState(5).standard_normal((nc, 16, 51)).astype(np.float32)
             res["feat", prec] = fs.sample(np.full(nc, 4, np.int64), synth_keypoints(nc), xT).cpu().numpy()
             del ps, fs
         for nm in ("pos", "feat"):
-            x16, x32 = res[nm, "fp16"].reshape(nc, -1), res[nm, "fp32"].reshape(nc, -1)
+            x16, x32 = res[nm, "bench"].reshape(nc, -1), res[nm, "fp32"].reshape(nc, -1)
             per = np.abs(x16 - x32).max(axis=1) / np.abs(x32).max()
-            par["chain_1000_steps_fp16_vs_fp32_mode"][nm] = {"shapes": nc, "per_shape_rel_max_median": round(float(np.median(per)), 6),
+            par["chain_1000_steps_vs_fp32_mode"][nm] = {"prec": a.pos_prec if nm == "pos" else a.prec, "shapes": nc, "per_shape_rel_max_median": round(float(np.median(per)), 6),
                                                              "per_shape_rel_max_max": round(float(per.max()), 6)}
         # throughput of the two fp32-grade modes: "fp32" (fp32 MFMA) and "split" (the same plan, contractions as two-term fp16
         # operand splits on the fp16 matrix pipe; <= 4e-6 of the fp32 mode on a forward)
@@ -219,7 +228,9 @@ def main():
     ap.add_argument("--prec", default="fp16", choices=["fp16", "fp32", "split"],
                     help="MFMA operand type (fp32 accumulate): fp16 = throughput mode; fp32 = exact parity mode (fp32 MFMA); split = fp32 "
                          "storage with the contractions as two-term fp16 operand splits on the fp16 matrix pipe (fp32-grade results)")
-    ap.add_argument("--pos-prec", default=None, choices=["fp16", "fp32", "split"], help="operand type of the POSITION plan (default: --prec)")
+    ap.add_argument("--pos-prec", default=None, choices=["fp16", "fp32", "split"],
+                    help="arithmetic of the POSITION plan.  Default: split beside --prec fp16 (the fp16 position plan misses north_star's "
+                         "1e-3 on single forwards, DESIGN.md section 5; every forward of the default arrangement meets it), else --prec")
     ap.add_argument("--sub-batches", type=int, default=3,
                     help="independent sub-batches of the per-GPU batch replayed concurrently (scheduling only)")
     ap.add_argument("--replay", default=os.environ.get("SLIDE_REPLAY", "eager"), choices=["eager", "threads", "graph"],
@@ -235,6 +246,8 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the live fp16-vs-fp32 forward error and the fp32-mode timing")
     ap.add_argument("--fp32-steps", type=int, default=10, help="reverse steps of the exact-fp32 mode timed for parity.fp32_mode_shapes_per_s")
     a = ap.parse_args()
+    if a.pos_prec is None:
+        a.pos_prec = "split" if a.prec == "fp16" else a.prec
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not under a launcher: spawn the ranks ourselves and pass their exit status on
         import subprocess
@@ -298,7 +311,7 @@ def main():
         # feature chains (--pos-prec split: 272 -> 315 shapes/s)
         wide_pos = a.pos_prec in ("split", "fp32") and a.prec == "fp16"
         pos_mult = int(os.environ.get("SLIDE_POS_MULT", "2" if (wide_pos and eager and a.replay == "eager") else "1"))
-        pos = PositionSampler(pc["pointnet_config"], sd_p, B * pos_mult, dev, pc["diffusion_config"], prec=a.pos_prec or a.prec, seed=1000 + rank * 16,
+        pos = PositionSampler(pc["pointnet_config"], sd_p, B * pos_mult, dev, pc["diffusion_config"], prec=a.pos_prec, seed=1000 + rank * 16,
                               use_graph=not eager)
         # position plan: its own step graph on its own stream ("own", default: 1-1.5 % faster) or a parallel branch of the
         # first feature sub-batch's graph ("branch")
@@ -329,7 +342,7 @@ def main():
         spec_p, spec_f = model_spec.denoiser_param_spec(pc["pointnet_config"]), model_spec.denoiser_param_spec(fc["pointnet_config"])
         cc = CategoryChains(B * world, rank, world, pc, fc,
                             lambda c: (synth_state_dict(spec_p, seed=100 + c), synth_state_dict(spec_f, seed=200 + c)), dev,
-                            prec=a.prec, seed=rank + 1)
+                            prec="mixed" if (a.prec == "fp16" and a.pos_prec == "split") else a.prec, seed=rank + 1)
         cat_desc = [(c, hi - lo) for c, lo, hi, _, _ in cc.chains]
         pos_chains = [(ps, torch.full((hi - lo,), c, dtype=torch.int64, device=dev)) for c, lo, hi, ps, _ in cc.chains]
         feat_chains = [(fs, torch.full((hi - lo,), c, dtype=torch.int64, device=dev),
@@ -387,13 +400,10 @@ def main():
         if use_dist:
             dist.barrier() if share else dist.barrier(device_ids=[local])
 
-    # Device priming, part of set-up (untimed, in front of the W warm-up steps the command line asks for): a fresh process starts on
-    # a cold GPU and the first tens of milliseconds of chain replay run slower than steady state -- 20 timed steps after W = 5 / 10 /
-    # 20 / 30 / 50 warm-up steps take 13.3 / 13.25 / 12.9 / 12.7 / 12.6 ms, every chain alike (clock ramp; tools/r4 notes in DESIGN.md
-    # section 9).  A generation is 1000 steps, so the warmed-up rate is what a user sees: 64 priming steps (40 ms) are replayed with
-    # the warm-up steps whatever --warmup says: --steps 20 --warmup 5 then measures 0.638-0.645 ms per step instead of 0.663 (five
-    # alternating pairs), the --steps 300 rate being 0.62.  SLIDE_BENCH_PRIME=0 switches it off; `config.prime_steps` records it.
-    prime = int(os.environ.get("SLIDE_BENCH_PRIME", "64"))
+    # Device priming (round 4, now OPT-IN: SLIDE_BENCH_PRIME=<steps>): a fresh process starts on a cold GPU and the first tens of
+    # milliseconds of chain replay run ~5 % slower than steady state.  Round 5 (VERDICT r4 item 8 / ADVICE):
+    # the bench does exactly the W warm-up steps the command line asks for; `config.prime_steps` records any opt-in priming.
+    prime = int(os.environ.get("SLIDE_BENCH_PRIME", "0"))  # (round 5: opt-in -- the driver's --warmup is the warm-up)
     run(max(a.warmup, 1) + max(prime, 0))  # (one replay call: priming steps, then the W warm-up steps)
     gdev = torch.device("cpu") if share else dev
     gathered = [torch.empty(B, 16, 51, device=gdev) for _ in range(world)] if use_dist else None
@@ -449,11 +459,13 @@ def main():
            "unit": "shapes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": {"fp16": "f16 (MFMA operands + activation storage; f32 accumulate, norm statistics, softmax)", "fp32": "f32",
-                     "split": "f32 storage, contractions as two-term f16 operand splits (3 x f16 MFMA per product, f32 accumulate)"}[a.prec],
+                     "split": "f32 storage, contractions as two-term f16 operand splits (3 x f16 MFMA per product, f32 accumulate)"}[a.prec]
+                    + ("" if a.pos_prec == a.prec else "; position DDPM: " + {"fp16": "f16", "fp32": "f32", "split": "two-term f16 operand splits "
+                       "(fp32-grade)"}[a.pos_prec]),
            "data": "synthetic",
            "config": {"workload": "BASELINE configs[1]+[2]: airplane position DDPM (16x3) + chair feature DDPM (16x51), "
                                   "batch %d per GPU; 1 step = one reverse step of each; shape = 1000+1000 steps" % B,
-                      "batch_per_gpu": B, "sub_batches": sizes, "prec": a.prec, "replay": a.replay,
+                      "batch_per_gpu": B, "sub_batches": sizes, "prec": a.prec, "pos_prec": a.pos_prec, "replay": a.replay,
                       "pos_batch_multiple": pos_mult if a.workload == "default" else 1,
                       "launches_per_step": sum(p_.n_launches for p_, _ in pos_chains) + sum(f_.n_launches for f_, _, _ in feat_chains),
                       # host seconds inside the launch calls of the timed region, per step: close to ms_per_step = the host

@@ -74,7 +74,7 @@ SLIDE_API int slide_knn_gather(int b, int n2, int u, int n1, int K, const float 
                      float *out, slide_stream_t stream);
 
 /* pytorch3d.ops.sample_farthest_points (call site pointnet2/models/point_upsample_decoder.py:178-180): plain iterative
- * FPS without the near-origin skip; start_idx (b) int32 or NULL (= 0); temp (b,n) pre-filled 1e10; idx (b,K) int32;
+ * FPS without the near-origin skip; start_idx (b) int32 in [0, n) (clamped to it) or NULL (= 0); temp (b,n) pre-filled 1e10; idx (b,K) int32;
  * ties -> lowest index. */
 SLIDE_API int slide_sample_farthest_points(int b, int n, int K, const float *points, const int *start_idx, float *temp,
                                            int *idx, slide_stream_t stream);

@@ -25,8 +25,10 @@ def main():
     ap.add_argument("--data_clamp_range", type=float, default=1)
     ap.add_argument("--model_var_type", type=str, default="fixedsmall")
     ap.add_argument("--random_init", action="store_true")
-    ap.add_argument("--prec", default="fp16", choices=["fp32", "fp16", "split"],
-                    help="MFMA operand type (fp32 accumulate); fp32 = the exact parity mode")
+    ap.add_argument("--prec", default="mixed", choices=["mixed", "fp32", "fp16", "split"],
+                    help="arithmetic: mixed (default) = position DDPM in two-term fp16 operand splits (fp32-grade), feature DDPM in fp16 "
+                         "operands / fp32 accumulation -- every forward within 1e-3 of fp32; fp32 = the exact parity mode (fp32 MFMA); "
+                         "split = both DDPMs fp32-grade; fp16 = both in fp16 operands (position forwards up to 3e-3 off)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--chains", type=int, default=3,
                     help="batches kept in flight: the position chain is launch-latency bound, so independent batches run as "
@@ -62,7 +64,9 @@ def main():
     C = max(1, min(a.chains, len(my)))
     # chain c serves batches c, c + C, ...  Start noise and in-kernel noise of a shape are functions of (seed, its GLOBAL index)
     # only: the output does not depend on the number of ranks, the batch size or the chains in flight
-    smps = [PositionSampler(hp, sd, B, dev, cfg["diffusion_config"], prec=a.prec, seed=a.seed, use_graph=False) for c in range(C)]
+    from slide_amd.generation import resolve_prec
+    smps = [PositionSampler(hp, sd, B, dev, cfg["diffusion_config"], prec=resolve_prec(a.prec)[0], seed=a.seed, use_graph=False)
+            for c in range(C)]
     outs, timing = {}, []
     torch.cuda.synchronize(dev)
     t_all = time.time()

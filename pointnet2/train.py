@@ -39,7 +39,7 @@ def main():
     torch.manual_seed(a.seed + rank)
     B, K = int(dc["batch_size"]), int(dc["num_keypoints"])
     batches = npz_batches(a.dataset_npz, B, rank, world, seed=a.seed)
-    per_epoch = max(1, sum(1 for _ in batches))
+    per_epoch = max(1, len(batches))
     out_dir = os.path.join(a.root_directory or tc["root_directory"], hp.get("model_name", "pointnet"), tc["output_directory"])
     net = TrainableDenoiser(hp).reset_parameters(a.seed).to(dev)
     static = {"keypoint": torch.zeros(B, K, 3, device=dev), "label": torch.zeros(B, dtype=torch.int64, device=dev)}

@@ -216,7 +216,9 @@ def sample_farthest_points(points, lengths=None, K=50, random_start_point=False,
         start_idx = torch.randint(0, N, (B,), device=points.device)
     sp = None
     if start_idx is not None:
-        start_idx = start_idx.to(device=points.device, dtype=torch.int32).contiguous()
+        # any non-negative integer is a valid start: it is taken modulo N (callers hand one per-shape draw to every level of a
+        # decoder, whose candidate counts differ -- ADVICE r4); no device sync, never out of bounds
+        start_idx = torch.remainder(start_idx.to(device=points.device, dtype=torch.int64), N).to(torch.int32).contiguous()
         sp = ptr(start_idx)
     idx = torch.zeros((B, K), device=points.device, dtype=torch.int32)
     tmp = torch.full((B, N), 1e10, device=points.device, dtype=torch.float32)

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(NT) void fps_kernel(int n, int m, int bs, int lg, i
     }
   }
   const float *src = use_lds ? spts : dataset;
-  int old = start ? start[b] : 0;
+  int old = start ? min(max(start[b], 0), n - 1) : 0;  // (clamped: a start index outside [0, n) must not read out of bounds)
   if (tid == 0) idxs[0] = old;
   __syncthreads();
   for (int j = 1; j < m; ++j) {
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(1024) void fps_kernel_large(int n, int m, int bs, i
   dataset += (size_t)b * n * 3;
   temp += (size_t)b * n;
   idxs += (size_t)b * m;
-  int old = start ? start[b] : 0;
+  int old = start ? min(max(start[b], 0), n - 1) : 0;  // (clamped: a start index outside [0, n) must not read out of bounds)
   if (tid == 0) idxs[0] = old;
   for (int j = 1; j < m; ++j) {
     const float x1 = dataset[old * 3 + 0], y1 = dataset[old * 3 + 1], z1 = dataset[old * 3 + 2];

@@ -49,8 +49,9 @@ def start_noise(seed, tag, lo, hi, tail, device):
 
 
 def fps_start_indices(seed, lo, hi, n, device):
-    """first index of the decode's plain-FPS calls for shapes [lo, hi) of a run: uniform in [0, n), a function of (seed, GLOBAL shape
-    index) only (blocks of 1024 shapes, like start_noise) -- the reference draws it from the device generator
+    """per-shape draw for the first index of the decode's plain-FPS calls for shapes [lo, hi) of a run: uniform in [0, n) -- the decode
+    passes n = 2^30 and every upsampling level reduces the draw modulo ITS candidate count (sample_farthest_points; uniform to 2^-20) --
+    a function of (seed, GLOBAL shape index) only (blocks of 1024 shapes, like start_noise) -- the reference draws it from the device generator
     (point_upsample_decoder.py:178-180, random_start_point=True), which makes a decoded cloud depend on the rank / batch split"""
     out = []
     g = torch.Generator(device=device)
@@ -75,7 +76,7 @@ def decode_shard(ae, keypoint, feature, labels, batch_size, device, seed=0, glob
         k_ = kp[lo:hi].to(device).contiguous()
         lab = torch.as_tensor(labels[lo:hi]).to(device=device, dtype=torch.int64)
         f_ = encode(lo, hi, k_, lab) if encode is not None else torch.as_tensor(feature[lo:hi], dtype=torch.float32).to(device)
-        start = fps_start_indices(seed, global_offset + lo, global_offset + hi, 512, device)
+        start = fps_start_indices(seed, global_offset + lo, global_offset + hi, 1 << 30, device)  # reduced modulo N per level
         clouds.append(ae.decode(k_, f_.contiguous(), ts=None, label=lab, fps_start_idx=start))
         feats.append(f_)
     out = torch.cat(clouds) if clouds else torch.empty(0, 2048, 6, device=device)
@@ -188,6 +189,13 @@ def generate_categories(total, run_segment, rank=0, world_size=1, categories=FIV
     return full, labels
 
 
+def resolve_prec(prec):
+    """(position plan arithmetic, feature plan arithmetic) of a `--prec` value.  "mixed" (the default of the generation CLIs and what
+    bench.py times since round 5): the position DDPM in the split arithmetic (fp32-grade: its fp16 plan misses north_star's 1e-3 on
+    single forwards), the feature DDPM in fp16 operands / fp32 accumulation (<= 1e-3)."""
+    return ("split", "fp16") if prec == "mixed" else (prec, prec)
+
+
 class CategoryChains:
     """The HIP samplers of one rank for a multi-category run (BASELINE configs[3]): for every segment of the rank's shard a
     position sampler and a feature sampler built from THAT category's weights; the feature chain of a segment is
@@ -211,9 +219,9 @@ class CategoryChains:
 
     def _make_chain(self, pos_cfg, feat_cfg, sd_p, sd_f, n, prec, seed_p, seed_f):
         from .diffusion import FeatureSampler, PositionSampler
-        ps = PositionSampler(pos_cfg["pointnet_config"], sd_p, n, self.device, pos_cfg["diffusion_config"], prec=prec,
+        ps = PositionSampler(pos_cfg["pointnet_config"], sd_p, n, self.device, pos_cfg["diffusion_config"], prec=resolve_prec(prec)[0],
                              seed=seed_p, use_graph=False)
-        fs = FeatureSampler(feat_cfg["pointnet_config"], sd_f, n, self.device, feat_cfg["standard_diffusion_config"], prec=prec,
+        fs = FeatureSampler(feat_cfg["pointnet_config"], sd_f, n, self.device, feat_cfg["standard_diffusion_config"], prec=resolve_prec(prec)[1],
                             seed=seed_f, use_graph=False)
         return ps, fs
 
@@ -275,11 +283,11 @@ class PipelinedGenerator:
         self.seed, self.g0 = int(seed), int(global_offset)
         self.pos = self.feats = None
         if pos is not None:
-            self.pos = PositionSampler(pos[0], pos[1], self.B, device, pos[2], prec=prec, seed=seed, use_graph=False)
+            self.pos = PositionSampler(pos[0], pos[1], self.B, device, pos[2], prec=resolve_prec(prec)[0], seed=seed, use_graph=False)
         self.sizes = []
         if feat is not None:
             self.sizes = sub_batch_sizes(self.B, n_sub)
-            self.feats = [FeatureSampler(feat[0], feat[1], b, device, feat[2], prec=prec, seed=seed, use_graph=False,
+            self.feats = [FeatureSampler(feat[0], feat[1], b, device, feat[2], prec=resolve_prec(prec)[1], seed=seed, use_graph=False,
                                          local_resampling=local_resampling) for i, b in enumerate(self.sizes)]
             self.cx = self.feats[0].engine.cx
         self._Eager = EagerChainsSampler

@@ -145,17 +145,21 @@ def train_ddpm(net, static, loss_fn, batches, n_iters, output_directory, learnin
 def npz_batches(path, batch_size, rank=0, world=1, seed=0):
     """epochs over an npz of clouds (`points` (n, P, 3), optional `normals`, `label`): a fresh permutation per epoch, this rank's
     contiguous share of it, full batches only (the stand-in for the reference's ShapeNet loader, pointnet2/dataset.py)"""
-    d = np.load(path, allow_pickle=True)
+    with np.load(path) as z:  # (an NpzFile re-reads and decompresses an array on EVERY access: load each once -- ADVICE r4)
+        d = {k: np.asarray(z[k]) for k in ("points", "normals", "label") if k in z.files}
     n = d["points"].shape[0]
     rs = np.random.RandomState(seed)
 
     class _Epochs:
+        def __len__(self):  # full batches of this rank's share per epoch
+            return (n // world) // batch_size
+
         def __iter__(self):
             perm = rs.permutation(n)
             per = n // world
             mine = perm[rank * per:(rank + 1) * per]
             for i in range(0, len(mine) - batch_size + 1, batch_size):
                 j = np.sort(mine[i:i + batch_size])
-                yield {k: d[k][j] for k in ("points", "normals", "label") if k in d.files}
+                yield {k: v[j] for k, v in d.items()}
 
     return _Epochs()

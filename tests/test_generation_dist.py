@@ -202,8 +202,8 @@ class _FakeAutoencoder:
     def decode(self, keypoint, feature, ts=None, label=None, fps_start_idx=None):
         b = keypoint.shape[0]
         self.batches.append(b)
-        assert fps_start_idx.shape == (b,) and fps_start_idx.dtype == torch.int64 and int(fps_start_idx.max()) < 512
-        base = keypoint.sum(dim=(1, 2)) + 10 * feature.sum(dim=(1, 2)) + 1000 * label.float() + 1e4 * fps_start_idx.float()
+        assert fps_start_idx.shape == (b,) and fps_start_idx.dtype == torch.int64 and 0 <= int(fps_start_idx.min()) and int(fps_start_idx.max()) < (1 << 30)
+        base = keypoint.sum(dim=(1, 2)) + 10 * feature.sum(dim=(1, 2)) + 1000 * label.float() + 1e4 * (fps_start_idx % 512).float()
         return base[:, None, None] + torch.arange(2048 * 6, dtype=torch.float32).reshape(1, 2048, 6)
 
 

@@ -37,10 +37,32 @@ def test_denoiser_forward_fp32_matches_reference(gpu_device, name, prec):
         assert _rel(y, g["eps_" + k]) <= 2e-4, (k, _rel(y, g["eps_" + k]))
 
 
-@pytest.mark.parametrize("name", ["pos", "feat"])
-def test_denoiser_forward_fp16_mfma(gpu_device, name):
+@pytest.mark.parametrize("name,prec", [("pos", "split"), ("feat", "fp16")])
+def test_benched_arithmetic_meets_1e3_on_reference_goldens(gpu_device, name, prec):
+    """north_star / BASELINE.md section 4: generated latents within 1e-3 (relative, fp32).  `bench.py`'s default arrangement
+    (round 5) runs the POSITION plan in the split arithmetic (fp32-grade) and the FEATURE plan in fp16 operands / fp32
+    accumulation: every single forward of both against the reference goldens, relative L2 AND max-norm <= 1e-3."""
     from slide_amd.engine import DenoiserEngine
     g, hp, sd = _load(name)
+    B = g["x_t0"].shape[0]
+    eng = DenoiserEngine(hp, sd, B, gpu_device, prec=prec)
+    worst = worst_max = 0.0
+    for k in ["t0", "t1", "t500", "t999", "mixed"]:
+        y = eng.forward(g["x_" + k], g["ts_" + k], g["label_" + k]).cpu().numpy()
+        assert np.isfinite(y).all(), k
+        ref = g["eps_" + k]
+        worst = max(worst, float(np.linalg.norm(y - ref) / np.linalg.norm(ref)))
+        worst_max = max(worst_max, _rel(y, ref))
+    print("benched arithmetic (%s net, %s): relative L2 %.3e, max-norm %.3e vs reference" % (name, prec, worst, worst_max))
+    assert worst <= 1e-3 and worst_max <= 1e-3, (worst, worst_max)
+
+
+def test_optin_fp16_position_plan_is_bounded(gpu_device):
+    """NOT the benched mode since round 5 (`bench.py --pos-prec fp16` / the CLIs' `--prec fp16` select it): the fp16 position
+    plan's single forwards miss 1e-3 on the reference goldens (3.2e-3: every layer's operand rounding contributes and the error
+    grows as the coordinates shrink).  Kept as an opt-in throughput plan; this test only bounds it."""
+    from slide_amd.engine import DenoiserEngine
+    g, hp, sd = _load("pos")
     B = g["x_t0"].shape[0]
     eng = DenoiserEngine(hp, sd, B, gpu_device, prec="fp16")
     worst = 0.0
@@ -49,13 +71,8 @@ def test_denoiser_forward_fp16_mfma(gpu_device, name):
         assert np.isfinite(y).all(), k
         ref = g["eps_" + k]
         worst = max(worst, float(np.linalg.norm(y - ref) / np.linalg.norm(ref)))
-    print("fp16-MFMA relative L2 error vs reference (%s): %.3e" % (name, worst))
-    # north_star / BASELINE.md section 4: 1e-3 relative on single forwards.  The FEATURE net meets it in the throughput mode
-    # (measured 8.5e-4).  The POSITION net does not (3.2e-3 on these inputs): every one of its layers' operand roundings
-    # contributes -- tools/prec_emul.py: weights-only 9.5e-4, activations-only 8.5e-4, no subset of modules in wide operands gets
-    # under 7.5e-4, a two-term fp16 split of both operands 1e-6 -- and the error grows as the coordinates shrink (DESIGN.md
-    # section 5).  Its 1e-3 mode is `prec="fp32"` (bench.py --pos-prec fp32; the CLIs' --prec fp32), asserted above at 2e-4.
-    assert worst <= (1e-3 if name == "feat" else 4e-3), worst
+    print("opt-in fp16 position plan, relative L2 error vs reference: %.3e" % worst)
+    assert worst <= 4e-3, worst
 
 
 @pytest.mark.parametrize("B", [88, 256])
@@ -85,8 +102,9 @@ def test_feature_denoiser_at_the_benched_launch_sizes_matches_oracle(gpu_device,
 
 
 def test_position_denoiser_at_the_benched_launch_size_matches_oracle(gpu_device):
-    """the position chain's launch size (256 samples): exact-fp32 engine vs the numpy oracle, <= 2e-4; the fp16 plan is reported
-    against the same output for two input families (chain start: N(0, 1); chain end: key-point-like coordinates)"""
+    """the position chain's launch size (256 samples): exact-fp32 engine vs the numpy oracle, <= 2e-4; the BENCHED position
+    arithmetic (split, round 5) against the same output, <= 1e-3 relative L2, for two input families (chain start: N(0, 1);
+    chain end: key-point-like coordinates -- where the opt-in fp16 plan is 1.5e-3 off)"""
     from oracle import denoiser_np as D
     from slide_amd.engine import DenoiserEngine
     from slide_amd.synth import synth_keypoints
@@ -96,15 +114,15 @@ def test_position_denoiser_at_the_benched_launch_size_matches_oracle(gpu_device)
     ts = rs.randint(0, 1000, B).astype(np.float32)
     label = rs.randint(0, 13, B).astype(np.int64)
     e32 = DenoiserEngine(hp, sd, B, gpu_device, prec="fp32")
-    e16 = DenoiserEngine(hp, sd, B, gpu_device, prec="fp16")
+    e16 = DenoiserEngine(hp, sd, B, gpu_device, prec="split")
     for fam, x in (("normal", rs.standard_normal((B, 16, 3)).astype(np.float32)), ("keypoints", synth_keypoints(B, seed=3).astype(np.float32))):
         ref = D.denoiser_forward(hp, sd, x, ts, label)
         y32 = e32.forward(x, ts, label).cpu().numpy()
         assert np.isfinite(y32).all() and _rel(y32, ref) <= 2e-4, (fam, _rel(y32, ref))
         y16 = e16.forward(x, ts, label).cpu().numpy()
         r16 = float(np.linalg.norm(y16 - ref) / np.linalg.norm(ref))
-        print("position net, B = 256, %s inputs: fp32 engine vs oracle %.2e; fp16 plan vs oracle %.2e relative L2" % (fam, _rel(y32, ref), r16))
-        assert np.isfinite(y16).all() and r16 <= (1.2e-3 if fam == "normal" else 4e-3), (fam, r16)
+        print("position net, B = 256, %s inputs: fp32 engine vs oracle %.2e; benched (split) plan vs oracle %.2e relative L2" % (fam, _rel(y32, ref), r16))
+        assert np.isfinite(y16).all() and r16 <= 1e-3, (fam, r16)
 
 
 def test_denoiser_larger_batch_matches_oracle(gpu_device):
@@ -650,45 +668,69 @@ def test_pair_decomposition_plan_variants(gpu_device, exp_lib, monkeypatch):
         assert np.array_equal(outs["two_launch_tables"], outs["default"]), name
 
 
-def test_fp16_full_chains_follow_the_fp32_chains(gpu_device):
-    """The throughput mode over COMPLETE generations: 1000-step position and feature chains in fp16 (MFMA operands and
-    activation storage; fp32 accumulation, statistics, softmax, DDPM update) against the same chains in the exact-fp32 mode
-    (which the tests above pin to the reference at <= 1e-3, measured 7e-7), 256 shapes, in-kernel Philox noise with equal
-    seeds.  Measured per shape (relative max distance): position median 1.2e-4 / max 9.8e-4, feature median 1.9e-4 / max
-    3.0e-4.  Asserted: <= 1e-3 for 95 % of the shapes, <= 3e-3 for every shape (a flipped near-tie of a per-step kNN could
-    move an individual shape further than the bulk), equal batch statistics."""
+def _full_chains(gpu_device, B, precs):
+    """complete 1000-step position / feature chains of B shapes per arithmetic in `precs` = {name: (pos prec, feat prec)}"""
     from slide_amd.diffusion import FeatureSampler, PositionSampler
     from slide_amd.synth import synth_keypoints
-    B = 256
     res = {}
-    for prec in ("fp16", "fp32"):
-        _, hp, sd = _load("pos")
-        ps = PositionSampler(hp, sd, B, gpu_device, _pos_cfg(), prec=prec, seed=77, use_graph=True)
-        xT = np.random.RandomState(4).standard_normal((B, 16, 3)).astype(np.float32)
-        res["pos", prec] = ps.sample(np.zeros(B, np.int64), xT).cpu().numpy()
-        g, hp, sd = _load("feat")
-        cfg = json.loads(str(load_golden("golden_sampler_feat.npz")["config_json"]))
-        fs = FeatureSampler(hp, sd, B, gpu_device, cfg, prec=prec, seed=78, use_graph=True)
-        xT = np.random.RandomState(5).standard_normal((B, 16, 51)).astype(np.float32)
-        res["feat", prec] = fs.sample(np.full(B, 4, np.int64), synth_keypoints(B), xT).cpu().numpy()
+    for tag, (pp, fp) in precs.items():
+        if pp is not None:
+            _, hp, sd = _load("pos")
+            ps = PositionSampler(hp, sd, B, gpu_device, _pos_cfg(), prec=pp, seed=77, use_graph=True)
+            xT = np.random.RandomState(4).standard_normal((B, 16, 3)).astype(np.float32)
+            res["pos", tag] = ps.sample(np.zeros(B, np.int64), xT).cpu().numpy()
+        if fp is not None:
+            g, hp, sd = _load("feat")
+            cfg = json.loads(str(load_golden("golden_sampler_feat.npz")["config_json"]))
+            fs = FeatureSampler(hp, sd, B, gpu_device, cfg, prec=fp, seed=78, use_graph=True)
+            xT = np.random.RandomState(5).standard_normal((B, 16, 51)).astype(np.float32)
+            res["feat", tag] = fs.sample(np.full(B, 4, np.int64), synth_keypoints(B), xT).cpu().numpy()
+    return res
+
+
+def _chain_agreement(name, a, b, B):
+    a, b = a.reshape(B, -1), b.reshape(B, -1)
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    per_shape = np.abs(a - b).max(axis=1) / np.abs(b).max()
+    a2, b2 = a.reshape(B * 16, -1), b.reshape(B * 16, -1)
+    if name == "feat":  # the key-point channels are the clamped condition: identical
+        assert np.array_equal(a2[:, :3], b2[:, :3])
+        a2, b2 = a2[:, 3:], b2[:, 3:]
+    sd_b = b2.std(axis=0) + 1e-6
+    dm = np.abs(a2.mean(axis=0) - b2.mean(axis=0)) / sd_b
+    ratio = a2.std(axis=0) / sd_b
+    print("%s: per-shape relative max distance: median %.2e, 95 %% %.2e, 99 %% %.2e, max %.2e; shapes above 1e-3: %d of %d; "
+          "|mean diff| / std <= %.1e, std ratio %.4f .. %.4f" % (name, np.median(per_shape), np.quantile(per_shape, 0.95),
+                                                                 np.quantile(per_shape, 0.99), per_shape.max(),
+                                                                 int((per_shape > 1e-3).sum()), B, dm.max(), ratio.min(), ratio.max()))
+    return per_shape, dm, ratio
+
+
+def test_benched_full_chains_follow_the_fp32_chains(gpu_device):
+    """north_star's criterion on GENERATED LATENTS, over complete generations in the arithmetic `bench.py` times (round 5:
+    position chain split, feature chain fp16 operands / fp32 accumulation) against the same chains in the exact-fp32 mode
+    (pinned to the reference at <= 1e-3 above, measured 7e-7), 256 shapes, in-kernel Philox noise with equal seeds.
+    Asserted per shape (relative max distance): <= 1e-3 for at least 99 % of the shapes.  The exemption is COUNTED and bounded:
+    a position chain re-runs its kNN on noisy points every step, and a near-tie that resolves differently under a 1e-6
+    perturbation turns that shape into another sample of the same distribution -- at most 1 % of the shapes (2 of 256) may
+    exceed 1e-3 and none 1e-2; batch statistics must agree."""
+    B = 256
+    res = _full_chains(gpu_device, B, {"bench": ("split", "fp16"), "fp32": ("fp32", "fp32")})
     for name in ("pos", "feat"):
-        a, b = res[name, "fp16"].reshape(B, -1), res[name, "fp32"].reshape(B, -1)
-        assert np.isfinite(a).all() and np.isfinite(b).all()
-        per_shape = np.abs(a - b).max(axis=1) / np.abs(b).max()
-        a2, b2 = res[name, "fp16"].reshape(B * 16, -1), res[name, "fp32"].reshape(B * 16, -1)
-        if name == "feat":  # the key-point channels are the clamped condition: identical
-            assert np.array_equal(a2[:, :3], b2[:, :3])
-            a2, b2 = a2[:, 3:], b2[:, 3:]
-        sd_b = b2.std(axis=0) + 1e-6
-        dm = np.abs(a2.mean(axis=0) - b2.mean(axis=0)) / sd_b
-        ratio = a2.std(axis=0) / sd_b
-        print("%s: per-shape relative max distance: median %.2e, 95 %% %.2e, max %.2e; |mean diff| / std <= %.1e, std ratio %.4f .. %.4f"
-              % (name, np.median(per_shape), np.quantile(per_shape, 0.95), per_shape.max(), dm.max(), ratio.min(), ratio.max()))
-        # measured (round 3 plan): position max 1.1e-3 / median 1.5e-4, feature max 4e-4.  A position chain re-runs its kNN on
-        # noisy points every step: a near-tie may flip for an individual shape, after which that shape is a different sample
-        # of the same distribution -- hence 2e-3 for every shape, 1e-3 for 95 % of them (the golden chains above: <= 1e-3)
-        assert per_shape.max() <= 2e-3 and np.quantile(per_shape, 0.95) <= 1e-3, (per_shape.max(), np.quantile(per_shape, 0.95))
+        per_shape, dm, ratio = _chain_agreement(name, res[name, "bench"], res[name, "fp32"], B)
+        n_over = int((per_shape > 1e-3).sum())
+        assert n_over <= B // 100 and per_shape.max() <= 1e-2, (name, n_over, per_shape.max())
         assert dm.max() <= 0.01 and 0.99 <= ratio.min() and ratio.max() <= 1.01
+
+
+def test_optin_fp16_position_chains_are_bounded(gpu_device):
+    """the opt-in fp16 POSITION plan (`--pos-prec fp16`; not benched since round 5) over complete chains: the error does not
+    accumulate (median 1.2e-4) but individual shapes reach 2.4e-3 -- bounded here at 95 % <= 1e-3, all <= 3e-3."""
+    B = 256
+    res = _full_chains(gpu_device, B, {"fp16": ("fp16", None), "fp32": ("fp32", None)})
+    per_shape, dm, ratio = _chain_agreement("pos", res["pos", "fp16"], res["pos", "fp32"], B)
+    assert per_shape.max() <= 3e-3 and np.quantile(per_shape, 0.95) <= 1e-3, (per_shape.max(), np.quantile(per_shape, 0.95))
+    assert dm.max() <= 0.01 and 0.99 <= ratio.min() and ratio.max() <= 1.01
 
 
 def test_position_sampler_full_chain_fp16_matches_reference(gpu_device):
