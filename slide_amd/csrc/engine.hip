@@ -22,6 +22,8 @@ int slide_launch_gemm_xs(const GemmArgs &a, int npxl, int cbw, bool aff, bool ga
 #endif
 // gemm_gx.hip: generated-X GEMM and the per-point table normalisation of the pair decomposition
 int slide_launch_gemm_gx(const SlideOp &o, hipStream_t s);
+int slide_launch_gemm_gxs(const SlideOp &o, hipStream_t s);  // gemm_gxs.hip (split arithmetic, float tables)
+int slide_launch_attn_tail_split(const SlideOp &o, hipStream_t s);  // gemm_gxs.hip
 int slide_launch_pair_norm(const SlideOp &o, hipStream_t s);
 int slide_launch_sa_chain(const SlideOp &o, hipStream_t s);
 int slide_launch_block_body(const SlideOp &o, hipStream_t s);  // block_body.hip
@@ -40,7 +42,7 @@ namespace {
 
 // (split mode: its two stages of four fp16 planes take 102 KB of LDS -- one workgroup per CU anyway, so it may use the whole
 //  register file: the second accumulator set of the cross products does not fit 256 registers next to the 16-row epilogue)
-template <int PREC, int NPXL, int CBW>
+template <int PREC, int NPXL, int CBW, bool PAIRRES = false>
 __global__ __launch_bounds__(256, (PREC == SLIDE_PREC_SPLIT && NPXL == 4) ? 1 : 2) void gemm_kernel(GemmArgs a) {
   using T = typename TileT<PREC>::T;
   constexpr int LDK = TileT<PREC>::LDK;
@@ -286,8 +288,8 @@ __global__ __launch_bounds__(256, (PREC == SLIDE_PREC_SPLIT && NPXL == 4) ? 1 : 
         for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaf(acc2[i][j][r], 1.f / 2048.f, acc[i][j][r]);
   }
   // (split mode stores float activations: the fp32 epilogue)
-  gemm_epilogue<SPLIT ? SLIDE_PREC_F32 : PREC, NPXL, CBW>(a, acc, row0, cob0, wave, half, col, epi_lds, vec_lds,
-                                                          reinterpret_cast<float *>(smem_raw));
+  gemm_epilogue<SPLIT ? SLIDE_PREC_F32 : PREC, NPXL, CBW, 2, PAIRRES>(a, acc, row0, cob0, wave, half, col, epi_lds, vec_lds,
+                                                                      reinterpret_cast<float *>(smem_raw));
 }
 
 // ------------------------------------------------------------------------------------------------ small split GEMM
@@ -1951,7 +1953,7 @@ inline int current_device_slot() {
   return d >= 0 && d < SLIDE_MAX_DEVICES ? d : 0;
 }
 
-template <int PREC, int NPXL, int CBW>
+template <int PREC, int NPXL, int CBW, bool PAIRRES = false>
 int launch_gemm(const GemmArgs &a, hipStream_t s) {
   constexpr int LDK = TileT<PREC>::LDK;
   // (split mode: two fp16 planes per operand tile)
@@ -1964,11 +1966,11 @@ int launch_gemm(const GemmArgs &a, hipStream_t s) {
   static bool attr_done[SLIDE_MAX_DEVICES] = {};
   bool &attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<PREC, NPXL, CBW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<PREC, NPXL, CBW, PAIRRES>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<PREC, NPXL, CBW>), dim3(grid), dim3(256), shm, s, a);
+  hipLaunchKernelGGL((gemm_kernel<PREC, NPXL, CBW, PAIRRES>), dim3(grid), dim3(256), shm, s, a);
   return (int)hipGetLastError();
 }
 
@@ -2141,6 +2143,12 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
   const int npxl = o.i[4], prec = o.i[6], cbw = o.i[7], glds = o.i[8] & 1;
   a.w_cm = (o.i[8] >> 1) & 1;  // chunk-major weights (ring kernels of the 128 / 256-row samples only)
   if ((o.i[8] >> 2) & 1) {     // a block of this GEMM carries a PAIR residual: the instantiations compiled for it
+    if (prec == SLIDE_PREC_SPLIT && !glds && !a.in_scale && !o.p[8] && !o.p[10] && cbw == 2) {  // float tables (round 5)
+      if (a.k_pad % BK || a.x_ld % 4 || a.rows <= 0 || a.n_cob <= 0) return -3;
+      if (npxl == 8) return launch_gemm<SLIDE_PREC_SPLIT, 8, 2, true>(a, s);
+      if (npxl == 7) return launch_gemm<SLIDE_PREC_SPLIT, 7, 2, true>(a, s);
+      return -12;
+    }
     if (!glds || prec != SLIDE_PREC_F16 || a.in_scale || o.p[8] || o.p[10]) return -12;
     // (two workgroups per CU, 256 registers: the three-workgroup form spills with the pair address arithmetic)
     if (npxl == 8) return launch_gemm_glds<8, 2, 3, 32, false, false, true>(a, s);
@@ -2469,9 +2477,9 @@ int run_op(const SlideOp &o, hipStream_t s) {
     }
 #endif
     case SLIDE_OP_ATTN_TAIL:
-      return run_attn_tail(o, s);
+      return ((int)o.f[1] & 8) ? slide_launch_attn_tail_split(o, s) : run_attn_tail(o, s);
     case SLIDE_OP_GEMM_GX:
-      return slide_launch_gemm_gx(o, s);
+      return (int)o.f[0] == 3 ? slide_launch_gemm_gxs(o, s) : slide_launch_gemm_gx(o, s);
     case SLIDE_OP_GEMM_GX_DUAL:
       return slide_launch_gemm_gx_dual(o, s);
     case SLIDE_OP_PAIR_NORM:

@@ -185,11 +185,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
   // (one dependent L2 round trip per block less: 11.3 -> 6 us of store phase on the FP1 layer of the feature net)
   int nbr_row[RB];
   f16x2 nbr_sc[RB];  // (d2, w)
-  if constexpr (PAIRRES && NPXL == 7 && std::is_same<T, _Float16>::value) {
+  float nbr_d2f[RB], nbr_wf[RB];  // float activations (split mode, round 5): the two per-slot scalars in fp32
+  if constexpr (PAIRRES && NPXL == 7) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       nbr_row[rb] = 0;
       nbr_sc[rb] = f16x2{(_Float16)0.f, (_Float16)0.f};
+      nbr_d2f[rb] = nbr_wf[rb] = 0.f;
       const int row = row0 + wave * 64 + rb * 32 + col;
       if (a.gidx && a.gx_d2 && a.gx_w && row < a.rows) {
         const int smp = row >> NPXL, pxl = row & (NPX - 1);
@@ -199,7 +201,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
         //  residual itself stays in packed fp16, like the generated-X fragments of the same block: evaluating it in fp32 -- tried in
         //  round 4 -- left single forwards unchanged and made 1000-step position chains deviate 5x MORE from the fp32 mode
         //  (median per-shape distance 6.8e-4 vs 1.4e-4, tools/ab/chain_dev.py): the block's two uses of (d2, w) then round differently)
-        nbr_sc[rb] = f16x2{(_Float16)fminf(a.gx_d2[slot], 65504.f), (_Float16)a.gx_w[slot]};
+        nbr_d2f[rb] = a.gx_d2[slot]; nbr_wf[rb] = a.gx_w[slot];
+        nbr_sc[rb] = f16x2{(_Float16)fminf(nbr_d2f[rb], 65504.f), (_Float16)nbr_wf[rb]};
       }
     }
   }
@@ -229,6 +232,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     constexpr int NA = NPXL >= 6 ? 1 : RB;  // a wave's 64 rows belong to one sample when NPX >= 64
     float4 apre[NA][4];
     u32x4 rpre[RB][2];
+    size_t pr_a[RB], pr_b[RB];  // float rows with a PAIR residual: the two table rows of the lane's row (read in the store phase)
     if (PH != 1) {
       if (addv && e_addvec_idx) addv += (size_t)e_addvec_idx[0] * e_idx_stride;  // row t of a per-timestep table
 #pragma unroll
@@ -245,6 +249,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
         // pair residual: the row's value is the sum of two per-point table rows (+ the two per-slot terms of group_knn)
         size_t ra_row = (size_t)row, rb_row = 0;
         _Float16 sd2 = (_Float16)0.f, sw = (_Float16)0.f;
+        pr_a[rb] = (size_t)row; pr_b[rb] = 0;
+        if constexpr (!kHalf && NPXL >= 7 && PAIRRES) {
+          if (pair && ok) {
+            const int smp = row >> NPXL, pxl = row & (NPX - 1);
+            if (flags & SLIDE_F_RES_PAIR) {
+              pr_a[rb] = (size_t)(smp * 16 + (pxl & 15)); pr_b[rb] = (size_t)(row >> 4);
+            } else if constexpr (NPXL == 7) {
+              pr_a[rb] = (size_t)nbr_row[rb]; pr_b[rb] = (size_t)(row >> 3);
+            }
+          }
+        }
         if constexpr (kHalf && NPXL >= 7 && PAIRRES) {
           if (pair && ok) {
             const int smp = row >> NPXL, pxl = row & (NPX - 1);
@@ -592,7 +607,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
               const int q = 2 * p + j, c0 = 8 * q + 4 * half;
               float4 y = make_float4(v[rb][2 * q][0], v[rb][2 * q][1], v[rb][2 * q + 1][0], v[rb][2 * q + 1][1]);
               if constexpr (HR) {
-                const float4 t = gload4(resid + (size_t)row * e_res_ld + c0);
+                float4 t;
+                bool plain = true;
+                if constexpr (!kHalf && NPXL >= 7 && PAIRRES) {
+                  if (pair) {  // PAIR residual on float rows (split mode): ta[q] + tb[p] (+ d2 vd + w vw), evaluated in fp32
+                    plain = false;
+                    t = gload4(resid + pr_a[rb] * e_res_ld + c0);
+                    const float4 t2 = gload4(gptr<const T>(rdp(34)) + pr_b[rb] * e_res_ld + c0);
+                    t.x += t2.x; t.y += t2.y; t.z += t2.z; t.w += t2.w;
+                    if constexpr (NPXL == 7) {
+                      if (flags & SLIDE_F_RES_PAIR_NBR) {
+                        const float4 vd = gload4(gptr<const float>(rdp(36)) + c0), vw = gload4(gptr<const float>(rdp(38)) + c0);
+                        const float d2 = nbr_d2f[rb], w_ = nbr_wf[rb];
+                        t.x = fmaf(w_, vw.x, fmaf(d2, vd.x, t.x)); t.y = fmaf(w_, vw.y, fmaf(d2, vd.y, t.y));
+                        t.z = fmaf(w_, vw.z, fmaf(d2, vd.z, t.z)); t.w = fmaf(w_, vw.w, fmaf(d2, vd.w, t.w));
+                      }
+                    }
+                  }
+                }
+                if (plain) t = gload4(resid + (size_t)row * e_res_ld + c0);
                 y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
               }
               if (flags & SLIDE_F_OUT_F32)

@@ -405,15 +405,16 @@ __global__ __launch_bounds__(256) void pair_norm_kernel(int ld, const float *__r
 // are complete inside the workgroup and the joint GroupNorm over the attention's [query | key] concatenation
 // (weight_conv.1, attention.py:45-47; SlideGnFin in include/slide_engine.h) is finalised here as well -- per-channel scale /
 // shift for the query GEMM and the generated-X key GEMM -- instead of inside the next launch's prologue.
-template <bool FP>
-__global__ __launch_bounds__(1024) void pair_norm2_kernel(int ld, const float *__restrict__ y, const float *__restrict__ xyz,
+// TT = float (round 5): the tables of the SPLIT-arithmetic plans (fp32-grade position DDPM) -- same pass, tables kept in fp32
+template <bool FP, typename TT = _Float16, int NT = 1024>
+__global__ __launch_bounds__(NT) void pair_norm2_kernel(int ld, const float *__restrict__ y, const float *__restrict__ xyz,
                                                           const float *__restrict__ wa, const float *__restrict__ wb,
-                                                          const SlideEpi *__restrict__ epi, _Float16 *__restrict__ ta,
-                                                          _Float16 *__restrict__ tb, const int *__restrict__ nbr,
+                                                          const SlideEpi *__restrict__ epi, TT *__restrict__ ta,
+                                                          TT *__restrict__ tb, const int *__restrict__ nbr,
                                                           const float *__restrict__ d2t, const float *__restrict__ wt,
                                                           const float *__restrict__ vv_in, float *__restrict__ vv_out,
                                                           const SlideGnFin *__restrict__ finp) {
-  extern __shared__ __attribute__((aligned(16))) float dyn_l[];  // FP: a-values [16][1025]
+  extern __shared__ __attribute__((aligned(16))) float dyn_l[];  // FP: a-values [16][NT + 1]
   __shared__ float sx[48];
   __shared__ int sq[16 * 8];
   __shared__ float sd[16 * 8], sw[16 * 8];
@@ -468,13 +469,13 @@ __global__ __launch_bounds__(1024) void pair_norm2_kernel(int ld, const float *_
           }
       } else {
 #pragma unroll
-        for (int p = 0; p < 16; ++p) dyn_l[p * 1025 + tid] = av[p];  // (a thread reads back only its own column: no barrier)
+        for (int p = 0; p < 16; ++p) dyn_l[p * (NT + 1) + tid] = av[p];  // (a thread reads back only its own column: no barrier)
 #pragma unroll
         for (int p = 0; p < 16; ++p)
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const int sl = p * 8 + j;
-            float v = dyn_l[sq[sl] * 1025 + tid] + bv[p] + sd[sl] * vd + sw[sl] * vw;
+            float v = dyn_l[sq[sl] * (NT + 1) + tid] + bv[p] + sd[sl] * vd + sw[sl] * vw;
             if (pre_relu) v = fmaxf(v, 0.f);
             s += v; ss = fmaf(v, v, ss);
           }
@@ -502,8 +503,8 @@ __global__ __launch_bounds__(1024) void pair_norm2_kernel(int ld, const float *_
     }
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
-      ta[((size_t)b * 16 + p) * ld + c] = (_Float16)(av[p] * g + sh);
-      tb[((size_t)b * 16 + p) * ld + c] = (_Float16)(bv[p] * g);
+      ta[((size_t)b * 16 + p) * ld + c] = (TT)(av[p] * g + sh);
+      tb[((size_t)b * 16 + p) * ld + c] = (TT)(bv[p] * g);
     }
     if (FP) {
       vv_out[(size_t)b * 2 * ld + c] = vd * g;
@@ -688,10 +689,46 @@ int slide_launch_gemm_gx(const SlideOp &o, hipStream_t s) {
 
 // SLIDE_OP_PAIR_NORM: the two-launch form of the pair-table pass (SLIDE_PAIR_FUSED=0) and its one-workgroup-per-sample version
 // (SLIDE_PAIR_NORM_V2=1) -- experiments build only; the default plans run SLIDE_OP_PAIR_FIRST (engine.hip)
+// version 2 with FLOAT tables (i[4] == 1): the pair-table pass of the split-arithmetic plans (product build)
+static int launch_pair_norm2_f32(const SlideOp &o, hipStream_t s) {
+  const int B = o.i[0], ld = o.i[1], K = o.i[2];
+  if (B <= 0 || ld <= 0 || ld % 32 || ld > 2048) return -3;
+  const SlideGnFin *fin = (const SlideGnFin *)o.p[12];
+  // (512-thread workgroups: 256 registers per thread -- with 1024 the 16 x 16 pair loop over two 16-entry register tables spills)
+  const int npass = (ld + 511) / 512, nthr = ((ld + npass - 1) / npass + 63) / 64 * 64;
+  const dim3 grid(B), blk(nthr < 512 ? nthr : 512);
+  if (K == 16)
+    hipLaunchKernelGGL((pair_norm2_kernel<false, float, 512>), grid, blk, 0, s, ld, (const float *)o.p[0], (const float *)o.p[1],
+                       (const float *)o.p[2], (const float *)o.p[3], (const SlideEpi *)o.p[4], (float *)o.p[5], (float *)o.p[6],
+                       (const int *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
+                       (float *)nullptr, fin);
+  else if (K == 8) {
+    if (!o.p[7] || !o.p[8] || !o.p[9] || !o.p[10] || !o.p[11]) return -3;
+    static bool attr_done[64] = {};
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d = d >= 0 && d < 64 ? d : 0;
+    if (!attr_done[d]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_norm2_kernel<true, float, 512>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 513 * 4);
+      attr_done[d] = true;
+    }
+    hipLaunchKernelGGL((pair_norm2_kernel<true, float, 512>), grid, blk, (size_t)16 * 513 * 4, s, ld, (const float *)o.p[0],
+                       (const float *)o.p[1], (const float *)o.p[2], (const float *)o.p[3], (const SlideEpi *)o.p[4],
+                       (float *)o.p[5], (float *)o.p[6], (const int *)o.p[7], (const float *)o.p[8], (const float *)o.p[9],
+                       (const float *)o.p[10], (float *)o.p[11], fin);
+  } else return -5;
+  return (int)hipGetLastError();
+}
+
 #ifndef SLIDE_EXPERIMENTS
-int slide_launch_pair_norm(const SlideOp &, hipStream_t) { return -20; }
+int slide_launch_pair_norm(const SlideOp &o, hipStream_t s) {
+  if (o.i[3] == 2 && o.i[4] == 1) return launch_pair_norm2_f32(o, s);
+  return -20;
+}
 #else
 int slide_launch_pair_norm(const SlideOp &o, hipStream_t s) {
+  if (o.i[3] == 2 && o.i[4] == 1) return launch_pair_norm2_f32(o, s);
   const int B = o.i[0], ld = o.i[1], K = o.i[2];
   if (B <= 0 || ld <= 0 || ld % 32) return -3;
   const SlideGnFin *fin = (const SlideGnFin *)o.p[12];

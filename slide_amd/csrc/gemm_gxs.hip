@@ -1,0 +1,540 @@
+// gemm_gxs.hip -- the K-expanded kernels of the SPLIT-arithmetic pair decomposition (round 5).
+//
+// The position DDPM has to be fp32-grade (north_star: generated latents within 1e-3; its fp16 plan is 1.5e-3 .. 3.2e-3 off on
+// single forwards), and the fp32-structured split plan of round 4 moved ~0.8 GB of K-expanded fp32
+// activations per step (batch 256).  This file carries the pair decomposition of gemm_gx.hip into the split arithmetic:
+//   * the per-point tables ta / tb stay FLOAT (pair_norm2_kernel<., float>);
+//   * gemm_gxs_kernel is the consumer GEMM of a block's first layer: x(p, j) = max(ta[q] + tb[p] (+ d2 vd + w vw), 0) (+ add |
+//     * scale + shift) is GENERATED in fp32 from the two 16-row tables (L1 / L2 resident: 2 x 16 x k_pad x 4 B per sample) while the
+//     chunk goes to LDS, split there into two fp16 terms x = hi + 2^-11 lo like the weights, three fp16 MFMAs per product
+//     (hi hi + 2^-11 (hi lo + lo hi)) into two fp32 accumulator sets -- the 256- / 128-row first-layer outputs (h1, r, keys:
+//     288 channels x 65536 rows x 4 B at the position net's SA1) are never written or read;
+//   * attn_tail_split_kernel is the tail of an AttentionModule (attention.py:86-95) on float rows: scores S = W5 u + b5 and values
+//     V = relu(GN(Wv mo + bv)) as split contractions with SWAPPED operand roles (a lane owns a channel, its registers run over
+//     the rows), soft-max over a point's neighbours and the weighted sum in registers -- S and V never reach memory.
+// Reference: pointnet2_ops/pointnet2_utils.py:383-430, :497-524 (grouped inputs), pointnet2_ops/pointnet2_modules.py:119-176
+// (Mlp_plus_t_emb), pointnet2_ops/attention.py:70-96.
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int GXS_MAX_DEVICES = 64;
+
+__device__ __forceinline__ void gxs_split4(const float4 v, f16x4 &hi, f16x4 &lo) {
+  // x = hi + 2^-11 lo: the scaling keeps lo a normal fp16 number at any magnitude (engine.hip, gemm_kernel<SPLIT>)
+  hi = f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+  lo = f16x4{(_Float16)((v.x - (float)hi[0]) * 2048.f), (_Float16)((v.y - (float)hi[1]) * 2048.f),
+             (_Float16)((v.z - (float)hi[2]) * 2048.f), (_Float16)((v.w - (float)hi[3]) * 2048.f)};
+}
+// ONE accumulator set for the three products (round 5): the WEIGHT's high term also enters scaled, hs = 2^11 hi (exact in fp16 while
+// |w| < 32 -- the plan checks its weights), so   2^11 (w x) = hs xh + hi xl' + wl' xh   (xl', wl' the scaled low terms) accumulates
+// in one fp32 register set and a final exact 2^-11 restores the scale: the cross products sit 2^-11 below the leading one and keep 13
+// of their own bits in the fp32 sum -- 2^-24 of the total, as with two sets -- at half the accumulator registers.
+__device__ __forceinline__ void gxs_split4w(const float4 v, f16x4 &hi, f16x4 &hs, f16x4 &lo) {
+  gxs_split4(v, hi, lo);
+  hs = hi * f16x4{(_Float16)2048.f, (_Float16)2048.f, (_Float16)2048.f, (_Float16)2048.f};
+}
+
+// ------------------------------------------------------------------------------------------------ generated-X split GEMM
+// Tile 256 rows (one 16 x 16 sample or two 16 x 8 samples) x 64 channels, four waves x 64 rows, K chunks of 32.  One LDS stage of
+// five fp16 planes [X hi | X lo | W hi | 2^11 W hi | W lo] (rows of LDK = 40 halves: 56 KB); the next chunk's table rows and weights wait in
+// registers.  Thread (l_row = tid / 8, l_c = 4 (tid % 8)) generates columns l_c .. l_c + 3 of tile rows l_row + 32 p, p = 0 .. 7:
+// 16 x 16-row samples run in NATURAL neighbour order, so its eight rows share ONE neighbour row (q = l_row % 16) and touch eight
+// centre rows; 16 x 8-row samples look their neighbours up once (nbr table) and keep the two per-slot scalars in registers.
+// The per-sample vectors (add | scale, shift | vd, vw) are staged once per workgroup in LDS.
+template <int NPXL, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_gxs_kernel(GemmArgs a) {
+  constexpr int NPX = 1 << NPXL;
+  constexpr bool FP = NPXL == 7;
+  constexpr int NSAMP = TM >> NPXL;  // 1 or 2
+  constexpr int CBW = 2, TN = 64;
+  constexpr int LDK = TileT<SLIDE_PREC_SPLIT>::LDK;
+  constexpr int XP = 8, WP = 2;                        // tile rows / weight rows per thread and chunk (32 rows per pass)
+  constexpr int NVEC = (MODE ? 2 : 1) + (FP ? 2 : 0);  // float vectors per sample in LDS: [add | scale, shift][vd, vw][k_pad]
+  constexpr int STAGE = (2 * TM + 3 * TN) * LDK;       // halves: planes [X hi | X lo | W hi | W hi 2^11 | W lo]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16 *const Xh = reinterpret_cast<_Float16 *>(smem_raw);
+  _Float16 *const Xl = Xh + TM * LDK, *const Wh = Xl + TM * LDK, *const Ws = Wh + TN * LDK, *const Wl = Ws + TN * LDK;
+  const int ntc = (a.n_cob + CBW - 1) / CBW;
+  const int xcd = blockIdx.x & 7, q0 = blockIdx.x >> 3;
+  const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;  // the column tiles of a row tile share one XCD's L2 (tables + weights)
+  if (tr * TM >= a.rows) return;
+  const int row0 = tr * TM, cob0 = tc * CBW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int l_row = tid >> 3, l_c = (tid & 7) * 4;
+  const float *ta = reinterpret_cast<const float *>(a.gx_ta), *tb = reinterpret_cast<const float *>(a.gx_tb);
+  const float *W = reinterpret_cast<const float *>(a.W);
+  const int nsm = a.rows >> NPXL, smp0 = row0 >> NPXL;
+
+  uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + (size_t)STAGE * 2);
+  float *const vec_lds = reinterpret_cast<float *>(epi_lds + CBW * EPI_DW + (CBW * EPI_DW) % 4);
+  float *const vv_l = vec_lds + CBW * 96;  // [sample][NVEC][k_pad]
+  stage_epilogue_tables<CBW>(a, cob0, tid, epi_lds, vec_lds);
+  {
+    const float *addp = a.in_add;
+    if (MODE == 0 && addp && a.gx_add_idx) addp += (size_t)a.gx_add_idx[0] * a.gx_add_idx_stride;  // row t of a per-timestep table
+    for (int i = tid * 4; i < NSAMP * a.k_pad; i += 1024) {
+      const int sl = i / a.k_pad, k = i - sl * a.k_pad;
+      int smp = smp0 + sl;
+      smp = smp < nsm ? smp : nsm - 1;
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, vd = v0, vw = v0;
+      if (MODE == 0) {
+        if (addp) v0 = *reinterpret_cast<const float4 *>(addp + (size_t)smp * a.add_bs + k);
+      } else {
+        v0 = *reinterpret_cast<const float4 *>(a.in_scale + (size_t)smp * a.in_bs + k);
+        v1 = *reinterpret_cast<const float4 *>(a.in_shift + (size_t)smp * a.in_bs + k);
+      }
+      if (FP && a.gx_vv) {
+        vd = *reinterpret_cast<const float4 *>(a.gx_vv + (size_t)smp * a.gx_vbs + k);
+        vw = *reinterpret_cast<const float4 *>(a.gx_vv + (size_t)smp * a.gx_vbs + (a.gx_vbs >> 1) + k);
+      }
+      float *dst = vv_l + (size_t)sl * NVEC * a.k_pad + k;
+      *reinterpret_cast<float4 *>(dst) = v0;
+      if (MODE) *reinterpret_cast<float4 *>(dst + a.k_pad) = v1;
+      if (FP) {
+        *reinterpret_cast<float4 *>(dst + (MODE ? 2 : 1) * a.k_pad) = vd;
+        *reinterpret_cast<float4 *>(dst + (MODE ? 3 : 2) * a.k_pad) = vw;
+      }
+    }
+  }
+  // this thread's eight tile rows: neighbour (a) and centre (b) table rows (element offsets: the tables are far below 2^31
+  // elements).  16 x 8-row samples: the neighbour's table row and the two per-slot scalars of every tile row live in LDS
+  // ([256] x (offset, d2, w): kept in registers they push the kernel over its 256)
+  int aoff0 = 0, boff[XP];
+  int *const arow_l = reinterpret_cast<int *>(vv_l + (size_t)NSAMP * NVEC * a.k_pad);
+  float *const d2_l = reinterpret_cast<float *>(arow_l + TM), *const w_l = d2_l + TM;
+#pragma unroll
+  for (int p = 0; p < XP; ++p) {
+    int row = row0 + p * 32 + l_row;
+    row = row < a.rows ? row : a.rows - 1;
+    const int smp = row >> NPXL, pxl = row & (NPX - 1);
+    if (!FP) {
+      if (p == 0) aoff0 = (smp * 16 + (pxl & 15)) * a.gx_ld + l_c;
+      boff[p] = (smp * 16 + (pxl >> 4)) * a.gx_ld + l_c;
+    } else {
+      boff[p] = (smp * 16 + (pxl >> 3)) * a.gx_ld + l_c;
+    }
+  }
+  if (FP) {
+    int row = row0 + tid;
+    row = row < a.rows ? row : a.rows - 1;
+    const int smp = row >> NPXL, pxl = row & (NPX - 1);
+    const int slot = (smp * 16 + (pxl >> 3)) * 16 + (pxl & 7);
+    arow_l[tid] = (smp * 16 + a.gidx[slot]) * a.gx_ld;
+    d2_l[tid] = a.gx_d2[slot];
+    w_l[tid] = a.gx_w[slot];
+  }
+
+  f32x16 acc[CBW][2];
+#pragma unroll
+  for (int i = 0; i < CBW; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // raw table rows / weight rows of the chunk in flight.  16 x 8-row samples (a gathered neighbour row per tile row: twice the
+  // registers) prefetch the first NPRE rows under the MFMAs and fetch the rest at the top of store_chunk, where no MFMA operand
+  // is live -- all eight in flight across the MFMAs spills 36 registers
+  constexpr int NPRE = FP ? 4 : XP;
+  float4 ar[FP ? XP : 1], br[XP], wr[WP];
+  auto load_rows = [&](int kc, auto lo_tag, auto hi_tag) __attribute__((always_inline)) {
+    constexpr int P0 = decltype(lo_tag)::value, P1 = decltype(hi_tag)::value;
+    const int ko = kc * BK;
+#pragma unroll
+    for (int p = P0; p < P1; ++p) {
+      if (FP) ar[FP ? p : 0] = *reinterpret_cast<const float4 *>(ta + arow_l[p * 32 + l_row] + l_c + ko);
+      else if (p == 0) ar[0] = *reinterpret_cast<const float4 *>(ta + aoff0 + ko);
+      br[p] = *reinterpret_cast<const float4 *>(tb + boff[p] + ko);
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using IP = std::integral_constant<int, NPRE>;
+  using IX = std::integral_constant<int, XP>;
+  auto load_chunk = [&](int kc) __attribute__((always_inline)) {
+    const int ko = kc * BK;
+    load_rows(kc, I0(), IP());
+#pragma unroll
+    for (int p = 0; p < WP; ++p) {
+      const int gco = cob0 * 32 + p * 32 + l_row;
+      wr[p] = gco < a.n_cob * 32 ? *reinterpret_cast<const float4 *>(W + (size_t)gco * a.k_pad + ko + l_c)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_chunk = [&](int kc) __attribute__((always_inline)) {
+    const int ko = kc * BK + l_c;
+    if constexpr (NPRE < XP) load_rows(kc, IP(), IX());
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      const float *vp = vv_l + (size_t)(FP ? (p >> 2) : 0) * NVEC * a.k_pad + ko;  // (two samples: tile rows 0..127 | 128..255)
+      const float4 av = ar[FP ? p : 0], bv = br[p];
+      float4 x = make_float4(av.x + bv.x, av.y + bv.y, av.z + bv.z, av.w + bv.w);
+      if (FP) {
+        const float4 vd = *reinterpret_cast<const float4 *>(vp + (MODE ? 2 : 1) * a.k_pad);
+        const float4 vw = *reinterpret_cast<const float4 *>(vp + (MODE ? 3 : 2) * a.k_pad);
+        const float d2 = d2_l[p * 32 + l_row], w_ = w_l[p * 32 + l_row];
+        x.x = fmaf(w_, vw.x, fmaf(d2, vd.x, x.x)); x.y = fmaf(w_, vw.y, fmaf(d2, vd.y, x.y));
+        x.z = fmaf(w_, vw.z, fmaf(d2, vd.z, x.z)); x.w = fmaf(w_, vw.w, fmaf(d2, vd.w, x.w));
+      }
+      x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f);
+      const float4 v0 = *reinterpret_cast<const float4 *>(vp);
+      if (MODE) {
+        const float4 v1 = *reinterpret_cast<const float4 *>(vp + a.k_pad);
+        x.x = fmaf(x.x, v0.x, v1.x); x.y = fmaf(x.y, v0.y, v1.y); x.z = fmaf(x.z, v0.z, v1.z); x.w = fmaf(x.w, v0.w, v1.w);
+      } else {
+        x.x += v0.x; x.y += v0.y; x.z += v0.z; x.w += v0.w;
+      }
+      f16x4 hi, lo;
+      gxs_split4(x, hi, lo);
+      *reinterpret_cast<f16x4 *>(Xh + (p * 32 + l_row) * LDK + l_c) = hi;
+      *reinterpret_cast<f16x4 *>(Xl + (p * 32 + l_row) * LDK + l_c) = lo;
+    }
+#pragma unroll
+    for (int p = 0; p < WP; ++p) {
+      f16x4 hi, hs, lo;
+      gxs_split4w(wr[p], hi, hs, lo);
+      *reinterpret_cast<f16x4 *>(Wh + (p * 32 + l_row) * LDK + l_c) = hi;
+      *reinterpret_cast<f16x4 *>(Ws + (p * 32 + l_row) * LDK + l_c) = hs;
+      *reinterpret_cast<f16x4 *>(Wl + (p * 32 + l_row) * LDK + l_c) = lo;
+    }
+  };
+  auto compute = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      f16x8 ah[CBW], as[CBW], al[CBW], bh[2], bl[2];
+#pragma unroll
+      for (int cb = 0; cb < CBW; ++cb) {
+        ah[cb] = *reinterpret_cast<const f16x8 *>(Wh + (cb * 32 + col) * LDK + st * 16 + half * 8);
+        as[cb] = *reinterpret_cast<const f16x8 *>(Ws + (cb * 32 + col) * LDK + st * 16 + half * 8);
+        al[cb] = *reinterpret_cast<const f16x8 *>(Wl + (cb * 32 + col) * LDK + st * 16 + half * 8);
+      }
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        bh[rb] = *reinterpret_cast<const f16x8 *>(Xh + (wave * 64 + rb * 32 + col) * LDK + st * 16 + half * 8);
+        bl[rb] = *reinterpret_cast<const f16x8 *>(Xl + (wave * 64 + rb * 32 + col) * LDK + st * 16 + half * 8);
+      }
+#pragma unroll
+      for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as[cb], bh[rb], acc[cb][rb], 0, 0, 0);
+          acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb], bl[rb], acc[cb][rb], 0, 0, 0);
+          acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb], bh[rb], acc[cb][rb], 0, 0, 0);
+        }
+    }
+  };
+
+  const int nk = a.k_pad / BK;
+  if (FP) __syncthreads();  // (the row table is read by load_chunk)
+  load_chunk(0);
+  __syncthreads();  // the staged vectors and epilogue tables are visible
+  store_chunk(0);
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    if (kc + 1 < nk) load_chunk(kc + 1);
+    compute();
+    __syncthreads();  // every wave is done reading the stage before it is overwritten
+    if (kc + 1 < nk) store_chunk(kc + 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < CBW; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] *= 1.f / 2048.f;
+  // float rows: the fp32 epilogue (mode 0 = the Mlp layers: PAIR residual on the float tables)
+  gemm_epilogue<SLIDE_PREC_F32, NPXL, CBW, 2, MODE == 0>(a, acc, row0, cob0, wave, half, col, epi_lds, vec_lds,
+                                                         reinterpret_cast<float *>(smem_raw));
+}
+
+template <int NPXL, int MODE>
+int launch_gxs(const GemmArgs &a, hipStream_t s) {
+  constexpr int LDK = TileT<SLIDE_PREC_SPLIT>::LDK;
+  constexpr int NSAMP = TM >> NPXL, NVEC = (MODE ? 2 : 1) + (NPXL == 7 ? 2 : 0);
+  const size_t shm = (size_t)(2 * TM + 3 * 64) * LDK * 2 + (2 * EPI_DW + (2 * EPI_DW) % 4 + 2 * 96) * 4 + (size_t)NSAMP * NVEC * a.k_pad * 4 + (NPXL == 7 ? 3 * TM * 4 : 0) + 16;
+  if (shm > 80 * 1024) return -8;
+  const int ntc = (a.n_cob + 1) / 2, ntr = (a.rows + TM - 1) / TM;
+  const int grid = ((ntr + 7) / 8) * 8 * ntc;
+  static bool attr_done[GXS_MAX_DEVICES] = {};
+  int d = 0;
+  (void)hipGetDevice(&d);
+  bool &attr_set = attr_done[d >= 0 && d < GXS_MAX_DEVICES ? d : 0];
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_gxs_kernel<NPXL, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              80 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_gxs_kernel<NPXL, MODE>), dim3(grid), dim3(256), shm, s, a);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ split attention tail
+// The end of an AttentionModule (attention.py:86-95) on FLOAT rows in the split arithmetic, ONE launch: values V = relu(GN(Wv mo + bv))
+// first (accumulators -> GroupNorm statistics over the sample -> normalised in place: 64 registers), then scores S = W5 u + b5 into a
+// second accumulator set, soft-max over a point's K neighbours and the weighted sum -- S and V (2 x rows x C x 4 B, written and read
+// back by the three-launch form: 134 MB per step at the position net's SA1) never leave the registers.  Operand roles are SWAPPED
+// (A = X rows, B = W rows) as in attn_tail_kernel (engine.hip): a lane owns one channel and its registers run over the rows.
+// Tile 256 rows x 64 channels, four waves x 64 rows; one LDS stage of five fp16 planes [X hi | X lo | W hi | 2^11 W hi | W lo].
+struct TailSArgs {
+  const float *X1, *W1, *X2, *W2;  // scores: u [rows][x1_ld] . W5 [n_cob*32][k1];  values: mo [rows][x2_ld] . Wv [n_cob*32][k2]
+  const float *vec;                // [bias_s | bias_v | gamma | beta], n_cob * 32 floats each
+  float *out;                      // [rows >> (NPXL - 4)][out_ld]
+  float *out2;                     // optional copy of the first out2_n channels into another per-point buffer [..][out2_ld]
+  int out2_ld, out2_n;
+  int rows, x1_ld, k1, x2_ld, k2, n_cob, gs, n_norm, out_ld;
+  float inv_count;
+};
+
+__device__ __forceinline__ float gxs_other_half(float x) {  // value of lane ^ 32
+  uint32_t a = __float_as_uint(x), b = a;
+  lane32_swap(a, b);
+  return __uint_as_float((threadIdx.x & 32) ? a : b);
+}
+
+template <int NPXL>
+__global__ __launch_bounds__(256, 2) void attn_tail_split_kernel(TailSArgs a) {
+  constexpr int CBW = 2, TN = 64;
+  constexpr int LDK = TileT<SLIDE_PREC_SPLIT>::LDK;
+  constexpr int XP = 8, WP = 2;
+  constexpr int KLOG = NPXL - 4, KN = 1 << KLOG, GPB = 32 / KN;  // neighbours per point, points per 32-row block
+  constexpr int WPS = (1 << NPXL) / 64;                            // waves per sample
+  constexpr int STAGE = (2 * TM + 3 * TN) * LDK;                   // halves
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16 *const Xh = reinterpret_cast<_Float16 *>(smem_raw);
+  _Float16 *const Xl = Xh + TM * LDK, *const Wh = Xl + TM * LDK, *const Ws = Wh + TN * LDK, *const Wl = Ws + TN * LDK;
+  const int ntc = (a.n_cob + CBW - 1) / CBW;
+  const int xcd = blockIdx.x & 7, q0 = blockIdx.x >> 3;
+  const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;
+  if (tr * TM >= a.rows) return;
+  const int row0 = tr * TM, cob0 = tc * CBW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+  const int l_row = tid >> 3, l_c = (tid & 7) * 4;
+  float *const vec_lds = reinterpret_cast<float *>(smem_raw + (size_t)STAGE * 2);  // [4 vectors][CBW*32]
+  for (int i = tid; i < 4 * CBW * 32; i += 256) {
+    const int which = i / (CBW * 32), c = i - which * (CBW * 32), gc = cob0 * 32 + c;
+    vec_lds[i] = gc < a.n_cob * 32 ? a.vec[(size_t)which * a.n_cob * 32 + gc] : 0.f;
+  }
+  // one split contraction: acc[cb][rb] = D[row][channel] (lane: channel col of block cb; reg r: row (r&3) + 8 (r>>2) + 4 half)
+  auto run = [&](const float *Xp, const float *Wp, int x_ld, int k_pad, f32x16 (&acc)[CBW][2]) __attribute__((always_inline)) {
+    float4 xr[XP], wr[WP];
+    auto load_chunk = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+      for (int p = 0; p < XP; ++p) {
+        int grow = row0 + p * 32 + l_row;
+        grow = grow < a.rows ? grow : a.rows - 1;
+        xr[p] = *reinterpret_cast<const float4 *>(Xp + (size_t)grow * x_ld + kc * BK + l_c);
+      }
+#pragma unroll
+      for (int p = 0; p < WP; ++p) {
+        int gco = cob0 * 32 + p * 32 + l_row;
+        gco = gco < a.n_cob * 32 ? gco : a.n_cob * 32 - 1;  // (channels beyond the matrix are never stored)
+        wr[p] = *reinterpret_cast<const float4 *>(Wp + (size_t)gco * k_pad + kc * BK + l_c);
+      }
+    };
+    auto store_chunk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int p = 0; p < XP; ++p) {
+        f16x4 hi, lo;
+        gxs_split4(xr[p], hi, lo);
+        *reinterpret_cast<f16x4 *>(Xh + (p * 32 + l_row) * LDK + l_c) = hi;
+        *reinterpret_cast<f16x4 *>(Xl + (p * 32 + l_row) * LDK + l_c) = lo;
+      }
+#pragma unroll
+      for (int p = 0; p < WP; ++p) {
+        f16x4 hi, hs, lo;
+        gxs_split4w(wr[p], hi, hs, lo);
+        *reinterpret_cast<f16x4 *>(Wh + (p * 32 + l_row) * LDK + l_c) = hi;
+        *reinterpret_cast<f16x4 *>(Ws + (p * 32 + l_row) * LDK + l_c) = hs;
+        *reinterpret_cast<f16x4 *>(Wl + (p * 32 + l_row) * LDK + l_c) = lo;
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < CBW; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nk = k_pad / BK;
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+      if (kc + 1 < nk) load_chunk(kc + 1);
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        f16x8 xh[2], xl[2], wh[CBW], ws[CBW], wl[CBW];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          xh[rb] = *reinterpret_cast<const f16x8 *>(Xh + (wave * 64 + rb * 32 + col) * LDK + st * 16 + half * 8);
+          xl[rb] = *reinterpret_cast<const f16x8 *>(Xl + (wave * 64 + rb * 32 + col) * LDK + st * 16 + half * 8);
+        }
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb) {
+          wh[cb] = *reinterpret_cast<const f16x8 *>(Wh + (cb * 32 + col) * LDK + st * 16 + half * 8);
+          ws[cb] = *reinterpret_cast<const f16x8 *>(Ws + (cb * 32 + col) * LDK + st * 16 + half * 8);
+          wl[cb] = *reinterpret_cast<const f16x8 *>(Wl + (cb * 32 + col) * LDK + st * 16 + half * 8);
+        }
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) {  // rows x channels
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[rb], ws[cb], acc[cb][rb], 0, 0, 0);
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[rb], wh[cb], acc[cb][rb], 0, 0, 0);
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[rb], wl[cb], acc[cb][rb], 0, 0, 0);
+          }
+      }
+      __syncthreads();  // every wave is done reading the stage
+      if (kc + 1 < nk) {
+        store_chunk();
+        __syncthreads();
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < CBW; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= 1.f / 2048.f;
+  };
+  f32x16 vacc[CBW][2], sacc[CBW][2];
+  run(a.X2, a.W2, a.x2_ld, a.k2, vacc);  // values first
+
+  // ---- values: bias, GroupNorm over the sample (rows of WPS waves x the gs adjacent channel lanes), ReLU -- in place
+  float *const red = reinterpret_cast<float *>(smem_raw);  // [wave][cb][32 channels][sum, sumsq] (the stage is free: run() ends on a barrier)
+  const float *b_s = vec_lds, *b_v = vec_lds + CBW * 32, *gam = vec_lds + 2 * CBW * 32, *bet = vec_lds + 3 * CBW * 32;
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb) {
+    const float bv = b_v[cb * 32 + col];
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float x = vacc[cb][rb][r] + bv;
+        vacc[cb][rb][r] = x;
+        s += x;
+        ss = fmaf(x, x, ss);
+      }
+    s += gxs_other_half(s);
+    ss += gxs_other_half(ss);
+    if (half == 0) *reinterpret_cast<f32x2 *>(red + ((wave * CBW + cb) * 32 + col) * 2) = f32x2{s, ss};
+  }
+  __syncthreads();
+  const int w0 = (wave / WPS) * WPS;
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb) {
+    f32x2 t = {0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < WPS; ++w) t += *reinterpret_cast<const f32x2 *>(red + (((w0 + w) * CBW + cb) * 32 + col) * 2);
+    float s = t[0], ss = t[1];
+    // the gs channels of a group sit in gs adjacent lanes (physical GroupNorm layout: power-of-two runs)
+    if (a.gs >= 2) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1, 0xF, 0xF, true));
+                     ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0xB1, 0xF, 0xF, true)); }
+    if (a.gs >= 4) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E, 0xF, 0xF, true));
+                     ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x4E, 0xF, 0xF, true)); }
+    if (a.gs >= 8) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x141, 0xF, 0xF, true));
+                     ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x141, 0xF, 0xF, true)); }
+    if (a.gs >= 16) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x140, 0xF, 0xF, true));
+                      ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x140, 0xF, 0xF, true)); }
+    if (a.gs >= 32) { s += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s), 0x401F));
+                      ss += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(ss), 0x401F)); }
+    const float mean = s * a.inv_count;
+    const float var = fmaxf(ss * a.inv_count - mean * mean, 0.f);
+    float g = gam[cb * 32 + col] * __builtin_amdgcn_rsqf(var + GN_EPS);
+    float bt = bet[cb * 32 + col] - mean * g;
+    if ((cob0 + cb) * 32 + col >= a.n_norm) { g = 1.f; bt = 0.f; }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) vacc[cb][rb][r] = fmaxf(fmaf(vacc[cb][rb][r], g, bt), 0.f);
+  }
+  __syncthreads();  // every wave has read the statistics: the stage is free for the score contraction
+  run(a.X1, a.W1, a.x1_ld, a.k1, sacc);
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb) {
+    const float bs = b_s[cb * 32 + col];
+    // ---- softmax over the K neighbour rows of every point, weighted sum of the values, one row out per point
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int pg = 0; pg < GPB; ++pg) {
+        // rows of point pg inside the 32-row block: 16 -> regs 8pg .. 8pg+7 (both halves); 8 -> regs 4pg .. 4pg+3
+        constexpr int RPG = 16 / GPB;
+        float sc[RPG];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < RPG; ++j) {
+          sc[j] = sacc[cb][rb][pg * RPG + j] + bs;
+          m = fmaxf(m, sc[j]);
+        }
+        m = fmaxf(m, gxs_other_half(m));
+        float den = 0.f, num = 0.f;
+#pragma unroll
+        for (int j = 0; j < RPG; ++j) {
+          const float e = expf(sc[j] - m);
+          den += e;
+          num = fmaf(e, vacc[cb][rb][pg * RPG + j], num);
+        }
+        den += gxs_other_half(den);
+        num += gxs_other_half(num);
+        const int rbase = row0 + wave * 64 + rb * 32 + pg * KN;
+        if (half == 0 && rbase < a.rows && cob0 + cb < a.n_cob) {
+          const float v = num / den;
+          a.out[(size_t)(rbase >> KLOG) * a.out_ld + (cob0 + cb) * 32 + col] = v;
+          // second copy into the columns of a later concatenation buffer (the skip input of an FP block's second Mlp)
+          if (a.out2 && (cob0 + cb) * 32 + col < a.out2_n)
+            a.out2[(size_t)(rbase >> KLOG) * a.out2_ld + (cob0 + cb) * 32 + col] = v;
+        }
+      }
+  }
+}
+
+}  // namespace
+
+// SLIDE_OP_GEMM_GX with f[0] == 3: float tables, float row-major weights [n_cob*32][k_pad], float outputs (split arithmetic)
+int slide_launch_gemm_gxs(const SlideOp &o, hipStream_t s) {
+  GemmArgs a = GemmArgs();
+  a.gx_ta = o.p[0]; a.W = o.p[1]; a.epi = (const SlideEpi *)o.p[2];
+  a.in_scale = (const float *)o.p[3]; a.in_shift = (const float *)o.p[4];
+  a.gx_tb = o.p[5]; a.in_add = (const float *)o.p[6]; a.gx_add_idx = (const int *)o.p[7];
+  a.gidx = (const int *)o.p[8]; a.gx_d2 = (const float *)o.p[9]; a.gx_w = (const float *)o.p[10];
+  a.gx_vv = (const float *)o.p[11];
+  a.rows = o.i[0]; a.gx_ld = o.i[1]; a.k_pad = o.i[2]; a.n_cob = o.i[3]; a.in_bs = o.i[5];
+  a.gx_mode = o.i[6]; a.add_bs = o.i[7]; a.gx_add_idx_stride = o.i[8]; a.gx_vbs = o.i[9];
+  a.aff_tps = 1;
+  const int npxl = o.i[4];
+  if (a.k_pad % 32 || a.k_pad <= 0 || a.gx_ld % 4 || a.rows <= 0 || a.n_cob <= 0 || !a.gx_ta || !a.gx_tb) return -3;
+  if ((uintptr_t)a.gx_ta % 16 || (uintptr_t)a.gx_tb % 16 || (uintptr_t)a.W % 16) return -3;
+  if (a.gx_mode != 0 && (!a.in_scale || !a.in_shift || (uintptr_t)a.in_scale % 16 || (uintptr_t)a.in_shift % 16 || a.in_bs % 4)) return -3;
+  if (a.in_add && ((uintptr_t)a.in_add % 16 || a.add_bs % 4 || a.gx_add_idx_stride % 4)) return -3;
+  if (a.gx_vv && ((uintptr_t)a.gx_vv % 16 || a.gx_vbs % 8)) return -3;
+  if (npxl == 7 && (!a.gidx || !a.gx_d2 || !a.gx_w)) return -3;
+  const bool m1 = a.gx_mode != 0;
+  if (npxl == 8) return m1 ? launch_gxs<8, 1>(a, s) : launch_gxs<8, 0>(a, s);
+  if (npxl == 7) return m1 ? launch_gxs<7, 1>(a, s) : launch_gxs<7, 0>(a, s);
+  return -4;
+}
+
+// SLIDE_OP_ATTN_TAIL with f[1] bit 3: float rows, float row-major weights, float output (split arithmetic)
+int slide_launch_attn_tail_split(const SlideOp &o, hipStream_t s) {
+  TailSArgs a;
+  a.X1 = (const float *)o.p[0]; a.W1 = (const float *)o.p[1]; a.X2 = (const float *)o.p[2]; a.W2 = (const float *)o.p[3];
+  a.out = (float *)o.p[4]; a.vec = (const float *)o.p[5];
+  a.out2 = (float *)o.p[7]; a.out2_ld = (int)o.f[2]; a.out2_n = (int)o.f[3];
+  a.rows = o.i[0]; a.x1_ld = o.i[1]; a.k1 = o.i[2]; a.x2_ld = o.i[3]; a.k2 = o.i[4]; a.n_cob = o.i[5];
+  a.gs = o.i[7]; a.n_norm = o.i[8]; a.out_ld = o.i[9];
+  a.inv_count = o.f[0];
+  const int npxl = o.i[6];
+  if (a.k1 % 32 || a.k2 % 32 || a.k1 <= 0 || a.k2 <= 0 || a.rows <= 0 || a.n_cob <= 0 || a.x1_ld % 4 || a.x2_ld % 4) return -3;
+  if ((uintptr_t)a.X1 % 16 || (uintptr_t)a.X2 % 16 || (uintptr_t)a.W1 % 16 || (uintptr_t)a.W2 % 16 || !a.out || !a.vec) return -3;
+  constexpr int LDK = TileT<SLIDE_PREC_SPLIT>::LDK;
+  const size_t shm = (size_t)(2 * TM + 3 * 64) * LDK * 2 + 4 * 2 * 32 * 4 + 64;
+  const int ntc = (a.n_cob + 1) / 2, ntr = (a.rows + TM - 1) / TM;
+  const int grid = ((ntr + 7) / 8) * 8 * ntc;
+  if (npxl == 8) hipLaunchKernelGGL(attn_tail_split_kernel<8>, dim3(grid), dim3(256), shm, s, a);
+  else if (npxl == 7) hipLaunchKernelGGL(attn_tail_split_kernel<7>, dim3(grid), dim3(256), shm, s, a);
+  else return -4;
+  return (int)hipGetLastError();
+}

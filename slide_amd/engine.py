@@ -161,6 +161,7 @@ class DenoiserEngine:
     # chunk-major storage (see _buf): off unless __init__ enables it (bare plan builders in tests / tools stay row-major)
     use_cm = False
     use_gx = False
+    use_gxs = False
     _cm = frozenset()
     _cm_copy = {}
 
@@ -197,6 +198,10 @@ class DenoiserEngine:
                        and not _os.environ.get("SLIDE_XS", ""))
         # pair decomposition of the blocks' first layers + generated-X GEMMs (csrc/gemm_gx.hip; SLIDE_GX=0: the round-2 plan)
         self.use_gx = self.use_cm and _os.environ.get("SLIDE_GX", "1") != "0"
+        # round 5: the pair decomposition in the SPLIT arithmetic (csrc/gemm_gxs.hip): float pair tables, generated-X split GEMMs,
+        # PAIR residuals on float rows, the split attention tail -- the K-expanded first-layer outputs, scores and values of a block
+        # never reach memory (SLIDE_GXS=0: the fp32-structured plan of round 4)
+        self.use_gxs = self.prec == 2 and _os.environ.get("SLIDE_GXS", "1") != "0"
         self._cm = set()
         self._cm_copy = {}  # per-point table (data_ptr) -> its chunk-major copy, written by the table's producer as well
         self.ops = []
@@ -265,7 +270,7 @@ class DenoiserEngine:
            in_cols: physical column index of every logical input channel (None = identity)."""
         if gx is not None:  # generated-X GEMM of the pair decomposition (SLIDE_OP_GEMM_GX): X is never stored
             rows, ld, x_ld = gx["rows"], gx["k_pad"], 32
-            assert X is None and gather is None and gn_fin is None and npx_log2 in (7, 8) and self.use_cm
+            assert X is None and gather is None and gn_fin is None and npx_log2 in (7, 8) and (self.use_cm or self.use_gxs)
         else:
             rows, ld = X.shape
             x_ld = self._ldp(X)
@@ -301,7 +306,7 @@ class DenoiserEngine:
         n_cob = W.shape[0] // 32
         # chunk-major weights [k / 32][n][32] for the ring kernels of the 128- / 256-row samples (the 16-row launches run the
         # split-K small-launch kernel, which reads row-major weights)
-        w_cm = bool(self.use_cm and npx_log2 >= 7) or gx is not None
+        w_cm = bool(self.use_cm and npx_log2 >= 7) or (gx is not None and self.prec == 1)
         Wst = np.ascontiguousarray(W.reshape(W.shape[0], ld // 32, 32).transpose(1, 0, 2)) if w_cm else W
         Wd = self.A.put(Wst, torch.float16 if self.prec == 1 else torch.float32)
         epis = (SlideEpi * n_cob)()
@@ -341,10 +346,10 @@ class DenoiserEngine:
                     # PAIR residual: residual(p, j) = ta[q] + tb[p] (+ d2 vd + w vw): (ta, tb fp16 tables, column offset,
                     # vd | vw fp32 [2][Opad] for the 8-neighbour samples or None)
                     rta, rtb, rcoff, rvv = sg["res_pair"]
-                    assert rta.dtype == torch.float16 and rta.shape == rtb.shape and rta.shape[0] == self.B * 16
-                    assert (rcoff + 32 * j) % 8 == 0 and rta.shape[1] >= rcoff + Opad
-                    e.residual = rta.data_ptr() + 2 * (rcoff + 32 * j)
-                    e.res_b = rtb.data_ptr() + 2 * (rcoff + 32 * j)
+                    assert rta.dtype == (torch.float16 if self.prec == 1 else torch.float32) and rta.shape == rtb.shape
+                    assert rta.shape[0] == self.B * 16 and (rcoff + 32 * j) % 8 == 0 and rta.shape[1] >= rcoff + Opad
+                    e.residual = rta.data_ptr() + rta.element_size() * (rcoff + 32 * j)
+                    e.res_b = rtb.data_ptr() + rta.element_size() * (rcoff + 32 * j)
                     e.res_ld = rta.shape[1]
                     if rvv is None:
                         assert npx_log2 == 8
@@ -458,15 +463,22 @@ class DenoiserEngine:
             self.ops[-1].p[9] = pair_tabs[0].data_ptr()
         self.flops += 2 * rows * sum(int(s["w"].size) for s in segs)
 
+    @staticmethod
+    def _split1_ok(*ws):
+        """the single-accumulator split kernels (csrc/gemm_gxs.hip) scale the weight's high term by 2^11 in fp16: |w| < 32"""
+        return all(float(np.abs(w).max()) < 31.0 for w in ws if w.size)
+
     def _emit_gx(self, gx, npx_log2, rows, ld, n_cob, Wd, ed, segs, W, vec_list, in_affine, pair_tabs):
         """SLIDE_OP_GEMM_GX (include/slide_engine.h): gx = dict(ta, tb (fp16 tables [B*16][t_ld]), coff (first table column),
         k_pad, rows, mode, add=(tensor, offset, per-sample stride, idx tensor or None, idx stride) or None, vv = per-sample
         (vd | vw) fp32 [B][2][t_ld] of the 8-neighbour samples or None); pair_tabs = (neighbour, d2, w tables) for those"""
         ta, tb, coff = gx["ta"], gx["tb"], gx["coff"]
-        assert ta.dtype == torch.float16 and ta.shape == tb.shape and coff % 8 == 0 and ta.shape[1] >= coff + ld
+        tes = ta.element_size()
+        assert ta.dtype == (torch.float16 if self.prec == 1 else torch.float32) and ta.shape == tb.shape and coff % 8 == 0
+        assert ta.shape[1] >= coff + ld
         fl = 2 * rows * sum(int(s_["w"].size) for s_ in segs)
         self.gemm_flops[len(self.ops)] = fl
-        rd = 2 * (rows >> npx_log2) * 16 * ld * 2 + W.size * 2
+        rd = 2 * (rows >> npx_log2) * 16 * ld * tes + W.size * tes
         wr = sum(rows * v[2] * v[1]["out"].element_size() for v in vec_list)
         self.gemm_bytes[len(self.ops)] = (rd, wr)
         sc = sh = None
@@ -496,14 +508,20 @@ class DenoiserEngine:
             shm128 = lambda k_: k_ * (16384 + 4096 * nsamp) + (4 * 40 + 4 * 96) * 4 + nsamp * nvec * ld * 2 + 16
             nst = 3 if shm128(3) <= 80 * 1024 else 2
         self.kernel_names[len(self.ops)] = "gemm_gx_%skernel<%d, %d, %d>" % (("", "n64_", "n64w_")[n64], npx_log2, nst, gx["mode"])
+        if self.prec == 2:  # split arithmetic on float tables: csrc/gemm_gxs.hip (256 x 64 tiles)
+            if not self._split1_ok(W):
+                raise SlideHipError("a weight of magnitude >= 31 in a generated-X layer: the split pair-decomposition kernels scale the "
+                                    "weights' high terms by 2^11 in fp16 -- build this plan with SLIDE_GXS=0")
+            n64 = 3
+            self.kernel_names[len(self.ops)] = "gemm_gxs_kernel<%d, %d>" % (npx_log2, gx["mode"])
         self._emit(make_op(OP_GEMM_GX,
                            i=(rows, ta.shape[1], ld, n_cob, npx_log2, in_bs, gx["mode"], 0 if add is None else add[2],
                               0 if add is None else add[4], 0 if vv is None else 2 * vv.shape[2]),
                            f=(float(n64),),
-                           p=(ta.data_ptr() + 2 * coff, Wd.data_ptr(), ed.data_ptr(),
+                           p=(ta.data_ptr() + tes * coff, Wd.data_ptr(), ed.data_ptr(),
                               None if sc is None else sc.data_ptr() + 4 * aff_off,
                               None if sh is None else sh.data_ptr() + 4 * aff_off,
-                              tb.data_ptr() + 2 * coff,
+                              tb.data_ptr() + tes * coff,
                               None if add is None else add[0].data_ptr() + 4 * add[1],
                               None if add is None or add[3] is None else add[3].data_ptr(),
                               None if pair_tabs is None else pair_tabs[0].data_ptr(),
@@ -577,7 +595,7 @@ class DenoiserEngine:
         """second_mlp -> rest_mlp of an SA block as ONE launch (SLIDE_OP_SA_CHAIN, csrc/gemm_gx.hip: h2 stays in registers).
         Returns False when the shapes are outside what the kernel covers (the two-launch path then runs)."""
         sd, B = self.sd, self.B
-        if npx_log2 != 8 or os.environ.get("SLIDE_SA_CHAIN", "1") == "0" or pair["vv"] is not None:
+        if npx_log2 != 8 or os.environ.get("SLIDE_SA_CHAIN", "1") == "0" or pair["vv"] is not None or self.prec != 1:
             return False
         w1, w2 = self._w(pfx + ".second_mlp.0.weight"), self._w(pfx + ".rest_mlp.0.weight")
         c2, c1 = w1.shape
@@ -667,8 +685,9 @@ class DenoiserEngine:
             ps["out"] = None
             psegs.append(ps)
         assert sum(3 for _ in ("rel", "abs", "ctr")) + (2 if coords.get("d2") is not None else 0) + C == segs[0]["w"].shape[1]
-        ta = self.A.zeros(B * 16, ldy, dtype=torch.float16)
-        tb = self.A.zeros(B * 16, ldy, dtype=torch.float16)
+        tdt = torch.float16 if self.prec == 1 else torch.float32  # (split plans: float tables)
+        ta = self.A.zeros(B * 16, ldy, dtype=tdt)
+        tb = self.A.zeros(B * 16, ldy, dtype=tdt)
         fp = K == 8
         d = [self.A.put(wa), self.A.put(wb)]
         vv = rvv_all = None
@@ -695,9 +714,10 @@ class DenoiserEngine:
         self._gemm(feat_in, 4, list(lead_segs) + ysegs)
         ed = self._epi_only(psegs, 1 << npx_log2)
         # loop-invariant when the coordinates are a fixed condition?  No: y changes every step.
-        v2 = ldy <= 2048 and os.environ.get("SLIDE_PAIR_NORM_V2", "0") != "0"
-        assert fin is None or v2
-        self._emit(make_op(OP_PAIR_NORM, i=(B, ldy, K, 2 if v2 else 1),
+        v2 = ldy <= 2048 and (os.environ.get("SLIDE_PAIR_NORM_V2", "0") != "0" or self.prec != 1)
+        assert (fin is None or v2) and (self.prec == 1 or v2)
+        self.kernel_names[len(self.ops)] = "pair_norm2_kernel<%s, %s>" % ("true" if fp else "false", "_Float16" if self.prec == 1 else "float")
+        self._emit(make_op(OP_PAIR_NORM, i=(B, ldy, K, 2 if v2 else 1, int(self.prec != 1)),
                            p=(Y.data_ptr(), self.xyz.data_ptr(), d[0].data_ptr(), d[1].data_ptr(), ed.data_ptr(),
                               ta.data_ptr(), tb.data_ptr(), self.kidx.data_ptr() if fp else None,
                               self.kd2.data_ptr() if fp else None, self.kw.data_ptr() if fp else None,
@@ -962,7 +982,7 @@ class DenoiserEngine:
             # the per-sample table pass also finalises the joint GroupNorm (SLIDE_OP_PAIR_NORM version 2)
             # (SLIDE_PAIR_NORM_V2=1, opt-in: one 1024-thread workgroup per sample that also finalises the joint GroupNorm -- 3 %
             #  faster for a single chain, 5 % slower with four chains in flight: sixteen waves must find room on ONE CU)
-            pair_fin = ldT <= 2048 and os.environ.get("SLIDE_PAIR_NORM_V2", "0") != "0"
+            pair_fin = ldT <= 2048 and (os.environ.get("SLIDE_PAIR_NORM_V2", "0") != "0" or self.use_gxs)
             ctx = self._pair_first(npx_log2, K, feat_tab, Cf, [mlp_first, mlp_res, kseg], coords,
                                    fin=fin_struct() if pair_fin else None,
                                    lead_segs=([qctx["qseg"]] + [e["qseg"] for e in extra_q]) if q_rides else ())
@@ -1051,6 +1071,12 @@ class DenoiserEngine:
                     np.array_equal(vlay[0], np.arange(cout))):
                 self._lane = 0
                 return ("fused", u, lay)  # scores are computed inside the fused attention tail (finish)
+            # round 5: the same tail in the split arithmetic on float rows (csrc/gemm_gxs.hip attn_tail_split_kernel;
+            # SLIDE_TAIL_SPLIT=0: scores GEMM + values GEMM + combine launch).  Its single-accumulator split needs |w| < 32.
+            if (self.use_gxs and os.environ.get("SLIDE_TAIL_SPLIT", "1") != "0" and np.array_equal(vlay[0], np.arange(cout))
+                    and self._split1_ok(self._w(apfx + ".weight_conv.5.weight"), self._w(apfx + ".feat_out_conv.0.weight"))):
+                self._lane = 0
+                return ("fused", u, lay)
             S = self._buf(rows, cout)
             self._gemm(u, npx_log2, [dict(w=self._w(apfx + ".weight_conv.5.weight"), bias=sd[apfx + ".weight_conv.5.bias"],
                                           mode=EPI_RAW, out=S)], in_cols=lay[0])
@@ -1074,7 +1100,10 @@ class DenoiserEngine:
                 vec[2, :gam.shape[0]] = gam
                 vec[3, :gam.shape[0]] = sd[apfx + ".feat_out_conv.1.group_norm.bias"]
                 cmw = (lambda w: np.ascontiguousarray(w.reshape(w.shape[0], -1, 32).transpose(1, 0, 2))) if self.use_cm else (lambda w: w)
-                d = [self.A.put(cmw(w5), torch.float16), self.A.put(cmw(wv), torch.float16), self.A.put(vec)]
+                wdt = torch.float16 if self.prec == 1 else torch.float32  # (split tail: float row-major weights)
+                d = [self.A.put(cmw(w5), wdt), self.A.put(cmw(wv), wdt), self.A.put(vec)]
+                if self.prec != 1:
+                    self.kernel_names[len(self.ops)] = "attn_tail_split_kernel<%d>" % npx_log2
                 assert out.dtype == self.adt and u.dtype == self.adt and mo.dtype == self.adt and not self._is_cm(out)
                 self._sync(1, 0)
                 self.flops += 2 * rows * (w5.size + wv.size)
@@ -1087,7 +1116,7 @@ class DenoiserEngine:
                                                     vlay[3], vlay[2], out.shape[1]),
                                         # f[1]: 1 = chunk-major operands, + 2 = two-stage ring at three workgroups per CU (opt-in,
                                         # SLIDE_TAIL_OCC3=1: measured neutral, 373.0 vs 372.3 shapes/s)
-                                        f=(1.0 / (vlay[4] * npx), (1.0 if self.use_cm else 0.0) +
+                                        f=(1.0 / (vlay[4] * npx), (1.0 if self.use_cm else 0.0) + (8.0 if self.prec != 1 else 0.0) +
                                            (2.0 if os.environ.get("SLIDE_TAIL_OCC3", "0") != "0" else 0.0) +
                                            (4.0 if (Cp // 32) % 4 == 0 and Cp // 32 >= int(os.environ.get("SLIDE_TAIL_WIDE", "1000")) else 0.0)),
                                         p=(u.data_ptr(), d[0].data_ptr(), mo.data_ptr(), d[1].data_ptr(), out.data_ptr(),
@@ -1137,7 +1166,7 @@ class DenoiserEngine:
         c_last = sd[mp + ".res_connect.weight"].shape[0]
         mo = self._buf(rows, c_last, cm=True)
         out = self._buf(B * 16, c_last)
-        if self.use_gx:
+        if self.use_gx or self.use_gxs:
             # pair decomposition (csrc/gemm_gx.hip): no grouped input, no h1 / r / key buffers; rows in natural neighbour order
             first, res = self._mlp_segments(mp, self.tvec, self.cvec, None, None)
             pair = (feat_in, C, dict(rel=C, abs=C + 3, ctr=C + 6))
@@ -1173,7 +1202,7 @@ class DenoiserEngine:
         c_last = sd[m1 + ".res_connect.weight"].shape[0]
         mo = self._buf(rows, c_last, cm=True)
         pair = h1 = r = g = gather = None
-        if self.use_gx:  # pair decomposition: group_knn's channels are [feats | d2 | w | abs | rel | centre]
+        if self.use_gx or self.use_gxs:  # pair decomposition: group_knn's channels are [feats | d2 | w | abs | rel | centre]
             pair = (Kf, C2, dict(d2=C2, w=C2 + 1, abs=C2 + 2, rel=C2 + 5, ctr=C2 + 8))
         else:
             g, gather, _ = self._grouped_input(OP_ASSEMBLE_FP, Kf, C2, Cg, K)
