@@ -141,6 +141,11 @@ enum {
   SLIDE_OP_SA_CHAIN_P = 35, /* an SA block's fused Mlp chain (SLIDE_OP_SA_CHAIN) and the per-point query GEMM of its attention (SLIDE_OP_GEMM, 16 rows per
                              * sample, input affine + statistics finalisation) in ONE launch -- both depend on the block's pair tables only:
                              * p[0] = HOST pointer to the two SlideOp (chain first), kept alive by the plan */
+  SLIDE_OP_PP_STAGE = 36,   /* split plans (round 5, csrc/gemm_gxs.hip): a run of consecutive per-point launches of one block -- 16-rows-per-sample
+                             * SLIDE_OP_GEMM in the split arithmetic (no gather / statistics finalisation / per-point pre_add) and SLIDE_OP_PAIR_NORM
+                             * version 2 on float tables -- as ONE launch, one workgroup per sample walking the steps; the dense layers are exact
+                             * fp32 FMA chains on the vector ALUs.  p[0] = HOST pointer to {int64 n, B; n records of 16 int64 slots} (device
+                             * pointers inside; layout in csrc/gemm_gxs.hip slide_launch_pp_stage), kept alive by the plan.  i: B, n */
   SLIDE_OP_HEAD_UPDATE = 33,/* output head (two per-point GEMMs with the GroupNorm between them) + DDPM update + device-side t -= 1 as one launch
                              * (csrc/engine.hip head_update_kernel): p[0] = HOST pointer to a SlideHeadArgs block */
   SLIDE_OP_BLOCK_BODY = 30, /* the whole K-expanded body of an SA / FP block whose widths are <= 256 channels in one launch (csrc/block_body.hip):

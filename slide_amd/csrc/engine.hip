@@ -24,6 +24,7 @@ int slide_launch_gemm_xs(const GemmArgs &a, int npxl, int cbw, bool aff, bool ga
 int slide_launch_gemm_gx(const SlideOp &o, hipStream_t s);
 int slide_launch_gemm_gxs(const SlideOp &o, hipStream_t s);  // gemm_gxs.hip (split arithmetic, float tables)
 int slide_launch_attn_tail_split(const SlideOp &o, hipStream_t s);  // gemm_gxs.hip
+int slide_launch_pp_stage(const SlideOp &o, hipStream_t s);  // gemm_gxs.hip
 int slide_launch_pair_norm(const SlideOp &o, hipStream_t s);
 int slide_launch_sa_chain(const SlideOp &o, hipStream_t s);
 int slide_launch_block_body(const SlideOp &o, hipStream_t s);  // block_body.hip
@@ -2484,6 +2485,8 @@ int run_op(const SlideOp &o, hipStream_t s) {
       return slide_launch_gemm_gx_dual(o, s);
     case SLIDE_OP_PAIR_NORM:
       return slide_launch_pair_norm(o, s);
+    case SLIDE_OP_PP_STAGE:
+      return slide_launch_pp_stage(o, s);
     case SLIDE_OP_PAIR_FIRST:
       return run_pair_first(o, s);
     case SLIDE_OP_SA_CHAIN:

@@ -15,6 +15,7 @@
 // Reference: pointnet2_ops/pointnet2_utils.py:383-430, :497-524 (grouped inputs), pointnet2_ops/pointnet2_modules.py:119-176
 // (Mlp_plus_t_emb), pointnet2_ops/attention.py:70-96.
 #include "gemm_common.h"
+#include "pair_norm.h"
 
 namespace {
 
@@ -43,7 +44,7 @@ __device__ __forceinline__ void gxs_split4w(const float4 v, f16x4 &hi, f16x4 &hs
 // centre rows; 16 x 8-row samples look their neighbours up once (nbr table) and keep the two per-slot scalars in registers.
 // The per-sample vectors (add | scale, shift | vd, vw) are staged once per workgroup in LDS.
 template <int NPXL, int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_gxs_kernel(GemmArgs a) {
+__device__ __forceinline__ void gemm_gxs_body(const GemmArgs &a, const int bid) {
   constexpr int NPX = 1 << NPXL;
   constexpr bool FP = NPXL == 7;
   constexpr int NSAMP = TM >> NPXL;  // 1 or 2
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void gemm_gxs_kernel(GemmArgs a) {
   _Float16 *const Xh = reinterpret_cast<_Float16 *>(smem_raw);
   _Float16 *const Xl = Xh + TM * LDK, *const Wh = Xl + TM * LDK, *const Ws = Wh + TN * LDK, *const Wl = Ws + TN * LDK;
   const int ntc = (a.n_cob + CBW - 1) / CBW;
-  const int xcd = blockIdx.x & 7, q0 = blockIdx.x >> 3;
+  const int xcd = bid & 7, q0 = bid >> 3;
   const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;  // the column tiles of a row tile share one XCD's L2 (tables + weights)
   if (tr * TM >= a.rows) return;
   const int row0 = tr * TM, cob0 = tc * CBW;
@@ -247,6 +248,19 @@ __global__ __launch_bounds__(256, 2) void gemm_gxs_kernel(GemmArgs a) {
   // float rows: the fp32 epilogue (mode 0 = the Mlp layers: PAIR residual on the float tables)
   gemm_epilogue<SLIDE_PREC_F32, NPXL, CBW, 2, MODE == 0>(a, acc, row0, cob0, wave, half, col, epi_lds, vec_lds,
                                                          reinterpret_cast<float *>(smem_raw));
+}
+
+template <int NPXL, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_gxs_kernel(GemmArgs a) {
+  gemm_gxs_body<NPXL, MODE>(a, blockIdx.x);
+}
+
+// the two independent generated-X GEMMs of a block (keys -> u: mode 1; first Mlp layer: mode 0) in ONE launch: they read the same
+// pair tables and nothing of each other -- one launch gap instead of two, and their workgroups fill the chip together
+template <int NPXL>
+__global__ __launch_bounds__(256, 2) void gemm_gxs_dual_kernel(GemmArgs a1, GemmArgs a0, int grid1) {
+  if ((int)blockIdx.x < grid1) gemm_gxs_body<NPXL, 1>(a1, blockIdx.x);
+  else gemm_gxs_body<NPXL, 0>(a0, blockIdx.x - grid1);
 }
 
 template <int NPXL, int MODE>
@@ -491,11 +505,147 @@ __global__ __launch_bounds__(256, 2) void attn_tail_split_kernel(TailSArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ per-point stage
+// Everything of a block that happens on the 16 points of a sample -- the per-point GEMM of the pair decomposition with the
+// attention queries riding on it, the pair-table pass with the joint GroupNorm, the query half of weight_conv.2, an FP block's
+// second Mlp_plus_t_emb, the output head -- is a chain of SMALL dense layers (16 rows, K <= 160, N <= 288 in the position net) whose
+// every step depends on the previous one for the SAME sample only.  As launches of their own they cost the chain a launch latency
+// each (17 of the split position plan's 30); here ONE workgroup per sample walks the whole chain:
+//   DENSE  y[16][n] = epilogue(W . x + bias): exact fp32 FMA chains on the vector ALUs (a thread owns one output channel and its 16
+//          rows; x transposed in LDS, read as broadcasts; the weights K-major so that a wave's loads coalesce) -- 16-row layers of
+//          this size do not fill a matrix tile, and fp32 FMAs need no operand split.  The epilogue is SlideEpi's (include/
+//          slide_engine.h): bias, PRE_RELU, GroupNorm over (gs channels x 16 rows) or STATS sums, POST_RELU, + addvec, + residual.
+//   PAIR   pair_norm2_body (pair_norm.h): tables ta / tb, key statistics, joint GroupNorm scale / shift.
+// A step reads what the previous step of the same workgroup wrote through L2 (device-scope fence + barrier between steps).
+struct PPDense {
+  const float *X, *Wt;        // X [B*16][x_ld]; Wt K-major [k_pad][n_cob*32]
+  const SlideEpi *epi;        // [n_cob]
+  const float *in_scale, *in_shift;  // consumer-side affine x' = x scale[b*in_bs + k] + shift[...] or NULL
+  int x_ld, k_pad, n_cob, in_bs;
+};
+struct PPPair {
+  const float *y, *xyz, *wa, *wb;
+  const SlideEpi *epi;
+  float *ta, *tb;
+  const int *nbr;
+  const float *d2t, *wt, *vv_in;
+  float *vv_out;
+  const SlideGnFin *fin;
+  int ld, K;
+};
+constexpr int PP_MAX = 8, PP_NT = 256, PP_KMAX = 192;
+struct PPArgs {
+  int n, B;
+  int kind[PP_MAX];   // 0 = dense d[idx], 1 = pair p[idx]
+  int idx[PP_MAX];
+  PPDense d[PP_MAX];
+  PPPair p[2];
+};
+
+__device__ __forceinline__ void pp_dense(const PPDense &d, const int b, float *xs) {
+  const int tid = threadIdx.x;
+  const int n = d.n_cob * 32;
+  // x transposed into LDS: xs[k][16 rows] (+ the consumer-side affine)
+  for (int i = tid; i < 16 * d.k_pad; i += PP_NT) {
+    const int r = i / d.k_pad, k = i - r * d.k_pad;
+    float v = d.X[((size_t)b * 16 + r) * d.x_ld + k];
+    if (d.in_scale) v = fmaf(v, d.in_scale[(size_t)b * d.in_bs + k], d.in_shift[(size_t)b * d.in_bs + k]);
+    xs[k * 16 + r] = v;
+  }
+  __syncthreads();
+  for (int c0 = 0; c0 < n; c0 += PP_NT) {
+    const int c = c0 + tid;
+    if (c >= n) continue;  // (whole 32-lane halves: n is a multiple of 32)
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float *wp = d.Wt + c;
+#pragma unroll 4
+    for (int k = 0; k < d.k_pad; ++k) {
+      const float w = wp[(size_t)k * n];
+      const float4 x0 = *reinterpret_cast<const float4 *>(xs + k * 16), x1 = *reinterpret_cast<const float4 *>(xs + k * 16 + 4);
+      const float4 x2 = *reinterpret_cast<const float4 *>(xs + k * 16 + 8), x3 = *reinterpret_cast<const float4 *>(xs + k * 16 + 12);
+      acc[0] = fmaf(w, x0.x, acc[0]); acc[1] = fmaf(w, x0.y, acc[1]); acc[2] = fmaf(w, x0.z, acc[2]); acc[3] = fmaf(w, x0.w, acc[3]);
+      acc[4] = fmaf(w, x1.x, acc[4]); acc[5] = fmaf(w, x1.y, acc[5]); acc[6] = fmaf(w, x1.z, acc[6]); acc[7] = fmaf(w, x1.w, acc[7]);
+      acc[8] = fmaf(w, x2.x, acc[8]); acc[9] = fmaf(w, x2.y, acc[9]); acc[10] = fmaf(w, x2.z, acc[10]); acc[11] = fmaf(w, x2.w, acc[11]);
+      acc[12] = fmaf(w, x3.x, acc[12]); acc[13] = fmaf(w, x3.y, acc[13]); acc[14] = fmaf(w, x3.z, acc[14]); acc[15] = fmaf(w, x3.w, acc[15]);
+    }
+    // ---- epilogue of channel c (SlideEpi of its 32-channel block; a group's channels are adjacent lanes)
+    const SlideEpi e = d.epi[c >> 5];
+    const int cl = c & 31;
+    const float bias = e.bias ? e.bias[cl] : 0.f;
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc[r] + bias;
+      if (e.flags & SLIDE_F_PRE_RELU) v = fmaxf(v, 0.f);
+      acc[r] = v;
+      s += v; ss = fmaf(v, v, ss);
+    }
+    if (e.mode == SLIDE_EPI_STATS) {
+      e.stats_sum[(size_t)b * e.stats_bs + cl] = s * e.stats_scale;
+      e.stats_sq[(size_t)b * e.stats_bs + cl] = ss * e.stats_scale;
+    } else if (e.mode == SLIDE_EPI_NORM) {
+      for (int m = 1; m < e.gs; m <<= 1) {
+        s += __shfl_xor(s, m, 64);
+        ss += __shfl_xor(ss, m, 64);
+      }
+      const float mean = s * e.inv_count;
+      const float var = fmaxf(ss * e.inv_count - mean * mean, 0.f);
+      float g = e.gamma[cl] * __builtin_amdgcn_rsqf(var + GN_EPS);
+      float sh = e.beta[cl] - mean * g;
+      if (cl >= e.n_norm) { g = 1.f; sh = 0.f; }  // MyGroupNorm leaves the last C % G channels as they are
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = fmaf(acc[r], g, sh);
+    }
+    float addv = 0.f;
+    if (e.addvec) {
+      const float *ap = e.addvec;
+      if (e.addvec_idx) ap += (size_t)e.addvec_idx[0] * e.addvec_idx_stride;  // row t of a per-timestep table
+      addv = ap[(size_t)b * e.addvec_bs + cl];
+    }
+    const float *res = reinterpret_cast<const float *>(e.residual);
+    float *out = reinterpret_cast<float *>(e.out);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc[r];
+      if (e.flags & SLIDE_F_POST_RELU) v = fmaxf(v, 0.f);
+      v += addv;
+      const size_t row = (size_t)b * 16 + r;
+      if (res) v += res[row * e.res_ld + cl];
+      out[row * e.out_ld + cl] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(PP_NT) void pp_stage_kernel(PPArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float pp_dyn[];  // [16][PP_NT + 1] floats of the FP pair form
+  __shared__ __attribute__((aligned(16))) float xs[PP_KMAX * 16];
+  const int b = blockIdx.x;
+  for (int st = 0; st < a.n; ++st) {
+    if (st) {
+      __threadfence();   // the previous step's stores are visible device-wide (and this CU's stale lines dropped)
+      __syncthreads();
+    }
+    if (a.kind[st] == 0) {
+      pp_dense(a.d[a.idx[st]], b, xs);
+    } else {
+      const PPPair &p = a.p[a.idx[st]];
+      if (p.K == 8)
+        pair_norm2_body<true, float, PP_NT>(p.ld, p.y, p.xyz, p.wa, p.wb, p.epi, p.ta, p.tb, p.nbr, p.d2t, p.wt, p.vv_in, p.vv_out, p.fin,
+                                            b, PP_NT, pp_dyn);
+      else
+        pair_norm2_body<false, float, PP_NT>(p.ld, p.y, p.xyz, p.wa, p.wb, p.epi, p.ta, p.tb, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                             p.fin, b, PP_NT, pp_dyn);
+    }
+  }
+}
+
 }  // namespace
 
-// SLIDE_OP_GEMM_GX with f[0] == 3: float tables, float row-major weights [n_cob*32][k_pad], float outputs (split arithmetic)
-int slide_launch_gemm_gxs(const SlideOp &o, hipStream_t s) {
-  GemmArgs a = GemmArgs();
+static int gxs_args_from_op(const SlideOp &o, GemmArgs &a) {
+  a = GemmArgs();
   a.gx_ta = o.p[0]; a.W = o.p[1]; a.epi = (const SlideEpi *)o.p[2];
   a.in_scale = (const float *)o.p[3]; a.in_shift = (const float *)o.p[4];
   a.gx_tb = o.p[5]; a.in_add = (const float *)o.p[6]; a.gx_add_idx = (const int *)o.p[7];
@@ -511,10 +661,64 @@ int slide_launch_gemm_gxs(const SlideOp &o, hipStream_t s) {
   if (a.in_add && ((uintptr_t)a.in_add % 16 || a.add_bs % 4 || a.gx_add_idx_stride % 4)) return -3;
   if (a.gx_vv && ((uintptr_t)a.gx_vv % 16 || a.gx_vbs % 8)) return -3;
   if (npxl == 7 && (!a.gidx || !a.gx_d2 || !a.gx_w)) return -3;
+  return 0;
+}
+
+// SLIDE_OP_GEMM_GX with f[0] == 3: float tables, float row-major weights [n_cob*32][k_pad], float outputs (split arithmetic)
+int slide_launch_gemm_gxs(const SlideOp &o, hipStream_t s) {
+  GemmArgs a;
+  const int st = gxs_args_from_op(o, a);
+  if (st != 0) return st;
+  const int npxl = o.i[4];
   const bool m1 = a.gx_mode != 0;
   if (npxl == 8) return m1 ? launch_gxs<8, 1>(a, s) : launch_gxs<8, 0>(a, s);
   if (npxl == 7) return m1 ? launch_gxs<7, 1>(a, s) : launch_gxs<7, 0>(a, s);
   return -4;
+}
+
+namespace {
+template <int NPXL>
+int launch_gxs_dual(const GemmArgs &a1, const GemmArgs &a0, hipStream_t s) {
+  constexpr int LDK = TileT<SLIDE_PREC_SPLIT>::LDK;
+  constexpr int NSAMP = TM >> NPXL;
+  auto lds = [&](const GemmArgs &a, int nvec) {
+    return (size_t)(2 * TM + 3 * 64) * LDK * 2 + (2 * EPI_DW + (2 * EPI_DW) % 4 + 2 * 96) * 4 + (size_t)NSAMP * nvec * a.k_pad * 4 +
+           (NPXL == 7 ? 3 * TM * 4 : 0) + 16;
+  };
+  const size_t s1 = lds(a1, 2 + (NPXL == 7 ? 2 : 0)), s0 = lds(a0, 1 + (NPXL == 7 ? 2 : 0));
+  const size_t shm = s1 > s0 ? s1 : s0;
+  if (shm > 80 * 1024) return -8;
+  const int ntr = (a1.rows + TM - 1) / TM;
+  const int g1 = ((ntr + 7) / 8) * 8 * ((a1.n_cob + 1) / 2), g0 = ((ntr + 7) / 8) * 8 * ((a0.n_cob + 1) / 2);
+  static bool attr_done[GXS_MAX_DEVICES] = {};
+  int d = 0;
+  (void)hipGetDevice(&d);
+  bool &attr_set = attr_done[d >= 0 && d < GXS_MAX_DEVICES ? d : 0];
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_gxs_dual_kernel<NPXL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              80 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_gxs_dual_kernel<NPXL>), dim3(g1 + g0), dim3(256), shm, s, a1, a0, g1);
+  return (int)hipGetLastError();
+}
+}  // namespace
+
+// SLIDE_OP_GEMM_GX_DUAL whose two ops carry f[0] == 3 (mode 1 first, then mode 0; same rows and sample size)
+int slide_launch_gemm_gxs_dual(const SlideOp *pr, hipStream_t s) {
+  GemmArgs a1, a0;
+  int st = gxs_args_from_op(pr[0], a1);
+  if (st == 0) st = gxs_args_from_op(pr[1], a0);
+  if (st != 0) return st;
+  if (a1.gx_mode == 0 || a0.gx_mode != 0 || a1.rows != a0.rows || pr[0].i[4] != pr[1].i[4]) return -3;
+  if (pr[0].i[4] == 8) st = launch_gxs_dual<8>(a1, a0, s);
+  else if (pr[0].i[4] == 7) st = launch_gxs_dual<7>(a1, a0, s);
+  else return -4;
+  if (st == -8) {  // (LDS of the dual form does not fit: two launches)
+    st = slide_launch_gemm_gxs(pr[0], s);
+    if (st == 0) st = slide_launch_gemm_gxs(pr[1], s);
+  }
+  return st;
 }
 
 // SLIDE_OP_ATTN_TAIL with f[1] bit 3: float rows, float row-major weights, float output (split arithmetic)
@@ -536,5 +740,45 @@ int slide_launch_attn_tail_split(const SlideOp &o, hipStream_t s) {
   if (npxl == 8) hipLaunchKernelGGL(attn_tail_split_kernel<8>, dim3(grid), dim3(256), shm, s, a);
   else if (npxl == 7) hipLaunchKernelGGL(attn_tail_split_kernel<7>, dim3(grid), dim3(256), shm, s, a);
   else return -4;
+  return (int)hipGetLastError();
+}
+
+// SLIDE_OP_PP_STAGE: p[0] = HOST pointer to {int32 n, B; then n records of 16 x 8-byte slots}:
+//   dense: slot 0 = 0, [1] X, [2] Wt (K-major float [k_pad][n_cob*32]), [3] epi, [4] in_scale, [5] in_shift, [6] x_ld, [7] k_pad, [8] n_cob, [9] in_bs
+//   pair : slot 0 = 1, [1] y, [2] xyz, [3] wa, [4] wb, [5] epi, [6] ta, [7] tb, [8] nbr, [9] d2, [10] w, [11] vv_in, [12] vv_out, [13] SlideGnFin*,
+//          [14] ld, [15] K
+int slide_launch_pp_stage(const SlideOp &o, hipStream_t s) {
+  const int64_t *h = (const int64_t *)o.p[0];
+  if (!h) return -3;
+  PPArgs a;
+  a.n = (int)h[0]; a.B = (int)h[1];
+  if (a.n <= 0 || a.n > PP_MAX || a.B <= 0) return -3;
+  int nd = 0, np = 0;
+  bool fp = false;
+  for (int i = 0; i < a.n; ++i) {
+    const int64_t *r = h + 2 + 16 * i;
+    if (r[0] == 0) {
+      if (nd >= PP_MAX) return -3;
+      PPDense &d = a.d[nd];
+      d.X = (const float *)r[1]; d.Wt = (const float *)r[2]; d.epi = (const SlideEpi *)r[3];
+      d.in_scale = (const float *)r[4]; d.in_shift = (const float *)r[5];
+      d.x_ld = (int)r[6]; d.k_pad = (int)r[7]; d.n_cob = (int)r[8]; d.in_bs = (int)r[9];
+      if (!d.X || !d.Wt || !d.epi || d.k_pad <= 0 || d.k_pad > PP_KMAX || d.n_cob <= 0) return -3;
+      a.kind[i] = 0; a.idx[i] = nd++;
+    } else {
+      if (np >= 2) return -3;
+      PPPair &q = a.p[np];
+      q.y = (const float *)r[1]; q.xyz = (const float *)r[2]; q.wa = (const float *)r[3]; q.wb = (const float *)r[4];
+      q.epi = (const SlideEpi *)r[5]; q.ta = (float *)r[6]; q.tb = (float *)r[7]; q.nbr = (const int *)r[8];
+      q.d2t = (const float *)r[9]; q.wt = (const float *)r[10]; q.vv_in = (const float *)r[11]; q.vv_out = (float *)r[12];
+      q.fin = (const SlideGnFin *)r[13]; q.ld = (int)r[14]; q.K = (int)r[15];
+      if (!q.y || !q.xyz || !q.ta || !q.tb || q.ld <= 0 || q.ld % 32 || q.ld > 2048 || (q.K != 8 && q.K != 16)) return -3;
+      if (q.K == 8 && (!q.nbr || !q.d2t || !q.wt || !q.vv_in || !q.vv_out)) return -3;
+      fp |= q.K == 8;
+      a.kind[i] = 1; a.idx[i] = np++;
+    }
+  }
+  const size_t shm = fp ? (size_t)16 * (PP_NT + 1) * 4 : 0;
+  hipLaunchKernelGGL(pp_stage_kernel, dim3(a.B), dim3(PP_NT), shm, s, a);
   return (int)hipGetLastError();
 }

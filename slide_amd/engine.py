@@ -27,6 +27,7 @@ PREC = {"fp32": 0, "fp16": 1, "split": 2}
 OP_SYNC = 14
 OP_ATTN_TAIL = 16
 OP_GEMM_GX, OP_PAIR_NORM, OP_SA_CHAIN, OP_BLOCK_BODY, OP_PAIR_FIRST, OP_GEMM_CHAIN, OP_HEAD_UPDATE, OP_GEMM_GX_DUAL, OP_SA_CHAIN_P = 17, 18, 19, 30, 31, 32, 33, 34, 35
+OP_PP_STAGE = 36
 
 
 class SlideEpi(ctypes.Structure):
@@ -205,6 +206,8 @@ class DenoiserEngine:
         self._cm = set()
         self._cm_copy = {}  # per-point table (data_ptr) -> its chunk-major copy, written by the table's producer as well
         self.ops = []
+        self._w16 = {}
+        self._w16_next = None
         self._lane = 0
         self.two_lanes = _os.environ.get("SLIDE_TWO_LANES", "0") != "0"  # measured: no gain at batch 256
         self._tvec = []   # (name, width) of every Mlp .fc           -> offsets into the t vector
@@ -243,6 +246,10 @@ class DenoiserEngine:
     def _emit(self, op):
         op.i[10] = self._lane if self.two_lanes else 0
         self.ops.append(op)
+        w16 = getattr(self, "_w16_next", None)
+        if w16 is not None:
+            self._w16[id(op)] = (op, w16)
+            self._w16_next = None
 
     def _sync(self, frm, to):
         if self.two_lanes:
@@ -445,6 +452,9 @@ class DenoiserEngine:
         if wfrag is not None and os.environ.get("SLIDE_XS_OCC"):
             knob = 10 + int(os.environ["SLIDE_XS_OCC"])  # cap the workgroups per CU of the X-stationary kernel (A/B timing)
         has_pair = any(v[1].get("res_pair") is not None for v in vec_list)  # -> the kernels compiled with the PAIR residual
+        if self.use_gxs and npx_log2 == 4 and gather is None and gn_fin is None and pre_gather is None and wfrag is None and \
+                not any(v[1].get("pre_add") is not None for v in vec_list):
+            self._w16_next = W  # (a per-point layer of a split plan: _merge_pp may fold it into a SLIDE_OP_PP_STAGE launch)
         self._emit(make_op(OP_GEMM, i=(rows, x_ld, ld, n_cob, npx_log2, in_bs, self.prec, cbw, glds | (2 if w_cm else 0) | (4 if has_pair else 0), knob),
                            f=(-1.0 if self.persistent == 2 else float(os.environ.get('SLIDE_STAGGER_US', '0')),) + gf,
                                 p=(X.data_ptr(), Wd.data_ptr(), ed.data_ptr(),
@@ -1399,6 +1409,8 @@ class DenoiserEngine:
         self._merge_chains()
         self._merge_gx_pairs()
         self._merge_chain_query()
+        self._merge_pp()
+        self._w16 = {}
         self.step_ops = (SlideOp * len(self.ops))(*self.ops)
         self.cond_ops = (SlideOp * 1)(self.cond_op)
 
@@ -1449,6 +1461,70 @@ class DenoiserEngine:
         self._body_args = {remap[q]: v for q, v in self._body_args.items()}
         self._tail_of = {k_: remap[v] for k_, v in self._tail_of.items()}
 
+    def _merge_pp(self):
+        """split plans (round 5): runs of consecutive per-point launches -- 16-row SLIDE_OP_GEMM in the split arithmetic and the float
+        pair-table pass -- become ONE SLIDE_OP_PP_STAGE launch each (csrc/gemm_gxs.hip: one workgroup per sample walks the steps, the
+        dense layers as exact fp32 FMA chains; 30 -> 17 launches per position step).  SLIDE_PP=0 keeps the launches apart.
+        Op-index tables are re-keyed."""
+        # OPT-IN (SLIDE_PP=1): measured SLOWER -- one workgroup per sample re-reads every layer's weights per sample and its K loop is a
+        # chain of dependent L2 round trips on four waves: 55 - 131 us per stage launch against 27 - 45 us for the launches it replaces
+        # (position chain alone 365 -> 652 us per step, bench 379 -> 227 shapes/s)
+        if not self.use_gxs or os.environ.get("SLIDE_PP", "0") == "0":
+            return
+        B = self.B
+
+        def step_of(o):
+            if o is None:
+                return None
+            if o.kind == OP_GEMM and id(o) in self._w16 and o.i[0] == B * 16 and o.i[2] <= 192 and not o.i[10]:
+                W = self._w16[id(o)][1]
+                wt = self.A.put(np.ascontiguousarray(W.T), torch.float32)  # K-major [k_pad][n_cob*32]
+                return [0, o.p[0], wt.data_ptr(), o.p[2], o.p[3] or 0, o.p[4] or 0, o.i[1], o.i[2], o.i[3], o.i[5]] + [0] * 6
+            if o.kind == OP_PAIR_NORM and o.i[3] == 2 and o.i[4] == 1 and o.i[0] == B and not o.i[10]:
+                return [1] + [o.p[k] or 0 for k in range(13)] + [o.i[1], o.i[2]]
+            return None
+        new_ops, remap, i = [], {}, 0
+        self._pp_keep = []
+        flops, nbytes, names = {}, {}, {}
+        while i < len(self.ops):
+            run, j = [], i
+            while j < len(self.ops) and len(run) < 8:
+                st = step_of(self.ops[j])
+                if st is None or (st[0] == 1 and sum(1 for r_ in run if r_[0] == 1) >= 2):
+                    break
+                run.append(st)
+                j += 1
+            k = len(new_ops)
+            if len(run) >= 2:
+                rec = np.array([len(run), B] + [v for st in run for v in st], np.int64)
+                self._pp_keep.append(rec)
+                op = make_op(OP_PP_STAGE, i=(B, len(run)), p=(rec.ctypes.data,))
+                new_ops.append(op)
+                for q in range(i, j):
+                    remap[q] = k
+                flops[k] = sum(self.gemm_flops.get(q, 0) for q in range(i, j))
+                nbytes[k] = tuple(sum(self.gemm_bytes.get(q, (0, 0))[z] for q in range(i, j)) for z in (0, 1))
+                names[k] = "pp_stage_kernel"
+                i = j
+                continue
+            new_ops.append(self.ops[i])
+            remap[i] = k
+            for src, dst in ((self.gemm_flops, flops), (self.gemm_bytes, nbytes), (self.kernel_names, names)):
+                if i in src:
+                    dst[k] = src[i]
+            i += 1
+        self.ops = new_ops
+        self.gemm_flops, self.gemm_bytes, self.kernel_names = flops, nbytes, names
+        self.xyz_copy_idx = [remap[q] for q in self.xyz_copy_idx]
+        self.eps_copy_idx = remap[self.eps_copy_idx]
+        self._prep_idx = remap[self._prep_idx]
+        if self.head is not None:
+            self.head["idx"] = [remap[q] for q in self.head["idx"]]
+            if len(set(self.head["idx"])) != 2:
+                self.head = None
+        self._body_args = {remap[q]: v for q, v in self._body_args.items()}
+        self._tail_of = {k_: remap[v] for k_, v in self._tail_of.items()}
+
     def _merge_gx_pairs(self):
         """the mode-1 (keys -> u) and mode-0 (first Mlp layer) generated-X GEMMs of an FP block are independent and adjacent in
         the plan: where both run 64-channel tiles at two workgroups per CU they become ONE SLIDE_OP_GEMM_GX_DUAL launch
@@ -1462,7 +1538,8 @@ class DenoiserEngine:
             a_, b_ = self.ops[i], self.ops[i + 1] if i + 1 < len(self.ops) else None
             k = len(new_ops)
             if (a_ is not None and b_ is not None and a_.kind == OP_GEMM_GX and b_.kind == OP_GEMM_GX and a_.i[6] == 1 and b_.i[6] == 0
-                    and a_.f[0] in (1.0, 2.0) and b_.f[0] == 2.0 and a_.i[0] == b_.i[0] and a_.i[4] == b_.i[4] and a_.i[10] == b_.i[10]):
+                    and ((a_.f[0] in (1.0, 2.0) and b_.f[0] == 2.0) or (a_.f[0] == 3.0 and b_.f[0] == 3.0))
+                    and a_.i[0] == b_.i[0] and a_.i[4] == b_.i[4] and a_.i[10] == b_.i[10]):
                 pair = (SlideOp * 2)(SlideOp.from_buffer_copy(bytes(a_)), SlideOp.from_buffer_copy(bytes(b_)))
                 self._dual_keep.append(pair)
                 op = make_op(OP_GEMM_GX_DUAL, i=(a_.i[0],), p=(ctypes.addressof(pair),))
@@ -1471,7 +1548,7 @@ class DenoiserEngine:
                 remap[i] = remap[i + 1] = k
                 flops[k] = self.gemm_flops.get(i, 0) + self.gemm_flops.get(i + 1, 0)
                 nbytes[k] = tuple(self.gemm_bytes.get(i, (0, 0))[z] + self.gemm_bytes.get(i + 1, (0, 0))[z] for z in (0, 1))
-                names[k] = "gemm_gx_dual_kernel<%d>" % a_.i[4]
+                names[k] = ("gemm_gxs_dual_kernel<%d>" if a_.f[0] == 3.0 else "gemm_gx_dual_kernel<%d>") % a_.i[4]
                 i += 2
                 continue
             new_ops.append(a_)
