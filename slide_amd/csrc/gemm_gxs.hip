@@ -506,12 +506,15 @@ __global__ __launch_bounds__(256, 2) void attn_tail_split_kernel(TailSArgs a) {
 }
 
 
+#ifdef SLIDE_EXPERIMENTS  // (opt-in variant that lost its A/B: experiments build only, SLIDE_PP=1)
 // ------------------------------------------------------------------------------------------------ per-point stage
 // Everything of a block that happens on the 16 points of a sample -- the per-point GEMM of the pair decomposition with the
 // attention queries riding on it, the pair-table pass with the joint GroupNorm, the query half of weight_conv.2, an FP block's
 // second Mlp_plus_t_emb, the output head -- is a chain of SMALL dense layers (16 rows, K <= 160, N <= 288 in the position net) whose
 // every step depends on the previous one for the SAME sample only.  As launches of their own they cost the chain a launch latency
-// each (17 of the split position plan's 30); here ONE workgroup per sample walks the whole chain:
+// each (17 of the split position plan's 30); here ONE workgroup per sample walks the whole chain (MEASURED SLOWER, opt-in:
+// every workgroup re-reads each layer's weights and its K loop is a chain of dependent L2 round trips on four waves --
+// 55 - 131 us per stage launch against 27 - 45 us for the launches it replaces; position chain alone 365 -> 652 us per step):
 //   DENSE  y[16][n] = epilogue(W . x + bias): exact fp32 FMA chains on the vector ALUs (a thread owns one output channel and its 16
 //          rows; x transposed in LDS, read as broadcasts; the weights K-major so that a wave's loads coalesce) -- 16-row layers of
 //          this size do not fill a matrix tile, and fp32 FMAs need no operand split.  The epilogue is SlideEpi's (include/
@@ -642,6 +645,8 @@ __global__ __launch_bounds__(PP_NT) void pp_stage_kernel(PPArgs a) {
   }
 }
 
+#endif  // SLIDE_EXPERIMENTS
+
 }  // namespace
 
 static int gxs_args_from_op(const SlideOp &o, GemmArgs &a) {
@@ -747,6 +752,9 @@ int slide_launch_attn_tail_split(const SlideOp &o, hipStream_t s) {
 //   dense: slot 0 = 0, [1] X, [2] Wt (K-major float [k_pad][n_cob*32]), [3] epi, [4] in_scale, [5] in_shift, [6] x_ld, [7] k_pad, [8] n_cob, [9] in_bs
 //   pair : slot 0 = 1, [1] y, [2] xyz, [3] wa, [4] wb, [5] epi, [6] ta, [7] tb, [8] nbr, [9] d2, [10] w, [11] vv_in, [12] vv_out, [13] SlideGnFin*,
 //          [14] ld, [15] K
+#ifndef SLIDE_EXPERIMENTS
+int slide_launch_pp_stage(const SlideOp &, hipStream_t) { return -20; }  // experiments build only
+#else
 int slide_launch_pp_stage(const SlideOp &o, hipStream_t s) {
   const int64_t *h = (const int64_t *)o.p[0];
   if (!h) return -3;
@@ -782,3 +790,4 @@ int slide_launch_pp_stage(const SlideOp &o, hipStream_t s) {
   hipLaunchKernelGGL(pp_stage_kernel, dim3(a.B), dim3(PP_NT), shm, s, a);
   return (int)hipGetLastError();
 }
+#endif

@@ -7,6 +7,9 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 88  # samples per launch of the PMC passes (tools/rocprof_run3.sh <tag> <batch>)
+# optional third argument: the profiled command of the PMC passes when it is not the default feature step (round 5: the position
+# DDPM's split plan, `--which pos --prec split`); hbm_pmc_latest.json (bench.py's `roofline.traffic`) is then left alone
+pmc_cmd = sys.argv[3] if len(sys.argv) > 3 else None
 src = os.path.join("gpurun_out", "prof_" + tag)
 dst = "profiles"
 os.makedirs(dst, exist_ok=True)
@@ -51,7 +54,7 @@ wp = os.path.join(src, "pmc_write", "write_counter_collection.csv")
 if os.path.exists(fp) and os.path.exists(wp):
     fa, wa = pmc(fp, "FETCH_SIZE"), pmc(wp, "WRITE_SIZE")
     with open(os.path.join(dst, tag + "_hbm_pmc.md"), "w") as f:
-        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python tools/profile_ops.py --reps 2 --batch %d`\n\n" % batch +
+        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python tools/profile_ops.py --reps 2 --batch %d%s`\n\n" % (batch, " " + pmc_cmd if pmc_cmd else "") +
                 "Units: KiB per dispatch as reported by rocprofv3.  On gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x\n"
                 "(MI355X_MICROARCH.md, HBM section): the `fetch x2` column applies that correction.\n\n"
                 "| kernel | dispatches | FETCH KiB/disp | fetch x2 KiB | WRITE KiB/disp | avg us |\n|---|---|---|---|---|---|\n")
@@ -67,7 +70,8 @@ if os.path.exists(fp) and os.path.exists(wp):
             w = wa.get(k, [0, 1, 0])
             kern[k] = {"hbm_bytes_per_launch": int(1024 * (2 * fa[k][0] / fa[k][1] + w[0] / max(w[1], 1))),
                        "fetch_kib_x2": 2 * fa[k][0] / fa[k][1], "write_kib": w[0] / max(w[1], 1), "dispatches": fa[k][1]}
-    json.dump({"source": "profiles/%s_hbm_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH x2 gfx950 "
+    if pmc_cmd is None:
+      json.dump({"source": "profiles/%s_hbm_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH x2 gfx950 "
                          "correction; %d samples per launch)" % (tag, batch), "samples_per_launch": batch, "kernels": kern}, open(os.path.join(dst, "hbm_pmc_latest.json"), "w"), indent=1)
 mp = os.path.join(src, "pmc_mfma", "mfma_counter_collection.csv")
 if os.path.exists(mp):
@@ -75,7 +79,7 @@ if os.path.exists(mp):
     acc = {n: pmc(mp, n) for n in names}
     with open(os.path.join(dst, tag + "_mfma_pmc.md"), "w") as f:
         f.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_ANY over "
-                "`python tools/profile_ops.py --reps 2 --batch %d` (one feature-denoiser step, every launch alone on the GPU)\n\n" % batch +
+                "`python tools/profile_ops.py --reps 2 --batch %d%s` (one %s step, every launch alone on the GPU)\n\n" % (batch, " " + pmc_cmd if pmc_cmd else "", "denoiser" if pmc_cmd else "feature-denoiser") +
                 "MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (kernel duration x 2.4 GHz x 1024 SIMDs): the fraction of the chip's "
                 "SIMD-cycles with the matrix pipe busy while the kernel runs, priced at the MAXIMUM clock (a lower bound under DVFS; "
                 "MI355X_MICROARCH.md: the counter advances 32 per 32x32x16 MFMA, summed over all SIMDs).  "
