@@ -17,6 +17,7 @@ import torch.nn as nn
 
 from pointnet2_ops import pointnet2_utils
 from pointnet2_ops.attention import AttentionModule, GlobalAttentionModule
+from slide_amd import _ext
 from slide_amd import rows as R
 from slide_amd.nn_ops import HipConv1x1, HipGroupNorm, HipLinear
 
@@ -280,7 +281,9 @@ class PointnetSAModuleMSG(nn.Module):
             centres, query = xyz, feat
         else:
             picked = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
-            centres = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), picked).transpose(1, 2).contiguous()
+            # (row-layout gather of the (B, N, 3) coordinates: one launch that moves exactly the picked rows, instead of transpose ->
+            #  gather_points on (B, 3, N) -> transpose; the reference's gather_operation call site: pointnet2_modules.py:368-378)
+            centres = _ext.gather_rows(xyz.contiguous().float(), picked)
             query = R.gather_rows(feat, picked) if (self.use_attention_module and feat is not None) else None
         emb = _emb_kwargs(self, t_emb, condition_emb, second_condition_emb)
         outs = []

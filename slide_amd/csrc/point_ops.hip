@@ -662,17 +662,27 @@ __global__ __launch_bounds__(NT) void knn_key_kernel(int n1, int n2, int K, cons
       }
     }
   }
-  if (active) {
-    float *od = dists + ((size_t)b * n1 + i) * K;
-    int64_t *oi = idx + ((size_t)b * n1 + i) * K;
-    const int cnt = len2 < K ? len2 : K;
+  // Output through LDS (round 5): a lane's K results are K x 12 bytes at a stride of K elements from the next lane's, so written
+  // straight from the registers every store instruction touched 4 / 8 bytes of 64 different cache lines -- the launch moved 5.2x its
+  // algorithmic bytes (profiles/r04_ops_roofline.md: 152 vs 29 MB at B 256, n2 1024, K 32), nearly all of it partial-line writes.
+  // The workgroup's NT x K block of distances (and of indices) is CONTIGUOUS in the outputs: the keys go to LDS as [K][NT + 1]
+  // (the queue region, free by now) and leave as coalesced stores, element e of the block by thread e % NT.
+  __syncthreads();
+  double *const ol = queue;
 #pragma unroll
-    for (int p = 0; p < KT; ++p)
-      if (p < K) {
-        const long long key = __double_as_longlong(L[p]);
-        od[p] = p < cnt ? __int_as_float((int)(key >> 32)) : 0.f;
-        oi[p] = p < cnt ? (int64_t)(key & 0xffffffffLL) : 0;
-      }
+  for (int p = 0; p < KT; ++p)
+    if (p < K) ol[p * (NT + 1) + tid] = L[p];
+  __syncthreads();
+  const int q0 = blockIdx.x * NT;
+  const int nq = min(NT, n1 - q0);
+  const int cnt = len2 < K ? len2 : K;
+  float *const od = dists + ((size_t)b * n1 + q0) * K;
+  int64_t *const oi = idx + ((size_t)b * n1 + q0) * K;
+  for (int e = tid; e < nq * K; e += NT) {
+    const int q = e / K, p = e - q * K;
+    const long long key = __double_as_longlong(ol[p * (NT + 1) + q]);
+    od[e] = p < cnt ? __int_as_float((int)(key >> 32)) : 0.f;
+    oi[e] = p < cnt ? (int64_t)(key & 0xffffffffLL) : 0;
   }
 }
 
@@ -993,7 +1003,8 @@ int slide_knn_points(int b, int n1, int n2, int K, const float *p1, const float 
   hipStream_t s = (hipStream_t)stream;
 #define KNN_KEY(NT, KT)                                                                                  \
   hipLaunchKernelGGL((knn_key_kernel<NT, KT>), dim3((n1 + NT - 1) / NT, b), dim3(NT),                      \
-                     (size_t)KNN_TILE * 16 + (size_t)(knn_queue_slots(KT) + 1) * NT * 8, s, n1, n2, K, p1, p2, lengths2, dists, idx)
+                     (size_t)KNN_TILE * 16 + (size_t)((knn_queue_slots(KT) + 1) * NT > KT * (NT + 1) ? (knn_queue_slots(KT) + 1) * NT : KT * (NT + 1)) * 8, \
+                     s, n1, n2, K, p1, p2, lengths2, dists, idx)
   // few queries per sample: 64-thread workgroups keep more of them on different compute units
   if (n1 > 64) {
     if (K <= 4) KNN_KEY(256, 4); else if (K <= 8) KNN_KEY(256, 8); else if (K <= 16) KNN_KEY(256, 16);

@@ -292,7 +292,8 @@ def test_clis_drive_the_benched_arrangement(gpu_device, tmp_path):
                             "--num_samples", "40", "--batch_size", "8", "--chains", "3", "--save_dir", str(o1)] + extra,
                            env=env, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
-        assert "shapes/s" in r.stdout and "fp16" in r.stdout  # end-to-end rate of the run, fp16 operands by default
+        # end-to-end rate of the run; default arithmetic "mixed" (round 5): position DDPM split (fp32-grade), feature DDPM fp16 operands
+        assert "shapes/s" in r.stdout and "mixed" in r.stdout
         outs["pos_" + tag] = np.load(o1 / "shapenet_psr_generated_data_16_pts.npz")
         o2 = tmp_path / ("feat_" + tag)
         r = subprocess.run([sys.executable, os.path.join(cli, "latent_ddpm_keypoint_conditional_generation.py"), "-c", str(cdir / "feat.json"),
