@@ -46,6 +46,11 @@ struct GemmArgs {
   const float *gx_d2, *gx_w, *gx_vv;
   const int *gx_add_idx;
   int gx_ld, gx_mode, gx_add_idx_stride, gx_vbs;
+  // split generated-X GEMM with a CHAINED second layer (gemm_gxs.hip, round 5: second_mlp -> rest_mlp of an SA block in one launch,
+  // the middle activation in registers): float row-major weights [ch_n_cob*32][ch_k_pad] and epilogue descriptors of that layer
+  const void *ch_W;
+  const SlideEpi *ch_epi;
+  int ch_n_cob, ch_k_pad;
 };
 
 // SLIDE_OP_PAIR_FIRST (pair_first_kernel, engine.hip): what the pair-table epilogue reads beside the GEMM arguments
@@ -170,7 +175,11 @@ __device__ __forceinline__ void stage_epilogue_tables(const GemmArgs &a, int cob
 // RB = 32-row blocks per wave (2; 1 for the split-K small-launch kernel, whose waves own one block each).
 // PAIRRES: the instantiation also serves the PAIR residual (SLIDE_F_RES_PAIR / _NBR: two table rows instead of one stored row) --
 // a template parameter because its address arithmetic costs every instantiation registers, also where no plan uses it
-template <int PREC, int NPXL, int CBW, int RB = 2, bool PAIRRES = false>
+// KEEP: the finished values (normalised, ReLU, + add vector) are written back to `acc` instead of memory -- the caller chains the
+// next layer on them (gemm_gxs.hip)
+// NOADDV: LEAN instantiation for a layer that is known to be "GroupNorm epilogue, no add vector, no per-point pre-activation term"
+// (the chained rest_mlp of gemm_gxs.hip): the STATS / RAW paths and the add-vector row registers are compiled out
+template <int PREC, int NPXL, int CBW, int RB = 2, bool PAIRRES = false, bool KEEP = false, bool NOADDV = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[CBW][RB], int row0, int cob0, int wave,
                                               int half, int col, const uint32_t *epi_lds, const float *vec_lds,
                                               float *red) {
@@ -212,14 +221,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     if (cobi >= a.n_cob) return;  // uniform per workgroup
     auto rd = [&](int k) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)epi_lds[cb * EPI_DW + k]); };
     auto rdp = [&](int k) { return (uint64_t)rd(k) | ((uint64_t)rd(k + 1) << 32); };
-    const int mode = (int)rd(0), flags = (int)rd(1), e_gs = (int)rd(2), e_n_norm = (int)rd(3);
+    const int mode = NOADDV ? (int)SLIDE_EPI_NORM : (int)rd(0), flags = (int)rd(1), e_gs = (int)rd(2), e_n_norm = (int)rd(3);
     const float e_inv_count = __uint_as_float(rd(4)), e_stats_scale = __uint_as_float(rd(5));
     const int e_out_ld = (int)rd(6), e_res_ld = (int)rd(7), e_addvec_bs = (int)rd(8), e_stats_bs = (int)rd(9),
               e_pre_ld = (int)rd(10), e_pre_shift = (int)rd(11), e_idx_stride = (int)rd(12);
     const GLOBAL_AS float *e_addvec = gptr<const float>(rdp(20));
     const float *v_bias = vec_lds + cb * 96, *v_gamma = v_bias + 32, *v_beta = v_bias + 64;
     const GLOBAL_AS int *e_addvec_idx = gptr<const int>(rdp(22));
-    const GLOBAL_AS T *resid = gptr<const T>(rdp(24)), *pre = gptr<const T>(rdp(26));
+    const GLOBAL_AS T *resid = gptr<const T>(rdp(24)), *pre = NOADDV ? nullptr : gptr<const T>(rdp(26));
     const uint64_t e_out = rdp(28);
     GLOBAL_AS float *e_stats_sum = gptr<float>(rdp(30)), *e_stats_sq = gptr<float>(rdp(32));
     if (PH == 2 && cb == 0) SLIDE_STAMP(a, 8);
@@ -227,12 +236,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     constexpr bool kHalf = std::is_same<T, _Float16>::value;
     const bool wide16 = kHalf && !(flags & SLIDE_F_OUT_F32);
     const bool pair = PAIRRES && (flags & (SLIDE_F_RES_PAIR | SLIDE_F_RES_PAIR_NBR)) != 0;  // (fp16 rows, 128- / 256-row samples only)
-    const GLOBAL_AS float *addv = e_addvec;
+    const GLOBAL_AS float *addv = NOADDV ? nullptr : e_addvec;
     static_assert(RB == 2 || NPXL < 6, "one row block per wave only for samples of at most 32 rows");
     constexpr int NA = NPXL >= 6 ? 1 : RB;  // a wave's 64 rows belong to one sample when NPX >= 64
     float4 apre[NA][4];
     u32x4 rpre[RB][2];
-    size_t pr_a[RB], pr_b[RB];  // float rows with a PAIR residual: the two table rows of the lane's row (read in the store phase)
+    int pr_a[RB], pr_b[RB];  // float rows with a PAIR residual: the two table rows of the lane's row (read in the store phase)
     if (PH != 1) {
       if (addv && e_addvec_idx) addv += (size_t)e_addvec_idx[0] * e_idx_stride;  // row t of a per-timestep table
 #pragma unroll
@@ -249,14 +258,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
         // pair residual: the row's value is the sum of two per-point table rows (+ the two per-slot terms of group_knn)
         size_t ra_row = (size_t)row, rb_row = 0;
         _Float16 sd2 = (_Float16)0.f, sw = (_Float16)0.f;
-        pr_a[rb] = (size_t)row; pr_b[rb] = 0;
+        pr_a[rb] = row; pr_b[rb] = 0;
         if constexpr (!kHalf && NPXL >= 7 && PAIRRES) {
           if (pair && ok) {
             const int smp = row >> NPXL, pxl = row & (NPX - 1);
             if (flags & SLIDE_F_RES_PAIR) {
-              pr_a[rb] = (size_t)(smp * 16 + (pxl & 15)); pr_b[rb] = (size_t)(row >> 4);
+              pr_a[rb] = smp * 16 + (pxl & 15); pr_b[rb] = row >> 4;
             } else if constexpr (NPXL == 7) {
-              pr_a[rb] = (size_t)nbr_row[rb]; pr_b[rb] = (size_t)(row >> 3);
+              pr_a[rb] = nbr_row[rb]; pr_b[rb] = row >> 3;
             }
           }
         }
@@ -562,6 +571,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
           }
           v[rb][2 * q] = lo; v[rb][2 * q + 1] = hi;
         }
+        if constexpr (KEEP) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { acc[cb][rb][2 * i] = v[rb][i][0]; acc[cb][rb][2 * i + 1] = v[rb][i][1]; }
+        }
         if constexpr (HR && kHalf) {
           if (wide16) {
 #pragma unroll
@@ -580,6 +593,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
           }
         }
       }
+      if constexpr (KEEP) return;
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
         const int row = row0 + wave * 64 + rb * 32 + col;
@@ -612,8 +626,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
                 if constexpr (!kHalf && NPXL >= 7 && PAIRRES) {
                   if (pair) {  // PAIR residual on float rows (split mode): ta[q] + tb[p] (+ d2 vd + w vw), evaluated in fp32
                     plain = false;
-                    t = gload4(resid + pr_a[rb] * e_res_ld + c0);
-                    const float4 t2 = gload4(gptr<const T>(rdp(34)) + pr_b[rb] * e_res_ld + c0);
+                    t = gload4(resid + (size_t)pr_a[rb] * e_res_ld + c0);
+                    const float4 t2 = gload4(gptr<const T>(rdp(34)) + (size_t)pr_b[rb] * e_res_ld + c0);
                     t.x += t2.x; t.y += t2.y; t.z += t2.z; t.w += t2.w;
                     if constexpr (NPXL == 7) {
                       if (flags & SLIDE_F_RES_PAIR_NBR) {
@@ -627,6 +641,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
                 }
                 if (plain) t = gload4(resid + (size_t)row * e_res_ld + c0);
                 y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+                // (float PAIR instantiations: keep the compiler from hoisting all sixteen table loads of the store phase above the
+                //  first store -- 64 registers of loads in flight push the chained kernel of gemm_gxs.hip over its 256)
+                if constexpr (!kHalf && NPXL >= 7 && PAIRRES) asm volatile("" ::: "memory");
               }
               if (flags & SLIDE_F_OUT_F32)
                 gstore4(gptr<float>(e_out) + (size_t)row * e_out_ld + c0, y);
@@ -652,7 +669,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
     if (cobi >= a.n_cob) return;
     auto rd = [&](int k) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)epi_lds[cb * EPI_DW + k]); };
     auto rdp = [&](int k) { return (uint64_t)rd(k) | ((uint64_t)rd(k + 1) << 32); };
-    const int mode = (int)rd(0);
+    const int mode = NOADDV ? (int)SLIDE_EPI_NORM : (int)rd(0);
     if (mode == SLIDE_EPI_RAW) return;
     if (WPSF == 4 && half) return;                    // one sample per workgroup: the upper lane half has nothing to do
     const int smp = WPSF == 2 ? half : 0, w0 = smp * WPSF;

@@ -43,7 +43,11 @@ __device__ __forceinline__ void gxs_split4w(const float4 v, f16x4 &hi, f16x4 &hs
 // 16 x 16-row samples run in NATURAL neighbour order, so its eight rows share ONE neighbour row (q = l_row % 16) and touch eight
 // centre rows; 16 x 8-row samples look their neighbours up once (nbr table) and keep the two per-slot scalars in registers.
 // The per-sample vectors (add | scale, shift | vd, vw) are staged once per workgroup in LDS.
-template <int NPXL, int MODE>
+// CHAIN (16 x 16-row samples, mode 0; round 5): the layer's output -- h2 = relu(GN(second_mlp(h1))) + class embedding of an SA block,
+// at most 64 channels: one column tile -- is NOT stored: the common epilogue leaves it in the accumulators (KEEP), each 32-channel
+// block of them IS one K chunk of the next layer (rest_mlp), written as split planes into the dead X stage, and the workgroup runs that
+// layer's column tiles with its own epilogue (GroupNorm, ReLU, PAIR residual) -- one launch and one K-expanded round trip less per block.
+template <int NPXL, int MODE, bool CHAIN = false>
 __device__ __forceinline__ void gemm_gxs_body(const GemmArgs &a, const int bid) {
   constexpr int NPX = 1 << NPXL;
   constexpr bool FP = NPXL == 7;
@@ -200,7 +204,7 @@ __device__ __forceinline__ void gemm_gxs_body(const GemmArgs &a, const int bid) 
       *reinterpret_cast<f16x4 *>(Wl + (p * 32 + l_row) * LDK + l_c) = lo;
     }
   };
-  auto compute = [&]() __attribute__((always_inline)) {
+  auto compute = [&](f32x16 (&acc)[CBW][2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       f16x8 ah[CBW], as[CBW], al[CBW], bh[2], bl[2];
@@ -234,7 +238,7 @@ __device__ __forceinline__ void gemm_gxs_body(const GemmArgs &a, const int bid) 
   __syncthreads();
   for (int kc = 0; kc < nk; ++kc) {
     if (kc + 1 < nk) load_chunk(kc + 1);
-    compute();
+    compute(acc);
     __syncthreads();  // every wave is done reading the stage before it is overwritten
     if (kc + 1 < nk) store_chunk(kc + 1);
     __syncthreads();
@@ -245,6 +249,68 @@ __device__ __forceinline__ void gemm_gxs_body(const GemmArgs &a, const int bid) 
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] *= 1.f / 2048.f;
+  if constexpr (CHAIN) {
+    // ---- this layer's epilogue with the result kept in `acc` (all its channels sit in this one column tile: cob0 == 0)
+    gemm_epilogue<SLIDE_PREC_F32, NPXL, CBW, 2, false, true>(a, acc, row0, cob0, wave, half, col, epi_lds, vec_lds,
+                                                             reinterpret_cast<float *>(smem_raw));
+    GemmArgs b = a;
+    b.W = a.ch_W; b.epi = a.ch_epi; b.n_cob = a.ch_n_cob; b.k_pad = a.ch_k_pad;
+    const float *W2 = reinterpret_cast<const float *>(a.ch_W);
+    const int nk2 = a.ch_k_pad / BK;  // <= CBW: chunk kc2 of the next layer = channel block kc2 of this one
+    for (int tc2 = 0; tc2 < (a.ch_n_cob + CBW - 1) / CBW; ++tc2) {
+      __syncthreads();  // the previous epilogue is done with its tables and scratch
+      stage_epilogue_tables<CBW>(b, tc2 * CBW, tid, epi_lds, vec_lds);
+      f32x16 acc2[CBW][2];
+#pragma unroll
+      for (int i = 0; i < CBW; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+#pragma unroll
+      for (int kc2 = 0; kc2 < CBW; ++kc2) {
+        if (kc2 >= nk2) break;
+        if (kc2) __syncthreads();  // the stage is free again
+        // X planes from the accumulators: lane (row, half) holds channels 8 q + 4 half + 0 .. 3 of block kc2
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          const int trow = wave * 64 + rb * 32 + col;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f16x4 hi, lo;
+            gxs_split4(make_float4(acc[kc2][rb][4 * q], acc[kc2][rb][4 * q + 1], acc[kc2][rb][4 * q + 2], acc[kc2][rb][4 * q + 3]), hi, lo);
+            *reinterpret_cast<f16x4 *>(Xh + trow * LDK + 8 * q + 4 * half) = hi;
+            *reinterpret_cast<f16x4 *>(Xl + trow * LDK + 8 * q + 4 * half) = lo;
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < WP; ++p) {
+          const int gco = tc2 * CBW * 32 + p * 32 + l_row;
+          const float4 w4 = gco < a.ch_n_cob * 32 ? *reinterpret_cast<const float4 *>(W2 + (size_t)gco * a.ch_k_pad + kc2 * BK + l_c)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+          f16x4 hi, hs, lo;
+          gxs_split4w(w4, hi, hs, lo);
+          *reinterpret_cast<f16x4 *>(Wh + (p * 32 + l_row) * LDK + l_c) = hi;
+          *reinterpret_cast<f16x4 *>(Ws + (p * 32 + l_row) * LDK + l_c) = hs;
+          *reinterpret_cast<f16x4 *>(Wl + (p * 32 + l_row) * LDK + l_c) = lo;
+        }
+        __syncthreads();
+        compute(acc2);
+      }
+      __syncthreads();  // the stage turns into the epilogue's scratch
+#pragma unroll
+      for (int i = 0; i < CBW; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc2[i][j][r] *= 1.f / 2048.f;
+      // (rest_mlp carries no add vector -- the class embedding is added to second_mlp's output: the NOADDV epilogue, whose 16 fewer
+      //  registers keep h2 alive across this tile's epilogue without a spill)
+      gemm_epilogue<SLIDE_PREC_F32, NPXL, CBW, 2, true, false, true>(b, acc2, row0, tc2 * CBW, wave, half, col, epi_lds, vec_lds,
+                                                                     reinterpret_cast<float *>(smem_raw));
+    }
+    return;
+  }
   // float rows: the fp32 epilogue (mode 0 = the Mlp layers: PAIR residual on the float tables)
   gemm_epilogue<SLIDE_PREC_F32, NPXL, CBW, 2, MODE == 0>(a, acc, row0, cob0, wave, half, col, epi_lds, vec_lds,
                                                          reinterpret_cast<float *>(smem_raw));
@@ -257,13 +323,18 @@ __global__ __launch_bounds__(256, 2) void gemm_gxs_kernel(GemmArgs a) {
 
 // the two independent generated-X GEMMs of a block (keys -> u: mode 1; first Mlp layer: mode 0) in ONE launch: they read the same
 // pair tables and nothing of each other -- one launch gap instead of two, and their workgroups fill the chip together
-template <int NPXL>
+template <int NPXL, bool CHAIN = false>
 __global__ __launch_bounds__(256, 2) void gemm_gxs_dual_kernel(GemmArgs a1, GemmArgs a0, int grid1) {
   if ((int)blockIdx.x < grid1) gemm_gxs_body<NPXL, 1>(a1, blockIdx.x);
-  else gemm_gxs_body<NPXL, 0>(a0, blockIdx.x - grid1);
+  else gemm_gxs_body<NPXL, 0, CHAIN>(a0, blockIdx.x - grid1);
 }
 
-template <int NPXL, int MODE>
+template <int NPXL>
+__global__ __launch_bounds__(256, 2) void gemm_gxs_chain_kernel(GemmArgs a) {
+  gemm_gxs_body<NPXL, 0, true>(a, blockIdx.x);
+}
+
+template <int NPXL, int MODE, bool CHAIN = false>
 int launch_gxs(const GemmArgs &a, hipStream_t s) {
   constexpr int LDK = TileT<SLIDE_PREC_SPLIT>::LDK;
   constexpr int NSAMP = TM >> NPXL, NVEC = (MODE ? 2 : 1) + (NPXL == 7 ? 2 : 0);
@@ -275,12 +346,21 @@ int launch_gxs(const GemmArgs &a, hipStream_t s) {
   int d = 0;
   (void)hipGetDevice(&d);
   bool &attr_set = attr_done[d >= 0 && d < GXS_MAX_DEVICES ? d : 0];
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_gxs_kernel<NPXL, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              80 * 1024);
-    attr_set = true;
+  if constexpr (CHAIN) {
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_gxs_chain_kernel<NPXL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                80 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_gxs_chain_kernel<NPXL>), dim3(grid), dim3(256), shm, s, a);
+  } else {
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_gxs_kernel<NPXL, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                80 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_gxs_kernel<NPXL, MODE>), dim3(grid), dim3(256), shm, s, a);
   }
-  hipLaunchKernelGGL((gemm_gxs_kernel<NPXL, MODE>), dim3(grid), dim3(256), shm, s, a);
   return (int)hipGetLastError();
 }
 
@@ -666,6 +746,12 @@ static int gxs_args_from_op(const SlideOp &o, GemmArgs &a) {
   if (a.in_add && ((uintptr_t)a.in_add % 16 || a.add_bs % 4 || a.gx_add_idx_stride % 4)) return -3;
   if (a.gx_vv && ((uintptr_t)a.gx_vv % 16 || a.gx_vbs % 8)) return -3;
   if (npxl == 7 && (!a.gidx || !a.gx_d2 || !a.gx_w)) return -3;
+  // chained second layer (p[12] = its float weights, p[13] = its epilogue descriptors, f[1] = its n_cob, f[2] = its k_pad): 16 x 16-row
+  // samples, mode 0, every channel of this layer in one 64-channel tile, which is also the next layer's whole K
+  a.ch_W = o.p[12]; a.ch_epi = (const SlideEpi *)o.p[13]; a.ch_n_cob = (int)o.f[1]; a.ch_k_pad = (int)o.f[2];
+  if (a.ch_W && (npxl != 8 || a.gx_mode != 0 || a.n_cob > 2 || !a.ch_epi || a.ch_n_cob <= 0 || a.ch_k_pad != a.n_cob * 32 ||
+                 (uintptr_t)a.ch_W % 16))
+    return -3;
   return 0;
 }
 
@@ -676,13 +762,14 @@ int slide_launch_gemm_gxs(const SlideOp &o, hipStream_t s) {
   if (st != 0) return st;
   const int npxl = o.i[4];
   const bool m1 = a.gx_mode != 0;
+  if (a.ch_W) return launch_gxs<8, 0, true>(a, s);
   if (npxl == 8) return m1 ? launch_gxs<8, 1>(a, s) : launch_gxs<8, 0>(a, s);
   if (npxl == 7) return m1 ? launch_gxs<7, 1>(a, s) : launch_gxs<7, 0>(a, s);
   return -4;
 }
 
 namespace {
-template <int NPXL>
+template <int NPXL, bool CHAIN = false>
 int launch_gxs_dual(const GemmArgs &a1, const GemmArgs &a0, hipStream_t s) {
   constexpr int LDK = TileT<SLIDE_PREC_SPLIT>::LDK;
   constexpr int NSAMP = TM >> NPXL;
@@ -700,11 +787,11 @@ int launch_gxs_dual(const GemmArgs &a1, const GemmArgs &a0, hipStream_t s) {
   (void)hipGetDevice(&d);
   bool &attr_set = attr_done[d >= 0 && d < GXS_MAX_DEVICES ? d : 0];
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_gxs_dual_kernel<NPXL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_gxs_dual_kernel<NPXL, CHAIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               80 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_gxs_dual_kernel<NPXL>), dim3(g1 + g0), dim3(256), shm, s, a1, a0, g1);
+  hipLaunchKernelGGL((gemm_gxs_dual_kernel<NPXL, CHAIN>), dim3(g1 + g0), dim3(256), shm, s, a1, a0, g1);
   return (int)hipGetLastError();
 }
 }  // namespace
@@ -716,7 +803,7 @@ int slide_launch_gemm_gxs_dual(const SlideOp *pr, hipStream_t s) {
   if (st == 0) st = gxs_args_from_op(pr[1], a0);
   if (st != 0) return st;
   if (a1.gx_mode == 0 || a0.gx_mode != 0 || a1.rows != a0.rows || pr[0].i[4] != pr[1].i[4]) return -3;
-  if (pr[0].i[4] == 8) st = launch_gxs_dual<8>(a1, a0, s);
+  if (pr[0].i[4] == 8) st = a0.ch_W ? launch_gxs_dual<8, true>(a1, a0, s) : launch_gxs_dual<8>(a1, a0, s);
   else if (pr[0].i[4] == 7) st = launch_gxs_dual<7>(a1, a0, s);
   else return -4;
   if (st == -8) {  // (LDS of the dual form does not fit: two launches)

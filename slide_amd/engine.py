@@ -270,12 +270,15 @@ class DenoiserEngine:
         return off
 
     def _gemm(self, X, npx_log2, segs, in_cols=None, in_affine=None, k_logical=None, gather=None, gn_fin=None,
-              pre_gather=None, gx=None, pair_tabs=None, pair_fused=None):
+              pre_gather=None, gx=None, pair_tabs=None, pair_fused=None, defer=None, chain=None):
         """X: input buffer [rows][ld].  segs: list of dicts describing consecutive output segments:
              w (O,I) bias (O) | out (tensor) out_coff | mode flags | gn=(gamma,beta) for NORM | layout (gn_layout) |
              addvec=(tensor, off, bs) | residual tensor | bcast | stats=(sum,sq tensors, coff, scale)
            in_cols: physical column index of every logical input channel (None = identity)."""
-        if gx is not None:  # generated-X GEMM of the pair decomposition (SLIDE_OP_GEMM_GX): X is never stored
+        if defer is not None:  # a layer CHAINED onto a split generated-X GEMM (csrc/gemm_gxs.hip): packed, not launched
+            rows, ld, x_ld = defer["rows"], defer["k_pad"], defer["k_pad"]
+            assert X is None and self.use_gxs and gather is None and gn_fin is None and gx is None and in_affine is None
+        elif gx is not None:  # generated-X GEMM of the pair decomposition (SLIDE_OP_GEMM_GX): X is never stored
             rows, ld, x_ld = gx["rows"], gx["k_pad"], 32
             assert X is None and gather is None and gn_fin is None and npx_log2 in (7, 8) and (self.use_cm or self.use_gxs)
         else:
@@ -322,13 +325,16 @@ class DenoiserEngine:
             vd = self.A.put(vec)
             out = sg["out"]
             coff = sg.get("out_coff", 0)
-            assert out.shape[1] >= coff + Opad and coff % (32 if self._is_cm(out) else 8) == 0, (out.shape, coff, Opad)
-            assert out.shape[0] == rows, (out.shape, rows)
             flags = sg.get("flags", 0)
-            if out.dtype == torch.float32 and self.prec == 1:
-                flags |= F_OUT_F32
+            if out is None:  # (the layer's output stays in the chaining kernel's registers)
+                assert chain is not None and len(segs) == 1
             else:
-                assert out.dtype == self.adt
+                assert out.shape[1] >= coff + Opad and coff % (32 if self._is_cm(out) else 8) == 0, (out.shape, coff, Opad)
+                assert out.shape[0] == rows, (out.shape, rows)
+                if out.dtype == torch.float32 and self.prec == 1:
+                    flags |= F_OUT_F32
+                else:
+                    assert out.dtype == self.adt
             for j in range(Opad // 32):
                 e = epis[blk]
                 e.mode = sg.get("mode", EPI_RAW)
@@ -336,11 +342,11 @@ class DenoiserEngine:
                 e.gs = gs_p
                 e.n_norm = int(min(32, max(0, n_norm_p - 32 * j)))
                 e.inv_count = 1.0 / (gs_l * sg.get("npx", npx))  # (npx: a pair segment's GroupNorm runs over the K-expanded rows)
-                e.out_ld = self._ldp(out)
+                e.out_ld = 0 if out is None else self._ldp(out)
                 e.bias = vd.data_ptr() + 4 * (32 * j)
                 e.gamma = vd.data_ptr() + 4 * (Opad + 32 * j)
                 e.beta = vd.data_ptr() + 4 * (2 * Opad + 32 * j)
-                e.out = self._colptr(out, coff + 32 * j)
+                e.out = None if out is None else self._colptr(out, coff + 32 * j)
                 if sg.get("addvec") is not None:
                     t, off, bs, idx, idx_stride = sg["addvec"]
                     assert off % 4 == 0 and bs % 4 == 0 and idx_stride % 4 == 0
@@ -393,8 +399,11 @@ class DenoiserEngine:
         in_bs = aff_off = 0
         if in_affine is not None:
             sc, sh, aff_off, in_bs = in_affine
+        if defer is not None:
+            return dict(W=Wd, epi=ed, n_cob=n_cob, k_pad=ld, flops=2 * rows * sum(int(s_["w"].size) for s_ in segs),
+                        wr=sum(rows * v[2] * v[1]["out"].element_size() for v in vec_list), wbytes=W.size * 4)
         if gx is not None:
-            return self._emit_gx(gx, npx_log2, rows, ld, n_cob, Wd, ed, segs, W, vec_list, in_affine, pair_tabs)
+            return self._emit_gx(gx, npx_log2, rows, ld, n_cob, Wd, ed, segs, W, vec_list, in_affine, pair_tabs, chain=chain)
         if pair_fused is not None:  # SLIDE_OP_PAIR_FIRST: per-point GEMM + pair-table pass in one launch (_pair_first)
             pf = pair_fused
             assert npx_log2 == 4 and self.prec == 1 and in_affine is None and gather is None and gn_fin is None and not w_cm
@@ -478,7 +487,7 @@ class DenoiserEngine:
         """the single-accumulator split kernels (csrc/gemm_gxs.hip) scale the weight's high term by 2^11 in fp16: |w| < 32"""
         return all(float(np.abs(w).max()) < 31.0 for w in ws if w.size)
 
-    def _emit_gx(self, gx, npx_log2, rows, ld, n_cob, Wd, ed, segs, W, vec_list, in_affine, pair_tabs):
+    def _emit_gx(self, gx, npx_log2, rows, ld, n_cob, Wd, ed, segs, W, vec_list, in_affine, pair_tabs, chain=None):
         """SLIDE_OP_GEMM_GX (include/slide_engine.h): gx = dict(ta, tb (fp16 tables [B*16][t_ld]), coff (first table column),
         k_pad, rows, mode, add=(tensor, offset, per-sample stride, idx tensor or None, idx stride) or None, vv = per-sample
         (vd | vw) fp32 [B][2][t_ld] of the 8-neighbour samples or None); pair_tabs = (neighbour, d2, w tables) for those"""
@@ -489,7 +498,10 @@ class DenoiserEngine:
         fl = 2 * rows * sum(int(s_["w"].size) for s_ in segs)
         self.gemm_flops[len(self.ops)] = fl
         rd = 2 * (rows >> npx_log2) * 16 * ld * tes + W.size * tes
-        wr = sum(rows * v[2] * v[1]["out"].element_size() for v in vec_list)
+        wr = sum(rows * v[2] * v[1]["out"].element_size() for v in vec_list if v[1]["out"] is not None)
+        if chain is not None:  # the chained layer's work rides on this launch
+            fl += chain["flops"]; rd += chain["wbytes"]; wr += chain["wr"]
+            self.gemm_flops[len(self.ops)] = fl
         self.gemm_bytes[len(self.ops)] = (rd, wr)
         sc = sh = None
         in_bs = aff_off = 0
@@ -523,11 +535,13 @@ class DenoiserEngine:
                 raise SlideHipError("a weight of magnitude >= 31 in a generated-X layer: the split pair-decomposition kernels scale the "
                                     "weights' high terms by 2^11 in fp16 -- build this plan with SLIDE_GXS=0")
             n64 = 3
-            self.kernel_names[len(self.ops)] = "gemm_gxs_kernel<%d, %d>" % (npx_log2, gx["mode"])
+            self.kernel_names[len(self.ops)] = ("gemm_gxs_chain_kernel<%d>" % npx_log2) if chain is not None else \
+                "gemm_gxs_kernel<%d, %d>" % (npx_log2, gx["mode"])
+            assert chain is None or (npx_log2 == 8 and gx["mode"] == 0 and n_cob <= 2 and chain["k_pad"] == n_cob * 32)
         self._emit(make_op(OP_GEMM_GX,
                            i=(rows, ta.shape[1], ld, n_cob, npx_log2, in_bs, gx["mode"], 0 if add is None else add[2],
                               0 if add is None else add[4], 0 if vv is None else 2 * vv.shape[2]),
-                           f=(float(n64),),
+                           f=(float(n64),) + ((float(chain["n_cob"]), float(chain["k_pad"])) if chain is not None else ()),
                            p=(ta.data_ptr() + tes * coff, Wd.data_ptr(), ed.data_ptr(),
                               None if sc is None else sc.data_ptr() + 4 * aff_off,
                               None if sh is None else sh.data_ptr() + 4 * aff_off,
@@ -537,7 +551,8 @@ class DenoiserEngine:
                               None if pair_tabs is None else pair_tabs[0].data_ptr(),
                               None if pair_tabs is None else pair_tabs[1].data_ptr(),
                               None if pair_tabs is None else pair_tabs[2].data_ptr(),
-                              None if vv is None else vv.data_ptr() + 4 * coff)))
+                              None if vv is None else vv.data_ptr() + 4 * coff,
+                              None if chain is None else chain["W"].data_ptr(), None if chain is None else chain["epi"].data_ptr())))
         self.flops += fl
 
     # ------------------------------------------------------------------ blocks
@@ -585,6 +600,24 @@ class DenoiserEngine:
             seg["addvec"] = (cvec, self._cvec_off(pfx + ".fc_condition", c2), self._c_bs, None, 0)
         if has_rest and pair is not None and self._sa_chain(pfx, npx_log2, pair, cvec, seg, final_out, final_coff):
             return
+        if (has_rest and pair is not None and self.use_gxs and npx_log2 == 8 and ru(gn_layout(c2)[1]) <= 64
+                and os.environ.get("SLIDE_GXS_CHAIN", "1") != "0"):
+            # split plans (round 5): second_mlp -> rest_mlp of an SA block in ONE launch -- h2 stays in the generated-X kernel's
+            # accumulators and feeds rest_mlp's contraction from there (csrc/gemm_gxs.hip, CHAIN); needs every channel of h2 in
+            # one 64-channel tile.  SLIDE_GXS_CHAIN=0: two launches and an h2 round trip
+            c3 = sd[pfx + ".rest_mlp.0.weight"].shape[0]
+            assert np.array_equal(gn_layout(c2)[0], np.arange(c2)), "second_mlp width with padded GroupNorm groups"
+            seg3 = with_res(dict(w=self._w(pfx + ".rest_mlp.0.weight"), bias=sd[pfx + ".rest_mlp.0.bias"], mode=EPI_NORM,
+                                 flags=F_POST_RELU, layout=gn_layout(c3), out=final_out, out_coff=final_coff,
+                                 gn=(sd[pfx + ".rest_mlp.1.group_norm.weight"], sd[pfx + ".rest_mlp.1.group_norm.bias"])))
+            if self._split1_ok(seg3["w"]):
+                layer2 = self._gemm(None, npx_log2, [seg3], pair_tabs=pair["tabs"], defer=dict(rows=rows, k_pad=ru(c2)))
+                seg["out"] = None
+                lay1 = pair["lay1"]
+                self._gemm(None, npx_log2, [seg], in_cols=lay1[0],
+                           gx=dict(ta=pair["ta"], tb=pair["tb"], coff=pair["off1"], k_pad=ru(lay1[1]), rows=rows, mode=0,
+                                   add=pair["add1"], vv=pair["vv"]), pair_tabs=pair["tabs"], chain=layer2)
+                return
         if has_rest:
             h2 = self._buf(rows, c2, cm=npx_log2 >= 7)
             seg["out"] = h2
