@@ -203,6 +203,15 @@ class DenoiserEngine:
         # PAIR residuals on float rows, the split attention tail -- the K-expanded first-layer outputs, scores and values of a block
         # never reach memory (SLIDE_GXS=0: the fp32-structured plan of round 4)
         self.use_gxs = self.prec == 2 and _os.environ.get("SLIDE_GXS", "1") != "0"
+        if self.use_gxs:
+            # its kernels run the split products on ONE accumulator set with the weight's high term scaled by 2^11 in fp16 (DESIGN.md
+            # section 5): exact while |w| < 32.  A checkpoint with a larger convolution weight takes the fp32-structured split plan.
+            wmax = max([float(np.abs(v).max()) for k, v in self.sd.items() if k.endswith(".weight") and v.ndim >= 3 and v.size] + [0.0])
+            if wmax >= 31.0:
+                import warnings
+                warnings.warn("a convolution weight of magnitude %.1f >= 31: the split plan falls back to its fp32-structured form "
+                              "(SLIDE_GXS=0 behaviour)" % wmax)
+                self.use_gxs = False
         self._cm = set()
         self._cm_copy = {}  # per-point table (data_ptr) -> its chunk-major copy, written by the table's producer as well
         self.ops = []

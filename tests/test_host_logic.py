@@ -91,6 +91,30 @@ def test_plan_structure_and_flops():
             pass
 
 
+def test_split_plan_structure_and_fallback():
+    """round 5: the split plan is the pair decomposition in the split arithmetic (generated-X GEMMs, dual launches, the SA blocks'
+    second_mlp -> rest_mlp chained, split attention tails): the position step is 28 launches (round 4: 49).  Its kernels scale the
+    weights' high terms by 2^11 in fp16, so a checkpoint with a convolution weight >= 31 falls back to the fp32-structured plan."""
+    import warnings
+    from slide_amd.engine import OP_ATTN_TAIL, OP_GEMM_GX, OP_GEMM_GX_DUAL, DenoiserEngine
+    from slide_amd.synth import synth_state_dict
+    hp = configs.position_ddpm_config()["pointnet_config"]
+    sd = synth_state_dict(model_spec.denoiser_param_spec(hp))
+    e = DenoiserEngine(hp, sd, 4, torch.device("cpu"), prec="split", per_sample_t=False, t_table=10)
+    kinds = [o.kind for o in e.ops]
+    assert e.use_gxs and len(kinds) == 28 and kinds.count(OP_GEMM_GX_DUAL) == 4 and kinds.count(OP_ATTN_TAIL) == 4
+    chained = [o for o in e._dual_keep if o[1].p[12]]          # mode-0 ops of the dual launches that carry a chained layer
+    assert len(chained) == 2 and all(o[1].i[4] == 8 for o in chained)  # the two SA blocks (16 x 16-row samples)
+    big = dict(sd)
+    k = "SA_modules.0.mlps.0.second_mlp.0.weight"
+    big[k] = sd[k].copy(); big[k].flat[0] = 40.0
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        e2 = DenoiserEngine(hp, big, 4, torch.device("cpu"), prec="split", per_sample_t=False, t_table=10)
+    assert not e2.use_gxs and any("falls back" in str(x.message) for x in w)
+    assert not any(o.kind in (OP_GEMM_GX, OP_GEMM_GX_DUAL, OP_ATTN_TAIL) for o in e2.ops) and len(e2.ops) == 49
+
+
 def test_checkpoint_layout(tmp_path):
     from slide_amd.checkpoint import load_denoiser_state
     from slide_amd.synth import synth_state_dict
