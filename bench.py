@@ -97,6 +97,22 @@ def _decode_profile_note():
     return {"source": os.path.relpath(fs[-1], REPO)}
 
 
+def _decode_hbm_note():
+    """HBM-side rate of the decode leg from the newest committed PMC summary (profiles/r*_decode_hbm_pmc.md, tools/decode_hbm.sh):
+    the leg's GEMMs run on millions of rows at K, N <= 256 -- it is HBM-bound, not matrix-pipe-bound"""
+    import glob
+    import re
+    fs = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_decode_hbm_pmc.md")))
+    if not fs:
+        return None
+    m = re.search(r"All kernels: (\d+) MB in ([0-9.]+) ms of kernel time = (\d+) GB/s = ([0-9.]+) of the 8 TB/s peak", open(fs[-1]).read())
+    if not m:
+        return {"source": os.path.relpath(fs[-1], REPO)}
+    return {"source": os.path.relpath(fs[-1], REPO), "bound": "hbm", "moved_MB": int(m.group(1)), "kernel_ms": float(m.group(2)),
+            "achieved": int(m.group(3)), "peak": 8000, "unit": "GB/s", "frac": float(m.group(4)),
+            "note": "FETCH_SIZE x2 + WRITE_SIZE over every kernel of tools/time_decode.py (fp16 operands), from the committed profile"}
+
+
 def decode_leg(dev, B):
     """BASELINE configs[4] on the driver's record: PointAutoencoder.decode of B synthetic latents to
     (B, 2048, 6) on the HIP module path (fp16 MFMA operands), shapes/s over three timed passes after two warm-up passes; not part
@@ -133,7 +149,7 @@ def decode_leg(dev, B):
                 # MFMA work); its per-kernel breakdown is the committed rocprofv3 summary
                 "roofline": {"bound": "mfma", "achieved": round(16.6e9 * B / dt / 1e12, 1), "peak": PEAK_TFLOPS["fp16"],
                              "unit": "TFLOP/s", "frac": round(16.6e9 * B / dt / 1e12 / PEAK_TFLOPS["fp16"], 4),
-                             "kernel_breakdown": _decode_profile_note()}}
+                             "kernel_breakdown": _decode_profile_note(), "hbm": _decode_hbm_note()}}
     finally:
         if prev is None:
             os.environ.pop("SLIDE_MODULE_PREC", None)

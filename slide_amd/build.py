@@ -22,9 +22,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # engine: the GEMM epilogue's per-channel-block loop must unroll fully (the accumulators are indexed by it; left rolled
 # they are demoted to scratch), which needs more than LLVM's default 16k-instruction cap for `#pragma unroll`.
 UNROLL = ["-mllvm", "-pragma-unroll-threshold=100000"]
-SOURCES = [("point_ops.hip", ["-ffp-contract=off"]), ("engine.hip", UNROLL), ("gemm_gx.hip", UNROLL), ("block_body.hip", UNROLL), ("gemm_gxs.hip", UNROLL),
+SOURCES = [("point_ops.hip", ["-ffp-contract=off"]), ("engine.hip", UNROLL), ("gemm_gx.hip", UNROLL), ("gemm_gxs.hip", UNROLL),
            ("rows_ops.hip", []), ("train_ops.hip", [])]
-SOURCES_EXP = SOURCES + [("experiments/gemm_xs.hip", UNROLL), ("experiments/gemm_chain.hip", UNROLL),
+SOURCES_EXP = SOURCES + [("experiments/block_body.hip", UNROLL), ("experiments/gemm_xs.hip", UNROLL), ("experiments/gemm_chain.hip", UNROLL),
                          ("experiments/resident.hip", UNROLL)]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
           "-Wno-unused-function", "-I", CSRC]

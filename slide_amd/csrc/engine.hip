@@ -27,7 +27,7 @@ int slide_launch_attn_tail_split(const SlideOp &o, hipStream_t s);  // gemm_gxs.
 int slide_launch_pp_stage(const SlideOp &o, hipStream_t s);  // gemm_gxs.hip
 int slide_launch_pair_norm(const SlideOp &o, hipStream_t s);
 int slide_launch_sa_chain(const SlideOp &o, hipStream_t s);
-int slide_launch_block_body(const SlideOp &o, hipStream_t s);  // block_body.hip
+int slide_launch_block_body(const SlideOp &o, hipStream_t s);  // experiments/block_body.hip
 #ifdef SLIDE_EXPERIMENTS
 int slide_launch_gemm_chain(const SlideOp &o, hipStream_t s);  // gemm_chain.hip
 #endif
@@ -2494,7 +2494,11 @@ int run_op(const SlideOp &o, hipStream_t s) {
     case SLIDE_OP_SA_CHAIN_P:
       return slide_launch_sa_chain_p(o, s);
     case SLIDE_OP_BLOCK_BODY:
+#ifdef SLIDE_EXPERIMENTS
       return slide_launch_block_body(o, s);
+#else
+      return SLIDE_ST_EXPERIMENT;  // (opt-in since round 5: block_body.hip is part of the experiments build)
+#endif
     case SLIDE_OP_TRANSPOSE:
       if (o.i[7])  // fp16 destination (module-level throughput mode)
         hipLaunchKernelGGL(transpose_kernel<_Float16>, dim3((o.i[2] + 31) / 32, (o.i[1] + 31) / 32, o.i[0]), dim3(256), 0, s,

@@ -12,7 +12,7 @@
 // of the attention tail (D[row][channel]: a lane owns a channel, the softmax over a point's neighbours is a register loop).
 // Nothing K-expanded touches memory: inputs are the per-point pair tables, outputs 16 rows per sample.  All weights stream
 // through one LDS-DMA ring of 16 KB slots whose (host-built) descriptor list runs ahead across every stage.
-#include "gemm_common.h"
+#include "../gemm_common.h"
 
 namespace {
 

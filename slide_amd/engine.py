@@ -814,7 +814,10 @@ class DenoiserEngine:
     def _body_shape(self, mpfx, apfx, npx_log2):
         """(rest, nb1, nbm, nbu) if SLIDE_OP_BLOCK_BODY has an instantiation for this block's widths, else None"""
         sd = self.sd
-        if not self.use_gx or os.environ.get("SLIDE_BODY", "1") == "0":
+        # OPT-IN since round 5 (SLIDE_BODY=1, experiments build): with the split position plan beside the feature chains the one-launch
+        # body of the FP0-sized blocks LOSES 0.9 % to its three separate launches (378.5 vs 382.0 shapes/s, four alternating pairs) --
+        # one workgroup per CU at 0.024 MFMA-busy holds a CU for 31 us where the ring kernels' small workgroups interleave
+        if not self.use_gx or os.environ.get("SLIDE_BODY", "0") == "0":
             return None
         rest = (mpfx + ".rest_mlp.0.weight") in sd
         c1 = sd[mpfx + ".first_mlp.0.weight"].shape[0]
@@ -832,7 +835,7 @@ class DenoiserEngine:
         shape = (npx_log2, rest, (c2 // 32) if rest else 0, n_mo // 32, n_u // 32)
         # ((7, False, 0, 8, 8) -- FP1 -- was built and measured slower than its three separate launches: one wave per SIMD)
         # ((8, True, 4, 8, 5) -- SA0 -- spills under its 256-register budget: opt-in with SLIDE_BODY=2)
-        if shape not in (((7, False, 0, 4, 4), (8, True, 4, 8, 5)) if os.environ.get("SLIDE_BODY", "1") == "2" else ((7, False, 0, 4, 4),)):
+        if shape not in (((7, False, 0, 4, 4), (8, True, 4, 8, 5)) if os.environ.get("SLIDE_BODY", "0") == "2" else ((7, False, 0, 4, 4),)):
             return None
         return shape
 

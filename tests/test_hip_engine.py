@@ -636,9 +636,9 @@ def test_pair_decomposition_plan_variants(gpu_device, exp_lib, monkeypatch):
         x, ts, lab = g["x_mixed"], g["ts_mixed"], g["label_mixed"]
         ref = g["eps_mixed"]
         outs = {}
-        for tag, knobs in (("round2", {"SLIDE_GX": "0"}), ("default", {}), ("no_body", {"SLIDE_BODY": "0"}),
-                           ("no_body_no_chain", {"SLIDE_BODY": "0", "SLIDE_SA_CHAIN": "0"}),
-                           ("pair_norm_v2", {"SLIDE_PAIR_NORM_V2": "1"}), ("tail8", {"SLIDE_TAIL8": "1", "SLIDE_BODY": "0"}),
+        for tag, knobs in (("round2", {"SLIDE_GX": "0"}), ("default", {}), ("block_body", {"SLIDE_BODY": "1"}),
+                           ("no_chain", {"SLIDE_SA_CHAIN": "0"}),
+                           ("pair_norm_v2", {"SLIDE_PAIR_NORM_V2": "1"}), ("tail8", {"SLIDE_TAIL8": "1"}),
                            ("two_launch_tables", {"SLIDE_PAIR_FUSED": "0"}), ("gemm_chains", {"SLIDE_GEMM_CHAIN": "256"}),
                            ("wide_key_tiles", {"SLIDE_GX_N64": "0"}), ("no_half_tiles_on_small_grids", {"SLIDE_GX_N64W": "0"}), ("no_dual_launch", {"SLIDE_GX_DUAL": "0"}), ("query_gemm_apart", {"SLIDE_CHAIN_P": "0"}), ("tail_occ3", {"SLIDE_TAIL_OCC3": "1"}), ("wide_tail", {"SLIDE_TAIL_WIDE": "8"}),
                            ("long_gemm_chains", {"SLIDE_GEMM_CHAIN": "100000"})):
@@ -653,6 +653,7 @@ def test_pair_decomposition_plan_variants(gpu_device, exp_lib, monkeypatch):
             else:
                 assert 31 in kinds and 18 not in kinds  # SLIDE_OP_PAIR_FIRST: GEMM + table pass in one launch
             assert (32 in kinds) == ("gemm_chain" in tag)  # SLIDE_OP_GEMM_CHAIN (opt-in): per-point layer chains, one launch each
+            assert (30 in kinds) == (tag == "block_body" and name == "feat")  # SLIDE_OP_BLOCK_BODY (opt-in since round 5): FP0 of the feature net
             outs[tag] = e.forward(x, ts, lab).cpu().numpy().astype(np.float64)
             for k_ in knobs:
                 monkeypatch.delenv(k_)
