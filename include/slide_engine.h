@@ -89,7 +89,7 @@ enum {
   SLIDE_OP_ADVANCE_T = 12,  /* p: t_dev  (t_dev[0] -= 1; t_dev[1] += 1); t_dev = [t, step, blocks-done counter, chain nonce, global index of the first sample, 3 spare] (8 ints) */
   SLIDE_OP_SYNC = 14,       /* i: from_lane, to_lane -- lane `to` waits for everything issued so far on lane `from` */
   SLIDE_OP_GROUPNORM_NCHW = 13,/* p: x, gamma, beta, y (NCHW fp32)   i: B, C, HW, G, n_norm, relu  (module-level path) */
-  SLIDE_OP_ATTN_TAIL = 16,  /* fp16: scores GEMM + values GEMM (GroupNorm, ReLU) + softmax-weighted sum over the neighbours in one launch.  p: u, W5, mo, Wv, out, vec [bias_s | bias_v | gamma | beta][n_cob*32], [6] optional chunk-major copy of out [c/32][points][32] (a gather table of the next block: SLIDE_OP_GEMM f[2] == 32 reads p[8] that way), [7] optional copy of the first f[3] channels into another per-point buffer with leading dimension f[2]   i: rows, u_ld, k1, mo_ld, k2, n_cob, npx_log2, gs, n_norm, out_ld   f: 1 / (gs * rows per sample), [1] bit 0: both weight matrices chunk-major [k/32][n_cob*32][32] (u / mo are chunk-major [k/32][rows][32] when their ld is 32), bit 1: the two-stage-ring form at three workgroups per CU */
+  SLIDE_OP_ATTN_TAIL = 16,  /* fp16: scores GEMM + values GEMM (GroupNorm, ReLU) + softmax-weighted sum over the neighbours in one launch.  p: u, W5, mo, Wv, out, vec [bias_s | bias_v | gamma | beta][n_cob*32], [6] optional chunk-major copy of out [c/32][points][32] (a gather table of the next block: SLIDE_OP_GEMM f[2] == 32 reads p[8] that way), [7] optional copy of the first f[3] channels into another per-point buffer with leading dimension f[2]   i: rows, u_ld, k1, mo_ld, k2, n_cob, npx_log2, gs, n_norm, out_ld   f: 1 / (gs * rows per sample), [1] bit 0: both weight matrices chunk-major [k/32][n_cob*32][32] (u / mo are chunk-major [k/32][rows][32] when their ld is 32), bit 1: the two-stage-ring form at three workgroups per CU, bit 3 (round 5, csrc/gemm_gxs.hip attn_tail_split_kernel): SPLIT arithmetic -- u, mo and out are FLOAT rows, both weight matrices float row-major [n_cob*32][k], every contraction as two-term fp16 operand splits on one accumulator set (|w| < 32 required) */
   SLIDE_OP_GEMM_GX = 17,    /* fp16 "generated-X" GEMM of the pair decomposition (gemm_gx.hip): the first layer of an SA / FP
                              * block is linear in [neighbour features | coordinates], so its output for row (point p, slot j) is ta[q] + tb[p]
                              * (q = the slot's neighbour) -- the 256- / 128-row activation this GEMM consumes is never stored: a workgroup keeps
@@ -103,7 +103,13 @@ enum {
                              *    [8] nbr table, [9] d2, [10] w (fp32 [B*16][16]; npx_log2 7), [11] vd | vw fp32 [b*vbs + {0, vbs/2} + k] (SLIDE_OP_PAIR_NORM's vv, column offset applied) or NULL
                              * i: rows, t_ld (elements between table rows), k_pad, n_cob, npx_log2, in_bs, mode, add_bs, add_idx_stride, vbs
                              * f: [0] = 1 (mode 1): 256 x 64 tiles at three workgroups per CU when their LDS fits; 2: 256 x 64 tiles at two per CU
-                             *    (launches whose 128-channel grid leaves CUs empty); else 256 x 128 tiles */
+                             *    (launches whose 128-channel grid leaves CUs empty); else 256 x 128 tiles
+                             * SPLIT ARITHMETIC (round 5, csrc/gemm_gxs.hip): f[0] = 3 -- ta / tb are FLOAT tables, W float row-major
+                             *    [n_cob*32][k_pad], outputs float rows; x is generated in fp32 and split into two fp16 terms like the weights,
+                             *    three fp16 MFMAs per product into one accumulator set (|w| < 32 required); the PAIR residual of a mode-0
+                             *    block reads float tables.  CHAINED second layer (16 x 16-row samples, mode 0, n_cob <= 2): p[12] = its float
+                             *    weights [f[1]*32][f[2]], p[13] = its SlideEpi[f[1]] (GroupNorm epilogue, no add vector), f[2] == n_cob*32 --
+                             *    this layer's output stays in registers (its SlideEpi.out is NULL) and only the second layer's is stored */
   SLIDE_OP_PAIR_NORM = 18,  /* per-point tables of the pair decomposition: a[q][c] = y[q][c] + wa[c] . xyz[q], b[p][c] = wb[c] . xyz[p]; for each
                              * 32-channel block by its SlideEpi (mode, gs, n_norm, inv_count, gamma, beta, stats_*; bias already in y):
                              *   NORM : GroupNorm statistics over the sample's (p, slot) pairs of a[q] + b[p] (+ d2 vd + w vw), folded into the
@@ -114,7 +120,8 @@ enum {
                              *    [5] ta, [6] tb (fp16 [B*16][ld]), [7] nbr table or NULL (natural order, K = 16), [8] d2, [9] w, [10] vd | vw
                              *    fp32 [2][ld] (K = 8), [11] vv fp32 [B][2][ld] out (K = 8), [12] SlideGnFin* or NULL (version 2: the joint GroupNorm over the
                              *    attention's [query | key] concatenation is finalised here: scale / shift rows written, the STATS sums stay on chip)
-                             * i: B, ld, K, version (2: one 1024-thread workgroup per sample, ld <= 2048; else one per 256 channels) */
+                             * i: B, ld, K, version (2: one 1024-thread workgroup per sample, ld <= 2048; else one per 256 channels),
+                             *    [4] = 1: ta / tb are FLOAT tables (split plans, round 5; version 2 only: 512-thread workgroups) */
   SLIDE_OP_SA_CHAIN = 19,   /* second_mlp -> rest_mlp of an SA block's Mlp_plus_t_emb in one launch, one workgroup per 16 x 16-row sample:
                              * h2 = relu(GN(W1 . h1 + b1)) + add1 with h1 = max(ta[q] + tb[p], 0) + add0 generated from the pair tables, kept in
                              * registers as the B fragments of mo = relu(GN(W2 . h2 + b2)) + ra[q] + rb[p] (pair residual), stored chunk-major.

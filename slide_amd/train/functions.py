@@ -49,7 +49,8 @@ def _packs(weight, kp, op_):
     c = _PACK_CACHE.get(key)
     if c is None:
         if len(_PACK_CACHE) > 4096:
-            _PACK_CACHE.clear()
+            # (never evict: the buffers' addresses are baked into captured step graphs -- ADVICE r4; a model has a few hundred entries)
+            raise RuntimeError("slide_amd.train: more than 4096 packed weight buffers alive -- parameters are being re-created every step")
         dev = weight.device
         c = {"W": torch.zeros(op_, kp, device=dev), "Wt": torch.zeros(kp, op_, device=dev), "vec": torch.zeros(op_, device=dev),
              "zero": torch.zeros(kp, device=dev)}
@@ -68,7 +69,7 @@ def _gemm(x, w_packed, bias_vec, n_out_pad):
     c = _EPI_CACHE.get(key)
     if c is None:
         if len(_EPI_CACHE) > 8192:
-            _EPI_CACHE.clear()
+            raise RuntimeError("slide_amd.train: more than 8192 epilogue tables alive (their addresses are baked into captured graphs)")
         tab = (SlideEpi * n_cob)()
         for j in range(n_cob):
             t = tab[j]
