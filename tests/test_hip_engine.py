@@ -704,6 +704,26 @@ def test_split_pair_decomposition_plan_variants(gpu_device, exp_lib, monkeypatch
         assert np.array_equal(outs["no_dual_launch"], outs["default"]), name
 
 
+@pytest.mark.parametrize("name", ["pos", "feat"])
+def test_split_plan_on_ragged_batches(gpu_device, name):
+    """the split pair-decomposition kernels own 256-row tiles: one 16 x 16-row sample, or TWO 16 x 8-row samples -- an odd batch leaves
+    the last FP-block tile half empty, a batch of one leaves it with a single sample.  Split plan vs the exact-fp32 plan on random
+    inputs for B = 1, 3, 5, 9: <= 2e-5 (max-norm), every output finite."""
+    from slide_amd.engine import DenoiserEngine
+    from slide_amd.synth import synth_keypoints
+    g, hp, sd = _load(name)
+    cx = 3 + hp["in_fea_dim"]
+    for B in (1, 3, 5, 9):
+        rs = np.random.RandomState(100 + B)
+        x = rs.standard_normal((B, 16, cx)).astype(np.float32)
+        x[:, :, :3] = synth_keypoints(B, seed=B)
+        ts = rs.randint(0, 1000, B).astype(np.float32)
+        lab = rs.randint(0, 13, B).astype(np.int64)
+        y32 = DenoiserEngine(hp, sd, B, gpu_device, prec="fp32").forward(x, ts, lab).cpu().numpy()
+        ysp = DenoiserEngine(hp, sd, B, gpu_device, prec="split").forward(x, ts, lab).cpu().numpy()
+        assert np.isfinite(ysp).all() and _rel(ysp, y32) <= 2e-5, (name, B, _rel(ysp, y32))
+
+
 def _full_chains(gpu_device, B, precs):
     """complete 1000-step position / feature chains of B shapes per arithmetic in `precs` = {name: (pos prec, feat prec)}"""
     from slide_amd.diffusion import FeatureSampler, PositionSampler
