@@ -41,7 +41,7 @@ __device__ __forceinline__ void gxs_split4w(const float4 v, f16x4 &hi, f16x4 &hs
 // five fp16 planes [X hi | X lo | W hi | 2^11 W hi | W lo] (rows of LDK = 40 halves: 56 KB); the next chunk's table rows and weights wait in
 // registers.  Thread (l_row = tid / 8, l_c = 4 (tid % 8)) generates columns l_c .. l_c + 3 of tile rows l_row + 32 p, p = 0 .. 7:
 // 16 x 16-row samples run in NATURAL neighbour order, so its eight rows share ONE neighbour row (q = l_row % 16) and touch eight
-// centre rows; 16 x 8-row samples look their neighbours up once (nbr table) and keep the two per-slot scalars in registers.
+// centre rows; 16 x 8-row samples look their neighbours up once (nbr table) into a per-tile-row LDS table (offset, d2, w).
 // The per-sample vectors (add | scale, shift | vd, vw) are staged once per workgroup in LDS.
 // CHAIN (16 x 16-row samples, mode 0; round 5): the layer's output -- h2 = relu(GN(second_mlp(h1))) + class embedding of an SA block,
 // at most 64 channels: one column tile -- is NOT stored: the common epilogue leaves it in the accumulators (KEEP), each 32-channel
