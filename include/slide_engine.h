@@ -170,7 +170,8 @@ enum {
   SLIDE_OP_ROWS_GN = 23,       /* p: x, gamma, beta, addvec [B][addvec_ld] fp32 (or NULL), residual rows (or NULL), scratch (B*64*ld*2 + B*2*ld floats), y (may be x), [7] / [8] per-tile channel sums / sums of squares [B*i[8]][ld] from the producing GEMM's STATS epilogue (256-row tiles, i[8] tiles per sample) instead of a statistics pass, [10] optional OUT: the statistics [B][64][mean | rstd] fp32 (the training step's backward, slide_train.h)   i: B, S, ld, G (0 = no normalisation), n_norm, flags (1 ReLU before, 2 ReLU after, 4 statistics + scale / shift only -> p[9] [B][2][ld] fp32, for a consumer GEMM with the deferred affine; 8 apply only with p[9]), addvec_ld, res_ld, tiles per sample */
   SLIDE_OP_ROWS_CONCAT_QK = 24,/* p: q [rows/K][ldq], k [rows][ldk], out [rows][ldo] = relu([q | k])   i: rows, K, C1, ldq, C2, ldk, ldo */
   SLIDE_OP_ROWS_ATTN = 25,     /* p: scores [pts*K][lds], values [pts*K][ldv], out [pts][ldo], [3] counts int32 [pts] or NULL (softmax over the first max(1,count) slots), [4] deferred normalisation of the values: scale / shift [sample][2][ldv] fp32 or NULL   i: pts, K, C, lds, ldv, ldo, points per sample, ReLU after the affine */
-  SLIDE_OP_ROWS_POOL = 26      /* p: x [pts*K][ldx], out [pts][ldo], counts int32 [pts] or NULL   i: pts, K, C, ldx, ldo, mode (0 max, 1 mean over the counted slots, 2 max for channels < C/2 and mean for the rest) */
+  SLIDE_OP_ROWS_POOL = 26,     /* p: x [pts*K][ldx], out [pts][ldo], counts int32 [pts] or NULL   i: pts, K, C, ldx, ldo, mode (0 max, 1 mean over the counted slots, 2 max for channels < C/2 and mean for the rest) */
+  SLIDE_OP_ROWS_GN_JOINT = 27  /* round 5: GroupNorm over the VIRTUAL concatenation [q(point) x K | k(point, neighbour)] of an AttentionModule (attention.py:45-47) from the per-256-row-tile channel sums of the two producing GEMMs (STATS epilogue): p: qsum, qsq [B*tq][ldq], ksum, ksq [B*tk][ldk], gamma, beta [n_norm], OUT ssq [B][2][ldq], ssk [B][2][ldk] (scale | shift per sample and channel in the producers' layouts)   i: B, C1, ldq, tq, K, C2, ldk, tk, G   f: 1 / (rows of k per sample), n_norm */
 };
 
 /* GroupNorm finalisation folded into the first consumer (fp16 small-launch GEMM with input affine, SlideOp.p[6]):

@@ -3,6 +3,8 @@ AttentionModule (:35-96, vector attention over the K neighbours), GlobalAttentio
 signatures and state-dict names.  AttentionModule runs row-major (slide_amd.rows: GEMMs on [B * np * K][C] matrices, in-place
 GroupNorm passes, one softmax-reduction kernel); GlobalAttentionModule (N x N scores, unused by the shipped configs) is a
 tensor program over the HIP convolution / GroupNorm kernels."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -51,19 +53,46 @@ class AttentionModule(nn.Module):
                 layers.append(nn.ReLU(inplace=True))
             self.feat_out_conv = nn.Sequential(*layers)
 
+    def _u_without_concat(self, query, grouped, K, wc):
+        """round 5: relu(weight_conv.2(GN(relu([q | k])))) WITHOUT building the concatenation.  Both producers store their ReLU'd outputs
+        and publish tile sums from their GEMM epilogues, the joint GroupNorm over the virtual concatenation is finalised from those
+        (SLIDE_OP_ROWS_GN_JOINT), and weight_conv.2 is linear: its q half is evaluated once per POINT (1 / K of the MACs) and enters
+        the k half's GEMM as a per-point term ahead of the ReLU -- what the fused DDPM plan does (slide_amd/engine.py _attention).
+        Saves the concat + ReLU pass, the statistics pass over it and C1 / (C1 + C2) of the consumer GEMM's input bytes.  None when the
+        shapes do not qualify (fp32 module mode, samples that are not whole 256-row tiles, K not a power of two): the caller concatenates."""
+        if not (R.deferral() and R.fused_stats() and query.half and query.S % 256 == 0 and grouped.S % 256 == 0 and K & (K - 1) == 0
+                and grouped.rows == query.rows * K and os.environ.get("SLIDE_MODULE_SPLIT_QK", "1") != "0"):
+            return None
+        q1 = R.conv(query, self.feat_conv, stats="relu")
+        k1 = R.conv(grouped, self.grouped_feat_conv, stats="relu")
+        C1, C2 = q1.C, k1.C
+        if not R.joint_norm_qk(q1, k1, K, wc[1].group_norm):
+            tot = R.concat_qk(q1, k1, K)  # (no tile statistics after all: the three-pass form on the outputs already computed)
+            R.norm_act(tot, wc[1].group_norm, defer=True)
+            return R.conv(tot, wc[2], stats="relu")
+        sl = self.__dict__.get("_w2_slices")
+        if sl is None or sl[0] is not wc[2] or sl[1] != (C1, C2):
+            sl = (wc[2], (C1, C2), R.WeightSlice(wc[2], 0, C1, False), R.WeightSlice(wc[2], C1, C1 + C2, True))
+            self.__dict__["_w2_slices"] = sl
+        P = R.conv(q1, sl[2])                                     # per point: W2[:, :C1] . GN(relu(q))
+        return R.conv(k1, sl[3], stats="relu", pre_add=(P, K))    # relu(W2[:, C1:] . GN(relu(k)) + b2 + P[point])
+
     def forward_rows(self, query, grouped, grouped_out, K, counts=None):
         """query Rows [B * np][C_in1], grouped Rows [B * np * K][C_in2], grouped_out Rows [B * np * K][C_out] -> Rows
         [B * np][C_out].  Reference :81-95 as 4-5 GEMMs, three in-place normalise passes, one concat-ReLU pass and one
         softmax-weighted reduction over the K rows of a point; counts (B, np): only the first max(1, count) neighbour
         slots of a point are real (ball query) -- the reference masks the others with -1e9 before the softmax."""
         wc = list(self.weight_conv)
-        tot = R.concat_qk(R.conv(query, self.feat_conv), R.conv(grouped, self.grouped_feat_conv), K)  # wc[0]: ReLU
         if isinstance(wc[1], MyGroupNorm):
-            R.norm_act(tot, wc[1].group_norm, defer=True)  # (both normalisations are applied by the GEMMs that follow)
-            u = R.conv(tot, wc[2], stats="relu")
+            u = self._u_without_concat(query, grouped, K, wc)
+            if u is None:
+                tot = R.concat_qk(R.conv(query, self.feat_conv), R.conv(grouped, self.grouped_feat_conv), K)  # wc[0]: ReLU
+                R.norm_act(tot, wc[1].group_norm, defer=True)  # (both normalisations are applied by the GEMMs that follow)
+                u = R.conv(tot, wc[2], stats="relu")
             R.norm_act(u, wc[4].group_norm, pre_relu=True, defer=True)
             scores = R.conv(u, wc[5])
         else:
+            tot = R.concat_qk(R.conv(query, self.feat_conv), R.conv(grouped, self.grouped_feat_conv), K)  # wc[0]: ReLU
             u = R.conv(tot, wc[1])
             R.norm_act(u, relu=True)
             scores = R.conv(u, wc[3])

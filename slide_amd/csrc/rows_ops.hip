@@ -262,6 +262,59 @@ __global__ __launch_bounds__(256) void rows_gn_finalize_kernel(int S, int ld, in
   }
 }
 
+// Joint GroupNorm of the attention's VIRTUAL concatenation [q(point) broadcast over the K neighbours | k(point, neighbour)]
+// (weight_conv.1 of AttentionModule, attention.py:45-47) from the per-tile channel sums the two producing GEMMs published: the
+// concatenated tensor is never built (round 5; the concat + ReLU pass and the statistics pass over it were 16 % of the decode leg's
+// bytes).  Per sample: channel sums of the q half = mult_q x its tile sums (every point row stands K times in the concatenation),
+// of the k half = its tile sums; groups may straddle the two halves; scale / shift go to TWO tables in the producers' own layouts
+// (ssq [B][2][ldq], ssk [B][2][ldk]) for the consumers' deferred-normalisation loaders.
+__global__ __launch_bounds__(256) void rows_gn_joint_kernel(int C1, int ldq, int tq, float mult_q, int C2, int ldk, int tk, int G,
+                                                            int n_norm, float inv_rows, const float *__restrict__ qsum,
+                                                            const float *__restrict__ qsq, const float *__restrict__ ksum,
+                                                            const float *__restrict__ ksq, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, float *__restrict__ ssq,
+                                                            float *__restrict__ ssk) {
+  __shared__ float lsum[1024], lsq[1024], lmean[64], lrstd[64];
+  const int b = blockIdx.x, C = C1 + C2;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s1 = 0.f, q1 = 0.f;
+    if (c < C1) {
+      for (int t = 0; t < tq; ++t) { s1 += qsum[((size_t)b * tq + t) * ldq + c]; q1 += qsq[((size_t)b * tq + t) * ldq + c]; }
+      s1 *= mult_q; q1 *= mult_q;
+    } else {
+      for (int t = 0; t < tk; ++t) { s1 += ksum[((size_t)b * tk + t) * ldk + (c - C1)]; q1 += ksq[((size_t)b * tk + t) * ldk + (c - C1)]; }
+    }
+    lsum[c] = s1; lsq[c] = q1;
+  }
+  __syncthreads();
+  const int gs = n_norm / G;
+  const float inv = inv_rows / (float)gs;
+  for (int g = threadIdx.x; g < G; g += 256) {
+    float s1 = 0.f, q1 = 0.f;
+    for (int j = 0; j < gs; ++j) { s1 += lsum[g * gs + j]; q1 += lsq[g * gs + j]; }
+    const float mean = s1 * inv;
+    const float var = fmaxf(q1 * inv - mean * mean, 0.f);
+    lmean[g] = mean;
+    lrstd[g] = 1.0f / sqrtf(var + 1e-5f);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < ldq + ldk; c += 256) {
+    const bool isq = c < ldq;
+    const int cl = isq ? c : c - ldq;              // channel inside its producer's row
+    const bool valid = isq ? cl < C1 : cl < C2;    // (pad columns: identity -- their rows are zero and so are their weights)
+    const int cj = isq ? cl : C1 + cl;             // logical channel of the concatenation
+    float sc = 1.f, sh = 0.f;
+    if (valid && cj < n_norm) {
+      const int g = cj / gs;
+      sc = gamma[cj] * lrstd[g];
+      sh = beta[cj] - lmean[g] * sc;
+    }
+    float *dst = isq ? ssq + (size_t)b * 2 * ldq + cl : ssk + (size_t)b * 2 * ldk + cl;
+    dst[0] = sc;
+    dst[isq ? ldq : ldk] = sh;
+  }
+}
+
 // Pass 2: y = post_relu( pre_relu(x) * scale + shift ) + addvec[b] + residual[row]; ss == NULL: no normalisation at all --
 // the plain ReLU / add epilogue of a layer without GroupNorm.
 template <typename T>
@@ -511,6 +564,17 @@ int launch_rows(const SlideOp &o, hipStream_t s) {
       hipLaunchKernelGGL(rows_attn_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, o.i[1], o.i[2], o.i[3],
                          o.i[4], o.i[5], (const T *)o.p[0], (const T *)o.p[1], (const int *)o.p[3], (T *)o.p[2], total,
                          (const float *)o.p[4], o.i[6] > 0 ? o.i[6] : 1, o.i[7]);
+      break;
+    }
+    case SLIDE_OP_ROWS_GN_JOINT: {  // i: B, C1, ldq, tq, K, C2, ldk, tk, G (n_norm in f[1])   f: 1 / rows per sample, n_norm   p: qsum, qsq, ksum, ksq, gamma, beta, ssq, ssk
+      const int B = o.i[0], C1 = o.i[1], ldq = o.i[2], tq = o.i[3], K = o.i[4], C2 = o.i[5], ldk = o.i[6], tk = o.i[7], G = o.i[8];
+      const int n_norm = (int)o.f[1];
+      if (C1 + C2 > 1024 || G <= 0 || G > 64 || n_norm % G || n_norm > C1 + C2 || tq <= 0 || tk <= 0 || C1 > ldq || C2 > ldk) return -3;
+      for (int k = 0; k < 8; ++k)
+        if (!o.p[k]) return -3;
+      hipLaunchKernelGGL(rows_gn_joint_kernel, dim3(B), dim3(256), 0, s, C1, ldq, tq, (float)K, C2, ldk, tk, G, n_norm, o.f[0],
+                         (const float *)o.p[0], (const float *)o.p[1], (const float *)o.p[2], (const float *)o.p[3],
+                         (const float *)o.p[4], (const float *)o.p[5], (float *)o.p[6], (float *)o.p[7]);
       break;
     }
     case SLIDE_OP_ROWS_POOL: {  // i: points, K, C, ldx, ldo, mode   p: x, out, counts

@@ -20,6 +20,7 @@ from .engine import EPI_RAW, EPI_STATS, F_PRE_RELU, OP_GEMM, SlideEpi, SlideOp, 
 
 OP_COPY_COLS = 7
 OP_ROWS_FROM_NCX, OP_ROWS_TO_NCX, OP_ROWS_GROUP, OP_ROWS_GN, OP_ROWS_CONCAT_QK, OP_ROWS_ATTN, OP_ROWS_POOL = 20, 21, 22, 23, 24, 25, 26
+OP_ROWS_GN_JOINT = 27
 GROUP_FP, GROUP_ABS, GROUP_CENTER, GROUP_NO_XYZ, GROUP_IDX32 = 1, 2, 4, 8, 16
 POOL_MAX, POOL_AVG, POOL_MAX_AVG = 0, 1, 2
 GN_PRE_RELU, GN_POST_RELU, GN_STATS_ONLY, GN_APPLY_ONLY = 1, 2, 4, 8
@@ -147,8 +148,10 @@ class _ConvPlan:
             self.vec[:O] = bias.detach().float()
         self.epis = {}  # output pointer -> device epilogue table (the caching allocator recycles a handful of addresses)
 
-    def epi(self, out, stats=None, pre_relu=False):
-        key = (out.device.index, out.data_ptr(), None if stats is None else (stats[0].data_ptr(), stats[1].data_ptr()), pre_relu)
+    def epi(self, out, stats=None, pre_relu=False, pre_add=None):
+        """pre_add = (per-point tensor [points][ld], log2 K): + pre_add[row >> log2 K] before the ReLU (SlideEpi.pre_add)"""
+        key = (out.device.index, out.data_ptr(), None if stats is None else (stats[0].data_ptr(), stats[1].data_ptr()), pre_relu,
+               None if pre_add is None else (pre_add[0].data_ptr(), pre_add[1]))
         e = self.epis.get(key)
         if e is None:
             if len(self.epis) >= 16:
@@ -163,6 +166,10 @@ class _ConvPlan:
                 t.out_ld = self.op_
                 t.bias = self.vec.data_ptr() + 4 * 32 * j
                 t.out = out.data_ptr() + esz * 32 * j
+                if pre_add is not None:
+                    t.pre_add = pre_add[0].data_ptr() + pre_add[0].element_size() * 32 * j
+                    t.pre_add_ld = pre_add[0].shape[1]
+                    t.pre_add_shift = pre_add[1]
                 if stats is not None:
                     t.stats_sum = stats[0].data_ptr() + 4 * 32 * j
                     t.stats_sq = stats[1].data_ptr() + 4 * 32 * j
@@ -172,10 +179,16 @@ class _ConvPlan:
             self.epis[key] = e
         return e
 
-    def run(self, x, stats=None):
+    def run(self, x, stats=None, pre_add=None):
         """stats: None | "raw" | "relu" -- also publish per-256-row-tile channel sums of the output (of its ReLU) from the
-        GEMM epilogue, for the GroupNorm that follows (saves its statistics pass); only when tiles do not straddle samples"""
+        GEMM epilogue, for the GroupNorm that follows (saves its statistics pass); only when tiles do not straddle samples.
+        pre_add = (Rows of per-point terms, K): + term[row // K] ahead of the ReLU (K a power of two)"""
         assert x.ld == self.kp and x.half == self.half, (x.ld, self.kp, x.half, self.half)
+        pa = None
+        if pre_add is not None:
+            pr, K = pre_add
+            assert pr.pending is None and pr.half == self.half and pr.rows * K == x.rows and pr.ld >= self.op_ and K & (K - 1) == 0
+            pa = (pr.data, K.bit_length() - 1)
         rows = x.rows
         out = _empty(rows, self.op_, self.half, x.data.device)
         if rows == 0:  # empty batch: nothing to launch
@@ -196,7 +209,7 @@ class _ConvPlan:
             f = (0.0, float(x.S // 256), float(addvec.shape[1]) if addvec is not None else 0.0,
                  float(2 * (addvec.shape[1] if addvec is not None else 0) + int(relu)))
         _run(make_op(OP_GEMM, i=(rows, self.kp, self.kp, n_cob, 8, in_bs, int(self.half), cbw, int(self.half), 0), f=f,
-                     p=(x.data.data_ptr(), self.W.data_ptr(), self.epi(out, st, stats == "relu").data_ptr(), sc, sh,
+                     p=(x.data.data_ptr(), self.W.data_ptr(), self.epi(out, st, stats == "relu", pa).data_ptr(), sc, sh,
                         None, None, None, None, None, None, add)))
         return Rows(out, x.B, x.S, self.O, stats=None if st is None else (st[0], st[1], stats == "relu"))
 
@@ -220,8 +233,25 @@ def materialise(x):
     return x
 
 
-def conv(x, module, stats=None):
-    """HipConv1x1 / HipLinear applied to Rows (weights re-packed when the parameter changes); stats: see _ConvPlan.run.
+class WeightSlice:
+    """a column slice [c0, c1) of a 1x1 convolution's weight as a layer of its own for conv() (bias: the module's, or none) -- the two
+    halves of AttentionModule.weight_conv.2 over the virtual concatenation [q | k]"""
+
+    def __init__(self, module, c0, c1, with_bias):
+        self.module, self.c0, self.c1, self.with_bias = module, c0, c1, with_bias
+
+    @property
+    def weight(self):
+        w = self.module.weight
+        return w.reshape(w.shape[0], -1)[:, self.c0:self.c1]
+
+    @property
+    def bias(self):
+        return self.module.bias if self.with_bias else None
+
+
+def conv(x, module, stats=None, pre_add=None):
+    """HipConv1x1 / HipLinear applied to Rows (weights re-packed when the parameter changes); stats, pre_add: see _ConvPlan.run.
     A deferred normalisation of x is applied by the GEMM itself when its tiles do not straddle samples."""
     if x.pending is not None and not (x.half and x.S % 256 == 0):
         materialise(x)
@@ -234,7 +264,28 @@ def conv(x, module, stats=None):
     if plan is None or plan[0] != key:
         plan = (key, _ConvPlan(w, module.bias, x.half, x.data.device))
         module.__dict__["_rows_plan"] = plan
-    return plan[1].run(x, stats)
+    return plan[1].run(x, stats, pre_add)
+
+
+def joint_norm_qk(q, k, K, gn):
+    """GroupNorm `gn` over the VIRTUAL concatenation [q(point) x K | k(point, neighbour)] from the tile sums the two producing GEMMs
+    published (conv(..., stats="relu")): leaves q and k with a deferred normalisation each (scale / shift in their own layouts) and
+    never builds the concatenation (SLIDE_OP_ROWS_GN_JOINT).  Returns False when the producers' statistics are not there."""
+    if q.stats is None or k.stats is None or not q.stats[2] or not k.stats[2] or q.pending is not None or k.pending is not None:
+        return False
+    B = q.B
+    dev = q.data.device
+    ssq = torch.empty(B * 2 * q.ld, device=dev, dtype=torch.float32)
+    ssk = torch.empty(B * 2 * k.ld, device=dev, dtype=torch.float32)
+    G, n_norm = gn.num_groups, gn.num_channels
+    tq, tk = q.S // 256, k.S // 256
+    op = make_op(OP_ROWS_GN_JOINT, i=(B, q.C, q.ld, tq, K, k.C, k.ld, tk, G, 0), f=(1.0 / k.S, float(n_norm)),
+                 p=(q.stats[0].data_ptr(), q.stats[1].data_ptr(), k.stats[0].data_ptr(), k.stats[1].data_ptr(),
+                    gn.weight.data_ptr(), gn.bias.data_ptr(), ssq.data_ptr(), ssk.data_ptr()))
+    _run(op)
+    q.pending, k.pending = (ssq, False, None), (ssk, False, None)
+    q.stats = k.stats = None
+    return True
 
 
 # ----------------------------------------------------------------------------------------------------------- fused layers

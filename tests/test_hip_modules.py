@@ -377,6 +377,47 @@ def test_rows_conv_plan_follows_bias_updates(gpu_device):
     assert float((lin(z) - a0).mean()) > 1.9
 
 
+def test_attention_without_the_concatenation(gpu_device, monkeypatch):
+    """round 5, fp16 module path: AttentionModule evaluates relu(weight_conv.2(GN(relu([q | k])))) WITHOUT building the concatenation --
+    joint GroupNorm statistics from the two producers' GEMM epilogues (SLIDE_OP_ROWS_GN_JOINT, groups straddling the q / k boundary
+    included: C1 = 48 of 32 groups over 112 channels), the q half of weight_conv.2 once per point and added ahead of the ReLU.  Same
+    layer as the three-pass form (SLIDE_MODULE_SPLIT_QK=0) up to fp16 operand rounding (<= 3e-3 relative L2), both within 6e-3 of an
+    fp64 restatement; ball-query counts (masked slots) take the same path."""
+    from pointnet2_ops.attention import AttentionModule
+    monkeypatch.setenv("SLIDE_MODULE_PREC", "fp16")
+    d = gpu_device
+    B, npnt, K, Cq, Cg, Cout = 2, 256, 8, 40, 70, 96
+    am = _randomise(AttentionModule(Cq, Cg, 48, 64, Cout), d, seed=5)
+    gen = torch.Generator().manual_seed(9)
+    feat = torch.randn(B, Cq, npnt, generator=gen).to(d)
+    gfeat = torch.randn(B, Cg, npnt, K, generator=gen).to(d)
+    gout = torch.randn(B, Cout, npnt, K, generator=gen).to(d)
+    count = torch.randint(0, K + 1, (B, npnt), generator=gen).to(d)
+    for cnt in ("all", count):
+        outs = {}
+        for v in ("1", "0"):
+            monkeypatch.setenv("SLIDE_MODULE_SPLIT_QK", v)
+            outs[v] = am(feat, gfeat, gout, cnt).double()
+        # fp64 restatement of attention.py:70-96
+        gn = lambda x, m: torch.cat([torch.nn.functional.group_norm(x[:, :m.num_channels], m.num_groups, m.group_norm.weight.double(),
+                                                                     m.group_norm.bias.double(), 1e-5), x[:, m.num_channels:]], 1)
+        c2 = lambda x, m: torch.nn.functional.conv2d(x, m.weight.double(), m.bias.double())
+        q = c2(feat.double()[..., None], am.feat_conv).expand(-1, -1, -1, K)
+        k = c2(gfeat.double(), am.grouped_feat_conv)
+        wc = list(am.weight_conv)
+        u = c2(gn(torch.cat([q, k], 1).relu(), wc[1]), wc[2])
+        sc = c2(gn(u.relu(), wc[4]), wc[5])
+        fo = list(am.feat_out_conv)
+        val = gn(c2(gout.double(), fo[0]), fo[1]).relu()
+        if not isinstance(cnt, str):
+            mask = (torch.arange(K, device=d)[None, None, :] < cnt.clamp(min=1)[..., None]).double()[:, None]
+            sc = sc * mask + (-1e9) * (1 - mask)
+        ref = (torch.softmax(sc, dim=-1) * val).sum(-1)
+        rel = lambda a, b: float(((a - b).norm() / b.norm()).detach())
+        assert torch.isfinite(outs["1"]).all() and rel(outs["1"], outs["0"]) <= 3e-3, rel(outs["1"], outs["0"])
+        assert rel(outs["1"], ref) <= 6e-3 and rel(outs["0"], ref) <= 6e-3, (rel(outs["1"], ref), rel(outs["0"], ref))
+
+
 def test_deferred_normalisation_matches_the_materialised_path(gpu_device, monkeypatch):
     """fp16 module path: a GroupNorm whose consumer is a GEMM is DEFERRED -- the producer's raw output stays in memory and the
     consumer's loader applies relu(x * scale + shift) + add from per-sample fp16 vectors in LDS (csrc/engine.hip, AFF
