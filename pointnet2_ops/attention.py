@@ -60,10 +60,15 @@ class AttentionModule(nn.Module):
         the k half's GEMM as a per-point term ahead of the ReLU -- what the fused DDPM plan does (slide_amd/engine.py _attention).
         Saves the concat + ReLU pass, the statistics pass over it and C1 / (C1 + C2) of the consumer GEMM's input bytes.  None when the
         shapes do not qualify (fp32 module mode, samples that are not whole 256-row tiles, K not a power of two): the caller concatenates."""
-        if not (R.deferral() and R.fused_stats() and query.half and query.S % 256 == 0 and grouped.S % 256 == 0 and K & (K - 1) == 0
-                and grouped.rows == query.rows * K and os.environ.get("SLIDE_MODULE_SPLIT_QK", "1") != "0"):
+        if not (R.deferral() and R.fused_stats() and query.half and grouped.S % 256 == 0 and K & (K - 1) == 0
+                and grouped.rows == query.rows * K and query.rows > 0 and os.environ.get("SLIDE_MODULE_SPLIT_QK", "1") != "0"):
             return None
-        q1 = R.conv(query, self.feat_conv, stats="relu")
+        if query.S % 256 == 0:
+            q1 = R.conv(query, self.feat_conv, stats="relu")
+        else:  # fewer than a tile of points per sample (np = 16 / 64 / 128 levels): the q side is 1 / K of the rows -- its ReLU and
+            q1 = R.conv(query, self.feat_conv)  # per-sample sums as small elementwise passes instead of the GEMM epilogue's
+            v = q1.data.relu_().view(q1.B, q1.S, q1.ld).float()
+            q1.stats = (v.sum(1).contiguous(), (v * v).sum(1).contiguous(), True)
         k1 = R.conv(grouped, self.grouped_feat_conv, stats="relu")
         C1, C2 = q1.C, k1.C
         if not R.joint_norm_qk(q1, k1, K, wc[1].group_norm):

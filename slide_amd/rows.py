@@ -278,7 +278,7 @@ def joint_norm_qk(q, k, K, gn):
     ssq = torch.empty(B * 2 * q.ld, device=dev, dtype=torch.float32)
     ssk = torch.empty(B * 2 * k.ld, device=dev, dtype=torch.float32)
     G, n_norm = gn.num_groups, gn.num_channels
-    tq, tk = q.S // 256, k.S // 256
+    tq, tk = (q.S // 256 if q.S % 256 == 0 else 1), k.S // 256  # (a sample of fewer rows than a tile: ONE row of sums, see attention.py)
     op = make_op(OP_ROWS_GN_JOINT, i=(B, q.C, q.ld, tq, K, k.C, k.ld, tk, G, 0), f=(1.0 / k.S, float(n_norm)),
                  p=(q.stats[0].data_ptr(), q.stats[1].data_ptr(), k.stats[0].data_ptr(), k.stats[1].data_ptr(),
                     gn.weight.data_ptr(), gn.bias.data_ptr(), ssq.data_ptr(), ssk.data_ptr()))

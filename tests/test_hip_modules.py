@@ -377,16 +377,18 @@ def test_rows_conv_plan_follows_bias_updates(gpu_device):
     assert float((lin(z) - a0).mean()) > 1.9
 
 
-def test_attention_without_the_concatenation(gpu_device, monkeypatch):
+@pytest.mark.parametrize("npnt,K", [(256, 8), (64, 32), (16, 16)])
+def test_attention_without_the_concatenation(gpu_device, monkeypatch, npnt, K):
     """round 5, fp16 module path: AttentionModule evaluates relu(weight_conv.2(GN(relu([q | k])))) WITHOUT building the concatenation --
     joint GroupNorm statistics from the two producers' GEMM epilogues (SLIDE_OP_ROWS_GN_JOINT, groups straddling the q / k boundary
     included: C1 = 48 of 32 groups over 112 channels), the q half of weight_conv.2 once per point and added ahead of the ReLU.  Same
     layer as the three-pass form (SLIDE_MODULE_SPLIT_QK=0) up to fp16 operand rounding (<= 3e-3 relative L2), both within 6e-3 of an
-    fp64 restatement; ball-query counts (masked slots) take the same path."""
+    fp64 restatement; ball-query counts (masked slots) take the same path.  Levels with fewer points than one 256-row tile per sample
+    (npnt = 64 / 16) take the q side's sums from small elementwise passes instead of the GEMM epilogue."""
     from pointnet2_ops.attention import AttentionModule
     monkeypatch.setenv("SLIDE_MODULE_PREC", "fp16")
     d = gpu_device
-    B, npnt, K, Cq, Cg, Cout = 2, 256, 8, 40, 70, 96
+    B, Cq, Cg, Cout = 2, 40, 70, 96
     am = _randomise(AttentionModule(Cq, Cg, 48, 64, Cout), d, seed=5)
     gen = torch.Generator().manual_seed(9)
     feat = torch.randn(B, Cq, npnt, generator=gen).to(d)
