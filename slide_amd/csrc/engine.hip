@@ -738,6 +738,104 @@ __device__ __forceinline__ float other_half(float x) {  // value of lane ^ 32
   return __uint_as_float((threadIdx.x & 32) ? a : b);
 }
 
+// The epilogue of the fused attention tail on the two accumulator sets (values: bias, GroupNorm over the sample, ReLU; scores: bias,
+// soft-max over a point's K rows; weighted sum, one row out per point).  vec_lds: [bias_s | bias_v | gamma | beta] of the tile's 64
+// channels of THIS wave (vstride floats apart), red: 2 KB of scratch shared by the waves of one channel group, wave: the row wave
+// (rows 64 wave ..); vectors / scratch must be visible / free on entry (the callers end their K loops with a workgroup barrier).
+template <int NPXL>
+__device__ __forceinline__ void attn_tail_finish(const AttnTailArgs &a, f32x16 (&sacc)[2][2], f32x16 (&vacc)[2][2], const float *vec_lds,
+                                                 int vstride, float *red, int row0, int cob0, int wave) {
+  using T = _Float16;
+  constexpr int CBW = 2;
+  constexpr int KLOG = NPXL - 4, KN = 1 << KLOG, GPB = 32 / KN;
+  constexpr int WPS = (1 << NPXL) / 64;
+  const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+
+  // ---- values: bias, GroupNorm over the sample (rows of WPS waves x the gs adjacent channel lanes), ReLU
+  // red: [wave][cb][32 channels][sum, sumsq]
+  const float *b_s = vec_lds, *b_v = vec_lds + vstride, *gam = vec_lds + 2 * vstride, *bet = vec_lds + 3 * vstride;
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb) {
+    const float bv = b_v[cb * 32 + col];
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float x = vacc[cb][rb][r] + bv;
+        vacc[cb][rb][r] = x;
+        s += x;
+        ss = fmaf(x, x, ss);
+      }
+    s += other_half(s);
+    ss += other_half(ss);
+    if (half == 0) *reinterpret_cast<f32x2 *>(red + ((wave * CBW + cb) * 32 + col) * 2) = f32x2{s, ss};
+  }
+  __syncthreads();
+  const int w0 = (wave / WPS) * WPS;
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb) {
+    f32x2 t = {0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < WPS; ++w) t += *reinterpret_cast<const f32x2 *>(red + (((w0 + w) * CBW + cb) * 32 + col) * 2);
+    float s = t[0], ss = t[1];
+    // the gs channels of a group sit in gs adjacent lanes (physical GroupNorm layout: power-of-two runs)
+    if (a.gs >= 2) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1, 0xF, 0xF, true));
+                     ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0xB1, 0xF, 0xF, true)); }
+    if (a.gs >= 4) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E, 0xF, 0xF, true));
+                     ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x4E, 0xF, 0xF, true)); }
+    if (a.gs >= 8) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x141, 0xF, 0xF, true));
+                     ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x141, 0xF, 0xF, true)); }
+    if (a.gs >= 16) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x140, 0xF, 0xF, true));
+                      ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x140, 0xF, 0xF, true)); }
+    if (a.gs >= 32) { s += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s), 0x401F));
+                      ss += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(ss), 0x401F)); }
+    const float mean = s * a.inv_count;
+    const float var = fmaxf(ss * a.inv_count - mean * mean, 0.f);
+    float g = gam[cb * 32 + col] * __builtin_amdgcn_rsqf(var + GN_EPS);
+    float bt = bet[cb * 32 + col] - mean * g;
+    if ((cob0 + cb) * 32 + col >= a.n_norm) { g = 1.f; bt = 0.f; }
+    const float bs = b_s[cb * 32 + col];
+    // ---- softmax over the K neighbour rows of every point, weighted sum of the values, one row out per point
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int pg = 0; pg < GPB; ++pg) {
+        // rows of point pg inside the 32-row block: 16 -> regs 8pg .. 8pg+7 (both halves); 8 -> regs 4pg .. 4pg+3
+        constexpr int RPG = 16 / GPB;
+        float sc[RPG], vv[RPG];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < RPG; ++j) {
+          sc[j] = sacc[cb][rb][pg * RPG + j] + bs;
+          vv[j] = fmaxf(fmaf(vacc[cb][rb][pg * RPG + j], g, bt), 0.f);
+          m = fmaxf(m, sc[j]);
+        }
+        m = fmaxf(m, other_half(m));
+        float den = 0.f, num = 0.f;
+#pragma unroll
+        for (int j = 0; j < RPG; ++j) {
+          const float e = __expf(sc[j] - m);
+          den += e;
+          num = fmaf(e, vv[j], num);
+        }
+        den += other_half(den);
+        num += other_half(num);
+        const int rbase = row0 + wave * 64 + rb * 32 + pg * KN;
+        if (half == 0 && rbase < a.rows && cob0 + cb < a.n_cob) {
+          const T v = (T)(num / den);
+          reinterpret_cast<T *>(a.out)[(size_t)(rbase >> KLOG) * a.out_ld + (cob0 + cb) * 32 + col] = v;
+          // chunk-major copy of the per-point table for the next block's gather-on-load GEMM
+          if (a.out_cm)
+            reinterpret_cast<T *>(a.out_cm)[((size_t)(cob0 + cb) * (a.rows >> KLOG) + (rbase >> KLOG)) * 32 + col] = v;
+          // second copy into the columns of a later concatenation buffer (the skip input of an FP block's second Mlp)
+          if (a.out2 && (cob0 + cb) * 32 + col < a.out2_n)
+            reinterpret_cast<T *>(a.out2)[(size_t)(rbase >> KLOG) * a.out2_ld + (cob0 + cb) * 32 + col] = v;
+        }
+      }
+  }
+}
+
 #ifndef SLIDE_ATTN_NST
 #define SLIDE_ATTN_NST 3  // ring stages of the fused attention tail
 #endif
@@ -745,8 +843,6 @@ template <int NPXL, int NST>
 __device__ __forceinline__ void attn_tail_body(const AttnTailArgs &a) {
   using T = _Float16;
   constexpr int CBW = 2, RT = TM + 64, STAGE_B = RT * 64, LPW = RT / 16 / 4;
-  constexpr int KLOG = NPXL - 4, KN = 1 << KLOG, GPB = 32 / KN;  // neighbours per point, points per 32-row block
-  constexpr int WPS = (1 << NPXL) / 64;                            // waves per sample
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int ntc = (a.n_cob + CBW - 1) / CBW;
   const int xcd = blockIdx.x & 7, q0 = blockIdx.x >> 3;
@@ -835,90 +931,136 @@ __device__ __forceinline__ void attn_tail_body(const AttnTailArgs &a) {
   f32x16 sacc[CBW][2], vacc[CBW][2];
   run(a.X1, a.W1, a.x1_ld, a.k1, sacc);
   run(a.X2, a.W2, a.x2_ld, a.k2, vacc);
+  attn_tail_finish<NPXL>(a, sacc, vacc, vec_lds, CBW * 32, reinterpret_cast<float *>(smem_raw), row0, cob0, wave);
+}
 
-  // ---- values: bias, GroupNorm over the sample (rows of WPS waves x the gs adjacent channel lanes), ReLU
-  float *const red = reinterpret_cast<float *>(smem_raw);  // [wave][cb][32 channels][sum, sumsq]
-  const float *b_s = vec_lds, *b_v = vec_lds + CBW * 32, *gam = vec_lds + 2 * CBW * 32, *bet = vec_lds + 3 * CBW * 32;
+// REGISTER-X form (round 5; the default, SLIDE_TAIL_RX=0 restores the ring form above).  16 KB of a 20 KB ring stage is the X tile,
+// which no two waves share -- a wave's MFMAs read only its own 64 rows.  Here a wave loads ITS X fragments straight into registers
+// (chunk-major u / mo: a 32-row block of one chunk is 2 KB contiguous, a lane's 16 bytes are its MFMA A fragment as stored) RXD chunks
+// ahead, and only the weights (64 channels x 32 k = 4 KB per chunk, read by all four waves) go through an LDS-DMA ring of RXD + 1
+// stages: 23 KB of LDS per workgroup instead of 61, a quarter of the ds_reads, RXD - 1 ... RXD chunks in flight per workgroup instead
+// of two.  ONE pipeline over both contractions, values first (their chunk count must be a multiple of RXD -- the launcher checks --
+// so that the register slot of a chunk is a compile-time index), then scores.  Measured (tools/r05_tailrx.sh): the feature step's two
+// SA tails 67.0 -> 64.4 us stand-alone, 378.9 -> 382.6 shapes/s in the arrangement (three alternating pairs) -- the deeper prefetch
+// buys little: the tile's fill rate (~58 GB/s per CU, round 3's ablations) is a throughput cap, not a latency one.
+constexpr int RXD = 4;
+// WC = 2 (eight waves, tile 256 rows x 128 channels: wave (wr, wc) owns rows 64 wr .. and the channel half wc, a row block's fragments
+// are requested by two waves) was measured and is not instantiated: 76.5 us per feature step's two SA tails against 64.4 (WC = 1) and
+// 67.0 (ring form) -- the second request is not free, and one eight-wave workgroup per CU overlaps less than two of four.
+template <int NPXL, int WC>
+__device__ __forceinline__ void attn_tail_rx_body(const AttnTailArgs &a) {
+  using T = _Float16;
+  constexpr int CBW = 2, CBWT = CBW * WC, NSTW = RXD + 1, WSTAGE = 64 * WC * 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int ntc = (a.n_cob + CBWT - 1) / CBWT;
+  const int xcd = blockIdx.x & 7, q0 = blockIdx.x >> 3;
+  const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;
+  if (tr * TM >= a.rows) return;
+  const int row0 = tr * TM, cob0 = tc * CBWT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+  const int wr = wave & 3, wc = wave >> 2;
+  float *const vec_lds = reinterpret_cast<float *>(smem_raw + (size_t)NSTW * WSTAGE);  // [4 vectors][CBWT*32]
+  float *const red = vec_lds + 4 * CBWT * 32;                                          // [wc][4 row waves][CBW][32][2]
+  for (int i = tid; i < 4 * CBWT * 32; i += 256 * WC) {
+    const int which = i / (CBWT * 32), c = i - which * (CBWT * 32), gc = cob0 * 32 + c;
+    vec_lds[i] = gc < a.n_cob * 32 ? a.vec[(size_t)which * a.n_cob * 32 + gc] : 0.f;
+  }
+  // weights: wave w stages channels 16 w .. 16 w + 15 of the tile (one 1 KB piece per chunk); fragments: lane = channel, swizzled pieces
+  const int wch = 16 * wave + (lane >> 2);
+  int gco = cob0 * 32 + wch;
+  gco = gco < a.n_cob * 32 ? gco : a.n_cob * 32 - 1;
+  const int wpiece = (lane & 3) ^ ((wch >> 2) & 3);
+  const size_t w_cs = a.w_cm ? (size_t)a.n_cob * 32 * 32 : 32;
+  const T *const w2p = reinterpret_cast<const T *>(a.W2) + (size_t)gco * (a.w_cm ? 32 : a.k2) + wpiece * 8;
+  const T *const w1p = reinterpret_cast<const T *>(a.W1) + (size_t)gco * (a.w_cm ? 32 : a.k1) + wpiece * 8;
+  int wrow[CBW], wkey[CBW];
 #pragma unroll
   for (int cb = 0; cb < CBW; ++cb) {
-    const float bv = b_v[cb * 32 + col];
-    float s = 0.f, ss = 0.f;
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float x = vacc[cb][rb][r] + bv;
-        vacc[cb][rb][r] = x;
-        s += x;
-        ss = fmaf(x, x, ss);
-      }
-    s += other_half(s);
-    ss += other_half(ss);
-    if (half == 0) *reinterpret_cast<f32x2 *>(red + ((wave * CBW + cb) * 32 + col) * 2) = f32x2{s, ss};
+    const int trow = wc * 64 + cb * 32 + col;
+    wrow[cb] = trow * 64; wkey[cb] = (trow >> 2) & 3;
   }
-  __syncthreads();
-  const int w0 = (wave / WPS) * WPS;
+  // X: lane (col, half) of row block rb reads row  row0 + 64 wave + 32 rb + col,  k pieces  2 st2 + half  of the chunk
+  const size_t x2_cs = a.x2_ld == 32 ? (size_t)a.rows * 32 : 32, x1_cs = a.x1_ld == 32 ? (size_t)a.rows * 32 : 32;
+  const T *x2p[2], *x1p[2];
 #pragma unroll
-  for (int cb = 0; cb < CBW; ++cb) {
-    f32x2 t = {0.f, 0.f};
-#pragma unroll
-    for (int w = 0; w < WPS; ++w) t += *reinterpret_cast<const f32x2 *>(red + (((w0 + w) * CBW + cb) * 32 + col) * 2);
-    float s = t[0], ss = t[1];
-    // the gs channels of a group sit in gs adjacent lanes (physical GroupNorm layout: power-of-two runs)
-    if (a.gs >= 2) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1, 0xF, 0xF, true));
-                     ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0xB1, 0xF, 0xF, true)); }
-    if (a.gs >= 4) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E, 0xF, 0xF, true));
-                     ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x4E, 0xF, 0xF, true)); }
-    if (a.gs >= 8) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x141, 0xF, 0xF, true));
-                     ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x141, 0xF, 0xF, true)); }
-    if (a.gs >= 16) { s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x140, 0xF, 0xF, true));
-                      ss += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x140, 0xF, 0xF, true)); }
-    if (a.gs >= 32) { s += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s), 0x401F));
-                      ss += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(ss), 0x401F)); }
-    const float mean = s * a.inv_count;
-    const float var = fmaxf(ss * a.inv_count - mean * mean, 0.f);
-    float g = gam[cb * 32 + col] * __builtin_amdgcn_rsqf(var + GN_EPS);
-    float bt = bet[cb * 32 + col] - mean * g;
-    if ((cob0 + cb) * 32 + col >= a.n_norm) { g = 1.f; bt = 0.f; }
-    const float bs = b_s[cb * 32 + col];
-    // ---- softmax over the K neighbour rows of every point, weighted sum of the values, one row out per point
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int pg = 0; pg < GPB; ++pg) {
-        // rows of point pg inside the 32-row block: 16 -> regs 8pg .. 8pg+7 (both halves); 8 -> regs 4pg .. 4pg+3
-        constexpr int RPG = 16 / GPB;
-        float sc[RPG], vv[RPG];
-        float m = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < RPG; ++j) {
-          sc[j] = sacc[cb][rb][pg * RPG + j] + bs;
-          vv[j] = fmaxf(fmaf(vacc[cb][rb][pg * RPG + j], g, bt), 0.f);
-          m = fmaxf(m, sc[j]);
-        }
-        m = fmaxf(m, other_half(m));
-        float den = 0.f, num = 0.f;
-#pragma unroll
-        for (int j = 0; j < RPG; ++j) {
-          const float e = __expf(sc[j] - m);
-          den += e;
-          num = fmaf(e, vv[j], num);
-        }
-        den += other_half(den);
-        num += other_half(num);
-        const int rbase = row0 + wave * 64 + rb * 32 + pg * KN;
-        if (half == 0 && rbase < a.rows && cob0 + cb < a.n_cob) {
-          const T v = (T)(num / den);
-          reinterpret_cast<T *>(a.out)[(size_t)(rbase >> KLOG) * a.out_ld + (cob0 + cb) * 32 + col] = v;
-          // chunk-major copy of the per-point table for the next block's gather-on-load GEMM
-          if (a.out_cm)
-            reinterpret_cast<T *>(a.out_cm)[((size_t)(cob0 + cb) * (a.rows >> KLOG) + (rbase >> KLOG)) * 32 + col] = v;
-          // second copy into the columns of a later concatenation buffer (the skip input of an FP block's second Mlp)
-          if (a.out2 && (cob0 + cb) * 32 + col < a.out2_n)
-            reinterpret_cast<T *>(a.out2)[(size_t)(rbase >> KLOG) * a.out2_ld + (cob0 + cb) * 32 + col] = v;
-        }
-      }
+  for (int rb = 0; rb < 2; ++rb) {
+    int grow = row0 + wr * 64 + rb * 32 + col;
+    grow = grow < a.rows ? grow : a.rows - 1;
+    x2p[rb] = reinterpret_cast<const T *>(a.X2) + (size_t)grow * a.x2_ld + half * 8;
+    x1p[rb] = reinterpret_cast<const T *>(a.X1) + (size_t)grow * a.x1_ld + half * 8;
   }
+  const int nk2 = a.k2 / 32, total = nk2 + a.k1 / 32;
+  f16x8 xq[RXD][2][2];
+  // EVERY chunk slot issues its five loads, also past the last chunk (there: all lanes read one valid address -- a broadcast, next to no
+  // traffic -- and nobody consumes the result): with unconditional issues the number of loads behind a chunk's is the constant
+  // 5 (RXD - 1), for the manual wait below and for the compiler's own wait-count insertion alike (a conditional issue made it fall
+  // back to vmcnt(0) at every use, which serialises the pipeline).
+  auto issue = [&](int c, f16x8 (&x)[2][2]) __attribute__((always_inline)) {
+    // (branch-free: an idle slot's addresses collapse onto `dummy` through a mask, not through a select the compiler could turn into
+    //  control flow -- every path through the pipeline must carry the same loads)
+    const bool second = c >= nk2;
+    const int kc = second ? c - nk2 : c;
+    const uint64_t mask = c < total ? ~0ull : 0ull;
+    const uint64_t dummy = reinterpret_cast<uint64_t>(a.vec);
+    const uint64_t wp = dummy + ((reinterpret_cast<uint64_t>((second ? w1p : w2p) + (size_t)kc * w_cs) - dummy) & mask);
+    const size_t xo = (size_t)kc * (second ? x1_cs : x2_cs);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const uint64_t xp = dummy + ((reinterpret_cast<uint64_t>((second ? x1p[rb] : x2p[rb]) + xo) - dummy) & mask);
+      // (asm: hipcc's wait-count insertion answers ANY register load pending beside an LDS-DMA load with vmcnt(0) -- the two may
+      //  return out of order for all it knows -- which drains the pipeline once per round; these loads are waited for by hand)
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x[rb][0]) : "v"(xp) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(x[rb][1]) : "v"(xp) : "memory");
+    }
+    __builtin_amdgcn_global_load_lds(reinterpret_cast<const GLOBAL_AS void *>(wp),
+                                     (__attribute__((address_space(3))) void *)(smem_raw + (size_t)(c % NSTW) * WSTAGE + wave * 1024), 16, 0, 0);
+  };
+  f32x16 sacc[CBW][2], vacc[CBW][2];
+#pragma unroll
+  for (int i = 0; i < CBW; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[i][j][r] = 0.f; vacc[i][j][r] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < RXD; ++j) issue(j, xq[j]);
+  auto step = [&](int c, f16x8 (&x)[2][2], f32x16 (&acc)[CBW][2]) __attribute__((always_inline)) {
+    // chunk c's loads have landed when only those of chunks c + 1 .. c + RXD - 1 are outstanding (the operands tie the fragments'
+    // uses to this wait)
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1]) : "n"((RXD - 1) * 5) : "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's piece of W chunk c has landed; W stage (c - 1) % NSTW is free
+    const unsigned char *sb = smem_raw + (size_t)(c % NSTW) * WSTAGE;
+#pragma unroll
+    for (int st2 = 0; st2 < 2; ++st2) {
+      f16x8 wf[CBW];
+      const int piece = st2 * 2 + half;
+#pragma unroll
+      for (int cb = 0; cb < CBW; ++cb) wf[cb] = *reinterpret_cast<const f16x8 *>(sb + wrow[cb] + ((piece ^ wkey[cb]) << 4));
+#pragma unroll
+      for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+          acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[rb][st2], wf[cb], acc[cb][rb], 0, 0, 0);  // rows x channels
+    }
+    issue(c + RXD, x);
+  };
+  for (int c0 = 0; c0 < nk2; c0 += RXD) {
+#pragma unroll
+    for (int j = 0; j < RXD; ++j) step(c0 + j, xq[j], vacc);
+  }
+  for (int c0 = nk2; c0 < total; c0 += RXD) {  // (leaves from the middle of a round after the last chunk: no path re-joins the pipeline)
+#pragma unroll
+    for (int j = 0; j < RXD; ++j) {
+      step(c0 + j, xq[j], sacc);
+      if (c0 + j + 1 >= total) break;
+    }
+  }
+  // the idle slots' loads: their registers stay reserved until they have landed
+#pragma unroll
+  for (int j = 0; j < RXD; ++j)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xq[j][0][0]), "+v"(xq[j][0][1]), "+v"(xq[j][1][0]), "+v"(xq[j][1][1]) :: "memory");
+  __syncthreads();  // (orders the staged vectors before their first use)
+  attn_tail_finish<NPXL>(a, sacc, vacc, vec_lds + wc * 64, CBWT * 32, red + wc * (4 * CBW * 32 * 2), row0, cob0 + wc * CBW, wr);
 }
 
 // WIDE form (round 3): 256 rows x 128 channels on the same four waves.  Per MFMA the tile moves 1.1 KB through the LDS instead
@@ -1120,6 +1262,11 @@ __global__ __launch_bounds__(256, 1) void attn_tail_wide_kernel(AttnTailArgs a) 
 template <int NPXL>
 __global__ __launch_bounds__(256, 2) void attn_tail_kernel(AttnTailArgs a) {
   attn_tail_body<NPXL, SLIDE_ATTN_NST>(a);
+}
+
+template <int NPXL>
+__global__ __launch_bounds__(256, 2) void attn_tail_rx_kernel(AttnTailArgs a) {
+  attn_tail_rx_body<NPXL, 1>(a);
 }
 
 // the same tile on a TWO-stage ring (41 KB) inside the 168-register budget: three workgroups per CU instead of two
@@ -2349,6 +2496,13 @@ int run_attn_tail(const SlideOp &o, hipStream_t s) {
     return (int)hipGetLastError();
   }
 #endif
+  static const int tail_rx = [] { const char *e = getenv("SLIDE_TAIL_RX"); return e ? atoi(e) : 1; }();
+  if (tail_rx && (npxl == 7 || npxl == 8) && (a.k2 / 32) % RXD == 0) {  // X fragments through registers (attn_tail_rx_kernel)
+    const size_t shmr = (size_t)(RXD + 1) * 64 * 64 + 4 * 2 * 32 * 4 + 4 * 2 * 32 * 2 * 4;
+    if (npxl == 8) hipLaunchKernelGGL(attn_tail_rx_kernel<8>, dim3(grid), dim3(256), shmr, s, a);
+    else hipLaunchKernelGGL(attn_tail_rx_kernel<7>, dim3(grid), dim3(256), shmr, s, a);
+    return (int)hipGetLastError();
+  }
   const size_t shm = (size_t)SLIDE_ATTN_NST * (TM + 64) * 64 + 4 * 2 * 32 * 4 + 64;
   static bool attr_done[SLIDE_MAX_DEVICES] = {};
   bool &attr_set = attr_done[current_device_slot()];

@@ -147,6 +147,13 @@ class _GraphedSampler:
             self._head_args = h  # (kept alive: the op carries its address)
             update_op = make_op(OP_HEAD_UPDATE, p=(ctypes.addressof(h),))
             drop = drop | set(head["idx"])
+        abl = os.environ.get("SLIDE_ABL_DROP")
+        if abl:  # TIMING ablation (tools/r05_ablate.sh): the launches whose kernel name contains one of the substrings are left out -- wrong results
+            from .engine import OP_ATTN_TAIL, OP_GEMM
+            names = getattr(e, "kernel_names", {})
+            lab = lambda i: names.get(i, "") + (" gemm16" if e.ops[i].kind == OP_GEMM and e.ops[i].i[0] == 16 * e.B else "") + \
+                (" tail" if e.ops[i].kind == OP_ATTN_TAIL else "")
+            drop = drop | {i for i in range(len(e.ops)) if any(s_ in lab(i) for s_ in abl.split(","))}
         kept = [i for i in range(len(e.ops)) if i not in drop]
         ops = [e.ops[i] for i in kept]
         # per-launch accounting of the engine, re-keyed by position in the step plan
