@@ -350,6 +350,9 @@ def main():
                 only = os.environ["SLIDE_BENCH_ONLY"]
                 order = {"pos": [pos], "feat": [s_[0] for s_ in subs], "feat1": [subs[0][0]], "feat2": [s_[0] for s_ in subs[:2]],
                          "pos+feat1": [subs[0][0], pos]}[only]
+            share_q = os.environ.get("SLIDE_POS_SHARE")  # diagnostic: the position chain on feature sub-batch <k>'s stream (one queue)
+            if share_q is not None and pos in order:
+                pos.stream = subs[int(share_q)][0].stream
             joint = EagerChainsSampler(order, every=[pos_mult if s_ is pos else 1 for s_ in order])
     cat_desc = None
     if a.workload == "five-cat":

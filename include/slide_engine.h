@@ -153,6 +153,10 @@ enum {
                              * version 2 on float tables -- as ONE launch, one workgroup per sample walking the steps; the dense layers are exact
                              * fp32 FMA chains on the vector ALUs.  p[0] = HOST pointer to {int64 n, B; n records of 16 int64 slots} (device
                              * pointers inside; layout in csrc/gemm_gxs.hip slide_launch_pp_stage), kept alive by the plan.  i: B, n */
+  SLIDE_OP_POINT_CHAIN = 37,/* round 5 (csrc/point_chain.hip): the per-point END of a denoiser step as one launch -- the last FP block's second
+                             * Mlp (first_mlp + res_connect, second_mlp + fc_condition + residual: pointnet2_modules.py:119-176, :842-855) and the
+                             * output head fc_lyaer (pointnet2_with_pcld_condition.py:480-483), four dependent 16-rows-per-sample GEMMs; writes
+                             * the prediction eps.  p[0] = HOST pointer to a SlidePointChainArgs block */
   SLIDE_OP_HEAD_UPDATE = 33,/* output head (two per-point GEMMs with the GroupNorm between them) + DDPM update + device-side t -= 1 as one launch
                              * (csrc/engine.hip head_update_kernel): p[0] = HOST pointer to a SlideHeadArgs block */
   SLIDE_OP_BLOCK_BODY = 30, /* the whole K-expanded body of an SA / FP block whose widths are <= 256 channels in one launch (csrc/block_body.hip):
@@ -218,6 +222,24 @@ typedef struct SlideHeadArgs {
   void *feat0;
   const struct SlidePrepCopy *copies;
 } SlideHeadArgs;
+
+/* SLIDE_OP_POINT_CHAIN (p[0] = HOST pointer to this block, device pointers inside; kept alive by the plan).  Every layer is 128 channels
+ * wide with GroupNorm(32, 128); fp16 operands / activations, fp32 accumulation, statistics and residual. */
+typedef struct SlidePointChainArgs {
+  const void *Z;        /* fp16 [rows][z_ld]: the block's per-point input [attention output | skip features | xyz], kz (<= 192) columns read */
+  const void *Wz;       /* fp16 [256][kz] row-major: first_mlp.0 (rows 0..127) | res_connect (rows 128..255) */
+  const void *W2;       /* fp16 [128][128]: second_mlp.0 */
+  const void *W0, *W1;  /* fp16 head: [128][k0], [n1c*32][128] */
+  const float *vz;      /* [bias | gamma | beta] of first_mlp, bias of res_connect: [4][128] */
+  const float *v2;      /* [bias | gamma | beta][128] of second_mlp */
+  const float *v0, *b1; /* head: [bias | gamma | beta][128]; bias [n1c*32] */
+  const float *tvec;    /* added after first_mlp's ReLU: tvec[(t_idx ? t_idx[0] * t_stride : 0) + c] (row t of the per-timestep table), or NULL */
+  const int32_t *t_idx;
+  const float *cvec;    /* added after second_mlp's ReLU: cvec[sample * c_bs + c], or NULL */
+  void *X;              /* fp16 [rows][x_ld], the head's input: columns [128, k0) are READ ([xyz | zero pad]), columns [0, 128) WRITTEN (the block's output) */
+  float *eps;           /* OUT fp32 [rows][eps_ld]: the prediction (eps_ld <= 32 n1c, a multiple of 4) */
+  int32_t rows, z_ld, kz, x_ld, k0, n1c, eps_ld, t_stride, t_bs /* must be 0 */, c_bs;
+} SlidePointChainArgs;
 
 typedef struct SlideOp {
   int32_t kind;

@@ -23,7 +23,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # they are demoted to scratch), which needs more than LLVM's default 16k-instruction cap for `#pragma unroll`.
 UNROLL = ["-mllvm", "-pragma-unroll-threshold=100000"]
 SOURCES = [("point_ops.hip", ["-ffp-contract=off"]), ("engine.hip", UNROLL), ("gemm_gx.hip", UNROLL), ("gemm_gxs.hip", UNROLL),
-           ("rows_ops.hip", []), ("train_ops.hip", [])]
+           ("point_chain.hip", UNROLL), ("rows_ops.hip", []), ("train_ops.hip", [])]
 SOURCES_EXP = SOURCES + [("experiments/block_body.hip", UNROLL), ("experiments/gemm_xs.hip", UNROLL), ("experiments/gemm_chain.hip", UNROLL),
                          ("experiments/resident.hip", UNROLL)]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",

@@ -24,6 +24,7 @@ int slide_launch_gemm_xs(const GemmArgs &a, int npxl, int cbw, bool aff, bool ga
 int slide_launch_gemm_gx(const SlideOp &o, hipStream_t s);
 int slide_launch_gemm_gxs(const SlideOp &o, hipStream_t s);  // gemm_gxs.hip (split arithmetic, float tables)
 int slide_launch_attn_tail_split(const SlideOp &o, hipStream_t s);  // gemm_gxs.hip
+int slide_launch_point_chain(const SlideOp &o, hipStream_t s);      // point_chain.hip
 int slide_launch_pp_stage(const SlideOp &o, hipStream_t s);  // gemm_gxs.hip
 int slide_launch_pair_norm(const SlideOp &o, hipStream_t s);
 int slide_launch_sa_chain(const SlideOp &o, hipStream_t s);
@@ -2631,6 +2632,8 @@ int run_op(const SlideOp &o, hipStream_t s) {
       break;
     }
 #endif
+    case SLIDE_OP_POINT_CHAIN:
+      return slide_launch_point_chain(o, s);
     case SLIDE_OP_ATTN_TAIL:
       return ((int)o.f[1] & 8) ? slide_launch_attn_tail_split(o, s) : run_attn_tail(o, s);
     case SLIDE_OP_GEMM_GX:

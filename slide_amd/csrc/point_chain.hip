@@ -1,0 +1,230 @@
+// point_chain.hip -- the per-point END of a denoiser step as ONE launch (round 5): the last FP block's second Mlp
+// (Mlp_plus_t_emb: first_mlp + res_connect, second_mlp + fc_condition + residual; pointnet2_modules.py:119-176, :842-855) and the
+// output head fc_lyaer (conv -> GroupNorm(32, 128) -> ReLU -> conv, pointnet2_with_pcld_condition.py:480-483) -- four dependent
+// 16-rows-per-sample GEMMs whose launches are pure latency on every chain's critical path (timing ablation, tools/r05_ablate.sh: the
+// twelve 16-row launches of a feature step cost 29 % of it with 0.3 % of its FLOPs).
+//
+// One workgroup owns 32 rows (two samples), four waves.  Every weight of the four layers (<= 98 + 32 + 40 + 16 KB) is loaded at kernel
+// start straight into MFMA A-fragment registers by the wave that uses it -- wave w owns channel block w of every layer -- together
+// with the input rows and all vectors (one L2 round trip for the whole chain); activations cross the waves through LDS as fp16
+// [row][channel]; accumulators are D[channel][row] (lane = row, register = channel), so a GroupNorm group (four consecutive channels)
+// is four registers of a lane and its statistics over the sample's 16 rows are one 16-lane DPP reduction.  The residual stays in fp32
+// registers; the block's output is also written to the head's input buffer (diagnostics read it), the prediction to eps [rows][eps_ld].
+// The DDPM update stays its own launch: fused in (head_update_kernel, experiments build) it put the Philox draws of 3264 state
+// elements on each of 22 workgroups' critical paths and lost 1.4 %.
+#include "gemm_common.h"
+
+namespace {
+
+typedef SlidePointChainArgs ChainArgs;  // include/slide_engine.h
+
+template <int KZMAX, int K0MAX>
+__global__ __launch_bounds__(256, 1) void point_chain_kernel(ChainArgs a) {
+#pragma clang fp contract(off)
+  using T = _Float16;
+  constexpr int LDZ = KZMAX + 8, LDH = 128 + 8, LDX = K0MAX + 8;
+  __shared__ __attribute__((aligned(16))) T zs[32 * LDZ];
+  __shared__ __attribute__((aligned(16))) T hs[32 * LDH];
+  __shared__ __attribute__((aligned(16))) T xs[32 * LDX];
+  // vectors: [b1 | g1 | be1 | b_res][128], tvec [128], [b2 | g2 | be2][128], cvec [2 samples][128], [b0 | g0 | be0][128], b_out [64]
+  __shared__ __attribute__((aligned(16))) float vl[512 + 128 + 384 + 256 + 384 + 64];
+  float *const vz_l = vl, *const tv_l = vl + 512, *const v2_l = vl + 640, *const cv_l = vl + 1024, *const v0_l = vl + 1280,
+        *const bo_l = vl + 1664;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+  const int row0 = blockIdx.x * 32;
+  const int nkz = a.kz >> 4, nk0 = a.k0 >> 4;
+  // ---- every global read of the chain, issued together
+  f16x8 wz[2][KZMAX / 16], w2[8], w0[K0MAX / 16], w1[8];
+  {
+    const GLOBAL_AS T *wp = gptr<const T>((uint64_t)a.Wz) + (size_t)(wave * 32 + col) * a.kz + half * 8;
+#pragma unroll
+    for (int s2 = 0; s2 < KZMAX / 16; ++s2)
+      if (s2 < nkz) {
+        wz[0][s2] = *(const GLOBAL_AS f16x8 *)(wp + s2 * 16);                          // first_mlp.0, channel block `wave`
+        wz[1][s2] = *(const GLOBAL_AS f16x8 *)(wp + (size_t)128 * a.kz + s2 * 16);     // res_connect, same channels
+      }
+    const GLOBAL_AS T *w2p = gptr<const T>((uint64_t)a.W2) + (size_t)(wave * 32 + col) * 128 + half * 8;
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) w2[s2] = *(const GLOBAL_AS f16x8 *)(w2p + s2 * 16);
+    const GLOBAL_AS T *w0p = gptr<const T>((uint64_t)a.W0) + (size_t)(wave * 32 + col) * a.k0 + half * 8;
+#pragma unroll
+    for (int s2 = 0; s2 < K0MAX / 16; ++s2)
+      if (s2 < nk0) w0[s2] = *(const GLOBAL_AS f16x8 *)(w0p + s2 * 16);
+    if (wave < a.n1c) {
+      const GLOBAL_AS T *w1p = gptr<const T>((uint64_t)a.W1) + (size_t)(wave * 32 + col) * 128 + half * 8;
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2) w1[s2] = *(const GLOBAL_AS f16x8 *)(w1p + s2 * 16);
+    }
+  }
+  {
+    const int ppr = a.kz >> 3;
+    for (int i = tid; i < 32 * ppr; i += 256) {
+      const int r = i / ppr, pc = i - r * ppr;
+      int grow = row0 + r;
+      grow = grow < a.rows ? grow : a.rows - 1;
+      *reinterpret_cast<u32x4 *>(zs + r * LDZ + pc * 8) = *(const GLOBAL_AS u32x4 *)(gptr<const T>((uint64_t)a.Z) + (size_t)grow * a.z_ld + pc * 8);
+    }
+    // the head's input beyond the block's 128 output channels: [xyz | zero pad], written once per chain by the point preparation
+    const int ppx = (a.k0 - 128) >> 3;
+    for (int i = tid; i < 32 * ppx; i += 256) {
+      const int r = i / ppx, pc = i - r * ppx;
+      int grow = row0 + r;
+      grow = grow < a.rows ? grow : a.rows - 1;
+      *reinterpret_cast<u32x4 *>(xs + r * LDX + 128 + pc * 8) =
+          *(const GLOBAL_AS u32x4 *)(gptr<const T>((uint64_t)a.X) + (size_t)grow * a.x_ld + 128 + pc * 8);
+    }
+    const int nsm = a.rows >> 4, smp0 = row0 >> 4;
+    for (int i = tid; i < 512 + 128 + 384 + 256 + 384 + 64; i += 256) {
+      float v = 0.f;
+      if (i < 512) v = a.vz[i];
+      else if (i < 640) { if (a.tvec) v = a.tvec[(a.t_idx ? (size_t)a.t_idx[0] * a.t_stride : 0) + (i - 512)]; }
+      else if (i < 1024) v = a.v2[i - 640];
+      else if (i < 1280) {
+        int sm = smp0 + ((i - 1024) >> 7);
+        sm = sm < nsm ? sm : nsm - 1;
+        if (a.cvec) v = a.cvec[(size_t)sm * a.c_bs + ((i - 1024) & 127)];
+      } else if (i < 1664) v = a.v0[i - 1280];
+      else if (i - 1664 < a.n1c * 32) v = a.b1[i - 1664];
+      vl[i] = v;
+    }
+  }
+  __syncthreads();
+  // lane's 16 channels of block `wave`: c(r) = wave * 32 + (r & 3) + 8 (r >> 2) + 4 half; quads q = r >> 2 are GroupNorm groups
+  auto vec16 = [&](const float *base, float (&o)[16]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 t4 = *reinterpret_cast<const float4 *>(base + wave * 32 + 8 * q + 4 * half);
+      o[4 * q] = t4.x; o[4 * q + 1] = t4.y; o[4 * q + 2] = t4.z; o[4 * q + 3] = t4.w;
+    }
+  };
+  // y = relu(GroupNorm(acc + bias)) over quads of channels x the sample's 16 rows (= the 16 lanes of the lane's row group)
+  auto gn_relu = [&](const f32x16 &acc, const float *vec3, float (&y)[16]) __attribute__((always_inline)) {
+    float bia[16], gam[16], bet[16];
+    vec16(vec3, bia); vec16(vec3 + 128, gam); vec16(vec3 + 256, bet);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[4], s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = acc[4 * q + j] + bia[4 * q + j];
+        s += v[j];
+        ss = fmaf(v[j], v[j], ss);
+      }
+      s = lane_group_sum<16>(s);
+      ss = lane_group_sum<16>(ss);
+      const float mean = s * (1.0f / 64.0f);
+      const float var = fmaxf(ss * (1.0f / 64.0f) - mean * mean, 0.f);
+      const float rstd = __builtin_amdgcn_rsqf(var + GN_EPS);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float g = gam[4 * q + j] * rstd;
+        y[4 * q + j] = fmaxf(fmaf(v[j], g, bet[4 * q + j] - mean * g), 0.f);
+      }
+    }
+  };
+  auto put16 = [&](T *dst_row, const float (&y)[16]) __attribute__((always_inline)) {  // the lane's row, its 16 channels, as fp16
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f16x4 h;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) h[j] = (T)y[4 * q + j];
+      *reinterpret_cast<f16x4 *>(dst_row + wave * 32 + 8 * q + 4 * half) = h;
+    }
+  };
+  // ---- layer 1: first_mlp.0 -> h = relu(GN(.)) + t-embedding row;  res_connect -> r (raw, stays in registers)
+  f32x16 ah, ar;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { ah[r] = 0.f; ar[r] = 0.f; }
+#pragma unroll
+  for (int s2 = 0; s2 < KZMAX / 16; ++s2)
+    if (s2 < nkz) {
+      const f16x8 xb = *reinterpret_cast<const f16x8 *>(zs + col * LDZ + s2 * 16 + half * 8);
+      ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(wz[0][s2], xb, ah, 0, 0, 0);
+      ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(wz[1][s2], xb, ar, 0, 0, 0);
+    }
+  float res[16];
+  {
+    float y[16], tv[16], br[16];
+    gn_relu(ah, vz_l, y);
+    vec16(tv_l, tv); vec16(vz_l + 384, br);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { y[r] += tv[r]; res[r] = ar[r] + br[r]; }
+    put16(hs + col * LDH, y);
+  }
+  __syncthreads();
+  // ---- layer 2: second_mlp.0 -> out = relu(GN(.)) + class-embedding row + r
+  {
+    f32x16 a2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a2[r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) {
+      const f16x8 hb = *reinterpret_cast<const f16x8 *>(hs + col * LDH + s2 * 16 + half * 8);
+      a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[s2], hb, a2, 0, 0, 0);
+    }
+    float y[16], cv[16];
+    gn_relu(a2, v2_l, y);
+    vec16(cv_l + (col >> 4) * 128, cv);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) y[r] = y[r] + cv[r] + res[r];
+    put16(xs + col * LDX, y);
+    if (row0 + col < a.rows) put16(reinterpret_cast<T *>(a.X) + (size_t)(row0 + col) * a.x_ld, y);
+  }
+  __syncthreads();
+  // ---- head layer 1: hh = relu(GN(W0 . [out | xyz] + b0))
+  {
+    f32x16 a3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a3[r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < K0MAX / 16; ++s2)
+      if (s2 < nk0) {
+        const f16x8 xb = *reinterpret_cast<const f16x8 *>(xs + col * LDX + s2 * 16 + half * 8);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[s2], xb, a3, 0, 0, 0);
+      }
+    float y[16];
+    gn_relu(a3, v0_l, y);
+    put16(hs + col * LDH, y);  // (every wave is past its layer-2 reads of hs: the barrier above)
+  }
+  __syncthreads();
+  // ---- head layer 2: eps = W1 . hh + b1
+  if (wave < a.n1c) {
+    f32x16 e2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e2[r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) {
+      const f16x8 hb = *reinterpret_cast<const f16x8 *>(hs + col * LDH + s2 * 16 + half * 8);
+      e2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[s2], hb, e2, 0, 0, 0);
+    }
+    float bo[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 t4 = *reinterpret_cast<const float4 *>(bo_l + wave * 32 + 8 * q + 4 * half);
+      bo[4 * q] = t4.x; bo[4 * q + 1] = t4.y; bo[4 * q + 2] = t4.z; bo[4 * q + 3] = t4.w;
+    }
+    const int p = row0 + col;
+    if (p < a.rows) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = wave * 32 + 8 * q + 4 * half;
+        if (c + 3 < a.eps_ld)
+          *reinterpret_cast<float4 *>(a.eps + (size_t)p * a.eps_ld + c) =
+              make_float4(e2[4 * q] + bo[4 * q], e2[4 * q + 1] + bo[4 * q + 1], e2[4 * q + 2] + bo[4 * q + 2], e2[4 * q + 3] + bo[4 * q + 3]);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// SLIDE_OP_POINT_CHAIN: p[0] = HOST pointer to a SlidePointChainArgs block (device pointers inside; kept alive by the plan)
+int slide_launch_point_chain(const SlideOp &o, hipStream_t s) {
+  const SlidePointChainArgs *h = (const SlidePointChainArgs *)o.p[0];
+  if (!h || h->rows <= 0 || h->rows % 16 || h->kz % 32 || h->kz <= 0 || h->kz > 192 || h->z_ld < h->kz || h->z_ld % 8 || h->k0 % 32 ||
+      h->k0 <= 128 || h->k0 > 160 || h->x_ld < h->k0 || h->x_ld % 8 || (h->n1c != 1 && h->n1c != 2) || h->eps_ld % 4 ||
+      h->eps_ld > 32 * h->n1c || h->t_bs != 0 || !h->Z || !h->Wz || !h->W2 || !h->W0 || !h->W1 || !h->vz || !h->v2 || !h->v0 || !h->b1 || !h->X || !h->eps)
+    return -3;
+  hipLaunchKernelGGL((point_chain_kernel<192, 160>), dim3((h->rows + 31) / 32), dim3(256), 0, s, *h);
+  return (int)hipGetLastError();
+}

@@ -147,6 +147,24 @@ class _GraphedSampler:
             self._head_args = h  # (kept alive: the op carries its address)
             update_op = make_op(OP_HEAD_UPDATE, p=(ctypes.addressof(h),))
             drop = drop | set(head["idx"])
+        # round 5: the last FP block's second Mlp + the output head (four dependent per-point GEMM launches) as ONE launch that writes the
+        # prediction (SLIDE_OP_POINT_CHAIN, csrc/point_chain.hip); the update launch follows as before.  SLIDE_POINT_CHAIN=0: four launches
+        pch = getattr(e, "point_chain", None)
+        chain_at = None
+        if pch is not None and not (set(pch["idx"]) & drop) and all(e.ops[i].kind == 1 for i in pch["idx"]):
+            from .engine import OP_POINT_CHAIN, SlidePointChainArgs
+            c = SlidePointChainArgs()
+            for k_ in ("Z", "Wz", "W2", "W0", "W1", "vz", "v2", "v0", "b1", "X"):
+                setattr(c, k_, pch[k_].data_ptr())
+            c.eps = e.eps_pad.data_ptr()
+            c.rows, c.z_ld, c.kz, c.x_ld, c.k0, c.n1c, c.eps_ld = self.B * 16, pch["Z"].shape[1], pch["kz"], pch["X"].shape[1], pch["k0"], pch["n1c"], e.eps_pad.shape[1]
+            if pch["t_off"] is not None:  # row t of the per-timestep table (the engine's t_dev[0])
+                c.tvec, c.t_idx, c.t_stride, c.t_bs = e.tvec.data_ptr() + 4 * pch["t_off"], e.t_dev.data_ptr(), e._n_fc, 0
+            if pch["c_off"] is not None:
+                c.cvec, c.c_bs = e.cvec.data_ptr() + 4 * pch["c_off"], e._c_bs
+            self._chain_args = c  # (kept alive: the op carries its address)
+            chain_at = pch["idx"][0]
+            drop = drop | set(pch["idx"][1:])
         abl = os.environ.get("SLIDE_ABL_DROP")
         if abl:  # TIMING ablation (tools/r05_ablate.sh): the launches whose kernel name contains one of the substrings are left out -- wrong results
             from .engine import OP_ATTN_TAIL, OP_GEMM
@@ -155,11 +173,18 @@ class _GraphedSampler:
                 (" tail" if e.ops[i].kind == OP_ATTN_TAIL else "")
             drop = drop | {i for i in range(len(e.ops)) if any(s_ in lab(i) for s_ in abl.split(","))}
         kept = [i for i in range(len(e.ops)) if i not in drop]
-        ops = [e.ops[i] for i in kept]
+        ops = [e.ops[i] if i != chain_at else make_op(OP_POINT_CHAIN, p=(ctypes.addressof(self._chain_args),)) for i in kept]
         # per-launch accounting of the engine, re-keyed by position in the step plan
         self.gemm_flops = {j: e.gemm_flops[i] for j, i in enumerate(kept) if i in e.gemm_flops}
         self.gemm_bytes = {j: e.gemm_bytes[i] for j, i in enumerate(kept) if i in e.gemm_bytes}
         self.kernel_names = {j: e.kernel_names[i] for j, i in enumerate(kept) if i in getattr(e, "kernel_names", {})}
+        if chain_at is not None and chain_at in kept:  # the chain launch stands for its four layers
+            j = kept.index(chain_at)
+            self.gemm_flops[j] = sum(e.gemm_flops.get(i, 0) for i in pch["idx"])
+            rows_ = self.B * 16  # algorithmic HBM bytes: input rows + every weight once; the block's output + the prediction
+            self.gemm_bytes[j] = (rows_ * pch["kz"] * 2 + sum(int(pch[k_].numel()) * 2 for k_ in ("Wz", "W2", "W0", "W1")),
+                                  rows_ * 128 * 2 + rows_ * e.eps_pad.shape[1] * 4)
+            self.kernel_names[j] = "point_chain_kernel<192, 160>"
         ops += [update_op]  # the update kernel's last block also advances the device-side timestep (t -= 1, step += 1)
         self.step_ops = (SlideOp * len(ops))(*ops)
         self.n_launches = len(ops)

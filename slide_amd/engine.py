@@ -28,6 +28,7 @@ OP_SYNC = 14
 OP_ATTN_TAIL = 16
 OP_GEMM_GX, OP_PAIR_NORM, OP_SA_CHAIN, OP_BLOCK_BODY, OP_PAIR_FIRST, OP_GEMM_CHAIN, OP_HEAD_UPDATE, OP_GEMM_GX_DUAL, OP_SA_CHAIN_P = 17, 18, 19, 30, 31, 32, 33, 34, 35
 OP_PP_STAGE = 36
+OP_POINT_CHAIN = 37
 
 
 class SlideEpi(ctypes.Structure):
@@ -90,6 +91,16 @@ class SlideHeadArgs(ctypes.Structure):  # include/slide_engine.h
                 ("keypoint", ctypes.c_void_p), ("t0", ctypes.c_void_p), ("t1", ctypes.c_void_p), ("t2", ctypes.c_void_p),
                 ("t3", ctypes.c_void_p), ("t4", ctypes.c_void_p), ("complete_x0", ctypes.c_void_p), ("kmask", ctypes.c_void_p),
                 ("feat0", ctypes.c_void_p), ("copies", ctypes.c_void_p)]
+
+
+class SlidePointChainArgs(ctypes.Structure):  # include/slide_engine.h
+    _fields_ = [("Z", ctypes.c_void_p), ("Wz", ctypes.c_void_p), ("W2", ctypes.c_void_p), ("W0", ctypes.c_void_p), ("W1", ctypes.c_void_p),
+                ("vz", ctypes.c_void_p), ("v2", ctypes.c_void_p), ("v0", ctypes.c_void_p), ("b1", ctypes.c_void_p),
+                ("tvec", ctypes.c_void_p), ("t_idx", ctypes.c_void_p), ("cvec", ctypes.c_void_p), ("X", ctypes.c_void_p),
+                ("eps", ctypes.c_void_p),
+                ("rows", ctypes.c_int32), ("z_ld", ctypes.c_int32), ("kz", ctypes.c_int32), ("x_ld", ctypes.c_int32),
+                ("k0", ctypes.c_int32), ("n1c", ctypes.c_int32), ("eps_ld", ctypes.c_int32), ("t_stride", ctypes.c_int32),
+                ("t_bs", ctypes.c_int32), ("c_bs", ctypes.c_int32)]
 
 
 class SlideOp(ctypes.Structure):
@@ -1306,10 +1317,59 @@ class DenoiserEngine:
         n2 = sd[m2 + ".res_connect.weight"].shape[0]
         hz, rz = self._buf(B * 16, n1), self._buf(B * 16, n2)
         f2, r2 = self._mlp_segments(m2, self.tvec, self.cvec, hz, rz)
+        i0 = len(self.ops)
         self._gemm(Z, 4, [f2, r2])
         out = out_buf if out_buf is not None else self._buf(B * 16, n2)
         self._mlp_tail(m2, 4, hz, self.cvec, rz, out)
+        if out_buf is not None:  # the last FP block: its second Mlp may join the output head in one launch (_point_chain)
+            self._chain_front = dict(idx=list(range(i0, len(self.ops))), Z=Z, zin=zin, m2=m2, n1=n1, n2=n2)
         return out, n2
+
+    def _remap_point_chain(self, remap):
+        pc = getattr(self, "point_chain", None)
+        if pc is not None:
+            pc["idx"] = [remap[q] for q in pc["idx"]]
+            if len(set(pc["idx"])) != 4 or pc["idx"] != list(range(pc["idx"][0], pc["idx"][0] + 4)):
+                self.point_chain = None  # (its launches went into another merged launch)
+
+    def _point_chain(self, dec0, head_i0, w0, w1, lay0):
+        """round 5: the last FP block's second Mlp + the output head as ONE launch (SLIDE_OP_POINT_CHAIN, csrc/point_chain.hip) -- what
+        the kernel needs, or None when the shapes are outside what it covers (fp16 plans; every width 128 with identity GroupNorm layout;
+        per-timestep t-embedding table).  The samplers swap it in for the four per-point GEMM launches (diffusion.py); the plan itself
+        keeps them (forward() of the engine, parity tests of the layers)."""
+        sd, fr = self.sd, getattr(self, "_chain_front", None)
+        if fr is None or self.prec != 1 or os.environ.get("SLIDE_POINT_CHAIN", "1") == "0":
+            return None
+        m2 = fr["m2"]
+        ident = lambda c: (lambda l: np.array_equal(l[0], np.arange(c)) and l[1] == c and l[2] == c and l[3] == 4)(gn_layout(c))
+        c2 = sd[m2 + ".second_mlp.0.weight"].shape[0]
+        has_t, has_c = (m2 + ".fc.weight") in sd, (m2 + ".fc_condition.weight") in sd
+        if not (fr["n1"] == 128 and fr["n2"] == 128 and c2 == 128 and (m2 + ".rest_mlp.0.weight") not in sd and ident(128)
+                and len(fr["idx"]) == 2 and fr["idx"][1] + 1 == head_i0 and fr["Z"].shape[1] <= 192 and w0.shape[0] == 128
+                and np.array_equal(lay0[0], np.arange(128)) and lay0[3] == 4 and lay0[2] == 128 and 128 < dec0.shape[1] <= 160
+                and w1.shape[1] == 128 and self.out_dim <= 64 and sd["fc_lyaer.1.weight"].shape[0] == 128
+                and (not has_t or not self.per_sample_t)):
+            return None
+        A = self.A
+        kz, zin = fr["Z"].shape[1], fr["zin"]
+        Wz = np.zeros((256, kz), np.float32)
+        Wz[:128, :zin] = self._w(m2 + ".first_mlp.0.weight")
+        Wz[128:, :zin] = self._w(m2 + ".res_connect.weight")
+        vz = np.stack([sd[m2 + ".first_mlp.0.bias"], sd[m2 + ".first_mlp.1.group_norm.weight"], sd[m2 + ".first_mlp.1.group_norm.bias"],
+                       sd[m2 + ".res_connect.bias"]]).astype(np.float32)
+        v2 = np.stack([sd[m2 + ".second_mlp.0.bias"], sd[m2 + ".second_mlp.1.group_norm.weight"],
+                       sd[m2 + ".second_mlp.1.group_norm.bias"]]).astype(np.float32)
+        n1c = ru(self.out_dim) // 32
+        W0 = np.zeros((128, dec0.shape[1]), np.float32); W0[:, :w0.shape[1]] = w0
+        W1 = np.zeros((n1c * 32, 128), np.float32); W1[:w1.shape[0]] = w1
+        b1 = np.zeros(n1c * 32, np.float32); b1[:w1.shape[0]] = sd["fc_lyaer.3.bias"]
+        v0 = np.stack([sd["fc_lyaer.0.bias"], sd["fc_lyaer.1.weight"], sd["fc_lyaer.1.bias"]]).astype(np.float32)
+        off = lambda lst, pfx: sum(w for _, w in lst[:[p_ for p_, _ in lst].index(pfx)])
+        return dict(idx=fr["idx"] + [head_i0, head_i0 + 1], Z=fr["Z"], kz=kz, X=dec0, k0=dec0.shape[1], n1c=n1c,
+                    Wz=A.put(Wz, torch.float16), W2=A.put(self._w(m2 + ".second_mlp.0.weight"), torch.float16),
+                    W0=A.put(W0, torch.float16), W1=A.put(W1, torch.float16), vz=A.put(vz), v2=A.put(v2), v0=A.put(v0), b1=A.put(b1),
+                    t_off=off(self._tvec, m2 + ".fc") if has_t else None,
+                    c_off=off(self._cvec, m2 + ".fc_condition") if has_c else None)
 
     # ------------------------------------------------------------------ whole network
     def _build(self):
@@ -1413,6 +1473,7 @@ class DenoiserEngine:
             v0 = np.stack([sd["fc_lyaer.0.bias"], sd["fc_lyaer.1.weight"], sd["fc_lyaer.1.bias"]]).astype(np.float32)
             self.head = dict(idx=[head_i0, head_i0 + 1], X=dec0, k0=dec0.shape[1], n1c=n1c,
                              W0=self.A.put(W0, torch.float16), W1=self.A.put(W1, torch.float16), v0=self.A.put(v0), b1=self.A.put(b1))
+        self.point_chain = self._point_chain(dec0, head_i0, w0, w1, lay0)
         self.eps = A.zeros(B, 16, self.out_dim)
         self.eps_copy_idx = len(self.ops)  # samplers read eps_pad directly and drop this op
         self._emit(make_op(OP_COPY_COLS, i=(B * 16, self.out_dim, self.eps_pad.shape[1], self.out_dim, 0, 0),
@@ -1501,6 +1562,7 @@ class DenoiserEngine:
         self.xyz_copy_idx = [remap[q] for q in self.xyz_copy_idx]
         self.eps_copy_idx = remap[self.eps_copy_idx]
         self._prep_idx = remap[self._prep_idx]
+        self._remap_point_chain(remap)
         if self.head is not None:
             self.head["idx"] = [remap[q] for q in self.head["idx"]]
         self._body_args = {remap[q]: v for q, v in self._body_args.items()}
@@ -1563,6 +1625,7 @@ class DenoiserEngine:
         self.xyz_copy_idx = [remap[q] for q in self.xyz_copy_idx]
         self.eps_copy_idx = remap[self.eps_copy_idx]
         self._prep_idx = remap[self._prep_idx]
+        self._remap_point_chain(remap)
         if self.head is not None:
             self.head["idx"] = [remap[q] for q in self.head["idx"]]
             if len(set(self.head["idx"])) != 2:
@@ -1607,6 +1670,7 @@ class DenoiserEngine:
         self.xyz_copy_idx = [remap[q] for q in self.xyz_copy_idx]
         self.eps_copy_idx = remap[self.eps_copy_idx]
         self._prep_idx = remap[self._prep_idx]
+        self._remap_point_chain(remap)
         if self.head is not None:
             self.head["idx"] = [remap[q] for q in self.head["idx"]]
         self._body_args = {remap[q]: v for q, v in self._body_args.items()}
@@ -1669,6 +1733,7 @@ class DenoiserEngine:
             if len(set(self.head["idx"])) != 2:
                 self.head = None  # (the head GEMMs went into a chain launch)
         self._prep_idx = remap[self._prep_idx]
+        self._remap_point_chain(remap)
         self._body_args = {remap[q]: v for q, v in self._body_args.items()}
         self._tail_of = {k_: remap[v] for k_, v in self._tail_of.items()}
 

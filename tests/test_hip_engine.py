@@ -328,6 +328,37 @@ def test_head_and_update_as_one_launch(gpu_device, exp_lib, monkeypatch):
         assert np.isfinite(a_).all() and _rel(a_, b_) <= 5e-4, _rel(a_, b_)
 
 
+def test_point_chain_launch_matches_its_four_layers(gpu_device, monkeypatch):
+    """round 5: the feature sampler's step plan ends its network with ONE launch for the last FP block's second Mlp + the output head
+    (SLIDE_OP_POINT_CHAIN, csrc/point_chain.hip: four dependent per-point GEMMs, weights in registers, activations through LDS) where
+    SLIDE_POINT_CHAIN=0 launches the four GEMMs of the engine's plan.  Same fp16 operands and roundings (the residual stays in fp32
+    inside the chain, the summation order of the K loops differs): ragged batches (1, 3, 6 samples: partial 32-row workgroups), ten
+    steps with in-kernel noise within 5e-4 relative max, and the prediction of ONE step (eps) within 2e-3 of its scale."""
+    from slide_amd.diffusion import FeatureSampler
+    g = load_golden("golden_sampler_feat.npz")
+    _, hpf, sdf = _load("feat")
+    cfg = json.loads(str(g["config_json"]))
+    for B in (1, 3, 6):
+        rs = np.random.RandomState(11 + B)
+        xf = rs.standard_normal((B, 16, g["head_x"].shape[2])).astype(np.float32)
+        lab = np.resize(g["label"], B)
+        kp = np.resize(g["keypoint"], (B,) + g["keypoint"].shape[1:])
+        out, eps, nl = {}, {}, {}
+        for on in ("1", "0"):
+            monkeypatch.setenv("SLIDE_POINT_CHAIN", on)
+            fs = FeatureSampler(hpf, sdf, B, gpu_device, cfg, prec="fp16", seed=9, use_graph=False)
+            kinds = [o.kind for o in fs.step_ops]
+            assert (37 in kinds) == (on == "1"), kinds
+            nl[on] = len(kinds)
+            x1 = fs.sample(lab, kp, xf, t_start=60, n_steps=1)
+            eps[on] = fs.engine.eps_pad.float().cpu().numpy().copy()
+            out[on] = fs.sample(lab, kp, xf, t_start=60, n_steps=10).cpu().numpy()
+            assert torch.isfinite(x1).all()
+        assert nl["0"] - nl["1"] == 3, nl  # four launches -> one
+        assert np.isfinite(out["1"]).all() and _rel(out["1"], out["0"]) <= 5e-4, (B, _rel(out["1"], out["0"]))
+        assert np.abs(eps["1"] - eps["0"]).max() <= 2e-3 * np.abs(eps["0"]).max(), B
+
+
 @pytest.mark.parametrize("prec", ["fp32", "split"])
 def test_position_sampler_full_chain_matches_reference(gpu_device, prec):
     from slide_amd.diffusion import PositionSampler
