@@ -525,8 +525,9 @@ def main():
         def kernel_of(o):
             """rocprofv3 name of the kernel run_gemm / run_attn_tail (engine.hip) launches for this op (default knobs)"""
             b = lambda v: "true" if v else "false"
-            if o.kind == OP_ATTN_TAIL:
-                return "attn_tail_kernel<%d>" % o.i[6]
+            if o.kind == OP_ATTN_TAIL:  # (run_attn_tail: the register-X form unless SLIDE_TAIL_RX=0 or the values' chunk count is odd)
+                rx = os.environ.get("SLIDE_TAIL_RX", "1") != "0" and (o.i[4] // 32) % 4 == 0
+                return "attn_tail_%skernel<%d>" % ("rx_" if rx else "", o.i[6])
             if o.kind != OP_GEMM:
                 return None
             rows, n_cob, npxl, cbw = o.i[0], o.i[3], o.i[4], o.i[7]
