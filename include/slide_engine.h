@@ -239,6 +239,10 @@ typedef struct SlidePointChainArgs {
   void *X;              /* fp16 [rows][x_ld], the head's input: columns [128, k0) are READ ([xyz | zero pad]), columns [0, 128) WRITTEN (the block's output) */
   float *eps;           /* OUT fp32 [rows][eps_ld]: the prediction (eps_ld <= 32 n1c, a multiple of 4) */
   int32_t rows, z_ld, kz, x_ld, k0, n1c, eps_ld, t_stride, t_bs /* must be 0 */, c_bs;
+  int32_t fuse_update;  /* 1: the launch also applies the feature DDPM's update (upd.kind == 1) to the state and advances the device-side
+                         * timestep -- the lane that holds eps[row][channel] updates x[row][channel]; the noise of the workgroup's elements
+                         * is drawn while the chain's loads are in flight.  Of `upd` the update members are read (kind ... copies). */
+  SlideHeadArgs upd;
 } SlidePointChainArgs;
 
 typedef struct SlideOp {

@@ -10,9 +10,13 @@
 // [row][channel]; accumulators are D[channel][row] (lane = row, register = channel), so a GroupNorm group (four consecutive channels)
 // is four registers of a lane and its statistics over the sample's 16 rows are one 16-lane DPP reduction.  The residual stays in fp32
 // registers; the block's output is also written to the head's input buffer (diagnostics read it), the prediction to eps [rows][eps_ld].
-// The DDPM update stays its own launch: fused in (head_update_kernel, experiments build) it put the Philox draws of 3264 state
-// elements on each of 22 workgroups' critical paths and lost 1.4 %.
+// fuse_update (OPT-IN, SLIDE_POINT_CHAIN_UPDATE=1): the launch also applies the feature DDPM's update (update_feat_element,
+// ddpm_update.h) and advances the device-side timestep -- the lane that holds eps[row][channel] updates x[row][channel]; all 256
+// threads draw the workgroup's 32 x C normals into LDS right after issuing the chain's loads.  Measured slower than the separate
+// update launch (the kernel 18.7 -> 45.8 us; 382.8 vs 389.8 shapes/s): Box-Muller with precise logf / cosf and the update's scattered
+// stores of 1632 elements per workgroup cost more than the 71-workgroup launch they replace (round 4's head_update_kernel: -1.4 %).
 #include "gemm_common.h"
+#include "ddpm_update.h"
 
 namespace {
 
@@ -87,6 +91,24 @@ __global__ __launch_bounds__(256, 1) void point_chain_kernel(ChainArgs a) {
       else if (i - 1664 < a.n1c * 32) v = a.b1[i - 1664];
       vl[i] = v;
     }
+  }
+  // the update's noise, drawn while the loads above are in flight: z[row][channel] of the workgroup's rows (t > 0, channels past the key points)
+  __shared__ float zl[32 * 64];
+  int ut = 0, ustep = 0;
+  uint32_t unonce = 0, ueoff = 0;
+  if (a.fuse_update) {
+    const SlideHeadArgs &u = a.upd;
+    ut = u.t_dev[0]; ustep = u.t_dev[1];
+    unonce = (uint32_t)u.t_dev[3];
+    ueoff = (uint32_t)u.t_dev[4] * (uint32_t)(16 * u.C);
+    if (ut > 0)
+      for (int i = tid; i < 32 * u.C; i += 256) {
+        const int r = i / u.C, c = i - r * u.C, p = row0 + r;
+        if (c < u.kdim || p >= a.rows) continue;
+        const int e = p * u.C + c;
+        zl[r * 64 + c] = u.noise ? u.noise[(size_t)ustep * a.rows * u.C + e]
+                                 : philox_normal(u.seed_lo, u.seed_hi, (uint32_t)ustep, (uint32_t)e + ueoff, unonce);
+      }
   }
   __syncthreads();
   // lane's 16 channels of block `wave`: c(r) = wave * 32 + (r & 3) + 8 (r >> 2) + 4 half; quads q = r >> 2 are GroupNorm groups
@@ -208,12 +230,24 @@ __global__ __launch_bounds__(256, 1) void point_chain_kernel(ChainArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c = wave * 32 + 8 * q + 4 * half;
-        if (c + 3 < a.eps_ld)
+        if (a.eps && c + 3 < a.eps_ld)
           *reinterpret_cast<float4 *>(a.eps + (size_t)p * a.eps_ld + c) =
               make_float4(e2[4 * q] + bo[4 * q], e2[4 * q + 1] + bo[4 * q + 1], e2[4 * q + 2] + bo[4 * q + 2], e2[4 * q + 3] + bo[4 * q + 3]);
       }
+      if (a.fuse_update) {
+        const SlideHeadArgs &u = a.upd;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (c >= u.C) continue;
+          update_feat_element(p * u.C + c, a.rows, u.C, u.kdim, 0, u.clamp, u.seed_lo, u.seed_hi, u.x, nullptr, u.noise, ut, ustep, unonce,
+                              ueoff, u.complete_x0, u.kmask, u.keypoint, u.t0, u.t1, u.t2, u.t3, u.t4, u.feat0, u.ldf, u.half_out,
+                              u.copies, u.n_copies, e2[r] + bo[r], zl + col * 64 + c);
+        }
+      }
     }
   }
+  if (a.fuse_update) advance_t_last_block(a.upd.t_dev, ut, ustep);
 }
 
 }  // namespace
@@ -223,7 +257,10 @@ int slide_launch_point_chain(const SlideOp &o, hipStream_t s) {
   const SlidePointChainArgs *h = (const SlidePointChainArgs *)o.p[0];
   if (!h || h->rows <= 0 || h->rows % 16 || h->kz % 32 || h->kz <= 0 || h->kz > 192 || h->z_ld < h->kz || h->z_ld % 8 || h->k0 % 32 ||
       h->k0 <= 128 || h->k0 > 160 || h->x_ld < h->k0 || h->x_ld % 8 || (h->n1c != 1 && h->n1c != 2) || h->eps_ld % 4 ||
-      h->eps_ld > 32 * h->n1c || h->t_bs != 0 || !h->Z || !h->Wz || !h->W2 || !h->W0 || !h->W1 || !h->vz || !h->v2 || !h->v0 || !h->b1 || !h->X || !h->eps)
+      h->eps_ld > 32 * h->n1c || h->t_bs != 0 || !h->Z || !h->Wz || !h->W2 || !h->W0 || !h->W1 || !h->vz || !h->v2 || !h->v0 || !h->b1 || !h->X || (!h->eps && !h->fuse_update))
+    return -3;
+  if (h->fuse_update && (h->upd.kind != 1 || h->upd.C > 32 * h->n1c || h->upd.C > 64 || !h->upd.x || !h->upd.t_dev || !h->upd.t0 || !h->upd.t1 ||
+                         !h->upd.t2 || !h->upd.t3 || !h->upd.t4 || (h->upd.kdim > 0 && !h->upd.keypoint)))
     return -3;
   hipLaunchKernelGGL((point_chain_kernel<192, 160>), dim3((h->rows + 31) / 32), dim3(256), 0, s, *h);
   return (int)hipGetLastError();

@@ -162,6 +162,21 @@ class _GraphedSampler:
                 c.tvec, c.t_idx, c.t_stride, c.t_bs = e.tvec.data_ptr() + 4 * pch["t_off"], e.t_dev.data_ptr(), e._n_fc, 0
             if pch["c_off"] is not None:
                 c.cvec, c.c_bs = e.cvec.data_ptr() + 4 * pch["c_off"], e._c_bs
+            # OPT-IN (SLIDE_POINT_CHAIN_UPDATE=1): the feature DDPM's update in the same launch, its noise drawn in the shadow of the
+            # chain's loads -- measured SLOWER (382.8 vs 389.8 shapes/s, three alternating pairs; the launch 18.7 -> 45.8 us): the
+            # Box-Muller draws (precise logf / cosf) and the update's scattered 4-byte stores of 1632 elements on 256 threads
+            # outweigh the 71-workgroup update launch they replace, as they did in round 4's head_update_kernel
+            if update_op.kind == OP_UPDATE_FEAT and os.environ.get("SLIDE_POINT_CHAIN_UPDATE", "0") != "0":
+                u, h = update_op, c.upd
+                h.kind, h.C, h.kdim = 1, u.i[1], u.i[2]
+                h.seed_lo, h.seed_hi = u.i[3] & 0xFFFFFFFF, u.i[4] & 0xFFFFFFFF
+                h.clamp = u.f[0]
+                h.x, h.noise, h.t_dev = u.p[0], u.p[2], u.p[3]
+                h.keypoint, h.t0, h.t1, h.t2, h.t3, h.t4 = u.p[4], u.p[5], u.p[6], u.p[7], u.p[8], u.p[9]
+                h.complete_x0, h.kmask = u.p[10], u.p[11]
+                h.feat0, h.ldf, h.half_out, h.copies, h.n_copies = u.p[12], u.i[6], u.i[7], u.p[13], u.i[8]
+                c.fuse_update = 1
+                update_op = None
             self._chain_args = c  # (kept alive: the op carries its address)
             chain_at = pch["idx"][0]
             drop = drop | set(pch["idx"][1:])
@@ -185,7 +200,8 @@ class _GraphedSampler:
             self.gemm_bytes[j] = (rows_ * pch["kz"] * 2 + sum(int(pch[k_].numel()) * 2 for k_ in ("Wz", "W2", "W0", "W1")),
                                   rows_ * 128 * 2 + rows_ * e.eps_pad.shape[1] * 4)
             self.kernel_names[j] = "point_chain_kernel<192, 160>"
-        ops += [update_op]  # the update kernel's last block also advances the device-side timestep (t -= 1, step += 1)
+        if update_op is not None:  # (None: the update rides on the point-chain launch)
+            ops += [update_op]  # the update kernel's last block also advances the device-side timestep (t -= 1, step += 1)
         self.step_ops = (SlideOp * len(ops))(*ops)
         self.n_launches = len(ops)
         # once per batch: everything up to the last hoisted copy that the copies depend on (the point preparation)

@@ -100,7 +100,7 @@ class SlidePointChainArgs(ctypes.Structure):  # include/slide_engine.h
                 ("eps", ctypes.c_void_p),
                 ("rows", ctypes.c_int32), ("z_ld", ctypes.c_int32), ("kz", ctypes.c_int32), ("x_ld", ctypes.c_int32),
                 ("k0", ctypes.c_int32), ("n1c", ctypes.c_int32), ("eps_ld", ctypes.c_int32), ("t_stride", ctypes.c_int32),
-                ("t_bs", ctypes.c_int32), ("c_bs", ctypes.c_int32)]
+                ("t_bs", ctypes.c_int32), ("c_bs", ctypes.c_int32), ("fuse_update", ctypes.c_int32), ("upd", SlideHeadArgs)]
 
 
 class SlideOp(ctypes.Structure):

@@ -331,32 +331,43 @@ def test_head_and_update_as_one_launch(gpu_device, exp_lib, monkeypatch):
 def test_point_chain_launch_matches_its_four_layers(gpu_device, monkeypatch):
     """round 5: the feature sampler's step plan ends its network with ONE launch for the last FP block's second Mlp + the output head
     (SLIDE_OP_POINT_CHAIN, csrc/point_chain.hip: four dependent per-point GEMMs, weights in registers, activations through LDS) where
-    SLIDE_POINT_CHAIN=0 launches the four GEMMs of the engine's plan.  Same fp16 operands and roundings (the residual stays in fp32
-    inside the chain, the summation order of the K loops differs): ragged batches (1, 3, 6 samples: partial 32-row workgroups), ten
-    steps with in-kernel noise within 5e-4 relative max, and the prediction of ONE step (eps) within 2e-3 of its scale."""
+    SLIDE_POINT_CHAIN=0 launches the four GEMMs of the engine's plan; SLIDE_POINT_CHAIN_UPDATE=1 (opt-in: measured slower) also
+    carries the DDPM update on that launch, its Philox draws in the shadow of the loads.  Same fp16 operands and roundings (the
+    residual stays in fp32 inside the chain, the summation order of the K loops differs) and the SAME noise (same Philox counters):
+    ragged batches (1, 3, 6 samples: partial 32-row workgroups), ten steps with in-kernel noise within 5e-4 relative max, the
+    prediction of ONE step (eps) within 2e-3 of its scale, the fused update bit-identical to the chain + update launch, and an explicit
+    noise tensor taking the same path."""
     from slide_amd.diffusion import FeatureSampler
     g = load_golden("golden_sampler_feat.npz")
     _, hpf, sdf = _load("feat")
     cfg = json.loads(str(g["config_json"]))
     for B in (1, 3, 6):
         rs = np.random.RandomState(11 + B)
-        xf = rs.standard_normal((B, 16, g["head_x"].shape[2])).astype(np.float32)
+        C = g["head_x"].shape[2]
+        xf = rs.standard_normal((B, 16, C)).astype(np.float32)
         lab = np.resize(g["label"], B)
         kp = np.resize(g["keypoint"], (B,) + g["keypoint"].shape[1:])
-        out, eps, nl = {}, {}, {}
-        for on in ("1", "0"):
+        noise = rs.standard_normal((4, B, 16, C)).astype(np.float32)
+        out, eps, nl, outn = {}, {}, {}, {}
+        for tag, on, upd in (("fused", "1", "1"), ("chain", "1", "0"), ("plan", "0", "1")):
             monkeypatch.setenv("SLIDE_POINT_CHAIN", on)
+            monkeypatch.setenv("SLIDE_POINT_CHAIN_UPDATE", upd)
             fs = FeatureSampler(hpf, sdf, B, gpu_device, cfg, prec="fp16", seed=9, use_graph=False)
             kinds = [o.kind for o in fs.step_ops]
-            assert (37 in kinds) == (on == "1"), kinds
-            nl[on] = len(kinds)
+            assert (37 in kinds) == (on == "1") and (11 in kinds) == (tag != "fused"), kinds  # 11: SLIDE_OP_UPDATE_FEAT
+            nl[tag] = len(kinds)
             x1 = fs.sample(lab, kp, xf, t_start=60, n_steps=1)
-            eps[on] = fs.engine.eps_pad.float().cpu().numpy().copy()
-            out[on] = fs.sample(lab, kp, xf, t_start=60, n_steps=10).cpu().numpy()
+            eps[tag] = fs.engine.eps_pad.float().cpu().numpy().copy()
+            out[tag] = fs.sample(lab, kp, xf, t_start=60, n_steps=10).cpu().numpy()
             assert torch.isfinite(x1).all()
-        assert nl["0"] - nl["1"] == 3, nl  # four launches -> one
-        assert np.isfinite(out["1"]).all() and _rel(out["1"], out["0"]) <= 5e-4, (B, _rel(out["1"], out["0"]))
-        assert np.abs(eps["1"] - eps["0"]).max() <= 2e-3 * np.abs(eps["0"]).max(), B
+            fn = FeatureSampler(hpf, sdf, B, gpu_device, cfg, prec="fp16", noise=noise, use_graph=False)
+            outn[tag] = fn.sample(lab, kp, xf, t_start=3, n_steps=4).cpu().numpy()
+        assert nl["plan"] - nl["chain"] == 3 and nl["chain"] - nl["fused"] == 1, nl  # four launches -> one; the update launch gone
+        assert np.isfinite(out["fused"]).all() and np.array_equal(out["fused"], out["chain"]) and np.array_equal(outn["fused"], outn["chain"])
+        assert np.array_equal(eps["fused"], eps["chain"])
+        assert _rel(out["fused"], out["plan"]) <= 5e-4, (B, _rel(out["fused"], out["plan"]))
+        assert _rel(outn["fused"], outn["plan"]) <= 5e-4, (B, _rel(outn["fused"], outn["plan"]))
+        assert np.abs(eps["fused"] - eps["plan"]).max() <= 2e-3 * np.abs(eps["plan"]).max(), B
 
 
 @pytest.mark.parametrize("prec", ["fp32", "split"])
