@@ -280,6 +280,7 @@ def main():
     from slide_amd import configs, model_spec
     from slide_amd._lib import check, lib
     from slide_amd.diffusion import EagerChainsSampler, FeatureSampler, JointSampler, OwnGraphSampler, PositionSampler, SplitJointSampler, ThreadedEagerSampler
+    from slide_amd.generation import POS_CU_SHARE  # share of the CUs the position chain's stream may use beside the feature chains
     from slide_amd.engine import OP_ATTN_TAIL, OP_GEMM
     from slide_amd.synth import synth_keypoints, synth_state_dict
 
@@ -328,7 +329,7 @@ def main():
         wide_pos = a.pos_prec in ("split", "fp32") and a.prec == "fp16"
         pos_mult = int(os.environ.get("SLIDE_POS_MULT", "2" if (wide_pos and eager and a.replay == "eager") else "1"))
         pos = PositionSampler(pc["pointnet_config"], sd_p, B * pos_mult, dev, pc["diffusion_config"], prec=a.pos_prec, seed=1000 + rank * 16,
-                              use_graph=not eager)
+                              use_graph=not eager, cu_share=POS_CU_SHARE if (a.replay == "eager" and P > 1) else 0.0)
         # position plan: its own step graph on its own stream ("own", default: 1-1.5 % faster) or a parallel branch of the
         # first feature sub-batch's graph ("branch")
         pos_own = os.environ.get("SLIDE_POS_GRAPH", "own") == "own" and P > 1
@@ -493,6 +494,7 @@ def main():
                                   "batch %d per GPU; 1 step = one reverse step of each; shape = 1000+1000 steps" % B,
                       "batch_per_gpu": B, "sub_batches": sizes, "prec": a.prec, "pos_prec": a.pos_prec, "replay": a.replay,
                       "pos_batch_multiple": pos_mult if a.workload == "default" else 1,
+                      "pos_stream_cus": (getattr(pos_chains[0][0], "n_cus", 0) or "all") if pos_chains else None,
                       "launches_per_step": sum(p_.n_launches for p_, _ in pos_chains) + sum(f_.n_launches for f_, _, _ in feat_chains),
                       # host seconds inside the launch calls of the timed region, per step: close to ms_per_step = the host
                       # (or a full hardware queue it is blocked on) paces the run, far below = the GPU does

@@ -282,6 +282,12 @@ SLIDE_API int slide_event_record(void *ev, slide_stream_t stream);
 SLIDE_API int slide_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
 SLIDE_API int slide_event_destroy(void *ev);
 
+/* A stream whose kernels run on a SUBSET of the compute units (hipExtStreamCreateWithCUMask): mask = n_words x 32 bits, bit i = CU i.
+ * For a chain that has slack on its own queue but whose wide launches would otherwise take every CU from the latency-critical
+ * chains beside it (the position DDPM beside the feature sub-batches). */
+SLIDE_API int slide_stream_create_cu_mask(const uint32_t *mask, int n_words, slide_stream_t *stream_out);
+SLIDE_API int slide_stream_destroy(slide_stream_t stream);
+
 SLIDE_API int slide_sizeof_epi(void);
 SLIDE_API int slide_sizeof_op(void);
 

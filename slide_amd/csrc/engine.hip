@@ -2707,6 +2707,15 @@ int slide_graph_launch(void *graph_exec, slide_stream_t stream) {
 }
 int slide_graph_destroy(void *graph_exec) { return (int)hipGraphExecDestroy((hipGraphExec_t)graph_exec); }
 
+int slide_stream_create_cu_mask(const uint32_t *mask, int n_words, slide_stream_t *stream_out) {
+  if (!mask || n_words <= 0 || !stream_out) return -3;
+  hipStream_t st = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, mask);
+  *stream_out = (slide_stream_t)st;
+  return (int)e;
+}
+int slide_stream_destroy(slide_stream_t stream) { return (int)hipStreamDestroy((hipStream_t)stream); }
+
 int slide_event_create(void **ev) {
   hipEvent_t e;
   const hipError_t st = hipEventCreate(&e);

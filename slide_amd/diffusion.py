@@ -82,7 +82,7 @@ def latent_diffusion_params(cfg):
 
 
 class _GraphedSampler:
-    def __init__(self, hp, state_dict, batch, device, prec, use_graph, T):
+    def __init__(self, hp, state_dict, batch, device, prec, use_graph, T, cu_share=0.0):
         self.engine = DenoiserEngine(hp, state_dict, batch, device, prec=prec, per_sample_t=False, t_table=T)
         self.B, self.device = int(batch), device
         self.use_graph = use_graph
@@ -92,6 +92,27 @@ class _GraphedSampler:
             pp = [int(v) for v in os.environ["SLIDE_STREAM_PRIO"].split(",")]
             prio = pp[0] if hp.get("in_fea_dim", 0) == 0 else pp[-1]
         self.stream = torch.cuda.Stream(device=device, priority=prio) if prio else torch.cuda.Stream(device=device)
+        self._masked_stream, self.n_cus = None, 0
+        # cu_share: run this chain's kernels on that fraction of the compute units only (SLIDE_POS_CUS / SLIDE_FEAT_CUS=<n> override it
+        # for the position / feature chains; 0 = all).  The position chain beside the feature sub-batches is given 11/16 of the chip:
+        # its wide split launches then never take EVERY CU from the latency-critical feature chains
+        env_cus = os.environ.get("SLIDE_POS_CUS" if hp.get("in_fea_dim", 0) == 0 else "SLIDE_FEAT_CUS")
+        ncu = int(env_cus) if env_cus is not None else (
+            int(torch.cuda.get_device_properties(device).multi_processor_count * cu_share) if (cu_share and device.type == "cuda") else 0)
+        if ncu > 0 and device.type == "cuda":
+            # a stream confined to `ncu` compute units (slide_stream_create_cu_mask): SLIDE_POS_CUS for the position chains,
+            # SLIDE_FEAT_CUS for the feature chains; SLIDE_CU_MASK_FROM=<first CU> (default 0)
+            total = torch.cuda.get_device_properties(device).multi_processor_count
+            first = int(os.environ.get("SLIDE_CU_MASK_FROM", "0"))
+            words = [0] * ((total + 31) // 32)
+            for cu in range(first, min(first + ncu, total)):
+                words[cu // 32] |= 1 << (cu % 32)
+            arr = (ctypes.c_uint32 * len(words))(*words)
+            ptr = ctypes.c_void_p()
+            with torch.cuda.device(device):
+                check(lib().slide_stream_create_cu_mask(arr, len(words), ctypes.byref(ptr)), "slide_stream_create_cu_mask")
+            self._masked_stream, self.n_cus = ptr.value, min(first + ncu, total) - first
+            self.stream = torch.cuda.ExternalStream(ptr.value, device=device)
         # second lane of the plan (independent branches overlap); single-lane plans (the default) do not take a second
         # stream: HIP spreads streams over a few hardware queues, and an idle stream still occupies a slot
         self.stream2 = torch.cuda.Stream(device=device) if self.engine.two_lanes else self.stream
@@ -295,8 +316,8 @@ class _GraphedSampler:
 class PositionSampler(_GraphedSampler):
     """sampling(net, (B,16,3), diffusion_hyperparams, label=...) -- pointnet2/util.py:197-259."""
 
-    def __init__(self, hp, state_dict, batch, device, diffusion_config, prec="fp32", noise=None, seed=0, use_graph=True):
-        super().__init__(hp, state_dict, batch, device, prec, use_graph, diffusion_config["T"])
+    def __init__(self, hp, state_dict, batch, device, diffusion_config, prec="fp32", noise=None, seed=0, use_graph=True, cu_share=0.0):
+        super().__init__(hp, state_dict, batch, device, prec, use_graph, diffusion_config["T"], cu_share=cu_share)
         e = self.engine
         dh = calc_diffusion_hyperparams(**diffusion_config)
         self.dh, self.T = dh, dh["T"]
