@@ -110,9 +110,13 @@ class _GraphedSampler:
             arr = (ctypes.c_uint32 * len(words))(*words)
             ptr = ctypes.c_void_p()
             with torch.cuda.device(device):
-                check(lib().slide_stream_create_cu_mask(arr, len(words), ctypes.byref(ptr)), "slide_stream_create_cu_mask")
-            self._masked_stream, self.n_cus = ptr.value, min(first + ncu, total) - first
-            self.stream = torch.cuda.ExternalStream(ptr.value, device=device)
+                st = lib().slide_stream_create_cu_mask(arr, len(words), ctypes.byref(ptr))
+            if st == 0 and ptr.value:
+                self._masked_stream, self.n_cus = ptr.value, min(first + ncu, total) - first
+                self.stream = torch.cuda.ExternalStream(ptr.value, device=device)
+            else:  # (a tuning, not a requirement: the chain runs on an ordinary stream)
+                import warnings
+                warnings.warn("slide_stream_create_cu_mask failed (status %d): the chain runs on all compute units" % st)
         # second lane of the plan (independent branches overlap); single-lane plans (the default) do not take a second
         # stream: HIP spreads streams over a few hardware queues, and an idle stream still occupies a slot
         self.stream2 = torch.cuda.Stream(device=device) if self.engine.two_lanes else self.stream

@@ -13,7 +13,7 @@ int main(int argc, char **argv) {
   hipStream_t st[8];
   for (int i = 0; i < 8; ++i) hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking);
   const int N = 2000;
-  for (int wgs : {1, 64, 512}) for (int cyc : {0, 10000, 40000}) for (int ns : {1, 2, 3, 4, 5}) {
+  for (int wgs : {1, 64, 512}) for (int cyc : {0, 10000, 40000}) for (int ns : {1, 2, 3, 4, 5, 6, 8}) {
     for (int w = 0; w < 2; ++w) {  // second pass timed
       hipDeviceSynchronize();
       auto t0 = std::chrono::steady_clock::now();
