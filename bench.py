@@ -329,7 +329,7 @@ def main():
         wide_pos = a.pos_prec in ("split", "fp32") and a.prec == "fp16"
         pos_mult = int(os.environ.get("SLIDE_POS_MULT", "2" if (wide_pos and eager and a.replay == "eager") else "1"))
         pos = PositionSampler(pc["pointnet_config"], sd_p, B * pos_mult, dev, pc["diffusion_config"], prec=a.pos_prec, seed=1000 + rank * 16,
-                              use_graph=not eager, cu_share=POS_CU_SHARE if (a.replay == "eager" and P > 1) else 0.0)
+                              use_graph=not eager, cu_share=POS_CU_SHARE if (a.replay == "eager" and P > 1 and wide_pos) else 0.0)
         # position plan: its own step graph on its own stream ("own", default: 1-1.5 % faster) or a parallel branch of the
         # first feature sub-batch's graph ("branch")
         pos_own = os.environ.get("SLIDE_POS_GRAPH", "own") == "own" and P > 1

@@ -266,7 +266,8 @@ def sub_batch_sizes(B, P):
 
 # The position chain beside the feature sub-batches runs on a stream confined to 11/16 of the compute units (176 of 256;
 # slide_stream_create_cu_mask): its wide split-arithmetic launches then leave CUs to the latency-critical feature chains at all
-# times.  Measured in bench.py's arrangement (tools/r05_cumask.sh, two runs each): all CUs 391.5 shapes/s, 240 CUs 392.1, 224 393.7,
+# times (only beside fp16 feature chains with the position plan in the split / fp32 arithmetic: the all-fp16 arrangement loses 3 % with
+# it).  Measured in bench.py's arrangement (tools/r05_cumask.sh, two runs each): all CUs 391.5 shapes/s, 240 CUs 392.1, 224 393.7,
 # 208 394.1, 192 394.6, 176 394.9, 160 394.3, 128 369.9, 64 275.2 (the chain becomes the long pole).
 POS_CU_SHARE = 11.0 / 16.0
 
@@ -291,7 +292,8 @@ class PipelinedGenerator:
         self.pos = self.feats = None
         if pos is not None:
             self.pos = PositionSampler(pos[0], pos[1], self.B, device, pos[2], prec=resolve_prec(prec)[0], seed=seed, use_graph=False,
-                                       cu_share=POS_CU_SHARE if (feat is not None and not serial) else 0.0)
+                                       cu_share=POS_CU_SHARE if (feat is not None and not serial and resolve_prec(prec)[0] != "fp16"
+                                                                 and resolve_prec(prec)[1] == "fp16") else 0.0)
         self.sizes = []
         if feat is not None:
             self.sizes = sub_batch_sizes(self.B, n_sub)
