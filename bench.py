@@ -429,8 +429,10 @@ def main():
     # the order of rounds 3-4).  It is other work than the timed steps -- its samplers are built, run and freed inside parity_leg.
     parity_first = os.environ.get("SLIDE_BENCH_PARITY_FIRST", "1") != "0"
     parity_obj = None
-    if rank == 0 and not a.no_parity and parity_first:
+    if not a.no_parity and parity_first:  # (every rank checks its own GPU -- and enters the timed region in the same state; rank 0 reports)
         parity_obj = parity_leg(dev, B, a, pc, fc, sd_p, sd_f, gen)
+        if rank != 0:
+            parity_obj = None
     run(max(a.warmup, 1) + max(prime, 0))  # (one replay call: priming steps, then the W warm-up steps)
     gdev = torch.device("cpu") if share else dev
     gathered = [torch.empty(B, 16, 51, device=gdev) for _ in range(world)] if use_dist else None
