@@ -12,6 +12,7 @@ Noise is either an explicit tensor (parity tests inject the reference's stream) 
 """
 import ctypes
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -81,6 +82,13 @@ def latent_diffusion_params(cfg):
             "posterior_mean_coef2": (1.0 - acp) * np.sqrt(alphas) / (1.0 - ac), "data_clamp_range": cfg["data_clamp_range"]}
 
 
+def _destroy_stream(handle):
+    try:
+        lib().slide_stream_destroy(ctypes.c_void_p(handle))
+    except Exception:  # (interpreter shutdown: the library may be gone)
+        pass
+
+
 class _GraphedSampler:
     def __init__(self, hp, state_dict, batch, device, prec, use_graph, T, cu_share=0.0):
         self.engine = DenoiserEngine(hp, state_dict, batch, device, prec=prec, per_sample_t=False, t_table=T)
@@ -114,6 +122,7 @@ class _GraphedSampler:
             if st == 0 and ptr.value:
                 self._masked_stream, self.n_cus = ptr.value, min(first + ncu, total) - first
                 self.stream = torch.cuda.ExternalStream(ptr.value, device=device)
+                weakref.finalize(self, _destroy_stream, ptr.value)  # (torch does not own an ExternalStream's handle)
             else:  # (a tuning, not a requirement: the chain runs on an ordinary stream)
                 import warnings
                 warnings.warn("slide_stream_create_cu_mask failed (status %d): the chain runs on all compute units" % st)
