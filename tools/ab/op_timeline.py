@@ -44,7 +44,10 @@ n = len(s.step_ops)
 st = ctypes.c_void_p(s.stream.cuda_stream)
 with torch.cuda.stream(s.stream):
     check(lib().slide_run_ops(s.step_ops, n, st), "warm")
-    for idx in (int(v) for v in sys.argv[3:]):
+    want = sys.argv[3:]
+    if want and want[0].startswith("kind"):  # "kind31" / "kind1": every launch of that op kind
+        want = [i for i in range(n) if s.step_ops[i].kind == int(want[0][4:])]
+    for idx in (int(v) for v in want):
         op = SlideOp.from_buffer_copy(bytes(s.step_ops[idx]))
         nwg = 16384
         dbg = torch.zeros(nwg * 16, dtype=torch.int64, device=dev)
