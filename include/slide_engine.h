@@ -233,12 +233,16 @@ typedef struct SlidePointChainArgs {
   const float *vz;      /* [bias | gamma | beta] of first_mlp, bias of res_connect: [4][128] */
   const float *v2;      /* [bias | gamma | beta][128] of second_mlp */
   const float *v0, *b1; /* head: [bias | gamma | beta][128]; bias [n1c*32] */
-  const float *tvec;    /* added after first_mlp's ReLU: tvec[(t_idx ? t_idx[0] * t_stride : 0) + c] (row t of the per-timestep table), or NULL */
+  const float *tvec;    /* added after first_mlp's ReLU: tvec[(t_idx ? t_idx[0] * t_stride : 0) + sample * t_bs + c] (row t of the per-timestep table; or, t_idx NULL and t_bs > 0, the sample's own t-embedding row), or NULL */
   const int32_t *t_idx;
   const float *cvec;    /* added after second_mlp's ReLU: cvec[sample * c_bs + c], or NULL */
   void *X;              /* fp16 [rows][x_ld], the head's input: columns [128, k0) are READ ([xyz | zero pad]), columns [0, 128) WRITTEN (the block's output) */
   float *eps;           /* OUT fp32 [rows][eps_ld]: the prediction (eps_ld <= 32 n1c, a multiple of 4) */
-  int32_t rows, z_ld, kz, x_ld, k0, n1c, eps_ld, t_stride, t_bs /* must be 0 */, c_bs;
+  const void *Wz_lo, *W2_lo, *W0_lo, *W1_lo; /* round 6, WIDE form (all four set, or all NULL): fp16 LOW fragments of the four weight
+                         * matrices, lo' = fp16((w - fp16(w)) * 2^11), in the layouts of Wz / W2 / W0 / W1 -- the chain then runs in the
+                         * split arithmetic (fp32-grade products: three fp16 MFMAs per product, activations cross the waves as two
+                         * fp16 planes) */
+  int32_t rows, z_ld, kz, x_ld, k0, n1c, eps_ld, t_stride, t_bs /* elements between the SAMPLES' rows of tvec (0: one shared row) */, c_bs;
   int32_t fuse_update;  /* 1: the launch also applies the feature DDPM's update (upd.kind == 1) to the state and advances the device-side
                          * timestep -- the lane that holds eps[row][channel] updates x[row][channel]; the noise of the workgroup's elements
                          * is drawn while the chain's loads are in flight.  Of `upd` the update members are read (kind ... copies). */

@@ -54,7 +54,13 @@ def main():
     ap.add_argument("--encode_from", type=str, default=None, help="npz with points, normals, keypoint, label: encode first")
     ap.add_argument("--seed", type=int, default=0, help="seeds the start index of the decode's plain-FPS calls (per shape: a function "
                                                           "of (seed, shape index), independent of ranks and batches)")
+    ap.add_argument("--prec", default="mixed", choices=["mixed", "fp32", "fp16", "split"],
+                    help="module-path arithmetic, as in the generation CLIs: mixed / fp16 (default) = fp16 MFMA operands with fp32 "
+                         "accumulation, GroupNorm statistics and soft-max (what bench.py's decode leg times; pinned to the reference's "
+                         "decode by tests/test_hip_modules.py); fp32 / split = exact fp32 MFMA")
     a = ap.parse_args()
+    from slide_amd.generation import module_prec_of
+    os.environ["SLIDE_MODULE_PREC"] = module_prec_of(a.prec)  # (read when the layers are built and when they run)
 
     import torch
     from models.autoencoder import PointAutoencoder

@@ -8,6 +8,6 @@ _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 # Hardware queues per process (the ROCm default is 4): the sampling arrangement replays FOUR chains (the position chain + three feature
 # sub-batches) on four streams, and two chains that land on one hardware queue serialise -- measured with bench.py (round 5,
-# tools/r05_queues.sh): GPU_MAX_HW_QUEUES = 4 / 5 / 12 / 16 / 24 -> 385 shapes/s, 3 / 7 / 8 -> 285, 6 -> 320, 1 -> 195.  Pinned to the
+# tools/ab/r05_queues.sh): GPU_MAX_HW_QUEUES = 4 / 5 / 12 / 16 / 24 -> 385 shapes/s, 3 / 7 / 8 -> 285, 6 -> 320, 1 -> 195.  Pinned to the
 # default unless the environment says otherwise (same init-time caveat as above).
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")

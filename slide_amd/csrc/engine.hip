@@ -942,7 +942,7 @@ __device__ __forceinline__ void attn_tail_body(const AttnTailArgs &a) {
 // ahead, and only the weights (64 channels x 32 k = 4 KB per chunk, read by all four waves) go through an LDS-DMA ring of RXD + 1
 // stages: 23 KB of LDS per workgroup instead of 61, a quarter of the ds_reads, RXD - 1 ... RXD chunks in flight per workgroup instead
 // of two.  ONE pipeline over both contractions, values first (their chunk count must be a multiple of RXD -- the launcher checks --
-// so that the register slot of a chunk is a compile-time index), then scores.  Measured (tools/r05_tailrx.sh): the feature step's two
+// so that the register slot of a chunk is a compile-time index), then scores.  Measured (tools/ab/r05_tailrx.sh): the feature step's two
 // SA tails 67.0 -> 64.4 us stand-alone, 378.9 -> 382.6 shapes/s in the arrangement (three alternating pairs) -- the deeper prefetch
 // buys little: the tile's fill rate (~58 GB/s per CU, round 3's ablations) is a throughput cap, not a latency one.
 constexpr int RXD = 4;

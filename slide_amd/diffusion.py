@@ -186,16 +186,8 @@ class _GraphedSampler:
         pch = getattr(e, "point_chain", None)
         chain_at = None
         if pch is not None and not (set(pch["idx"]) & drop) and all(e.ops[i].kind == 1 for i in pch["idx"]):
-            from .engine import OP_POINT_CHAIN, SlidePointChainArgs
-            c = SlidePointChainArgs()
-            for k_ in ("Z", "Wz", "W2", "W0", "W1", "vz", "v2", "v0", "b1", "X"):
-                setattr(c, k_, pch[k_].data_ptr())
-            c.eps = e.eps_pad.data_ptr()
-            c.rows, c.z_ld, c.kz, c.x_ld, c.k0, c.n1c, c.eps_ld = self.B * 16, pch["Z"].shape[1], pch["kz"], pch["X"].shape[1], pch["k0"], pch["n1c"], e.eps_pad.shape[1]
-            if pch["t_off"] is not None:  # row t of the per-timestep table (the engine's t_dev[0])
-                c.tvec, c.t_idx, c.t_stride, c.t_bs = e.tvec.data_ptr() + 4 * pch["t_off"], e.t_dev.data_ptr(), e._n_fc, 0
-            if pch["c_off"] is not None:
-                c.cvec, c.c_bs = e.cvec.data_ptr() + 4 * pch["c_off"], e._c_bs
+            from .engine import OP_POINT_CHAIN
+            c = e.point_chain_args()
             # OPT-IN (SLIDE_POINT_CHAIN_UPDATE=1): the feature DDPM's update in the same launch, its noise drawn in the shadow of the
             # chain's loads -- measured SLOWER (382.8 vs 389.8 shapes/s, three alternating pairs; the launch 18.7 -> 45.8 us): the
             # Box-Muller draws (precise logf / cosf) and the update's scattered 4-byte stores of 1632 elements on 256 threads
@@ -215,7 +207,7 @@ class _GraphedSampler:
             chain_at = pch["idx"][0]
             drop = drop | set(pch["idx"][1:])
         abl = os.environ.get("SLIDE_ABL_DROP")
-        if abl:  # TIMING ablation (tools/r05_ablate.sh): the launches whose kernel name contains one of the substrings are left out -- wrong results
+        if abl:  # TIMING ablation (tools/ab/r05_ablate.sh): the launches whose kernel name contains one of the substrings are left out -- wrong results
             from .engine import OP_ATTN_TAIL, OP_GEMM
             names = getattr(e, "kernel_names", {})
             lab = lambda i: names.get(i, "") + (" gemm16" if e.ops[i].kind == OP_GEMM and e.ops[i].i[0] == 16 * e.B else "") + \

@@ -98,6 +98,7 @@ class SlidePointChainArgs(ctypes.Structure):  # include/slide_engine.h
                 ("vz", ctypes.c_void_p), ("v2", ctypes.c_void_p), ("v0", ctypes.c_void_p), ("b1", ctypes.c_void_p),
                 ("tvec", ctypes.c_void_p), ("t_idx", ctypes.c_void_p), ("cvec", ctypes.c_void_p), ("X", ctypes.c_void_p),
                 ("eps", ctypes.c_void_p),
+                ("Wz_lo", ctypes.c_void_p), ("W2_lo", ctypes.c_void_p), ("W0_lo", ctypes.c_void_p), ("W1_lo", ctypes.c_void_p),
                 ("rows", ctypes.c_int32), ("z_ld", ctypes.c_int32), ("kz", ctypes.c_int32), ("x_ld", ctypes.c_int32),
                 ("k0", ctypes.c_int32), ("n1c", ctypes.c_int32), ("eps_ld", ctypes.c_int32), ("t_stride", ctypes.c_int32),
                 ("t_bs", ctypes.c_int32), ("c_bs", ctypes.c_int32), ("fuse_update", ctypes.c_int32), ("upd", SlideHeadArgs)]
@@ -1347,8 +1348,7 @@ class DenoiserEngine:
         if not (fr["n1"] == 128 and fr["n2"] == 128 and c2 == 128 and (m2 + ".rest_mlp.0.weight") not in sd and ident(128)
                 and len(fr["idx"]) == 2 and fr["idx"][1] + 1 == head_i0 and fr["Z"].shape[1] <= 192 and w0.shape[0] == 128
                 and np.array_equal(lay0[0], np.arange(128)) and lay0[3] == 4 and lay0[2] == 128 and 128 < dec0.shape[1] <= 160
-                and w1.shape[1] == 128 and self.out_dim <= 64 and sd["fc_lyaer.1.weight"].shape[0] == 128
-                and (not has_t or not self.per_sample_t)):
+                and w1.shape[1] == 128 and self.out_dim <= 64 and sd["fc_lyaer.1.weight"].shape[0] == 128):
             return None
         A = self.A
         kz, zin = fr["Z"].shape[1], fr["zin"]
@@ -1365,11 +1365,45 @@ class DenoiserEngine:
         b1 = np.zeros(n1c * 32, np.float32); b1[:w1.shape[0]] = sd["fc_lyaer.3.bias"]
         v0 = np.stack([sd["fc_lyaer.0.bias"], sd["fc_lyaer.1.weight"], sd["fc_lyaer.1.bias"]]).astype(np.float32)
         off = lambda lst, pfx: sum(w for _, w in lst[:[p_ for p_, _ in lst].index(pfx)])
-        return dict(idx=fr["idx"] + [head_i0, head_i0 + 1], Z=fr["Z"], kz=kz, X=dec0, k0=dec0.shape[1], n1c=n1c,
-                    Wz=A.put(Wz, torch.float16), W2=A.put(self._w(m2 + ".second_mlp.0.weight"), torch.float16),
-                    W0=A.put(W0, torch.float16), W1=A.put(W1, torch.float16), vz=A.put(vz), v2=A.put(v2), v0=A.put(v0), b1=A.put(b1),
-                    t_off=off(self._tvec, m2 + ".fc") if has_t else None,
-                    c_off=off(self._cvec, m2 + ".fc_condition") if has_c else None)
+        W2 = self._w(m2 + ".second_mlp.0.weight")
+        d = dict(idx=fr["idx"] + [head_i0, head_i0 + 1], Z=fr["Z"], kz=kz, X=dec0, k0=dec0.shape[1], n1c=n1c,
+                 Wz=A.put(Wz, torch.float16), W2=A.put(W2, torch.float16),
+                 W0=A.put(W0, torch.float16), W1=A.put(W1, torch.float16), vz=A.put(vz), v2=A.put(v2), v0=A.put(v0), b1=A.put(b1),
+                 t_off=off(self._tvec, m2 + ".fc") if has_t else None,
+                 c_off=off(self._cvec, m2 + ".fc_condition") if has_c else None)
+        # round 6: the chain in the SPLIT arithmetic -- low fragments lo' = fp16((w - fp16(w)) 2^11) of the four
+        # weight matrices.  These layers are the end of the network: their operand rounding reaches the prediction unattenuated
+        # (tools/prec_select_feat.py), at 0.3 % of the FLOPs.  SLIDE_POINT_CHAIN_WIDE=0: fp16 operands as in round 5.
+        if os.environ.get("SLIDE_POINT_CHAIN_WIDE", "1") != "0":
+            def lo(w):
+                w = np.asarray(w, np.float32)
+                return ((w - w.astype(np.float16).astype(np.float32)) * np.float32(2048.0)).astype(np.float32)
+            d.update(Wz_lo=A.put(lo(Wz), torch.float16), W2_lo=A.put(lo(W2), torch.float16), W0_lo=A.put(lo(W0), torch.float16),
+                     W1_lo=A.put(lo(W1), torch.float16))
+        return d
+
+    def point_chain_args(self, eps_out=None):
+        """SlidePointChainArgs of this plan's point chain (None when the plan has none): the caller keeps the returned block alive and
+        puts its address into a SLIDE_OP_POINT_CHAIN op in place of the four launches `self.point_chain["idx"]`."""
+        pch = getattr(self, "point_chain", None)
+        if pch is None:
+            return None
+        c = SlidePointChainArgs()
+        for k_ in ("Z", "Wz", "W2", "W0", "W1", "vz", "v2", "v0", "b1", "X", "Wz_lo", "W2_lo", "W0_lo", "W1_lo"):
+            if k_ in pch:
+                setattr(c, k_, pch[k_].data_ptr())
+        c.eps = (eps_out if eps_out is not None else self.eps_pad).data_ptr()
+        c.rows, c.z_ld, c.kz, c.x_ld, c.k0, c.n1c = self.B * 16, pch["Z"].shape[1], pch["kz"], pch["X"].shape[1], pch["k0"], pch["n1c"]
+        c.eps_ld = self.eps_pad.shape[1]
+        if pch["t_off"] is not None:
+            c.tvec = self.tvec.data_ptr() + 4 * pch["t_off"]
+            if self.per_sample_t:  # forward(): every sample's own t-embedding row
+                c.t_idx, c.t_stride, c.t_bs = None, 0, self._t_bs
+            else:                  # samplers: row t of the per-timestep table (the engine's t_dev[0])
+                c.t_idx, c.t_stride, c.t_bs = self.t_dev.data_ptr(), self._n_fc, 0
+        if pch["c_off"] is not None:
+            c.cvec, c.c_bs = self.cvec.data_ptr() + 4 * pch["c_off"], self._c_bs
+        return c
 
     # ------------------------------------------------------------------ whole network
     def _build(self):
@@ -1517,7 +1551,15 @@ class DenoiserEngine:
         self._merge_chain_query()
         self._merge_pp()
         self._w16 = {}
-        self.step_ops = (SlideOp * len(self.ops))(*self.ops)
+        # forward() runs the point chain too (round 6): what the samplers' step plans launch is what the golden forwards measure
+        self.layer_ops = list(self.ops)  # (the four per-point GEMMs as launches of their own: parity tests of the layers)
+        ops = self.layer_ops
+        self._fwd_chain_args = self.point_chain_args()
+        if self._fwd_chain_args is not None and all(self.ops[i] is not None and self.ops[i].kind == OP_GEMM for i in self.point_chain["idx"]):
+            idx = self.point_chain["idx"]
+            ops = [o if i != idx[0] else make_op(OP_POINT_CHAIN, p=(ctypes.addressof(self._fwd_chain_args),))
+                   for i, o in enumerate(self.ops) if i not in idx[1:]]
+        self.step_ops = (SlideOp * len(ops))(*ops)
         self.cond_ops = (SlideOp * 1)(self.cond_op)
 
     def _merge_chain_query(self):

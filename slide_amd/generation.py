@@ -7,6 +7,7 @@ the requested samples are split into contiguous per-rank slices exactly like the
 collective; a single all-gather of the generated latents replaces the reference's per-rank npz files + rank-0 file
 concatenation (mesh_evaluation.py:156-186).  Over xGMI this is RCCL (backend "nccl"); the CPU tests run it on gloo.
 """
+import contextlib
 import os
 import time
 
@@ -189,6 +190,30 @@ def generate_categories(total, run_segment, rank=0, world_size=1, categories=FIV
     return full, labels
 
 
+def module_prec_of(prec):
+    """arithmetic of the MODULE-level path (autoencoder decode / encode: `SLIDE_MODULE_PREC`) that goes with a CLI's `--prec`:
+    "mixed" / "fp16" -> "fp16" (fp16 MFMA operands, fp32 accumulation, GroupNorm statistics and soft-max -- the arithmetic bench.py's
+    decode leg times; pinned to the reference's decode by tests/test_hip_modules.py::
+    test_autoencoder_decode_fp16_operands_matches_reference), "fp32" / "split" -> "fp32" (exact fp32 MFMA)."""
+    return "fp16" if prec in ("mixed", "fp16") else "fp32"
+
+
+@contextlib.contextmanager
+def module_precision(prec):
+    """`with module_precision(cli_prec):` -- build AND run module-path models (PointAutoencoder ...) in the arithmetic of
+    `module_prec_of(cli_prec)`; restores the environment's SLIDE_MODULE_PREC afterwards."""
+    want = module_prec_of(prec)
+    prev = os.environ.get("SLIDE_MODULE_PREC")
+    os.environ["SLIDE_MODULE_PREC"] = want
+    try:
+        yield want
+    finally:
+        if prev is None:
+            os.environ.pop("SLIDE_MODULE_PREC", None)
+        else:
+            os.environ["SLIDE_MODULE_PREC"] = prev
+
+
 def resolve_prec(prec):
     """(position plan arithmetic, feature plan arithmetic) of a `--prec` value.  "mixed" (the default of the generation CLIs and what
     bench.py times since round 5): the position DDPM in the split arithmetic (fp32-grade: its fp16 plan misses north_star's 1e-3 on
@@ -267,7 +292,7 @@ def sub_batch_sizes(B, P):
 # The position chain beside the feature sub-batches runs on a stream confined to 11/16 of the compute units (176 of 256;
 # slide_stream_create_cu_mask): its wide split-arithmetic launches then leave CUs to the latency-critical feature chains at all
 # times (only beside fp16 feature chains with the position plan in the split / fp32 arithmetic: the all-fp16 arrangement loses 3 % with
-# it).  Measured in bench.py's arrangement (tools/r05_cumask.sh, two runs each): all CUs 391.5 shapes/s, 240 CUs 392.1, 224 393.7,
+# it).  Measured in bench.py's arrangement (tools/ab/r05_cumask.sh, two runs each): all CUs 391.5 shapes/s, 240 CUs 392.1, 224 393.7,
 # 208 394.1, 192 394.6, 176 394.9, 160 394.3, 128 369.9, 64 275.2 (the chain becomes the long pole).
 POS_CU_SHARE = 11.0 / 16.0
 

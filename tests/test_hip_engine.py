@@ -41,8 +41,9 @@ def test_denoiser_forward_fp32_matches_reference(gpu_device, name, prec):
 def test_benched_arithmetic_meets_1e3_on_reference_goldens(gpu_device, name, prec):
     """north_star / BASELINE.md section 4: generated latents within 1e-3 (relative, fp32).  `bench.py`'s default arrangement
     (round 5) runs the POSITION plan in the split arithmetic (fp32-grade) and the FEATURE plan in fp16 operands / fp32
-    accumulation: every single forward of both against the reference goldens, relative L2 <= 1e-3 (the position plan also in the
-    max-norm; the fp16 feature plan's max-norm error is reported: 1.2e-3 on these inputs)."""
+    accumulation: every single forward of both against the reference goldens, <= 1e-3 in the relative L2 norm AND in the max-norm
+    (max |difference| / max |reference|).  Round 6: no exemption for the fp16 feature plan -- the end of the network (FP0's second Mlp
+    + the head, SLIDE_OP_POINT_CHAIN) runs in the split arithmetic; round 5 measured 8.7e-4 / 1.2e-3 with fp16 operands there."""
     from slide_amd.engine import DenoiserEngine
     g, hp, sd = _load(name)
     B = g["x_t0"].shape[0]
@@ -55,7 +56,7 @@ def test_benched_arithmetic_meets_1e3_on_reference_goldens(gpu_device, name, pre
         worst = max(worst, float(np.linalg.norm(y - ref) / np.linalg.norm(ref)))
         worst_max = max(worst_max, _rel(y, ref))
     print("benched arithmetic (%s net, %s): relative L2 %.3e, max-norm %.3e vs reference" % (name, prec, worst, worst_max))
-    assert worst <= 1e-3 and (prec == "fp16" or worst_max <= 1e-3), (worst, worst_max)
+    assert worst <= 1e-3 and worst_max <= 1e-3, (worst, worst_max)
 
 
 def test_optin_fp16_position_plan_is_bounded(gpu_device):
@@ -349,7 +350,8 @@ def test_point_chain_launch_matches_its_four_layers(gpu_device, monkeypatch):
         kp = np.resize(g["keypoint"], (B,) + g["keypoint"].shape[1:])
         noise = rs.standard_normal((4, B, 16, C)).astype(np.float32)
         out, eps, nl, outn = {}, {}, {}, {}
-        for tag, on, upd in (("fused", "1", "1"), ("chain", "1", "0"), ("plan", "0", "1")):
+        monkeypatch.setenv("SLIDE_POINT_CHAIN_WIDE", "0")  # like with like: the chain in the four layers' fp16 operands (round 6's default, the
+        for tag, on, upd in (("fused", "1", "1"), ("chain", "1", "0"), ("plan", "0", "1")):  # split arithmetic, is compared below)
             monkeypatch.setenv("SLIDE_POINT_CHAIN", on)
             monkeypatch.setenv("SLIDE_POINT_CHAIN_UPDATE", upd)
             fs = FeatureSampler(hpf, sdf, B, gpu_device, cfg, prec="fp16", seed=9, use_graph=False)
@@ -368,6 +370,15 @@ def test_point_chain_launch_matches_its_four_layers(gpu_device, monkeypatch):
         assert _rel(out["fused"], out["plan"]) <= 5e-4, (B, _rel(out["fused"], out["plan"]))
         assert _rel(outn["fused"], outn["plan"]) <= 5e-4, (B, _rel(outn["fused"], outn["plan"]))
         assert np.abs(eps["fused"] - eps["plan"]).max() <= 2e-3 * np.abs(eps["plan"]).max(), B
+        # round 6: the chain's default form -- split arithmetic (fp32-grade products) -- against the fp16 layers: same network, fewer roundings
+        monkeypatch.setenv("SLIDE_POINT_CHAIN_WIDE", "1")
+        monkeypatch.setenv("SLIDE_POINT_CHAIN", "1")
+        monkeypatch.setenv("SLIDE_POINT_CHAIN_UPDATE", "0")
+        fw = FeatureSampler(hpf, sdf, B, gpu_device, cfg, prec="fp16", seed=9, use_graph=False)
+        assert 37 in [o.kind for o in fw.step_ops] and len(fw.step_ops) == nl["chain"]
+        fw.sample(lab, kp, xf, t_start=60, n_steps=1)
+        ew = fw.engine.eps_pad.float().cpu().numpy()
+        assert np.isfinite(ew).all() and np.abs(ew - eps["plan"]).max() <= 2e-3 * np.abs(eps["plan"]).max(), B
 
 
 @pytest.mark.parametrize("prec", ["fp32", "split"])
@@ -808,16 +819,15 @@ def test_benched_full_chains_follow_the_fp32_chains(gpu_device):
     """north_star's criterion on GENERATED LATENTS, over complete generations in the arithmetic `bench.py` times (round 5:
     position chain split, feature chain fp16 operands / fp32 accumulation) against the same chains in the exact-fp32 mode
     (pinned to the reference at <= 1e-3 above, measured 7e-7), 256 shapes, in-kernel Philox noise with equal seeds.
-    Asserted per shape (relative max distance): <= 1e-3 for at least 99 % of the shapes.  The exemption is COUNTED and bounded:
-    a position chain re-runs its kNN on noisy points every step, and a near-tie that resolves differently under a 1e-6
-    perturbation turns that shape into another sample of the same distribution -- at most 1 % of the shapes (2 of 256) may
-    exceed 1e-3 and none 1e-2; batch statistics must agree."""
+    Asserted per shape (relative max distance): <= 1e-3 for EVERY shape (round 6: no exemption -- rounds 4-5 allowed 1 % of the
+    shapes up to 1e-2 for flipped kNN near-ties of the position chain; the split position plan does not flip any on these seeds:
+    measured maximum 7.5e-4 position / 3.1e-4 feature); batch statistics must agree."""
     B = 256
     res = _full_chains(gpu_device, B, {"bench": ("split", "fp16"), "fp32": ("fp32", "fp32")})
     for name in ("pos", "feat"):
         per_shape, dm, ratio = _chain_agreement(name, res[name, "bench"], res[name, "fp32"], B)
         n_over = int((per_shape > 1e-3).sum())
-        assert n_over <= B // 100 and per_shape.max() <= 1e-2, (name, n_over, per_shape.max())
+        assert n_over == 0 and per_shape.max() <= 1e-3, (name, n_over, per_shape.max())
         assert dm.max() <= 0.01 and 0.99 <= ratio.min() and ratio.max() <= 1.01
 
 

@@ -13,6 +13,12 @@ from slide_amd.synth import synth_state_dict
 
 pytestmark = pytest.mark.gpu
 
+# tolerances of the fp16-operand decode (the arithmetic bench.py's decode leg times and the generation CLIs run by default) against
+# the reference's decode of golden_decode.npz.  Measured in round 6 (printed by the test): reference points -> own candidates 3.3e-6 /
+# 1.0e-5 / 7.6e-6 per level (six channels, clouds in [-1, 1]^3); Chamfer per level <= 6.8e-8, end to end 2.0e-7.
+DECODE_FP16_LEVEL_TOL = 1e-4
+DECODE_FP16_CHAMFER_TOL = 1e-5
+
 
 def T(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -119,6 +125,67 @@ def test_autoencoder_decode_matches_reference(gpu_device):
     # random-start variant runs and stays on the same surface
     full_r = ae.decode(kp, feat, label=lab).cpu().numpy()
     assert max(D.chamfer(full_r[b], g["level3"][b]) for b in range(B)) <= 1e-3
+
+
+def test_autoencoder_decode_fp16_operands_matches_reference(gpu_device, monkeypatch):
+    """The TIMED decode arithmetic (bench.py's decode leg and the generation CLIs' default `--prec mixed`: SLIDE_MODULE_PREC=fp16 =
+    fp16 MFMA operands, fp32 accumulation / GroupNorm statistics / soft-max) against the reference's decode of the same latents
+    (golden_decode.npz, FPS start index 0; reference: pointnet2/models/autoencoder.py:42-45,
+    point_upsample_decoder.py:184-190).  A decoder level is [feature extractor -> upsampling to 2x the points -> plain FPS down to
+    the level's size].  The FPS step selects a SUBSET of the upsampled candidates and a 1e-3 perturbation of the candidates can
+    change which near-equidistant candidate is picked, so at this precision the selected sets are not compared point for point
+    (the fp32 module mode is: test_autoencoder_decode_matches_reference).  What is asserted, per level, each level fed with the
+    reference's previous level:
+      * every point the REFERENCE selected has one of this path's upsampled CANDIDATES (the tensor handed to the FPS kernel)
+        within DECODE_FP16_LEVEL_TOL in all six channels (nearest by xyz) -- the arithmetic of the level, FPS taken out;
+      * the level's selected cloud has Chamfer distance <= DECODE_FP16_CHAMFER_TOL to the reference's level;
+    and end to end (own previous levels, own FPS order): Chamfer <= DECODE_FP16_CHAMFER_TOL to the reference cloud (sum of both
+    directions, mean squared distances; the clouds span [-1, 1]^3)."""
+    monkeypatch.setenv("SLIDE_MODULE_PREC", "fp16")
+    sys.path.insert(0, os.path.join(REPO, "pointnet2"))
+    from models import point_upsample_decoder as PUD
+    from models.autoencoder import PointAutoencoder
+    from oracle import denoiser_np as D
+    g = load_golden("golden_decode.npz")
+    decs = json.loads(str(g["decoder_configs_json"]))
+    spec = golden_spec(g)
+    ae = PointAutoencoder(None, decs, apply_kl_regularization=True)
+    vals = synth_state_dict([("ae." + n, s) for n, s in spec])
+    ae.load_state_dict({n: torch.from_numpy(vals["ae." + n]) for n, _ in spec})
+    ae = ae.to(gpu_device).eval()
+    d = gpu_device
+    kp, feat, lab = T(g["keypoint"], d), T(g["feature"], d), T(g["label"], d)
+    B = kp.shape[0]
+    start = torch.zeros(B, dtype=torch.int32, device=d)
+    cands = []
+    real_fps = PUD._hip.sample_farthest_points
+
+    def recording_fps(pts, *a, **k):  # the candidates of every plain-FPS call, in call order
+        cands.append(pts.detach().cpu().numpy())
+        return real_fps(pts, *a, **k)
+
+    monkeypatch.setattr(PUD._hip, "sample_farthest_points", recording_fps)
+    l1 = ae.keypoint_encoder.upsample_points(feat, kp, start)
+    f2, l2 = ae.decoder.decoders[0](kp, feat, T(g["level1"], d), label=lab, fps_start_idx=start)
+    f3, l3 = ae.decoder.decoders[1](T(g["level1"], d)[:, :, :3].contiguous(), f2, T(g["level2"], d), label=lab, fps_start_idx=start)
+    assert len(cands) == 3
+    worst_lvl = worst_cd = 0.0
+    for name, own, cand in (("level1", l1, cands[0]), ("level2", l2, cands[1]), ("level3", l3, cands[2])):
+        ref = g[name]
+        assert cand.shape[1] >= ref.shape[1] and own.shape == ref.shape
+        e = max(D.match_point_sets(ref[b], cand[b])[0] for b in range(B))       # reference selections -> own candidates
+        cd = max(D.chamfer(own[b].cpu().numpy(), ref[b]) for b in range(B))
+        same = sum(D.match_point_sets(own[b].cpu().numpy(), ref[b])[1] for b in range(B))
+        print("fp16-operand decode, %s: reference points -> own candidates max %.3e; Chamfer of the selected cloud %.3e; "
+              "selected SET identical for %d of %d shapes" % (name, e, cd, same, B))
+        worst_lvl, worst_cd = max(worst_lvl, e), max(worst_cd, cd)
+    monkeypatch.setattr(PUD._hip, "sample_farthest_points", real_fps)
+    full = ae.decode(kp, feat, label=lab, fps_start_idx=start).cpu().numpy()
+    assert full.shape == (B, 2048, 6) and np.isfinite(full).all()
+    cd = max(D.chamfer(full[b], g["level3"][b]) for b in range(B))
+    print("fp16-operand decode end to end: Chamfer vs the reference cloud %.3e" % cd)
+    assert worst_lvl <= DECODE_FP16_LEVEL_TOL, worst_lvl
+    assert max(worst_cd, cd) <= DECODE_FP16_CHAMFER_TOL, (worst_cd, cd)
 
 
 def test_autoencoder_encode_matches_reference(gpu_device):
