@@ -283,7 +283,10 @@ class PointnetSAModuleMSG(nn.Module):
             picked = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
             # (row-layout gather of the (B, N, 3) coordinates: one launch that moves exactly the picked rows, instead of transpose ->
             #  gather_points on (B, 3, N) -> transpose; the reference's gather_operation call site: pointnet2_modules.py:368-378)
-            centres = _ext.gather_rows(xyz.contiguous().float(), picked)
+            if xyz.requires_grad:  # gather_rows has no autograd Function: keep the coordinates' gradient path
+                centres = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), picked).transpose(1, 2).contiguous()
+            else:
+                centres = _ext.gather_rows(xyz.contiguous().float(), picked)
             query = R.gather_rows(feat, picked) if (self.use_attention_module and feat is not None) else None
         emb = _emb_kwargs(self, t_emb, condition_emb, second_condition_emb)
         outs = []

@@ -82,11 +82,30 @@ def latent_diffusion_params(cfg):
             "posterior_mean_coef2": (1.0 - acp) * np.sqrt(alphas) / (1.0 - ac), "data_clamp_range": cfg["data_clamp_range"]}
 
 
-def _destroy_stream(handle):
-    try:
-        lib().slide_stream_destroy(ctypes.c_void_p(handle))
-    except Exception:  # (interpreter shutdown: the library may be gone)
-        pass
+# CU-masked streams live for the whole process: torch's caching allocator may keep references to any stream it has seen
+# (record_stream on a sampler's inputs, blocks allocated under `torch.cuda.stream(...)`), so a masked stream is never destroyed while
+# tensors may still name it.
+# Handles are LEASED: a sampler takes a free one of its (device, mask) or creates one, and its finalizer hands it back to the pool.
+_MASKED_FREE = {}
+
+
+def _masked_stream_lease(device, words):
+    """(raw hipStream_t of a process-lifetime stream confined to the compute units of `words` on `device`, key, status)"""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), words)
+    free = _MASKED_FREE.setdefault(key, [])
+    if free:
+        return free.pop(), key, 0
+    arr = (ctypes.c_uint32 * len(words))(*words)
+    ptr = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        st = lib().slide_stream_create_cu_mask(arr, len(words), ctypes.byref(ptr))
+    if st != 0 or not ptr.value:
+        return None, key, st
+    return ptr.value, key, 0
+
+
+def _masked_stream_return(key, handle):
+    _MASKED_FREE.setdefault(key, []).append(handle)  # (never destroyed: see above)
 
 
 class _GraphedSampler:
@@ -115,14 +134,11 @@ class _GraphedSampler:
             words = [0] * ((total + 31) // 32)
             for cu in range(first, min(first + ncu, total)):
                 words[cu // 32] |= 1 << (cu % 32)
-            arr = (ctypes.c_uint32 * len(words))(*words)
-            ptr = ctypes.c_void_p()
-            with torch.cuda.device(device):
-                st = lib().slide_stream_create_cu_mask(arr, len(words), ctypes.byref(ptr))
-            if st == 0 and ptr.value:
-                self._masked_stream, self.n_cus = ptr.value, min(first + ncu, total) - first
-                self.stream = torch.cuda.ExternalStream(ptr.value, device=device)
-                weakref.finalize(self, _destroy_stream, ptr.value)  # (torch does not own an ExternalStream's handle)
+            handle, key, st = _masked_stream_lease(device, tuple(words))
+            if handle:
+                self._masked_stream, self.n_cus = handle, min(first + ncu, total) - first
+                self.stream = torch.cuda.ExternalStream(handle, device=device)
+                weakref.finalize(self, _masked_stream_return, key, handle)  # back to the pool; the stream itself lives on
             else:  # (a tuning, not a requirement: the chain runs on an ordinary stream)
                 import warnings
                 warnings.warn("slide_stream_create_cu_mask failed (status %d): the chain runs on all compute units" % st)

@@ -3,6 +3,7 @@ transposed weights.  Activations are fp32 CUDA tensors [rows, ld], ld a multiple
 them zero).  The GEMMs run in the split mode (fp32 storage, contractions as two-term fp16 operand splits: fp32-grade results on
 the fp16 matrix pipe, include/slide_engine.h SLIDE_PREC_SPLIT)."""
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -49,13 +50,25 @@ def _packs(weight, kp, op_):
     c = _PACK_CACHE.get(key)
     if c is None:
         if len(_PACK_CACHE) > 4096:
-            # (never evict: the buffers' addresses are baked into captured step graphs -- ADVICE r4; a model has a few hundred entries)
+            # (never evict a LIVE parameter's buffers: their addresses are baked into captured step graphs -- ADVICE r4; a model has a
+            #  few hundred entries, and entries die with their parameter, below)
             raise RuntimeError("slide_amd.train: more than 4096 packed weight buffers alive -- parameters are being re-created every step")
         dev = weight.device
         c = {"W": torch.zeros(op_, kp, device=dev), "Wt": torch.zeros(kp, op_, device=dev), "vec": torch.zeros(op_, device=dev),
              "zero": torch.zeros(kp, device=dev)}
         _PACK_CACHE[key] = c
+        # the entry lives exactly as long as its parameter: a collected parameter's buffers and epilogue tables are released,
+        # and a recycled id() can never pick up buffers whose addresses an older captured graph holds
+        weakref.finalize(weight, _drop_pack, key)
     return c
+
+
+def _drop_pack(key):
+    c = _PACK_CACHE.pop(key, None)
+    if c is not None:
+        addr = c["vec"].data_ptr()
+        for k in [k for k in _EPI_CACHE if k[0] == addr]:
+            _EPI_CACHE.pop(k, None)
 
 
 def _gemm(x, w_packed, bias_vec, n_out_pad):

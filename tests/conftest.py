@@ -13,6 +13,24 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long CPU test")
+    config.addinivalue_line("markers", "exp: exercises the EXPERIMENTS build (libslide_hip_exp.so: opt-in kernel variants that lost their A/B) -- "
+                                       "not part of the default selections; run with -m exp (or -m 'gpu and exp')")
+
+
+def pytest_collection_modifyitems(config, items):
+    """tests of the experiments library carry the `exp` marker (explicitly, or by using the `exp_lib` fixture) and are DESELECTED unless
+    the -m expression names it: the default `-m gpu` / `-m "not gpu"` runs spend their time on the product paths"""
+    for it in items:
+        if "exp_lib" in getattr(it, "fixturenames", ()):
+            it.add_marker(pytest.mark.exp)
+    if "exp" in (config.getoption("-m") or ""):
+        return
+    keep, drop = [], []
+    for it in items:
+        (drop if it.get_closest_marker("exp") else keep).append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 def load_golden(name):

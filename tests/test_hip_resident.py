@@ -10,7 +10,7 @@ import torch
 from conftest import NoiseStream, golden_spec, load_golden
 from slide_amd.synth import synth_state_dict
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.exp]
 
 
 @pytest.fixture(autouse=True)

@@ -4,6 +4,7 @@ against the reference-generated denoiser golden.  fp16 activation storage: toler
 import json
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import golden_spec, load_golden
@@ -12,6 +13,8 @@ from resident_emu import Emu
 from slide_amd.engine import DenoiserEngine
 from slide_amd.experiments.resident import LDS_LIMIT, R_GEMM, R_TAIL, ResidentPlan
 from slide_amd.synth import synth_state_dict
+
+pytestmark = pytest.mark.exp  # (the op program of the experiments build's LDS-resident kernel)
 
 
 def _vectors(hp, sd, e, ts, label):
