@@ -176,6 +176,132 @@ def decode_leg(dev, B):
             os.environ["SLIDE_MODULE_PREC"] = prev
 
 
+def configs_leg(dev, B, a, pc, fc, sd_p, sd_f, gen, feat_chains, pos_sampler, steps=20, warmup=5):
+    """`configs` object of the JSON line (round 6): every BASELINE config on the driver's record, each timed like
+    the headline (W untimed steps, barrier + synchronize, K timed steps, synchronize; the reference's convention: wall time of the
+    whole sampling loop, pointnet2/mesh_evaluation.py:102,126), in the benched arithmetic, after the headline's timed region:
+      config2_position_ddpm: BASELINE configs[1] ALONE -- the airplane position DDPM, one chain of B shapes (`pos_batch_multiple` 1) and
+        one chain of 2 B shapes (multiple 2, the headline arrangement's position chain), shapes/s of the position DDPM only
+        (a shape = 1000 position steps);
+      config3_feature_ddpm: BASELINE configs[2] ALONE -- the chair feature DDPM on fixed key points, B shapes as the headline's
+        sub-batches, shapes/s of the feature DDPM only;
+      joint_pos_batch_multiple_1: the headline arrangement with the position chain over B shapes stepping every round (config 2 at
+        its literal batch beside config 3) -- the headline runs it over 2 B shapes at half cadence;
+      config4_five_category_shard: BASELINE configs[3]'s per-GPU shard -- B shapes as five category segments (labels 0, 2, 3, 4, 6; one
+        position + one feature weight set per category; ten chains on four streams), shapes/s, and per category the forward error of
+        the benched arithmetic against the fp32 mode (relative L2, batch 8) for both nets;
+      config4_rank1_of_8_shard: the same config as the 8-GPU run shards it -- the B shapes of rank 1 of an 8 B-shape run in
+        category-major order (two segments: four chains)."""
+    import torch
+    from slide_amd.diffusion import EagerChainsSampler, FeatureSampler, PositionSampler
+    from slide_amd.engine import DenoiserEngine
+    from slide_amd.generation import POS_CU_SHARE, CategoryChains
+    from slide_amd.synth import synth_keypoints, synth_state_dict
+    from slide_amd import model_spec
+    out = {"steps": steps, "warmup": warmup}
+
+    def timed(joint, begin, streams):
+        begin()
+        joint.advance(warmup)
+        for st_ in streams:
+            st_.synchronize()
+        torch.cuda.synchronize(dev)
+        begin()
+        for st_ in streams:
+            st_.synchronize()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        joint.advance(steps)
+        for st_ in streams:
+            st_.synchronize()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / steps
+
+    # The stream -> hardware-queue assignment of the runtime decides whether concurrent chains overlap (four queues; two chains on one
+    # queue serialise: DESIGN.md section 9 item 5a'), and it depends on the order in which streams were created and first used.  The
+    # concurrent legs therefore run on the HEADLINE's own chains and streams: its feature samplers as they are, a batch-B position
+    # chain on the headline position chain's stream.
+    feats = list(feat_chains)
+    sizes = [f_.B for f_, _, _ in feats]
+    P = len(feats)
+
+    def begin_feats():
+        for f_, l_, k_ in feats:
+            f_.begin(l_, k_, torch.randn(f_.B, 16, 51, device=dev, generator=gen))
+
+    # config 3 alone
+    s = timed(EagerChainsSampler([f_ for f_, _, _ in feats]), begin_feats, [f_.stream for f_, _, _ in feats])
+    out["config3_feature_ddpm"] = {"batch": B, "sub_batches": sizes, "prec": a.prec, "ms_per_step": round(s * 1e3, 5),
+                                   "shapes_per_s": round(B / (1000.0 * s), 2)}
+    # config 2 alone, at its literal batch and at the headline's multiple
+    c2 = {}
+    for mult in (1, 2):
+        ps = PositionSampler(pc["pointnet_config"], sd_p, B * mult, dev, pc["diffusion_config"], prec=a.pos_prec, seed=3100 + mult, use_graph=False)
+        lab = torch.zeros(ps.B, dtype=torch.int64, device=dev)
+        s = timed(EagerChainsSampler([ps]), lambda: ps.begin(lab, torch.randn(ps.B, 16, 3, device=dev, generator=gen)), [ps.stream])
+        c2["pos_batch_multiple_%d" % mult] = {"batch": ps.B, "prec": a.pos_prec, "ms_per_step": round(s * 1e3, 5),
+                                              "shapes_per_s": round(ps.B / (1000.0 * s), 2)}
+        del ps
+    out["config2_position_ddpm"] = c2
+    # the joint arrangement with the position chain at config 2's literal batch
+    ps = PositionSampler(pc["pointnet_config"], sd_p, B, dev, pc["diffusion_config"], prec=a.pos_prec, seed=3200, use_graph=False)
+    ps.stream = ps.stream2 = pos_sampler.stream  # (the headline position chain's stream: its CU mask and its hardware queue)
+    lab = torch.zeros(B, dtype=torch.int64, device=dev)
+
+    def begin_joint():
+        ps.begin(lab, torch.randn(B, 16, 3, device=dev, generator=gen))
+        begin_feats()
+
+    order = [feats[0][0], ps] + [f_ for f_, _, _ in feats[1:]]
+    s = timed(EagerChainsSampler(order), begin_joint, [o_.stream for o_ in order])
+    out["joint_pos_batch_multiple_1"] = {"batch": B, "ms_per_step": round(s * 1e3, 5), "shapes_per_s": round(B / (1000.0 * s), 2),
+                                         "pos_stream_cus": getattr(pos_sampler, "n_cus", 0) or "all"}
+    del ps, feats, order
+    # config 4: (i) B shapes as ALL five category segments (a 1-GPU run of the config), (ii) the shard of rank 1 of 8 of the 8 B-shape
+    # run -- BASELINE configs[3] as quoted: category-major order, contiguous shards, so a rank's B shapes span at most two categories
+    spec_p, spec_f = model_spec.denoiser_param_spec(pc["pointnet_config"]), model_spec.denoiser_param_spec(fc["pointnet_config"])
+    wts = lambda c: (synth_state_dict(spec_p, seed=100 + c), synth_state_dict(spec_f, seed=200 + c))
+    for key, total, rank_, world_ in (("config4_five_category_shard", B, 0, 1), ("config4_rank1_of_8_shard", 8 * B, 1, 8)):
+        cc = CategoryChains(total, rank_, world_, pc, fc, wts, dev, prec="mixed" if (a.prec == "fp16" and a.pos_prec == "split") else a.prec, seed=11)
+        chains = []
+        for k, (c, lo, hi, ps, fs) in enumerate(cc.chains):
+            chains.append((ps, fs, torch.full((hi - lo,), c, dtype=torch.int64, device=dev), torch.as_tensor(synth_keypoints(hi - lo, seed=60 + k), device=dev)))
+
+        def begin_cat():
+            for ps, fs, l_, k_ in chains:
+                ps.begin(l_, torch.randn(ps.B, 16, 3, device=dev, generator=gen))
+                fs.begin(l_, k_, torch.randn(fs.B, 16, 51, device=dev, generator=gen))
+
+        order = []
+        for ps, fs, _, _ in chains:
+            order += [fs, ps]
+        s = timed(EagerChainsSampler(order), begin_cat, [o_.stream for o_ in order])
+        finite = all(bool(torch.isfinite(o_.state()).all().item()) for o_ in order)
+        n_sh = sum(hi - lo for _, lo, hi, _, _ in cc.chains)
+        out[key] = {"shapes": n_sh, "segments": [{"label": c, "shapes": hi - lo} for c, lo, hi, _, _ in cc.chains], "chains": len(order),
+                    "ms_per_step": round(s * 1e3, 5), "shapes_per_s": round(n_sh / (1000.0 * s), 2), "finite": finite}
+        del cc, chains, order
+    c4 = out["config4_five_category_shard"]
+    c4["forward_rel_l2_vs_fp32_mode"] = {}
+    nb = 8
+    rs = np.random.RandomState(321)
+    tsb = np.linspace(0, 999, nb).astype(np.float32)
+    for c in (0, 2, 3, 4, 6):
+        sd_pc, sd_fc = wts(c)
+        e = {}
+        for nm, cfg_, sd_, mode in (("pos", pc, sd_pc, a.pos_prec), ("feat", fc, sd_fc, a.prec)):
+            hp_ = cfg_["pointnet_config"]
+            xb = rs.standard_normal((nb, 16, 3 + hp_["in_fea_dim"])).astype(np.float32)
+            if nm == "feat":
+                xb[:, :, :3] = synth_keypoints(nb, seed=99)
+            lb = np.full(nb, c, np.int64)
+            y32 = DenoiserEngine(hp_, sd_, nb, dev, prec="fp32").forward(xb, tsb, lb).double()
+            yb = DenoiserEngine(hp_, sd_, nb, dev, prec=mode).forward(xb, tsb, lb).double()
+            e[nm] = round(float(((yb - y32).norm() / y32.norm()).item()), 7)
+        c4["forward_rel_l2_vs_fp32_mode"]["label_%d" % c] = e
+    return out
+
+
 def parity_leg(dev, B, a, pc, fc, sd_p, sd_f, gen):
     """`parity` object of the JSON line: ONLY numbers measured in this run, on this GPU.
     forward_rel_l2_vs_fp32_mode: relative L2 of one denoiser forward IN THE BENCHED ARITHMETIC (position plan: --pos-prec,
@@ -283,6 +409,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the autoencoder-decode leg (BASELINE configs[4]) of the JSON line")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (BASELINE configs 2, 3, 4 timed one by one after the headline)")
     ap.add_argument("--no-parity", action="store_true", help="skip the live fp16-vs-fp32 forward error and the fp32-mode timing")
     ap.add_argument("--fp32-steps", type=int, default=10, help="reverse steps of the exact-fp32 mode timed for parity.fp32_mode_shapes_per_s")
     a = ap.parse_args()
@@ -333,77 +460,89 @@ def main():
     pc, fc = configs.position_ddpm_config(), configs.feature_ddpm_config()
     sd_p = synth_state_dict(model_spec.denoiser_param_spec(pc["pointnet_config"]))
     sd_f = synth_state_dict(model_spec.denoiser_param_spec(fc["pointnet_config"]))
-    P = max(1, min(a.sub_batches, B))
-    sizes = [B // P + (1 if i < B % P else 0) for i in range(P)]
-    if B % 8 == 0 and B // 8 >= P:  # multiples of 8 samples: the row tiles of a launch then spread evenly over the 8 XCDs
-        sizes = [8 * ((B // 8) // P + (1 if i < (B // 8) % P else 0)) for i in range(P)]
-    if os.environ.get("SLIDE_SUB_SIZES"):  # experiment knob: explicit sub-batch sizes, e.g. 112,144
-        sizes = [int(v) for v in os.environ["SLIDE_SUB_SIZES"].split(",")]
-        assert sum(sizes) == B
-        P = len(sizes)
-    # the feature plan runs as P concurrent sub-batches; the position plan (launch-bound at any size) as ONE chain over
-    # the whole batch beside them
-    if P == 1:  # one chain pair: the two plans as the two branches of one step graph (two lone streams serialise)
-        a.replay = "graph"
-    eager = a.replay != "graph"
-    if a.workload == "default":
-        # position chain over pos_mult x B shapes, stepping once per pos_mult rounds of the feature chains (same shapes per unit time,
-        # fewer dependent launches): 1 for the fp16 plan (measured neutral), 2 when the position plan runs wide operands beside fp16
-        # feature chains (--pos-prec split: 272 -> 315 shapes/s)
-        wide_pos = a.pos_prec in ("split", "fp32") and a.prec == "fp16"
-        pos_mult = int(os.environ.get("SLIDE_POS_MULT", "2" if (wide_pos and eager and a.replay == "eager") else "1"))
-        pos = PositionSampler(pc["pointnet_config"], sd_p, B * pos_mult, dev, pc["diffusion_config"], prec=a.pos_prec, seed=1000 + rank * 16,
-                              use_graph=not eager, cu_share=POS_CU_SHARE if (a.replay == "eager" and P > 1 and wide_pos) else 0.0)
-        # position plan: its own step graph on its own stream ("own", default: 1-1.5 % faster) or a parallel branch of the
-        # first feature sub-batch's graph ("branch")
-        pos_own = os.environ.get("SLIDE_POS_GRAPH", "own") == "own" and P > 1
-        subs = []
-        for i, b in enumerate(sizes):
-            f_ = FeatureSampler(fc["pointnet_config"], sd_f, b, dev, fc["standard_diffusion_config"], prec=a.prec,
-                                seed=2000 + rank * 16 + i, use_graph=not eager)
-            subs.append((f_, JointSampler(pos if (i == 0 and not pos_own) else None, f_), synth_keypoints(b, seed=rank * 16 + i)))
-        feat, kp = subs[0][0], subs[0][2]  # sub-batch 0 also serves the roofline leg below
-        members = [OwnGraphSampler(s_[0]) if eager else s_[1] for s_ in subs]
-        if pos_own:
-            members.insert(int(os.environ.get("SLIDE_POS_ORDER", "1")), OwnGraphSampler(pos))
-        joint = SplitJointSampler(members)  # one hipGraph per member and step, launched round-robin
-        if a.replay == "threads":
-            joint = ThreadedEagerSampler([pos] + [s_[0] for s_ in subs])
-        elif a.replay == "eager":
-            order = [s_[0] for s_ in subs[:1]] + [pos] + [s_[0] for s_ in subs[1:]]
-            if os.environ.get("SLIDE_BENCH_ONLY"):  # diagnostic: time a subset of the chains ("pos", "feat", "feat1" = one sub-batch)
-                only = os.environ["SLIDE_BENCH_ONLY"]
-                order = {"pos": [pos], "feat": [s_[0] for s_ in subs], "feat1": [subs[0][0]], "feat2": [s_[0] for s_ in subs[:2]],
-                         "pos+feat1": [subs[0][0], pos]}[only]
-            share_q = os.environ.get("SLIDE_POS_SHARE")  # diagnostic: the position chain on feature sub-batch <k>'s stream (one queue)
-            if share_q is not None and pos in order:
-                pos.stream = subs[int(share_q)][0].stream
-            joint = EagerChainsSampler(order, every=[pos_mult if s_ is pos else 1 for s_ in order])
-    cat_desc = None
-    if a.workload == "five-cat":
-        # per-category weight sets (synthetic, keyed on the category id); every segment of this rank's shard is a chain pair
-        from slide_amd.generation import CategoryChains
-        spec_p, spec_f = model_spec.denoiser_param_spec(pc["pointnet_config"]), model_spec.denoiser_param_spec(fc["pointnet_config"])
-        cc = CategoryChains(B * world, rank, world, pc, fc,
-                            lambda c: (synth_state_dict(spec_p, seed=100 + c), synth_state_dict(spec_f, seed=200 + c)), dev,
-                            prec="mixed" if (a.prec == "fp16" and a.pos_prec == "split") else a.prec, seed=rank + 1)
-        cat_desc = [(c, hi - lo) for c, lo, hi, _, _ in cc.chains]
-        pos_chains = [(ps, torch.full((hi - lo,), c, dtype=torch.int64, device=dev)) for c, lo, hi, ps, _ in cc.chains]
-        feat_chains = [(fs, torch.full((hi - lo,), c, dtype=torch.int64, device=dev),
-                        torch.as_tensor(synth_keypoints(hi - lo, seed=rank * 16 + k), device=dev))
-                       for k, (c, lo, hi, _, fs) in enumerate(cc.chains)]
-        order = []
-        for (ps, _), (fs, _, _) in zip(pos_chains, feat_chains):
-            order += [fs, ps]
-        joint = EagerChainsSampler(order)
-        a.replay = "eager"
-        feat, kp = feat_chains[0][0], feat_chains[0][2].cpu().numpy()
-        sizes = [fs.B for fs, _, _ in feat_chains]
-        P = len(sizes)
-    else:
-        pos_chains = [(pos, torch.zeros(pos.B, dtype=torch.int64, device=dev))]
-        feat_chains = [(f_, torch.full((b,), 4, dtype=torch.int64, device=dev), torch.as_tensor(k_, device=dev))
-                       for (f_, _, k_), b in zip(subs, sizes)]
+
+    def build_arrangement(replay):
+        """the chains of this rank and the sampler that steps them, for one replay mode (built once; a second time only when the
+        host-enqueue calibration below switches an eager run to graph replay)"""
+        a.replay = replay
+        P = max(1, min(a.sub_batches, B))
+        sizes = [B // P + (1 if i < B % P else 0) for i in range(P)]
+        if B % 8 == 0 and B // 8 >= P:  # multiples of 8 samples: the row tiles of a launch then spread evenly over the 8 XCDs
+            sizes = [8 * ((B // 8) // P + (1 if i < (B // 8) % P else 0)) for i in range(P)]
+        if os.environ.get("SLIDE_SUB_SIZES"):  # experiment knob: explicit sub-batch sizes, e.g. 112,144
+            sizes = [int(v) for v in os.environ["SLIDE_SUB_SIZES"].split(",")]
+            assert sum(sizes) == B
+            P = len(sizes)
+        # the feature plan runs as P concurrent sub-batches; the position plan (launch-bound at any size) as ONE chain over
+        # the whole batch beside them
+        if P == 1:  # one chain pair: the two plans as the two branches of one step graph (two lone streams serialise)
+            a.replay = "graph"
+        eager = a.replay != "graph"
+        if a.workload == "default":
+            # position chain over pos_mult x B shapes, stepping once per pos_mult rounds of the feature chains (same shapes per unit time,
+            # fewer dependent launches): 1 for the fp16 plan (measured neutral), 2 when the position plan runs wide operands beside fp16
+            # feature chains (--pos-prec split: 272 -> 315 shapes/s)
+            wide_pos = a.pos_prec in ("split", "fp32") and a.prec == "fp16"
+            pos_mult = int(os.environ.get("SLIDE_POS_MULT", "2" if (wide_pos and eager and a.replay == "eager") else "1"))
+            pos = PositionSampler(pc["pointnet_config"], sd_p, B * pos_mult, dev, pc["diffusion_config"], prec=a.pos_prec, seed=1000 + rank * 16,
+                                  use_graph=not eager, cu_share=POS_CU_SHARE if (a.replay == "eager" and P > 1 and wide_pos) else 0.0)
+            # position plan: its own step graph on its own stream ("own", default: 1-1.5 % faster) or a parallel branch of the
+            # first feature sub-batch's graph ("branch")
+            pos_own = os.environ.get("SLIDE_POS_GRAPH", "own") == "own" and P > 1
+            subs = []
+            for i, b in enumerate(sizes):
+                f_ = FeatureSampler(fc["pointnet_config"], sd_f, b, dev, fc["standard_diffusion_config"], prec=a.prec,
+                                    seed=2000 + rank * 16 + i, use_graph=not eager)
+                subs.append((f_, JointSampler(pos if (i == 0 and not pos_own) else None, f_), synth_keypoints(b, seed=rank * 16 + i)))
+            feat, kp = subs[0][0], subs[0][2]  # sub-batch 0 also serves the roofline leg below
+            members = [OwnGraphSampler(s_[0]) if eager else s_[1] for s_ in subs]
+            if pos_own:
+                members.insert(int(os.environ.get("SLIDE_POS_ORDER", "1")), OwnGraphSampler(pos))
+            joint = SplitJointSampler(members)  # one hipGraph per member and step, launched round-robin
+            if a.replay == "threads":
+                joint = ThreadedEagerSampler([pos] + [s_[0] for s_ in subs])
+            elif a.replay == "eager":
+                order = [s_[0] for s_ in subs[:1]] + [pos] + [s_[0] for s_ in subs[1:]]
+                if os.environ.get("SLIDE_BENCH_ONLY"):  # diagnostic: time a subset of the chains ("pos", "feat", "feat1" = one sub-batch)
+                    only = os.environ["SLIDE_BENCH_ONLY"]
+                    order = {"pos": [pos], "feat": [s_[0] for s_ in subs], "feat1": [subs[0][0]], "feat2": [s_[0] for s_ in subs[:2]],
+                             "pos+feat1": [subs[0][0], pos]}[only]
+                share_q = os.environ.get("SLIDE_POS_SHARE")  # diagnostic: the position chain on feature sub-batch <k>'s stream (one queue)
+                if share_q is not None and pos in order:
+                    pos.stream = subs[int(share_q)][0].stream
+                joint = EagerChainsSampler(order, every=[pos_mult if s_ is pos else 1 for s_ in order])
+        cat_desc = None
+        if a.workload == "five-cat":
+            # per-category weight sets (synthetic, keyed on the category id); every segment of this rank's shard is a chain pair
+            from slide_amd.generation import CategoryChains
+            spec_p, spec_f = model_spec.denoiser_param_spec(pc["pointnet_config"]), model_spec.denoiser_param_spec(fc["pointnet_config"])
+            cc = CategoryChains(B * world, rank, world, pc, fc,
+                                lambda c: (synth_state_dict(spec_p, seed=100 + c), synth_state_dict(spec_f, seed=200 + c)), dev,
+                                prec="mixed" if (a.prec == "fp16" and a.pos_prec == "split") else a.prec, seed=rank + 1)
+            cat_desc = [(c, hi - lo) for c, lo, hi, _, _ in cc.chains]
+            pos_chains = [(ps, torch.full((hi - lo,), c, dtype=torch.int64, device=dev)) for c, lo, hi, ps, _ in cc.chains]
+            feat_chains = [(fs, torch.full((hi - lo,), c, dtype=torch.int64, device=dev),
+                            torch.as_tensor(synth_keypoints(hi - lo, seed=rank * 16 + k), device=dev))
+                           for k, (c, lo, hi, _, fs) in enumerate(cc.chains)]
+            order = []
+            for (ps, _), (fs, _, _) in zip(pos_chains, feat_chains):
+                order += [fs, ps]
+            joint = EagerChainsSampler(order)
+            a.replay = "eager"
+            feat, kp = feat_chains[0][0], feat_chains[0][2].cpu().numpy()
+            sizes = [fs.B for fs, _, _ in feat_chains]
+            P = len(sizes)
+        else:
+            pos_chains = [(pos, torch.zeros(pos.B, dtype=torch.int64, device=dev))]
+            feat_chains = [(f_, torch.full((b,), 4, dtype=torch.int64, device=dev), torch.as_tensor(k_, device=dev))
+                           for (f_, _, k_), b in zip(subs, sizes)]
+        return dict(joint=joint, pos_chains=pos_chains, feat_chains=feat_chains, feat=feat, kp=kp, sizes=sizes, P=P,
+                    pos_mult=pos_mult if a.workload == "default" else 1, cat_desc=cat_desc)
+
+    def adopt(arr):
+        return tuple(arr[k] for k in ("joint", "pos_chains", "feat_chains", "feat", "kp", "sizes", "P", "pos_mult", "cat_desc"))
+
+    joint, pos_chains, feat_chains, feat, kp, sizes, P, pos_mult, cat_desc = adopt(build_arrangement(a.replay))
     rs = np.random.RandomState(rank)
     # chain starts: x_T is drawn ON THE DEVICE (torch's Philox generator; plumbing) and labels / key points are resident,
     # so that a restart inside the timed region costs a few launches, not a host RNG pass + four uploads (round 1's
@@ -444,6 +583,33 @@ def main():
         if use_dist:
             dist.barrier() if share else dist.barrier(device_ids=[local])
 
+    # Host-enqueue calibration (round 6): eager replay needs the host to enqueue ~130 k launches/s per rank; with
+    # N launcher processes on one host that may not hold.  A few untimed steps measure the share of the wall time the host spends
+    # inside the launch calls (MAX over the ranks).  While the GPU paces the run that share is host cost / GPU time (0.45-0.5 on the
+    # boxes measured: 3.2 us per launch, 88 launches, 0.65 ms per step); it approaches 1 when the host does.  Above the limit (0.75;
+    # SLIDE_BENCH_AUTO_REPLAY_SHARE -- graph replay costs ~5 % while the GPU paces, so the switch is made only close to the edge) the
+    # arrangement is rebuilt for graph replay (one hipGraphLaunch per chain and step).  `config.replay` / `config.replay_auto` report
+    # what ran.
+    replay_auto = None
+    if a.replay == "eager" and a.workload == "default" and os.environ.get("SLIDE_BENCH_AUTO_REPLAY", "1") != "0":
+        run(3)
+        sync_all()
+        state["enq"] = 0.0
+        t_c = time.perf_counter()
+        run(12)
+        enq_c = state["enq"]
+        sync_all()
+        share_c = enq_c / max(time.perf_counter() - t_c, 1e-9)
+        if use_dist:
+            tt = torch.tensor([share_c], device=torch.device("cpu") if share else dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            share_c = float(tt.item())
+        limit = float(os.environ.get("SLIDE_BENCH_AUTO_REPLAY_SHARE", "0.75"))
+        replay_auto = {"host_enqueue_share_max_over_ranks": round(share_c, 3), "limit": limit, "switched_to_graph": share_c > limit}
+        if share_c > limit:
+            joint = pos_chains = feat_chains = feat = None  # (free the eager arrangement's buffers first)
+            joint, pos_chains, feat_chains, feat, kp, sizes, P, pos_mult, cat_desc = adopt(build_arrangement("graph"))
+        state["left"] = 0
     # Device priming (round 4, now OPT-IN: SLIDE_BENCH_PRIME=<steps>): a fresh process starts on a cold GPU and the first tens of
     # milliseconds of chain replay run ~5 % slower than steady state.  Round 5 (VERDICT r4 item 8 / ADVICE):
     # the bench does exactly the W warm-up steps the command line asks for; `config.prime_steps` records any opt-in priming.
@@ -499,10 +665,27 @@ def main():
     if chain_ev:
         print("chain ends (ms after its start event; position chain(s) first): %s; wall %.3f ms" %
               (", ".join("%.3f" % e0.elapsed_time(e1) for e0, e1, _ in chain_ev), dt * 1e3), file=sys.stderr)
+    dist_obj = None
     if use_dist:
         tt = torch.tensor([dt], device=gdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # what the process group saw (round 6): its size and backend, every rank's device, every rank's host enqueue
+        # time, and that slot r of the all-gather holds rank r's latents (checksums travel as Python objects beside the tensors)
+        mine = torch.cat([f_.engine.x.reshape(-1, 16, 51) for f_, _, _ in feat_chains], 0)
+        props = torch.cuda.get_device_properties(dev)
+        info = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": int(torch.cuda.current_device()),
+                "device_name": props.name, "device_uuid": str(getattr(props, "uuid", "")),
+                "host_enqueue_ms_per_step": round(host_enq * 1e3 / a.steps, 4), "latent_sum": float(mine.double().sum().item())}
+        infos = [None] * world
+        dist.all_gather_object(infos, info)
+        if rank == 0:
+            order_ok = all(abs(float(gathered[r].double().sum().item()) - infos[r]["latent_sum"]) <= 1e-6 * (1.0 + abs(infos[r]["latent_sum"]))
+                           for r in range(world))
+            dist_obj = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "gather_order_ok": bool(order_ok),
+                        "rank_devices": [[i_["rank"], i_["device"], i_["device_uuid"][-12:]] for i_ in infos],
+                        "host_enqueue_ms_per_step_max": max(i_["host_enqueue_ms_per_step"] for i_ in infos),
+                        "gathered_shapes": int(sum(g_.shape[0] for g_ in gathered))}
     finite = all(bool(torch.isfinite(p_.state()).all().item()) for p_, _ in pos_chains) and \
         all(bool(torch.isfinite(f_.state()).all().item()) for f_, _, _ in feat_chains)
     ms_per_step = dt * 1e3 / a.steps
@@ -525,8 +708,11 @@ def main():
                       # host seconds inside the launch calls of the timed region, per step: close to ms_per_step = the host
                       # (or a full hardware queue it is blocked on) paces the run, far below = the GPU does
                       "host_enqueue_ms_per_step": round(host_enq * 1e3 / a.steps, 4),
+                      "replay_auto": replay_auto,  # host-enqueue calibration: share measured before the run, whether it switched to graph replay
                       "prime_steps": prime,  # untimed device priming before the --warmup steps (set-up; see bench.py)
                       "finite": finite}}
+    if dist_obj is not None:
+        out["dist"] = dist_obj
     if cat_desc is not None:
         out["config"]["workload"] = ("BASELINE configs[3]: five-category run (labels 0, 2, 3, 4, 6; one position + one feature weight set "
                                      "per category), %d shapes sharded contiguously over %d GPU(s), %d per GPU; 1 step = one reverse step "
@@ -609,6 +795,12 @@ def main():
     if rank == 0 and not a.no_parity:
         out["parity"] = parity_obj if parity_obj is not None else parity_leg(dev, B, a, pc, fc, sd_p, sd_f, gen)
         out["parity"]["measured"] = "before the timed region" if parity_obj is not None else "after the timed region"
+    if rank == 0 and world == 1 and not a.no_configs and a.workload == "default" and a.prec == "fp16":
+        try:
+            out["configs"] = configs_leg(dev, B, a, pc, fc, sd_p, sd_f, gen, feat_chains, pos_chains[0][0])
+            out["configs"]["config5_decode"] = "see `decode` (BASELINE configs[4]: the CLIs' default arithmetic)"
+        except Exception as ex:  # (a reporting leg must not take the headline down with it)
+            out["configs"] = {"error": repr(ex)[:300]}
     if rank == 0 and not a.no_decode and a.workload == "default":
         out["decode"] = decode_leg(dev, B)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

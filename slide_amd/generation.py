@@ -241,6 +241,15 @@ class CategoryChains:
             ps, fs = self._make_chain(pos_cfg, feat_cfg, sd_p, sd_f, hi - lo, prec, seed, seed)
             self.chains.append((c, lo, hi, ps, fs))
         self.seed = int(seed)
+        # The GPU runs four hardware queues; the runtime maps streams onto them in creation / first-use order, and two busy chains on
+        # one queue serialise while another queue may sit idle (DESIGN.md section 9 item 5a').  With more than two segments (five
+        # categories: ten chains) the chains are therefore laid onto FOUR streams explicitly -- feature chain k on stream k mod 4,
+        # position chain k on stream (k + 2) mod 4: at most two feature chains per stream, deterministic from run to run.
+        if len(self.chains) > 2:
+            pool = [self.chains[0][4].stream, self.chains[0][3].stream, self.chains[1][4].stream, self.chains[1][3].stream]
+            for k, (_, _, _, ps, fs) in enumerate(self.chains):
+                fs.stream = fs.stream2 = pool[k % 4]
+                ps.stream = ps.stream2 = pool[(k + 2) % 4]
 
     def _make_chain(self, pos_cfg, feat_cfg, sd_p, sd_f, n, prec, seed_p, seed_f):
         from .diffusion import FeatureSampler, PositionSampler
