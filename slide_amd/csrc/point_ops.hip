@@ -221,44 +221,120 @@ __global__ __launch_bounds__(1024) void fps_kernel_large(int n, int m, int bs, i
   }
 }
 
+// ---------------------------------------------------------------------------------------------- search kernels: block map
+// XCD-aware (batch element, query tile) map of the search kernels (round 6; VERDICT r5 item 9: ball_query moved 6.5x its algorithmic
+// bytes at n = 8192).  Every workgroup of a batch element streams that element's WHOLE search set; consecutive workgroup ids go to
+// consecutive XCDs (MI355X_MICROARCH.md: block b runs on XCD b % 8 -- relied on for speed only), so with a (tile, b) grid the eight
+// query tiles of an element ran on eight XCDs and each private L2 fetched the set once more.  Here the grid is linear and id L ->
+// XCD L % 8 takes the elements b = 8 k + L % 8: all query tiles of an element run on ONE XCD and its set is fetched once.
+struct SearchBlock { int b, tile; bool valid; };
+__device__ __forceinline__ SearchBlock search_block(int nb, int tiles) {
+  const int L = blockIdx.x, x = L & 7, q = L >> 3;
+  SearchBlock r;
+  r.tile = q % tiles;
+  r.b = (q / tiles) * 8 + x;
+  r.valid = r.b < nb;
+  return r;
+}
+static inline unsigned search_grid(int nb, int tiles) { return (unsigned)(8 * ((nb + 7) / 8) * tiles); }
+
 // ---------------------------------------------------------------------------------------------- ball query
-// ball_query_gpu.cu:9-47: one thread per query, search set staged through LDS in tiles.
-constexpr int BQ_TILE = 1024;
-__global__ __launch_bounds__(256) void ball_query_kernel(int n, int m, float radius2, int nsample,
+// ball_query_gpu.cu:9-47
+constexpr int BQ_TILE = 1024;  // (three_nn's LDS tile)
+// WAVEFRONT SCAN (round 6).  Rounds 1-5 ran one THREAD per query over LDS-broadcast points: a wave ran until its slowest query was
+// done, and a query's nsample result slots -- 4 nsample contiguous bytes -- were written one at a time, hits apart, so every store
+// instruction touched 4 bytes of 64 different lines and a line left the L2 half-written many times (4.8x the algorithmic bytes at
+// n = 8192, profiles/r05_ops_roofline.md).  Here a WAVE owns 64 queries and walks the search set in chunks of 256 points held in
+// REGISTERS (four points per lane, loaded coalesced; no LDS, no workgroup barrier): for every unfinished query the chunk is
+// evaluated in four 64-wide steps against the query's coordinates (scalar registers), the hits of a step are ranked by a ballot
+// prefix count and written side by side, and a query leaves the scan the step its ball is full.  A wave's 64 queries keep their
+// state (coordinates, count, first hit) in the lanes of five registers.  Same result as the reference's sequential scan
+// (ball_query_gpu.cu:25-46): hits in index order, the first hit in every unused slot, zero rows / zero counts for empty balls (the
+// host wrapper zero-fills idx and counts).
+// STAGED (nsample <= 32, n < 65536): a query's hits arrive spread over the whole scan, so written in place its row of idx would leave
+// the L2 half-written again and again; the wave builds its 64 x nsample block in LDS as 16-bit indices (4 KB: eight workgroups per
+// CU as without it -- 32-bit staging at five per CU measured 20 % slower) and stores it once, coalesced, at the end.
+constexpr int BQ_PPL = 4;  // points per lane and chunk
+template <bool STAGED>
+__global__ __launch_bounds__(256) void ball_query_kernel(int nb, int n, int m, float radius2, int nsample,
                                                          const float *__restrict__ new_xyz,
                                                          const float *__restrict__ xyz, int *__restrict__ idx,
                                                          int *__restrict__ counts) {
-  __shared__ float tile[BQ_TILE * 3];
-  const int b = blockIdx.y;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const SearchBlock sb = search_block(nb, (m + 255) / 256);
+  if (!sb.valid) return;
+  const int b = sb.b, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q0 = sb.tile * 256 + wave * 64;  // this wave's queries q0 .. q0 + 63; lane i keeps the state of query q0 + i
+  const int nq = min(64, m - q0);
+  if (nq <= 0) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned short bq_stage[];  // STAGED: [4 waves][64 queries][nsample]
+  unsigned short *const stg = bq_stage + wave * 64 * nsample;
+  if (STAGED)
+    for (int e = lane; e < 64 * nsample; e += 64) stg[e] = 0;  // (wave-private: no barrier, LDS operations of a wave are in order)
   xyz += (size_t)b * n * 3;
-  const bool active = j < m;
-  float nx = 0.f, ny = 0.f, nz = 0.f;
-  int *oi = idx + ((size_t)b * m + (active ? j : 0)) * nsample;
-  if (active) {
-    const float *q = new_xyz + ((size_t)b * m + j) * 3;
-    nx = q[0]; ny = q[1]; nz = q[2];
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  if (lane < nq) {
+    const float *q = new_xyz + ((size_t)b * m + q0 + lane) * 3;
+    qx = q[0]; qy = q[1]; qz = q[2];
   }
-  int cnt = 0;
-  for (int t0 = 0; t0 < n; t0 += BQ_TILE) {
-    const int tn = min(BQ_TILE, n - t0);
-    __syncthreads();
-    for (int i = threadIdx.x; i < tn * 3; i += blockDim.x) tile[i] = xyz[(size_t)t0 * 3 + i];
-    __syncthreads();
-    if (active && cnt < nsample) {
-      for (int k = 0; k < tn && cnt < nsample; ++k) {
-        const float d2 = sqdist3(nx, ny, nz, tile[k * 3 + 0], tile[k * 3 + 1], tile[k * 3 + 2]);
-        if (d2 < radius2) {
-          const int kk = t0 + k;
-          if (cnt == 0)
-            for (int l = 0; l < nsample; ++l) oi[l] = kk;
-          oi[cnt] = kk;
-          ++cnt;
-        }
+  int cntv = lane < nq ? 0 : nsample, firstv = 0;  // (lanes without a query count as full)
+  for (int k0 = 0; k0 < n; k0 += 64 * BQ_PPL) {
+    if (__ballot(cntv < nsample) == 0) break;  // every ball of this wave is full
+    float px[BQ_PPL], py[BQ_PPL], pz[BQ_PPL];
+#pragma unroll
+    for (int u = 0; u < BQ_PPL; ++u) {
+      const int k = k0 + u * 64 + lane;
+      const float *c = xyz + (size_t)(k < n ? k : n - 1) * 3;
+      px[u] = c[0]; py[u] = c[1]; pz[u] = c[2];
+    }
+    for (int i = 0; i < nq; ++i) {
+      int cnt = __builtin_amdgcn_readlane(cntv, i);
+      if (cnt >= nsample) continue;
+      const float nx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qx), i));
+      const float ny = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qy), i));
+      const float nz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qz), i));
+      bool hit[BQ_PPL];
+      unsigned long long mask[BQ_PPL], any = 0;
+#pragma unroll
+      for (int u = 0; u < BQ_PPL; ++u) {
+        hit[u] = k0 + u * 64 + lane < n && sqdist3(nx, ny, nz, px[u], py[u], pz[u]) < radius2;
+        mask[u] = __ballot(hit[u]);
+        any |= mask[u];
       }
+      if (any == 0) continue;
+      int first = __builtin_amdgcn_readlane(firstv, i);
+      int *const oi = idx + ((size_t)b * m + q0 + i) * nsample;
+      unsigned short *const os = stg + i * nsample;
+#pragma unroll
+      for (int u = 0; u < BQ_PPL; ++u) {
+        if (mask[u] == 0 || cnt >= nsample) continue;
+        if (cnt == 0) first = k0 + u * 64 + (int)__builtin_ctzll(mask[u]);
+        const int r = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask[u], 0u));
+        if (hit[u] && r < nsample) {
+          if (STAGED) os[r] = (unsigned short)(k0 + u * 64 + lane);
+          else oi[r] = k0 + u * 64 + lane;
+        }
+        cnt += (int)__builtin_popcountll(mask[u]);
+      }
+      cnt = cnt < nsample ? cnt : nsample;
+      cntv = lane == i ? cnt : cntv;
+      firstv = lane == i ? first : firstv;
     }
   }
-  if (active && cnt > 0) counts[(size_t)b * m + j] = cnt;
+  if (lane < nq && cntv > 0) counts[(size_t)b * m + q0 + lane] = cntv;
+  // the unused slots of a non-empty ball repeat its first hit
+  for (int i = 0; i < nq; ++i) {
+    const int cnt = __builtin_amdgcn_readlane(cntv, i), first = __builtin_amdgcn_readlane(firstv, i);
+    if (cnt == 0 || cnt >= nsample) continue;
+    int *const oi = idx + ((size_t)b * m + q0 + i) * nsample;
+    for (int l = cnt + lane; l < nsample; l += 64) {
+      if (STAGED) stg[i * nsample + l] = (unsigned short)first;
+      else oi[l] = first;
+    }
+  }
+  if (STAGED) {
+    int *const ob = idx + ((size_t)b * m + q0) * nsample;
+    for (int e = lane; e < nq * nsample; e += 64) ob[e] = (int)stg[e];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- grouping
@@ -352,12 +428,14 @@ __global__ __launch_bounds__(256) void group_points_grad_kernel(int c, int n, in
 
 // ---------------------------------------------------------------------------------------------- three_nn
 // interpolate_gpu.cu:9-59.  (double 1e40 bests == +inf in float for every comparison that can occur.)
-__global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float *__restrict__ unknown,
+__global__ __launch_bounds__(256) void three_nn_kernel(int nb, int n, int m, const float *__restrict__ unknown,
                                                        const float *__restrict__ known,
                                                        float *__restrict__ dist2, int *__restrict__ idx) {
-  __shared__ float tile[BQ_TILE * 3];
-  const int b = blockIdx.y;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float4 tile[BQ_TILE];
+  const SearchBlock sb = search_block(nb, (n + 255) / 256);
+  if (!sb.valid) return;
+  const int b = sb.b;
+  const int j = sb.tile * blockDim.x + threadIdx.x;
   known += (size_t)b * m * 3;
   const bool active = j < n;
   float ux = 0.f, uy = 0.f, uz = 0.f;
@@ -370,11 +448,15 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float
   for (int t0 = 0; t0 < m; t0 += BQ_TILE) {
     const int tn = min(BQ_TILE, m - t0);
     __syncthreads();
-    for (int i = threadIdx.x; i < tn * 3; i += blockDim.x) tile[i] = known[(size_t)t0 * 3 + i];
+    for (int i = threadIdx.x; i < tn; i += blockDim.x) {
+      const float *c = known + (size_t)(t0 + i) * 3;
+      tile[i] = make_float4(c[0], c[1], c[2], 0.f);
+    }
     __syncthreads();
     if (active) {
       for (int k = 0; k < tn; ++k) {
-        const float d = sqdist3(ux, uy, uz, tile[k * 3 + 0], tile[k * 3 + 1], tile[k * 3 + 2]);
+        const float4 c = tile[k];
+        const float d = sqdist3(ux, uy, uz, c.x, c.y, c.z);
         const int kk = t0 + k;
         if (d < best1) {
           best3 = best2; besti3 = besti2;
@@ -584,7 +666,7 @@ __device__ __forceinline__ void knn_bitonic_merge(double (&a)[N]) {  // a bitoni
 }
 
 template <int NT, int KT>
-__global__ __launch_bounds__(NT) void knn_key_kernel(int n1, int n2, int K, const float *__restrict__ p1,
+__global__ __launch_bounds__(NT) void knn_key_kernel(int nb, int n1, int n2, int K, const float *__restrict__ p1,
                                                      const float *__restrict__ p2,
                                                      const int64_t *__restrict__ lengths2,
                                                      float *__restrict__ dists, int64_t *__restrict__ idx) {
@@ -592,8 +674,10 @@ __global__ __launch_bounds__(NT) void knn_key_kernel(int n1, int n2, int K, cons
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float4 *tile = reinterpret_cast<float4 *>(smem);                     // KNN_TILE points (x, y, z, -)
   double *queue = reinterpret_cast<double *>(smem + KNN_TILE * 4);      // [KNN_Q + 1][NT] keys
-  const int b = blockIdx.y, tid = threadIdx.x;
-  const int i = blockIdx.x * NT + tid;
+  const SearchBlock sb = search_block(nb, (n1 + NT - 1) / NT);
+  if (!sb.valid) return;
+  const int b = sb.b, tid = threadIdx.x;
+  const int i = sb.tile * NT + tid;
   p2 += (size_t)b * n2 * 3;
   const int len2 = lengths2 ? (int)lengths2[b] : n2;
   const bool active = i < n1;
@@ -673,7 +757,7 @@ __global__ __launch_bounds__(NT) void knn_key_kernel(int n1, int n2, int K, cons
   for (int p = 0; p < KT; ++p)
     if (p < K) ol[p * (NT + 1) + tid] = L[p];
   __syncthreads();
-  const int q0 = blockIdx.x * NT;
+  const int q0 = sb.tile * NT;
   const int nq = min(NT, n1 - q0);
   const int cnt = len2 < K ? len2 : K;
   float *const od = dists + ((size_t)b * n1 + q0) * K;
@@ -846,8 +930,12 @@ int query_ball_point_kernel_wrapper(int b, int n, int m, float radius, int nsamp
                                     const float *xyz, int *idx, int *counts, slide_stream_t stream) {
   if (b <= 0 || m <= 0) return 0;
   const float radius2 = radius * radius;
-  hipLaunchKernelGGL(ball_query_kernel, dim3((m + 255) / 256, b), dim3(256), 0, (hipStream_t)stream, n, m,
-                     radius2, nsample, new_xyz, xyz, idx, counts);
+  if (nsample <= 32 && n < 65536)
+    hipLaunchKernelGGL(ball_query_kernel<true>, dim3(search_grid(b, (m + 255) / 256)), dim3(256), (size_t)nsample * 512,
+                       (hipStream_t)stream, b, n, m, radius2, nsample, new_xyz, xyz, idx, counts);
+  else
+    hipLaunchKernelGGL(ball_query_kernel<false>, dim3(search_grid(b, (m + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b, n, m,
+                       radius2, nsample, new_xyz, xyz, idx, counts);
   return LAUNCH_STATUS();
 }
 
@@ -940,7 +1028,7 @@ __global__ __launch_bounds__(256) void three_interpolate_rows_kernel(int c, int 
 int three_nn_kernel_wrapper(int b, int n, int m, const float *unknown, const float *known, float *dist2,
                             int *idx, slide_stream_t stream) {
   if (b <= 0 || n <= 0) return 0;
-  hipLaunchKernelGGL(three_nn_kernel, dim3((n + 255) / 256, b), dim3(256), 0, (hipStream_t)stream, n, m,
+  hipLaunchKernelGGL(three_nn_kernel, dim3(search_grid(b, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b, n, m,
                      unknown, known, dist2, idx);
   return LAUNCH_STATUS();
 }
@@ -1002,9 +1090,9 @@ int slide_knn_points(int b, int n1, int n2, int K, const float *p1, const float 
   if (K > 64) return -2;
   hipStream_t s = (hipStream_t)stream;
 #define KNN_KEY(NT, KT)                                                                                  \
-  hipLaunchKernelGGL((knn_key_kernel<NT, KT>), dim3((n1 + NT - 1) / NT, b), dim3(NT),                      \
+  hipLaunchKernelGGL((knn_key_kernel<NT, KT>), dim3(search_grid(b, (n1 + NT - 1) / NT)), dim3(NT),         \
                      (size_t)KNN_TILE * 16 + (size_t)((knn_queue_slots(KT) + 1) * NT > KT * (NT + 1) ? (knn_queue_slots(KT) + 1) * NT : KT * (NT + 1)) * 8, \
-                     s, n1, n2, K, p1, p2, lengths2, dists, idx)
+                     s, b, n1, n2, K, p1, p2, lengths2, dists, idx)
   // few queries per sample: 64-thread workgroups keep more of them on different compute units
   if (n1 > 64) {
     if (K <= 4) KNN_KEY(256, 4); else if (K <= 8) KNN_KEY(256, 8); else if (K <= 16) KNN_KEY(256, 16);

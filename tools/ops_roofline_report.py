@@ -62,7 +62,12 @@ for i, c in enumerate(man):
     if "selections" in c:
         note = "%.2f us / selection" % (us / c["selections"])
     if "physical_read_B" in c:
-        note = "rows touched: %.0f MB" % (c["physical_read_B"] / 1e6)
+        # (B, C, N) layout: a touched element costs its whole 64-byte sector, and with m >= n / 4 picked columns nearly every sector of a
+        # channel row holds one -- the kernel cannot move fewer bytes than the rows it touches + what it writes (the LAYOUT FLOOR);
+        # `frac` on algorithmic bytes is bounded by algorithmic / floor whatever the kernel does
+        floor = c["physical_read_B"] + c["write_B"]
+        note = "layout floor %.0f MB (rows touched %.0f + written): %.2f of 8 TB/s on it; algorithmic frac <= %.2f" % (
+            floor / 1e6, c["physical_read_B"] / 1e6, floor / us / 1e3 / 8000.0, alg / floor)
     gbs = alg / us / 1e3
     moved = "-" if traffic is None else "%.0f (%.2f)" % (traffic / us * 1e3, traffic / us / 8.0)
     lines.append("| %s | %s | `%s` | %.1f | %.1f | %.0f | %.3f | %s | %s | %s |" % (c["op"], c["shape"], name, us, alg / 1e6, gbs, gbs / 8000.0,
