@@ -157,6 +157,15 @@ enum {
                              * Mlp (first_mlp + res_connect, second_mlp + fc_condition + residual: pointnet2_modules.py:119-176, :842-855) and the
                              * output head fc_lyaer (pointnet2_with_pcld_condition.py:480-483), four dependent 16-rows-per-sample GEMMs; writes
                              * the prediction eps.  p[0] = HOST pointer to a SlidePointChainArgs block */
+  SLIDE_OP_GEMM_ATTEND = 38,/* round 6 (module-level path, fp16 rows): the score convolution of an AttentionModule (weight_conv's last conv,
+                             * reference pointnet2_ops attention.py:86-95), the soft-max over the K neighbour rows of each point and the weighted
+                             * sum of the value rows in ONE launch -- the score map never reaches memory (SLIDE_OP_GEMM + SLIDE_OP_ROWS_ATTN
+                             * stored it and read it back).  p: [0] X fp16 [rows][x_ld], [1] W fp16 [n_cob*32][k_pad], [2] epi (bias only),
+                             * [3] in_scale, [4] in_shift (deferred normalisation of X as for SLIDE_OP_GEMM, or NULL), [5] V fp16 [rows][ldv],
+                             * [6] out fp16 [rows / K][ldo], [7] counts int32 [rows / K] or NULL, [8] vss fp32 [sample][2][ldv] (deferred
+                             * normalisation of V) or NULL, [11] add vectors of X's deferred step.  i: rows, x_ld, k_pad, n_cob, K (4 | 8 | 16 | 32),
+                             * in_bs, ldv, ldo, points per sample, ReLU after V's affine, C (logical channels).  f: [1] 256-row tiles per sample,
+                             * [2] add_bs, [3] 2 * add_n + relu (X's deferred step, as SLIDE_OP_GEMM) */
   SLIDE_OP_HEAD_UPDATE = 33,/* output head (two per-point GEMMs with the GroupNorm between them) + DDPM update + device-side t -= 1 as one launch
                              * (csrc/engine.hip head_update_kernel): p[0] = HOST pointer to a SlideHeadArgs block */
   SLIDE_OP_BLOCK_BODY = 30, /* the whole K-expanded body of an SA / FP block whose widths are <= 256 channels in one launch (csrc/block_body.hip):

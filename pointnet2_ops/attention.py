@@ -95,19 +95,21 @@ class AttentionModule(nn.Module):
                 R.norm_act(tot, wc[1].group_norm, defer=True)  # (both normalisations are applied by the GEMMs that follow)
                 u = R.conv(tot, wc[2], stats="relu")
             R.norm_act(u, wc[4].group_norm, pre_relu=True, defer=True)
-            scores = R.conv(u, wc[5])
+            score_conv = wc[5]
         else:
             tot = R.concat_qk(R.conv(query, self.feat_conv), R.conv(grouped, self.grouped_feat_conv), K)  # wc[0]: ReLU
             u = R.conv(tot, wc[1])
             R.norm_act(u, relu=True)
-            scores = R.conv(u, wc[3])
+            score_conv = wc[3]
         values = grouped_out
         if self.transform_grouped_feat_out:
             layers = list(self.feat_out_conv)
             gn = next((l.group_norm for l in layers[1:] if isinstance(l, MyGroupNorm)), None)
             values = R.conv(grouped_out, layers[0], stats="raw" if gn is not None else None)
             R.norm_act(values, gn, relu=any(isinstance(l, nn.ReLU) for l in layers[1:]), defer=True)  # applied by attend()
-        return R.attend(scores, values, K, counts)
+        # the score convolution, the soft-max over the neighbours and the weighted sum of the values: one launch where the rows allow
+        # it (fp16 rows, K in 4 .. 32: SLIDE_OP_GEMM_ATTEND, the score map stays on chip), else GEMM -> stored scores -> attend()
+        return R.conv_attend(u, score_conv, values, K, counts)
 
     def forward(self, feat, grouped_feat, grouped_feat_out, count):
         """feat (B, C_in1, np), grouped_feat (B, C_in2, np, K), grouped_feat_out (B, C_out, np, K), count (B, np) or

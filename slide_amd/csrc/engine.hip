@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256, 3) void gemm_split_small_kernel(GemmArgs a) {
 // WC = 1: four waves, tile 256 rows x 32*CBW channels.  WC = 2: eight waves, tile 256 rows x 64*CBW channels -- wave
 // (wr, wc) owns rows 64*wr.. and channel half wc, so the X chunk is fetched once per 64*CBW channels (less L2 -> LDS
 // traffic per MAC, half as many prologues); each channel half runs the 4-wave epilogue on its own LDS tables.
-template <int NPXL, int CBW, int NST, int BKT, bool AFF, int WC = 1, bool GAT = false, bool PAIRRES = false>
+template <int NPXL, int CBW, int NST, int BKT, bool AFF, int WC = 1, bool GAT = false, bool PAIRRES = false, bool ATTN = false>
 __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem_raw, const int tr, const int tc) {
   using T = _Float16;
   constexpr int NW = 4 * WC, NT = 256 * WC;  // waves, threads
@@ -607,9 +607,12 @@ __device__ __forceinline__ void glds_tile(const GemmArgs &a, unsigned char *smem
   __syncthreads();  // every wave is done with the tiles before `red` reuses them
   SLIDE_STAMP(a, 2);
 
-  gemm_epilogue<SLIDE_PREC_F16, NPXL, CBW, 2, PAIRRES>(a, acc, row0, cob0 + wc * CBW, wave, half, col, epi_lds + wc * CBW * EPI_DW,
-                                           vec_lds + wc * CBW * 96,
-                                           reinterpret_cast<float *>(smem_raw) + wc * (256 + 128) * CBW);
+  if constexpr (ATTN)
+    attend_epilogue<CBW>(a, acc, row0, cob0, wave, half, col, vec_lds, reinterpret_cast<float *>(smem_raw));
+  else
+    gemm_epilogue<SLIDE_PREC_F16, NPXL, CBW, 2, PAIRRES>(a, acc, row0, cob0 + wc * CBW, wave, half, col, epi_lds + wc * CBW * EPI_DW,
+                                             vec_lds + wc * CBW * 96,
+                                             reinterpret_cast<float *>(smem_raw) + wc * (256 + 128) * CBW);
   SLIDE_STAMP(a, 5);
 #ifdef SLIDE_TIMELINE
   if (a.dbg) {
@@ -686,6 +689,20 @@ __global__ __launch_bounds__(256, 3) void gemm_glds_occ3_kernel(GemmArgs a) {
   const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;
   if (tr >= ntr) return;
   glds_tile<NPXL, 2, 2, 32, AFF, 1, GAT, PAIRRES>(a, smem_raw, tr, tc);
+}
+
+// SLIDE_OP_GEMM_ATTEND (round 6): the 256 x 64 ring tile with the ATTEND epilogue (gemm_common.h) -- the score GEMM of an
+// AttentionModule of the module-level path, its soft-max over the neighbours and the weighted sum of the values in one launch
+// (two-stage ring and 126 registers: three workgroups per CU, as gemm_glds_occ3_kernel -- the launch is HBM-bound)
+template <bool AFF>
+__global__ __launch_bounds__(256, 3) void gemm_attend_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int ntc = (a.n_cob + 1) / 2;
+  const int ntr = (a.rows + TM - 1) / TM;
+  const int xcd = blockIdx.x & 7, q0 = blockIdx.x >> 3;
+  const int tc = q0 % ntc, tr = (q0 / ntc) * 8 + xcd;
+  if (tr >= ntr) return;
+  glds_tile<8, 2, 2, 32, AFF, 1, false, false, true>(a, smem_raw, tr, tc);
 }
 
 // eight-wave variant (one tile per workgroup, one workgroup per CU: its deeper ring needs the LDS of two)
@@ -2183,6 +2200,49 @@ int launch_gemm_small(const GemmArgs &a, hipStream_t s) {
   return a.in_scale ? launch_gemm_small_t<2, true>(a, s) : launch_gemm_small_t<2, false>(a, s);
 }
 
+template <bool AFF>
+int launch_gemm_attend(const GemmArgs &a, hipStream_t s) {
+  const size_t shm = (size_t)2 * (TM + 64) * 32 * 2 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32 + (AFF ? (size_t)3 * a.k_pad * 2 : 0);
+  if (shm > 53 * 1024) return -8;  // three workgroups per CU must fit
+  const int ntc = (a.n_cob + 1) / 2, ntr = (a.rows + TM - 1) / TM;
+  const int grid = ((ntr + 7) / 8) * 8 * ntc;
+  GemmArgs b = a;
+  b.shm_bytes = (int)((shm + 15) & ~(size_t)15);
+  b.sched = nullptr;
+  static bool attr_done[SLIDE_MAX_DEVICES] = {};
+  bool &attr_set = attr_done[current_device_slot()];
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_attend_kernel<AFF>), hipFuncAttributeMaxDynamicSharedMemorySize, 53 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_attend_kernel<AFF>), dim3(grid), dim3(256), (size_t)b.shm_bytes, s, b);
+  return (int)hipGetLastError();
+}
+
+// SLIDE_OP_GEMM_ATTEND (include/slide_engine.h)
+int run_gemm_attend(const SlideOp &o, hipStream_t s) {
+  GemmArgs a = GemmArgs();
+  a.X = o.p[0]; a.W = o.p[1]; a.epi = (const SlideEpi *)o.p[2];
+  a.in_scale = (const float *)o.p[3]; a.in_shift = (const float *)o.p[4];
+  a.aff_tps = 1;
+  if (a.in_scale) {
+    a.in_add = (const float *)o.p[11];
+    a.aff_tps = (int)o.f[1] > 1 ? (int)o.f[1] : 1;
+    a.add_bs = (int)o.f[2];
+    a.add_n = (int)o.f[3] >> 1;
+    a.aff_relu = (int)o.f[3] & 1;
+  }
+  a.at_V = o.p[5]; a.at_out = o.p[6]; a.at_counts = (const int *)o.p[7]; a.at_vss = (const float *)o.p[8];
+  a.rows = o.i[0]; a.x_ld = o.i[1]; a.k_pad = o.i[2]; a.n_cob = o.i[3]; a.in_bs = o.i[5];
+  const int K = o.i[4];
+  a.at_ldv = o.i[6]; a.at_ldo = o.i[7]; a.at_pps = o.i[8] > 0 ? o.i[8] : 1; a.at_vrelu = o.i[9]; a.at_C = o.i[10];
+  a.at_klog2 = K == 4 ? 2 : K == 8 ? 3 : K == 16 ? 4 : K == 32 ? 5 : -1;
+  if (a.at_klog2 < 0 || a.rows <= 0 || a.rows % K || a.k_pad % BK || a.x_ld % 8 || a.n_cob <= 0 || !a.X || !a.W || !a.epi || !a.at_V ||
+      !a.at_out || a.at_ldv % 4 || a.at_ldo % 4 || a.at_ldv < a.n_cob * 32 || a.at_ldo < a.n_cob * 32 || (a.in_scale && !a.in_shift))
+    return -3;
+  return a.in_scale ? launch_gemm_attend<true>(a, s) : launch_gemm_attend<false>(a, s);
+}
+
 int run_gemm(const SlideOp &o, hipStream_t s) {
   GemmArgs a;
   a.X = o.p[0]; a.W = o.p[1]; a.epi = (const SlideEpi *)o.p[2];
@@ -2550,6 +2610,8 @@ int run_op(const SlideOp &o, hipStream_t s) {
 #endif
     case SLIDE_OP_POINT_CHAIN:
       return slide_launch_point_chain(o, s);
+    case SLIDE_OP_GEMM_ATTEND:
+      return run_gemm_attend(o, s);
     case SLIDE_OP_ATTN_TAIL:
       return ((int)o.f[1] & 8) ? slide_launch_attn_tail_split(o, s) : run_attn_tail(o, s);
     case SLIDE_OP_GEMM_GX:

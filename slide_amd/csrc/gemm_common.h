@@ -51,6 +51,13 @@ struct GemmArgs {
   const void *ch_W;
   const SlideEpi *ch_epi;
   int ch_n_cob, ch_k_pad;
+  // ATTEND epilogue (round 6, module-level path; SLIDE_OP_GEMM_ATTEND): this GEMM's output is the score map of an AttentionModule --
+  // instead of being stored it is soft-maxed over the K neighbour rows of each point and contracted with the value rows
+  const void *at_V;          // values [rows][at_ldv] fp16
+  void *at_out;              // out [rows / K][at_ldo] fp16
+  const float *at_vss;       // deferred normalisation of the values: [sample][scale | shift][at_ldv] fp32, or NULL
+  const int *at_counts;      // [rows / K] or NULL: only the first max(1, count) neighbour slots of a point take part
+  int at_ldv, at_ldo, at_klog2, at_pps, at_vrelu, at_C;
 };
 
 // SLIDE_OP_PAIR_FIRST (pair_first_kernel, engine.hip): what the pair-table epilogue reads beside the GEMM arguments
@@ -167,6 +174,69 @@ __device__ __forceinline__ void stage_epilogue_tables(const GemmArgs &a, int cob
       if (src) val = src[c];
     }
     vec_lds[i] = val;
+  }
+}
+
+// ATTEND epilogue (round 6; SLIDE_OP_GEMM_ATTEND, module-level path): the accumulators are the SCORE map of an AttentionModule
+// (weight_conv's last convolution; reference pointnet2_ops attention.py:86-95: softmax(dim=-1) over the K neighbours, weighted sum of
+// the values).  Per 32-channel block the workgroup's 256 x 32 scores (+ bias) go through LDS (the dead ring: [row][33] floats) so that
+// a thread owns (point, channel) and walks the point's K = 4 .. 32 neighbour rows -- the arithmetic of rows_attn_kernel (rows_ops.hip:
+// maximum, exponentials, normalised weighted sum over the first max(1, count) slots; the values' deferred GroupNorm + ReLU applied on
+// load) on fp32 scores that never reach memory: the unfused path stored the score map in fp16 and read it back beside the values,
+// 2 x rows x C x 2 B per attention block.  (A first version reduced over the lanes of the C layout with DPP: 15 cross-lane steps per
+// channel register made the launch 2.4x the plain GEMM's time.)
+template <int CBW>
+__device__ __forceinline__ void attend_epilogue(const GemmArgs &a, f32x16 (&acc)[CBW][2], int row0, int cob0, int wave, int half,
+                                                int col, const float *vec_lds, float *stile) {
+  using T = _Float16;
+  const int lg = a.at_klog2, K = 1 << lg, tid = threadIdx.x;
+  const GLOBAL_AS T *V = gptr<const T>((uint64_t)a.at_V);
+  GLOBAL_AS T *out = gptr<T>((uint64_t)a.at_out);
+  const int c = tid & 31;
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb) {
+    const int cobi = cob0 + cb;
+    if (cobi >= a.n_cob) break;  // uniform per workgroup
+    if (cb) __syncthreads();     // the previous block's reads are done
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = (r & 3) + 8 * (r >> 2) + 4 * half;
+        stile[(wave * 64 + rb * 32 + col) * 33 + ch] = acc[cb][rb][r] + vec_lds[cb * 96 + ch];
+      }
+    __syncthreads();
+    const int cg = cobi * 32 + c;  // this thread's channel
+    for (int p = tid >> 5; p < (TM >> lg); p += 8) {
+      const int r0 = row0 + (p << lg);
+      if (r0 >= a.rows) break;
+      const int pt = r0 >> lg;
+      int kk = K;
+      if (a.at_counts) { kk = a.at_counts[pt]; kk = kk < 1 ? 1 : (kk > K ? K : kk); }
+      float vs = 1.f, vh = 0.f;
+      if (a.at_vss) {
+        const int smp = pt / a.at_pps;
+        vs = a.at_vss[((size_t)smp * 2 + 0) * a.at_ldv + cg];
+        vh = a.at_vss[((size_t)smp * 2 + 1) * a.at_ldv + cg];
+      }
+      const float *sp = stile + (p << lg) * 33 + c;
+      const GLOBAL_AS T *vp = V + (size_t)r0 * a.at_ldv + cg;
+      float m = -INFINITY;
+      for (int k = 0; k < kk; ++k) m = fmaxf(m, sp[k * 33]);
+      float l = 0.f, n = 0.f;
+#pragma unroll 4
+      for (int k = 0; k < kk; ++k) {
+        float v = (float)vp[(size_t)k * a.at_ldv];
+        if (a.at_vss) {
+          v = v * vs + vh;
+          if (a.at_vrelu) v = fmaxf(v, 0.f);
+        }
+        const float e = __expf(sp[k * 33] - m);
+        l += e;
+        n = fmaf(e, v, n);
+      }
+      out[(size_t)pt * a.at_ldo + cg] = (T)(cg < a.at_C ? n / l : 0.f);
+    }
   }
 }
 

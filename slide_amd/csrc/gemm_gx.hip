@@ -18,6 +18,8 @@
 // In the SA blocks every point is a neighbour of every point (K = N = 16) and everything downstream (GroupNorm statistics,
 // softmax-weighted sum over the neighbours) is invariant to the neighbour ORDER, so rows run in natural order (q = j): no
 // index table, and the a-fragment is shared by all row blocks of a wave.
+#include <cstdlib>
+
 #include "gemm_common.h"
 #include "gemm_small.h"
 #include "pair_norm.h"
@@ -677,6 +679,7 @@ struct F1Args {
   unsigned long long *dbg;
   int B, t_ld, k1, n1, n2, gs1, gs2, add0_stride, add0_bs, add1_bs;
   float inv1, inv2;
+  int nsplit;  // round 6: workgroups per sample (1 | 2): each takes n2 / 256 / nsplit of the stage-2 slabs (stage 1 is computed by all)
 };
 
 // sum over the 32 lanes of a half wave; the total is valid in the half's UPPER 16 lanes (col >= 16).  Pure DPP: four steps
@@ -703,10 +706,13 @@ __device__ __forceinline__ void sa_chain_body(const F1Args &a, const int bid) {
   constexpr int CH_B = 256 * 64, STAGE_B = 2 * CH_B, NST = 2;
   constexpr int NR = 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int b = bid;
+  // SLAB SPLIT (round 6): with few samples per launch (one 8-wave workgroup per sample: 88 of 256 CUs at bench.py's sub-batch size)
+  // a sample's stage-2 slabs go to nsplit workgroups -- each repeats stage 1 (a third of the chain's FLOPs at n2 = 512) and runs
+  // its own slabs: 1.5x the matrix work per sample on twice the CUs, a shorter critical path for the chain that waits on this launch
+  const int b = bid / a.nsplit, sl0 = (bid % a.nsplit) * ((a.n2 >> 8) / a.nsplit);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, col = lane & 31;
-  const int nk1 = a.k1 >> 5, nk2 = (NB1 * 32) >> 5, nslab = a.n2 >> 8;
+  const int nk1 = a.k1 >> 5, nk2 = (NB1 * 32) >> 5, nslab = (a.n2 >> 8) / a.nsplit;
   const int nchunks = nk1 + nslab * nk2, nks = nchunks >> 1;  // (nk1, nk2 even)
   unsigned char *const ring = smem_raw;
   float *const vec1_l = reinterpret_cast<float *>(smem_raw + (size_t)NST * STAGE_B);  // [3][n1]
@@ -774,7 +780,7 @@ __device__ __forceinline__ void sa_chain_body(const F1Args &a, const int bid) {
       if (g < nk1) { base = reinterpret_cast<const T *>(a.W1); nrow = a.n1; kc = g; r0 = 0; }
       else {
         const int h = g - nk1, sl = h / nk2;
-        base = reinterpret_cast<const T *>(a.W2); nrow = a.n2; kc = h - sl * nk2; r0 = sl * 256;
+        base = reinterpret_cast<const T *>(a.W2); nrow = a.n2; kc = h - sl * nk2; r0 = (sl0 + sl) * 256;
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -951,10 +957,11 @@ __device__ __forceinline__ void sa_chain_body(const F1Args &a, const int bid) {
   const size_t R = (size_t)a.B * 256;
   const int row = b * 256 + wave * 32 + col;
   const int raoff = (col & 15) * 16, rboff = (2 * wave + (col >> 4)) * 16;  // this lane's rows inside a piece of the residual tables
-  for (int sl = 0; sl < nslab; ++sl) {
+  for (int sli = 0; sli < nslab; ++sli) {
+    const int sl = sl0 + sli;  // the slab's position in the layer; sli: its position in this workgroup's ring sequence
     f32x16 acc2[NB2];
     init_acc(std::integral_constant<int, NB2>(), acc2, vec2_l + sl * 256);
-    const int st0 = nks1 + sl * (nk2 >> 1);  // first ring stage of this slab
+    const int st0 = nks1 + sli * (nk2 >> 1);  // first ring stage of this slab
     f16x8 afc[NB2], afn[NB2];
     auto loadw = [&](f16x8 (&o)[NB2], const unsigned char *sb, int c2, int st2) __attribute__((always_inline)) {
       const int piece = st2 * 2 + half;
@@ -983,9 +990,9 @@ __device__ __forceinline__ void sa_chain_body(const F1Args &a, const int bid) {
 #pragma unroll
       for (int cb = 0; cb < NB2; ++cb) acc2[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afn[cb], h2b[4 * s2 + 3], acc2[cb], 0, 0, 0);
     }
-    F1_STAMP(3 + 3 * sl);
+    F1_STAMP(3 + 3 * sli);
     group_stats(std::integral_constant<int, NB2>(), acc2, vec2_l, sl * NB2, a.n2, a.gs2, a.inv2);
-    F1_STAMP(4 + 3 * sl);
+    F1_STAMP(4 + 3 * sli);
 #pragma unroll
     for (int cb = 0; cb < NB2; ++cb) {
       const int cg = sl * 256 + cb * 32;
@@ -1005,7 +1012,7 @@ __device__ __forceinline__ void sa_chain_body(const F1Args &a, const int bid) {
             __builtin_bit_cast(u32x4, y);
       }
     }
-    F1_STAMP(5 + 3 * sl);
+    F1_STAMP(5 + 3 * sli);
   }
 #ifdef SLIDE_TIMELINE
   if (a.dbg) {
@@ -1046,6 +1053,13 @@ static int sa_args_from_op(const SlideOp &o, F1Args &a, size_t &shm) {
   a.B = o.i[0]; a.t_ld = o.i[1]; a.k1 = o.i[2]; a.n1 = o.i[3]; a.n2 = o.i[4]; a.gs1 = o.i[5]; a.gs2 = o.i[6];
   a.add0_stride = o.i[7]; a.add0_bs = o.i[8]; a.add1_bs = o.i[9];
   a.inv1 = o.f[0]; a.inv2 = o.f[1];
+  // OPT-IN (SLIDE_SA_SPLIT_MAX=<samples>: two workgroups per sample for launches of at most that many samples).  Measured in bench.py's
+  // arrangement (tools/ab/r06_split.sh, three alternating pairs, --steps 300): 379.1 shapes/s with the split at 88 samples per launch
+  // against 387.5 without -- the launch itself gets shorter, but the arrangement is bound by CU-time, not by this launch's latency,
+  // and the repeated stage 1 is 1.33x the chain's matrix work.
+  static const bool no_split = getenv("SLIDE_SA_SPLIT") && getenv("SLIDE_SA_SPLIT")[0] == '0';
+  static const int split_max = getenv("SLIDE_SA_SPLIT_MAX") ? atoi(getenv("SLIDE_SA_SPLIT_MAX")) : 0;
+  a.nsplit = (!no_split && (a.n2 >> 8) % 2 == 0 && a.B <= split_max) ? 2 : 1;
   if (a.B <= 0 || a.k1 % 64 || a.k1 <= 0 || (a.n1 != 128 && a.n1 != 256) || a.n2 % 256 || a.n2 <= 0 || a.t_ld % 8) return -3;
   auto okgs = [](int g) { return g == 4 || g == 8 || g == 16; };
   if (!okgs(a.gs1) || !okgs(a.gs2)) return -3;
@@ -1086,13 +1100,13 @@ int slide_launch_sa_chain_p(const SlideOp &o, hipStream_t s) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_chain_p_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_done[0][d] = true;
     }
-    hipLaunchKernelGGL((sa_chain_p_kernel<4>), dim3(a.B + grid_p), dim3(512), shm, s, a, g, a.B);
+    hipLaunchKernelGGL((sa_chain_p_kernel<4>), dim3(a.B * a.nsplit + grid_p), dim3(512), shm, s, a, g, a.B * a.nsplit);
   } else {
     if (!attr_done[1][d]) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_chain_p_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_done[1][d] = true;
     }
-    hipLaunchKernelGGL((sa_chain_p_kernel<8>), dim3(a.B + grid_p), dim3(512), shm, s, a, g, a.B);
+    hipLaunchKernelGGL((sa_chain_p_kernel<8>), dim3(a.B * a.nsplit + grid_p), dim3(512), shm, s, a, g, a.B * a.nsplit);
   }
   return (int)hipGetLastError();
 }
@@ -1111,13 +1125,13 @@ int slide_launch_sa_chain(const SlideOp &o, hipStream_t s) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_chain_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_done[0][d] = true;
     }
-    hipLaunchKernelGGL((sa_chain_kernel<4>), dim3(a.B), dim3(512), shm, s, a);
+    hipLaunchKernelGGL((sa_chain_kernel<4>), dim3(a.B * a.nsplit), dim3(512), shm, s, a);
   } else {
     if (!attr_done[1][d]) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_chain_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_done[1][d] = true;
     }
-    hipLaunchKernelGGL((sa_chain_kernel<8>), dim3(a.B), dim3(512), shm, s, a);
+    hipLaunchKernelGGL((sa_chain_kernel<8>), dim3(a.B * a.nsplit), dim3(512), shm, s, a);
   }
   return (int)hipGetLastError();
 }

@@ -21,6 +21,7 @@ from .engine import EPI_RAW, EPI_STATS, F_PRE_RELU, OP_GEMM, SlideEpi, SlideOp, 
 OP_COPY_COLS = 7
 OP_ROWS_FROM_NCX, OP_ROWS_TO_NCX, OP_ROWS_GROUP, OP_ROWS_GN, OP_ROWS_CONCAT_QK, OP_ROWS_ATTN, OP_ROWS_POOL = 20, 21, 22, 23, 24, 25, 26
 OP_ROWS_GN_JOINT = 27
+OP_GEMM_ATTEND = 38
 GROUP_FP, GROUP_ABS, GROUP_CENTER, GROUP_NO_XYZ, GROUP_IDX32 = 1, 2, 4, 8, 16
 POOL_MAX, POOL_AVG, POOL_MAX_AVG = 0, 1, 2
 GN_PRE_RELU, GN_POST_RELU, GN_STATS_ONLY, GN_APPLY_ONLY = 1, 2, 4, 8
@@ -385,6 +386,48 @@ def attend(scores, values, K, counts=None):
     _run(_rop(OP_ROWS_ATTN, scores.half, (pts, K, scores.C, scores.ld, values.ld, out.shape[1], scores.S // K, int(v_relu)),
               (scores.data, values.data, out, _counts32(counts, pts), vss)))
     return Rows(out, scores.B, scores.S // K, scores.C)
+
+
+def conv_attend(u, module, values, K, counts=None):
+    """attend(conv(u, module), values, K, counts) with the score map kept on chip (SLIDE_OP_GEMM_ATTEND, round 6): the score
+    convolution's 256 x 64 output tile is soft-maxed over the neighbour rows and contracted with the value rows in the GEMM's epilogue.
+    fp16 rows, K in (4, 8, 16, 32), tiles that do not straddle samples; otherwise (or SLIDE_MODULE_FUSE_ATTEND=0) the two launches."""
+    ok = (u.half and K in (4, 8, 16, 32) and u.rows % 256 == 0 and u.rows == values.rows and u.rows > 0 and
+          os.environ.get("SLIDE_MODULE_FUSE_ATTEND", "1") != "0" and (u.pending is None or u.S % 256 == 0) and u.ld <= 1536)
+    if not ok:
+        return attend(conv(u, module), values, K, counts)
+    w, bias = module.weight, module.bias
+    dev = u.data.device
+    key = (w._version, w.data_ptr(), None if bias is None else (bias._version, bias.data_ptr()), u.half, dev.type, dev.index)
+    plan = module.__dict__.get("_rows_plan")
+    if plan is None or plan[0] != key:
+        plan = (key, _ConvPlan(w, module.bias, u.half, dev))
+        module.__dict__["_rows_plan"] = plan
+    cp = plan[1]
+    assert u.ld == cp.kp and values.C == cp.O and values.half
+    vss, v_relu = None, False
+    if values.pending is not None and values.pending[2] is None:  # deferred GroupNorm (+ ReLU) of the values: applied in the epilogue
+        vss, v_relu, _ = values.pending
+        values.pending = None
+    else:
+        materialise(values)
+    pts = u.rows // K
+    out = _empty(pts, cp.op_, True, dev)
+    assert values.ld >= cp.op_
+    sc = sh = add = None
+    f = (0.0, 0.0, 0.0, 0.0)
+    in_bs = 0
+    if u.pending is not None:
+        ss, relu, addvec = u.pending
+        sc, sh, in_bs = ss.data_ptr(), ss.data_ptr() + 4 * u.ld, 2 * u.ld
+        add = None if addvec is None else addvec.data_ptr()
+        f = (0.0, float(u.S // 256), float(addvec.shape[1]) if addvec is not None else 0.0,
+             float(2 * (addvec.shape[1] if addvec is not None else 0) + int(relu)))
+    c32 = _counts32(counts, pts)
+    _run(make_op(OP_GEMM_ATTEND, i=(u.rows, cp.kp, cp.kp, cp.op_ // 32, K, in_bs, values.ld, out.shape[1], u.S // K, int(v_relu), cp.O), f=f,
+                 p=(u.data.data_ptr(), cp.W.data_ptr(), cp.epi(out).data_ptr(), sc, sh, values.data.data_ptr(), out.data_ptr(),
+                    None if c32 is None else c32.data_ptr(), None if vss is None else vss.data_ptr(), None, None, add)))
+    return Rows(out, u.B, u.S // K, cp.O)
 
 
 def pool(x, K, mode, counts=None):

@@ -487,6 +487,54 @@ def test_attention_without_the_concatenation(gpu_device, monkeypatch, npnt, K):
         assert rel(outs["1"], ref) <= 6e-3 and rel(outs["0"], ref) <= 6e-3, (rel(outs["1"], ref), rel(outs["0"], ref))
 
 
+@pytest.mark.parametrize("npnt,K", [(64, 4), (32, 8), (64, 16), (16, 32), (256, 32)])
+def test_attention_fused_score_gemm_and_attend(gpu_device, monkeypatch, npnt, K):
+    """round 6, fp16 module path: the score convolution of an AttentionModule, the soft-max over the K neighbours and the weighted sum
+    of the values as ONE launch (SLIDE_OP_GEMM_ATTEND: the score map stays in the accumulators) against the two-launch form
+    (SLIDE_MODULE_FUSE_ATTEND=0: scores stored in fp16, rows_attn_kernel) and an fp64 restatement of attention.py:70-96, with and
+    without ball-query counts.  The fused form soft-maxes fp32 scores, the two-launch form fp16-rounded ones: they agree to <= 3e-3
+    relative L2 and the fused form is not further from the restatement than the two-launch form (+ 10 %)."""
+    from pointnet2_ops.attention import AttentionModule
+    monkeypatch.setenv("SLIDE_MODULE_PREC", "fp16")
+    d = gpu_device
+    B, Cq, Cg, Cout = 2, 40, 70, 96
+    am = _randomise(AttentionModule(Cq, Cg, 48, 64, Cout), d, seed=6)
+    gen = torch.Generator().manual_seed(10 + K)
+    feat = torch.randn(B, Cq, npnt, generator=gen).to(d)
+    gfeat = torch.randn(B, Cg, npnt, K, generator=gen).to(d)
+    gout = torch.randn(B, Cout, npnt, K, generator=gen).to(d)
+    count = torch.randint(0, K + 1, (B, npnt), generator=gen).to(d)
+    from slide_amd import rows as R
+    launched = []
+    real_run = R._run
+    monkeypatch.setattr(R, "_run", lambda op: (launched.append(op.kind), real_run(op))[1])
+    for cnt in ("all", count):
+        outs = {}
+        for v in ("1", "0"):
+            monkeypatch.setenv("SLIDE_MODULE_FUSE_ATTEND", v)
+            del launched[:]
+            outs[v] = am(feat, gfeat, gout, cnt).double()
+            fusable = (npnt * K) % 256 == 0
+            assert (R.OP_GEMM_ATTEND in launched) == (v == "1" and fusable) and (R.OP_ROWS_ATTN in launched) == (v == "0" or not fusable), launched
+        gn = lambda x, m: torch.cat([torch.nn.functional.group_norm(x[:, :m.num_channels], m.num_groups, m.group_norm.weight.double(),
+                                                                     m.group_norm.bias.double(), 1e-5), x[:, m.num_channels:]], 1)
+        c2 = lambda x, m: torch.nn.functional.conv2d(x, m.weight.double(), m.bias.double())
+        q = c2(feat.double()[..., None], am.feat_conv).expand(-1, -1, -1, K)
+        k = c2(gfeat.double(), am.grouped_feat_conv)
+        wc = list(am.weight_conv)
+        u = c2(gn(torch.cat([q, k], 1).relu(), wc[1]), wc[2])
+        sc = c2(gn(u.relu(), wc[4]), wc[5])
+        fo = list(am.feat_out_conv)
+        val = gn(c2(gout.double(), fo[0]), fo[1]).relu()
+        if not isinstance(cnt, str):
+            mask = (torch.arange(K, device=d)[None, None, :] < cnt.clamp(min=1)[..., None]).double()[:, None]
+            sc = sc * mask + (-1e9) * (1 - mask)
+        ref = (torch.softmax(sc, dim=-1) * val).sum(-1)
+        rel = lambda a, b: float(((a - b).norm() / b.norm()).detach())
+        assert torch.isfinite(outs["1"]).all() and rel(outs["1"], outs["0"]) <= 3e-3, rel(outs["1"], outs["0"])
+        assert rel(outs["1"], ref) <= 6e-3 and rel(outs["1"], ref) <= 1.1 * rel(outs["0"], ref) + 1e-4, (rel(outs["1"], ref), rel(outs["0"], ref))
+
+
 def test_deferred_normalisation_matches_the_materialised_path(gpu_device, monkeypatch):
     """fp16 module path: a GroupNorm whose consumer is a GEMM is DEFERRED -- the producer's raw output stays in memory and the
     consumer's loader applies relu(x * scale + shift) + add from per-sample fp16 vectors in LDS (csrc/engine.hip, AFF

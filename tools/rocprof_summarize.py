@@ -58,7 +58,7 @@ if os.path.exists(fp) and os.path.exists(wp):
                 "Units: KiB per dispatch as reported by rocprofv3.  On gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x\n"
                 "(MI355X_MICROARCH.md, HBM section): the `fetch x2` column applies that correction.\n\n"
                 "| kernel | dispatches | FETCH KiB/disp | fetch x2 KiB | WRITE KiB/disp | avg us |\n|---|---|---|---|---|---|\n")
-        keys = [k for k in fa if any(t in k for t in ("gemm", "assemble", "attn", "copy", "prep", "update", "finalize", "sa_chain", "block_body", "pair_norm", "pair_first", "head_update"))]
+        keys = [k for k in fa if any(t in k for t in ("gemm", "assemble", "attn", "copy", "prep", "update", "finalize", "sa_chain", "block_body", "pair_norm", "pair_first", "head_update", "point_chain"))]
         for k in sorted(keys, key=lambda k: -fa[k][0]):
             w = wa.get(k, [0, 1, 0])
             f.write("| %s | %d | %.0f | %.0f | %.0f | %.1f |\n" % (k, fa[k][1], fa[k][0] / fa[k][1], 2 * fa[k][0] / fa[k][1],
@@ -66,10 +66,17 @@ if os.path.exists(fp) and os.path.exists(wp):
     import json
     kern = {}
     for k in fa:
-        if any(t in k for t in ("gemm", "attn_tail", "sa_chain", "block_body", "pair_first", "head_update")):
+        if any(t in k for t in ("gemm", "attn_tail", "sa_chain", "block_body", "pair_first", "pair_norm", "head_update", "point_chain")):
             w = wa.get(k, [0, 1, 0])
             kern[k] = {"hbm_bytes_per_launch": int(1024 * (2 * fa[k][0] / fa[k][1] + w[0] / max(w[1], 1))),
                        "fetch_kib_x2": 2 * fa[k][0] / fa[k][1], "write_kib": w[0] / max(w[1], 1), "dispatches": fa[k][1]}
+    latest = os.path.join(dst, "hbm_pmc_latest.json")
+    if pmc_cmd is not None and os.path.exists(latest):
+        # (round 6) the position plan's kernels join the file under their own key, with their own launch size
+        d_ = json.load(open(latest))
+        d_["position_plan"] = {"source": "profiles/%s_hbm_pmc.md (`tools/profile_ops.py %s`; same passes and correction)" % (tag, pmc_cmd),
+                               "samples_per_launch": batch, "kernels": kern}
+        json.dump(d_, open(latest, "w"), indent=1)
     if pmc_cmd is None:
       json.dump({"source": "profiles/%s_hbm_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH x2 gfx950 "
                          "correction; %d samples per launch)" % (tag, batch), "samples_per_launch": batch, "kernels": kern}, open(os.path.join(dst, "hbm_pmc_latest.json"), "w"), indent=1)
@@ -85,7 +92,7 @@ if os.path.exists(mp):
                 "MI355X_MICROARCH.md: the counter advances 32 per 32x32x16 MFMA, summed over all SIMDs).  "
                 "wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES: share of wave-cycles parked in s_waitcnt / barriers.\n\n"
                 "| kernel | dispatches | avg us | MFMA utilisation | VALU per MFMA | wait share |\n|---|---|---|---|---|---|\n")
-        ks = [k for k in acc["SQ_BUSY_CYCLES"] if any(t in k for t in ("gemm", "attn", "sa_chain", "block_body", "pair_norm"))]
+        ks = [k for k in acc["SQ_BUSY_CYCLES"] if any(t in k for t in ("gemm", "attn", "sa_chain", "block_body", "pair_norm", "pair_first", "point_chain"))]
         for k in sorted(ks, key=lambda k: -acc["SQ_BUSY_CYCLES"][k][2]):
             g_ = lambda n: acc[n].get(k, [0.0, 1, 0.0])[0]
             d = acc["SQ_BUSY_CYCLES"][k]
