@@ -245,7 +245,7 @@ class CategoryChains:
         # one queue serialise while another queue may sit idle (DESIGN.md section 9 item 5a').  With more than two segments (five
         # categories: ten chains) the chains are therefore laid onto FOUR streams explicitly -- feature chain k on stream k mod 4,
         # position chain k on stream (k + 2) mod 4: at most two feature chains per stream, deterministic from run to run.
-        if len(self.chains) > 2:
+        if len(self.chains) > 2 and all(hasattr(o_, "stream") for ch_ in self.chains for o_ in ch_[3:5]):
             pool = [self.chains[0][4].stream, self.chains[0][3].stream, self.chains[1][4].stream, self.chains[1][3].stream]
             for k, (_, _, _, ps, fs) in enumerate(self.chains):
                 fs.stream = fs.stream2 = pool[k % 4]

@@ -650,6 +650,7 @@ def test_chunk_major_layout_bit_identical(gpu_device, exp_lib, monkeypatch):
     from slide_amd.engine import DenoiserEngine
     monkeypatch.setenv("SLIDE_GX", "0")  # the round-2 plan on both sides (the pair decomposition needs chunk-major weights)
     monkeypatch.setenv("SLIDE_GEMM_CHAIN", "0")  # (COPY launches between the per-point GEMMs change which of them form a chain)
+    monkeypatch.setenv("SLIDE_POINT_CHAIN", "0")  # (... and whether forward() ends with the point chain, split arithmetic since round 6)
     for name in ("pos", "feat"):
         g, hp, sd = _load(name)
         x, ts, lab = g["x_mixed"], g["ts_mixed"], g["label_mixed"]
