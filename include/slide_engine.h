@@ -184,6 +184,13 @@ enum {
   SLIDE_OP_ROWS_CONCAT_QK = 24,/* p: q [rows/K][ldq], k [rows][ldk], out [rows][ldo] = relu([q | k])   i: rows, K, C1, ldq, C2, ldk, ldo */
   SLIDE_OP_ROWS_ATTN = 25,     /* p: scores [pts*K][lds], values [pts*K][ldv], out [pts][ldo], [3] counts int32 [pts] or NULL (softmax over the first max(1,count) slots), [4] deferred normalisation of the values: scale / shift [sample][2][ldv] fp32 or NULL   i: pts, K, C, lds, ldv, ldo, points per sample, ReLU after the affine */
   SLIDE_OP_ROWS_POOL = 26,     /* p: x [pts*K][ldx], out [pts][ldo], counts int32 [pts] or NULL   i: pts, K, C, ldx, ldo, mode (0 max, 1 mean over the counted slots, 2 max for channels < C/2 and mean for the rest) */
+  SLIDE_OP_ROWS_PAIR_EXPAND = 39, /* round 6 (fp16 rows): a 1 x 1 convolution over a GROUPED input without the grouped matrix -- out[(b, p, k)][c] =
+                             * A[b*N + idx[b][p][k]][c] + bias[c] + coef[c][0..2] . xyz[neighbour] + coef[c][3..5] . xyz[centre] + coef[c][6] d2 +
+                             * coef[c][7] w, A = the convolution's feature columns applied per SOURCE point (fp32 [B*N][ldA], or NULL without
+                             * features), coef = (W_rel + W_abs | W_centre - W_rel | w_d2 | w_w) per output channel, fp32 [ld][8]; flags: 1 = ReLU,
+                             * 2 = group_knn slot scalars (d2, w = normalised inverse squared distance; p[6] = d2 (B, np, K)), 16 = idx is int32.
+                             * p: A, bias [ld], coef, xyz (B,N,3), new_xyz (B,np,3), idx (B,np,K), d2 or NULL, out [B*np*K][ld], [8] / [9] per-256-row-
+                             * tile channel sums / sums of squares of the (ReLU'd) output [rows/256][ld] or both NULL.  i: B, N, np, K, ld, ldA, flags */
   SLIDE_OP_ROWS_GN_JOINT = 27  /* round 5: GroupNorm over the VIRTUAL concatenation [q(point) x K | k(point, neighbour)] of an AttentionModule (attention.py:45-47) from the per-256-row-tile channel sums of the two producing GEMMs (STATS epilogue): p: qsum, qsq [B*tq][ldq], ksum, ksq [B*tk][ldk], gamma, beta [n_norm], OUT ssq [B][2][ldq], ssk [B][2][ldk] (scale | shift per sample and channel in the producers' layouts)   i: B, C1, ldq, tq, K, C2, ldk, tk, G   f: 1 / (rows of k per sample), n_norm */
 };
 

@@ -2653,7 +2653,8 @@ int run_op(const SlideOp &o, hipStream_t s) {
       hipLaunchKernelGGL(advance_t_kernel, dim3(1), dim3(64), 0, s, (int *)o.p[0]);
       break;
     default:
-      if (o.kind >= SLIDE_OP_ROWS_FROM_NCX && o.kind <= SLIDE_OP_ROWS_GN_JOINT) return slide_launch_rows_op(o, s);
+      if ((o.kind >= SLIDE_OP_ROWS_FROM_NCX && o.kind <= SLIDE_OP_ROWS_GN_JOINT) || o.kind == SLIDE_OP_ROWS_PAIR_EXPAND)
+        return slide_launch_rows_op(o, s);
       return -1;
   }
   return (int)hipGetLastError();

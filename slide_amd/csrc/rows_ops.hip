@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/slide_engine.h"
 
 namespace {
@@ -500,6 +502,115 @@ __global__ __launch_bounds__(256) void rows_pool_kernel(int K, int C, int ldx, i
   *reinterpret_cast<Pack<T, VEC> *>(out + pt * ldo + c0) = r;
 }
 
+// ------------------------------------------------------------------------------------------ pair expansion (round 6)
+// A 1 x 1 convolution over a GROUPED input is linear in [features of the neighbour | coordinate channels], and every coordinate
+// channel is linear in xyz[neighbour] and xyz[centre] (SA: rel | abs | centre; FP: d2 | w | abs | rel | centre: the layouts of
+// rows_group_kernel above), so its output for row (b, p, k) separates:
+//     y(b, p, k) = A[b][idx(b, p, k)]  +  bias  +  Cq . xyz[neighbour]  +  Cc . xyz[centre]  (+ wd d2 + ww w)
+// with A = W_features . features one row per SOURCE point (a GEMM on B * N rows instead of B * npoint * K: 1 / 64 of the MACs at
+// 1024 centres x 16 neighbours of 256 points), Cq = W_rel + W_abs, Cc = W_centre - W_rel.  This kernel builds y from the fp32 table A
+// and the coordinates -- the grouped matrix (the widest tensor of a level) is never written or read, and the coordinate terms are
+// evaluated in fp32 from fp32 coordinates (the grouped matrix held them rounded to the activation type).  The pair decomposition of
+// the fused DDPM plan (gemm_gx.hip), for the module-level path's arbitrary N / npoint / K.
+// One workgroup per 256-row tile: thread r first derives row r's neighbour row, coordinates and slot scalars into LDS, then a thread
+// owns FOUR channels and walks its share of the rows (a wave reads 1 KB of one A row and writes 512 B of one output row per step);
+// ReLU (flags & 1) and the per-tile channel sums of the GroupNorm that follows (the GEMM epilogue's STATS mode) ride along.
+template <typename T>
+__global__ __launch_bounds__(256) void rows_pair_expand_kernel(int N, int np, int K, int ld, int ldA, int flags, size_t rows,
+                                                               const float *__restrict__ A, const float *__restrict__ bias,
+                                                               const float *__restrict__ coef, const float *__restrict__ xyz,
+                                                               const float *__restrict__ new_xyz, const void *__restrict__ idx,
+                                                               const float *__restrict__ d2, T *__restrict__ out,
+                                                               float *__restrict__ st_sum, float *__restrict__ st_sq) {
+  __shared__ __attribute__((aligned(16))) float rs[256][8];  // qx qy qz cx cy cz d2 w
+  __shared__ int rsrc[256];
+  __shared__ float red[2][2048];
+  const int tid = threadIdx.x;
+  const size_t row0 = (size_t)blockIdx.x * 256;
+  {
+    const size_t row = row0 + tid;
+    int src = -1;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (row < rows) {
+      const size_t pt = row / K;
+      const int b = (int)(pt / np);
+      const int nb = (flags & 16) ? static_cast<const int *>(idx)[row] : (int)static_cast<const int64_t *>(idx)[row];
+      src = b * N + nb;
+      const float *q = xyz + (size_t)src * 3, *c = new_xyz + pt * 3;
+      v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = c[0]; v[4] = c[1]; v[5] = c[2];
+      if (flags & 2) {  // group_knn's slot scalars (pointnet2_utils.py:510-513)
+        const float *dd = d2 + pt * K;
+        float sum = 0.f;
+        for (int k = 0; k < K; ++k) sum += 1.0f / (dd[k] + 1e-8f);
+        v[6] = d2[row];
+        v[7] = (1.0f / (v[6] + 1e-8f)) / sum;
+      }
+    }
+    rsrc[tid] = src;
+    *reinterpret_cast<float4 *>(&rs[tid][0]) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4 *>(&rs[tid][4]) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+  __syncthreads();
+  const int pieces = ld >> 2;                       // 4-channel pieces per row (ld <= 1024)
+  const int nsub = 256 / pieces > 0 ? 256 / pieces : 1;
+  const bool relu = (flags & 1) != 0, want_stats = st_sum != nullptr;
+  for (int p0 = 0; p0 < pieces; p0 += 256) {        // (one trip unless ld > 1024 / never: the launcher bounds ld)
+    const int pc = p0 + tid % (pieces < 256 ? pieces : 256), sub = tid / (pieces < 256 ? pieces : 256);
+    const bool active = pc < pieces && sub < nsub;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+      const int c0 = pc * 4;
+      float cf[4][8], bi[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 u0 = *reinterpret_cast<const float4 *>(coef + (size_t)(c0 + j) * 8);
+        const float4 u1 = *reinterpret_cast<const float4 *>(coef + (size_t)(c0 + j) * 8 + 4);
+        cf[j][0] = u0.x; cf[j][1] = u0.y; cf[j][2] = u0.z; cf[j][3] = u0.w; cf[j][4] = u1.x; cf[j][5] = u1.y; cf[j][6] = u1.z; cf[j][7] = u1.w;
+        bi[j] = bias[c0 + j];
+      }
+      for (int rr = sub; rr < 256; rr += nsub) {
+        const int src = rsrc[rr];
+        if (src < 0) break;  // (rows beyond the end of the matrix: the tail of the last tile)
+        const float4 a4 = A ? *reinterpret_cast<const float4 *>(A + (size_t)src * ldA + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 r0 = *reinterpret_cast<const float4 *>(&rs[rr][0]), r1 = *reinterpret_cast<const float4 *>(&rs[rr][4]);
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+        float y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float t = av[j] + bi[j];
+          t = fmaf(cf[j][0], r0.x, t); t = fmaf(cf[j][1], r0.y, t); t = fmaf(cf[j][2], r0.z, t);
+          t = fmaf(cf[j][3], r0.w, t); t = fmaf(cf[j][4], r1.x, t); t = fmaf(cf[j][5], r1.y, t);
+          t = fmaf(cf[j][6], r1.z, t); t = fmaf(cf[j][7], r1.w, t);
+          if (relu) t = fmaxf(t, 0.f);
+          y[j] = t;
+          s[j] += t; ss[j] = fmaf(t, t, ss[j]);
+        }
+        Pack<T, 4> o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o.v[j] = (T)y[j];
+        *reinterpret_cast<Pack<T, 4> *>(out + (row0 + rr) * ld + c0) = o;
+      }
+    }
+    if (want_stats) {  // the tile's channel sums: the row subsets meet in LDS
+      __syncthreads();
+      if (active) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          red[0][sub * (pieces * 4) + (pc - p0) * 4 + j] = s[j];
+          red[1][sub * (pieces * 4) + (pc - p0) * 4 + j] = ss[j];
+        }
+      }
+      __syncthreads();
+      for (int c = tid; c < ld; c += 256) {
+        float a_ = 0.f, b_ = 0.f;
+        for (int u = 0; u < nsub; ++u) { a_ += red[0][u * ld + c]; b_ += red[1][u * ld + c]; }
+        st_sum[(size_t)blockIdx.x * ld + c] = a_;
+        st_sq[(size_t)blockIdx.x * ld + c] = b_;
+      }
+    }
+  }
+}
+
 template <typename T>
 int launch_rows(const SlideOp &o, hipStream_t s) {
   if (o.i[0] <= 0) return 0;  // no samples / rows / points: nothing to launch (a zero-sized grid is a launch error)
@@ -575,6 +686,19 @@ int launch_rows(const SlideOp &o, hipStream_t s) {
       hipLaunchKernelGGL(rows_gn_joint_kernel, dim3(B), dim3(256), 0, s, C1, ldq, tq, (float)K, C2, ldk, tk, G, n_norm, o.f[0],
                          (const float *)o.p[0], (const float *)o.p[1], (const float *)o.p[2], (const float *)o.p[3],
                          (const float *)o.p[4], (const float *)o.p[5], (float *)o.p[6], (float *)o.p[7]);
+      break;
+    }
+    case SLIDE_OP_ROWS_PAIR_EXPAND: {  // i: B, N, np, K, ld, ldA, flags   p: A, bias, coef, xyz, new_xyz, idx, d2, out, st_sum, st_sq
+      const int B = o.i[0], N = o.i[1], np = o.i[2], K = o.i[3], ld = o.i[4], ldA = o.i[5], flags = o.i[6];
+      if (ld % 32 || ld <= 0 || ld > 1024 || (o.p[0] && (ldA % 4 || ldA < ld)) || !o.p[1] || !o.p[2] || !o.p[3] || !o.p[4] || !o.p[5] || !o.p[7] ||
+          ((flags & 2) && !o.p[6]) || (!o.p[8]) != (!o.p[9]) || N <= 0 || K <= 0)
+        return -3;
+      if (std::is_same<T, float>::value) return -3;  // fp16 rows only
+      const size_t rows = (size_t)B * np * K;
+      if (rows == 0) return 0;
+      hipLaunchKernelGGL(rows_pair_expand_kernel<T>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, N, np, K, ld, ldA, flags, rows,
+                         (const float *)o.p[0], (const float *)o.p[1], (const float *)o.p[2], (const float *)o.p[3], (const float *)o.p[4],
+                         (const void *)o.p[5], (const float *)o.p[6], (T *)o.p[7], (float *)o.p[8], (float *)o.p[9]);
       break;
     }
     case SLIDE_OP_ROWS_POOL: {  // i: points, K, C, ldx, ldo, mode   p: x, out, counts

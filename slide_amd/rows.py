@@ -16,12 +16,13 @@ import numpy as np
 import torch
 
 from ._lib import check, lib
-from .engine import EPI_RAW, EPI_STATS, F_PRE_RELU, OP_GEMM, SlideEpi, SlideOp, make_op, ru
+from .engine import EPI_RAW, EPI_STATS, F_OUT_F32, F_PRE_RELU, OP_GEMM, SlideEpi, SlideOp, make_op, ru
 
 OP_COPY_COLS = 7
 OP_ROWS_FROM_NCX, OP_ROWS_TO_NCX, OP_ROWS_GROUP, OP_ROWS_GN, OP_ROWS_CONCAT_QK, OP_ROWS_ATTN, OP_ROWS_POOL = 20, 21, 22, 23, 24, 25, 26
 OP_ROWS_GN_JOINT = 27
 OP_GEMM_ATTEND = 38
+OP_ROWS_PAIR_EXPAND = 39
 GROUP_FP, GROUP_ABS, GROUP_CENTER, GROUP_NO_XYZ, GROUP_IDX32 = 1, 2, 4, 8, 16
 POOL_MAX, POOL_AVG, POOL_MAX_AVG = 0, 1, 2
 GN_PRE_RELU, GN_POST_RELU, GN_STATS_ONLY, GN_APPLY_ONLY = 1, 2, 4, 8
@@ -66,6 +67,39 @@ class Rows:
     @property
     def rows(self):
         return self.data.shape[0]
+
+
+class LazyGroup(Rows):
+    """The grouped input of an SA / feature-map / kNN-FP block that is NOT built until somebody needs its rows (round 6).  Its only
+    consumers in the module programs are 1 x 1 convolutions (first_mlp / res_connect / grouped_feat_conv), and a convolution over
+    [features of the neighbour | coordinate channels] separates into a per-SOURCE-point table and coordinate terms (`_pair_conv`): the
+    grouped matrix -- the widest tensor of a level, B * npoint * K rows -- is then never written or read.  Any other use (`.data`)
+    materialises it with the grouping kernel."""
+    __slots__ = ("_buf", "spec", "_ld", "_half")
+
+    def __init__(self, spec, B, S, C, ld, half):
+        self._buf, self.spec, self._ld, self._half = None, spec, ld, half
+        self.B, self.S, self.C = B, S, C
+        self.stats = None
+        self.pending = None
+
+    @property
+    def data(self):
+        if self._buf is None:
+            self._buf = _group_now(*self.spec)
+        return self._buf
+
+    @property
+    def ld(self):
+        return self._ld
+
+    @property
+    def half(self):
+        return self._half
+
+    @property
+    def rows(self):
+        return self.B * self.S
 
 
 def _empty(rows, ld, half, device):
@@ -149,10 +183,10 @@ class _ConvPlan:
             self.vec[:O] = bias.detach().float()
         self.epis = {}  # output pointer -> device epilogue table (the caching allocator recycles a handful of addresses)
 
-    def epi(self, out, stats=None, pre_relu=False, pre_add=None):
+    def epi(self, out, stats=None, pre_relu=False, pre_add=None, out_f32=False):
         """pre_add = (per-point tensor [points][ld], log2 K): + pre_add[row >> log2 K] before the ReLU (SlideEpi.pre_add)"""
         key = (out.device.index, out.data_ptr(), None if stats is None else (stats[0].data_ptr(), stats[1].data_ptr()), pre_relu,
-               None if pre_add is None else (pre_add[0].data_ptr(), pre_add[1]))
+               None if pre_add is None else (pre_add[0].data_ptr(), pre_add[1]), out_f32)
         e = self.epis.get(key)
         if e is None:
             if len(self.epis) >= 16:
@@ -163,7 +197,7 @@ class _ConvPlan:
             for j in range(n_cob):
                 t = tab[j]
                 t.mode = EPI_RAW if stats is None else EPI_STATS
-                t.flags = F_PRE_RELU if pre_relu else 0
+                t.flags = (F_PRE_RELU if pre_relu else 0) | (F_OUT_F32 if out_f32 else 0)
                 t.out_ld = self.op_
                 t.bias = self.vec.data_ptr() + 4 * 32 * j
                 t.out = out.data_ptr() + esz * 32 * j
@@ -180,7 +214,7 @@ class _ConvPlan:
             self.epis[key] = e
         return e
 
-    def run(self, x, stats=None, pre_add=None):
+    def run(self, x, stats=None, pre_add=None, out_f32=False):
         """stats: None | "raw" | "relu" -- also publish per-256-row-tile channel sums of the output (of its ReLU) from the
         GEMM epilogue, for the GroupNorm that follows (saves its statistics pass); only when tiles do not straddle samples.
         pre_add = (Rows of per-point terms, K): + term[row // K] ahead of the ReLU (K a power of two)"""
@@ -191,7 +225,7 @@ class _ConvPlan:
             assert pr.pending is None and pr.half == self.half and pr.rows * K == x.rows and pr.ld >= self.op_ and K & (K - 1) == 0
             pa = (pr.data, K.bit_length() - 1)
         rows = x.rows
-        out = _empty(rows, self.op_, self.half, x.data.device)
+        out = _empty(rows, self.op_, self.half and not out_f32, x.data.device)  # (out_f32: fp16 operands, float output rows)
         if rows == 0:  # empty batch: nothing to launch
             return Rows(out, x.B, x.S, self.O)
         st = None
@@ -210,7 +244,7 @@ class _ConvPlan:
             f = (0.0, float(x.S // 256), float(addvec.shape[1]) if addvec is not None else 0.0,
                  float(2 * (addvec.shape[1] if addvec is not None else 0) + int(relu)))
         _run(make_op(OP_GEMM, i=(rows, self.kp, self.kp, n_cob, 8, in_bs, int(self.half), cbw, int(self.half), 0), f=f,
-                     p=(x.data.data_ptr(), self.W.data_ptr(), self.epi(out, st, stats == "relu", pa).data_ptr(), sc, sh,
+                     p=(x.data.data_ptr(), self.W.data_ptr(), self.epi(out, st, stats == "relu", pa, out_f32).data_ptr(), sc, sh,
                         None, None, None, None, None, None, add)))
         return Rows(out, x.B, x.S, self.O, stats=None if st is None else (st[0], st[1], stats == "relu"))
 
@@ -254,6 +288,8 @@ class WeightSlice:
 def conv(x, module, stats=None, pre_add=None):
     """HipConv1x1 / HipLinear applied to Rows (weights re-packed when the parameter changes); stats, pre_add: see _ConvPlan.run.
     A deferred normalisation of x is applied by the GEMM itself when its tiles do not straddle samples."""
+    if isinstance(x, LazyGroup) and x._buf is None and pre_add is None:
+        return _pair_conv(x, module, stats)
     if x.pending is not None and not (x.half and x.S % 256 == 0):
         materialise(x)
     w, bias = module.weight, module.bias
@@ -336,21 +372,98 @@ def group(xyz, new_xyz, feat, idx, flags, d2=None, empty_counts=None, half=None)
     """grouped input of an SA / feature-map block (QueryAndGroup) or of a kNN feature-propagation block (group_knn):
     xyz (B,N,3), new_xyz (B,np,3), feat Rows [B*N] or None, idx (B,np,K) int64 (kNN) or int32 (ball query) -> Rows
     [B*np*K].  empty_counts (B,np): centres with count 0 become their own single neighbour with zero features."""
-    materialise(feat)
     B, N = xyz.shape[:2]
     npnt, K = idx.shape[1:]
     C = feat.C if feat is not None else 0
     ncoord = 11 if flags & GROUP_FP else 0 if flags & GROUP_NO_XYZ else 3 + (3 if flags & GROUP_ABS else 0) + (3 if flags & GROUP_CENTER else 0)
     half = feat.half if feat is not None else (half_mode() if half is None else half)
-    out = _empty(B * npnt * K, ru(C + ncoord), half, xyz.device)
     assert idx.dtype in (torch.int64, torch.int32)
     idx = idx.contiguous()
     if idx.dtype == torch.int32:
         flags |= GROUP_IDX32
+    spec = (xyz.contiguous().float(), new_xyz.contiguous().float(), feat, idx, flags, d2.contiguous() if d2 is not None else None,
+            empty_counts, half)
+    if (half and empty_counts is None and not (flags & GROUP_NO_XYZ) and B * npnt * K > 0 and ru(C + ncoord) <= 1024
+            and os.environ.get("SLIDE_MODULE_PAIR", "1") != "0"):
+        return LazyGroup(spec, B, npnt * K, C + ncoord, ru(C + ncoord), half)
+    return Rows(_group_now(*spec), B, npnt * K, C + ncoord)
+
+
+def _group_now(xyz, new_xyz, feat, idx, flags, d2, empty_counts, half):
+    """the grouped matrix [B * npoint * K][ld] (SLIDE_OP_ROWS_GROUP)"""
+    materialise(feat)
+    B, N = xyz.shape[:2]
+    npnt, K = idx.shape[1:]
+    C = feat.C if feat is not None else 0
+    ncoord = 11 if flags & GROUP_FP else 0 if flags & GROUP_NO_XYZ else 3 + (3 if flags & GROUP_ABS else 0) + (3 if flags & GROUP_CENTER else 0)
+    out = _empty(B * npnt * K, ru(C + ncoord), half, xyz.device)
     _run(_rop(OP_ROWS_GROUP, half, (B, N, npnt, K, C, feat.ld if feat is not None else 8, out.shape[1], flags),
-              (xyz.contiguous().float(), new_xyz.contiguous().float(), feat.data if feat is not None else None, idx,
-               d2.contiguous() if d2 is not None else None, out, _counts32(empty_counts, B * npnt))))
-    return Rows(out, B, npnt * K, C + ncoord)
+              (xyz, new_xyz, feat.data if feat is not None else None, idx, d2, out, _counts32(empty_counts, B * npnt))))
+    return out
+
+
+def _pair_coef(w2, C, flags, op_):
+    """coefficients of the coordinate terms of a convolution over a grouped input, fp32 [op_][8]: (W_rel + W_abs | W_centre - W_rel | w_d2 |
+    w_w) per output channel, from the weight columns behind the C feature columns (layouts: rows_group_kernel, rows_ops.hip)"""
+    O = w2.shape[0]
+    z = torch.zeros(O, 3, device=w2.device, dtype=torch.float32)
+    wd = ww = torch.zeros(O, device=w2.device, dtype=torch.float32)
+    if flags & GROUP_FP:   # [feat | d2 | w | abs | rel | centre]
+        wd, ww = w2[:, C], w2[:, C + 1]
+        w_abs, w_rel, w_ctr = w2[:, C + 2:C + 5], w2[:, C + 5:C + 8], w2[:, C + 8:C + 11]
+    else:                  # [feat | rel | abs? | centre?]
+        w_rel = w2[:, C:C + 3]
+        c = C + 3
+        w_abs = w2[:, c:c + 3] if flags & GROUP_ABS else z
+        c += 3 if flags & GROUP_ABS else 0
+        w_ctr = w2[:, c:c + 3] if flags & GROUP_CENTER else z
+    coef = torch.zeros(op_, 8, device=w2.device, dtype=torch.float32)
+    coef[:O, 0:3] = w_rel + w_abs
+    coef[:O, 3:6] = w_ctr - w_rel
+    coef[:O, 6] = wd
+    coef[:O, 7] = ww
+    return coef.contiguous()
+
+
+def _pair_conv(x, module, stats):
+    """conv(group(...), module, stats) WITHOUT the grouped matrix (LazyGroup above; SLIDE_OP_ROWS_PAIR_EXPAND): the convolution's feature
+    columns applied per SOURCE point (one small GEMM -> fp32 table), expanded over the neighbour table with the coordinate terms in fp32,
+    ReLU and the per-tile channel sums of the following GroupNorm on the way.  Reference: QueryAndGroup / group_knn feeding
+    Mlp_plus_t_emb.first_mlp / res_connect and AttentionModule.grouped_feat_conv (pointnet2_utils.py:383-430, :497-524;
+    pointnet2_modules.py:119-176; attention.py:70-85)."""
+    xyz, new_xyz, feat, idx, flags, d2, _, _ = x.spec
+    w, bias = module.weight, module.bias
+    dev = xyz.device
+    C = feat.C if feat is not None else 0
+    w2 = w.detach().reshape(w.shape[0], -1).float()
+    assert w2.shape[1] == x.C, (w2.shape, x.C)
+    O, op_ = w2.shape[0], ru(w2.shape[0])
+    key = (w._version, w.data_ptr(), None if bias is None else (bias._version, bias.data_ptr()), flags & ~GROUP_IDX32, C, dev.type, dev.index)
+    plan = module.__dict__.get("_rows_pair_plan")
+    if plan is None or plan[0] != key:
+        fplan = _ConvPlan(w2[:, :C], None, True, dev) if C > 0 else None
+        bvec = torch.zeros(op_, device=dev, dtype=torch.float32)
+        if bias is not None:
+            bvec[:O] = bias.detach().float()
+        plan = (key, fplan, bvec, _pair_coef(w2, C, flags, op_))
+        module.__dict__["_rows_pair_plan"] = plan
+    _, fplan, bvec, coef = plan
+    A = None
+    if fplan is not None:
+        if feat.pending is not None and not (feat.half and feat.S % 256 == 0):
+            materialise(feat)
+        A = fplan.run(feat, out_f32=True).data  # fp32 [B * N][op_]: W_features . features, one row per source point
+    B, N = xyz.shape[:2]
+    npnt, K = idx.shape[1:]
+    rows = B * npnt * K
+    out = _empty(rows, op_, True, dev)
+    st = None
+    if stats is not None and x.S % 256 == 0 and fused_stats():
+        st = (torch.empty(rows // 256, op_, device=dev), torch.empty(rows // 256, op_, device=dev))
+    kflags = (1 if stats == "relu" else 0) | (2 if flags & GROUP_FP else 0) | (16 if flags & GROUP_IDX32 else 0)
+    _run(_rop(OP_ROWS_PAIR_EXPAND, True, (B, N, npnt, K, op_, op_, kflags),
+              (A, bvec, coef, xyz, new_xyz, idx, d2, out, None if st is None else st[0], None if st is None else st[1])))
+    return Rows(out, B, npnt * K, O, stats=None if st is None else (st[0], st[1], stats == "relu"))
 
 
 def gather_rows(feat, idx):

@@ -535,6 +535,78 @@ def test_attention_fused_score_gemm_and_attend(gpu_device, monkeypatch, npnt, K)
         assert rel(outs["1"], ref) <= 6e-3 and rel(outs["1"], ref) <= 1.1 * rel(outs["0"], ref) + 1e-4, (rel(outs["1"], ref), rel(outs["0"], ref))
 
 
+@pytest.mark.parametrize("layout", ["sa", "sa_abs_ctr", "fp", "xyz_only"])
+def test_pair_decomposition_of_the_module_path(gpu_device, monkeypatch, layout):
+    """round 6, fp16 module path: a 1 x 1 convolution over a GROUPED input evaluated without the grouped matrix (slide_amd.rows.LazyGroup /
+    _pair_conv, SLIDE_OP_ROWS_PAIR_EXPAND: per-source-point feature table + fp32 coordinate terms) against the materialised form
+    (SLIDE_MODULE_PAIR=0: grouping kernel + GEMM) and an fp64 restatement of conv(QueryAndGroup / group_knn) (reference
+    pointnet2_utils.py:383-430, :497-524): raw / ReLU'd outputs, the per-tile channel sums handed to the following GroupNorm, cross-set
+    grouping (centres != sources), ragged last tile.  The pair form evaluates the coordinate channels in fp32 where the grouped matrix
+    held them in fp16: it is at least as close to the restatement as the materialised form."""
+    from slide_amd import rows as R
+    from slide_amd.nn_ops import HipConv1x1
+    monkeypatch.setenv("SLIDE_MODULE_PREC", "fp16")
+    d = gpu_device
+    gen = torch.Generator().manual_seed(21)
+    B, N, npnt, K, C, O = 3, 200, 72, 8, (0 if layout == "xyz_only" else 45), 70
+    xyz = torch.rand(B, N, 3, generator=gen).to(d) * 2 - 1
+    ctr = (torch.rand(B, npnt, 3, generator=gen).to(d) * 2 - 1) if layout != "sa" else xyz[:, :npnt].contiguous()
+    feat = torch.randn(B, C, N, generator=gen).to(d) if C else None
+    idx = torch.randint(0, N, (B, npnt, K), generator=gen).to(d)
+    flags = {"sa": 0, "sa_abs_ctr": R.GROUP_ABS | R.GROUP_CENTER, "fp": R.GROUP_FP, "xyz_only": R.GROUP_ABS}[layout]
+    d2 = (torch.rand(B, npnt, K, generator=gen).to(d) * 0.5 + 1e-3) if layout == "fp" else None
+    ncoord = 11 if layout == "fp" else 3 + (3 if flags & R.GROUP_ABS else 0) + (3 if flags & R.GROUP_CENTER else 0)
+    conv = _randomise(HipConv1x1(C + ncoord, O), d, seed=3)
+    # fp64 restatement
+    q = torch.gather(xyz.double(), 1, idx.reshape(B, -1, 1).expand(-1, -1, 3)).reshape(B, npnt, K, 3)
+    c = ctr.double()[:, :, None, :].expand(-1, -1, K, -1)
+    parts = []
+    if C:
+        parts.append(torch.gather(feat.double().transpose(1, 2), 1, idx.reshape(B, -1, 1).expand(-1, -1, C)).reshape(B, npnt, K, C))
+    if layout == "fp":
+        w = 1.0 / (d2.double() + 1e-8)
+        parts += [d2.double()[..., None], (w / w.sum(-1, keepdim=True))[..., None], q, q - c, c]
+    else:
+        parts.append(q - c)
+        if flags & R.GROUP_ABS:
+            parts.append(q)
+        if flags & R.GROUP_CENTER:
+            parts.append(c)
+    g = torch.cat(parts, -1)
+    W = conv.weight.double().reshape(O, -1)
+    ref = g @ W.T + conv.bias.double()
+    rel = lambda a, b: float(((a - b).norm() / b.norm()).detach())
+    for stats in (None, "raw", "relu"):
+        outs = {}
+        for v in ("1", "0"):
+            monkeypatch.setenv("SLIDE_MODULE_PAIR", v)
+            fr = R.from_ncx(feat) if C else None
+            gr = R.group(xyz, ctr, fr, idx, flags, d2=d2)
+            assert isinstance(gr, R.LazyGroup) == (v == "1")
+            y = R.conv(gr, conv, stats=stats)
+            assert (getattr(gr, "_buf", 0) is None) == (v == "1")  # the pair form never built the grouped matrix
+            outs[v] = (y.data.double()[:, :O].reshape(B, npnt, K, O), y.stats)
+        want = ref.relu() if stats == "relu" else ref
+        e1, e0 = rel(outs["1"][0], want), rel(outs["0"][0], want)
+        assert e1 <= 2e-3 and e1 <= 1.1 * e0 + 1e-4, (layout, stats, e1, e0)
+        if stats is not None and (npnt * K) % 256 == 0:
+            assert outs["1"][1] is not None
+    # tile statistics (samples of whole tiles): sums and sums of squares per 256-row tile
+    npnt2 = 64
+    idx2 = torch.randint(0, N, (B, npnt2, K), generator=gen).to(d)
+    ctr2 = torch.rand(B, npnt2, 3, generator=gen).to(d)
+    d22 = (torch.rand(B, npnt2, K, generator=gen).to(d) * 0.5 + 1e-3) if layout == "fp" else None
+    res = {}
+    for v in ("1", "0"):
+        monkeypatch.setenv("SLIDE_MODULE_PAIR", v)
+        y = R.conv(R.group(xyz, ctr2, R.from_ncx(feat) if C else None, idx2, flags, d2=d22), conv, stats="relu")
+        assert y.stats is not None and y.stats[2] is True
+        res[v] = (y.data.double(), y.stats[0].double(), y.stats[1].double())
+    t = res["1"][0].reshape(-1, 256, res["1"][0].shape[1])
+    assert rel(res["1"][1], t.sum(1)) <= 2e-3 and rel(res["1"][2], (t * t).sum(1)) <= 4e-3
+    assert rel(res["1"][1], res["0"][1]) <= 3e-3 and rel(res["1"][2], res["0"][2]) <= 6e-3
+
+
 def test_deferred_normalisation_matches_the_materialised_path(gpu_device, monkeypatch):
     """fp16 module path: a GroupNorm whose consumer is a GEMM is DEFERRED -- the producer's raw output stays in memory and the
     consumer's loader applies relu(x * scale + shift) + add from per-sample fp16 vectors in LDS (csrc/engine.hip, AFF
