@@ -187,7 +187,7 @@ enum {
   SLIDE_OP_ROWS_PAIR_EXPAND = 39, /* round 6 (fp16 rows): a 1 x 1 convolution over a GROUPED input without the grouped matrix -- out[(b, p, k)][c] =
                              * A[b*N + idx[b][p][k]][c] + bias[c] + coef[c][0..2] . xyz[neighbour] + coef[c][3..5] . xyz[centre] + coef[c][6] d2 +
                              * coef[c][7] w, A = the convolution's feature columns applied per SOURCE point (fp32 [B*N][ldA], or NULL without
-                             * features), coef = (W_rel + W_abs | W_centre - W_rel | w_d2 | w_w) per output channel, fp32 [ld][8]; flags: 1 = ReLU,
+                             * features), coef = (W_rel + W_abs: applied by the host program to A | W_centre - W_rel | w_d2 | w_w) per output channel, fp32 [ld][8]; flags: 1 = ReLU,
                              * 2 = group_knn slot scalars (d2, w = normalised inverse squared distance; p[6] = d2 (B, np, K)), 16 = idx is int32.
                              * p: A, bias [ld], coef, xyz (B,N,3), new_xyz (B,np,3), idx (B,np,K), d2 or NULL, out [B*np*K][ld], [8] / [9] per-256-row-
                              * tile channel sums / sums of squares of the (ReLU'd) output [rows/256][ld] or both NULL.  i: B, N, np, K, ld, ldA, flags */

@@ -506,17 +506,18 @@ __global__ __launch_bounds__(256) void rows_pool_kernel(int K, int C, int ldx, i
 // A 1 x 1 convolution over a GROUPED input is linear in [features of the neighbour | coordinate channels], and every coordinate
 // channel is linear in xyz[neighbour] and xyz[centre] (SA: rel | abs | centre; FP: d2 | w | abs | rel | centre: the layouts of
 // rows_group_kernel above), so its output for row (b, p, k) separates:
-//     y(b, p, k) = A[b][idx(b, p, k)]  +  bias  +  Cq . xyz[neighbour]  +  Cc . xyz[centre]  (+ wd d2 + ww w)
-// with A = W_features . features one row per SOURCE point (a GEMM on B * N rows instead of B * npoint * K: 1 / 64 of the MACs at
-// 1024 centres x 16 neighbours of 256 points), Cq = W_rel + W_abs, Cc = W_centre - W_rel.  This kernel builds y from the fp32 table A
+//     y(b, p, k) = A[b][idx(b, p, k)]  +  bias  +  Cc . xyz[centre]  (+ wd d2 + ww w)
+// with A = W_features . features + Cq . xyz one row per SOURCE point (a GEMM on B * N rows instead of B * npoint * K: 1 / 64 of the
+// MACs at 1024 centres x 16 neighbours of 256 points; the coordinate part added in fp32 by the host program), Cq = W_rel + W_abs,
+// Cc = W_centre - W_rel.  This kernel builds y from the fp32 table A
 // and the coordinates -- the grouped matrix (the widest tensor of a level) is never written or read, and the coordinate terms are
 // evaluated in fp32 from fp32 coordinates (the grouped matrix held them rounded to the activation type).  The pair decomposition of
 // the fused DDPM plan (gemm_gx.hip), for the module-level path's arbitrary N / npoint / K.
 // One workgroup per 256-row tile: thread r first derives row r's neighbour row, coordinates and slot scalars into LDS, then a thread
 // owns FOUR channels and walks its share of the rows (a wave reads 1 KB of one A row and writes 512 B of one output row per step);
 // ReLU (flags & 1) and the per-tile channel sums of the GroupNorm that follows (the GEMM epilogue's STATS mode) ride along.
-template <typename T>
-__global__ __launch_bounds__(256) void rows_pair_expand_kernel(int N, int np, int K, int ld, int ldA, int flags, size_t rows,
+template <typename T, int CH>  // CH = channels per thread: 8 (16-byte stores: wide rows) or 4 (more threads per row: narrow rows)
+__global__ __launch_bounds__(256) void rows_pair_expand_kernel(int N, int np, int K, int ld, int ldA, int flags, int tps, size_t rows,
                                                                const float *__restrict__ A, const float *__restrict__ bias,
                                                                const float *__restrict__ coef, const float *__restrict__ xyz,
                                                                const float *__restrict__ new_xyz, const void *__restrict__ idx,
@@ -526,7 +527,16 @@ __global__ __launch_bounds__(256) void rows_pair_expand_kernel(int N, int np, in
   __shared__ int rsrc[256];
   __shared__ float red[2][2048];
   const int tid = threadIdx.x;
-  const size_t row0 = (size_t)blockIdx.x * 256;
+  // XCD-aware tile map (samples of whole tiles): every tile of a sample runs on ONE XCD (workgroup id mod 8; for speed only), so the
+  // sample's table -- N x ld floats, gathered 16 x K / N times over -- stays in that XCD's L2 instead of being fetched by all eight
+  size_t tile = blockIdx.x;
+  if (tps > 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int smp = (j / tps) * 8 + xcd;
+    if ((size_t)smp * tps * 256 >= rows) return;
+    tile = (size_t)smp * tps + j % tps;
+  }
+  const size_t row0 = tile * 256;
   {
     const size_t row = row0 + tid;
     int src = -1;
@@ -551,62 +561,82 @@ __global__ __launch_bounds__(256) void rows_pair_expand_kernel(int N, int np, in
     *reinterpret_cast<float4 *>(&rs[tid][4]) = make_float4(v[4], v[5], v[6], v[7]);
   }
   __syncthreads();
-  const int pieces = ld >> 2;                       // 4-channel pieces per row (ld <= 1024)
+  const int pieces = ld / CH;                       // pieces per row (ld <= 1024, a multiple of 32)
   const int nsub = 256 / pieces > 0 ? 256 / pieces : 1;
-  const bool relu = (flags & 1) != 0, want_stats = st_sum != nullptr;
-  for (int p0 = 0; p0 < pieces; p0 += 256) {        // (one trip unless ld > 1024 / never: the launcher bounds ld)
-    const int pc = p0 + tid % (pieces < 256 ? pieces : 256), sub = tid / (pieces < 256 ? pieces : 256);
-    const bool active = pc < pieces && sub < nsub;
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
-    if (active) {
-      const int c0 = pc * 4;
-      float cf[4][8], bi[4];
+  const bool relu = (flags & 1) != 0, fp = (flags & 2) != 0, want_stats = st_sum != nullptr;
+  const int pc = tid % pieces, sub = tid / pieces;
+  const bool active = sub < nsub;
+  float s[CH], ss[CH];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 u0 = *reinterpret_cast<const float4 *>(coef + (size_t)(c0 + j) * 8);
-        const float4 u1 = *reinterpret_cast<const float4 *>(coef + (size_t)(c0 + j) * 8 + 4);
-        cf[j][0] = u0.x; cf[j][1] = u0.y; cf[j][2] = u0.z; cf[j][3] = u0.w; cf[j][4] = u1.x; cf[j][5] = u1.y; cf[j][6] = u1.z; cf[j][7] = u1.w;
-        bi[j] = bias[c0 + j];
+  for (int j = 0; j < CH; ++j) s[j] = ss[j] = 0.f;
+  if (active) {
+    const int c0 = pc * CH;
+    // coef[c] = (unused: the neighbour's coordinate term is part of A | Cc = W_centre - W_rel | w_d2 | w_w)
+    float cc[CH][3], wd[CH], ww[CH], bi[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const float4 u1 = *reinterpret_cast<const float4 *>(coef + (size_t)(c0 + j) * 8 + 4);
+      cc[j][0] = coef[(size_t)(c0 + j) * 8 + 3]; cc[j][1] = u1.x; cc[j][2] = u1.y; wd[j] = u1.z; ww[j] = u1.w;
+      bi[j] = bias[c0 + j];
+    }
+    // a thread's rows are CONSECUTIVE (chunk of the tile): the K neighbour rows of a point share the centre term
+    const int chunk = (256 + nsub - 1) / nsub, r_end = (sub + 1) * chunk < 256 ? (sub + 1) * chunk : 256;
+    float ct[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) ct[j] = 0.f;
+    float pcx = __builtin_nanf(""), pcy = 0.f, pcz = 0.f;
+    // four rows per trip: their table rows are requested together (a trip is one L2 round trip, not four)
+    constexpr int UB = 4;
+    for (int r8 = sub * chunk; r8 < r_end; r8 += UB) {
+      int src[UB];
+      float4 a4[UB][CH == 8 ? 2 : 1];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        src[u] = r8 + u < r_end ? rsrc[r8 + u] : -1;
+        const float *ap = A + (size_t)(src[u] < 0 ? 0 : src[u]) * ldA + c0;
+        a4[u][0] = *reinterpret_cast<const float4 *>(ap);
+        if (CH == 8) a4[u][1] = *reinterpret_cast<const float4 *>(ap + 4);
       }
-      for (int rr = sub; rr < 256; rr += nsub) {
-        const int src = rsrc[rr];
-        if (src < 0) break;  // (rows beyond the end of the matrix: the tail of the last tile)
-        const float4 a4 = A ? *reinterpret_cast<const float4 *>(A + (size_t)src * ldA + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 r0 = *reinterpret_cast<const float4 *>(&rs[rr][0]), r1 = *reinterpret_cast<const float4 *>(&rs[rr][4]);
-        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-        float y[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float t = av[j] + bi[j];
-          t = fmaf(cf[j][0], r0.x, t); t = fmaf(cf[j][1], r0.y, t); t = fmaf(cf[j][2], r0.z, t);
-          t = fmaf(cf[j][3], r0.w, t); t = fmaf(cf[j][4], r1.x, t); t = fmaf(cf[j][5], r1.y, t);
-          t = fmaf(cf[j][6], r1.z, t); t = fmaf(cf[j][7], r1.w, t);
-          if (relu) t = fmaxf(t, 0.f);
-          y[j] = t;
-          s[j] += t; ss[j] = fmaf(t, t, ss[j]);
+      for (int u = 0; u < UB; ++u) {
+        if (src[u] < 0) continue;  // (rows beyond the chunk / the end of the matrix)
+        const int rr = r8 + u;
+        const float4 r1 = *reinterpret_cast<const float4 *>(&rs[rr][4]);
+        const float cx = rs[rr][3];
+        if (!(cx == pcx && r1.x == pcy && r1.y == pcz)) {  // a new centre
+          pcx = cx; pcy = r1.x; pcz = r1.y;
+#pragma unroll
+          for (int j = 0; j < CH; ++j) ct[j] = fmaf(cc[j][2], pcz, fmaf(cc[j][1], pcy, fmaf(cc[j][0], pcx, bi[j])));
         }
-        Pack<T, 4> o;
+        float av[8] = {a4[u][0].x, a4[u][0].y, a4[u][0].z, a4[u][0].w, 0.f, 0.f, 0.f, 0.f};
+        if (CH == 8) { av[4] = a4[u][1].x; av[5] = a4[u][1].y; av[6] = a4[u][1].z; av[7] = a4[u][1].w; }
+        Pack<T, CH> o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o.v[j] = (T)y[j];
-        *reinterpret_cast<Pack<T, 4> *>(out + (row0 + rr) * ld + c0) = o;
+        for (int j = 0; j < CH; ++j) {
+          float t = av[j] + ct[j];
+          if (fp) t = fmaf(ww[j], r1.w, fmaf(wd[j], r1.z, t));
+          if (relu) t = fmaxf(t, 0.f);
+          s[j] += t; ss[j] = fmaf(t, t, ss[j]);
+          o.v[j] = (T)t;
+        }
+        *reinterpret_cast<Pack<T, CH> *>(out + (row0 + rr) * ld + c0) = o;
       }
     }
-    if (want_stats) {  // the tile's channel sums: the row subsets meet in LDS
-      __syncthreads();
-      if (active) {
+  }
+  if (want_stats) {  // the tile's channel sums: the row subsets meet in LDS
+    if (active) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          red[0][sub * (pieces * 4) + (pc - p0) * 4 + j] = s[j];
-          red[1][sub * (pieces * 4) + (pc - p0) * 4 + j] = ss[j];
-        }
+      for (int j = 0; j < CH; ++j) {
+        red[0][sub * ld + pc * CH + j] = s[j];
+        red[1][sub * ld + pc * CH + j] = ss[j];
       }
-      __syncthreads();
-      for (int c = tid; c < ld; c += 256) {
-        float a_ = 0.f, b_ = 0.f;
-        for (int u = 0; u < nsub; ++u) { a_ += red[0][u * ld + c]; b_ += red[1][u * ld + c]; }
-        st_sum[(size_t)blockIdx.x * ld + c] = a_;
-        st_sq[(size_t)blockIdx.x * ld + c] = b_;
-      }
+    }
+    __syncthreads();
+    for (int c = tid; c < ld; c += 256) {
+      float a_ = 0.f, b_ = 0.f;
+      for (int u = 0; u < nsub; ++u) { a_ += red[0][u * ld + c]; b_ += red[1][u * ld + c]; }
+      st_sum[tile * ld + c] = a_;
+      st_sq[tile * ld + c] = b_;
     }
   }
 }
@@ -690,15 +720,22 @@ int launch_rows(const SlideOp &o, hipStream_t s) {
     }
     case SLIDE_OP_ROWS_PAIR_EXPAND: {  // i: B, N, np, K, ld, ldA, flags   p: A, bias, coef, xyz, new_xyz, idx, d2, out, st_sum, st_sq
       const int B = o.i[0], N = o.i[1], np = o.i[2], K = o.i[3], ld = o.i[4], ldA = o.i[5], flags = o.i[6];
-      if (ld % 32 || ld <= 0 || ld > 1024 || (o.p[0] && (ldA % 4 || ldA < ld)) || !o.p[1] || !o.p[2] || !o.p[3] || !o.p[4] || !o.p[5] || !o.p[7] ||
+      if (ld % 32 || ld <= 0 || ld > 1024 || !o.p[0] || ldA % 4 || ldA < ld || !o.p[1] || !o.p[2] || !o.p[3] || !o.p[4] || !o.p[5] || !o.p[7] ||
           ((flags & 2) && !o.p[6]) || (!o.p[8]) != (!o.p[9]) || N <= 0 || K <= 0)
         return -3;
       if (std::is_same<T, float>::value) return -3;  // fp16 rows only
       const size_t rows = (size_t)B * np * K;
       if (rows == 0) return 0;
-      hipLaunchKernelGGL(rows_pair_expand_kernel<T>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, N, np, K, ld, ldA, flags, rows,
-                         (const float *)o.p[0], (const float *)o.p[1], (const float *)o.p[2], (const float *)o.p[3], (const float *)o.p[4],
-                         (const void *)o.p[5], (const float *)o.p[6], (T *)o.p[7], (float *)o.p[8], (float *)o.p[9]);
+      const int S = np * K, tps = S % 256 == 0 ? S / 256 : 0;  // 256-row tiles per sample (0: samples are not whole tiles -> linear map)
+      const unsigned grid = tps ? (unsigned)(8 * ((B + 7) / 8) * tps) : (unsigned)((rows + 255) / 256);
+      if (ld >= 256)
+        hipLaunchKernelGGL((rows_pair_expand_kernel<T, 8>), dim3(grid), dim3(256), 0, s, N, np, K, ld, ldA, flags, tps, rows,
+                           (const float *)o.p[0], (const float *)o.p[1], (const float *)o.p[2], (const float *)o.p[3], (const float *)o.p[4],
+                           (const void *)o.p[5], (const float *)o.p[6], (T *)o.p[7], (float *)o.p[8], (float *)o.p[9]);
+      else
+        hipLaunchKernelGGL((rows_pair_expand_kernel<T, 4>), dim3(grid), dim3(256), 0, s, N, np, K, ld, ldA, flags, tps, rows,
+                           (const float *)o.p[0], (const float *)o.p[1], (const float *)o.p[2], (const float *)o.p[3], (const float *)o.p[4],
+                           (const void *)o.p[5], (const float *)o.p[6], (T *)o.p[7], (float *)o.p[8], (float *)o.p[9]);
       break;
     }
     case SLIDE_OP_ROWS_POOL: {  // i: points, K, C, ldx, ldo, mode   p: x, out, counts

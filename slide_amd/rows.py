@@ -448,12 +448,17 @@ def _pair_conv(x, module, stats):
         plan = (key, fplan, bvec, _pair_coef(w2, C, flags, op_))
         module.__dict__["_rows_pair_plan"] = plan
     _, fplan, bvec, coef = plan
-    A = None
+    B, N = xyz.shape[:2]
+    # the per-source-point table, fp32 [B * N][op_]: W_features . features (fp16 operands, as the grouped GEMM had them) + the neighbour's
+    # coordinate term (W_rel + W_abs) . xyz in fp32
+    cq = coef[:, 0:3].t()
     if fplan is not None:
         if feat.pending is not None and not (feat.half and feat.S % 256 == 0):
             materialise(feat)
-        A = fplan.run(feat, out_f32=True).data  # fp32 [B * N][op_]: W_features . features, one row per source point
-    B, N = xyz.shape[:2]
+        A = fplan.run(feat, out_f32=True).data
+        A.addmm_(xyz.reshape(B * N, 3), cq)
+    else:
+        A = torch.mm(xyz.reshape(B * N, 3), cq)
     npnt, K = idx.shape[1:]
     rows = B * npnt * K
     out = _empty(rows, op_, True, dev)

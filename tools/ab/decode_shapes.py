@@ -16,10 +16,11 @@ def wrap(name, fn, nbytes):
     return w
 es = lambda r: r.data.element_size()
 R.norm_act = wrap("norm_act", R.norm_act, lambda a, k, o: (2 * a[0].rows * a[0].ld * es(a[0]), (a[0].rows, a[0].ld, len(a) > 1 and a[1] is not None)))
-R.conv = wrap("conv", R.conv, lambda a, k, o: ((a[0].rows * a[0].ld + o.rows * o.ld) * es(o), (a[0].rows, a[0].ld, o.ld)))
+R.conv = wrap("conv", R.conv, lambda a, k, o: ((a[0].rows * a[0].ld + o.rows * o.ld) * es(o), (a[0].rows, a[0].ld, o.ld, type(a[0]).__name__)))
 R.concat_qk = wrap("concat_qk", R.concat_qk, lambda a, k, o: ((a[1].rows * a[1].ld + o.rows * o.ld) * es(o), (o.rows, o.ld)))
 R.attend = wrap("attend", R.attend, lambda a, k, o: (2 * a[0].rows * a[0].ld * es(o), (a[0].rows, a[0].ld, a[2])))
-R.group = wrap("group", R.group, lambda a, k, o: (o.rows * o.ld * es(o), (o.rows, o.ld)))
+R._pair_conv = wrap("pair_conv", R._pair_conv, lambda a, k, o: (o.rows * o.ld * es(o), (o.rows, a[0].ld, o.ld, a[2])))
+R.group = wrap("group", R.group, lambda a, k, o: (0, (o.rows, o.ld, type(o).__name__)))
 R.conv_attend = wrap("conv_attend", R.conv_attend, lambda a, k, o: ((a[0].rows * a[0].ld + a[2].rows * a[2].ld + o.rows * o.ld) * es(o), (a[0].rows, a[0].ld, a[2].ld, a[3])))
 exec(open(os.path.join(REPO, "tools", "time_decode.py")).read().split("for _ in range(2):")[0].replace("REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))", ""))
 out = ae.decode(kp, feat, label=lab); torch.cuda.synchronize(); rec.clear()
