@@ -109,7 +109,7 @@ def _masked_stream_return(key, handle):
 
 
 class _GraphedSampler:
-    def __init__(self, hp, state_dict, batch, device, prec, use_graph, T, cu_share=0.0):
+    def __init__(self, hp, state_dict, batch, device, prec, use_graph, T, cu_share=0.0, stream=None):
         self.engine = DenoiserEngine(hp, state_dict, batch, device, prec=prec, per_sample_t=False, t_table=T)
         self.B, self.device = int(batch), device
         self.use_graph = use_graph
@@ -118,8 +118,15 @@ class _GraphedSampler:
         if os.environ.get("SLIDE_STREAM_PRIO"):
             pp = [int(v) for v in os.environ["SLIDE_STREAM_PRIO"].split(",")]
             prio = pp[0] if hp.get("in_fea_dim", 0) == 0 else pp[-1]
-        self.stream = torch.cuda.Stream(device=device, priority=prio) if prio else torch.cuda.Stream(device=device)
+        # stream: run this chain on an existing stream (a second sampler of one chain slot: the runtime maps streams onto the four
+        # hardware queues in creation order, so taking another pool stream would shift every later sampler's queue)
+        if stream is not None:
+            self.stream = stream
+        else:
+            self.stream = torch.cuda.Stream(device=device, priority=prio) if prio else torch.cuda.Stream(device=device)
         self._masked_stream, self.n_cus = None, 0
+        if stream is not None:
+            cu_share = 0.0
         # cu_share: run this chain's kernels on that fraction of the compute units only (SLIDE_POS_CUS / SLIDE_FEAT_CUS=<n> override it
         # for the position / feature chains; 0 = all).  The position chain beside the feature sub-batches is given 11/16 of the chip:
         # its wide split launches then never take EVERY CU from the latency-critical feature chains
@@ -337,8 +344,9 @@ class _GraphedSampler:
 class PositionSampler(_GraphedSampler):
     """sampling(net, (B,16,3), diffusion_hyperparams, label=...) -- pointnet2/util.py:197-259."""
 
-    def __init__(self, hp, state_dict, batch, device, diffusion_config, prec="fp32", noise=None, seed=0, use_graph=True, cu_share=0.0):
-        super().__init__(hp, state_dict, batch, device, prec, use_graph, diffusion_config["T"], cu_share=cu_share)
+    def __init__(self, hp, state_dict, batch, device, diffusion_config, prec="fp32", noise=None, seed=0, use_graph=True, cu_share=0.0,
+                 stream=None):
+        super().__init__(hp, state_dict, batch, device, prec, use_graph, diffusion_config["T"], cu_share=cu_share, stream=stream)
         e = self.engine
         dh = calc_diffusion_hyperparams(**diffusion_config)
         self.dh, self.T = dh, dh["T"]

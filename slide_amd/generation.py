@@ -324,10 +324,23 @@ class PipelinedGenerator:
         # row): start noise and in-kernel noise of a shape do not depend on ranks, batches or the sub-batch split
         self.seed, self.g0 = int(seed), int(global_offset)
         self.pos = self.feats = None
-        if pos is not None:
+        # bench.py's headline arrangement (round 6): with both DDPMs, fp16 feature chains and a wide position plan, the position chain
+        # runs over TWO batches at half cadence (one step per two rounds of the feature chains: same shapes per unit time, half the
+        # dependent launches beside the feature chains; SLIDE_POS_MULT=1 keeps one batch per chain).  The chains' per-sample arithmetic
+        # and noise streams do not depend on the batch they run in.
+        wide = (pos is not None and feat is not None and not serial and resolve_prec(prec)[0] != "fp16" and resolve_prec(prec)[1] == "fp16")
+        self.pos_mult = 2 if (wide and int(os.environ.get("SLIDE_POS_MULT", "2")) == 2) else 1
+        self._pos2 = None
+        if self.pos_mult == 2:
+            # (built BEFORE the feature samplers, and the one-batch position sampler runs on ITS stream: the runtime maps streams onto the
+            #  four hardware queues in creation order, and a position chain that lands on a feature chain's queue serialises with it --
+            #  244 instead of 370 shapes/s when a fifth stream shifted the feature chains' queues)
+            self._pos2 = PositionSampler(pos[0], pos[1], 2 * self.B, device, pos[2], prec=resolve_prec(prec)[0], seed=seed, use_graph=False,
+                                         cu_share=POS_CU_SHARE)
+        self._pos_args = (pos, prec, seed)
+        if pos is not None and self._pos2 is None:
             self.pos = PositionSampler(pos[0], pos[1], self.B, device, pos[2], prec=resolve_prec(prec)[0], seed=seed, use_graph=False,
-                                       cu_share=POS_CU_SHARE if (feat is not None and not serial and resolve_prec(prec)[0] != "fp16"
-                                                                 and resolve_prec(prec)[1] == "fp16") else 0.0)
+                                       cu_share=POS_CU_SHARE if wide else 0.0)
         self.sizes = []
         if feat is not None:
             self.sizes = sub_batch_sizes(self.B, n_sub)
@@ -335,10 +348,11 @@ class PipelinedGenerator:
                                          local_resampling=local_resampling) for i, b in enumerate(self.sizes)]
             self.cx = self.feats[0].engine.cx
         self._Eager = EagerChainsSampler
-        self.T = (self.pos or self.feats[0]).T
+        self.T = (self.pos or self._pos2 or self.feats[0]).T
         # one slide_run_chains call replays every chain of a group for the SAME number of steps: configurations whose
         # position and feature schedules differ in length advance chain by chain instead
         self._same_T = all(s_.T == self.T for s_ in ([self.pos] if self.pos is not None else []) + (self.feats or []))
+        self._have_pos = pos is not None
 
     def _advance(self, samplers):
         if not samplers:
@@ -362,6 +376,13 @@ class PipelinedGenerator:
         keypoints [n, 16, 3] when there is no position DDPM; extra: per-shape arrays handed to FeatureSampler.begin (local
         re-sampling).  Returns [n, 16, 3] / [n, 16, cx] on the device."""
         B, dev = self.B, self.device
+        if self.pos_mult == 2 and self._same_T and self.T % 2 == 0 and n > B:
+            return self._run_half_cadence(n, labels, extra)
+        if self.pos is None and self._have_pos:  # (a run of at most one batch on a generator built for pairs of batches)
+            from .diffusion import PositionSampler
+            pos, prec, seed = self._pos_args
+            self.pos = PositionSampler(pos[0], pos[1], B, dev, pos[2], prec=resolve_prec(prec)[0], seed=seed, use_graph=False,
+                                       stream=self._pos2.stream)
         x_T_pos = lambda lo, hi: start_noise(self.seed, 1, self.g0 + lo, self.g0 + lo + B, (16, 3), dev)
         x_T_feat = lambda lo, hi: start_noise(self.seed, 2, self.g0 + lo, self.g0 + lo + B, (16, self.cx), dev)
         labels = torch.as_tensor(np.asarray(labels), dtype=torch.int64, device=dev)
@@ -394,6 +415,53 @@ class PipelinedGenerator:
                     self._begin_feats(pad(labels[lo:hi], hi - lo), kp, x_T_feat(lo, hi), ex, self.g0 + lo)
                     pending = (lo, hi)
         return torch.cat(outs) if outs else torch.empty(0, 16, self.cx if self.feats else 3, device=dev)
+
+
+    def _run_half_cadence(self, n, labels, extra):
+        """run() for both DDPMs with the position chain over PAIRS of batches at half cadence (bench.py's headline arrangement).
+        Time is counted in groups of T rounds of feature steps: the position chain of pair k (batches 2k, 2k + 1) makes T / 2 steps in
+        each of the groups 2k and 2k + 1; the feature chains of batch j run in group j + 2, beside the position chain of the next pair."""
+        B, dev, T = self.B, self.device, self.T
+        pos2 = self._pos2
+        labels = torch.as_tensor(np.asarray(labels), dtype=torch.int64, device=dev)
+        padn = lambda t, m, cap: torch.cat([t, torch.zeros((cap - m,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)]) if m < cap else t
+        ranges = list(batches(0, n, B))
+        m = len(ranges)
+        npairs = (m + 1) // 2
+        outs = []
+        kp_pair = None     # key points of the pair whose feature chains are being fed
+        pending = None     # (lo, hi) of the batch whose feature chains are in flight
+        for g in range(2 * npairs + 2):
+            group, every = [], []
+            k = g // 2
+            if g % 2 == 0 and k < npairs:  # begin the position chain of pair k: shapes [lo, lo + 2 B) of the run
+                lo = ranges[2 * k][0]
+                hi = min(lo + 2 * B, n)
+                pos2.begin(padn(labels[lo:hi], hi - lo, 2 * B), start_noise(self.seed, 1, self.g0 + lo, self.g0 + lo + 2 * B, (16, 3), dev),
+                           nonce=1, sample_offset=self.g0 + lo)
+            if k < npairs:
+                group.append(pos2); every.append(2)
+            j = g - 2              # the batch whose feature chains run in this group
+            if 0 <= j < m:
+                lo, hi = ranges[j]
+                kp = kp_pair[(j % 2) * B:(j % 2 + 1) * B]
+                ex = {k_: padn(torch.as_tensor(v_[lo:hi], dtype=torch.float32, device=dev), hi - lo, B) for k_, v_ in (extra or {}).items()}
+                self._begin_feats(padn(labels[lo:hi], hi - lo, B), kp, start_noise(self.seed, 2, self.g0 + lo, self.g0 + lo + B, (16, self.cx), dev),
+                                  ex, self.g0 + lo)
+                pending = (lo, hi)
+                group = self.feats[:1] + group + self.feats[1:]   # (the order bench.py launches them in)
+                every = [1] + every + [1] * (len(self.feats) - 1)
+            if group:
+                self._Eager(group, every=every).advance(T)
+                for s_ in group:
+                    s_.stream.synchronize()
+            if pending is not None:
+                plo, phi = pending
+                outs.append(torch.cat([f_.state() for f_ in self.feats])[:phi - plo])
+                pending = None
+            if g % 2 == 1 and k < npairs:  # the pair's position chain has made its T steps
+                kp_pair = pos2.state()
+        return torch.cat(outs) if outs else torch.empty(0, 16, self.cx, device=dev)
 
 
 def save_generated(save_dir, points, labels, timing, num_points, keypoint=None, keypoint_feature=None, ckpt_info=""):
