@@ -741,7 +741,9 @@ def main():
             b = lambda v: "true" if v else "false"
             if o.kind == OP_ATTN_TAIL:  # (run_attn_tail: the register-X form unless SLIDE_TAIL_RX=0 or the values' chunk count is odd)
                 rx = os.environ.get("SLIDE_TAIL_RX", "1") != "0" and (o.i[4] // 32) % 4 == 0
-                return "attn_tail_%skernel<%d>" % ("rx_" if rx else "", o.i[6])
+                if rx:  # (second template argument: fragment-major u / mo, f[1] bit 4)
+                    return "attn_tail_rx_kernel<%d, %s>" % (o.i[6], b(int(o.f[1]) & 16))
+                return "attn_tail_kernel<%d>" % o.i[6]
             if o.kind != OP_GEMM:
                 return None
             rows, n_cob, npxl, cbw = o.i[0], o.i[3], o.i[4], o.i[7]

@@ -33,7 +33,15 @@ enum { SLIDE_F_PRE_RELU = 1, SLIDE_F_POST_RELU = 2, SLIDE_F_OUT_F32 = 4,
         * RES_PAIR: 16 x 16-row samples in NATURAL neighbour order (q = j; every point is a neighbour of every point).
         * RES_PAIR_NBR: 16 x 8-row samples, q = nbr[(sample*16 + p)*16 + j] (the GEMM op's neighbour table) and the two
         * per-row scalars of group_knn enter as + d2 * res_vd[c] + w * res_vw[c]. */
-       SLIDE_F_RES_PAIR = 8, SLIDE_F_RES_PAIR_NBR = 16 };
+       SLIDE_F_RES_PAIR = 8, SLIDE_F_RES_PAIR_NBR = 16,
+       /* FRAGMENT-MAJOR output (round 6; fp16 storage, 128- / 256-row samples): like chunk-major the block's 32 channels of
+        * the rows are one [rows][32] slab (out = slab base, out_ld == 32), but inside every 32-row group the 2 KB are ordered
+        * as the two MFMA operand fragments a consumer wave loads for that group: element (row, c) at
+        * (row & ~31)*32 + (c >> 4)*512 + ((c >> 3) & 1)*256 + (row & 31)*8 + (c & 7)  halves -- [k16 step][k half][row][8].
+        * A wave's global_load_dwordx4 of one fragment then reads 1 KB of CONSECUTIVE memory (chunk-major: 32 B of each of 32
+        * rows 64 B apart -- the request-bound pattern: 28 vs 44-49 B/clk/CU L2 -> VGPR, tools/lds_fill.hip XP / XF), and one
+        * epilogue store instruction writes 1 KB of it.  Consumer: SLIDE_OP_ATTN_TAIL with f[1] bit 4 (attn_tail_rx_kernel). */
+       SLIDE_F_OUT_FM = 32 };
 /* MFMA precision of a GEMM: exact fp32 (v_mfma_f32_32x32x2_f32) or fp16 inputs / fp32 accumulate
  * (v_mfma_f32_32x32x16_f16) */
 /* SLIDE_PREC_SPLIT (round 4): fp32 STORAGE (the fp32 plan: same ops, buffers and epilogues as SLIDE_PREC_F32), the contractions
@@ -89,7 +97,7 @@ enum {
   SLIDE_OP_ADVANCE_T = 12,  /* p: t_dev  (t_dev[0] -= 1; t_dev[1] += 1); t_dev = [t, step, blocks-done counter, chain nonce, global index of the first sample, 3 spare] (8 ints) */
   SLIDE_OP_SYNC = 14,       /* i: from_lane, to_lane -- lane `to` waits for everything issued so far on lane `from` */
   SLIDE_OP_GROUPNORM_NCHW = 13,/* p: x, gamma, beta, y (NCHW fp32)   i: B, C, HW, G, n_norm, relu  (module-level path) */
-  SLIDE_OP_ATTN_TAIL = 16,  /* fp16: scores GEMM + values GEMM (GroupNorm, ReLU) + softmax-weighted sum over the neighbours in one launch.  p: u, W5, mo, Wv, out, vec [bias_s | bias_v | gamma | beta][n_cob*32], [6] optional chunk-major copy of out [c/32][points][32] (a gather table of the next block: SLIDE_OP_GEMM f[2] == 32 reads p[8] that way), [7] optional copy of the first f[3] channels into another per-point buffer with leading dimension f[2]   i: rows, u_ld, k1, mo_ld, k2, n_cob, npx_log2, gs, n_norm, out_ld   f: 1 / (gs * rows per sample), [1] bit 0: both weight matrices chunk-major [k/32][n_cob*32][32] (u / mo are chunk-major [k/32][rows][32] when their ld is 32), bit 1: the two-stage-ring form at three workgroups per CU, bit 3 (round 5, csrc/gemm_gxs.hip attn_tail_split_kernel): SPLIT arithmetic -- u, mo and out are FLOAT rows, both weight matrices float row-major [n_cob*32][k], every contraction as two-term fp16 operand splits on one accumulator set (|w| < 32 required) */
+  SLIDE_OP_ATTN_TAIL = 16,  /* fp16: scores GEMM + values GEMM (GroupNorm, ReLU) + softmax-weighted sum over the neighbours in one launch.  p: u, W5, mo, Wv, out, vec [bias_s | bias_v | gamma | beta][n_cob*32], [6] optional chunk-major copy of out [c/32][points][32] (a gather table of the next block: SLIDE_OP_GEMM f[2] == 32 reads p[8] that way), [7] optional copy of the first f[3] channels into another per-point buffer with leading dimension f[2]   i: rows, u_ld, k1, mo_ld, k2, n_cob, npx_log2, gs, n_norm, out_ld   f: 1 / (gs * rows per sample), [1] bit 0: both weight matrices chunk-major [k/32][n_cob*32][32] (u / mo are chunk-major [k/32][rows][32] when their ld is 32), bit 1: the two-stage-ring form at three workgroups per CU, bit 3 (round 5, csrc/gemm_gxs.hip attn_tail_split_kernel): SPLIT arithmetic -- u, mo and out are FLOAT rows, both weight matrices float row-major [n_cob*32][k], every contraction as two-term fp16 operand splits on one accumulator set (|w| < 32 required), bit 4 (round 6): u and mo are FRAGMENT-major (SLIDE_F_OUT_FM; register-X kernel only: the launcher refuses other forms) */
   SLIDE_OP_GEMM_GX = 17,    /* fp16 "generated-X" GEMM of the pair decomposition (gemm_gx.hip): the first layer of an SA / FP
                              * block is linear in [neighbour features | coordinates], so its output for row (point p, slot j) is ta[q] + tb[p]
                              * (q = the slot's neighbour) -- the 256- / 128-row activation this GEMM consumes is never stored: a workgroup keeps
@@ -129,7 +137,7 @@ enum {
                              *    ([bias | gamma | beta][n] fp32), [8] add0 fp32 [idx*add0_stride + b*add0_bs + k] or NULL, [9] idx or NULL,
                              *    [10] add1 fp32 [b*add1_bs + c] or NULL, [11] out [n2/32][B*256][32] fp16
                              * i: B, t_ld, k1, n1 (128 | 256), n2 (multiple of 256), gs1, gs2 (GroupNorm group sizes 4 | 8 | 16), add0_stride,
-                             *    add0_bs, add1_bs      f: 1 / (gs1 * 256), 1 / (gs2 * 256) */
+                             *    add0_bs, add1_bs      f: 1 / (gs1 * 256), 1 / (gs2 * 256), [2] != 0 (round 6): out is FRAGMENT-major (SLIDE_F_OUT_FM) */
   SLIDE_OP_PAIR_FIRST = 31, /* the per-point GEMM of a block's pair decomposition AND its pair-table pass (SLIDE_OP_PAIR_NORM version 1) in one
                              * launch: y = W . feat + bias never goes through memory.  The channel blocks [0, pair_cob0) are ordinary segments
                              * (the attention queries riding on the launch: common epilogue, SlideEpi as for SLIDE_OP_GEMM); the blocks from

@@ -748,6 +748,7 @@ struct AttnTailArgs {
   unsigned long long *dbg;        // optional per-workgroup timeline (instrumented builds)
   int abl;                        // timing ablations of attn_tail8_kernel (tools only): 1 no DMA, 2 no fragment reads, 3 no MFMA
   int w_cm;                       // both weight matrices are chunk-major [k / 32][n_cob * 32][32] (u / mo are when their ld is 32)
+  int x_fm;                       // u / mo are FRAGMENT-major (SLIDE_F_OUT_FM, include/slide_engine.h; register-X kernel only)
   float inv_count;
 };
 
@@ -966,7 +967,10 @@ constexpr int RXD = 4;
 // WC = 2 (eight waves, tile 256 rows x 128 channels: wave (wr, wc) owns rows 64 wr .. and the channel half wc, a row block's fragments
 // are requested by two waves) was measured and is not instantiated: 76.5 us per feature step's two SA tails against 64.4 (WC = 1) and
 // 67.0 (ring form) -- the second request is not free, and one eight-wave workgroup per CU overlaps less than two of four.
-template <int NPXL, int WC>
+// FM (round 6): u / mo FRAGMENT-major -- inside a 32-row group the chunk's 2 KB are [k16 step][k half][row][8 halves], i.e. the two
+// A fragments of the group as the wave's lanes hold them: each global_load_dwordx4 below then reads 1 KB of consecutive memory instead
+// of 32 B from each of 32 rows 64 B apart (the request-bound pattern; tools/lds_fill.hip XP vs XF: 28 -> 44-49 B/clk/CU into VGPRs).
+template <int NPXL, int WC, bool FM>
 __device__ __forceinline__ void attn_tail_rx_body(const AttnTailArgs &a) {
   using T = _Float16;
   constexpr int CBW = 2, CBWT = CBW * WC, NSTW = RXD + 1, WSTAGE = 64 * WC * 64;
@@ -1005,8 +1009,9 @@ __device__ __forceinline__ void attn_tail_rx_body(const AttnTailArgs &a) {
   for (int rb = 0; rb < 2; ++rb) {
     int grow = row0 + wr * 64 + rb * 32 + col;
     grow = grow < a.rows ? grow : a.rows - 1;
-    x2p[rb] = reinterpret_cast<const T *>(a.X2) + (size_t)grow * a.x2_ld + half * 8;
-    x1p[rb] = reinterpret_cast<const T *>(a.X1) + (size_t)grow * a.x1_ld + half * 8;
+    const size_t fmo = (size_t)(grow & ~31) * 32 + half * 256 + (grow & 31) * 8;
+    x2p[rb] = reinterpret_cast<const T *>(a.X2) + (FM ? fmo : (size_t)grow * a.x2_ld + half * 8);
+    x1p[rb] = reinterpret_cast<const T *>(a.X1) + (FM ? fmo : (size_t)grow * a.x1_ld + half * 8);
   }
   const int nk2 = a.k2 / 32, total = nk2 + a.k1 / 32;
   f16x8 xq[RXD][2][2];
@@ -1029,7 +1034,8 @@ __device__ __forceinline__ void attn_tail_rx_body(const AttnTailArgs &a) {
       // (asm: hipcc's wait-count insertion answers ANY register load pending beside an LDS-DMA load with vmcnt(0) -- the two may
       //  return out of order for all it knows -- which drains the pipeline once per round; these loads are waited for by hand)
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x[rb][0]) : "v"(xp) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(x[rb][1]) : "v"(xp) : "memory");
+      if constexpr (FM) asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(x[rb][1]) : "v"(xp) : "memory");
+      else asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(x[rb][1]) : "v"(xp) : "memory");
     }
     __builtin_amdgcn_global_load_lds(reinterpret_cast<const GLOBAL_AS void *>(wp),
                                      (__attribute__((address_space(3))) void *)(smem_raw + (size_t)(c % NSTW) * WSTAGE + wave * 1024), 16, 0, 0);
@@ -1283,9 +1289,9 @@ __global__ __launch_bounds__(256, 2) void attn_tail_kernel(AttnTailArgs a) {
   attn_tail_body<NPXL, SLIDE_ATTN_NST>(a);
 }
 
-template <int NPXL>
+template <int NPXL, bool FM>
 __global__ __launch_bounds__(256, 2) void attn_tail_rx_kernel(AttnTailArgs a) {
-  attn_tail_rx_body<NPXL, 1>(a);
+  attn_tail_rx_body<NPXL, 1, FM>(a);
 }
 
 // the same tile on a TWO-stage ring (41 KB) inside the 168-register budget: three workgroups per CU instead of two
@@ -2424,6 +2430,7 @@ int run_attn_tail(const SlideOp &o, hipStream_t s) {
   a.gs = o.i[7]; a.n_norm = o.i[8]; a.out_ld = o.i[9];
   a.inv_count = o.f[0];
   a.w_cm = ((int)o.f[1] & 1) != 0;
+  a.x_fm = ((int)o.f[1] & 16) != 0;
   static const int tail_abl = [] { const char *e = getenv("SLIDE_TAIL_ABL"); return e ? atoi(e) : 0; }();
   a.abl = tail_abl;
   const int npxl = o.i[6];
@@ -2476,10 +2483,17 @@ int run_attn_tail(const SlideOp &o, hipStream_t s) {
   static const int tail_rx = [] { const char *e = getenv("SLIDE_TAIL_RX"); return e ? atoi(e) : 1; }();
   if (tail_rx && (npxl == 7 || npxl == 8) && (a.k2 / 32) % RXD == 0) {  // X fragments through registers (attn_tail_rx_kernel)
     const size_t shmr = (size_t)(RXD + 1) * 64 * 64 + 4 * 2 * 32 * 4 + 4 * 2 * 32 * 2 * 4;
-    if (npxl == 8) hipLaunchKernelGGL(attn_tail_rx_kernel<8>, dim3(grid), dim3(256), shmr, s, a);
-    else hipLaunchKernelGGL(attn_tail_rx_kernel<7>, dim3(grid), dim3(256), shmr, s, a);
+    if (a.x_fm) {
+      if (a.x1_ld != 32 || a.x2_ld != 32 || a.rows % 32) return -3;
+      if (npxl == 8) hipLaunchKernelGGL((attn_tail_rx_kernel<8, true>), dim3(grid), dim3(256), shmr, s, a);
+      else hipLaunchKernelGGL((attn_tail_rx_kernel<7, true>), dim3(grid), dim3(256), shmr, s, a);
+      return (int)hipGetLastError();
+    }
+    if (npxl == 8) hipLaunchKernelGGL((attn_tail_rx_kernel<8, false>), dim3(grid), dim3(256), shmr, s, a);
+    else hipLaunchKernelGGL((attn_tail_rx_kernel<7, false>), dim3(grid), dim3(256), shmr, s, a);
     return (int)hipGetLastError();
   }
+  if (a.x_fm) return -3;  // fragment-major u / mo: only the register-X kernel reads that layout
   const size_t shm = (size_t)SLIDE_ATTN_NST * (TM + 64) * 64 + 4 * 2 * 32 * 4 + 64;
   static bool attr_done[SLIDE_MAX_DEVICES] = {};
   bool &attr_set = attr_done[current_device_slot()];

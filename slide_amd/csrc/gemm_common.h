@@ -249,7 +249,9 @@ __device__ __forceinline__ void attend_epilogue(const GemmArgs &a, f32x16 (&acc)
 // next layer on them (gemm_gxs.hip)
 // NOADDV: LEAN instantiation for a layer that is known to be "GroupNorm epilogue, no add vector, no per-point pre-activation term"
 // (the chained rest_mlp of gemm_gxs.hip): the STATS / RAW paths and the add-vector row registers are compiled out
-template <int PREC, int NPXL, int CBW, int RB = 2, bool PAIRRES = false, bool KEEP = false, bool NOADDV = false>
+// FMOK: the instantiation can store FRAGMENT-major blocks (SLIDE_F_OUT_FM; the generated-X kernels of gemm_gx.hip, whose outputs u / mo
+// the register-X attention tail reads) -- a template parameter for the same reason as PAIRRES
+template <int PREC, int NPXL, int CBW, int RB = 2, bool PAIRRES = false, bool KEEP = false, bool NOADDV = false, bool FMOK = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[CBW][RB], int row0, int cob0, int wave,
                                               int half, int col, const uint32_t *epi_lds, const float *vec_lds,
                                               float *red) {
@@ -668,6 +670,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
       for (int rb = 0; rb < RB; ++rb) {
         const int row = row0 + wave * 64 + rb * 32 + col;
         const bool ok = row < a.rows;  // identical in both lane halves
+        // 16-byte piece (p, half) of this lane's row: row-major / chunk-major rows, or FRAGMENT-major (SLIDE_F_OUT_FM: the 32-row
+        // group's 2 KB as [p][half][row][8 halves] -- the 64 lanes of one store instruction write 1 KB of consecutive memory)
+        // (row = a wave-uniform multiple of 32 + col: the group's base is SCALAR arithmetic, the lane's part one register for both rb)
+        const bool fm = FMOK && (flags & SLIDE_F_OUT_FM) != 0;
+        const int rbase = __builtin_amdgcn_readfirstlane(row0 + wave * 64) + rb * 32;
+        const size_t o16 = (size_t)rbase * (fm ? 32 : e_out_ld) + (fm ? half * 256 + col * 8 : col * e_out_ld + 8 * half);
+        const int o16p = fm ? 512 : 16;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {  // quads 2p and 2p+1
           if constexpr (kHalf) if (wide16) {
@@ -679,9 +688,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
             lane32_swap(ua1, ub1);
             u32x4 o = {ua0, ua1, ub0, ub1};
 #if !defined(SLIDE_ABL) || SLIDE_ABL != 1
-            if (ok) *(GLOBAL_AS u32x4 *)(gptr<_Float16>(e_out) + (size_t)row * e_out_ld + 16 * p + 8 * half) = o;
+            if (ok) *(GLOBAL_AS u32x4 *)(gptr<_Float16>(e_out) + o16 + o16p * p) = o;
 #else
-            if (ok && o[0] == 0x12345678u) *(GLOBAL_AS u32x4 *)(gptr<_Float16>(e_out) + (size_t)row * e_out_ld + 16 * p + 8 * half) = o;
+            if (ok && o[0] == 0x12345678u) *(GLOBAL_AS u32x4 *)(gptr<_Float16>(e_out) + o16 + o16p * p) = o;
 #endif
             continue;
           }

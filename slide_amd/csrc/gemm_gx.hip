@@ -275,7 +275,7 @@ __device__ __forceinline__ void gemm_gx_body(const GemmArgs &a, const int bid) {
   }
   __syncthreads();  // every wave is done with the ring before `red` reuses it
   SLIDE_STAMP(a, 2);
-  gemm_epilogue<SLIDE_PREC_F16, NPXL, CBW, 2, MODE == 0>(a, acc, row0, cob0, wave, half, col, epi_lds, vec_lds,  // (mode 0 = the Mlp layers: PAIR residual)
+  gemm_epilogue<SLIDE_PREC_F16, NPXL, CBW, 2, MODE == 0, false, false, true>(a, acc, row0, cob0, wave, half, col, epi_lds, vec_lds,  // (mode 0 = the Mlp layers: PAIR residual)
                                            reinterpret_cast<float *>(smem_raw));
   SLIDE_STAMP(a, 5);
 #ifdef SLIDE_TIMELINE
@@ -679,6 +679,7 @@ struct F1Args {
   unsigned long long *dbg;
   int B, t_ld, k1, n1, n2, gs1, gs2, add0_stride, add0_bs, add1_bs;
   float inv1, inv2;
+  int out_fm;  // round 6: out is fragment-major (SLIDE_F_OUT_FM)
   int nsplit;  // round 6: workgroups per sample (1 | 2): each takes n2 / 256 / nsplit of the stage-2 slabs (stage 1 is computed by all)
 };
 
@@ -1008,8 +1009,9 @@ __device__ __forceinline__ void sa_chain_body(const F1Args &a, const int bid) {
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const f16x8 y = o[p] + (ra4[p] + rb4[p]);
-        *reinterpret_cast<u32x4 *>(reinterpret_cast<T *>(a.out) + ((size_t)((cg >> 5)) * R + row) * 32 + 16 * p + 8 * half) =
-            __builtin_bit_cast(u32x4, y);
+        // (chunk-major rows, or FRAGMENT-major: SLIDE_F_OUT_FM, include/slide_engine.h -- 1 KB of consecutive memory per instruction)
+        const size_t o16 = a.out_fm ? (size_t)(row & ~31) * 32 + p * 512 + half * 256 + (row & 31) * 8 : (size_t)row * 32 + 16 * p + 8 * half;
+        *reinterpret_cast<u32x4 *>(reinterpret_cast<T *>(a.out) + (size_t)(cg >> 5) * R * 32 + o16) = __builtin_bit_cast(u32x4, y);
       }
     }
     F1_STAMP(5 + 3 * sli);
@@ -1053,6 +1055,7 @@ static int sa_args_from_op(const SlideOp &o, F1Args &a, size_t &shm) {
   a.B = o.i[0]; a.t_ld = o.i[1]; a.k1 = o.i[2]; a.n1 = o.i[3]; a.n2 = o.i[4]; a.gs1 = o.i[5]; a.gs2 = o.i[6];
   a.add0_stride = o.i[7]; a.add0_bs = o.i[8]; a.add1_bs = o.i[9];
   a.inv1 = o.f[0]; a.inv2 = o.f[1];
+  a.out_fm = o.f[2] != 0.f;
   // OPT-IN (SLIDE_SA_SPLIT_MAX=<samples>: two workgroups per sample for launches of at most that many samples).  Measured in bench.py's
   // arrangement (tools/ab/r06_split.sh, three alternating pairs, --steps 300): 379.1 shapes/s with the split at 88 samples per launch
   // against 387.5 without -- the launch itself gets shorter, but the arrangement is bound by CU-time, not by this launch's latency,

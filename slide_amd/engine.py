@@ -18,7 +18,7 @@ import torch
 from ._lib import SlideHipError, check, lib
 
 EPI_RAW, EPI_NORM, EPI_STATS = 0, 1, 2
-F_PRE_RELU, F_POST_RELU, F_OUT_F32, F_RES_PAIR, F_RES_PAIR_NBR = 1, 2, 4, 8, 16
+F_PRE_RELU, F_POST_RELU, F_OUT_F32, F_RES_PAIR, F_RES_PAIR_NBR, F_OUT_FM = 1, 2, 4, 8, 16, 32
 # "split": the fp32 plan (float storage, same ops) with its contractions on the fp16 matrix pipe as two-term operand splits --
 # fp32-grade results (include/slide_engine.h: SLIDE_PREC_SPLIT)
 PREC = {"fp32": 0, "fp16": 1, "split": 2}
@@ -176,6 +176,7 @@ class DenoiserEngine:
     use_gx = False
     use_gxs = False
     _cm = frozenset()
+    _fm = frozenset()
     _cm_copy = {}
 
     def __init__(self, hp, state_dict, batch, device, prec="fp32", per_sample_t=True, t_table=0):
@@ -225,6 +226,7 @@ class DenoiserEngine:
                               "(SLIDE_GXS=0 behaviour)" % wmax)
                 self.use_gxs = False
         self._cm = set()
+        self._fm = set()  # chunk-major buffers whose 32-row groups are fragment-major (_tail_fm)
         self._cm_copy = {}  # per-point table (data_ptr) -> its chunk-major copy, written by the table's producer as well
         self.ops = []
         self._w16 = {}
@@ -240,7 +242,7 @@ class DenoiserEngine:
         w = self.sd[name]
         return w.reshape(w.shape[0], -1)
 
-    def _buf(self, rows, ch, dtype=None, cm=False):
+    def _buf(self, rows, ch, dtype=None, cm=False, fm=False):
         """activation matrix [rows][ld].  cm=True (fp16 LDS-DMA plans): CHUNK-MAJOR storage [ld / 32][rows][32] -- the same
         bytes, but the 64-byte piece a ring kernel's DMA lane group fetches for row r + 1 follows the one of row r, so one
         LDS-DMA instruction reads 1 KB of consecutive memory (2.2x the L2 -> LDS rate, tools/lds_fill.hip) and one epilogue
@@ -249,10 +251,34 @@ class DenoiserEngine:
         t = self.A.zeros(rows, ru(ch), dtype=self.adt if dtype is None else dtype)
         if cm and self.use_cm:
             self._cm.add(t.data_ptr())
+            if fm:
+                assert t.dtype == torch.float16 and rows % 32 == 0
+                self._fm.add(t.data_ptr())
         return t
 
     def _is_cm(self, t):
         return t.data_ptr() in self._cm
+
+    def _is_fm(self, t):
+        return t.data_ptr() in self._fm
+
+    def _tail_fm(self, mpfx, apfx, npx_log2, n_mo):
+        """round 6: are the K-expanded inputs u / mo of this attention block's fused tail stored FRAGMENT-major (SLIDE_F_OUT_FM,
+        include/slide_engine.h: a chunk-major slab whose 32-row groups are ordered as the MFMA fragments the register-X tail
+        kernel loads -- 1 KB of consecutive memory per wave load)?  Exactly when run_attn_tail (csrc/engine.hip) picks
+        attn_tail_rx_kernel for it: fp16 pair-decomposition plan (its generated-X kernels and the SA chain are the producers that
+        can store the layout), fused tail, values' chunk count a multiple of 4, none
+        of the opt-in tail forms.  SLIDE_FM=0: chunk-major u / mo (A/B)."""
+        env = os.environ.get
+        cout = self.sd[apfx + ".weight_conv.5.weight"].shape[0]
+        # mo's producer must be one that stores the layout: the generated-X GEMM of a two-layer Mlp, or the SA chain -- a rest_mlp
+        # outside the chain is a ring GEMM over a stored h2 (engine.hip: its epilogue instantiations do not carry the layout)
+        if (mpfx + ".rest_mlp.0.weight") in self.sd and not self._sa_chain_shapes(mpfx, npx_log2):
+            return False
+        return bool(self.use_cm and self.use_gx and self.prec == 1 and self.use_glds and env("SLIDE_FM", "1") != "0"
+                    and env("SLIDE_ATTN_TAIL", "1") != "0" and env("SLIDE_TAIL_RX", "1") != "0" and env("SLIDE_TAIL8", "0") == "0"
+                    and env("SLIDE_TAIL_OCC3", "0") == "0" and "SLIDE_TAIL_WIDE" not in os.environ and env("SLIDE_BODY", "0") == "0"
+                    and npx_log2 in (7, 8) and (ru(n_mo) // 32) % 4 == 0 and np.array_equal(gn_layout(cout)[0], np.arange(cout)))
 
     def _ldp(self, t):
         """leading dimension as the kernels see it"""
@@ -306,6 +332,7 @@ class DenoiserEngine:
             rows, ld = X.shape
             x_ld = self._ldp(X)
             assert not self._is_cm(X) or (npx_log2 >= 7 and gather is None)
+            assert not self._is_fm(X), "fragment-major buffers are read by the register-X attention tail only"
         if gather is not None:  # (feature table, neighbour table, K, chunks read from the table): X holds the remaining columns
             ld = gather[3] * 32 + ld
         npx = 1 << npx_log2
@@ -356,6 +383,9 @@ class DenoiserEngine:
                     flags |= F_OUT_F32
                 else:
                     assert out.dtype == self.adt
+                if self._is_fm(out):
+                    assert self.prec == 1 and npx_log2 >= 7 and out.dtype == torch.float16
+                    flags |= F_OUT_FM
             for j in range(Opad // 32):
                 e = epis[blk]
                 e.mode = sg.get("mode", EPI_RAW)
@@ -655,20 +685,32 @@ class DenoiserEngine:
             seg["out_coff"] = final_coff
             first_gemm(seg)
 
+    def _sa_chain_shapes(self, pfx, npx_log2):
+        """does SLIDE_OP_SA_CHAIN cover this Mlp's second_mlp -> rest_mlp (widths, identity GroupNorm layouts, group sizes)?"""
+        sd = self.sd
+        if (npx_log2 != 8 or os.environ.get("SLIDE_SA_CHAIN", "1") == "0" or self.prec != 1 or not self.use_gx
+                or (pfx + ".rest_mlp.0.weight") not in sd):
+            return False
+        c1 = sd[pfx + ".first_mlp.0.weight"].shape[0]
+        c2 = sd[pfx + ".second_mlp.0.weight"].shape[0]
+        c3 = sd[pfx + ".rest_mlp.0.weight"].shape[0]
+        l1, l2, l3 = gn_layout(c1), gn_layout(c2), gn_layout(c3)
+        ident = lambda l, c: np.array_equal(l[0], np.arange(c)) and l[1] == c and l[2] == c
+        return bool(c2 in (128, 256) and c3 % 256 == 0 and c1 % 64 == 0 and ident(l1, c1) and ident(l2, c2) and ident(l3, c3)
+                    and l2[3] in (4, 8, 16) and l3[3] in (4, 8, 16))
+
     def _sa_chain(self, pfx, npx_log2, pair, cvec, seg, final_out, final_coff):
         """second_mlp -> rest_mlp of an SA block as ONE launch (SLIDE_OP_SA_CHAIN, csrc/gemm_gx.hip: h2 stays in registers).
         Returns False when the shapes are outside what the kernel covers (the two-launch path then runs)."""
         sd, B = self.sd, self.B
-        if npx_log2 != 8 or os.environ.get("SLIDE_SA_CHAIN", "1") == "0" or pair["vv"] is not None or self.prec != 1:
+        if pair["vv"] is not None or not self._sa_chain_shapes(pfx, npx_log2):
             return False
         w1, w2 = self._w(pfx + ".second_mlp.0.weight"), self._w(pfx + ".rest_mlp.0.weight")
         c2, c1 = w1.shape
         c3 = w2.shape[0]
         lay1, l2, l3 = pair["lay1"], gn_layout(c2), gn_layout(c3)
-        ident = lambda l, c: np.array_equal(l[0], np.arange(c)) and l[1] == c and l[2] == c
-        if not (c2 in (128, 256) and c3 % 256 == 0 and c1 % 64 == 0 and ident(lay1, c1) and ident(l2, c2) and ident(l3, c3)
-                and l2[3] in (4, 8, 16) and l3[3] in (4, 8, 16) and self._is_cm(final_out) and final_coff == 0
-                and final_out.shape[1] == c3):
+        assert np.array_equal(lay1[0], np.arange(c1)) and lay1[1] == c1
+        if not (self._is_cm(final_out) and final_coff == 0 and final_out.shape[1] == c3):
             return False
         cm = lambda w: np.ascontiguousarray(w.reshape(w.shape[0], -1, 32).transpose(1, 0, 2))
         vec = lambda b_, g_, bt_: np.stack([b_, g_, bt_]).astype(np.float32)
@@ -687,7 +729,7 @@ class DenoiserEngine:
         self._emit(make_op(OP_SA_CHAIN,
                            i=(B, ta.shape[1], c1, c2, c3, l2[3], l3[3], 0 if add0 is None else add0[4], 0 if add0 is None else add0[2],
                               0 if add1 is None else add1[2]),
-                           f=(1.0 / (l2[4] * 256), 1.0 / (l3[4] * 256)),
+                           f=(1.0 / (l2[4] * 256), 1.0 / (l3[4] * 256), 1.0 if self._is_fm(final_out) else 0.0),
                            p=(ta.data_ptr() + 2 * pair["off1"], tb.data_ptr() + 2 * pair["off1"],
                               ta.data_ptr() + 2 * pair["offr"], tb.data_ptr() + 2 * pair["offr"],
                               d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
@@ -1122,7 +1164,7 @@ class DenoiserEngine:
                             cout=cout, inter=inter)
                 return ("body",)
             # neighbour half: u = GN4(relu(W2[:, C1:] . GN(relu(k)) + bias + P[point]))
-            u = self._buf(rows, ru(lay[1]), cm=True)
+            u = self._buf(rows, ru(lay[1]), cm=True, fm=self._is_fm(mo))
             useg = dict(w=w2[:, C1:], bias=sd[apfx + ".weight_conv.2.bias"], mode=EPI_NORM,
                         flags=F_PRE_RELU, layout=lay, out=u, pre_add=(P, kshift),
                         gn=(sd[apfx + ".weight_conv.4.group_norm.weight"], sd[apfx + ".weight_conv.4.group_norm.bias"]))
@@ -1172,6 +1214,7 @@ class DenoiserEngine:
                 if self.prec != 1:
                     self.kernel_names[len(self.ops)] = "attn_tail_split_kernel<%d>" % npx_log2
                 assert out.dtype == self.adt and u.dtype == self.adt and mo.dtype == self.adt and not self._is_cm(out)
+                assert self._is_fm(u) == self._is_fm(mo)
                 self._sync(1, 0)
                 self.flops += 2 * rows * (w5.size + wv.size)
                 self.gemm_flops[len(self.ops)] = 2 * rows * cout * (len(lay[0]) + wv_l.shape[1])  # logical channels
@@ -1185,7 +1228,8 @@ class DenoiserEngine:
                                         # SLIDE_TAIL_OCC3=1: measured neutral, 373.0 vs 372.3 shapes/s)
                                         f=(1.0 / (vlay[4] * npx), (1.0 if self.use_cm else 0.0) + (8.0 if self.prec != 1 else 0.0) +
                                            (2.0 if os.environ.get("SLIDE_TAIL_OCC3", "0") != "0" else 0.0) +
-                                           (4.0 if (Cp // 32) % 4 == 0 and Cp // 32 >= int(os.environ.get("SLIDE_TAIL_WIDE", "1000")) else 0.0)),
+                                           (4.0 if (Cp // 32) % 4 == 0 and Cp // 32 >= int(os.environ.get("SLIDE_TAIL_WIDE", "1000")) else 0.0) +
+                                           (16.0 if self._is_fm(mo) else 0.0)),  # bit 4: u / mo fragment-major
                                         p=(u.data_ptr(), d[0].data_ptr(), mo.data_ptr(), d[1].data_ptr(), out.data_ptr(),
                                            d[2].data_ptr(), None if out_cm is None else out_cm.data_ptr())))
                 return
@@ -1231,7 +1275,7 @@ class DenoiserEngine:
         assert sd[mp + ".first_mlp.0.weight"].shape[1] == Cg
         c1 = sd[mp + ".first_mlp.0.weight"].shape[0]
         c_last = sd[mp + ".res_connect.weight"].shape[0]
-        mo = self._buf(rows, c_last, cm=True)
+        mo = self._buf(rows, c_last, cm=True, fm=self._tail_fm(mp, ap, 8, c_last))
         out = self._buf(B * 16, c_last)
         if self.use_gx or self.use_gxs:
             # pair decomposition (csrc/gemm_gx.hip): no grouped input, no h1 / r / key buffers; rows in natural neighbour order
@@ -1267,7 +1311,7 @@ class DenoiserEngine:
         assert sd[m1 + ".first_mlp.0.weight"].shape[1] == Cg
         c1 = sd[m1 + ".first_mlp.0.weight"].shape[0]
         c_last = sd[m1 + ".res_connect.weight"].shape[0]
-        mo = self._buf(rows, c_last, cm=True)
+        mo = self._buf(rows, c_last, cm=True, fm=self._tail_fm(m1, ap, 7, c_last))
         pair = h1 = r = g = gather = None
         if self.use_gx or self.use_gxs:  # pair decomposition: group_knn's channels are [feats | d2 | w | abs | rel | centre]
             pair = (Kf, C2, dict(d2=C2, w=C2 + 1, abs=C2 + 2, rel=C2 + 5, ctr=C2 + 8))

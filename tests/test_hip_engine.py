@@ -643,6 +643,40 @@ def test_x_stationary_kernel_bit_identical(gpu_device, exp_lib, monkeypatch):
             assert np.array_equal(got, ref), (name, mode, cbw, occ, float(np.abs(got - ref).max()))
 
 
+def test_fragment_major_layout_bit_identical(gpu_device, monkeypatch):
+    """Round 6: the K-expanded inputs u / mo of the fused attention tails stored FRAGMENT-major (SLIDE_F_OUT_FM: inside every
+    32-row group of a chunk the bytes are ordered as the MFMA fragments attn_tail_rx_kernel loads, 1 KB of consecutive memory
+    per wave load) -- a pure re-layout between the producers' epilogue stores (generated-X GEMMs, SA chain) and
+    the tail's loads: the denoiser output must be bit-identical to the chunk-major plan (SLIDE_FM=0), on the default
+    (pair-decomposition) plan, with the two-launch Mlp tail instead of the SA chain, with separate instead of dual generated-X
+    launches, and on ragged batches."""
+    from slide_amd.engine import DenoiserEngine
+    for name in ("feat", "pos"):
+        g, hp, sd = _load(name)
+        x, ts, lab = g["x_mixed"], g["ts_mixed"], g["label_mixed"]
+        for knobs in ({}, {"SLIDE_SA_CHAIN": "0"}, {"SLIDE_GX_DUAL": "0"}):
+            for k_, v_ in knobs.items():
+                monkeypatch.setenv(k_, v_)
+            for B in (x.shape[0], 9, 33):
+                rep = (B + x.shape[0] - 1) // x.shape[0]
+                xb, tb, lb = np.concatenate([x] * rep)[:B], np.concatenate([ts] * rep)[:B], np.concatenate([lab] * rep)[:B]
+                monkeypatch.setenv("SLIDE_FM", "0")
+                e0 = DenoiserEngine(hp, sd, B, gpu_device, prec="fp16")
+                assert not e0._fm and not any(o.kind == 16 and (int(o.f[1]) & 16) for o in e0.ops)
+                ref = e0.forward(xb, tb, lb).cpu().numpy()
+                monkeypatch.setenv("SLIDE_FM", "1")
+                e1 = DenoiserEngine(hp, sd, B, gpu_device, prec="fp16")
+                tails = [o for o in e1.ops if o.kind == 16]
+                # (without the SA chain an SA block's rest_mlp is a ring GEMM over a stored h2: that block stays chunk-major)
+                nfm = sum(1 for o in tails if int(o.f[1]) & 16)
+                # (the position net's narrow blocks are outside the layout's conditions -- _tail_fm: its plan must simply not change)
+                assert nfm == (0 if name == "pos" else 2 if "SLIDE_SA_CHAIN" in knobs else 4) and bool(e1._fm) == (nfm > 0), (name, knobs, B, nfm)
+                got = e1.forward(xb, tb, lb).cpu().numpy()
+                assert np.array_equal(got, ref), (name, knobs, B, float(np.abs(got - ref).max()))
+            for k_ in knobs:
+                monkeypatch.delenv(k_)
+
+
 def test_chunk_major_layout_bit_identical(gpu_device, exp_lib, monkeypatch):
     """Chunk-major activations / weights ([k / 32][rows][32]: one LDS-DMA instruction reads 1 KB of consecutive memory) are a
     pure re-layout of the K-expanded buffers between GEMM epilogues and ring-kernel loaders: the denoiser output must be

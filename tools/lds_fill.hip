@@ -187,6 +187,58 @@ __global__ __launch_bounds__(256) void fill_xreg(const u16 *__restrict__ X, cons
   if (acc == 0x12345678u) sink[0] = acc;
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// register-X pipeline as attn_tail_rx_kernel runs it (four chunks ahead, W through a five-stage LDS-DMA ring, one barrier per chunk),
+// without the MFMAs.  FRAG = 0: chunk-major X [K/32][rows][32] (a wave instruction touches 32 B of each of 32 rows 64 B apart);
+// FRAG = 1: FRAGMENT-major X [K/32][rows/32][2 k16-steps][64 lanes][8 halves] (a wave instruction reads 1 KB of consecutive memory)
+template <int FRAG, int DEPTH>
+__global__ __launch_bounds__(256, 2) void fill_xr_pipe(const u16 *__restrict__ X, const u16 *__restrict__ W, int rows_total, int wrows,
+                                                       int nchunk, int reps, unsigned int *sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, ct = q & 7, rt = (q >> 3) * 8 + xcd;
+  const u16 *xp[2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    if (FRAG) xp[rb] = X + ((size_t)(rt * 8 + wv * 2 + rb) * 2 * 64 + lane) * 8;   // 32-row block (rt*8 + wv*2 + rb), k16-step 0
+    else xp[rb] = X + ((size_t)rt * 256 + wv * 64 + rb * 32 + col) * 32 + half * 8;
+  }
+  const u16 *wp = W + ((size_t)ct * 64 + wv * 16 + (lane >> 2)) * 32 + (lane & 3) * 8;
+  const size_t xcs = (size_t)rows_total * 32, wcs = (size_t)wrows * 32;
+  constexpr int S2OFF = FRAG ? 512 : 16;  // halves between the two k16-steps of a chunk
+  unsigned int acc = 0;
+  u32x4 r[DEPTH][2][2];
+  auto issue = [&](int kc, u32x4 (&x)[2][2]) __attribute__((always_inline)) {
+    const int k = kc < nchunk ? kc : nchunk - 1;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const u16 *p = xp[rb] + k * xcs;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x[rb][0]) : "v"(p) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x[rb][1]) : "v"(p + S2OFF) : "memory");
+    }
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(wp + k * wcs), (LDS_AS void *)(smem + (kc % (DEPTH + 1)) * 4096 + wv * 1024), 16, 0, 0);
+  };
+  for (int rep = 0; rep < reps; ++rep) {
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) issue(j, r[j]);
+    for (int c0 = 0; c0 < nchunk; c0 += DEPTH) {
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j) {
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[j][0][0]), "+v"(r[j][0][1]), "+v"(r[j][1][0]), "+v"(r[j][1][1]) : "n"((DEPTH - 1) * 5) : "memory");
+        __builtin_amdgcn_s_barrier();
+        acc += r[j][0][0].x ^ r[j][0][1].y ^ r[j][1][0].z ^ r[j][1][1].w;
+        acc += *reinterpret_cast<const unsigned int *>(smem + ((c0 + j) % (DEPTH + 1)) * 4096 + threadIdx.x * 16);
+        issue(c0 + j + DEPTH, r[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[j][0][0]), "+v"(r[j][0][1]), "+v"(r[j][1][0]), "+v"(r[j][1][1]) :: "memory");
+    __syncthreads();
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 template <typename F>
@@ -242,6 +294,20 @@ int main() {
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       const double bytes = (double)wgs * nchunk * reps * 20480.0;
       printf("%-28s %4d WGs: %.1f us, %.2f TB/s, %.1f KB/us/CU, %.1f B/clk/CU (2.4 GHz)\n", "XR X->VGPR (MFMA layout) + W DMA", wgs,
+             ms * 1e3, bytes / ms / 1e9, bytes / (ms * 1e3) / 256 / 1024, bytes / (ms * 1e-3) / 256 / 2.4e9);
+    }
+    for (int v = 0; v < 4; ++v) {
+      typedef void (*KT)(const u16 *, const u16 *, int, int, int, int, unsigned int *);
+      KT k = v == 0 ? fill_xr_pipe<0, 4> : v == 1 ? fill_xr_pipe<1, 4> : v == 2 ? fill_xr_pipe<0, 2> : fill_xr_pipe<1, 2>;
+      const char *nm = v == 0 ? "XP chunk-major X->VGPR depth 4" : v == 1 ? "XF FRAGMENT-major X->VGPR depth 4" : v == 2 ? "XP chunk-major depth 2" : "XF FRAGMENT-major depth 2";
+      hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      hipLaunchKernelGGL(k, dim3(wgs), dim3(256), 41 * 1024, 0, X, W, ntr * 256, 8 * 64, nchunk, 1, sink);
+      CK(hipDeviceSynchronize()); CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(k, dim3(wgs), dim3(256), 41 * 1024, 0, X, W, ntr * 256, 8 * 64, nchunk, reps, sink);
+      CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      const double bytes = (double)wgs * nchunk * reps * 20480.0;
+      printf("%-36s %4d WGs: %.1f us, %.2f TB/s, %.1f KB/us/CU, %.1f B/clk/CU (2.4 GHz)\n", nm, wgs,
              ms * 1e3, bytes / ms / 1e9, bytes / (ms * 1e3) / 256 / 1024, bytes / (ms * 1e-3) / 256 / 2.4e9);
     }
     run("R64  one stage, 64 B/row", fill_rb<64>, wgs, X, W, ld, nchunk, reps, sink);
