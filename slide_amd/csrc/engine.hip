@@ -765,11 +765,18 @@ __device__ __forceinline__ float other_half(float x) {  // value of lane ^ 32
 template <int NPXL>
 __device__ __forceinline__ void attn_tail_finish(const AttnTailArgs &a, f32x16 (&sacc)[2][2], f32x16 (&vacc)[2][2], const float *vec_lds,
                                                  int vstride, float *red, int row0, int cob0, int wave) {
+  // Round 6: the per-workgroup timeline (tools/ab/op_timeline.py) put 4.4 - 6.1 us of a tail workgroup's 11 - 21 us into this epilogue,
+  // VALU-issue-bound (~1340 issue slots per wave).  Rewritten on register PAIRS (accumulator registers 2 i, 2 i + 1 are rows of one
+  // point: v_pk_add / v_pk_fma_f32), log2(e) folded into the score bias step (exp2 of a difference: no multiply per value), one
+  // v_rcp per output instead of an IEEE division, ONE lane-half exchange for numerator and denominator together, store addresses as
+  // scalar base + one per-lane offset.
   using T = _Float16;
   constexpr int CBW = 2;
   constexpr int KLOG = NPXL - 4, KN = 1 << KLOG, GPB = 32 / KN;
   constexpr int WPS = (1 << NPXL) / 64;
+  constexpr float LOG2E = 1.44269504088896340736f;
   const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+  auto pr = [](const f32x16 &v, int i) __attribute__((always_inline)) { return f32x2{v[2 * i], v[2 * i + 1]}; };
 
   // ---- values: bias, GroupNorm over the sample (rows of WPS waves x the gs adjacent channel lanes), ReLU
   // red: [wave][cb][32 channels][sum, sumsq]
@@ -777,22 +784,28 @@ __device__ __forceinline__ void attn_tail_finish(const AttnTailArgs &a, f32x16 (
 #pragma unroll
   for (int cb = 0; cb < CBW; ++cb) {
     const float bv = b_v[cb * 32 + col];
-    float s = 0.f, ss = 0.f;
+    const f32x2 bv2 = {bv, bv};
+    f32x2 s2 = {0.f, 0.f}, ss2 = {0.f, 0.f};
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float x = vacc[cb][rb][r] + bv;
-        vacc[cb][rb][r] = x;
-        s += x;
-        ss = fmaf(x, x, ss);
+      for (int i = 0; i < 8; ++i) {
+        const f32x2 x = pr(vacc[cb][rb], i) + bv2;
+        vacc[cb][rb][2 * i] = x[0]; vacc[cb][rb][2 * i + 1] = x[1];
+        s2 += x;
+        ss2 = __builtin_elementwise_fma(x, x, ss2);
       }
+    float s = s2[0] + s2[1], ss = ss2[0] + ss2[1];
     s += other_half(s);
     ss += other_half(ss);
     if (half == 0) *reinterpret_cast<f32x2 *>(red + ((wave * CBW + cb) * 32 + col) * 2) = f32x2{s, ss};
   }
   __syncthreads();
   const int w0 = (wave / WPS) * WPS;
+  // output row of the wave's first point: scalar base + the lane's channel (bytes)
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int pt0 = (row0 + wave_s * 64) >> KLOG, npts = a.rows >> KLOG;
+  const uint32_t lofs = (uint32_t)col * 2;
 #pragma unroll
   for (int cb = 0; cb < CBW; ++cb) {
     f32x2 t = {0.f, 0.f};
@@ -815,42 +828,53 @@ __device__ __forceinline__ void attn_tail_finish(const AttnTailArgs &a, f32x16 (
     float g = gam[cb * 32 + col] * __builtin_amdgcn_rsqf(var + GN_EPS);
     float bt = bet[cb * 32 + col] - mean * g;
     if ((cob0 + cb) * 32 + col >= a.n_norm) { g = 1.f; bt = 0.f; }
-    const float bs = b_s[cb * 32 + col];
-    // ---- softmax over the K neighbour rows of every point, weighted sum of the values, one row out per point
+    const float bsl = b_s[cb * 32 + col] * LOG2E;
+    const f32x2 g2 = {g, g}, bt2 = {bt, bt}, bs2 = {bsl, bsl}, l2 = {LOG2E, LOG2E};
+    const bool cb_ok = cob0 + cb < a.n_cob;  // (uniform)
+    // ---- softmax over the K neighbour rows of every point (base 2: the scores carry log2 e), weighted sum of the values, one row out per point
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
       for (int pg = 0; pg < GPB; ++pg) {
         // rows of point pg inside the 32-row block: 16 -> regs 8pg .. 8pg+7 (both halves); 8 -> regs 4pg .. 4pg+3
-        constexpr int RPG = 16 / GPB;
-        float sc[RPG], vv[RPG];
+        constexpr int PPG = 8 / GPB;  // register pairs per point
+        f32x2 sc[PPG], vv[PPG];
         float m = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < RPG; ++j) {
-          sc[j] = sacc[cb][rb][pg * RPG + j] + bs;
-          vv[j] = fmaxf(fmaf(vacc[cb][rb][pg * RPG + j], g, bt), 0.f);
-          m = fmaxf(m, sc[j]);
+        for (int j = 0; j < PPG; ++j) {
+          sc[j] = __builtin_elementwise_fma(pr(sacc[cb][rb], pg * PPG + j), l2, bs2);
+          vv[j] = __builtin_elementwise_fma(pr(vacc[cb][rb], pg * PPG + j), g2, bt2);
+          vv[j][0] = fmaxf(vv[j][0], 0.f); vv[j][1] = fmaxf(vv[j][1], 0.f);
+          m = fmaxf(m, fmaxf(sc[j][0], sc[j][1]));
         }
         m = fmaxf(m, other_half(m));
-        float den = 0.f, num = 0.f;
+        const f32x2 m2 = {m, m};
+        f32x2 den2 = {0.f, 0.f}, num2 = {0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < RPG; ++j) {
-          const float e = __expf(sc[j] - m);
-          den += e;
-          num = fmaf(e, vv[j], num);
+        for (int j = 0; j < PPG; ++j) {
+          const f32x2 d = sc[j] - m2;
+          const f32x2 e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+          den2 += e;
+          num2 = __builtin_elementwise_fma(e, vv[j], num2);
         }
-        den += other_half(den);
-        num += other_half(num);
-        const int rbase = row0 + wave * 64 + rb * 32 + pg * KN;
-        if (half == 0 && rbase < a.rows && cob0 + cb < a.n_cob) {
-          const T v = (T)(num / den);
-          reinterpret_cast<T *>(a.out)[(size_t)(rbase >> KLOG) * a.out_ld + (cob0 + cb) * 32 + col] = v;
+        // one exchange for both sums: afterwards the LOWER lanes hold (num.lo, num.hi), the upper lanes (den.lo, den.hi); the upper
+        // lanes' total (den) then comes down with a second exchange
+        uint32_t un = __float_as_uint(num2[0] + num2[1]), ud = __float_as_uint(den2[0] + den2[1]);
+        lane32_swap(un, ud);
+        const float tot = __uint_as_float(un) + __uint_as_float(ud);  // lower lanes: numerator, upper lanes: denominator
+        uint32_t ua = __float_as_uint(tot), ub = ua;
+        lane32_swap(ua, ub);  // ub (lower lanes) = the upper lanes' tot
+        const int pidx = rb * GPB + pg;  // point of the wave
+        if (half == 0 && pt0 + pidx < npts && cb_ok) {
+          const T v = (T)(tot * __builtin_amdgcn_rcpf(__uint_as_float(ub)));
+          const int ch = (cob0 + cb) * 32;
+          *reinterpret_cast<T *>(reinterpret_cast<char *>(reinterpret_cast<T *>(a.out) + (size_t)(pt0 + pidx) * a.out_ld + ch) + lofs) = v;
           // chunk-major copy of the per-point table for the next block's gather-on-load GEMM
           if (a.out_cm)
-            reinterpret_cast<T *>(a.out_cm)[((size_t)(cob0 + cb) * (a.rows >> KLOG) + (rbase >> KLOG)) * 32 + col] = v;
+            *reinterpret_cast<T *>(reinterpret_cast<char *>(reinterpret_cast<T *>(a.out_cm) + ((size_t)(cob0 + cb) * npts + pt0 + pidx) * 32) + lofs) = v;
           // second copy into the columns of a later concatenation buffer (the skip input of an FP block's second Mlp)
-          if (a.out2 && (cob0 + cb) * 32 + col < a.out2_n)
-            reinterpret_cast<T *>(a.out2)[(size_t)(rbase >> KLOG) * a.out2_ld + (cob0 + cb) * 32 + col] = v;
+          if (a.out2 && ch + col < a.out2_n)
+            *reinterpret_cast<T *>(reinterpret_cast<char *>(reinterpret_cast<T *>(a.out2) + (size_t)(pt0 + pidx) * a.out2_ld + ch) + lofs) = v;
         }
       }
   }
@@ -984,9 +1008,16 @@ __device__ __forceinline__ void attn_tail_rx_body(const AttnTailArgs &a) {
   const int wr = wave & 3, wc = wave >> 2;
   float *const vec_lds = reinterpret_cast<float *>(smem_raw + (size_t)NSTW * WSTAGE);  // [4 vectors][CBWT*32]
   float *const red = vec_lds + 4 * CBWT * 32;                                          // [wc][4 row waves][CBW][32][2]
-  for (int i = tid; i < 4 * CBWT * 32; i += 256 * WC) {
-    const int which = i / (CBWT * 32), c = i - which * (CBWT * 32), gc = cob0 * 32 + c;
-    vec_lds[i] = gc < a.n_cob * 32 ? a.vec[(size_t)which * a.n_cob * 32 + gc] : 0.f;
+  // the tile's four vectors go to LDS by LDS-DMA (wave w: vector w, 64 floats) -- through registers the ds_write's wait was a full
+  // memory round trip BEFORE the first chunk load could issue (~1 us of every workgroup: "primed" in tools/ab/op_timeline.py); as the
+  // oldest loads of the pipeline they have landed with chunk 0 and the first step's barrier publishes them.  (Channels past n_cob * 32
+  // read a valid address: their values are never stored and never mix with valid channels -- GroupNorm groups lie inside a block.)
+  static_assert(WC == 1, "vector staging: one LDS-DMA instruction per wave covers the tile's 64 channels");
+  {
+    int gc = cob0 * 32 + lane;
+    gc = gc < a.n_cob * 32 ? gc : a.n_cob * 32 - 1;
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(a.vec + (size_t)wave * a.n_cob * 32 + gc),
+                                     (__attribute__((address_space(3))) void *)(vec_lds + wave * 64), 4, 0, 0);
   }
   // weights: wave w stages channels 16 w .. 16 w + 15 of the tile (one 1 KB piece per chunk); fragments: lane = channel, swizzled pieces
   const int wch = 16 * wave + (lane >> 2);
@@ -1019,7 +1050,31 @@ __device__ __forceinline__ void attn_tail_rx_body(const AttnTailArgs &a) {
   // traffic -- and nobody consumes the result): with unconditional issues the number of loads behind a chunk's is the constant
   // 5 (RXD - 1), for the manual wait below and for the compiler's own wait-count insertion alike (a conditional issue made it fall
   // back to vmcnt(0) at every use, which serialises the pipeline).
+  // FM: every address is SCALAR base + one per-lane 32-bit offset (lane * 16 bytes: a fragment is 1 KB in lane order; the second k16
+  // step, the second row group are immediate offsets when the group exists) -- the chunk-major form below spends ~10 VALU
+  // instructions per load on 64-bit pointer arithmetic, ~50 per chunk against the chunk's 8 MFMAs (32 clocks each): as much issue
+  // time as the matrix work itself.  Idle slots (past the last chunk) read one address in all lanes (offset 0 of chunk 0).
+  const int wr_s = __builtin_amdgcn_readfirstlane(wr), ngrp = a.rows >> 5;
+  const int g0u = (row0 >> 5) + wr_s * 2, g0 = g0u < ngrp ? g0u : ngrp - 1, g1 = g0u + 1 < ngrp ? g0u + 1 : ngrp - 1;
+  const uint64_t xg0 = (uint64_t)g0 * 2048, xg1 = (uint64_t)g1 * 2048, xcsb = (uint64_t)a.rows * 64;  // bytes
+  const uint32_t lane16 = lane * 16, woff = (uint32_t)(gco * 32 + wpiece * 8) * 2;
+  auto issue_fm = [&](int c, f16x8 (&x)[2][2]) __attribute__((always_inline)) {
+    const bool live = c < total;
+    const int cl = live ? c : 0;
+    const bool second = cl >= nk2;
+    const int kc = second ? cl - nk2 : cl;
+    const uint32_t vo = live ? lane16 : 0u, vw = live ? woff : 0u;
+    const uint64_t xb = reinterpret_cast<uint64_t>(second ? a.X1 : a.X2) + (uint64_t)kc * xcsb, b0 = xb + xg0, b1 = xb + xg1;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(x[0][0]) : "v"(vo), "s"(b0) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(x[0][1]) : "v"(vo), "s"(b0) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(x[1][0]) : "v"(vo), "s"(b1) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(x[1][1]) : "v"(vo), "s"(b1) : "memory");
+    const uint64_t wb = reinterpret_cast<uint64_t>(second ? a.W1 : a.W2) + (uint64_t)kc * (w_cs * 2);
+    __builtin_amdgcn_global_load_lds(reinterpret_cast<const GLOBAL_AS void *>(wb + vw),
+                                     (__attribute__((address_space(3))) void *)(smem_raw + (size_t)(c % NSTW) * WSTAGE + wave * 1024), 16, 0, 0);
+  };
   auto issue = [&](int c, f16x8 (&x)[2][2]) __attribute__((always_inline)) {
+    if constexpr (FM) { issue_fm(c, x); return; }
     // (branch-free: an idle slot's addresses collapse onto `dummy` through a mask, not through a select the compiler could turn into
     //  control flow -- every path through the pipeline must carry the same loads)
     const bool second = c >= nk2;
@@ -1047,8 +1102,10 @@ __device__ __forceinline__ void attn_tail_rx_body(const AttnTailArgs &a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { sacc[i][j][r] = 0.f; vacc[i][j][r] = 0.f; }
+  SLIDE_STAMP(a, 0);
 #pragma unroll
   for (int j = 0; j < RXD; ++j) issue(j, xq[j]);
+  SLIDE_STAMP(a, 1);
   auto step = [&](int c, f16x8 (&x)[2][2], f32x16 (&acc)[CBW][2]) __attribute__((always_inline)) {
     // chunk c's loads have landed when only those of chunks c + 1 .. c + RXD - 1 are outstanding (the operands tie the fragments'
     // uses to this wait)
@@ -1072,7 +1129,9 @@ __device__ __forceinline__ void attn_tail_rx_body(const AttnTailArgs &a) {
   for (int c0 = 0; c0 < nk2; c0 += RXD) {
 #pragma unroll
     for (int j = 0; j < RXD; ++j) step(c0 + j, xq[j], vacc);
+    if (c0 == 0) SLIDE_STAMP(a, 2);
   }
+  SLIDE_STAMP(a, 3);
   for (int c0 = nk2; c0 < total; c0 += RXD) {  // (leaves from the middle of a round after the last chunk: no path re-joins the pipeline)
 #pragma unroll
     for (int j = 0; j < RXD; ++j) {
@@ -1084,8 +1143,14 @@ __device__ __forceinline__ void attn_tail_rx_body(const AttnTailArgs &a) {
 #pragma unroll
   for (int j = 0; j < RXD; ++j)
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(xq[j][0][0]), "+v"(xq[j][0][1]), "+v"(xq[j][1][0]), "+v"(xq[j][1][1]) :: "memory");
+  SLIDE_STAMP(a, 4);
   __syncthreads();  // (orders the staged vectors before their first use)
+  SLIDE_STAMP(a, 5);
   attn_tail_finish<NPXL>(a, sacc, vacc, vec_lds + wc * 64, CBWT * 32, red + wc * (4 * CBW * 32 * 2), row0, cob0 + wc * CBW, wr);
+  SLIDE_STAMP(a, 6);
+#ifdef SLIDE_TIMELINE
+  if (a.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SLIDE_STAMP(a, 7); }
+#endif
 }
 
 // WIDE form (round 3): 256 rows x 128 channels on the same four waves.  Per MFMA the tile moves 1.1 KB through the LDS instead
@@ -2484,7 +2549,7 @@ int run_attn_tail(const SlideOp &o, hipStream_t s) {
   if (tail_rx && (npxl == 7 || npxl == 8) && (a.k2 / 32) % RXD == 0) {  // X fragments through registers (attn_tail_rx_kernel)
     const size_t shmr = (size_t)(RXD + 1) * 64 * 64 + 4 * 2 * 32 * 4 + 4 * 2 * 32 * 2 * 4;
     if (a.x_fm) {
-      if (a.x1_ld != 32 || a.x2_ld != 32 || a.rows % 32) return -3;
+      if (a.x1_ld != 32 || a.x2_ld != 32 || a.rows % 32 || !a.w_cm) return -3;
       if (npxl == 8) hipLaunchKernelGGL((attn_tail_rx_kernel<8, true>), dim3(grid), dim3(256), shmr, s, a);
       else hipLaunchKernelGGL((attn_tail_rx_kernel<7, true>), dim3(grid), dim3(256), shmr, s, a);
       return (int)hipGetLastError();

@@ -70,6 +70,8 @@ with torch.cuda.stream(s.stream):
         if op.kind == 16:  # eight-wave attention tail: 1 first DMA issued | 2 landed | 3 scores K loop | 4 values K loop | 5 statistics | 6 softmax + stores | 7 retired
             seq = [0, 1, 2, 3, 4, 5, 6, 7]
             names = {1: "prologue", 2: "first_stage", 3: "kloop_s", 4: "kloop_v", 5: "stats", 6: "softmax", 7: "retired"}
+            if os.environ.get("SLIDE_TAIL8", "0") == "0":  # register-X tail: 1 pipeline primed | 2 first RXD chunks | 3 values K loop | 4 scores K loop | 5 drained + barrier | 6 epilogue | 7 retired
+                names = {1: "primed", 2: "first4", 3: "kloop_v", 4: "kloop_s", 5: "drain", 6: "epilogue", 7: "retired"}
         if op.kind == 30:  # block body: 1 prologue | 2 h2 | 3 mo | 4 u | 5 tail | 6 retired
             seq = [0, 1, 2, 3, 4, 5, 6]
             names = {1: "prologue", 2: "h2", 3: "mo", 4: "u", 5: "tail", 6: "retired"}
