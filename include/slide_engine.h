@@ -58,6 +58,13 @@ enum { SLIDE_PREC_F32 = 0, SLIDE_PREC_F16 = 1, SLIDE_PREC_SPLIT = 2 };
  * STATS instead emits per-sample channel sums / sums of squares (x stats_scale) for a later FINALIZE_GN and stores
  * the un-normalised value.  Activation pointers (pre_add, residual, out) are fp32 or fp16 according to the GEMM's
  * precision; bias / gamma / beta / addvec / stats are always fp32. */
+/* PACKED VECTORS (round 6).  A descriptor array passed to a GEMM-type op (p[2]; p[13] of a chained split layer) may be FOLLOWED in the
+ * same device buffer by the blocks' vectors as values, [n_cob][bias 32 | gamma 32 | beta 32] fp32 (zeros where a pointer is NULL);
+ * the caller says so by setting BIT 0 of the pointer it passes (the array itself is at least 8-byte aligned).  The kernels then stage
+ * descriptors and vectors by LDS-DMA straight from that buffer -- without it every workgroup reads the three pointers of each block
+ * and then the vectors behind them: two dependent memory round trips in its prologue.  bias / gamma / beta below stay valid
+ * pointers either way (the pair-table pass reads gamma / beta from them). */
+#define SLIDE_EPI_PACKED_VECS ((uintptr_t)1)
 typedef struct SlideEpi {
   int32_t mode, flags, gs, n_norm;
   float inv_count, stats_scale;

@@ -2241,6 +2241,7 @@ int run_pair_first(const SlideOp &o, hipStream_t s) {
   a.X = o.p[0]; a.W = o.p[1]; a.epi = (const SlideEpi *)o.p[2];
   a.aff_tps = 1;
   a.rows = o.i[0]; a.x_ld = o.i[1]; a.k_pad = o.i[2]; a.n_cob = o.i[3];
+  resolve_epi(a);
   a.dbg = (unsigned long long *)o.p[13];
   PairArgs pa;
   pa.pair_cob0 = o.i[4]; pa.ld = o.i[5];
@@ -2305,6 +2306,7 @@ int run_gemm_attend(const SlideOp &o, hipStream_t s) {
   }
   a.at_V = o.p[5]; a.at_out = o.p[6]; a.at_counts = (const int *)o.p[7]; a.at_vss = (const float *)o.p[8];
   a.rows = o.i[0]; a.x_ld = o.i[1]; a.k_pad = o.i[2]; a.n_cob = o.i[3]; a.in_bs = o.i[5];
+  resolve_epi(a);
   const int K = o.i[4];
   a.at_ldv = o.i[6]; a.at_ldo = o.i[7]; a.at_pps = o.i[8] > 0 ? o.i[8] : 1; a.at_vrelu = o.i[9]; a.at_C = o.i[10];
   a.at_klog2 = K == 4 ? 2 : K == 8 ? 3 : K == 16 ? 4 : K == 32 ? 5 : -1;
@@ -2336,6 +2338,8 @@ int run_gemm(const SlideOp &o, hipStream_t s) {
   a.gx_ta = a.gx_tb = nullptr; a.gx_vv = nullptr; a.gx_add_idx = nullptr;
   a.g_nsplit = (int)o.f[1]; a.g_ldf = (int)o.f[2]; a.g_klog2 = (int)o.f[3];
   a.rows = o.i[0]; a.x_ld = o.i[1]; a.k_pad = o.i[2]; a.n_cob = o.i[3]; a.in_bs = o.i[5];
+  a.ch_epi = nullptr; a.ch_n_cob = 0;
+  resolve_epi(a);
   const int npxl = o.i[4], prec = o.i[6], cbw = o.i[7], glds = o.i[8] & 1;
   a.w_cm = (o.i[8] >> 1) & 1;  // chunk-major weights (ring kernels of the 128 / 256-row samples only)
   if ((o.i[8] >> 2) & 1) {     // a block of this GEMM carries a PAIR residual: the instantiations compiled for it

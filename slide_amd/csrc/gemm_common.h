@@ -51,6 +51,9 @@ struct GemmArgs {
   const void *ch_W;
   const SlideEpi *ch_epi;
   int ch_n_cob, ch_k_pad;
+  // PACKED VECTORS (round 6, SLIDE_EPI_PACKED_VECS in include/slide_engine.h): [n_cob][bias 32 | gamma 32 | beta 32] fp32 behind the
+  // descriptor array, or NULL (the kernels then read the vectors through the descriptors' pointers); resolve_epi() sets them
+  const float *vecs, *ch_vecs;
   // ATTEND epilogue (round 6, module-level path; SLIDE_OP_GEMM_ATTEND): this GEMM's output is the score map of an AttentionModule --
   // instead of being stored it is soft-maxed over the K neighbour rows of each point and contracted with the value rows
   const void *at_V;          // values [rows][at_ldv] fp16
@@ -59,6 +62,19 @@ struct GemmArgs {
   const int *at_counts;      // [rows / K] or NULL: only the first max(1, count) neighbour slots of a point take part
   int at_ldv, at_ldo, at_klog2, at_pps, at_vrelu, at_C;
 };
+
+// the descriptor pointers as the ops carry them -> array + packed vectors (call once n_cob / ch_n_cob are set)
+static inline void resolve_epi(GemmArgs &a) {
+  a.vecs = a.ch_vecs = nullptr;
+  if ((uintptr_t)a.epi & SLIDE_EPI_PACKED_VECS) {
+    a.epi = reinterpret_cast<const SlideEpi *>((uintptr_t)a.epi & ~SLIDE_EPI_PACKED_VECS);
+    a.vecs = reinterpret_cast<const float *>(a.epi + a.n_cob);
+  }
+  if ((uintptr_t)a.ch_epi & SLIDE_EPI_PACKED_VECS) {
+    a.ch_epi = reinterpret_cast<const SlideEpi *>((uintptr_t)a.ch_epi & ~SLIDE_EPI_PACKED_VECS);
+    a.ch_vecs = reinterpret_cast<const float *>(a.ch_epi + a.ch_n_cob);
+  }
+}
 
 // SLIDE_OP_PAIR_FIRST (pair_first_kernel, engine.hip): what the pair-table epilogue reads beside the GEMM arguments
 struct PairArgs {
@@ -158,9 +174,35 @@ static_assert(sizeof(SlideEpi) == 160, "descriptor layout is read by dword index
 
 // copies the CBW epilogue descriptors of this workgroup and their per-channel vectors [cb][bias | gamma | beta][32]
 // into LDS (visible after the caller's next barrier)
+// With packed vectors (a.vecs) both go by LDS-DMA, four bytes per lane, straight from the descriptor buffer: no register staging,
+// no pointer chase (descriptor -> bias / gamma / beta pointers -> values: two dependent round trips in every workgroup's prologue).
+// The DMAs are complete after the issuing wave's next vmcnt wait that covers them -- every caller drains its VM counter and passes
+// a workgroup barrier before its epilogue reads the tables.  Blocks past n_cob copy the last block (process() never reads them).
 template <int CBW, int NT = 256>
 __device__ __forceinline__ void stage_epilogue_tables(const GemmArgs &a, int cob0, int tid, uint32_t *epi_lds,
                                                       float *vec_lds) {
+  if (a.vecs) {  // (uniform)
+    const int lane = tid & 63, w0 = __builtin_amdgcn_readfirstlane(tid >> 6) * 64;
+    for (int i0 = w0; i0 < CBW * EPI_DW; i0 += NT) {
+      const int i = i0 + lane;
+      if (i < CBW * EPI_DW) {
+        int cobi = cob0 + i / EPI_DW;
+        cobi = cobi < a.n_cob ? cobi : a.n_cob - 1;
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(reinterpret_cast<const uint32_t *>(a.epi + cobi) + i % EPI_DW),
+                                         (__attribute__((address_space(3))) void *)(epi_lds + i0), 4, 0, 0);
+      }
+    }
+    for (int i0 = w0; i0 < CBW * 96; i0 += NT) {
+      const int i = i0 + lane;
+      if (i < CBW * 96) {
+        int cobi = cob0 + i / 96;
+        cobi = cobi < a.n_cob ? cobi : a.n_cob - 1;
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(a.vecs + (size_t)cobi * 96 + i % 96),
+                                         (__attribute__((address_space(3))) void *)(vec_lds + i0), 4, 0, 0);
+      }
+    }
+    return;
+  }
   for (int i = tid; i < CBW * EPI_DW; i += NT) {
     const int cobi = cob0 + i / EPI_DW;
     epi_lds[i] = cobi < a.n_cob ? reinterpret_cast<const uint32_t *>(a.epi + cobi)[i % EPI_DW] : 0u;

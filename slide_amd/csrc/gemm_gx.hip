@@ -473,6 +473,7 @@ static int gx_args_from_op(const SlideOp &o, GemmArgs &a) {
   a.rows = o.i[0]; a.gx_ld = o.i[1]; a.k_pad = o.i[2]; a.n_cob = o.i[3]; a.in_bs = o.i[5];
   a.gx_mode = o.i[6]; a.add_bs = o.i[7]; a.gx_add_idx_stride = o.i[8]; a.gx_vbs = o.i[9];
   a.w_cm = 1; a.x_ld = 32;
+  resolve_epi(a);
   const int npxl = o.i[4];
   if (a.k_pad % 32 || a.k_pad <= 0 || a.gx_ld % 8 || a.rows <= 0 || a.n_cob <= 0 || !a.gx_ta || !a.gx_tb) return -3;
   if (a.gx_mode != 0 && (!a.in_scale || !a.in_shift)) return -3;
@@ -1088,6 +1089,7 @@ int slide_launch_sa_chain_p(const SlideOp &o, hipStream_t s) {
   g.gn_fin = (const SlideGnFin *)q.p[6];
   g.aff_tps = 1;
   g.rows = q.i[0]; g.x_ld = q.i[1]; g.k_pad = q.i[2]; g.n_cob = q.i[3]; g.in_bs = q.i[5];
+  resolve_epi(g);
   if (q.i[4] != 4 || q.i[6] != SLIDE_PREC_F16 || (q.i[8] & 6) || !g.in_scale || !g.in_shift || q.p[8] || q.p[9] ||
       q.p[10] || q.p[11] || g.k_pad % 32 || g.x_ld % 8 || g.rows != a.B * 16 || g.n_cob <= 0)
     return -3;

@@ -254,7 +254,7 @@ __device__ __forceinline__ void gemm_gxs_body(const GemmArgs &a, const int bid) 
     gemm_epilogue<SLIDE_PREC_F32, NPXL, CBW, 2, false, true>(a, acc, row0, cob0, wave, half, col, epi_lds, vec_lds,
                                                              reinterpret_cast<float *>(smem_raw));
     GemmArgs b = a;
-    b.W = a.ch_W; b.epi = a.ch_epi; b.n_cob = a.ch_n_cob; b.k_pad = a.ch_k_pad;
+    b.W = a.ch_W; b.epi = a.ch_epi; b.vecs = a.ch_vecs; b.n_cob = a.ch_n_cob; b.k_pad = a.ch_k_pad;
     const float *W2 = reinterpret_cast<const float *>(a.ch_W);
     const int nk2 = a.ch_k_pad / BK;  // <= CBW: chunk kc2 of the next layer = channel block kc2 of this one
     for (int tc2 = 0; tc2 < (a.ch_n_cob + CBW - 1) / CBW; ++tc2) {
@@ -749,6 +749,7 @@ static int gxs_args_from_op(const SlideOp &o, GemmArgs &a) {
   // chained second layer (p[12] = its float weights, p[13] = its epilogue descriptors, f[1] = its n_cob, f[2] = its k_pad): 16 x 16-row
   // samples, mode 0, every channel of this layer in one 64-channel tile, which is also the next layer's whole K
   a.ch_W = o.p[12]; a.ch_epi = (const SlideEpi *)o.p[13]; a.ch_n_cob = (int)o.f[1]; a.ch_k_pad = (int)o.f[2];
+  resolve_epi(a);
   if (a.ch_W && (npxl != 8 || a.gx_mode != 0 || a.n_cob > 2 || !a.ch_epi || a.ch_n_cob <= 0 || a.ch_k_pad != a.n_cob * 32 ||
                  (uintptr_t)a.ch_W % 16))
     return -3;

@@ -445,16 +445,28 @@ class DenoiserEngine:
                     e.stats_bs = ssum.shape[1]
                     e.stats_scale = scale
                 blk += 1
-        ed = self.A.put(np.frombuffer(bytes(epis), dtype=np.uint8).copy())
+        # PACKED VECTORS (SLIDE_EPI_PACKED_VECS, include/slide_engine.h): the blocks' [bias | gamma | beta] values behind the descriptor
+        # array, bit 0 of the pointer the ops carry says so -- the kernels stage both by LDS-DMA instead of chasing the three pointers
+        # of every block in every workgroup's prologue (SLIDE_PACKED_VECS=0: plain pointer, A/B)
+        pv = np.zeros((n_cob, 3, 32), np.float32)
+        blk = 0
+        for vec, sg, Opad, _n, _g, _l in vec_list:
+            v3 = np.asarray(vec, np.float32).reshape(3, Opad)
+            for j in range(Opad // 32):
+                pv[blk] = v3[:, 32 * j:32 * j + 32]
+                blk += 1
+        assert blk == n_cob
+        ed = self.A.put(np.concatenate([np.frombuffer(bytes(epis), dtype=np.uint8), pv.reshape(-1).view(np.uint8)]))
+        edp = ed.data_ptr() | (1 if os.environ.get("SLIDE_PACKED_VECS", "1") != "0" else 0)
         sc = sh = None
         in_bs = aff_off = 0
         if in_affine is not None:
             sc, sh, aff_off, in_bs = in_affine
         if defer is not None:
-            return dict(W=Wd, epi=ed, n_cob=n_cob, k_pad=ld, flops=2 * rows * sum(int(s_["w"].size) for s_ in segs),
+            return dict(W=Wd, epi=ed, epi_ptr=edp, n_cob=n_cob, k_pad=ld, flops=2 * rows * sum(int(s_["w"].size) for s_ in segs),
                         wr=sum(rows * v[2] * v[1]["out"].element_size() for v in vec_list), wbytes=W.size * 4)
         if gx is not None:
-            return self._emit_gx(gx, npx_log2, rows, ld, n_cob, Wd, ed, segs, W, vec_list, in_affine, pair_tabs, chain=chain)
+            return self._emit_gx(gx, npx_log2, rows, ld, n_cob, Wd, edp, segs, W, vec_list, in_affine, pair_tabs, chain=chain, keep=ed)
         if pair_fused is not None:  # SLIDE_OP_PAIR_FIRST: per-point GEMM + pair-table pass in one launch (_pair_first)
             pf = pair_fused
             assert npx_log2 == 4 and self.prec == 1 and in_affine is None and gather is None and gn_fin is None and not w_cm
@@ -465,7 +477,7 @@ class DenoiserEngine:
             self.kernel_names[len(self.ops)] = "pair_first_kernel<%s>" % ("true" if pf["K"] == 8 else "false")
             ptr = lambda t: None if t is None else t.data_ptr()
             self._emit(make_op(OP_PAIR_FIRST, i=(rows, x_ld, ld, n_cob, pf["cob0"], pf["ld"], pf["K"]),
-                               p=(X.data_ptr(), Wd.data_ptr(), ed.data_ptr(), self.xyz.data_ptr(), pf["wa"].data_ptr(),
+                               p=(X.data_ptr(), Wd.data_ptr(), edp, self.xyz.data_ptr(), pf["wa"].data_ptr(),
                                   pf["wb"].data_ptr(), pf["ta"].data_ptr(), pf["tb"].data_ptr(), ptr(pf.get("nbr")), ptr(pf.get("d2")),
                                   ptr(pf.get("w")), ptr(pf.get("vv_in")), ptr(pf.get("vv")))))
             return
@@ -517,7 +529,7 @@ class DenoiserEngine:
             self._w16_next = W  # (a per-point layer of a split plan: _merge_pp may fold it into a SLIDE_OP_PP_STAGE launch)
         self._emit(make_op(OP_GEMM, i=(rows, x_ld, ld, n_cob, npx_log2, in_bs, self.prec, cbw, glds | (2 if w_cm else 0) | (4 if has_pair else 0), knob),
                            f=(-1.0 if self.persistent == 2 else float(os.environ.get('SLIDE_STAGGER_US', '0')),) + gf,
-                                p=(X.data_ptr(), Wd.data_ptr(), ed.data_ptr(),
+                                p=(X.data_ptr(), Wd.data_ptr(), edp,
                                    None if sc is None else sc.data_ptr() + 4 * aff_off,
                                    None if sh is None else sh.data_ptr() + 4 * aff_off, None,
                                    None if gn_fin is None else gn_fin.data_ptr(),
@@ -538,7 +550,7 @@ class DenoiserEngine:
         """the single-accumulator split kernels (csrc/gemm_gxs.hip) scale the weight's high term by 2^11 in fp16: |w| < 32"""
         return all(float(np.abs(w).max()) < 31.0 for w in ws if w.size)
 
-    def _emit_gx(self, gx, npx_log2, rows, ld, n_cob, Wd, ed, segs, W, vec_list, in_affine, pair_tabs, chain=None):
+    def _emit_gx(self, gx, npx_log2, rows, ld, n_cob, Wd, edp, segs, W, vec_list, in_affine, pair_tabs, chain=None, keep=None):
         """SLIDE_OP_GEMM_GX (include/slide_engine.h): gx = dict(ta, tb (fp16 tables [B*16][t_ld]), coff (first table column),
         k_pad, rows, mode, add=(tensor, offset, per-sample stride, idx tensor or None, idx stride) or None, vv = per-sample
         (vd | vw) fp32 [B][2][t_ld] of the 8-neighbour samples or None); pair_tabs = (neighbour, d2, w tables) for those"""
@@ -593,7 +605,7 @@ class DenoiserEngine:
                            i=(rows, ta.shape[1], ld, n_cob, npx_log2, in_bs, gx["mode"], 0 if add is None else add[2],
                               0 if add is None else add[4], 0 if vv is None else 2 * vv.shape[2]),
                            f=(float(n64),) + ((float(chain["n_cob"]), float(chain["k_pad"])) if chain is not None else ()),
-                           p=(ta.data_ptr() + tes * coff, Wd.data_ptr(), ed.data_ptr(),
+                           p=(ta.data_ptr() + tes * coff, Wd.data_ptr(), edp,
                               None if sc is None else sc.data_ptr() + 4 * aff_off,
                               None if sh is None else sh.data_ptr() + 4 * aff_off,
                               tb.data_ptr() + tes * coff,
@@ -603,7 +615,7 @@ class DenoiserEngine:
                               None if pair_tabs is None else pair_tabs[1].data_ptr(),
                               None if pair_tabs is None else pair_tabs[2].data_ptr(),
                               None if vv is None else vv.data_ptr() + 4 * coff,
-                              None if chain is None else chain["W"].data_ptr(), None if chain is None else chain["epi"].data_ptr())))
+                              None if chain is None else chain["W"].data_ptr(), None if chain is None else chain["epi_ptr"])))
         self.flops += fl
 
     # ------------------------------------------------------------------ blocks
@@ -1672,7 +1684,7 @@ class DenoiserEngine:
             if o.kind == OP_GEMM and id(o) in self._w16 and o.i[0] == B * 16 and o.i[2] <= 192 and not o.i[10]:
                 W = self._w16[id(o)][1]
                 wt = self.A.put(np.ascontiguousarray(W.T), torch.float32)  # K-major [k_pad][n_cob*32]
-                return [0, o.p[0], wt.data_ptr(), o.p[2], o.p[3] or 0, o.p[4] or 0, o.i[1], o.i[2], o.i[3], o.i[5]] + [0] * 6
+                return [0, o.p[0], wt.data_ptr(), o.p[2] & ~1, o.p[3] or 0, o.p[4] or 0, o.i[1], o.i[2], o.i[3], o.i[5]] + [0] * 6
             if o.kind == OP_PAIR_NORM and o.i[3] == 2 and o.i[4] == 1 and o.i[0] == B and not o.i[10]:
                 return [1] + [o.p[k] or 0 for k in range(13)] + [o.i[1], o.i[2]]
             return None
@@ -1791,7 +1803,7 @@ class DenoiserEngine:
             if j - i >= 2:
                 tab = (SlideChainLayer * (j - i))()
                 for q, o in enumerate(self.ops[i:j]):
-                    tab[q].X, tab[q].W, tab[q].epi = o.p[0], o.p[1], o.p[2]
+                    tab[q].X, tab[q].W, tab[q].epi = o.p[0], o.p[1], o.p[2] & ~1  # (strip SLIDE_EPI_PACKED_VECS: this kernel reads the descriptors' pointers)
                     tab[q].x_ld, tab[q].k_pad, tab[q].n_cob = o.i[1], o.i[2], o.i[3]
                 self._chain_keep.append(tab)
                 op = make_op(OP_GEMM_CHAIN, i=(self.ops[i].i[0], j - i), p=(ctypes.addressof(tab),))
