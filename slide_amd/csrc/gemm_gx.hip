@@ -72,7 +72,58 @@ __device__ __forceinline__ void gemm_gx_body(const GemmArgs &a, const int bid) {
   T *const vv_l = reinterpret_cast<T *>(vec_lds + CBW * 96);
   const int nsm = a.rows >> NPXL, smp0 = row0 >> NPXL;
 
-  // ---- per-sample vectors first (plain loads, converted to fp16): their latency runs under everything issued below
+  // PROLOGUE ORDER (round 6): descriptor / vector DMAs and the first ring stages are ISSUED before anything waits -- the plain loads
+  // below (per-sample vectors, neighbour slots) then share ONE memory round trip with them instead of preceding them (the
+  // per-workgroup timeline's "tables" phase: 1.0 - 1.7 us of a 7 - 17 us workgroup; tools/ab/op_timeline.py)
+  stage_epilogue_tables<CBW, 256>(a, cob0, tid, epi_lds, vec_lds);
+  // ---- table stream: this wave's NTI instructions per stage; instruction id = wave + 4 n -> (chunk of the stage, table, piece half)
+  const T *tsrc[NTI];
+  int tdst[NTI];
+#pragma unroll
+  for (int n = 0; n < NTI; ++n) {
+    const int id = wave + 4 * n;                       // SA: 0..3 = (c2, t); FP: 0..7 = (c2, t, h)
+    const int c2 = FP ? (id >> 2) & 1 : (id >> 1) & 1, t = FP ? (id >> 1) & 1 : id & 1, h = FP ? id & 1 : 0;
+    const int piece = FP ? 2 * h + (lane >> 5) : lane >> 4, r = lane & (NR - 1);
+    int smp = smp0 + (r >> 4);
+    smp = smp < nsm ? smp : nsm - 1;
+    tsrc[n] = reinterpret_cast<const T *>(t ? a.gx_tb : a.gx_ta) + ((size_t)smp * 16 + (r & 15)) * a.gx_ld + piece * 8;
+    tdst[n] = 2 * CH_B + (c2 * 2 + t) * TBL_B + (FP ? 2 * h * NR * 16 : 0);
+  }
+  // ---- weight ring: this lane's source piece of the wave's two DMA instructions per 32-deep chunk
+  const T *wsrc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int trow = 16 * (j * 4 + wave) + (lane >> 2);
+    const int piece = (lane & 3) ^ ((trow >> 2) & 3);
+    int gco = cob0 * 32 + trow;
+    gco = gco < a.n_cob * 32 ? gco : a.n_cob * 32 - 1;  // rows beyond the matrix: clamp (their channels are never stored)
+    wsrc[j] = reinterpret_cast<const T *>(a.W) + (size_t)gco * 32 + piece * 8;
+  }
+  const size_t w_cs = (size_t)a.n_cob * 32 * 32;  // elements between consecutive chunks
+  auto issue = [&](int st) __attribute__((always_inline)) {  // stage st -> slot st % NST (2 NJ DMA instructions per wave)
+    unsigned char *dst = ring + (size_t)(st % NST) * STAGE_B;
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+      int kc = st * 2 + c2;
+      kc = kc < nk32 ? kc : nk32 - 1;  // odd chunk count: the last stage's second image is a dummy (never read)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(wsrc[j] + (size_t)kc * w_cs),
+                                         (__attribute__((address_space(3))) void *)(dst + c2 * CH_B + (j * 4 + wave) * 1024),
+                                         16, 0, 0);
+    }
+#pragma unroll
+    for (int n = 0; n < NTI; ++n) {
+      int kc = st * 2 + (FP ? n : (wave >> 1));  // the chunk of the stage this instruction serves (id = wave + 4 n)
+      kc = kc < nk32 ? kc : nk32 - 1;
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(tsrc[n] + kc * 32),
+                                       (__attribute__((address_space(3))) void *)(dst + tdst[n]), 16, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0)
+    if (s0 < nks) issue(s0);
+  // ---- per-sample vectors (plain loads, converted to fp16)
   {
     const float *addp = a.in_add;
     if (MODE == 0 && addp && a.gx_add_idx) addp += (size_t)a.gx_add_idx[0] * a.gx_add_idx_stride;  // row t of a per-timestep table
@@ -124,56 +175,8 @@ __device__ __forceinline__ void gemm_gx_body(const GemmArgs &a, const int bid) {
     d2s[rb] = f16x2{(T)d2, (T)d2};
     ws[rb] = f16x2{(T)w, (T)w};
   }
-  stage_epilogue_tables<CBW, 256>(a, cob0, tid, epi_lds, vec_lds);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every plain load above has landed: from here the VM counter counts DMA only
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every plain load above has landed (and the primed stages with them)
 
-  // ---- table stream: this wave's NTI instructions per stage; instruction id = wave + 4 n -> (chunk of the stage, table, piece half)
-  const T *tsrc[NTI];
-  int tdst[NTI];
-#pragma unroll
-  for (int n = 0; n < NTI; ++n) {
-    const int id = wave + 4 * n;                       // SA: 0..3 = (c2, t); FP: 0..7 = (c2, t, h)
-    const int c2 = FP ? (id >> 2) & 1 : (id >> 1) & 1, t = FP ? (id >> 1) & 1 : id & 1, h = FP ? id & 1 : 0;
-    const int piece = FP ? 2 * h + (lane >> 5) : lane >> 4, r = lane & (NR - 1);
-    int smp = smp0 + (r >> 4);
-    smp = smp < nsm ? smp : nsm - 1;
-    tsrc[n] = reinterpret_cast<const T *>(t ? a.gx_tb : a.gx_ta) + ((size_t)smp * 16 + (r & 15)) * a.gx_ld + piece * 8;
-    tdst[n] = 2 * CH_B + (c2 * 2 + t) * TBL_B + (FP ? 2 * h * NR * 16 : 0);
-  }
-  // ---- weight ring: this lane's source piece of the wave's two DMA instructions per 32-deep chunk
-  const T *wsrc[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int trow = 16 * (j * 4 + wave) + (lane >> 2);
-    const int piece = (lane & 3) ^ ((trow >> 2) & 3);
-    int gco = cob0 * 32 + trow;
-    gco = gco < a.n_cob * 32 ? gco : a.n_cob * 32 - 1;  // rows beyond the matrix: clamp (their channels are never stored)
-    wsrc[j] = reinterpret_cast<const T *>(a.W) + (size_t)gco * 32 + piece * 8;
-  }
-  const size_t w_cs = (size_t)a.n_cob * 32 * 32;  // elements between consecutive chunks
-  auto issue = [&](int st) __attribute__((always_inline)) {  // stage st -> slot st % NST (2 NJ DMA instructions per wave)
-    unsigned char *dst = ring + (size_t)(st % NST) * STAGE_B;
-#pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2) {
-      int kc = st * 2 + c2;
-      kc = kc < nk32 ? kc : nk32 - 1;  // odd chunk count: the last stage's second image is a dummy (never read)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(wsrc[j] + (size_t)kc * w_cs),
-                                         (__attribute__((address_space(3))) void *)(dst + c2 * CH_B + (j * 4 + wave) * 1024),
-                                         16, 0, 0);
-    }
-#pragma unroll
-    for (int n = 0; n < NTI; ++n) {
-      int kc = st * 2 + (FP ? n : (wave >> 1));  // the chunk of the stage this instruction serves (id = wave + 4 n)
-      kc = kc < nk32 ? kc : nk32 - 1;
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(tsrc[n] + kc * 32),
-                                       (__attribute__((address_space(3))) void *)(dst + tdst[n]), 16, 0, 0);
-    }
-  };
-#pragma unroll
-  for (int s0 = 0; s0 < NST - 1; ++s0)
-    if (s0 < nks) issue(s0);
   SLIDE_STAMP(a, 7);
 
   const unsigned char *const vbase = reinterpret_cast<const unsigned char *>(vv_l + (size_t)sl_w * NVEC * a.k_pad) + half * 16;
@@ -735,16 +738,6 @@ __device__ __forceinline__ void sa_chain_body(const F1Args &a, const int bid) {
 #define F1_STAMP(k) do { } while (0)
 #endif
 
-  // ---- vectors (plain loads)
-  for (int i = tid; i < 3 * a.n1; i += 512) vec1_l[i] = a.vec1[i];
-  for (int i = tid; i < 3 * a.n2; i += 512) vec2_l[i] = a.vec2[i];
-  for (int i = tid; i < a.n1; i += 512) add1_l[i] = a.add1 ? a.add1[(size_t)b * a.add1_bs + i] : 0.f;
-  {
-    const float *addp = a.add0;
-    if (addp && a.add0_idx) addp += (size_t)a.add0_idx[0] * a.add0_stride;
-    for (int i = tid; i < a.k1; i += 512) add0_l[i] = (T)(addp ? addp[(size_t)b * a.add0_bs + i] : 0.f);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // ---- pair tables by LDS-DMA: [piece][16 rows][16 B]; one instruction = 4 pieces x 16 rows
   {
     const int r = lane & 15, pl = lane >> 4;
@@ -795,6 +788,28 @@ __device__ __forceinline__ void sa_chain_body(const F1Args &a, const int bid) {
     }
   };
   issue(0);
+  // ---- vectors.  PROLOGUE ORDER (round 6): the table DMAs and the first ring stage above are in flight before anything waits; the fp32
+  // vectors go by LDS-DMA as well (four bytes per lane), only the t-embedding row (fp16 in LDS, behind a device-side row index) takes
+  // plain loads -- one memory round trip + the index instead of four in a row (timeline "prologue": 1.8 - 2.3 us, and the first stage's
+  // wait behind it)
+  {
+    const int w64 = wave * 64;
+    auto dma4 = [&](const float *src, float *dst, int n) __attribute__((always_inline)) {
+      for (int i0 = w64; i0 < n; i0 += 512)
+        if (i0 + lane < n)
+          __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(src + i0 + lane), (__attribute__((address_space(3))) void *)(dst + i0), 4, 0, 0);
+    };
+    dma4(a.vec1, vec1_l, 3 * a.n1);
+    dma4(a.vec2, vec2_l, 3 * a.n2);
+    if (a.add1) dma4(a.add1 + (size_t)b * a.add1_bs, add1_l, a.n1);
+    else for (int i = tid; i < a.n1; i += 512) add1_l[i] = 0.f;
+  }
+  {
+    const float *addp = a.add0;
+    if (addp && a.add0_idx) addp += (size_t)a.add0_idx[0] * a.add0_stride;
+    for (int i = tid; i < a.k1; i += 512) add0_l[i] = (T)(addp ? addp[(size_t)b * a.add0_bs + i] : 0.f);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   F1_STAMP(14);
   // stage st must have landed before anyone reads it (NST = 2: nothing else is in flight)
   auto stage_ready = [&](int st) __attribute__((always_inline)) {
