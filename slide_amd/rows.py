@@ -182,6 +182,12 @@ class _ConvPlan:
         if bias is not None:
             self.vec[:O] = bias.detach().float()
         self.epis = {}  # output pointer -> device epilogue table (the caching allocator recycles a handful of addresses)
+        # PACKED VECTORS (SLIDE_EPI_PACKED_VECS, include/slide_engine.h): the blocks' [bias | gamma | beta] values behind the descriptors,
+        # bit 0 of the pointer set -- descriptors and vectors are then staged by LDS-DMA, without the per-workgroup pointer chase
+        pv = np.zeros((self.op_ // 32, 3, 32), np.float32)
+        pv[:, 0, :] = self.vec.cpu().numpy().reshape(-1, 32)
+        self._pv = pv.reshape(-1).view(np.uint8)
+        self._tag = 1 if os.environ.get("SLIDE_PACKED_VECS", "1") != "0" else 0
 
     def epi(self, out, stats=None, pre_relu=False, pre_add=None, out_f32=False):
         """pre_add = (per-point tensor [points][ld], log2 K): + pre_add[row >> log2 K] before the ReLU (SlideEpi.pre_add)"""
@@ -210,9 +216,13 @@ class _ConvPlan:
                     t.stats_sq = stats[1].data_ptr() + 4 * 32 * j
                     t.stats_bs = self.op_
                     t.stats_scale = 1.0
-            e = torch.from_numpy(np.frombuffer(bytes(tab), dtype=np.uint8).copy()).to(out.device)
+            e = torch.from_numpy(np.concatenate([np.frombuffer(bytes(tab), dtype=np.uint8), self._pv])).to(out.device)
             self.epis[key] = e
         return e
+
+    def epi_ptr(self, *args, **kw):
+        """the pointer an op carries: the table of epi() with the packed-vectors bit"""
+        return self.epi(*args, **kw).data_ptr() | self._tag
 
     def run(self, x, stats=None, pre_add=None, out_f32=False):
         """stats: None | "raw" | "relu" -- also publish per-256-row-tile channel sums of the output (of its ReLU) from the
@@ -244,7 +254,7 @@ class _ConvPlan:
             f = (0.0, float(x.S // 256), float(addvec.shape[1]) if addvec is not None else 0.0,
                  float(2 * (addvec.shape[1] if addvec is not None else 0) + int(relu)))
         _run(make_op(OP_GEMM, i=(rows, self.kp, self.kp, n_cob, 8, in_bs, int(self.half), cbw, int(self.half), 0), f=f,
-                     p=(x.data.data_ptr(), self.W.data_ptr(), self.epi(out, st, stats == "relu", pa, out_f32).data_ptr(), sc, sh,
+                     p=(x.data.data_ptr(), self.W.data_ptr(), self.epi_ptr(out, st, stats == "relu", pa, out_f32), sc, sh,
                         None, None, None, None, None, None, add)))
         return Rows(out, x.B, x.S, self.O, stats=None if st is None else (st[0], st[1], stats == "relu"))
 
@@ -543,7 +553,7 @@ def conv_attend(u, module, values, K, counts=None):
              float(2 * (addvec.shape[1] if addvec is not None else 0) + int(relu)))
     c32 = _counts32(counts, pts)
     _run(make_op(OP_GEMM_ATTEND, i=(u.rows, cp.kp, cp.kp, cp.op_ // 32, K, in_bs, values.ld, out.shape[1], u.S // K, int(v_relu), cp.O), f=f,
-                 p=(u.data.data_ptr(), cp.W.data_ptr(), cp.epi(out).data_ptr(), sc, sh, values.data.data_ptr(), out.data_ptr(),
+                 p=(u.data.data_ptr(), cp.W.data_ptr(), cp.epi_ptr(out), sc, sh, values.data.data_ptr(), out.data_ptr(),
                     None if c32 is None else c32.data_ptr(), None if vss is None else vss.data_ptr(), None, None, add)))
     return Rows(out, u.B, u.S // K, cp.O)
 
