@@ -38,7 +38,7 @@ if which == "feat":
 else:
     c = configs.position_ddpm_config()
     s = PositionSampler(c["pointnet_config"], synth_state_dict(model_spec.denoiser_param_spec(c["pointnet_config"])), B, dev,
-                        c["diffusion_config"], prec="fp16")
+                        c["diffusion_config"], prec=os.environ.get("TL_PREC", "fp16"))
     s.begin(np.zeros(B, np.int64), rs.standard_normal((B, 16, 3)).astype(np.float32))
 n = len(s.step_ops)
 st = ctypes.c_void_p(s.stream.cuda_stream)
