@@ -168,6 +168,43 @@ def concat_cols(parts):
 
 
 # ----------------------------------------------------------------------------------------------------------- GEMM
+class _PinnedUploader:
+    """Descriptor tables carry the addresses of a call's output / statistics / per-point tensors, and the caching allocator hands a
+    decode pass different addresses often enough that two thirds of the GEMM calls build a fresh table (measured: 489 of 750 in
+    tools/time_decode.py).  `torch.from_numpy(...).to(device)` of pageable memory is a SYNCHRONOUS copy: the host stalled once per such
+    call and the launch queue drained behind it.  Tables now go through a ring of pinned slots and an asynchronous stream-ordered copy;
+    a slot is reused only after the event of its previous copy (SLIDE_PINNED_TABLES=0: the synchronous upload)."""
+    SLOT, NSLOT = 64 * 1024, 256
+
+    def __init__(self):
+        self.buf = None
+        self.events = [None] * self.NSLOT
+        self.next = 0
+
+    def upload(self, arr, device):
+        n = arr.nbytes
+        if n > self.SLOT or os.environ.get("SLIDE_PINNED_TABLES", "1") == "0":
+            return torch.from_numpy(arr.copy()).to(device)
+        if self.buf is None:
+            self.buf = torch.empty(self.SLOT * self.NSLOT, dtype=torch.uint8).pin_memory()
+            self.np = self.buf.numpy()
+        i = self.next
+        self.next = (i + 1) % self.NSLOT
+        ev = self.events[i]
+        if ev is not None:
+            ev.synchronize()  # (256 tables ago: long since done)
+        self.np[i * self.SLOT:i * self.SLOT + n] = arr
+        dev = torch.empty(n, dtype=torch.uint8, device=device)
+        dev.copy_(self.buf[i * self.SLOT:i * self.SLOT + n], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        self.events[i] = ev
+        return dev
+
+
+_uploader = _PinnedUploader()
+
+
 class _ConvPlan:
     """packed weight + bias of one 1x1 convolution / linear for the row-major GEMM: y[rows, O] = x[rows, I] @ W^T + b"""
 
@@ -216,7 +253,7 @@ class _ConvPlan:
                     t.stats_sq = stats[1].data_ptr() + 4 * 32 * j
                     t.stats_bs = self.op_
                     t.stats_scale = 1.0
-            e = torch.from_numpy(np.concatenate([np.frombuffer(bytes(tab), dtype=np.uint8), self._pv])).to(out.device)
+            e = _uploader.upload(np.concatenate([np.frombuffer(bytes(tab), dtype=np.uint8), self._pv]), out.device)
             self.epis[key] = e
         return e
 
