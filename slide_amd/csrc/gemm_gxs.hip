@@ -501,16 +501,18 @@ __global__ __launch_bounds__(256, 2) void attn_tail_split_kernel(TailSArgs a) {
 #pragma unroll
   for (int cb = 0; cb < CBW; ++cb) {
     const float bv = b_v[cb * 32 + col];
-    float s = 0.f, ss = 0.f;
+    const f32x2 bv2 = {bv, bv};
+    f32x2 s2 = {0.f, 0.f}, ss2 = {0.f, 0.f};  // (register pairs: v_pk_add / v_pk_fma_f32)
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float x = vacc[cb][rb][r] + bv;
-        vacc[cb][rb][r] = x;
-        s += x;
-        ss = fmaf(x, x, ss);
+      for (int i = 0; i < 8; ++i) {
+        const f32x2 x = f32x2{vacc[cb][rb][2 * i], vacc[cb][rb][2 * i + 1]} + bv2;
+        vacc[cb][rb][2 * i] = x[0]; vacc[cb][rb][2 * i + 1] = x[1];
+        s2 += x;
+        ss2 = __builtin_elementwise_fma(x, x, ss2);
       }
+    float s = s2[0] + s2[1], ss = ss2[0] + ss2[1];
     s += gxs_other_half(s);
     ss += gxs_other_half(ss);
     if (half == 0) *reinterpret_cast<f32x2 *>(red + ((wave * CBW + cb) * 32 + col) * 2) = f32x2{s, ss};
@@ -539,47 +541,66 @@ __global__ __launch_bounds__(256, 2) void attn_tail_split_kernel(TailSArgs a) {
     float g = gam[cb * 32 + col] * __builtin_amdgcn_rsqf(var + GN_EPS);
     float bt = bet[cb * 32 + col] - mean * g;
     if ((cob0 + cb) * 32 + col >= a.n_norm) { g = 1.f; bt = 0.f; }
+    const f32x2 g2 = {g, g}, bt2 = {bt, bt};
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) vacc[cb][rb][r] = fmaxf(fmaf(vacc[cb][rb][r], g, bt), 0.f);
+      for (int i = 0; i < 8; ++i) {
+        const f32x2 v = __builtin_elementwise_fma(f32x2{vacc[cb][rb][2 * i], vacc[cb][rb][2 * i + 1]}, g2, bt2);
+        vacc[cb][rb][2 * i] = fmaxf(v[0], 0.f); vacc[cb][rb][2 * i + 1] = fmaxf(v[1], 0.f);
+      }
   }
   __syncthreads();  // every wave has read the statistics: the stage is free for the score contraction
   run(a.X1, a.W1, a.x1_ld, a.k1, sacc);
+  // ---- base-2 soft-max over the K neighbour rows of every point, weighted sum of the values, one row out per point.  Round 6: written
+  // like attn_tail_finish (engine.hip) -- register pairs (v_pk_fma / v_pk_add_f32), log2 e folded into the bias step and v_exp_f32 on
+  // the difference (libm's expf cost ~25 instructions per value here), v_rcp instead of an IEEE division (1 ulp), one lane-half
+  // exchange for numerator and denominator together.  The scores' rounding (one fma at magnitude |s| log2 e) stays at a few 1e-6 of a
+  // soft-max weight: fp32-grade (position forwards vs the fp32 mode: bench.py parity, tests/test_hip_engine.py).
+  constexpr float LOG2E = 1.44269504088896340736f;
+  auto pr = [](const f32x16 &v, int i) __attribute__((always_inline)) { return f32x2{v[2 * i], v[2 * i + 1]}; };
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int pt0 = (row0 + wave_s * 64) >> KLOG, npts = a.rows >> KLOG;
 #pragma unroll
   for (int cb = 0; cb < CBW; ++cb) {
-    const float bs = b_s[cb * 32 + col];
-    // ---- softmax over the K neighbour rows of every point, weighted sum of the values, one row out per point
+    const float bsl = b_s[cb * 32 + col] * LOG2E;
+    const f32x2 bs2 = {bsl, bsl}, l2 = {LOG2E, LOG2E};
+    const bool cb_ok = cob0 + cb < a.n_cob;  // (uniform)
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
       for (int pg = 0; pg < GPB; ++pg) {
         // rows of point pg inside the 32-row block: 16 -> regs 8pg .. 8pg+7 (both halves); 8 -> regs 4pg .. 4pg+3
-        constexpr int RPG = 16 / GPB;
-        float sc[RPG];
+        constexpr int PPG = 8 / GPB;  // register pairs per point
+        f32x2 sc[PPG];
         float m = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < RPG; ++j) {
-          sc[j] = sacc[cb][rb][pg * RPG + j] + bs;
-          m = fmaxf(m, sc[j]);
+        for (int j = 0; j < PPG; ++j) {
+          sc[j] = __builtin_elementwise_fma(pr(sacc[cb][rb], pg * PPG + j), l2, bs2);
+          m = fmaxf(m, fmaxf(sc[j][0], sc[j][1]));
         }
         m = fmaxf(m, gxs_other_half(m));
-        float den = 0.f, num = 0.f;
+        const f32x2 m2 = {m, m};
+        f32x2 den2 = {0.f, 0.f}, num2 = {0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < RPG; ++j) {
-          const float e = expf(sc[j] - m);
-          den += e;
-          num = fmaf(e, vacc[cb][rb][pg * RPG + j], num);
+        for (int j = 0; j < PPG; ++j) {
+          const f32x2 d = sc[j] - m2;
+          const f32x2 e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+          den2 += e;
+          num2 = __builtin_elementwise_fma(e, pr(vacc[cb][rb], pg * PPG + j), num2);
         }
-        den += gxs_other_half(den);
-        num += gxs_other_half(num);
-        const int rbase = row0 + wave * 64 + rb * 32 + pg * KN;
-        if (half == 0 && rbase < a.rows && cob0 + cb < a.n_cob) {
-          const float v = num / den;
-          a.out[(size_t)(rbase >> KLOG) * a.out_ld + (cob0 + cb) * 32 + col] = v;
+        uint32_t un = __float_as_uint(num2[0] + num2[1]), ud = __float_as_uint(den2[0] + den2[1]);
+        lane32_swap(un, ud);
+        const float tot = __uint_as_float(un) + __uint_as_float(ud);  // lower lanes: numerator, upper lanes: denominator
+        uint32_t ua = __float_as_uint(tot), ub = ua;
+        lane32_swap(ua, ub);  // ub (lower lanes) = the upper lanes' tot
+        const int pidx = rb * GPB + pg;  // point of the wave
+        if (half == 0 && pt0 + pidx < npts && cb_ok) {
+          const float v = tot * __builtin_amdgcn_rcpf(__uint_as_float(ub));
+          a.out[(size_t)(pt0 + pidx) * a.out_ld + (cob0 + cb) * 32 + col] = v;
           // second copy into the columns of a later concatenation buffer (the skip input of an FP block's second Mlp)
           if (a.out2 && (cob0 + cb) * 32 + col < a.out2_n)
-            a.out2[(size_t)(rbase >> KLOG) * a.out2_ld + (cob0 + cb) * 32 + col] = v;
+            a.out2[(size_t)(pt0 + pidx) * a.out2_ld + (cob0 + cb) * 32 + col] = v;
         }
       }
   }
