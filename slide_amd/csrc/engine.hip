@@ -366,6 +366,7 @@ __global__ __launch_bounds__(256, 3) void gemm_split_small_kernel(GemmArgs a) {
   };
   uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + 2 * (size_t)STAGE * sizeof(_Float16));
   float *const vec_lds = reinterpret_cast<float *>(epi_lds + 2 * EPI_DW + (2 * EPI_DW) % 4);
+  SLIDE_STAMP(a, 0);
   stage_epilogue_tables<2>(a, cob0, tid, epi_lds, vec_lds);
   if (a.in_scale) {
     float *al = vec_lds + 2 * 96;
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(256, 3) void gemm_split_small_kernel(GemmArgs a) {
   for (int j = 0; j < PD; ++j)
     if (j + 1 < nk) load_chunk(j + 1, xr[j], wr[j]);  // buffer j: chunks j + 1, j + 1 + PD, ...
   __syncthreads();
+  SLIDE_STAMP(a, 1);
   for (int kc0 = 0; kc0 < nk; kc0 += PD) {
 #pragma unroll
     for (int j = 0; j < PD; ++j) {
@@ -412,8 +414,13 @@ __global__ __launch_bounds__(256, 3) void gemm_split_small_kernel(GemmArgs a) {
   f32x16 one[1][1];
 #pragma unroll
   for (int r = 0; r < 16; ++r) one[0][0][r] = fmaf(acc2[r], 1.f / 2048.f, acc[r]);
+  SLIDE_STAMP(a, 2);
   gemm_epilogue<SLIDE_PREC_F32, NPXL, 1, 1>(a, one, row0 + rb * 32, cob0 + cb, 0, half, col, epi_lds + cb * EPI_DW, vec_lds + cb * 96,
                                             nullptr);
+  SLIDE_STAMP(a, 5);
+#ifdef SLIDE_TIMELINE
+  if (a.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SLIDE_STAMP(a, 6); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ LDS-DMA GEMM

@@ -708,6 +708,67 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
         }
       }
       if constexpr (KEEP) return;
+      // PAIR residual on float rows (split plans, 128- / 256-row samples): the table rows of a 16-byte piece pair (row block rb, quads
+      // 2p, 2p + 1) are requested ONE PIECE PAIR AHEAD of the stores that consume the previous pair, the coefficient vectors of
+      // group_knn's scalars once per block -- a load cannot move above a store the compiler must assume aliases it, so the plain
+      // loop below paid one dependent memory round trip per quad: 9.2 of a 17.5 us workgroup on the FP blocks' Mlp layers of the
+      // position plan (tools/ab/op_timeline.py)
+      if constexpr (HR && !kHalf && NPXL == 7 && PAIRRES && RB == 2) {
+        if (pair) {
+          const GLOBAL_AS T *resb = gptr<const T>(rdp(34));
+          const bool nbr = NPXL == 7 && (flags & SLIDE_F_RES_PAIR_NBR) != 0;
+          bool okr[2];
+          size_t orow[2];
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) {
+            const int row = row0 + wave * 64 + rb * 32 + col;
+            okr[rb] = row < a.rows;
+            orow[rb] = (size_t)row * e_out_ld;
+          }
+          float4 vd[4], vw[4];
+          if (nbr) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              vd[q] = gload4(gptr<const float>(rdp(36)) + 8 * q + 4 * half);
+              vw[q] = gload4(gptr<const float>(rdp(38)) + 8 * q + 4 * half);
+            }
+          }
+          float4 A[2][2], B[2][2];
+          auto fetch = [&](int idx, float4 (&A_)[2], float4 (&B_)[2]) __attribute__((always_inline)) {
+            const int p = idx >> 1, rb = idx & 1;
+            if (!okr[rb]) return;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int c0 = 8 * (2 * p + j) + 4 * half;
+              A_[j] = gload4(resid + (size_t)pr_a[rb] * e_res_ld + c0);
+              B_[j] = gload4(resb + (size_t)pr_b[rb] * e_res_ld + c0);
+            }
+          };
+          fetch(0, A[0], B[0]);
+#pragma unroll
+          for (int idx = 0; idx < 4; ++idx) {
+            const int p = idx >> 1, rb = idx & 1;
+            if (idx + 1 < 4) fetch(idx + 1, A[(idx + 1) & 1], B[(idx + 1) & 1]);
+            if (!okr[rb]) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int q = 2 * p + j, c0 = 8 * q + 4 * half;
+              float4 y = make_float4(v[rb][2 * q][0], v[rb][2 * q][1], v[rb][2 * q + 1][0], v[rb][2 * q + 1][1]);
+              float4 t = A[idx & 1][j];
+              const float4 t2 = B[idx & 1][j];
+              t.x += t2.x; t.y += t2.y; t.z += t2.z; t.w += t2.w;
+              if (nbr) {
+                const float d2 = nbr_d2f[rb], w_ = nbr_wf[rb];
+                t.x = fmaf(w_, vw[q].x, fmaf(d2, vd[q].x, t.x)); t.y = fmaf(w_, vw[q].y, fmaf(d2, vd[q].y, t.y));
+                t.z = fmaf(w_, vw[q].z, fmaf(d2, vd[q].z, t.z)); t.w = fmaf(w_, vw[q].w, fmaf(d2, vd[q].w, t.w));
+              }
+              y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+              gstore4(gptr<T>(e_out) + orow[rb] + c0, y);
+            }
+          }
+          return;
+        }
+      }
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
         const int row = row0 + wave * 64 + rb * 32 + col;
@@ -737,6 +798,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
             continue;
           }
           if (ok) {
+            // PAIR residual on float rows: the table rows (and group_knn's coefficient vectors) of BOTH quads of this piece are
+            // requested together, ahead of the piece's stores -- a load cannot move above a store the compiler must assume aliases
+            // it, so one quad at a time was a dependent memory round trip per quad: 9.2 of a 17.5 us workgroup on the FP blocks'
+            // Mlp layers of the position plan (tools/ab/op_timeline.py), 6 with two quads per trip
+            float4 pa[2], pb[2], pvd[2], pvw[2];
+            if constexpr (HR && !kHalf && NPXL >= 7 && PAIRRES) {
+              if (pair) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                  const int c0 = 8 * (2 * p + j) + 4 * half;
+                  pa[j] = gload4(resid + (size_t)pr_a[rb] * e_res_ld + c0);
+                  pb[j] = gload4(gptr<const T>(rdp(34)) + (size_t)pr_b[rb] * e_res_ld + c0);
+                  if constexpr (NPXL == 7) {
+                    if (flags & SLIDE_F_RES_PAIR_NBR) {
+                      pvd[j] = gload4(gptr<const float>(rdp(36)) + c0);
+                      pvw[j] = gload4(gptr<const float>(rdp(38)) + c0);
+                    }
+                  }
+                }
+              }
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               const int q = 2 * p + j, c0 = 8 * q + 4 * half;
@@ -747,12 +829,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
                 if constexpr (!kHalf && NPXL >= 7 && PAIRRES) {
                   if (pair) {  // PAIR residual on float rows (split mode): ta[q] + tb[p] (+ d2 vd + w vw), evaluated in fp32
                     plain = false;
-                    t = gload4(resid + (size_t)pr_a[rb] * e_res_ld + c0);
-                    const float4 t2 = gload4(gptr<const T>(rdp(34)) + (size_t)pr_b[rb] * e_res_ld + c0);
+                    t = pa[j];
+                    const float4 t2 = pb[j];
                     t.x += t2.x; t.y += t2.y; t.z += t2.z; t.w += t2.w;
                     if constexpr (NPXL == 7) {
                       if (flags & SLIDE_F_RES_PAIR_NBR) {
-                        const float4 vd = gload4(gptr<const float>(rdp(36)) + c0), vw = gload4(gptr<const float>(rdp(38)) + c0);
+                        const float4 vd = pvd[j], vw = pvw[j];
                         const float d2 = nbr_d2f[rb], w_ = nbr_wf[rb];
                         t.x = fmaf(w_, vw.x, fmaf(d2, vd.x, t.x)); t.y = fmaf(w_, vw.y, fmaf(d2, vd.y, t.y));
                         t.z = fmaf(w_, vw.z, fmaf(d2, vd.z, t.z)); t.w = fmaf(w_, vw.w, fmaf(d2, vd.w, t.w));
@@ -764,7 +846,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[C
                 y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
                 // (float PAIR instantiations: keep the compiler from hoisting all sixteen table loads of the store phase above the
                 //  first store -- 64 registers of loads in flight push the chained kernel of gemm_gxs.hip over its 256)
-                if constexpr (!kHalf && NPXL >= 7 && PAIRRES) asm volatile("" ::: "memory");
+                if constexpr (!kHalf && NPXL >= 7 && PAIRRES && NOADDV) asm volatile("" ::: "memory");
               }
               if (flags & SLIDE_F_OUT_F32)
                 gstore4(gptr<float>(e_out) + (size_t)row * e_out_ld + c0, y);

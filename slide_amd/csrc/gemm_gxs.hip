@@ -75,6 +75,7 @@ __device__ __forceinline__ void gemm_gxs_body(const GemmArgs &a, const int bid) 
   uint32_t *const epi_lds = reinterpret_cast<uint32_t *>(smem_raw + (size_t)STAGE * 2);
   float *const vec_lds = reinterpret_cast<float *>(epi_lds + CBW * EPI_DW + (CBW * EPI_DW) % 4);
   float *const vv_l = vec_lds + CBW * 96;  // [sample][NVEC][k_pad]
+  SLIDE_STAMP(a, 0);
   stage_epilogue_tables<CBW>(a, cob0, tid, epi_lds, vec_lds);
   {
     const float *addp = a.in_add;
@@ -231,11 +232,13 @@ __device__ __forceinline__ void gemm_gxs_body(const GemmArgs &a, const int bid) 
   };
 
   const int nk = a.k_pad / BK;
+  SLIDE_STAMP(a, 7);
   if (FP) __syncthreads();  // (the row table is read by load_chunk)
   load_chunk(0);
   __syncthreads();  // the staged vectors and epilogue tables are visible
   store_chunk(0);
   __syncthreads();
+  SLIDE_STAMP(a, 1);
   for (int kc = 0; kc < nk; ++kc) {
     if (kc + 1 < nk) load_chunk(kc + 1);
     compute(acc);
@@ -243,6 +246,7 @@ __device__ __forceinline__ void gemm_gxs_body(const GemmArgs &a, const int bid) 
     if (kc + 1 < nk) store_chunk(kc + 1);
     __syncthreads();
   }
+  SLIDE_STAMP(a, 2);
 #pragma unroll
   for (int i = 0; i < CBW; ++i)
 #pragma unroll
@@ -314,6 +318,10 @@ __device__ __forceinline__ void gemm_gxs_body(const GemmArgs &a, const int bid) 
   // float rows: the fp32 epilogue (mode 0 = the Mlp layers: PAIR residual on the float tables)
   gemm_epilogue<SLIDE_PREC_F32, NPXL, CBW, 2, MODE == 0>(a, acc, row0, cob0, wave, half, col, epi_lds, vec_lds,
                                                          reinterpret_cast<float *>(smem_raw));
+  SLIDE_STAMP(a, 5);
+#ifdef SLIDE_TIMELINE
+  if (a.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SLIDE_STAMP(a, 6); }
+#endif
 }
 
 template <int NPXL, int MODE>
@@ -770,6 +778,9 @@ static int gxs_args_from_op(const SlideOp &o, GemmArgs &a) {
   // chained second layer (p[12] = its float weights, p[13] = its epilogue descriptors, f[1] = its n_cob, f[2] = its k_pad): 16 x 16-row
   // samples, mode 0, every channel of this layer in one 64-channel tile, which is also the next layer's whole K
   a.ch_W = o.p[12]; a.ch_epi = (const SlideEpi *)o.p[13]; a.ch_n_cob = (int)o.f[1]; a.ch_k_pad = (int)o.f[2];
+#ifdef SLIDE_TIMELINE
+  if (!a.ch_W) { a.dbg = (unsigned long long *)o.p[13]; a.ch_epi = nullptr; }  // (tools/ab/op_timeline.py: stamps of an unchained launch)
+#endif
   resolve_epi(a);
   if (a.ch_W && (npxl != 8 || a.gx_mode != 0 || a.n_cob > 2 || !a.ch_epi || a.ch_n_cob <= 0 || a.ch_k_pad != a.n_cob * 32 ||
                  (uintptr_t)a.ch_W % 16))

@@ -52,6 +52,8 @@ with torch.cuda.stream(s.stream):
         nwg = 16384
         dbg = torch.zeros(nwg * 16, dtype=torch.int64, device=dev)
         slot = {1: 5, 17: 12, 19: 12, 16: 8, 30: 1, 31: 13}.get(op.kind)
+        if op.kind == 17 and int(op.f[0]) == 3:  # split generated-X GEMM (gemm_gxs.hip): p[12] / p[13] carry a chained layer
+            slot = None if op.p[12] else 13
         if slot is None:
             print("op %d: kind %d carries no stamps" % (idx, op.kind)); continue
         op.p[slot] = dbg.data_ptr()

@@ -6,3 +6,4 @@ echo "rep $rep: $(python bench.py --gpus 1 --steps 300 --warmup 20 --no-cpu-base
 done
 python tools/profile_ops.py --which pos --prec split --batch 512 2>&1 | grep "ATTN_TAIL\|total us"
 python bench.py --gpus 1 --steps 40 --warmup 5 --no-cpu-baseline --no-decode --no-roofline --no-configs 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.read());print(json.dumps(d['parity'])[:700])"
+( export SLIDE_GX_DUAL=0 TL_PREC=split; python tools/ab/op_timeline.py pos 512 kind17 2>&1 | grep -v "amdgpu.ids\|no stamps" )
