@@ -77,33 +77,6 @@ __device__ __forceinline__ void gemm_gxs_body(const GemmArgs &a, const int bid) 
   float *const vv_l = vec_lds + CBW * 96;  // [sample][NVEC][k_pad]
   SLIDE_STAMP(a, 0);
   stage_epilogue_tables<CBW>(a, cob0, tid, epi_lds, vec_lds);
-  {
-    const float *addp = a.in_add;
-    if (MODE == 0 && addp && a.gx_add_idx) addp += (size_t)a.gx_add_idx[0] * a.gx_add_idx_stride;  // row t of a per-timestep table
-    for (int i = tid * 4; i < NSAMP * a.k_pad; i += 1024) {
-      const int sl = i / a.k_pad, k = i - sl * a.k_pad;
-      int smp = smp0 + sl;
-      smp = smp < nsm ? smp : nsm - 1;
-      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, vd = v0, vw = v0;
-      if (MODE == 0) {
-        if (addp) v0 = *reinterpret_cast<const float4 *>(addp + (size_t)smp * a.add_bs + k);
-      } else {
-        v0 = *reinterpret_cast<const float4 *>(a.in_scale + (size_t)smp * a.in_bs + k);
-        v1 = *reinterpret_cast<const float4 *>(a.in_shift + (size_t)smp * a.in_bs + k);
-      }
-      if (FP && a.gx_vv) {
-        vd = *reinterpret_cast<const float4 *>(a.gx_vv + (size_t)smp * a.gx_vbs + k);
-        vw = *reinterpret_cast<const float4 *>(a.gx_vv + (size_t)smp * a.gx_vbs + (a.gx_vbs >> 1) + k);
-      }
-      float *dst = vv_l + (size_t)sl * NVEC * a.k_pad + k;
-      *reinterpret_cast<float4 *>(dst) = v0;
-      if (MODE) *reinterpret_cast<float4 *>(dst + a.k_pad) = v1;
-      if (FP) {
-        *reinterpret_cast<float4 *>(dst + (MODE ? 2 : 1) * a.k_pad) = vd;
-        *reinterpret_cast<float4 *>(dst + (MODE ? 3 : 2) * a.k_pad) = vw;
-      }
-    }
-  }
   // this thread's eight tile rows: neighbour (a) and centre (b) table rows (element offsets: the tables are far below 2^31
   // elements).  16 x 8-row samples: the neighbour's table row and the two per-slot scalars of every tile row live in LDS
   // ([256] x (offset, d2, w): kept in registers they push the kernel over its 256)
@@ -232,9 +205,41 @@ __device__ __forceinline__ void gemm_gxs_body(const GemmArgs &a, const int bid) 
   };
 
   const int nk = a.k_pad / BK;
+  // PROLOGUE ORDER (round 6): 16 x 16-row samples (natural neighbour order: no row table) request their first chunk BEFORE the
+  // per-sample vectors are staged -- one memory round trip instead of two in front of the first MFMA
+  if (!FP) load_chunk(0);
+  {
+    const float *addp = a.in_add;
+    if (MODE == 0 && addp && a.gx_add_idx) addp += (size_t)a.gx_add_idx[0] * a.gx_add_idx_stride;  // row t of a per-timestep table
+    for (int i = tid * 4; i < NSAMP * a.k_pad; i += 1024) {
+      const int sl = i / a.k_pad, k = i - sl * a.k_pad;
+      int smp = smp0 + sl;
+      smp = smp < nsm ? smp : nsm - 1;
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, vd = v0, vw = v0;
+      if (MODE == 0) {
+        if (addp) v0 = *reinterpret_cast<const float4 *>(addp + (size_t)smp * a.add_bs + k);
+      } else {
+        v0 = *reinterpret_cast<const float4 *>(a.in_scale + (size_t)smp * a.in_bs + k);
+        v1 = *reinterpret_cast<const float4 *>(a.in_shift + (size_t)smp * a.in_bs + k);
+      }
+      if (FP && a.gx_vv) {
+        vd = *reinterpret_cast<const float4 *>(a.gx_vv + (size_t)smp * a.gx_vbs + k);
+        vw = *reinterpret_cast<const float4 *>(a.gx_vv + (size_t)smp * a.gx_vbs + (a.gx_vbs >> 1) + k);
+      }
+      float *dst = vv_l + (size_t)sl * NVEC * a.k_pad + k;
+      *reinterpret_cast<float4 *>(dst) = v0;
+      if (MODE) *reinterpret_cast<float4 *>(dst + a.k_pad) = v1;
+      if (FP) {
+        *reinterpret_cast<float4 *>(dst + (MODE ? 2 : 1) * a.k_pad) = vd;
+        *reinterpret_cast<float4 *>(dst + (MODE ? 3 : 2) * a.k_pad) = vw;
+      }
+    }
+  }
   SLIDE_STAMP(a, 7);
-  if (FP) __syncthreads();  // (the row table is read by load_chunk)
-  load_chunk(0);
+  if (FP) {
+    __syncthreads();  // (the row table is read by load_chunk)
+    load_chunk(0);
+  }
   __syncthreads();  // the staged vectors and epilogue tables are visible
   store_chunk(0);
   __syncthreads();
