@@ -2228,9 +2228,9 @@ int launch_gemm_small_t(const GemmArgs &a, hipStream_t s) {
 template <bool FP>
 int launch_pair_first_t(const GemmArgs &a, const PairArgs &pa, hipStream_t s) {
   const int grid = ((a.rows + 63) / 64) * ((a.n_cob + 1) / 2);
-  // (SA blocks stage only the four samples' coordinates: 51 KB -> THREE workgroups per CU; FP blocks also the neighbour / distance /
-  //  weight slots: 57 KB, two per CU)
-  const size_t shm = (size_t)4 * 2 * 6144 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32 + (192 + (FP ? 3 * 512 : 0)) * 4;
+  // (51 KB -> THREE workgroups per CU: the four samples' coordinates behind the rings; the FP blocks' neighbour / distance / weight
+  //  slots wait in registers and land in the dead ring area after the K loop, gemm_small.h)
+  const size_t shm = (size_t)4 * 2 * 6144 + 2 * (sizeof(SlideEpi) + 96 * 4) + 32 + 192 * 4;
   static bool attr_done[SLIDE_MAX_DEVICES] = {};
   bool &attr_set = attr_done[current_device_slot()];
   if (!attr_set) {

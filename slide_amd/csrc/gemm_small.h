@@ -75,8 +75,11 @@ __device__ __forceinline__ void small_body(const GemmArgs &a, const PairArgs &pa
     if (s0 < mine) issue(kh + 2 * s0, s0);
   // tables (and the affine vectors) are staged behind the primed rings: their latency overlaps the first chunks'
   stage_epilogue_tables<2>(a, cob0, tid, epi_lds, vec_lds);
-  // PAIR: the four samples' coordinates [4][48] and (FP) neighbour / squared-distance / weight slots [4][16 x 8] each
+  // PAIR: the four samples' coordinates [4][48]; (FP) the neighbour / squared-distance / weight slots [4][16 x 8] each: pair_ext
   float *const pair_lds = vec_lds + 2 * 96;
+  float *const pair_ext = reinterpret_cast<float *>(smem_raw + 20480);  // [nbr | d2 | w][4 samples][16 x 8]: behind `part` / `tr` (18 KB)
+  int ext_n[2] = {0, 0};
+  float ext_d[2] = {0.f, 0.f}, ext_w[2] = {0.f, 0.f};
   if constexpr (PAIR != 0) {
     const int nb = a.rows >> NPXL, b0 = row0 >> NPXL;
     if (tid < 192) {
@@ -84,12 +87,14 @@ __device__ __forceinline__ void small_body(const GemmArgs &a, const PairArgs &pa
       pair_lds[tid] = pa.xyz[(size_t)bb * 48 + tid % 48];
     }
     if (PAIR == 2) {
-      for (int i = tid; i < 512; i += 256) {
+      // (round 6) the slot tables wait in SIX registers across the K loop and go to the DEAD ring area behind it (pair_ext below):
+      // staged next to the coordinates they made the workgroup 57 KB -- two per CU; 51 KB fit three
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = tid + 256 * u;
         const int bb = b0 + (i >> 7) < nb ? b0 + (i >> 7) : nb - 1, t = i & 127;
         const int slot = (bb * 16 + (t >> 3)) * 16 + (t & 7);
-        reinterpret_cast<int *>(pair_lds + 192)[i] = pa.nbr[slot];
-        pair_lds[192 + 512 + i] = pa.d2t[slot];
-        pair_lds[192 + 1024 + i] = pa.wt[slot];
+        ext_n[u] = pa.nbr[slot]; ext_d[u] = pa.d2t[slot]; ext_w[u] = pa.wt[slot];
       }
     }
   }
@@ -222,6 +227,15 @@ __device__ __forceinline__ void small_body(const GemmArgs &a, const PairArgs &pa
   }
   __syncthreads();  // rings are dead, tables are visible
   SLIDE_STAMP(a, 2);
+  if constexpr (PAIR == 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = tid + 256 * u;
+      reinterpret_cast<int *>(pair_ext)[i] = ext_n[u];
+      pair_ext[512 + i] = ext_d[u];
+      pair_ext[1024 + i] = ext_w[u];
+    }
+  }
   // wave (kh, cbw) finishes the block (channel block cbw, row block kh): it keeps its own partial of that block in registers
   // and takes the other K half's from its partner (1 - kh, cbw) through LDS [wave][reg][lane]
   float *const part = reinterpret_cast<float *>(smem_raw);
@@ -292,8 +306,8 @@ __device__ __forceinline__ void small_body(const GemmArgs &a, const PairArgs &pa
               s += v; ss = fmaf(v, v, ss);
             }
         } else {
-          const int *sqs = reinterpret_cast<const int *>(pair_lds + 192) + sl4 * 128;
-          const float *sds = pair_lds + 192 + 512 + sl4 * 128, *sws = pair_lds + 192 + 1024 + sl4 * 128;
+          const int *sqs = reinterpret_cast<const int *>(pair_ext) + sl4 * 128;
+          const float *sds = pair_ext + 512 + sl4 * 128, *sws = pair_ext + 1024 + sl4 * 128;
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the transposed block has been read: its area takes the columns
           float *const sa = tr;  // [16][65]
 #pragma unroll
