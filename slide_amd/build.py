@@ -31,7 +31,9 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=h
 
 # PRODUCT build: NO kernel may spill a register or use scratch (the build fails otherwise; SLIDE_ALLOW_SPILLS=1 downgrades that
 # to a warning for other ROCm / LLVM versions).  The experiments build is not linted.
-SPILL_OPT_IN = []
+# The ONE exception: gemm_gx_dual_kernel<7> runs at three workgroups per CU (168 registers) with 15 values parked in scratch OUTSIDE
+# its MFMA steps (gemm_gx.hip; measured +1.1 % on the headline against the spill-free two-per-CU form).
+SPILL_OPT_IN = [r"gemm_gx_dual_kernel<7>"]
 
 
 def parse_resource_remarks(stderr):

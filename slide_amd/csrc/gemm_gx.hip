@@ -313,10 +313,19 @@ __global__ __launch_bounds__(256, 2) void gemm_gx_n64w_kernel(GemmArgs a) {
 // TWO independent generated-X GEMMs of one block in ONE launch (SLIDE_OP_GEMM_GX_DUAL): the keys -> u layer (mode 1) and the
 // first Mlp layer (mode 0) of an FP block read the same pair tables and nothing of each other; as one grid they cost one
 // launch gap instead of two and their workgroups fill the chip together (64-channel tiles, two workgroups per CU)
+// FP blocks (NPXL = 7; round 6): THREE workgroups per CU -- a two-stage ring (42 KB with the per-sample vectors of K = 544 instead of 58)
+// inside the 168-register budget.  The K loops of these layers are bound by the LDS reads and packed-fp16 generation of their fragments
+// (ten ds_read_b128 and ~40 VALU per four MFMAs), their workgroups by prologue and epilogue latency: a third resident workgroup -- of
+// this launch or of another chain's -- fills what two leave idle: 415.2 -> 419.7 shapes/s in bench.py's arrangement (four alternating
+// pairs in one call, tools/ab/r06_libab.sh dual3).  The mode-0 body (PAIR residual) needs 178 registers when left alone: at 168 the
+// compiler parks 15 values in scratch -- addressing terms of the prologue / epilogue and ONE 8-byte reload per ring stage (none in the
+// MFMA steps) -- which is the one deliberate exception to the product build's no-spill rule (slide_amd/build.py SPILL_OPT_IN).
 template <int NPXL>
-__global__ __launch_bounds__(256, 2) void gemm_gx_dual_kernel(GemmArgs a1, GemmArgs a0, int grid1) {
-  if ((int)blockIdx.x < grid1) gemm_gx_body<NPXL, 3, 1, 2>(a1, blockIdx.x);
-  else gemm_gx_body<NPXL, 3, 0, 2>(a0, blockIdx.x - grid1);
+constexpr int GX_DUAL_NST = NPXL == 7 ? 2 : 3;
+template <int NPXL>
+__global__ __launch_bounds__(256, NPXL == 7 ? 3 : 2) void gemm_gx_dual_kernel(GemmArgs a1, GemmArgs a0, int grid1) {
+  if ((int)blockIdx.x < grid1) gemm_gx_body<NPXL, GX_DUAL_NST<NPXL>, 1, 2>(a1, blockIdx.x);
+  else gemm_gx_body<NPXL, GX_DUAL_NST<NPXL>, 0, 2>(a0, blockIdx.x - grid1);
 }
 
 // ------------------------------------------------------------------------------------------------ pair-table normalisation
@@ -491,11 +500,11 @@ template <int NPXL>
 static int launch_gx_dual(const GemmArgs &a1, const GemmArgs &a0, hipStream_t s) {
   constexpr int NSAMP = TM >> NPXL;
   auto lds = [&](const GemmArgs &a, int nvec) {
-    return (size_t)3 * (8192 + 4 * 64 * 16 * NSAMP) + (2 * EPI_DW + (2 * EPI_DW) % 4 + 2 * 96) * 4 + (size_t)NSAMP * nvec * a.k_pad * 2 + 16;
+    return (size_t)GX_DUAL_NST<NPXL> * (8192 + 4 * 64 * 16 * NSAMP) + (2 * EPI_DW + (2 * EPI_DW) % 4 + 2 * 96) * 4 + (size_t)NSAMP * nvec * a.k_pad * 2 + 16;
   };
   const size_t s1 = lds(a1, 2 + (NPXL == 7 ? 2 : 0)), s0 = lds(a0, 1 + (NPXL == 7 ? 2 : 0));
   const size_t shm = s1 > s0 ? s1 : s0;
-  if (shm > 80 * 1024) return -8;
+  if (shm > (NPXL == 7 ? 53 : 80) * 1024) return -8;  // (three / two workgroups per CU)
   const int ntr = (a1.rows + TM - 1) / TM;
   const int g1 = ((ntr + 7) / 8) * 8 * ((a1.n_cob + 1) / 2), g0 = ((ntr + 7) / 8) * 8 * ((a0.n_cob + 1) / 2);
   static bool attr_done[SLIDE_MAX_DEVICES] = {};
