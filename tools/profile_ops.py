@@ -40,5 +40,6 @@ for i in range(n):
         rd, wr = s.gemm_bytes[i]
         print("%3d %-7s %8.1f %7d %6d %6d %6d %8.2f %8.1f %8.1f %8.1f %8.0f" % (i, "GEMM", tot[i] * 1e3, o.i[0], o.i[2], o.i[3] * 32, 1 << o.i[4], fl / 1e9, fl / (tot[i] * 1e-3) / 1e12, rd / 1e6, wr / 1e6, (rd + wr) / (tot[i] * 1e-3) / 1e9))
     else:
-        print("%3d %-7s %8.1f" % (i, names.get(o.kind, "?"), tot[i] * 1e3))
+        kn = getattr(s, "kernel_names", {}).get(i, "")
+        print("%3d %-7s %8.1f   %s  i=%s" % (i, names.get(o.kind, "k%d" % o.kind), tot[i] * 1e3, kn, list(o.i)[:6]))
 print("total us %.1f  gemm us %.1f" % (tot.sum() * 1e3, sum(tot[i] for i in range(n) if s.step_ops[i].kind == 1) * 1e3))
