@@ -68,7 +68,7 @@ class AttentionModule(nn.Module):
         else:  # fewer than a tile of points per sample (np = 16 / 64 / 128 levels): the q side is 1 / K of the rows -- its ReLU and
             q1 = R.conv(query, self.feat_conv)  # per-sample sums as small elementwise passes instead of the GEMM epilogue's
             v = q1.data.relu_().view(q1.B, q1.S, q1.ld).float()
-            q1.stats = (v.sum(1).contiguous(), (v * v).sum(1).contiguous(), True)
+            q1.stats = R.sample_sums(v) + (True,)  # (NOT torch.sum: its reduction order depends on the batch size)
         k1 = R.conv(grouped, self.grouped_feat_conv, stats="relu")
         C1, C2 = q1.C, k1.C
         if not R.joint_norm_qk(q1, k1, K, wc[1].group_norm):

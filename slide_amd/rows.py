@@ -296,6 +296,21 @@ class _ConvPlan:
         return Rows(out, x.B, x.S, self.O, stats=None if st is None else (st[0], st[1], stats == "relu"))
 
 
+def sample_sums(v):
+    """per-sample column sums of v and v * v, v float [B, S, C] -> ([B, C], [B, C]), as a PAIRWISE TREE of elementwise additions: the
+    order of every output's additions depends on S alone.  (torch.sum picks its reduction split from the whole tensor's shape, so a
+    shape's statistics -- and through a near-tie of a later FPS / kNN its decoded cloud -- depended on the batch it was decoded in:
+    found by tests/test_hip_cli.py::test_decode_is_sharded_over_the_ranks, round 6.)"""
+    x = torch.cat([v, v * v], 2)
+    while x.shape[1] > 1:
+        S = x.shape[1]
+        h = S // 2
+        y = x[:, :h] + x[:, h:2 * h]
+        x = torch.cat([y, x[:, 2 * h:]], 1) if S & 1 else y  # (odd: the last row is carried)
+    C = v.shape[2]
+    return x[:, 0, :C].contiguous(), x[:, 0, C:].contiguous()
+
+
 def fused_stats():
     return os.environ.get("SLIDE_MODULE_STATS", "1") != "0"
 
