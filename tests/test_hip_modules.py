@@ -188,6 +188,39 @@ def test_autoencoder_decode_fp16_operands_matches_reference(gpu_device, monkeypa
     assert max(worst_cd, cd) <= DECODE_FP16_CHAMFER_TOL, (worst_cd, cd)
 
 
+@pytest.mark.parametrize("prec", ["fp16", "fp32"])
+def test_decode_of_a_shape_does_not_depend_on_its_batch(gpu_device, monkeypatch, prec):
+    """BASELINE configs[4] shards the decode over ranks and batches: a shape's cloud must not depend on the batch it is decoded in
+    (the reference decodes per rank, mesh_evaluation.py:113-118; the CLI test compares one rank with two bit for bit).  Seven shapes at
+    once against the same shapes as batches of 3, 3 and 1 -- small batches, where samples straddle row tiles and the query side of the
+    split q / k attention takes its statistics outside the GEMM epilogue -- over several latent sets: bit-identical, both module
+    precisions.  (Round 6: torch.sum's batch-dependent reduction order there turned into re-ordered clouds through FPS near-ties.)"""
+    monkeypatch.setenv("SLIDE_MODULE_PREC", prec)
+    sys.path.insert(0, os.path.join(REPO, "pointnet2"))
+    from models.autoencoder import PointAutoencoder
+    from slide_amd.synth import synth_keypoints
+    g = load_golden("golden_decode.npz")
+    decs = json.loads(str(g["decoder_configs_json"]))
+    spec = golden_spec(g)
+    ae = PointAutoencoder(None, decs, apply_kl_regularization=True)
+    vals = synth_state_dict([("ae." + n, s) for n, s in spec])
+    ae.load_state_dict({n: torch.from_numpy(vals["ae." + n]) for n, _ in spec})
+    ae = ae.to(gpu_device).eval()
+    d = gpu_device
+    B = 7
+    for seed in range(4 if prec == "fp16" else 1):
+        gen = torch.Generator(device="cpu").manual_seed(seed)
+        kp = torch.from_numpy(synth_keypoints(B)).float() + 0.01 * torch.randn(B, 16, 3, generator=gen)
+        feat = 0.5 * torch.randn(B, 16, 48, generator=gen)
+        kp, feat = kp.to(d), feat.to(d)
+        lab = torch.zeros(B, dtype=torch.long, device=d)
+        start = torch.zeros(B, dtype=torch.int32, device=d)
+        ref = ae.decode(kp, feat, label=lab, fps_start_idx=start)
+        parts = torch.cat([ae.decode(kp[a:b], feat[a:b], label=lab[a:b], fps_start_idx=start[a:b]) for a, b in ((0, 3), (3, 6), (6, 7))])
+        assert ref.shape == (B, 2048, 6) and torch.isfinite(ref).all()
+        assert torch.equal(parts, ref), (prec, seed, (parts - ref).abs().flatten(1).max(1).values.tolist())
+
+
 def test_autoencoder_encode_matches_reference(gpu_device):
     """2048 x 6 cloud -> PointNet2Encoder (FPS 1024/256/64/32, kNN-32 SA stack) -> key-point encoder ->
     (B,16,48) latent features, HIP module path vs the reference's `PointAutoencoder.encode` (posterior mode).  FPS runs on
