@@ -6,6 +6,7 @@ copied) on seeded inputs and records inputs + outputs as small fixtures:
                                   features (forward hooks), state-dict spec (names + shapes)
   golden_sampler_{pos,feat}.npz   util.sampling / LatentDiffusion.denoise_and_reconstruct segments with
                                   the noise stream injected (seeded numpy RandomState), schedule tables
+  golden_denoiser_variants.npz    the same forward with the FP-module / layer-order branches switched (use_knn_FP False, bn_first, bn False)
   golden_blocks.npz               stand-alone reference modules (QueryAndGroup, group_knn, Mlp_plus_t_emb,
                                   AttentionModule, PointnetSAModule w/ FPS, PointnetFPModule (three_nn path))
   golden_ops.npz                  op-level adversarial cases (computed by the C oracle -- the reference has
@@ -117,6 +118,50 @@ def gen_denoiser(name, cfg_path, out, B=3):
     np.savez_compressed(os.path.join(out, "golden_denoiser_%s.npz" % name), **res)
     print("denoiser", name, "params", sum(int(np.prod(s)) for _, s in spec), "tensors", len(spec))
     return net, cfg
+
+
+DENOISER_VARIANTS = {  # configuration branches no shipped latent-DDPM config takes (reference pointnet2_with_pcld_condition.py:226-241, :259-277)
+    "fp3nn": dict(use_knn_FP=False),                                 # PointnetFPModule: three_nn / three_interpolate + one Mlp
+    "bnfirst": dict(bn_first=True),                                  # GroupNorm -> ReLU -> conv order, activation + conv output head
+    "fp3nn_bnfirst": dict(use_knn_FP=False, bn_first=True),
+    "nobn": dict(bn=False),                                          # no GroupNorm in the Mlps; conv -> ReLU -> conv head
+}
+
+
+def variant_config(base_hp, name):
+    hp = copy.deepcopy(base_hp)
+    v = DENOISER_VARIANTS[name]
+    if "use_knn_FP" in v:
+        hp["architecture"]["use_knn_FP"] = v["use_knn_FP"]
+    for k in ("bn_first", "bn"):
+        if k in v:
+            hp[k] = v[k]
+    if name == "nobn":  # (the attention modules carry their own switch)
+        hp["attention_setting"] = dict(hp["attention_setting"], attention_bn=False)
+    return hp
+
+
+def gen_denoiser_variants(out, B=2):
+    """PointNet2CloudCondition.forward of the position net's configuration with the FP-module / layer-order branches switched"""
+    base = load_cfg(POS_CFG)
+    res = {}
+    rs = np.random.RandomState(11)
+    for name in DENOISER_VARIANTS:
+        cfg = copy.deepcopy(base)
+        cfg["pointnet_config"] = variant_config(base["pointnet_config"], name)
+        net, spec = build_net(cfg)
+        names, shapes = spec_arrays(spec)
+        res[name + "_spec_names"], res[name + "_spec_shapes"] = names, shapes
+        res[name + "_config_json"] = np.array(json.dumps(cfg["pointnet_config"]))
+        x = rs.standard_normal((B, 16, 3)).astype(np.float32)
+        x[1] *= 0.4
+        ts = np.array([999, 7][:B], np.float32)
+        label = np.array([0, 4][:B], np.int64)
+        with torch.no_grad():
+            y = net(torch.from_numpy(x), ts=torch.from_numpy(ts), label=torch.from_numpy(label))
+        res[name + "_x"], res[name + "_ts"], res[name + "_label"], res[name + "_eps"] = x, ts, label, y.numpy()
+        print("variant", name, "params", sum(int(np.prod(s_)) for _, s_ in spec), "eps rms %.3f" % float(np.sqrt((y.numpy() ** 2).mean())))
+    np.savez_compressed(os.path.join(out, "golden_denoiser_variants.npz"), **res)
 
 
 def gen_sampler_pos(net, cfg, out, B=2):
@@ -571,7 +616,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.manual_seed(0)
-    want = set(a.only.split(",")) if a.only else {"ops", "blocks", "pos", "feat", "resample", "sched", "train", "decode", "encode"}
+    want = set(a.only.split(",")) if a.only else {"ops", "blocks", "pos", "feat", "variants", "resample", "sched", "train", "decode", "encode"}
     if "ops" in want:
         gen_ops(a.out)
     if "blocks" in want:
@@ -586,6 +631,8 @@ if __name__ == "__main__":
         import tempfile
         net, cfg = gen_denoiser("feat", FEAT_CFG, tempfile.mkdtemp())  # (the denoiser fixture itself is not rewritten)
         gen_sampler_feat_full(net, cfg, a.out)
+    if "variants" in want:
+        gen_denoiser_variants(a.out)
     if "resample" in want:
         gen_sampler_feat_resample(a.out)
     if "sched" in want:
