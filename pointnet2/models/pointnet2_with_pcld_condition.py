@@ -1,7 +1,11 @@
 """`PointNet2CloudCondition` -- the per-timestep denoiser (reference: pointnet2/models/pointnet2_with_pcld_condition.py:
 27-489 on top of pointnet2/models/pointnet2_ssg_sem.py:34-177) assembled from the HIP-backed `pointnet2_ops` modules, with
 the reference's attribute / state-dict names, for the configuration family every shipped
-latent-DDPM config uses (no condition cloud: include_local_feature / include_global_feature False).
+latent-DDPM config uses (no condition cloud: include_local_feature / include_global_feature False), and -- round 6, module path --
+its CONDITION-CLOUD form (reference :94-260, :301-447): a second PointNet++ over the condition cloud whose encoder / decoder levels
+feed the noisy cloud's levels through feature-transfer modules (`include_local_feature`), and / or a `Pnet2Stage` global feature of
+the condition cloud in the Mlps' first condition slot (`include_global_feature`), with the retained-feature path a sampler uses
+(`use_retained_condition_feature`, `reset_cond_features`); pinned by tests/golden/golden_denoiser_condition.npz.
 
 Two execution paths:
   forward(...)             general module path (any N, FPS when N > npoint), one HIP launch per primitive
@@ -15,7 +19,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from pointnet2_ops.pointnet2_modules import PointnetFPModule, PointnetKnnFPModule, PointnetSAModule
+from pointnet2_ops.pointnet2_modules import FeatureMapModule, PointnetFPModule, PointnetKnnFPModule, PointnetSAModule
 from slide_amd.nn_ops import HipConv1x1, HipGroupNorm, HipLinear
 
 
@@ -37,82 +41,192 @@ class PointNet2CloudCondition(nn.Module):
     def __init__(self, hparams):
         super().__init__()
         self.hparams = hp = hparams
-        if hp.get("include_local_feature", True) or hp.get("include_global_feature", False):
-            raise NotImplementedError("condition-cloud branches are outside the latent-DDPM sampling path (SURVEY.md section 8)")
         arch = hp["architecture"]
         assert hp.get("activation", "relu") == "relu" and hp.get("point_upsample_factor", 1) == 1
         assert not hp.get("use_position_encoding", False) and not hp.get("concate_partial_with_noisy_input", False)
+        assert not hp.get("global_attention_setting", None)
         self.bn, self.bn_first, self.use_knn_FP = hp.get("bn", True), hp["bn_first"], arch.get("use_knn_FP", False)
-        att = hp.get("attention_setting", None)
+        self.include_local_feature = hp.get("include_local_feature", True)
+        self.include_global_feature = hp.get("include_global_feature", False)
+        self.pooling = hp.get("pooling", "max")
+        self.att = att = hp.get("attention_setting", None)
         t_dim = hp["t_dim"]
         self.class_emb = nn.Embedding(hp["num_class"], hp["class_condition_dim"]) if hp["include_class_condition"] else None
-        in_fea = hp["in_fea_dim"] + (3 if hp["attach_position_to_input_feature"] else 0)
+        attach = 3 if hp["attach_position_to_input_feature"] else 0
+        in_fea = hp["in_fea_dim"] + attach
+        self.partial_in_fea_dim = cin = hp.get("partial_in_fea_dim", hp["in_fea_dim"]) + attach  # condition cloud's feature channels
         self.fc_t1, self.fc_t2 = HipLinear(t_dim, 4 * t_dim), HipLinear(4 * t_dim, 4 * t_dim)
-        common = dict(t_dim=4 * t_dim, include_t=hp["include_t"], bn_first=self.bn_first, res_connect=hp["res_connect"], bias=hp["bias"],
-                      include_condition=hp["include_class_condition"], condition_dim=hp["class_condition_dim"],
-                      use_xyz=hp["model.use_xyz"], include_abs_coordinate=hp["include_abs_coordinate"],
-                      include_center_coordinate=hp.get("include_center_coordinate", False),
-                      neighbor_def=arch["neighbor_definition"], bn=self.bn)
+        # ---- global feature of the condition cloud: it takes the first condition slot of every Mlp, the class embedding the second
+        gdim = None
+        if self.include_global_feature:
+            from models.pnet import Pnet2Stage
+            pa = hp["pnet_global_feature_architecture"]
+            gdim = pa[1][-1]
+            self.global_pnet = Pnet2Stage(pa[0], pa[1], bn=self.bn,
+                                          remove_last_activation=hp.get("global_feature_remove_last_activation", True))
+        cls = hp["include_class_condition"]
+        self._geo = geo = dict(use_xyz=hp["model.use_xyz"], include_abs_coordinate=hp["include_abs_coordinate"],
+                               include_center_coordinate=hp.get("include_center_coordinate", False))
+        self._mlp = mlp_kw = dict(bn=self.bn, bn_first=self.bn_first, res_connect=hp["res_connect"], bias=hp["bias"])
+        if gdim is not None:
+            noisy_cond = dict(include_condition=True, condition_dim=gdim, include_second_condition=cls,
+                              second_condition_dim=hp["class_condition_dim"])
+        else:
+            noisy_cond = dict(include_condition=cls, condition_dim=hp["class_condition_dim"])
+        noisy = dict(t_dim=4 * t_dim, include_t=hp["include_t"], **noisy_cond)
+        plain = dict(t_dim=4 * t_dim, include_t=False, include_condition=False)  # the condition cloud's own network: no t, no class
         f, depth = arch["feature_dim"], arch["mlp_depth"]
-        self.SA_modules = nn.ModuleList()
-        for i in range(len(arch["npoint"])):
-            first_conv = self.bn_first and i == 0  # (bn_first: a convolution ahead of the first GroupNorm, pointnet2_ssg_sem.py:66-73)
-            spec = [in_fea if (i == 0 and not first_conv) else f[i]] + [f[i]] * (depth - 1) + [f[i + 1]]
-            self.SA_modules.append(PointnetSAModule(npoint=arch["npoint"][i], radius=arch["radius"][i], nsample=arch["nsample"][i],
-                                                    mlp=spec, first_conv=first_conv, first_conv_in_channel=in_fea,
-                                                    attention_setting=att, **common))
         d, ddepth = arch["decoder_feature_dim"], arch["decoder_mlp_depth"]
         assert d[-1] == f[-1]
-        self.FP_modules = nn.ModuleList()
-        for i in range(len(d) - 1):
-            skip = in_fea if i == 0 else f[i]
-            if self.use_knn_FP:
-                self.FP_modules.append(PointnetKnnFPModule(mlp1=[d[i + 1]] + [d[i]] * ddepth, mlp2=[d[i] + skip] + [d[i]] * ddepth,
-                                                           K=arch.get("K", 3), first_conv=False,
-                                                           include_grouper=arch.get("include_grouper", False),
-                                                           radius=arch["radius"][i], nsample=arch["nsample"][i],
-                                                           attention_setting=att, **common))
-            else:  # three nearest known points, inverse-distance weights, ONE Mlp (pointnet2_ssg_sem.py:160-176)
-                self.FP_modules.append(PointnetFPModule(mlp=[d[i + 1] + skip] + [d[i]] * ddepth, first_conv=False,
-                                                        include_grouper=arch.get("include_grouper", False),
-                                                        radius=arch["radius"][i], nsample=arch["nsample"][i], **common))
+        enc_map = dec_map = None
+        if self.include_local_feature:
+            ca, ma = hp["condition_net_architecture"], hp["feature_mapper_architecture"]
+            cf, cd = ca["feature_dim"], ca["decoder_feature_dim"]
+            assert cd[-1] == cf[-1] and len(ca["npoint"]) == len(arch["npoint"])
+            enc_map, dec_map = ma["encoder_feature_map_dim"], ma["decoder_feature_map_dim"]
+            self.SA_modules_condition = self._sa_stack(ca, cf, ca["mlp_depth"], cin, None, att, plain)
+            # feature transfer: condition cloud level i -> the noisy cloud's level i, queried with the noisy points' own features
+            fm_att = None if att is None else dict(att, use_attention_module=att["add_attention_to_FeatureMapper_module"])
+            self.encoder_feature_map = nn.ModuleList()
+            for i, od in enumerate(enc_map):
+                fc0 = self.bn_first and i == 0
+                ind = cin if (i == 0 and not fc0) else cf[i]
+                self.encoder_feature_map.append(FeatureMapModule(
+                    [ind] + [od] * ma["encoder_mlp_depth"], ma["encoder_radius"][i], ma["encoder_nsample"][i], first_conv=fc0,
+                    first_conv_in_channel=cin, neighbor_def=ma["neighbor_definition"], attention_setting=fm_att,
+                    query_feature_dim=in_fea if i == 0 else f[i], **geo, **mlp_kw))
+        self.SA_modules = self._sa_stack(arch, f, depth, in_fea, enc_map, att, noisy)
+        if self.include_local_feature:
+            self.FP_modules_condition = self._fp_stack(ca, cd, ca["decoder_mlp_depth"], cf, cin, None, att, plain)
+            self.decoder_feature_map = nn.ModuleList()
+            for i, od in enumerate(dec_map):
+                self.decoder_feature_map.append(FeatureMapModule(
+                    [cd[i]] + [od] * ma["decoder_mlp_depth"], ma["decoder_radius"][i], ma["decoder_nsample"][i], first_conv=False,
+                    first_conv_in_channel=0, neighbor_def=ma["neighbor_definition"], attention_setting=fm_att,
+                    query_feature_dim=d[i], **geo, **mlp_kw))
+        self.FP_modules = self._fp_stack(arch, d, ddepth, f, in_fea, None if dec_map is None else dec_map[1:], att, noisy)
         self.transform_output = hp.get("transform_output", True)
         if self.transform_output:  # (layer positions as in the reference's Sequentials: state-dict keys fc_lyaer.<index>.*)
+            hin = d[0] + 3 + (dec_map[0] if dec_map is not None else 0)
             if self.bn_first:
-                self.fc_lyaer = nn.Sequential(nn.ReLU(True), HipConv1x1(d[0] + 3, hp["out_dim"], ndim=1))
+                self.fc_lyaer = nn.Sequential(nn.ReLU(True), HipConv1x1(hin, hp["out_dim"], ndim=1))
             elif self.bn:
-                self.fc_lyaer = nn.Sequential(HipConv1x1(d[0] + 3, 128, bias=hp["bias"], ndim=1), HipGroupNorm(32, 128),
+                self.fc_lyaer = nn.Sequential(HipConv1x1(hin, 128, bias=hp["bias"], ndim=1), HipGroupNorm(32, 128),
                                               nn.ReLU(True), HipConv1x1(128, hp["out_dim"], ndim=1))
             else:
-                self.fc_lyaer = nn.Sequential(HipConv1x1(d[0] + 3, 128, bias=hp["bias"], ndim=1), nn.ReLU(True),
+                self.fc_lyaer = nn.Sequential(HipConv1x1(hin, 128, bias=hp["bias"], ndim=1), nn.ReLU(True),
                                               HipConv1x1(128, hp["out_dim"], ndim=1))
         self._engines = {}
+        self.reset_cond_features()
+
+    # ---- module stacks (reference: pointnet2_ssg_sem.py:44-177)
+    def _sa_stack(self, a, f, depth, in_dim, extra, att, emb):
+        """set-abstraction levels; extra[i] = channels the level's input gains from the condition cloud (feature transfer)"""
+        out = nn.ModuleList()
+        nb = a["neighbor_definition"]
+        for i in range(len(a["npoint"])):
+            first_conv = self.bn_first and i == 0  # (bn_first: a convolution ahead of the first GroupNorm)
+            e = 0 if extra is None else extra[i]
+            c0 = in_dim + e if i == 0 else f[i] + e
+            spec = [f[i] + e if (i == 0 and first_conv) else c0] + [f[i]] * (depth - 1) + [f[i + 1]]
+            out.append(PointnetSAModule(npoint=a["npoint"][i], radius=a["radius"][i], nsample=a["nsample"][i], mlp=spec,
+                                        first_conv=first_conv, first_conv_in_channel=in_dim + e, attention_setting=att,
+                                        neighbor_def=nb[i] if isinstance(nb, list) else nb, **self._geo, **self._mlp, **emb))
+        return out
+
+    def _fp_stack(self, a, d, ddepth, f, in_dim, extra, att, emb):
+        out = nn.ModuleList()
+        nb = a["neighbor_definition"]
+        for i in range(len(d) - 1):
+            skip = in_dim if i == 0 else f[i]
+            e = 0 if extra is None else extra[i]
+            kw = dict(first_conv=False, include_grouper=a.get("include_grouper", False), radius=a["radius"][i], nsample=a["nsample"][i],
+                      neighbor_def=nb[i] if isinstance(nb, list) else nb, **self._geo, **self._mlp, **emb)
+            if a.get("use_knn_FP", False):
+                out.append(PointnetKnnFPModule(mlp1=[d[i + 1] + e] + [d[i]] * ddepth, mlp2=[d[i] + skip] + [d[i]] * ddepth,
+                                               K=a.get("K", 3), attention_setting=att, **kw))
+            else:  # three nearest known points, inverse-distance weights, ONE Mlp
+                out.append(PointnetFPModule(mlp=[d[i + 1] + skip + e] + [d[i]] * ddepth, **kw))
+        return out
+
+    def reset_cond_features(self):
+        """forget the retained condition-cloud features (use_retained_condition_feature: a sampler calls the network 1000 times with
+        ONE condition cloud, whose own network does not see t)"""
+        self.l_uvw = self.encoder_cond_features = self.decoder_cond_features = self.global_feature = None
 
     def _break_up_pc(self, pc):
         return pc[..., 0:3].contiguous(), (pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None)
 
     @torch.no_grad()
     def forward(self, pointcloud, condition=None, ts=None, label=None, use_retained_condition_feature=False, fused=False):
-        assert condition is None
+        hp = self.hparams
+        local, glob = self.include_local_feature, self.include_global_feature
+        assert (condition is not None) == (local or glob), "a condition cloud is given exactly when the configuration uses one"
         if fused:
             return self._fused(pointcloud, ts, label)
-        hp = self.hparams
-        pc = torch.cat([pointcloud, pointcloud[:, :, 0:3]], dim=2) if hp["attach_position_to_input_feature"] else pointcloud
+        keep = use_retained_condition_feature
+        attach = hp["attach_position_to_input_feature"]
+        pc = torch.cat([pointcloud, pointcloud[:, :, 0:3]], dim=2) if attach else pointcloud
         xyz, features = self._break_up_pc(pc)
+        if condition is not None:
+            cpc = torch.cat([condition, condition[:, :, 0:3]], dim=2) if attach else condition
+            uvw, cond_features = self._break_up_pc(cpc)
         t_emb = None
         if ts is not None and hp["include_t"]:
             t_emb = swish(self.fc_t2(swish(self.fc_t1(calc_t_emb(ts, hp["t_dim"])))))
-        cond = self.class_emb(label) if (label is not None and self.class_emb is not None) else None
+        cls = self.class_emb(label) if (label is not None and self.class_emb is not None) else None
+        if glob:
+            if keep and self.global_feature is not None:
+                gfeat = self.global_feature
+            else:
+                own = self.partial_in_fea_dim - (3 if attach else 0)  # the condition cloud's own feature channels
+                gin = torch.cat([uvw, condition[:, :, 3:3 + own]], dim=2) if own > 0 else uvw
+                gfeat = self.global_pnet(gin.transpose(1, 2).contiguous())
+                if keep:
+                    self.global_feature = gfeat.detach().clone()
+            emb = dict(t_emb=t_emb, condition_emb=gfeat, second_condition_emb=cls if hp["include_class_condition"] else None)
+        else:
+            emb = dict(t_emb=t_emb, condition_emb=cls)
+        pool = dict(pooling=self.pooling)
+        # ---- encoder: the condition cloud's levels run beside the noisy cloud's; level i of the noisy cloud reads level i of the
+        # condition cloud through a feature-transfer module queried with its own features
+        retained_enc = keep and self.encoder_cond_features is not None
+        retained_dec = keep and self.decoder_cond_features is not None
+        if local:
+            l_uvw, l_cf = ([uvw], [cond_features]) if not retained_enc else (self.l_uvw, self.encoder_cond_features)
         l_xyz, l_features = [xyz], [features]
         for i, m in enumerate(self.SA_modules):
-            nx, nf = m(l_xyz[i], l_features[i], t_emb=t_emb, condition_emb=cond, subset=True, pooling=hp.get("pooling", "max"))
+            x_in = l_features[i]
+            if local:
+                if not retained_enc:
+                    nu, nf = self.SA_modules_condition[i](l_uvw[i], l_cf[i], subset=True, **pool)
+                    l_uvw.append(nu); l_cf.append(nf)
+                mapped = self.encoder_feature_map[i](l_uvw[i], l_cf[i], l_xyz[i], subset=False, features_at_new_xyz=l_features[i], **pool)
+                x_in = torch.cat([mapped, l_features[i]], dim=1)
+            nx, nf = m(l_xyz[i], x_in, subset=True, **emb, **pool)
             l_xyz.append(nx); l_features.append(nf)
+        if local and keep and not retained_enc:
+            self.l_uvw, self.encoder_cond_features = l_uvw, [None if v is None else v.clone() for v in l_cf]
+        # ---- decoder
+        if local:
+            l_cd = list(l_cf) if not retained_dec else self.decoder_cond_features
         for i in range(-1, -(len(self.FP_modules) + 1), -1):
-            l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i], t_emb=t_emb,
-                                                   condition_emb=cond)
+            k_in = l_features[i]
+            if local:
+                if not retained_dec:
+                    l_cd[i - 1] = self.FP_modules_condition[i](l_uvw[i - 1], l_uvw[i], l_cd[i - 1], l_cd[i], **pool)
+                mapped = self.decoder_feature_map[i](l_uvw[i], l_cd[i], l_xyz[i], subset=False, features_at_new_xyz=l_features[i], **pool)
+                k_in = torch.cat([mapped, l_features[i]], dim=1)
+            l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], k_in, **emb, **pool)
+        out = l_features[0]
+        if local:
+            if keep and not retained_dec:
+                self.decoder_cond_features = [None if v is None else v.clone() for v in l_cd]
+            mapped = self.decoder_feature_map[0](l_uvw[0], l_cd[0], l_xyz[0], subset=False, features_at_new_xyz=l_features[0], **pool)
+            out = torch.cat([mapped, l_features[0]], dim=1)
         if not self.transform_output:  # feature-extractor use (autoencoder decoder levels): per-point features
-            return l_features[0].transpose(1, 2).contiguous()
-        out = torch.cat([l_features[0], xyz.transpose(1, 2)], dim=1)
+            return out.transpose(1, 2).contiguous()
+        out = torch.cat([out, xyz.transpose(1, 2)], dim=1)
         if self.bn_first:
             return self.fc_lyaer[1](torch.relu(out)).transpose(1, 2).contiguous()
         h = self.fc_lyaer[0](out)
@@ -122,8 +236,8 @@ class PointNet2CloudCondition(nn.Module):
         return self.fc_lyaer[3](h).transpose(1, 2).contiguous()
 
     def _fused(self, pointcloud, ts, label, prec="fp32"):
-        if not (self.use_knn_FP and self.bn and not self.bn_first):
-            raise NotImplementedError("the fused plan covers the shipped latent-DDPM configuration family (use_knn_FP, bn, not bn_first); "
+        if not (self.use_knn_FP and self.bn and not self.bn_first) or self.include_local_feature or self.include_global_feature:
+            raise NotImplementedError("the fused plan covers the shipped latent-DDPM configuration family (use_knn_FP, bn, not bn_first, no condition cloud); "
                                       "this configuration runs on the module path: forward(..., fused=False)")
         from slide_amd.engine import DenoiserEngine
         B = pointcloud.shape[0]

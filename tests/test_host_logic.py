@@ -159,18 +159,19 @@ def test_bench_self_launch_argv(monkeypatch):
     assert len(calls) == 1 and calls[0][calls[0].index("--nproc-per-node") + 1] == "2" and calls[0][-4:] == ["--gpus", "2", "--steps", "3"]
 
 
-@pytest.mark.parametrize("name", ["fp3nn", "bnfirst", "fp3nn_bnfirst", "nobn"])
+@pytest.mark.parametrize("name", ["fp3nn", "bnfirst", "fp3nn_bnfirst", "nobn", "local", "global", "both"])
 def test_denoiser_configuration_branches_are_checkpoint_compatible(name):
     """CPU: the module tree PointNet2CloudCondition builds for the non-shipped configuration branches (three-nearest-neighbour FP
-    module, bn_first with its leading convolution and activation + conv head, bn False) has the reference's state-dict names and
-    shapes (golden_denoiser_variants.npz: generated by importing the reference, tools/gen_golden.py `--only variants`); the forward
+    module, bn_first with its leading convolution and activation + conv head, bn False; the condition-cloud forms: local feature
+    transfer, global feature, both) has the reference's state-dict names and shapes (golden_denoiser_{variants,condition}.npz:
+    generated by importing the reference, tools/gen_golden.py `--only variants,condition`); the forward
     itself is a -m gpu test (tests/test_hip_modules.py)."""
     import os
     import sys
     from conftest import REPO
     sys.path.insert(0, os.path.join(REPO, "pointnet2"))
     from models.pointnet2_with_pcld_condition import PointNet2CloudCondition
-    g = load_golden("golden_denoiser_variants.npz")
+    g = load_golden("golden_denoiser_condition.npz" if name in ("local", "global", "both") else "golden_denoiser_variants.npz")
     hp = json.loads(str(g[name + "_config_json"]))
     net = PointNet2CloudCondition(hp)
     assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == dict(golden_spec(g, name + "_spec"))

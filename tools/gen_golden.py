@@ -7,6 +7,7 @@ copied) on seeded inputs and records inputs + outputs as small fixtures:
   golden_sampler_{pos,feat}.npz   util.sampling / LatentDiffusion.denoise_and_reconstruct segments with
                                   the noise stream injected (seeded numpy RandomState), schedule tables
   golden_denoiser_variants.npz    the same forward with the FP-module / layer-order branches switched (use_knn_FP False, bn_first, bn False)
+  golden_denoiser_condition.npz   the same forward WITH a condition cloud (local feature transfer, global feature, both; retained features)
   golden_blocks.npz               stand-alone reference modules (QueryAndGroup, group_knn, Mlp_plus_t_emb,
                                   AttentionModule, PointnetSAModule w/ FPS, PointnetFPModule (three_nn path))
   golden_ops.npz                  op-level adversarial cases (computed by the C oracle -- the reference has
@@ -162,6 +163,57 @@ def gen_denoiser_variants(out, B=2):
         res[name + "_x"], res[name + "_ts"], res[name + "_label"], res[name + "_eps"] = x, ts, label, y.numpy()
         print("variant", name, "params", sum(int(np.prod(s_)) for _, s_ in spec), "eps rms %.3f" % float(np.sqrt((y.numpy() ** 2).mean())))
     np.savez_compressed(os.path.join(out, "golden_denoiser_variants.npz"), **res)
+
+
+def condition_config(base_hp, local, glob):
+    """the position net's configuration with a CONDITION CLOUD (the two-stream form of pointnet2_with_pcld_condition.py:94-260; no
+    shipped configuration sets it -- a small architecture of this repo's choosing, the reference's keys)"""
+    hp = copy.deepcopy(base_hp)
+    hp["include_local_feature"], hp["include_global_feature"] = local, glob
+    hp["pnet_global_feature_architecture"] = [[3, 32, 64], [64, 96]]
+    hp["condition_net_architecture"] = {"npoint": [32, 16], "radius": [0, 0], "neighbor_definition": "nn", "nsample": [8, 8],
+                                        "feature_dim": [16, 32, 64], "mlp_depth": 3, "decoder_feature_dim": [16, 32, 64],
+                                        "decoder_mlp_depth": 2, "use_knn_FP": True, "K": 3}
+    hp["feature_mapper_architecture"] = {"neighbor_definition": "nn", "encoder_feature_map_dim": [16, 32], "encoder_mlp_depth": 2,
+                                         "encoder_radius": [0, 0], "encoder_nsample": [8, 8],
+                                         "decoder_feature_map_dim": [16, 32, 64], "decoder_mlp_depth": 2,
+                                         "decoder_radius": [0, 0, 0], "decoder_nsample": [8, 8, 8]}
+    return hp
+
+
+def gen_denoiser_condition(out, B=2, M=64):
+    """PointNet2CloudCondition.forward WITH a condition cloud: local features (two-stream encoder / decoder with feature transfer
+    modules), the global feature (Pnet2Stage), both; and the retained-condition-feature path (second call re-uses the first's)"""
+    base = load_cfg(POS_CFG)
+    res = {}
+    rs = np.random.RandomState(13)
+    for name, (local, glob) in {"local": (True, False), "global": (False, True), "both": (True, True)}.items():
+        cfg = copy.deepcopy(base)
+        cfg["pointnet_config"] = condition_config(base["pointnet_config"], local, glob)
+        net, spec = build_net(cfg)
+        names, shapes = spec_arrays(spec)
+        res[name + "_spec_names"], res[name + "_spec_shapes"] = names, shapes
+        res[name + "_config_json"] = np.array(json.dumps(cfg["pointnet_config"]))
+        x = rs.standard_normal((B, 16, 3)).astype(np.float32)
+        cond = (0.6 * rs.standard_normal((B, M, 3))).astype(np.float32)
+        ts = np.array([999, 7][:B], np.float32)
+        label = np.array([0, 4][:B], np.int64)
+        with torch.no_grad():
+            y = net(torch.from_numpy(x), condition=torch.from_numpy(cond), ts=torch.from_numpy(ts), label=torch.from_numpy(label))
+            # retained condition features: the first call stores them, the second (other x, other t) re-uses them
+            net.reset_cond_features()
+            y1 = net(torch.from_numpy(x), condition=torch.from_numpy(cond), ts=torch.from_numpy(ts), label=torch.from_numpy(label),
+                     use_retained_condition_feature=True)
+            x2 = rs.standard_normal((B, 16, 3)).astype(np.float32)
+            ts2 = np.array([500, 3][:B], np.float32)
+            y2 = net(torch.from_numpy(x2), condition=torch.from_numpy(cond), ts=torch.from_numpy(ts2), label=torch.from_numpy(label),
+                     use_retained_condition_feature=True)
+        assert np.allclose(y.numpy(), y1.numpy(), atol=1e-6)
+        for k, v in (("x", x), ("cond", cond), ("ts", ts), ("label", label), ("eps", y.numpy()), ("x2", x2), ("ts2", ts2), ("eps2", y2.numpy())):
+            res[name + "_" + k] = v
+        print("condition", name, "params", sum(int(np.prod(s_)) for _, s_ in spec), "eps rms %.3f %.3f" % (
+            float(np.sqrt((y.numpy() ** 2).mean())), float(np.sqrt((y2.numpy() ** 2).mean()))))
+    np.savez_compressed(os.path.join(out, "golden_denoiser_condition.npz"), **res)
 
 
 def gen_sampler_pos(net, cfg, out, B=2):
@@ -616,7 +668,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.manual_seed(0)
-    want = set(a.only.split(",")) if a.only else {"ops", "blocks", "pos", "feat", "variants", "resample", "sched", "train", "decode", "encode"}
+    want = set(a.only.split(",")) if a.only else {"ops", "blocks", "pos", "feat", "variants", "condition", "resample", "sched", "train", "decode", "encode"}
     if "ops" in want:
         gen_ops(a.out)
     if "blocks" in want:
@@ -633,6 +685,8 @@ if __name__ == "__main__":
         gen_sampler_feat_full(net, cfg, a.out)
     if "variants" in want:
         gen_denoiser_variants(a.out)
+    if "condition" in want:
+        gen_denoiser_condition(a.out)
     if "resample" in want:
         gen_sampler_feat_resample(a.out)
     if "sched" in want:
