@@ -5,7 +5,9 @@ latent-DDPM config uses (no condition cloud: include_local_feature / include_glo
 its CONDITION-CLOUD form (reference :94-260, :301-447): a second PointNet++ over the condition cloud whose encoder / decoder levels
 feed the noisy cloud's levels through feature-transfer modules (`include_local_feature`), and / or a `Pnet2Stage` global feature of
 the condition cloud in the Mlps' first condition slot (`include_global_feature`), with the retained-feature path a sampler uses
-(`use_retained_condition_feature`, `reset_cond_features`); pinned by tests/golden/golden_denoiser_condition.npz.
+(`use_retained_condition_feature`, `reset_cond_features`); pinned by tests/golden/golden_denoiser_condition.npz.  The parent
+project's other switches of the class (swish, position encoding, global attention per level, up-sampling head, condition cloud
+concatenated behind an indicator channel): tests/golden/golden_denoiser_switches.npz.
 
 Two execution paths:
   forward(...)             general module path (any N, FPS when N > npoint), one HIP launch per primitive
@@ -19,7 +21,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from pointnet2_ops.pointnet2_modules import FeatureMapModule, PointnetFPModule, PointnetKnnFPModule, PointnetSAModule
+from pointnet2_ops.pointnet2_modules import FeatureMapModule, PointnetFPModule, PointnetKnnFPModule, PointnetSAModule, Swish
 from slide_amd.nn_ops import HipConv1x1, HipGroupNorm, HipLinear
 
 
@@ -42,19 +44,35 @@ class PointNet2CloudCondition(nn.Module):
         super().__init__()
         self.hparams = hp = hparams
         arch = hp["architecture"]
-        assert hp.get("activation", "relu") == "relu" and hp.get("point_upsample_factor", 1) == 1
-        assert not hp.get("use_position_encoding", False) and not hp.get("concate_partial_with_noisy_input", False)
-        assert not hp.get("global_attention_setting", None)
         self.bn, self.bn_first, self.use_knn_FP = hp.get("bn", True), hp["bn_first"], arch.get("use_knn_FP", False)
         self.include_local_feature = hp.get("include_local_feature", True)
         self.include_global_feature = hp.get("include_global_feature", False)
+        # the parent project's switches (reference :47-93, :119-126, :243-257): activation, NeRF-style position encoding of the
+        # coordinates as extra input features, the condition cloud concatenated to the noisy one (an indicator channel tells them
+        # apart), an up-sampling output head, global attention behind chosen levels
+        self.activation = hp.get("activation", "relu")
+        assert self.activation in ("relu", "swish")
+        self.concat_partial = hp.get("concate_partial_with_noisy_input", False)
+        assert not (self.concat_partial and (self.include_local_feature or self.include_global_feature))
+        self.pe_freqs = None
+        if hp.get("use_position_encoding", False):
+            self.pe_freqs = [float(2.0 ** k) for k in np.linspace(0.0, hp["position_encoding_multires"] - 1, hp["position_encoding_multires"])]
+        pe = 0 if self.pe_freqs is None else 6 * len(self.pe_freqs)
+        self.gatt = hp.get("global_attention_setting", None)
+        up = hp.get("point_upsample_factor", 1)
+        if up > 1:
+            if hp["first_refine_coarse_points"]:
+                up = up + (0 if hp["include_displacement_center_to_final_output"] else 1)
+            else:
+                assert not hp["include_displacement_center_to_final_output"]
+        self.out_dim = int(hp["out_dim"] * up)
         self.pooling = hp.get("pooling", "max")
         self.att = att = hp.get("attention_setting", None)
         t_dim = hp["t_dim"]
         self.class_emb = nn.Embedding(hp["num_class"], hp["class_condition_dim"]) if hp["include_class_condition"] else None
         attach = 3 if hp["attach_position_to_input_feature"] else 0
-        in_fea = hp["in_fea_dim"] + attach
-        self.partial_in_fea_dim = cin = hp.get("partial_in_fea_dim", hp["in_fea_dim"]) + attach  # condition cloud's feature channels
+        in_fea = hp["in_fea_dim"] + attach + pe
+        self.partial_in_fea_dim = cin = hp.get("partial_in_fea_dim", hp["in_fea_dim"]) + attach + pe  # condition cloud's feature channels
         self.fc_t1, self.fc_t2 = HipLinear(t_dim, 4 * t_dim), HipLinear(4 * t_dim, 4 * t_dim)
         # ---- global feature of the condition cloud: it takes the first condition slot of every Mlp, the class embedding the second
         gdim = None
@@ -62,12 +80,13 @@ class PointNet2CloudCondition(nn.Module):
             from models.pnet import Pnet2Stage
             pa = hp["pnet_global_feature_architecture"]
             gdim = pa[1][-1]
-            self.global_pnet = Pnet2Stage(pa[0], pa[1], bn=self.bn,
+            self.global_pnet = Pnet2Stage([pa[0][0] + pe] + list(pa[0][1:]), pa[1], bn=self.bn,
                                           remove_last_activation=hp.get("global_feature_remove_last_activation", True))
         cls = hp["include_class_condition"]
         self._geo = geo = dict(use_xyz=hp["model.use_xyz"], include_abs_coordinate=hp["include_abs_coordinate"],
                                include_center_coordinate=hp.get("include_center_coordinate", False))
-        self._mlp = mlp_kw = dict(bn=self.bn, bn_first=self.bn_first, res_connect=hp["res_connect"], bias=hp["bias"])
+        self._mlp = mlp_kw = dict(bn=self.bn, bn_first=self.bn_first, res_connect=hp["res_connect"], bias=hp["bias"],
+                                  activation=self.activation)
         if gdim is not None:
             noisy_cond = dict(include_condition=True, condition_dim=gdim, include_second_condition=cls,
                               second_condition_dim=hp["class_condition_dim"])
@@ -108,14 +127,15 @@ class PointNet2CloudCondition(nn.Module):
         self.transform_output = hp.get("transform_output", True)
         if self.transform_output:  # (layer positions as in the reference's Sequentials: state-dict keys fc_lyaer.<index>.*)
             hin = d[0] + 3 + (dec_map[0] if dec_map is not None else 0)
+            act = (lambda: nn.ReLU(True)) if self.activation == "relu" else Swish
             if self.bn_first:
-                self.fc_lyaer = nn.Sequential(nn.ReLU(True), HipConv1x1(hin, hp["out_dim"], ndim=1))
+                self.fc_lyaer = nn.Sequential(act(), HipConv1x1(hin, self.out_dim, ndim=1))
             elif self.bn:
                 self.fc_lyaer = nn.Sequential(HipConv1x1(hin, 128, bias=hp["bias"], ndim=1), HipGroupNorm(32, 128),
-                                              nn.ReLU(True), HipConv1x1(128, hp["out_dim"], ndim=1))
+                                              act(), HipConv1x1(128, self.out_dim, ndim=1))
             else:
-                self.fc_lyaer = nn.Sequential(HipConv1x1(hin, 128, bias=hp["bias"], ndim=1), nn.ReLU(True),
-                                              HipConv1x1(128, hp["out_dim"], ndim=1))
+                self.fc_lyaer = nn.Sequential(HipConv1x1(hin, 128, bias=hp["bias"], ndim=1), act(),
+                                              HipConv1x1(128, self.out_dim, ndim=1))
         self._engines = {}
         self.reset_cond_features()
 
@@ -131,6 +151,7 @@ class PointNet2CloudCondition(nn.Module):
             spec = [f[i] + e if (i == 0 and first_conv) else c0] + [f[i]] * (depth - 1) + [f[i + 1]]
             out.append(PointnetSAModule(npoint=a["npoint"][i], radius=a["radius"][i], nsample=a["nsample"][i], mlp=spec,
                                         first_conv=first_conv, first_conv_in_channel=in_dim + e, attention_setting=att,
+                                        global_attention_setting=self._gatt_at(i) if a is self.hparams["architecture"] else None,
                                         neighbor_def=nb[i] if isinstance(nb, list) else nb, **self._geo, **self._mlp, **emb))
         return out
 
@@ -144,10 +165,19 @@ class PointNet2CloudCondition(nn.Module):
                       neighbor_def=nb[i] if isinstance(nb, list) else nb, **self._geo, **self._mlp, **emb)
             if a.get("use_knn_FP", False):
                 out.append(PointnetKnnFPModule(mlp1=[d[i + 1] + e] + [d[i]] * ddepth, mlp2=[d[i] + skip] + [d[i]] * ddepth,
-                                               K=a.get("K", 3), attention_setting=att, **kw))
+                                               K=a.get("K", 3), attention_setting=att,
+                                               global_attention_setting=self._gatt_at(i) if a is self.hparams["architecture"] else None, **kw))
             else:  # three nearest known points, inverse-distance weights, ONE Mlp
                 out.append(PointnetFPModule(mlp=[d[i + 1] + skip + e] + [d[i]] * ddepth, **kw))
         return out
+
+    def _gatt_at(self, i):
+        g = self.gatt
+        return g if (g is not None and g["use_global_attention_module"] and i in g["global_attention_layer_index"]) else None
+
+    def _position_code(self, xyz):
+        """[sin(f x), cos(f x)] over the octave frequencies (reference models/model_utils.py:3-51; input not included)"""
+        return torch.cat([fn(xyz * f) for f in self.pe_freqs for fn in (torch.sin, torch.cos)], dim=-1)
 
     def reset_cond_features(self):
         """forget the retained condition-cloud features (use_retained_condition_feature: a sampler calls the network 1000 times with
@@ -161,15 +191,24 @@ class PointNet2CloudCondition(nn.Module):
     def forward(self, pointcloud, condition=None, ts=None, label=None, use_retained_condition_feature=False, fused=False):
         hp = self.hparams
         local, glob = self.include_local_feature, self.include_global_feature
-        assert (condition is not None) == (local or glob), "a condition cloud is given exactly when the configuration uses one"
+        assert (condition is not None) == (local or glob or self.concat_partial), "a condition cloud is given exactly when the configuration uses one"
         if fused:
             return self._fused(pointcloud, ts, label)
         keep = use_retained_condition_feature
         attach = hp["attach_position_to_input_feature"]
-        pc = torch.cat([pointcloud, pointcloud[:, :, 0:3]], dim=2) if attach else pointcloud
+        n_own = pointcloud.shape[1]
+        if self.concat_partial:  # ONE cloud: the noisy points (indicator 0) followed by the condition points (indicator 1)
+            assert pointcloud.shape[2] == 3 and condition.shape[2] in (3, 4) and condition.shape[0] == pointcloud.shape[0]
+            tag = lambda c, v: torch.cat([c, torch.full_like(c[:, :, :1], v)], dim=2)
+            pointcloud = torch.cat([tag(pointcloud, 0.0), condition if condition.shape[2] == 4 else tag(condition, 1.0)], dim=1)
+            condition = None
+        code = (lambda c: torch.cat([c, self._position_code(c[:, :, 0:3])], dim=2)) if self.pe_freqs is not None else (lambda c: c)
+        pc = code(pointcloud)
+        pc = torch.cat([pc, pointcloud[:, :, 0:3]], dim=2) if attach else pc
         xyz, features = self._break_up_pc(pc)
         if condition is not None:
-            cpc = torch.cat([condition, condition[:, :, 0:3]], dim=2) if attach else condition
+            cpc = code(condition)
+            cpc = torch.cat([cpc, condition[:, :, 0:3]], dim=2) if attach else cpc
             uvw, cond_features = self._break_up_pc(cpc)
         t_emb = None
         if ts is not None and hp["include_t"]:
@@ -179,8 +218,8 @@ class PointNet2CloudCondition(nn.Module):
             if keep and self.global_feature is not None:
                 gfeat = self.global_feature
             else:
-                own = self.partial_in_fea_dim - (3 if attach else 0)  # the condition cloud's own feature channels
-                gin = torch.cat([uvw, condition[:, :, 3:3 + own]], dim=2) if own > 0 else uvw
+                own = self.partial_in_fea_dim - (3 if attach else 0)  # the condition cloud's own feature channels (+ its position code)
+                gin = torch.cat([uvw, cpc[:, :, 3:3 + own]], dim=2) if own > 0 else uvw
                 gfeat = self.global_pnet(gin.transpose(1, 2).contiguous())
                 if keep:
                     self.global_feature = gfeat.detach().clone()
@@ -225,18 +264,26 @@ class PointNet2CloudCondition(nn.Module):
             mapped = self.decoder_feature_map[0](l_uvw[0], l_cd[0], l_xyz[0], subset=False, features_at_new_xyz=l_features[0], **pool)
             out = torch.cat([mapped, l_features[0]], dim=1)
         if not self.transform_output:  # feature-extractor use (autoencoder decoder levels): per-point features
-            return out.transpose(1, 2).contiguous()
+            y = out.transpose(1, 2).contiguous()
+            return y[:, :n_own].contiguous() if self.concat_partial else y
         out = torch.cat([out, xyz.transpose(1, 2)], dim=1)
+        relu = self.activation == "relu"
+        act = torch.relu if relu else swish
         if self.bn_first:
-            return self.fc_lyaer[1](torch.relu(out)).transpose(1, 2).contiguous()
-        h = self.fc_lyaer[0](out)
-        if not self.bn:
-            return self.fc_lyaer[2](torch.relu(h)).transpose(1, 2).contiguous()
-        h = self.fc_lyaer[1](h, relu=True)
-        return self.fc_lyaer[3](h).transpose(1, 2).contiguous()
+            y = self.fc_lyaer[1](act(out))
+        else:
+            h = self.fc_lyaer[0](out)
+            if not self.bn:
+                y = self.fc_lyaer[2](act(h))
+            else:
+                h = self.fc_lyaer[1](h, relu=relu)
+                y = self.fc_lyaer[3](h if relu else swish(h))
+        y = y.transpose(1, 2).contiguous()
+        return y[:, :n_own].contiguous() if self.concat_partial else y
 
     def _fused(self, pointcloud, ts, label, prec="fp32"):
-        if not (self.use_knn_FP and self.bn and not self.bn_first) or self.include_local_feature or self.include_global_feature:
+        if (not (self.use_knn_FP and self.bn and not self.bn_first) or self.include_local_feature or self.include_global_feature
+                or self.activation != "relu" or self.pe_freqs is not None or self.concat_partial or self.gatt or self.out_dim != self.hparams["out_dim"]):
             raise NotImplementedError("the fused plan covers the shipped latent-DDPM configuration family (use_knn_FP, bn, not bn_first, no condition cloud); "
                                       "this configuration runs on the module path: forward(..., fused=False)")
         from slide_amd.engine import DenoiserEngine

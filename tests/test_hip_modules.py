@@ -148,6 +148,31 @@ def test_denoiser_with_a_condition_cloud_matches_reference(gpu_device, name):
         net(x, ts=ts, label=lab)
 
 
+@pytest.mark.parametrize("name", ["swish_pe_ga", "concat_partial"])
+def test_denoiser_parent_project_switches_match_reference(gpu_device, name):
+    """The completion / refinement parent project's switches of PointNet2CloudCondition (reference :47-93, :119-126, :243-257, :302-347):
+    swish activation + NeRF-style position encoding of the coordinates + global attention behind both levels + the up-sampling output
+    head (out_dim x 2), and the condition cloud concatenated to the noisy cloud behind an indicator channel -- module path against the
+    reference's forward (golden_denoiser_switches.npz, tools/gen_golden.py `--only switches`)."""
+    sys.path.insert(0, os.path.join(REPO, "pointnet2"))
+    from models.pointnet2_with_pcld_condition import PointNet2CloudCondition
+    g = load_golden("golden_denoiser_switches.npz")
+    hp = json.loads(str(g[name + "_config_json"]))
+    spec = golden_spec(g, name + "_spec")
+    net = PointNet2CloudCondition(hp)
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == dict(spec)
+    sd = synth_state_dict(spec)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.to(gpu_device).eval()
+    d = gpu_device
+    kw = {"condition": T(g[name + "_cond"], d)} if name == "concat_partial" else {}
+    y = net(T(g[name + "_x"], d), ts=T(g[name + "_ts"], d), label=T(g[name + "_label"], d), **kw).cpu().numpy()
+    ref = g[name + "_eps"]
+    err = np.abs(y - ref).max() / np.abs(ref).max()
+    print("switches %s: output %s, max-norm error vs reference %.2e" % (name, y.shape, err))
+    assert y.shape == ref.shape and err <= 2e-4, (name, err)
+
+
 def test_autoencoder_decode_matches_reference(gpu_device):
     """config 5: latents -> 256 -> 1024 -> 2048 x 6 on the HIP module path vs the reference's decode (FPS start index 0)."""
     sys.path.insert(0, os.path.join(REPO, "pointnet2"))

@@ -159,7 +159,7 @@ def test_bench_self_launch_argv(monkeypatch):
     assert len(calls) == 1 and calls[0][calls[0].index("--nproc-per-node") + 1] == "2" and calls[0][-4:] == ["--gpus", "2", "--steps", "3"]
 
 
-@pytest.mark.parametrize("name", ["fp3nn", "bnfirst", "fp3nn_bnfirst", "nobn", "local", "global", "both"])
+@pytest.mark.parametrize("name", ["fp3nn", "bnfirst", "fp3nn_bnfirst", "nobn", "local", "global", "both", "swish_pe_ga", "concat_partial"])
 def test_denoiser_configuration_branches_are_checkpoint_compatible(name):
     """CPU: the module tree PointNet2CloudCondition builds for the non-shipped configuration branches (three-nearest-neighbour FP
     module, bn_first with its leading convolution and activation + conv head, bn False; the condition-cloud forms: local feature
@@ -171,8 +171,9 @@ def test_denoiser_configuration_branches_are_checkpoint_compatible(name):
     from conftest import REPO
     sys.path.insert(0, os.path.join(REPO, "pointnet2"))
     from models.pointnet2_with_pcld_condition import PointNet2CloudCondition
-    g = load_golden("golden_denoiser_condition.npz" if name in ("local", "global", "both") else "golden_denoiser_variants.npz")
+    g = load_golden("golden_denoiser_condition.npz" if name in ("local", "global", "both") else
+                    "golden_denoiser_switches.npz" if name in ("swish_pe_ga", "concat_partial") else "golden_denoiser_variants.npz")
     hp = json.loads(str(g[name + "_config_json"]))
     net = PointNet2CloudCondition(hp)
     assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == dict(golden_spec(g, name + "_spec"))
-    assert g[name + "_eps"].shape == (2, 16, 3) and np.isfinite(g[name + "_eps"]).all()
+    assert g[name + "_eps"].shape == (2, 16, 6 if name == "swish_pe_ga" else 3) and np.isfinite(g[name + "_eps"]).all()

@@ -216,6 +216,41 @@ def gen_denoiser_condition(out, B=2, M=64):
     np.savez_compressed(os.path.join(out, "golden_denoiser_condition.npz"), **res)
 
 
+DENOISER_SWITCHES = {  # the completion / refinement parent project's switches of the same class (reference :47-93, :119-126, :243-257, :302-347)
+    "swish_pe_ga": dict(activation="swish", use_position_encoding=True, position_encoding_multires=4,
+                        global_attention_setting={"use_global_attention_module": True, "global_attention_layer_index": [0, 1],
+                                                  "attention_bn": True, "last_activation": True},
+                        point_upsample_factor=2, first_refine_coarse_points=False, include_displacement_center_to_final_output=False),
+    "concat_partial": dict(concate_partial_with_noisy_input=True, in_fea_dim=1, attach_position_to_input_feature=False),
+}
+
+
+def gen_denoiser_switches(out, B=2, M=24):
+    base = load_cfg(POS_CFG)
+    res = {}
+    rs = np.random.RandomState(17)
+    for name, sw in DENOISER_SWITCHES.items():
+        cfg = copy.deepcopy(base)
+        cfg["pointnet_config"].update(copy.deepcopy(sw))
+        res[name + "_config_json"] = np.array(json.dumps(cfg["pointnet_config"]))  # (before the constructor edits it in place)
+        net, spec = build_net(cfg)
+        names, shapes = spec_arrays(spec)
+        res[name + "_spec_names"], res[name + "_spec_shapes"] = names, shapes
+        x = rs.standard_normal((B, 16, 3)).astype(np.float32)
+        ts = np.array([999, 7][:B], np.float32)
+        label = np.array([0, 4][:B], np.int64)
+        kw = {}
+        if name == "concat_partial":
+            cond = (0.6 * rs.standard_normal((B, M, 3))).astype(np.float32)
+            kw["condition"] = torch.from_numpy(cond)
+            res[name + "_cond"] = cond
+        with torch.no_grad():
+            y = net(torch.from_numpy(x), ts=torch.from_numpy(ts), label=torch.from_numpy(label), **kw)
+        res[name + "_x"], res[name + "_ts"], res[name + "_label"], res[name + "_eps"] = x, ts, label, y.numpy()
+        print("switches", name, "params", sum(int(np.prod(s_)) for _, s_ in spec), "out", tuple(y.shape), "rms %.3f" % float(np.sqrt((y.numpy() ** 2).mean())))
+    np.savez_compressed(os.path.join(out, "golden_denoiser_switches.npz"), **res)
+
+
 def gen_sampler_pos(net, cfg, out, B=2):
     import util
     res = {}
@@ -668,7 +703,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.manual_seed(0)
-    want = set(a.only.split(",")) if a.only else {"ops", "blocks", "pos", "feat", "variants", "condition", "resample", "sched", "train", "decode", "encode"}
+    want = set(a.only.split(",")) if a.only else {"ops", "blocks", "pos", "feat", "variants", "condition", "switches", "resample", "sched", "train", "decode", "encode"}
     if "ops" in want:
         gen_ops(a.out)
     if "blocks" in want:
@@ -687,6 +722,8 @@ if __name__ == "__main__":
         gen_denoiser_variants(a.out)
     if "condition" in want:
         gen_denoiser_condition(a.out)
+    if "switches" in want:
+        gen_denoiser_switches(a.out)
     if "resample" in want:
         gen_sampler_feat_resample(a.out)
     if "sched" in want:
