@@ -173,6 +173,27 @@ def test_denoiser_parent_project_switches_match_reference(gpu_device, name):
     assert y.shape == ref.shape and err <= 2e-4, (name, err)
 
 
+def test_encoder_parent_project_switches_match_reference(gpu_device):
+    """PointNet2Encoder (the autoencoder's encoder class, reference pointnet2_feature_extractor.py:25-218) with swish, position
+    encoding, bn_first and global attention behind level 0 (128 -> 64 -> 16 points with FPS) against the reference's forward
+    (golden_encoder_switches.npz, tools/gen_golden.py `--only switches`): FPS selections bit-equal, features <= 2e-4."""
+    sys.path.insert(0, os.path.join(REPO, "pointnet2"))
+    from models.pointnet2_feature_extractor import PointNet2Encoder
+    g = load_golden("golden_encoder_switches.npz")
+    hp = json.loads(str(g["config_json"]))
+    spec = golden_spec(g)
+    net = PointNet2Encoder(hp)
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == dict(spec)
+    sd = synth_state_dict(spec)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.to(gpu_device).eval()
+    y, l_xyz, _ = net(T(g["pointcloud"], gpu_device), ts=None, label=T(g["label"], gpu_device))
+    assert np.array_equal(l_xyz[-1].cpu().numpy(), g["xyz_last"])
+    err = np.abs(y.cpu().numpy() - g["out"]).max() / np.abs(g["out"]).max()
+    print("encoder switches: max-norm error vs reference %.2e" % err)
+    assert err <= 2e-4, err
+
+
 def test_autoencoder_decode_matches_reference(gpu_device):
     """config 5: latents -> 256 -> 1024 -> 2048 x 6 on the HIP module path vs the reference's decode (FPS start index 0)."""
     sys.path.insert(0, os.path.join(REPO, "pointnet2"))

@@ -635,6 +635,39 @@ def gen_encode(out, B=2, N=2048):
     print("encode", tuple(out_e.shape), tuple(feat.shape), "params", sum(int(np.prod(s)) for _, s in spec))
 
 
+def gen_encoder_switches(out, B=2, N=128):
+    """PointNet2Encoder.forward (the autoencoder's encoder class) with the parent project's switches: swish, position encoding, bn_first
+    (leading convolution), global attention behind level 0 -- a small architecture under the airplane AE encoder's other settings
+    (reference pointnet2_feature_extractor.py:25-218; no global feature here: with position encoding the reference widens the global
+    PointNet's input twice, :73-78, and cannot run)"""
+    from data_utils.json_reader import read_json_file, autoencoder_read_config
+    from models.pointnet2_feature_extractor import PointNet2Encoder
+    d = CFG + "autoencoder_configs/"
+    cfg = read_json_file(d + "config_autoencoder_s3_kl_1e-5_16_keypoints_latent_dim_16_32_normal_weight_0_0_0.1_with_augm_kp_noise_0.04_airplane.json")
+    enc, _ = autoencoder_read_config(d, cfg)
+    hp = copy.deepcopy(enc)
+    hp["architecture"] = dict(hp["architecture"], npoint=[64, 16], radius=[0, 0], nsample=[8, 8], feature_dim=[16, 32, 64])
+    hp.update(activation="swish", use_position_encoding=True, position_encoding_multires=3, bn_first=True, include_global_feature=False,
+              global_attention_setting={"use_global_attention_module": True, "global_attention_layer_index": [0],
+                                        "attention_bn": True, "last_activation": True})
+    res = {"config_json": np.array(json.dumps(hp))}
+    net = PointNet2Encoder(copy.deepcopy(hp))
+    spec = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    sd = synth_state_dict(spec)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    res["spec_names"], res["spec_shapes"] = spec_arrays(spec)
+    rs = np.random.RandomState(23)
+    pc = rs.standard_normal((B, N, 3 + hp["in_fea_dim"])).astype(np.float32)
+    pc[:, :, :3] *= 0.5
+    label = np.array([0, 4][:B], np.int64)
+    with torch.no_grad():
+        y, l_xyz, _ = net(torch.from_numpy(pc), ts=None, label=torch.from_numpy(label))
+    res["pointcloud"], res["label"], res["out"], res["xyz_last"] = pc, label, y.numpy(), l_xyz[-1].numpy()
+    np.savez_compressed(os.path.join(out, "golden_encoder_switches.npz"), **res)
+    print("encoder switches", tuple(y.shape), "params", sum(int(np.prod(s_)) for _, s_ in spec))
+
+
 def gen_ops(out):
     from oracle import ops as O
     rs = np.random.RandomState(3)
@@ -724,6 +757,7 @@ if __name__ == "__main__":
         gen_denoiser_condition(a.out)
     if "switches" in want:
         gen_denoiser_switches(a.out)
+        gen_encoder_switches(a.out)
     if "resample" in want:
         gen_sampler_feat_resample(a.out)
     if "sched" in want:
